@@ -1,0 +1,12 @@
+"""MI355X-native implementation of the CGG (Betrayed by Captions) decoder + mask-prediction hot path.
+
+The directory name carries a hyphen (repo contract); import it as `cgg_amd` (repo-root alias module)
+or with importlib.import_module('betrayed-by-captions_amd').
+
+Product code only: HIP kernels (csrc/ -> lib/libcgg_hip.so, C ABI in include/cgg_hip.h), their torch
+wrappers (ops.py) and the host-side mirror of the reference's register_module() interface.
+The CPU oracle lives in /oracle and is never imported from here.
+"""
+from . import _lib, ops  # noqa: F401
+
+__version__ = '0.1.0'

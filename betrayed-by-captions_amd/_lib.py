@@ -1,0 +1,90 @@
+"""ctypes binding of libcgg_hip.so (the C ABI declared in include/cgg_hip.h).
+
+There is NO fallback: if the shared library is missing, or a wrapped op is handed tensors that do not
+live on a ROCm device, the call raises. The CPU restatement under /oracle is test infrastructure and
+is never imported from here.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libcgg_hip.so')
+
+CGG_F32 = 0
+CGG_BF16 = 1
+
+_c_int = ctypes.c_int
+_c_vp = ctypes.c_void_p
+_c_f = ctypes.c_float
+_c_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol of include/cgg_hip.h
+PROTOTYPES = {
+    'cgg_version': (_c_int, []),
+    'cgg_last_error_string': (ctypes.c_char_p, []),
+    'cgg_msda_forward': (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
+    'cgg_msda_forward_fused': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 8 + [_c_vp]),
+    'cgg_msda_forward_hostlevels': (_c_int, [_c_vp] * 6 + [_c_int] + [_c_vp] + [_c_int] * 9 + [_c_vp]),
+    'cgg_msda_backward': (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp]),
+    'cgg_pack_mask_feature': (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
+    'cgg_mask_logits': (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
+    'cgg_attn_mask_fix_full_rows': (_c_int, [_c_vp, _c_int, _c_int, _c_vp]),
+    'cgg_attn_mask_from_logits': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
+    'cgg_masked_xattn_workspace_bytes': (_c_i64, [_c_int] * 5),
+    'cgg_masked_xattn_forward': (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
+    'cgg_upsample_bilinear': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
+    'cgg_instance_masks': (_c_int, [_c_vp] * 6 + [_c_int] * 10 + [_c_vp]),
+    'cgg_panoptic_argmax': (_c_int, [_c_vp] * 6 + [_c_int] * 10 + [_c_vp]),
+    'cgg_panoptic_paint': (_c_int, [_c_vp] * 5 + [_c_i64, _c_int, _c_vp]),
+    'cgg_rowwise_softmax_argmax': (_c_int, [_c_vp] * 4 + [_c_int, _c_int, _c_vp]),
+}
+
+_lib = None
+
+
+class CggError(RuntimeError):
+    """A libcgg_hip.so entry point returned non-zero."""
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CggError(
+            f'{LIB_PATH} is missing: build it with `python __graft_entry__.py` '
+            '(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for the CGG hot path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cgg_last_error_string()
+        raise CggError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_ptr(t, name='tensor', dtype=None):
+    """data_ptr of a contiguous ROCm tensor (None passes through as NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CggError(f'{name} must live on a ROCm device (got {t.device}); the CGG hot path has '
+                       'no CPU implementation outside /oracle')
+    if not t.is_contiguous():
+        raise CggError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise CggError(f'{name} must be {dtype} (got {t.dtype})')
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,380 @@
+// K1/K2: multi-scale deformable attention sampling + aggregation for gfx950.
+// Replaces [3P] mmcv ms_deform_attn_forward/backward (MultiScaleDeformableAttnFunction), reached
+// from MSDeformAttnPixelDecoder.forward built at open_set/models/mask2former_head.py:112-117.
+//
+// Roofline: a gather -- HBM/L2-bound, no MFMA. Mapping: one lane owns 4 consecutive channels of one
+// (query, head): with H=8, D=32 a wavefront is exactly one query, so
+//   * every corner fetch is a 16-B load per lane = one full 128-B line per head (coalesced),
+//   * the query's sampling row (offsets/weights) is read as broadcast loads,
+//   * the 1-KiB output row leaves as one contiguous store per wave.
+// Blocks are remapped so that each XCD walks ONE contiguous range of queries (row-major within a
+// level): its private 4-MiB L2 then only has to hold a spatial band of every value level.
+#include "cgg_common.h"
+
+struct MsdaLevels {
+  int h[8];
+  int w[8];
+  int start[8];
+};
+
+__device__ __forceinline__ f32x4 cgg_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 cgg_ld4(const uint16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  f32x4 r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+             __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  return r;
+}
+
+// Four corner addresses (clamped into the map) + four weights (zeroed outside) of one sample.
+struct MsdaTap {
+  int o00, o01, o10, o11;  // row index (y*W+x) inside the level
+  float w00, w01, w10, w11;
+  float lh, lw;            // fractional parts (for backward)
+  bool in;                 // sample inside (-1, H) x (-1, W)
+};
+
+__device__ __forceinline__ MsdaTap cgg_msda_tap(float x, float y, int Hl, int Wl) {
+  MsdaTap t;
+  const float him = y * (float)Hl - 0.5f;
+  const float wim = x * (float)Wl - 0.5f;
+  t.in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
+  const float hf = floorf(him), wf = floorf(wim);
+  const int h0 = (int)hf, w0 = (int)wf;
+  const int h1 = h0 + 1, w1 = w0 + 1;
+  t.lh = him - hf;
+  t.lw = wim - wf;
+  const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+  const bool vh0 = t.in && h0 >= 0, vh1 = t.in && h1 <= Hl - 1;
+  const bool vw0 = w0 >= 0, vw1 = w1 <= Wl - 1;
+  t.w00 = (vh0 && vw0) ? hh * hw : 0.f;
+  t.w01 = (vh0 && vw1) ? hh * t.lw : 0.f;
+  t.w10 = (vh1 && vw0) ? t.lh * hw : 0.f;
+  t.w11 = (vh1 && vw1) ? t.lh * t.lw : 0.f;
+  const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h1, 0), Hl - 1);
+  const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w1, 0), Wl - 1);
+  t.o00 = ch0 * Wl + cw0;
+  t.o01 = ch0 * Wl + cw1;
+  t.o10 = ch1 * Wl + cw0;
+  t.o11 = ch1 * Wl + cw1;
+  return t;
+}
+
+// FUSED: offs_logits row = [H*L*P*2 raw offsets | H*L*P raw logits]; loc = ref + off/(W_l,H_l),
+// weights = softmax over L*P. Otherwise loc/attw are given (mmcv boundary).
+template <typename VT, int P_, bool FUSED>
+__global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
+    const VT* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
+    const float* __restrict__ attw, const float* __restrict__ ref, int ld,
+    float* __restrict__ out, int Nv, int H, int D, int L, int Nq, int Prt, long long total) {
+  const int P = P_ > 0 ? P_ : Prt;
+  const int DQ = D >> 2;
+  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
+  const long long gid = (long long)bid * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cq = (int)(gid % DQ);
+  const int h = (int)((gid / DQ) % H);
+  const long long bq = gid / ((long long)DQ * H);
+  const int b = (int)(bq / Nq);
+  const int q = (int)(bq - (long long)b * Nq);
+  const size_t rowstride = (size_t)H * D;
+  const VT* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * 4;
+  const int LP = L * P;
+
+  const float* lp;
+  const float* wp;
+  float rx = 0.f, ry = 0.f, smax = 0.f, sinv = 1.f;
+  if (FUSED) {
+    const float* row = loc + (size_t)bq * ld;
+    lp = row + (size_t)h * LP * 2;
+    wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
+    rx = ref[2 * q];
+    ry = ref[2 * q + 1];
+    smax = wp[0];
+    for (int i = 1; i < LP; ++i) smax = fmaxf(smax, wp[i]);
+    float ssum = 0.f;
+    for (int i = 0; i < LP; ++i) ssum += expf(wp[i] - smax);
+    sinv = 1.f / ssum;
+  } else {
+    lp = loc + ((size_t)bq * H + h) * LP * 2;
+    wp = attw + ((size_t)bq * H + h) * LP;
+  }
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.h[l], Wl = lv.w[l];
+    const VT* vl = vb + (size_t)lv.start[l] * rowstride;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      float x = lp[2 * i], y = lp[2 * i + 1], w = wp[i];
+      if (FUSED) {
+        x = rx + x / (float)Wl;
+        y = ry + y / (float)Hl;
+        w = expf(w - smax) * sinv;
+      }
+      const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
+      const f32x4 v00 = cgg_ld4(vl + (size_t)t.o00 * rowstride);
+      const f32x4 v01 = cgg_ld4(vl + (size_t)t.o01 * rowstride);
+      const f32x4 v10 = cgg_ld4(vl + (size_t)t.o10 * rowstride);
+      const f32x4 v11 = cgg_ld4(vl + (size_t)t.o11 * rowstride);
+      const f32x4 s = t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
+      acc += w * s;
+    }
+  }
+  *reinterpret_cast<f32x4*>(out + (size_t)bq * rowstride + (size_t)h * D + cq * 4) = acc;
+}
+
+// Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
+// grad_loc / grad_attn are wave shuffles; grad_value is scattered with hardware f32 atomics.
+template <int P_>
+__global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
+    const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
+    const float* __restrict__ attw, const float* __restrict__ gout, float* __restrict__ gvalue,
+    float* __restrict__ gloc, float* __restrict__ gattw, int Nv, int H, int D, int L, int Nq,
+    int Prt, long long total) {
+  const int P = P_ > 0 ? P_ : Prt;
+  const int DQ = D >> 2;
+  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
+  const long long gid = (long long)bid * 256 + threadIdx.x;
+  const bool live = gid < total;
+  const long long g2 = live ? gid : total - 1;  // keep every lane in the shuffles
+  const int cq = (int)(g2 % DQ);
+  const int h = (int)((g2 / DQ) % H);
+  const long long bq = g2 / ((long long)DQ * H);
+  const int b = (int)(bq / Nq);
+  const size_t rowstride = (size_t)H * D;
+  const size_t coff = (size_t)h * D + cq * 4;
+  const float* vb = value + (size_t)b * Nv * rowstride + coff;
+  float* gvb = gvalue + (size_t)b * Nv * rowstride + coff;
+  const int LP = L * P;
+  const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
+  const float* wp = attw + ((size_t)bq * H + h) * LP;
+  float* glp = gloc + ((size_t)bq * H + h) * LP * 2;
+  float* gwp = gattw + ((size_t)bq * H + h) * LP;
+  f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + coff);
+  if (!live) g = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.h[l], Wl = lv.w[l];
+    const float* vl = vb + (size_t)lv.start[l] * rowstride;
+    float* gvl = gvb + (size_t)lv.start[l] * rowstride;
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      const float x = lp[2 * i], y = lp[2 * i + 1], w = wp[i];
+      const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
+      const f32x4 v00 = cgg_ld4(vl + (size_t)t.o00 * rowstride);
+      const f32x4 v01 = cgg_ld4(vl + (size_t)t.o01 * rowstride);
+      const f32x4 v10 = cgg_ld4(vl + (size_t)t.o10 * rowstride);
+      const f32x4 v11 = cgg_ld4(vl + (size_t)t.o11 * rowstride);
+      const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+      // validity flags recovered from the tap (weights can be legitimately 0 on integer coords,
+      // so recompute instead of testing w != 0)
+      const float him = y * (float)Hl - 0.5f, wim = x * (float)Wl - 0.5f;
+      const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+      const bool vh0 = t.in && h0 >= 0, vh1 = t.in && (h0 + 1) <= Hl - 1;
+      const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wl - 1;
+      const float f00 = (vh0 && vw0) ? 1.f : 0.f, f01 = (vh0 && vw1) ? 1.f : 0.f;
+      const float f10 = (vh1 && vw0) ? 1.f : 0.f, f11 = (vh1 && vw1) ? 1.f : 0.f;
+      // d(val)/d(w_im), d(val)/d(h_im) per channel, dotted with grad_out
+      float dotv = 0.f, dotx = 0.f, doty = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float a00 = f00 * v00[c], a01 = f01 * v01[c], a10 = f10 * v10[c], a11 = f11 * v11[c];
+        const float val = hh * hw * a00 + hh * t.lw * a01 + t.lh * hw * a10 + t.lh * t.lw * a11;
+        const float dw = hh * (a01 - a00) + t.lh * (a11 - a10);
+        const float dh = hw * (a10 - a00) + t.lw * (a11 - a01);
+        dotv += val * g[c];
+        dotx += dw * g[c];
+        doty += dh * g[c];
+      }
+      for (int o = 1; o < DQ; o <<= 1) {
+        dotv += __shfl_xor(dotv, o);
+        dotx += __shfl_xor(dotx, o);
+        doty += __shfl_xor(doty, o);
+      }
+      if (live && cq == 0) {
+        gwp[i] += dotv;
+        glp[2 * i] += (float)Wl * w * dotx;
+        glp[2 * i + 1] += (float)Hl * w * doty;
+      }
+      if (live) {
+        const f32x4 wg = w * g;
+        if (t.w00 != 0.f) {
+          float* d = gvl + (size_t)t.o00 * rowstride;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) atomicAdd(d + c, t.w00 * wg[c]);
+        }
+        if (t.w01 != 0.f) {
+          float* d = gvl + (size_t)t.o01 * rowstride;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) atomicAdd(d + c, t.w01 * wg[c]);
+        }
+        if (t.w10 != 0.f) {
+          float* d = gvl + (size_t)t.o10 * rowstride;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) atomicAdd(d + c, t.w10 * wg[c]);
+        }
+        if (t.w11 != 0.f) {
+          float* d = gvl + (size_t)t.o11 * rowstride;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) atomicAdd(d + c, t.w11 * wg[c]);
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+static int msda_read_levels(const int64_t* spatial_shapes, const int64_t* level_start, int L,
+                            int Nv, hipStream_t s, MsdaLevels* lv, const char* who) {
+  // The level table is kernel-argument data (<= 8 levels): copy it to the host once per call.
+  // It is device-resident in the mmcv contract, hence the (tiny, stream-ordered) D2H.
+  int64_t hs[16], st[8];
+  hipError_t e = hipMemcpyAsync(hs, spatial_shapes, sizeof(int64_t) * 2 * L, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st, level_start, sizeof(int64_t) * L, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    cgg_set_error("%s: reading level table failed: %s", who, hipGetErrorString(e));
+    return (int)e;
+  }
+  long long tot = 0;
+  for (int l = 0; l < L; ++l) {
+    lv->h[l] = (int)hs[2 * l];
+    lv->w[l] = (int)hs[2 * l + 1];
+    lv->start[l] = (int)st[l];
+    if (lv->h[l] <= 0 || lv->w[l] <= 0 || st[l] < 0 || st[l] + hs[2 * l] * hs[2 * l + 1] > Nv) {
+      cgg_set_error("%s: level %d (%lldx%lld @%lld) does not fit Nv=%d", who, l, (long long)hs[2 * l],
+                    (long long)hs[2 * l + 1], (long long)st[l], Nv);
+      return CGG_EINVAL;
+    }
+    tot += hs[2 * l] * hs[2 * l + 1];
+  }
+  (void)tot;
+  return CGG_OK;
+}
+
+// Host-side level table variant: identical kernels, no D2H (used by the graph-captured forward).
+extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
+                                           const int32_t* level_start, const float* sampling_loc,
+                                           const float* attn_weight, const float* ref_points, int ld,
+                                           float* out, int B, int Nv, int H, int D, int L, int Nq,
+                                           int P, int value_dtype, int fused, cgg_stream_t stream);
+
+static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float* loc,
+                           const float* attw, const float* ref, int ld, float* out, int B, int Nv,
+                           int H, int D, int L, int Nq, int P, int dtype, bool fused, hipStream_t s) {
+  const long long total = (long long)B * Nq * H * (D / 4);
+  const int nblk = (int)((total + 255) / 256);
+#define CGG_MSDA_LAUNCH(VT, PT, FU)                                                              \
+  hipLaunchKernelGGL((cgg_msda_fwd_kernel<VT, PT, FU>), dim3(nblk), dim3(256), 0, s,             \
+                     (const VT*)value, lv, loc, attw, ref, ld, out, Nv, H, D, L, Nq, P, total)
+  if (dtype == CGG_F32) {
+    if (fused) { if (P == 4) CGG_MSDA_LAUNCH(float, 4, true); else CGG_MSDA_LAUNCH(float, 0, true); }
+    else       { if (P == 4) CGG_MSDA_LAUNCH(float, 4, false); else CGG_MSDA_LAUNCH(float, 0, false); }
+  } else {
+    if (fused) { if (P == 4) CGG_MSDA_LAUNCH(uint16_t, 4, true); else CGG_MSDA_LAUNCH(uint16_t, 0, true); }
+    else       { if (P == 4) CGG_MSDA_LAUNCH(uint16_t, 4, false); else CGG_MSDA_LAUNCH(uint16_t, 0, false); }
+  }
+#undef CGG_MSDA_LAUNCH
+  CGG_CHECK_LAUNCH("cgg_msda_forward");
+  return CGG_OK;
+}
+
+static int msda_check(const char* who, const void* value, const void* a, const void* b_, const void* o,
+                      int B, int Nv, int H, int D, int L, int Nq, int P, int dtype) {
+  CGG_REQUIRE(value && a && b_ && o, CGG_EINVAL, "%s: null pointer", who);
+  CGG_REQUIRE(B > 0 && Nv > 0 && H > 0 && D > 0 && L > 0 && Nq > 0 && P > 0, CGG_EINVAL,
+              "%s: bad sizes", who);
+  CGG_REQUIRE(D % 4 == 0, CGG_EUNSUPPORTED, "%s: head dim D=%d must be a multiple of 4", who, D);
+  CGG_REQUIRE(L <= 8, CGG_EUNSUPPORTED, "%s: L=%d levels (max 8)", who, L);
+  CGG_REQUIRE(dtype == CGG_F32 || dtype == CGG_BF16, CGG_EUNSUPPORTED, "%s: dtype %d", who, dtype);
+  CGG_REQUIRE(cgg_aligned16(value) && cgg_aligned16(o), CGG_EALIGN, "%s: value/out must be 16-B aligned", who);
+  return CGG_OK;
+}
+
+extern "C" int cgg_msda_forward(const void* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start, const float* sampling_loc,
+                                const float* attn_weight, float* out, int B, int Nv, int H, int D,
+                                int L, int Nq, int P, int value_dtype, cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_forward", value, sampling_loc, attn_weight, out, B, Nv, H, D, L, Nq, P,
+                      value_dtype);
+  if (rc) return rc;
+  CGG_REQUIRE(spatial_shapes && level_start, CGG_EINVAL, "cgg_msda_forward: null level table");
+  MsdaLevels lv;
+  hipStream_t s = (hipStream_t)stream;
+  rc = msda_read_levels(spatial_shapes, level_start, L, Nv, s, &lv, "cgg_msda_forward");
+  if (rc) return rc;
+  return msda_fwd_launch(value, lv, sampling_loc, attn_weight, nullptr, 0, out, B, Nv, H, D, L, Nq, P,
+                         value_dtype, false, s);
+}
+
+extern "C" int cgg_msda_forward_fused(const void* value, const int64_t* spatial_shapes,
+                                      const int64_t* level_start, const float* offs_logits, int ld,
+                                      const float* ref_points, float* out, int B, int Nv, int H,
+                                      int D, int L, int Nq, int P, int value_dtype,
+                                      cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_forward_fused", value, offs_logits, ref_points, out, B, Nv, H, D, L, Nq,
+                      P, value_dtype);
+  if (rc) return rc;
+  CGG_REQUIRE(spatial_shapes && level_start, CGG_EINVAL, "cgg_msda_forward_fused: null level table");
+  CGG_REQUIRE(ld >= H * L * P * 3, CGG_EINVAL, "cgg_msda_forward_fused: ld=%d < H*L*P*3", ld);
+  MsdaLevels lv;
+  hipStream_t s = (hipStream_t)stream;
+  rc = msda_read_levels(spatial_shapes, level_start, L, Nv, s, &lv, "cgg_msda_forward_fused");
+  if (rc) return rc;
+  return msda_fwd_launch(value, lv, offs_logits, nullptr, ref_points, ld, out, B, Nv, H, D, L, Nq, P,
+                         value_dtype, true, s);
+}
+
+extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
+                                           const int32_t* level_start, const float* sampling_loc,
+                                           const float* attn_weight, const float* ref_points, int ld,
+                                           float* out, int B, int Nv, int H, int D, int L, int Nq,
+                                           int P, int value_dtype, int fused, cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_forward_hostlevels", value, sampling_loc,
+                      fused ? (const void*)ref_points : (const void*)attn_weight, out, B, Nv, H, D, L,
+                      Nq, P, value_dtype);
+  if (rc) return rc;
+  CGG_REQUIRE(level_hw && level_start, CGG_EINVAL, "cgg_msda_forward_hostlevels: null level table");
+  if (fused) CGG_REQUIRE(ld >= H * L * P * 3, CGG_EINVAL, "cgg_msda_forward_hostlevels: ld too small");
+  MsdaLevels lv;
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = level_start[l];
+    CGG_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0 && lv.start[l] >= 0 &&
+                    (long long)lv.start[l] + (long long)lv.h[l] * lv.w[l] <= Nv,
+                CGG_EINVAL, "cgg_msda_forward_hostlevels: level %d does not fit Nv=%d", l, Nv);
+  }
+  return msda_fwd_launch(value, lv, sampling_loc, attn_weight, ref_points, ld, out, B, Nv, H, D, L, Nq,
+                         P, value_dtype, fused != 0, (hipStream_t)stream);
+}
+
+extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shapes,
+                                 const int64_t* level_start, const float* sampling_loc,
+                                 const float* attn_weight, const float* grad_out, float* grad_value,
+                                 float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
+                                 int L, int Nq, int P, cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_backward", value, sampling_loc, attn_weight, grad_out, B, Nv, H, D, L,
+                      Nq, P, CGG_F32);
+  if (rc) return rc;
+  CGG_REQUIRE(spatial_shapes && level_start && grad_value && grad_loc && grad_attn, CGG_EINVAL,
+              "cgg_msda_backward: null pointer");
+  const int DQ = D / 4;
+  CGG_REQUIRE((DQ & (DQ - 1)) == 0 && DQ <= 64, CGG_EUNSUPPORTED,
+              "cgg_msda_backward: D/4=%d must be a power of two <= 64", DQ);
+  MsdaLevels lv;
+  hipStream_t s = (hipStream_t)stream;
+  rc = msda_read_levels(spatial_shapes, level_start, L, Nv, s, &lv, "cgg_msda_backward");
+  if (rc) return rc;
+  const long long total = (long long)B * Nq * H * DQ;
+  const int nblk = (int)((total + 255) / 256);
+  if (P == 4)
+    hipLaunchKernelGGL(cgg_msda_bwd_kernel<4>, dim3(nblk), dim3(256), 0, s, value, lv, sampling_loc,
+                       attn_weight, grad_out, grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+  else
+    hipLaunchKernelGGL(cgg_msda_bwd_kernel<0>, dim3(nblk), dim3(256), 0, s, value, lv, sampling_loc,
+                       attn_weight, grad_out, grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+  CGG_CHECK_LAUNCH("cgg_msda_backward");
+  return CGG_OK;
+}

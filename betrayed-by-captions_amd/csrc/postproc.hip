@@ -1,0 +1,319 @@
+// K19: inference tail -- wavefront softmax/argmax and the fused "upsample -> threshold / argmax"
+// kernels that keep the (Q, H_img, W_img) f32 logit tensor of
+// open_set/models/mask2former_head.py:960-964 from ever being written.
+// All HBM-bound streaming kernels; low-res logits (Q x H/4 x W/4) are re-read through L1/L2.
+#include "cgg_common.h"
+
+// torch upsample_bilinear2d (align_corners=False) source coordinate for output index `o`
+struct BiTap {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ BiTap cgg_bitap(int o, float scale, int in_size) {
+  float f = scale * ((float)o + 0.5f) - 0.5f;
+  f = f < 0.f ? 0.f : f;
+  BiTap t;
+  t.i0 = (int)f;
+  if (t.i0 > in_size - 1) t.i0 = in_size - 1;
+  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+  t.l1 = f - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+__device__ __forceinline__ float cgg_bilerp(const float* __restrict__ s, int W, const BiTap& ty,
+                                            const BiTap& tx) {
+  return ty.l0 * (tx.l0 * s[(size_t)ty.i0 * W + tx.i0] + tx.l1 * s[(size_t)ty.i0 * W + tx.i1]) +
+         ty.l1 * (tx.l0 * s[(size_t)ty.i1 * W + tx.i0] + tx.l1 * s[(size_t)ty.i1 * W + tx.i1]);
+}
+
+// value of the (optionally two-stage) resized logit at final pixel (oy, ox):
+//   stage 1: [H, W] -> [up_h, up_w] (batch_input_shape), crop to [crop_h, crop_w] (img_shape)
+//   stage 2 (if out != crop): [crop_h, crop_w] -> [out_h, out_w] (ori_shape, `rescale`)
+struct ResizeGeom {
+  int H, W, up_h, up_w, crop_h, crop_w, out_h, out_w;
+  float s1y, s1x, s2y, s2x;
+  int two_stage;
+};
+__device__ __forceinline__ float cgg_resized_logit(const float* __restrict__ s, const ResizeGeom& g,
+                                                   int oy, int ox) {
+  if (!g.two_stage) {
+    const BiTap ty = cgg_bitap(oy, g.s1y, g.H), tx = cgg_bitap(ox, g.s1x, g.W);
+    return cgg_bilerp(s, g.W, ty, tx);
+  }
+  const BiTap uy = cgg_bitap(oy, g.s2y, g.crop_h), ux = cgg_bitap(ox, g.s2x, g.crop_w);
+  float v[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const BiTap ty = cgg_bitap(a ? uy.i1 : uy.i0, g.s1y, g.H);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const BiTap tx = cgg_bitap(c ? ux.i1 : ux.i0, g.s1x, g.W);
+      v[a][c] = cgg_bilerp(s, g.W, ty, tx);
+    }
+  }
+  return uy.l0 * (ux.l0 * v[0][0] + ux.l1 * v[0][1]) + uy.l1 * (ux.l0 * v[1][0] + ux.l1 * v[1][1]);
+}
+
+static ResizeGeom make_geom(int H, int W, int up_h, int up_w, int crop_h, int crop_w, int out_h,
+                            int out_w) {
+  ResizeGeom g;
+  g.H = H; g.W = W; g.up_h = up_h; g.up_w = up_w; g.crop_h = crop_h; g.crop_w = crop_w;
+  g.out_h = out_h; g.out_w = out_w;
+  g.s1y = (float)H / (float)up_h;
+  g.s1x = (float)W / (float)up_w;
+  g.two_stage = (out_h != crop_h || out_w != crop_w) ? 1 : 0;
+  g.s2y = (float)crop_h / (float)out_h;
+  g.s2x = (float)crop_w / (float)out_w;
+  return g;
+}
+
+__device__ __forceinline__ float cgg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cgg_upsample_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int H, int W, int h,
+                                                           int w, float sy, float sx) {
+  const int n = blockIdx.y;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)h * w) return;
+  const int oy = (int)(p / w), ox = (int)(p - (long long)oy * w);
+  const BiTap ty = cgg_bitap(oy, sy, H), tx = cgg_bitap(ox, sx, W);
+  y[(size_t)n * h * w + p] = cgg_bilerp(x + (size_t)n * H * W, W, ty, tx);
+}
+
+// instance masks: block = 256 consecutive output pixels of detection blockIdx.y
+// ws per detection: [0] f32 sum sigmoid*[m>0], [1] i32 count, [2..5] i32 xmin, ymin, xmax, ymax
+__global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __restrict__ logits,
+                                                                 const int32_t* __restrict__ sel,
+                                                                 uint8_t* __restrict__ masks,
+                                                                 int32_t* __restrict__ ws,
+                                                                 ResizeGeom g) {
+  const int i = blockIdx.y;
+  const long long npix = (long long)g.out_h * g.out_w;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const float* s = logits + (size_t)sel[i] * g.H * g.W;
+  float sig = 0.f;
+  int cnt = 0, xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
+  if (p < npix) {
+    const int oy = (int)(p / g.out_w), ox = (int)(p - (long long)oy * g.out_w);
+    const float v = cgg_resized_logit(s, g, oy, ox);
+    const bool on = v > 0.f;
+    masks[(size_t)i * npix + p] = on ? 1 : 0;
+    if (on) {
+      sig = cgg_sigmoid(v);
+      cnt = 1;
+      xmin = xmax = ox;
+      ymin = ymax = oy;
+    }
+  }
+  // wave reduce, then one atomic set per wave
+  for (int o = 32; o > 0; o >>= 1) {
+    sig += __shfl_xor(sig, o);
+    cnt += __shfl_xor(cnt, o);
+    xmin = min(xmin, __shfl_xor(xmin, o));
+    ymin = min(ymin, __shfl_xor(ymin, o));
+    xmax = max(xmax, __shfl_xor(xmax, o));
+    ymax = max(ymax, __shfl_xor(ymax, o));
+  }
+  if ((threadIdx.x & 63) == 0 && cnt > 0) {
+    int32_t* w = ws + (size_t)i * 8;
+    atomicAdd(reinterpret_cast<float*>(w), sig);
+    atomicAdd(w + 1, cnt);
+    atomicMin(w + 2, xmin);
+    atomicMin(w + 3, ymin);
+    atomicMax(w + 4, xmax);
+    atomicMax(w + 5, ymax);
+  }
+}
+
+__global__ void cgg_instance_init_kernel(int32_t* __restrict__ ws, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t* w = ws + (size_t)i * 8;
+  w[0] = 0; w[1] = 0; w[2] = 0x7fffffff; w[3] = 0x7fffffff; w[4] = -1; w[5] = -1; w[6] = 0; w[7] = 0;
+}
+
+__global__ void cgg_instance_final_kernel(const int32_t* __restrict__ ws, float* __restrict__ score,
+                                          float* __restrict__ bbox, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* w = ws + (size_t)i * 8;
+  const float sum = __int_as_float(w[0]);
+  const int cnt = w[1];
+  score[i] = sum / ((float)cnt + 1e-6f);
+  if (cnt > 0) {
+    bbox[4 * i] = (float)w[2];
+    bbox[4 * i + 1] = (float)w[3];
+    bbox[4 * i + 2] = (float)(w[4] + 1);
+    bbox[4 * i + 3] = (float)(w[5] + 1);
+  } else {
+    bbox[4 * i] = bbox[4 * i + 1] = bbox[4 * i + 2] = bbox[4 * i + 3] = 0.f;
+  }
+}
+
+// panoptic: per output pixel argmax_k score[k]*sigmoid(logit_keep[k]); first max wins (torch.argmax)
+// counts [n, 3] i32: #(id==k), #(sigmoid_k >= 0.5), #(id==k && sigmoid_k >= 0.5)
+__global__ __launch_bounds__(256) void cgg_panoptic_argmax_kernel(
+    const float* __restrict__ logits, const int32_t* __restrict__ keep, const float* __restrict__ score,
+    int32_t* __restrict__ ids, uint8_t* __restrict__ win_half, int32_t* __restrict__ counts,
+    ResizeGeom g, int n) {
+  extern __shared__ int32_t hist[];  // [n*3]
+  for (int i = threadIdx.x; i < n * 3; i += 256) hist[i] = 0;
+  __syncthreads();
+  const long long npix = (long long)g.out_h * g.out_w;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p < npix) {
+    const int oy = (int)(p / g.out_w), ox = (int)(p - (long long)oy * g.out_w);
+    float best = -INFINITY;
+    int bk = 0;
+    bool bhalf = false;
+    for (int k = 0; k < n; ++k) {
+      const float v = cgg_resized_logit(logits + (size_t)keep[k] * g.H * g.W, g, oy, ox);
+      const float sg = cgg_sigmoid(v);
+      const bool half = sg >= 0.5f;
+      if (half) atomicAdd(&hist[k * 3 + 1], 1);
+      const float pv = score[k] * sg;
+      if (pv > best) {
+        best = pv;
+        bk = k;
+        bhalf = half;
+      }
+    }
+    ids[p] = bk;
+    win_half[p] = bhalf ? 1 : 0;
+    atomicAdd(&hist[bk * 3], 1);
+    if (bhalf) atomicAdd(&hist[bk * 3 + 2], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n * 3; i += 256)
+    if (hist[i]) atomicAdd(&counts[i], hist[i]);
+}
+
+// paint: seg[p] = lut_val[id] if lut_val[id] >= 0 and (!lut_half[id] || win_half[p]) else void
+__global__ __launch_bounds__(256) void cgg_panoptic_paint_kernel(const int32_t* __restrict__ ids,
+                                                                 const uint8_t* __restrict__ win_half,
+                                                                 const int32_t* __restrict__ lut_val,
+                                                                 const int32_t* __restrict__ lut_half,
+                                                                 int32_t* __restrict__ seg,
+                                                                 long long npix, int void_label) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const int k = ids[p];
+  const int v = lut_val[k];
+  const bool ok = v >= 0 && (!lut_half[k] || win_half[p]);
+  seg[p] = ok ? v : void_label;
+}
+
+// row-wise softmax + (max, argmax); one wavefront per row, first max wins
+__global__ __launch_bounds__(256) void cgg_softmax_argmax_kernel(const float* __restrict__ x,
+                                                                 float* __restrict__ prob,
+                                                                 float* __restrict__ maxv,
+                                                                 int64_t* __restrict__ argmax,
+                                                                 int rows, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * n;
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int i = lane; i < n; i += 64) {
+    const float v = xr[i];
+    if (v > m || (v == m && i < mi)) { m = v; mi = i; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o);
+    const int oi = __shfl_xor(mi, o);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  float sum = 0.f;
+  for (int i = lane; i < n; i += 64) sum += expf(xr[i] - m);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  if (prob != nullptr)
+    for (int i = lane; i < n; i += 64) prob[(size_t)row * n + i] = expf(xr[i] - m) * inv;
+  if (lane == 0) {
+    if (maxv) maxv[row] = inv;  // exp(m - m) / sum
+    if (argmax) argmax[row] = mi;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+extern "C" int cgg_upsample_bilinear(const float* x, float* y, int N, int H, int W, int h, int w,
+                                     cgg_stream_t stream) {
+  CGG_REQUIRE(x && y, CGG_EINVAL, "cgg_upsample_bilinear: null pointer");
+  CGG_REQUIRE(N > 0 && H > 0 && W > 0 && h > 0 && w > 0, CGG_EINVAL, "cgg_upsample_bilinear: bad sizes");
+  const long long npix = (long long)h * w;
+  hipLaunchKernelGGL(cgg_upsample_kernel, dim3((unsigned)((npix + 255) / 256), N), dim3(256), 0,
+                     (hipStream_t)stream, x, y, H, W, h, w, (float)H / (float)h, (float)W / (float)w);
+  CGG_CHECK_LAUNCH("cgg_upsample_bilinear");
+  return CGG_OK;
+}
+
+extern "C" int cgg_instance_masks(const float* logits, const int32_t* sel, uint8_t* masks,
+                                  float* mask_score, float* bbox, void* ws, int Q, int H, int W,
+                                  int up_h, int up_w, int crop_h, int crop_w, int out_h, int out_w,
+                                  int n, cgg_stream_t stream) {
+  CGG_REQUIRE(logits && sel && masks && mask_score && bbox && ws, CGG_EINVAL,
+              "cgg_instance_masks: null pointer");
+  CGG_REQUIRE(Q > 0 && H > 0 && W > 0 && up_h > 0 && up_w > 0 && out_h > 0 && out_w > 0 && n > 0,
+              CGG_EINVAL, "cgg_instance_masks: bad sizes");
+  CGG_REQUIRE(crop_h > 0 && crop_h <= up_h && crop_w > 0 && crop_w <= up_w, CGG_EINVAL,
+              "cgg_instance_masks: crop %dx%d outside %dx%d", crop_h, crop_w, up_h, up_w);
+  hipStream_t s = (hipStream_t)stream;
+  const ResizeGeom g = make_geom(H, W, up_h, up_w, crop_h, crop_w, out_h, out_w);
+  hipLaunchKernelGGL(cgg_instance_init_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (int32_t*)ws, n);
+  const long long npix = (long long)out_h * out_w;
+  hipLaunchKernelGGL(cgg_instance_masks_kernel, dim3((unsigned)((npix + 255) / 256), n), dim3(256), 0,
+                     s, logits, sel, masks, (int32_t*)ws, g);
+  hipLaunchKernelGGL(cgg_instance_final_kernel, dim3((n + 63) / 64), dim3(64), 0, s,
+                     (const int32_t*)ws, mask_score, bbox, n);
+  CGG_CHECK_LAUNCH("cgg_instance_masks");
+  return CGG_OK;
+}
+
+extern "C" int cgg_panoptic_argmax(const float* logits, const int32_t* keep, const float* score,
+                                   int32_t* ids, uint8_t* win_half, int32_t* counts, int Q, int H,
+                                   int W, int up_h, int up_w, int crop_h, int crop_w, int out_h,
+                                   int out_w, int n, cgg_stream_t stream) {
+  CGG_REQUIRE(logits && keep && score && ids && win_half && counts, CGG_EINVAL,
+              "cgg_panoptic_argmax: null pointer");
+  CGG_REQUIRE(Q > 0 && H > 0 && W > 0 && up_h > 0 && up_w > 0 && out_h > 0 && out_w > 0 && n > 0,
+              CGG_EINVAL, "cgg_panoptic_argmax: bad sizes");
+  CGG_REQUIRE(n <= 1024, CGG_EUNSUPPORTED, "cgg_panoptic_argmax: n=%d kept queries (max 1024)", n);
+  CGG_REQUIRE(crop_h > 0 && crop_h <= up_h && crop_w > 0 && crop_w <= up_w, CGG_EINVAL,
+              "cgg_panoptic_argmax: crop outside the upsampled image");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * 3 * n, s);
+  if (e != hipSuccess) {
+    cgg_set_error("cgg_panoptic_argmax: memset failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  const ResizeGeom g = make_geom(H, W, up_h, up_w, crop_h, crop_w, out_h, out_w);
+  const long long npix = (long long)out_h * out_w;
+  hipLaunchKernelGGL(cgg_panoptic_argmax_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256),
+                     sizeof(int32_t) * 3 * n, s, logits, keep, score, ids, win_half, counts, g, n);
+  CGG_CHECK_LAUNCH("cgg_panoptic_argmax");
+  return CGG_OK;
+}
+
+extern "C" int cgg_panoptic_paint(const int32_t* ids, const uint8_t* win_half, const int32_t* lut_val,
+                                  const int32_t* lut_half, int32_t* seg, int64_t npix, int void_label,
+                                  cgg_stream_t stream) {
+  CGG_REQUIRE(ids && win_half && lut_val && lut_half && seg, CGG_EINVAL, "cgg_panoptic_paint: null pointer");
+  CGG_REQUIRE(npix > 0, CGG_EINVAL, "cgg_panoptic_paint: bad size");
+  hipLaunchKernelGGL(cgg_panoptic_paint_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, ids, win_half, lut_val, lut_half, seg, (long long)npix,
+                     void_label);
+  CGG_CHECK_LAUNCH("cgg_panoptic_paint");
+  return CGG_OK;
+}
+
+extern "C" int cgg_rowwise_softmax_argmax(const float* x, float* prob, float* maxv, int64_t* argmax,
+                                          int rows, int n, cgg_stream_t stream) {
+  CGG_REQUIRE(x, CGG_EINVAL, "cgg_rowwise_softmax_argmax: null pointer");
+  CGG_REQUIRE(rows > 0 && n > 0, CGG_EINVAL, "cgg_rowwise_softmax_argmax: bad sizes");
+  hipLaunchKernelGGL(cgg_softmax_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     x, prob, maxv, argmax, rows, n);
+  CGG_CHECK_LAUNCH("cgg_rowwise_softmax_argmax");
+  return CGG_OK;
+}

@@ -1,0 +1,237 @@
+// K6 (+K5 contract): masked multi-head cross-attention core, flash-style with split over keys.
+// Replaces the baddbmm + masked softmax + bmm inside nn.MultiheadAttention reached from
+// open_set/models/mask2former_head.py:829-840 (attn_masks=[attn_mask, None]).
+//
+// Shape regime (Q=100 queries, D=32, S = 1024 / 4096 / 16384 keys, B*H = 16): K/V are streamed
+// exactly once (HBM/L2-bound), so the work is split over (batch, head, key chunk) to fill 256 CUs
+// and recombined by a tiny second kernel. The boolean mask is a bit-packed [B, Q, S/32] image shared
+// by all heads (never the x8 head repeat of mask2former_head.py:756-757).
+//
+// Wave mapping ("swapped" QK^T): S^T = K Q^T with keys on MFMA rows and queries on MFMA columns,
+// so a lane owns ONE query and 16 keys of the tile -> the row max / row sum of the online softmax
+// are in-register reductions + one cross-half shuffle; P^T feeds the PV MFMA as B operand with no
+// data movement at all.
+//   f32 path:  v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate) -- parity mode.
+//   bf16 path: v_mfma_f32_32x32x16_bf16 on bf16 K / V^T (see cgg_masked_xattn_forward_bf16).
+#include "cgg_common.h"
+
+#define XA_TK 64  // keys per LDS tile
+
+__device__ __forceinline__ int xa_kswz(int key, int slot) { return slot ^ ((key >> 1) & 7); }
+
+// -------------------------------------------------------------------------------------------------
+// partial pass: one workgroup = (key chunk, head, batch); wave w owns queries [32w, 32w+32).
+// ws_o  [B, H, nchunks, Q, D]  un-normalised O;  ws_ml [B, H, nchunks, Q, 2]  (m, l)
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
+    const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
+    float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S, int words, int KC,
+    int nchunks, float scale) {
+  constexpr int D = 32;
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int HD = H * D;
+  const int s_begin = chunk * KC;
+  const int s_end = min(S, s_begin + KC);
+  const int cw = KC / 32;       // mask words per row in this chunk
+  const int cws = cw + 1;       // padded LDS stride
+  const int nmt = (Q + 31) / 32;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Ks = reinterpret_cast<float*>(smem_raw);             // [64][32] swizzled 16-B slots
+  float* Vs = Ks + XA_TK * D;                                 // [64][32]
+  uint32_t* Ms = reinterpret_cast<uint32_t*>(Vs + XA_TK * D); // [nmt*32][cws]
+
+  // ---- mask words of this chunk -> LDS ----
+  for (int i = tid; i < nmt * 32 * cw; i += 256) {
+    const int qq = i / cw, w = i - qq * cw;
+    const int gw = s_begin / 32 + w;
+    uint32_t m = 0u;
+    if (bits != nullptr && qq < Q && gw < words) m = bits[((size_t)b * Q + qq) * words + gw];
+    Ms[qq * cws + w] = m;
+  }
+
+  // ---- this wave's queries (pre-scaled), B operand of S^T: lane (j, hi) holds d = 16*hi + s ----
+  const int qi = wave * 32 + j;
+  const bool wave_live = wave < nmt;
+  float qf[16];
+  {
+    const bool ok = qi < Q;
+    const float* qp = q + ((size_t)b * Q + (ok ? qi : 0)) * HD + h * D + 16 * hi;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(qp + 4 * s4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = ok ? v[e] * scale : 0.f;
+    }
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+
+  const float* kvb = kv + (size_t)b * S * (2 * HD) + h * D;
+  for (int s0 = s_begin; s0 < s_end; s0 += XA_TK) {
+    __syncthreads();  // previous tile fully consumed (also orders the Ms fill on first trip)
+    // ---- stage K, V tile: 64 keys x 128 B each; thread = 16-B chunk (2 per operand) ----
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + 256 * it;
+      const int key = c >> 3, slot = c & 7;
+      const int s = s0 + key;
+      f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (s < s_end) {
+        const float* row = kvb + (size_t)s * (2 * HD) + slot * 4;
+        kx = *reinterpret_cast<const f32x4*>(row);
+        vx = *reinterpret_cast<const f32x4*>(row + HD);
+      }
+      *reinterpret_cast<f32x4*>(Ks + key * D + xa_kswz(key, slot) * 4) = kx;
+      *reinterpret_cast<f32x4*>(Vs + key * D + slot * 4) = vx;
+    }
+    __syncthreads();
+    if (!wave_live) continue;
+
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kt = sub * 32;  // key offset in tile
+      // ---- S^T[key][query] : 16 x v_mfma_f32_32x32x2_f32 ----
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+      const int krow = kt + j;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 ka =
+            *reinterpret_cast<const f32x4*>(Ks + krow * D + xa_kswz(krow, hi * 4 + s4) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[4 * s4 + e], sc, 0, 0, 0);
+      }
+      // ---- mask + online softmax (lane = query j; 16 keys in-register, partner lane^32 has the rest)
+      const uint32_t mw = Ms[qi * cws + ((s0 - s_begin + kt) >> 5)];
+      float rmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ki = (r & 3) + 8 * (r >> 2) + 4 * hi;  // key inside the 32-key sub tile
+        const bool blocked = ((mw >> ki) & 1u) || (s0 + kt + ki >= s_end);
+        sc[r] = blocked ? -INFINITY : sc[r];
+        rmax = fmaxf(rmax, sc[r]);
+      }
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+      const float m_new = fmaxf(m_run, rmax);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = expf(m_run - m_use);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sc[r] = expf(sc[r] - m_use);
+        psum += sc[r];
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      // ---- O^T[d][query] += V^T[d][key] P^T[key][query] : 16 x v_mfma_f32_32x32x2_f32 ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ki = kt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float va = Vs[ki * D + j];
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(va, sc[r], o, 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partials out: lane (j, hi) holds O[q = qi][d = (r&3) + 8*(r>>2) + 4*hi] ----
+  if (wave_live && qi < Q) {
+    const size_t base = (((size_t)b * H + h) * nchunks + chunk) * Q + qi;
+    float* op = ws_o + base * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hi) = v;
+    }
+    if (hi == 0) {
+      ws_ml[base * 2] = m_run;
+      ws_ml[base * 2 + 1] = l_run;
+    }
+  }
+}
+
+// combine the per-chunk partials: thread = (b, q, h, d)
+__global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict__ ws_o,
+                                                         const float* __restrict__ ws_ml,
+                                                         float* __restrict__ out, int B, int Q, int H,
+                                                         int D, int nchunks) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * Q * H * D;
+  if (gid >= total) return;
+  const int d = (int)(gid % D);
+  const int h = (int)((gid / D) % H);
+  const int qq = (int)((gid / ((long long)D * H)) % Q);
+  const int b = (int)(gid / ((long long)D * H * Q));
+  const size_t base = ((size_t)b * H + h) * nchunks;
+  float M = -INFINITY;
+  for (int c = 0; c < nchunks; ++c) M = fmaxf(M, ws_ml[((base + c) * Q + qq) * 2]);
+  float num = 0.f, den = 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    const size_t r = (base + c) * Q + qq;
+    const float mc = ws_ml[r * 2];
+    const float f = (mc == -INFINITY) ? 0.f : expf(mc - M);
+    num += f * ws_o[r * D + d];
+    den += f * ws_ml[r * 2 + 1];
+  }
+  out[((size_t)b * Q + qq) * (H * D) + h * D + d] = num / den;  // den == 0 -> NaN, as the reference
+}
+
+// -------------------------------------------------------------------------------------------------
+static void xattn_plan(int B, int H, int S, int* KC, int* nchunks) {
+  // aim at ~2 workgroups per CU; chunk = multiple of XA_TK keys, at most 1024 (mask LDS budget)
+  int want = (512 + B * H - 1) / (B * H);
+  int tiles = (S + XA_TK - 1) / XA_TK;
+  if (want > tiles) want = tiles;
+  if (want < 1) want = 1;
+  int tpc = (tiles + want - 1) / want;  // tiles per chunk
+  if (tpc > 1024 / XA_TK) tpc = 1024 / XA_TK;
+  *KC = tpc * XA_TK;
+  *nchunks = (S + *KC - 1) / *KC;
+}
+
+extern "C" int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, int S) {
+  if (B <= 0 || Q <= 0 || H <= 0 || D <= 0 || S <= 0) return 0;
+  int KC, nch;
+  xattn_plan(B, H, S, &KC, &nch);
+  return (int64_t)B * H * nch * Q * (D + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bits,
+                                        float* out, void* ws, int B, int Q, int H, int D, int S,
+                                        float scale, int kv_dtype, cgg_stream_t stream) {
+  CGG_REQUIRE(q && kv && out && ws, CGG_EINVAL, "cgg_masked_xattn_forward: null pointer");
+  CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_forward: bad sizes");
+  CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward: head dim %d (only 32 is built)", D);
+  CGG_REQUIRE(Q <= 128, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward: Q=%d > 128", Q);
+  CGG_REQUIRE(kv_dtype == CGG_F32, CGG_EUNSUPPORTED,
+              "cgg_masked_xattn_forward: kv dtype %d (f32 here; bf16 via cgg_masked_xattn_forward_bf16)",
+              kv_dtype);
+  CGG_REQUIRE(cgg_aligned16(q) && cgg_aligned16(kv) && cgg_aligned16(ws), CGG_EALIGN,
+              "cgg_masked_xattn_forward: q / kv / ws must be 16-B aligned");
+  int KC, nch;
+  xattn_plan(B, H, S, &KC, &nch);
+  const int words = (S + 31) / 32;
+  const int nmt = (Q + 31) / 32;
+  float* ws_o = (float*)ws;
+  float* ws_ml = ws_o + (size_t)B * H * nch * Q * D;
+  const size_t lds = (size_t)2 * XA_TK * D * sizeof(float) + (size_t)nmt * 32 * (KC / 32 + 1) * 4;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
+                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale);
+  CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
+  const long long total = (long long)B * Q * H * D;
+  hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o,
+                     ws_ml, out, B, Q, H, D, nch);
+  CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
+  return CGG_OK;
+}

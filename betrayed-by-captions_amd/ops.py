@@ -1,0 +1,301 @@
+"""Torch-facing wrappers of the HIP kernels in libcgg_hip.so.
+
+Every function takes/returns torch tensors on a ROCm device, allocates outputs with PyTorch's
+caching allocator, and enqueues on torch's current stream. None of them has a CPU path: a CPU
+tensor raises `CggError` (see _lib.dev_ptr). References are to the reference repo / SURVEY.md
+kernel ids (K1..K19).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import CGG_BF16, CGG_F32, CggError, check, dev_ptr, stream_ptr
+
+_WS_CACHE = {}
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _int_array(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+# ------------------------------------------------------------------------------------------------
+# K1/K2  MSDeformAttn core   ([3P] mmcv MultiScaleDeformableAttnFunction)
+# ------------------------------------------------------------------------------------------------
+def _msda_dims(value, sampling_loc):
+    B, Nv, H, D = value.shape
+    _, Nq, H2, L, P, two = sampling_loc.shape
+    if H2 != H or two != 2:
+        raise CggError(f'sampling_locations shape {tuple(sampling_loc.shape)} does not match value '
+                       f'{tuple(value.shape)}')
+    return B, Nv, H, D, L, Nq, P
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    """value (B,Nv,H,D) f32|bf16; spatial_shapes (L,2) int64; level_start_index (L,) int64;
+    sampling_locations (B,Nq,H,L,P,2) f32; attention_weights (B,Nq,H,L,P) f32 -> (B,Nq,H*D) f32."""
+    B, Nv, H, D, L, Nq, P = _msda_dims(value, sampling_locations)
+    vdt = CGG_BF16 if value.dtype == torch.bfloat16 else CGG_F32
+    if value.dtype not in (torch.float32, torch.bfloat16):
+        raise CggError(f'msda_forward: value dtype {value.dtype}')
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
+    rc = _lib_().cgg_msda_forward(
+        dev_ptr(value, 'value'), dev_ptr(spatial_shapes, 'spatial_shapes', torch.int64),
+        dev_ptr(level_start_index, 'level_start_index', torch.int64),
+        dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
+        dev_ptr(attention_weights, 'attention_weights', torch.float32), dev_ptr(out), B, Nv, H, D, L,
+        Nq, P, vdt, stream_ptr(value.device))
+    check(rc, 'cgg_msda_forward')
+    return out
+
+
+def msda_forward_hostlevels(value, level_hw, level_start, sampling_locations, attention_weights):
+    """Same op, level table as python lists (no D2H; legal under hipGraph capture)."""
+    B, Nv, H, D, L, Nq, P = _msda_dims(value, sampling_locations)
+    vdt = CGG_BF16 if value.dtype == torch.bfloat16 else CGG_F32
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
+    hw = _int_array([v for pair in level_hw for v in pair])
+    st = _int_array(level_start)
+    rc = _lib_().cgg_msda_forward_hostlevels(
+        dev_ptr(value, 'value'), hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
+        dev_ptr(attention_weights, 'attention_weights', torch.float32), None, 0, dev_ptr(out), B, Nv,
+        H, D, L, Nq, P, vdt, 0, stream_ptr(value.device))
+    check(rc, 'cgg_msda_forward_hostlevels')
+    return out
+
+
+def msda_forward_fused(value, level_hw, level_start, offs_logits, ref_points, num_points):
+    """value (B,Nv,H,D); offs_logits (B,Nq,ld) raw [offsets | logits] of the two linears;
+    ref_points (Nq,2) -> (B,Nq,H*D). Softmax over L*P and loc = ref + off/(W,H) run in-kernel."""
+    B, Nv, H, D = value.shape
+    Bq, Nq, ld = offs_logits.shape
+    L = len(level_start)
+    P = int(num_points)
+    vdt = CGG_BF16 if value.dtype == torch.bfloat16 else CGG_F32
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
+    hw = _int_array([v for pair in level_hw for v in pair])
+    st = _int_array(level_start)
+    rc = _lib_().cgg_msda_forward_hostlevels(
+        dev_ptr(value, 'value'), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.float32), None,
+        dev_ptr(ref_points, 'ref_points', torch.float32), ld, dev_ptr(out), B, Nv, H, D, L, Nq, P, vdt,
+        1, stream_ptr(value.device))
+    check(rc, 'cgg_msda_forward_hostlevels(fused)')
+    return out
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                  grad_output):
+    B, Nv, H, D, L, Nq, P = _msda_dims(value, sampling_locations)
+    gv = torch.zeros_like(value)
+    gl = torch.zeros_like(sampling_locations)
+    gw = torch.zeros_like(attention_weights)
+    rc = _lib_().cgg_msda_backward(
+        dev_ptr(value, 'value', torch.float32), dev_ptr(spatial_shapes, 'spatial_shapes', torch.int64),
+        dev_ptr(level_start_index, 'level_start_index', torch.int64),
+        dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
+        dev_ptr(attention_weights, 'attention_weights', torch.float32),
+        dev_ptr(grad_output, 'grad_output', torch.float32), dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B,
+        Nv, H, D, L, Nq, P, stream_ptr(value.device))
+    check(rc, 'cgg_msda_backward')
+    return gv, gl, gw
+
+
+class MultiScaleDeformableAttnFunction(torch.autograd.Function):
+    """Drop-in for [3P] mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction
+    (same positional signature incl. the unused im2col_step)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step=64):
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return msda_forward(value.contiguous(), value_spatial_shapes, value_level_start_index,
+                            sampling_locations.contiguous(), attention_weights.contiguous())
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, attw = ctx.saved_tensors
+        gv, gl, gw = msda_backward(value.contiguous().float(), shapes, starts, loc.contiguous(),
+                                   attw.contiguous(), grad_output.contiguous())
+        return gv.to(value.dtype), None, None, gl, gw, None
+
+
+# ------------------------------------------------------------------------------------------------
+# K3/K4/K5  mask logits  (open_set/models/mask2former_head.py:748-759, :825-826)
+# ------------------------------------------------------------------------------------------------
+class PackedFeature:
+    """mask_feature packed for the MFMA B operand (see include/cgg_hip.h)."""
+
+    def __init__(self, hi, lo, B, C, h, w):
+        self.hi, self.lo, self.B, self.C, self.h, self.w = hi, lo, B, C, h, w
+        self.npix = h * w
+        self.words = (self.npix + 31) // 32
+
+
+def pack_mask_feature(feat, pool=1, split=True):
+    """feat (B,C,H,W) f32 -> PackedFeature of the map bilinear-downsampled by `pool`."""
+    B, C, H, W = feat.shape
+    if H % pool or W % pool:
+        raise CggError(f'pack_mask_feature: {H}x{W} not divisible by pool={pool}')
+    h, w = H // pool, W // pool
+    T = (h * w + 31) // 32
+    hi = torch.empty((B, T, C // 8, 32, 8), dtype=torch.bfloat16, device=feat.device)
+    lo = torch.empty_like(hi) if split else None
+    rc = _lib_().cgg_pack_mask_feature(dev_ptr(feat, 'mask_feature', torch.float32), dev_ptr(hi),
+                                       dev_ptr(lo), B, C, H, W, pool, stream_ptr(feat.device))
+    check(rc, 'cgg_pack_mask_feature')
+    return PackedFeature(hi, lo, B, C, h, w)
+
+
+def mask_logits(embed, packed, want_logits=True, want_bits=False):
+    """embed (B,Q,C) f32 x PackedFeature -> (logits (B,Q,h,w) f32 | None, bits (B,Q,words) int32 | None)."""
+    B, Q, C = embed.shape
+    if B != packed.B or C != packed.C:
+        raise CggError(f'mask_logits: embed {tuple(embed.shape)} vs packed B={packed.B} C={packed.C}')
+    out = torch.empty((B, Q, packed.h, packed.w), dtype=torch.float32, device=embed.device) \
+        if want_logits else None
+    bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device) \
+        if want_bits else None
+    rc = _lib_().cgg_mask_logits(dev_ptr(embed, 'mask_embed', torch.float32), dev_ptr(packed.hi),
+                                 dev_ptr(packed.lo), dev_ptr(out), dev_ptr(bits), B, Q, C, packed.npix,
+                                 stream_ptr(embed.device))
+    check(rc, 'cgg_mask_logits')
+    return out, bits
+
+
+def attn_mask_fix_full_rows(bits, npix):
+    """In place: rows of the bit mask that block all `npix` keys are cleared."""
+    rows = bits.numel() // bits.shape[-1]
+    rc = _lib_().cgg_attn_mask_fix_full_rows(dev_ptr(bits, 'bits', torch.int32), rows, npix,
+                                             stream_ptr(bits.device))
+    check(rc, 'cgg_attn_mask_fix_full_rows')
+    return bits
+
+
+def attn_mask_from_logits(logits, size):
+    """logits (B,Q,H,W) f32 -> bits (B,Q,ceil(h*w/32)) int32 of (bilinear-resized logit < 0)."""
+    B, Q, H, W = logits.shape
+    h, w = int(size[0]), int(size[1])
+    words = (h * w + 31) // 32
+    bits = torch.empty((B, Q, words), dtype=torch.int32, device=logits.device)
+    rc = _lib_().cgg_attn_mask_from_logits(dev_ptr(logits, 'logits', torch.float32), dev_ptr(bits),
+                                           B * Q, H, W, h, w, stream_ptr(logits.device))
+    check(rc, 'cgg_attn_mask_from_logits')
+    return bits
+
+
+def unpack_bits(bits, npix):
+    """bits (..., words) int32 -> bool (..., npix)  (test / debugging helper, plain torch)."""
+    shifts = torch.arange(32, device=bits.device, dtype=torch.int32)
+    b = ((bits.unsqueeze(-1) >> shifts) & 1).bool()
+    return b.flatten(-2)[..., :npix]
+
+
+# ------------------------------------------------------------------------------------------------
+# K6  masked cross attention core
+# ------------------------------------------------------------------------------------------------
+def masked_xattn(q, kv, bits, num_heads, scale=None):
+    """q (B,Q,E) f32 projected queries; kv (B,S,2E) f32 [K|V] projected; bits (B,Q,ceil(S/32)) int32
+    (bit set = blocked) or None -> (B,Q,E) f32 = softmax(q k^T * scale + mask) v, per head."""
+    B, Q, E = q.shape
+    S = kv.shape[1]
+    H = int(num_heads)
+    D = E // H
+    if kv.shape[2] != 2 * E:
+        raise CggError(f'masked_xattn: kv last dim {kv.shape[2]} != 2*{E}')
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    lib = _lib_()
+    nbytes = lib.cgg_masked_xattn_workspace_bytes(B, Q, H, D, S)
+    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
+        _WS_CACHE[key] = ws
+    out = torch.empty((B, Q, E), dtype=torch.float32, device=q.device)
+    rc = lib.cgg_masked_xattn_forward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
+                                      dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(ws), B,
+                                      Q, H, D, S, float(scale), CGG_F32, stream_ptr(q.device))
+    check(rc, 'cgg_masked_xattn_forward')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K19  inference tail
+# ------------------------------------------------------------------------------------------------
+def upsample_bilinear(x, size):
+    """x (N,C,H,W) or (N,H,W) f32 -> bilinear (align_corners=False) resize to `size`."""
+    shp = x.shape
+    H, W = shp[-2:]
+    h, w = int(size[0]), int(size[1])
+    n = x.numel() // (H * W)
+    y = torch.empty(tuple(shp[:-2]) + (h, w), dtype=torch.float32, device=x.device)
+    rc = _lib_().cgg_upsample_bilinear(dev_ptr(x, 'x', torch.float32), dev_ptr(y), n, H, W, h, w,
+                                       stream_ptr(x.device))
+    check(rc, 'cgg_upsample_bilinear')
+    return y
+
+
+def instance_masks(logits, sel, up_size, crop_size, out_size):
+    """logits (Q,H,W) f32 low-res; sel (n,) int32 -> masks (n,oh,ow) bool, mask_score (n,), bbox (n,4)."""
+    Q, H, W = logits.shape
+    n = sel.numel()
+    oh, ow = int(out_size[0]), int(out_size[1])
+    masks = torch.empty((n, oh, ow), dtype=torch.uint8, device=logits.device)
+    score = torch.empty((n,), dtype=torch.float32, device=logits.device)
+    bbox = torch.empty((n, 4), dtype=torch.float32, device=logits.device)
+    if n == 0:
+        return masks.bool(), score, bbox
+    ws = torch.empty((n, 8), dtype=torch.int32, device=logits.device)
+    rc = _lib_().cgg_instance_masks(dev_ptr(logits, 'logits', torch.float32),
+                                    dev_ptr(sel, 'sel', torch.int32), dev_ptr(masks), dev_ptr(score),
+                                    dev_ptr(bbox), dev_ptr(ws), Q, H, W, int(up_size[0]),
+                                    int(up_size[1]), int(crop_size[0]), int(crop_size[1]), oh, ow, n,
+                                    stream_ptr(logits.device))
+    check(rc, 'cgg_instance_masks')
+    return masks.view(torch.bool), score, bbox
+
+
+def panoptic_argmax(logits, keep, score, up_size, crop_size, out_size):
+    """-> ids (oh,ow) int32 in [0,n), win_half (oh,ow) uint8, counts (n,3) int32."""
+    Q, H, W = logits.shape
+    n = keep.numel()
+    oh, ow = int(out_size[0]), int(out_size[1])
+    ids = torch.empty((oh, ow), dtype=torch.int32, device=logits.device)
+    half = torch.empty((oh, ow), dtype=torch.uint8, device=logits.device)
+    counts = torch.empty((n, 3), dtype=torch.int32, device=logits.device)
+    rc = _lib_().cgg_panoptic_argmax(dev_ptr(logits, 'logits', torch.float32),
+                                     dev_ptr(keep, 'keep', torch.int32),
+                                     dev_ptr(score, 'score', torch.float32), dev_ptr(ids), dev_ptr(half),
+                                     dev_ptr(counts), Q, H, W, int(up_size[0]), int(up_size[1]),
+                                     int(crop_size[0]), int(crop_size[1]), oh, ow, n,
+                                     stream_ptr(logits.device))
+    check(rc, 'cgg_panoptic_argmax')
+    return ids, half, counts
+
+
+def panoptic_paint(ids, win_half, lut_val, lut_half, void_label):
+    seg = torch.empty_like(ids)
+    rc = _lib_().cgg_panoptic_paint(dev_ptr(ids, 'ids', torch.int32), dev_ptr(win_half, 'win_half', torch.uint8),
+                                    dev_ptr(lut_val, 'lut_val', torch.int32),
+                                    dev_ptr(lut_half, 'lut_half', torch.int32), dev_ptr(seg),
+                                    ids.numel(), int(void_label), stream_ptr(ids.device))
+    check(rc, 'cgg_panoptic_paint')
+    return seg
+
+
+def rowwise_softmax_argmax(x, want_prob=True):
+    """x (rows,n) f32 -> (prob (rows,n) | None, max prob (rows,), argmax (rows,) int64)."""
+    rows, n = x.shape
+    prob = torch.empty_like(x) if want_prob else None
+    maxv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    arg = torch.empty((rows,), dtype=torch.int64, device=x.device)
+    rc = _lib_().cgg_rowwise_softmax_argmax(dev_ptr(x, 'x', torch.float32), dev_ptr(prob), dev_ptr(maxv),
+                                            dev_ptr(arg), rows, n, stream_ptr(x.device))
+    check(rc, 'cgg_rowwise_softmax_argmax')
+    return prob, maxv, arg

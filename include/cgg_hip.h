@@ -1,0 +1,208 @@
+/*
+ * cgg_hip.h -- C ABI of libcgg_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the hot path of
+ * CGG ("Betrayed by Captions"): MSDeformAttn pixel decoder -> masked-cross-attention query decoder ->
+ * mask_embed x mask_feature mask logits -> open-vocabulary post-processing.
+ *
+ * Conventions (every entry point):
+ *   - extern "C", plain pointers and sizes; NO torch / C++ types cross this boundary.
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in
+ *     this repo); the library never allocates, frees or keeps global state between calls.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
+ *   - return value: 0 (CGG_OK) on success, a negative CGG_E* for argument errors, or a positive
+ *     hipError_t if the launch failed. No C++ exception crosses the ABI.
+ *     cgg_last_error_string() gives a thread-local description of the last failure.
+ *   - re-entrant and thread-safe (autograd / DDP threads pass their own stream).
+ *
+ * Each function names the reference interface it replaces (paths relative to the reference repo
+ * jianzongwu/betrayed-by-captions; "[3P]" = upstream mmcv 1.7.1 / mmdet 2.28.2 symbol that the
+ * reference selects through a `type=` string and whose source is not part of the reference tree).
+ */
+#ifndef CGG_HIP_H_
+#define CGG_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGG_VERSION 100 /* 0.1.0 */
+
+/* error codes (negative); positive return values are hipError_t */
+#define CGG_OK 0
+#define CGG_EINVAL (-1)       /* bad argument (null pointer, non-positive size, ...)            */
+#define CGG_EUNSUPPORTED (-2) /* shape / dtype combination this build has no kernel for        */
+#define CGG_EALIGN (-3)       /* pointer not aligned as the kernel requires (16 B)             */
+
+/* dtype tags */
+#define CGG_F32 0
+#define CGG_BF16 1
+
+typedef void* cgg_stream_t; /* hipStream_t */
+
+int cgg_version(void);
+const char* cgg_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1/K2  Multi-scale deformable attention (sampling + aggregation).
+ *
+ * Replaces [3P] mmcv `ext_module.ms_deform_attn_forward(value, spatial_shapes, level_start_index,
+ * sampling_locations, attention_weights, im2col_step)` / `ms_deform_attn_backward(...)`, i.e.
+ * `MultiScaleDeformableAttnFunction`, selected by `type='MultiScaleDeformableAttention'` in
+ * configs/instance/coco_b48n17.py:49-58 and executed 6x per forward by the pixel decoder built at
+ * open_set/models/mask2former_head.py:112-117 (called :787).
+ *
+ *   value            [B, Nv, H, D]        f32 (CGG_F32) or bf16 (CGG_BF16); Nv = sum_l H_l*W_l
+ *   spatial_shapes   [L, 2] int64 (H_l, W_l)        (device)
+ *   level_start      [L]    int64                   (device)
+ *   sampling_loc     [B, Nq, H, L, P, 2] f32, (x, y) in [0,1]
+ *   attn_weight      [B, Nq, H, L, P]    f32 (already soft-maxed over L*P)
+ *   out              [B, Nq, H*D]        f32
+ * out[b,q,h*D+c] = sum_{l,p} w * bilinear_zero_pad(value_l[b,:,h,c]; x*W_l-0.5, y*H_l-0.5)
+ * (grid_sample(align_corners=False, padding_mode='zeros') semantics).
+ * Requires D % 4 == 0, L <= 8.
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_msda_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                     const float* sampling_loc, const float* attn_weight, float* out, int B, int Nv,
+                     int H, int D, int L, int Nq, int P, int value_dtype, cgg_stream_t stream);
+
+/* Fused variant: takes the RAW outputs of the `sampling_offsets` (H*L*P*2) and `attention_weights`
+ * (H*L*P) linears and does `loc = ref + off / (W_l, H_l)` and the softmax over L*P in the kernel
+ * prologue ([3P] MultiScaleDeformableAttention.forward). ref_points [Nq, 2] (x, y) in [0,1] are
+ * shared by all levels and batch items (valid_ratios == 1, as in MSDeformAttnPixelDecoder).
+ *   offs_logits  [B, Nq, ld]  f32, row = [H*L*P*2 offsets | H*L*P logits], ld >= H*L*P*3        */
+int cgg_msda_forward_fused(const void* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start, const float* offs_logits, int ld,
+                           const float* ref_points, float* out, int B, int Nv, int H, int D, int L,
+                           int Nq, int P, int value_dtype, cgg_stream_t stream);
+
+/* Same kernels with the level table given as HOST int32 arrays (level_hw [L,2] = (H_l, W_l),
+ * level_start [L]): no device->host read of the table, so the call is legal inside a hipGraph
+ * capture. fused != 0 selects the cgg_msda_forward_fused argument meaning (sampling_loc =
+ * offs_logits with row stride ld, attn_weight ignored, ref_points used).                          */
+int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
+                                const int32_t* level_start, const float* sampling_loc,
+                                const float* attn_weight, const float* ref_points, int ld,
+                                float* out, int B, int Nv, int H, int D, int L, int Nq, int P,
+                                int value_dtype, int fused, cgg_stream_t stream);
+
+/* Backward of cgg_msda_forward (f32 value). grad_value / grad_loc / grad_attn must be ZEROED by the
+ * caller and are accumulated in place (same contract as mmcv's ms_deform_attn_backward).           */
+int cgg_msda_backward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                      const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                      float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H,
+                      int D, int L, int Nq, int P, cgg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3/K4/K5  Mask logits: mask_pred[b,q,h,w] = sum_c mask_embed[b,q,c] * mask_feature[b,c,h,w]
+ *
+ * Replaces `torch.einsum('bqc,bchw->bqhw', mask_embed, mask_feature)` and the attention-mask rule
+ * `sigmoid(interpolate(mask_pred, size_l, 'bilinear')) < 0.5` at
+ * open_set/models/mask2former_head.py:748-759 (10x per forward), and the all-masked-row fix-up at
+ * :825-826.
+ *
+ * mask_feature is packed ONCE per forward into an MFMA-fragment-major bf16 image
+ *   packed[b][t][c/8][p%32][c%8]   (t = p/32, 16 B per (c/8, p) slot; tiles zero padded)
+ * so that every `v_mfma_f32_32x32x16_bf16` B operand is one coalesced 1-KiB global_load_dwordx4.
+ * `lo` (nullable) receives the bf16 residual f - bf16(f): with it the contraction runs as three
+ * bf16 MFMAs (hi*hi + hi*lo + lo*hi), |err| ~1e-5 relative = f32-class accuracy; without it the
+ * contraction is plain bf16 (north_star's MFMA bf16 path).
+ * `pool` in {1,2,4,8}: pool == 1 packs the feature map itself; pool == s > 1 packs the map that
+ * `F.interpolate(.., scale 1/s, bilinear, align_corners=False)` reads, i.e. the mean of the 2x2
+ * block at rows/cols {s*i+s/2-1, s*i+s/2}: by linearity, logits of the pooled feature ARE the
+ * interpolated logits, so the attention mask of a level needs a GEMM over H*W/s^2 pixels only.
+ *   feat   [B, C, H, W] f32;  hi/lo  [B, ceil(H/s*W/s / 32), C/8, 32, 8] bf16
+ * Requires C % 16 == 0, H % s == 0, W % s == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int B, int C, int H, int W,
+                          int pool, cgg_stream_t stream);
+
+/*   embed   [B, Q, C] f32          (mask_embed MLP output)
+ *   hi, lo  packed feature (lo nullable -> bf16 mode)        npix = number of (pooled) pixels
+ *   out     [B, Q, npix] f32, nullable (logits not stored)
+ *   bits    [B, Q, ceil(npix/32)] u32, nullable: bit (p%32) of word p/32 = (logit < 0), i.e. the
+ *           boolean attention mask (True = blocked) shared by all heads -- never repeated x8.
+ * Requires C == 256 (feat_channels of every shipped config), Q <= 256 (bf16) / Q <= 128 (split).  */
+int cgg_mask_logits(const float* embed, const void* hi, const void* lo, float* out, uint32_t* bits,
+                    int B, int Q, int C, int npix, cgg_stream_t stream);
+
+/* rows of `bits` that block every key are cleared (open_set/models/mask2former_head.py:825-826).
+ *   bits [rows, words] u32, npix valid bits per row.                                             */
+int cgg_attn_mask_fix_full_rows(uint32_t* bits, int rows, int npix, cgg_stream_t stream);
+
+/* generic path for level sizes that are not an even integer divisor of the mask-feature size:
+ * bilinear (align_corners=False) resize of stored logits [N, H, W] -> [N, h, w], then (x < 0) bits */
+int cgg_attn_mask_from_logits(const float* logits, uint32_t* bits, int N, int H, int W, int h,
+                              int w, cgg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  Masked multi-head cross-attention core (flash-style, split over keys).
+ *
+ * Replaces the `baddbmm + masked softmax + bmm` inside `nn.MultiheadAttention` reached through
+ * [3P] mmcv MultiheadAttention <- DetrTransformerDecoderLayer, called at
+ * open_set/models/mask2former_head.py:829-840 with attn_masks=[attn_mask, None].
+ *
+ *   q     [B, Q, H*D]  f32   (already projected, NOT yet scaled)
+ *   kv    [B, S, 2*H*D] f32 or bf16: row = [K(H*D) | V(H*D)]  (projected keys / values)
+ *   bits  [B, Q, ceil(S/32)] u32, nullable; bit set = key blocked; shared by heads. A row with all
+ *         S bits set must have been cleared by cgg_attn_mask_fix_full_rows (else output is NaN,
+ *         exactly like the reference).
+ *   out   [B, Q, H*D]  f32   softmax(q k^T * scale + mask) v, heads concatenated
+ *   ws    workspace, cgg_masked_xattn_workspace_bytes(...) bytes (split-K partials)
+ * Requires D == 32, H*D <= 256, Q <= 128.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, int S);
+int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bits, float* out,
+                             void* ws, int B, int Q, int H, int D, int S, float scale,
+                             int kv_dtype, cgg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K19  Inference tail.
+ *
+ * cgg_upsample_bilinear: F.interpolate(x, (h, w), 'bilinear', align_corners=False) for
+ * [N, H, W] -> [N, h, w] f32 (open_set/models/mask2former_head.py:960-964,
+ * open_set/models/maskformer_fusion_head.py:421-425).
+ *
+ * cgg_instance_masks: fused "upsample -> (>0) -> mask score -> bbox" of
+ * MaskFormerFusionHeadOpen.instance_postprocess_emb (maskformer_fusion_head.py:349-363) for the
+ * selected queries, reading the LOW-RES logits, so the (Q, H_img, W_img) f32 tensor is never
+ * written:
+ *   logits [Q, H, W] f32;  sel [n] int32 query index per detection
+ *   (up_h, up_w): batch_input_shape the head upsamples to (mask2former_head.py:957-964)
+ *   (crop_h, crop_w): img_shape crop (maskformer_fusion_head.py:415-416)
+ *   (out_h, out_w): ori_shape when `rescale` (:418-425), else == crop
+ *   masks  [n, out_h, out_w] u8 (0/1);  mask_score [n] f32 = sum(sigmoid*[m>0]) / (sum[m>0]+1e-6);
+ *   bbox [n, 4] f32 (x0, y0, x1+1, y1+1), zeros for an empty mask ([3P] mmdet mask2bbox)
+ *   ws     scratch, n * 32 bytes
+ *
+ * cgg_panoptic_argmax: per-pixel argmax_k score[k] * sigmoid(resized logit[keep[k]])
+ * (maskformer_fusion_head.py:100-120) fused with the resize; first max wins (torch.argmax).
+ *   ids [out_h, out_w] int32 in [0, n);  win_half [out_h, out_w] u8 = winner's sigmoid >= 0.5
+ *   counts [n, 3] int32: #(id == k), #(sigmoid_k >= 0.5), #(id == k && sigmoid_k >= 0.5)
+ *   -- the three areas the segment loop of :122-157 needs (one D2H instead of 3 .item() per query)
+ * cgg_panoptic_paint: seg[p] = lut_val[ids[p]] if lut_val >= 0 and (!lut_half[id] || win_half[p])
+ *   else void_label  (the decisions of :129-157 applied in one pass).
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_upsample_bilinear(const float* x, float* y, int N, int H, int W, int h, int w,
+                          cgg_stream_t stream);
+int cgg_instance_masks(const float* logits, const int32_t* sel, uint8_t* masks, float* mask_score,
+                       float* bbox, void* ws, int Q, int H, int W, int up_h, int up_w, int crop_h,
+                       int crop_w, int out_h, int out_w, int n, cgg_stream_t stream);
+int cgg_panoptic_argmax(const float* logits, const int32_t* keep, const float* score, int32_t* ids,
+                        uint8_t* win_half, int32_t* counts, int Q, int H, int W, int up_h, int up_w,
+                        int crop_h, int crop_w, int out_h, int out_w, int n, cgg_stream_t stream);
+int cgg_panoptic_paint(const int32_t* ids, const uint8_t* win_half, const int32_t* lut_val,
+                       const int32_t* lut_half, int32_t* seg, int64_t npix, int void_label,
+                       cgg_stream_t stream);
+
+/* Row-wise softmax + max/argmax: scores = softmax(x) over the last dim, one wavefront per row
+ * (MaskFormerFusionHeadOpen.get_cls_emb_scores, maskformer_fusion_head.py:297-315, and the
+ * `.max(-1)` at :99).  x [rows, n] f32 -> prob [rows, n] f32 (nullable), maxv [rows] f32,
+ * argmax [rows] int64 (first max wins).                                                          */
+int cgg_rowwise_softmax_argmax(const float* x, float* prob, float* maxv, int64_t* argmax, int rows,
+                               int n, cgg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGG_HIP_H_ */

@@ -1,0 +1,284 @@
+"""-m gpu parity tests: each HIP kernel, called through the C ABI (ctypes), against the CPU oracle on the
+same seeded inputs. Tolerances are written next to each check.
+  * integer / index / bit outputs: exact (ties excluded where the oracle's own value is within 1e-5
+    of the decision threshold -- stated per test);
+  * mask logits, split (f32-class) mode: |err| <= 1e-3 absolute (north_star), bf16 mode: 2^-7 relative
+    to sum|a||b| (bf16 input rounding);
+  * MSDeformAttn / attention f32: 1e-4 absolute.
+"""
+import math
+
+import pytest
+import torch
+
+import cgg_amd  # noqa: F401
+from cgg_amd import ops
+from oracle import ops as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels(shapes):
+    starts, s = [], 0
+    for h, w in shapes:
+        starts.append(s)
+        s += h * w
+    return starts, s
+
+
+def _msda_inputs(B, shapes, H, D, P, Nq, seed, spread=1.0):
+    g = torch.Generator().manual_seed(seed)
+    starts, Nv = _levels(shapes)
+    L = len(shapes)
+    value = torch.randn(B, Nv, H, D, generator=g)
+    # locations mostly inside [0,1] with some outside (exercise zero padding / skip rule)
+    loc = torch.rand(B, Nq, H, L, P, 2, generator=g) * (1 + 0.4 * spread) - 0.2 * spread
+    aw = torch.softmax(torch.randn(B, Nq, H, L * P, generator=g), -1).view(B, Nq, H, L, P)
+    ss = torch.tensor(shapes, dtype=torch.int64)
+    st = torch.tensor(starts, dtype=torch.int64)
+    return value, ss, st, loc, aw
+
+
+@pytest.mark.parametrize('shapes,B,Nq', [
+    ([(4, 4), (8, 8), (16, 16)], 2, 336),
+    ([(5, 7), (10, 14), (20, 28)], 1, 1190),  # ragged, non power of two
+    ([(32, 32), (64, 64), (128, 128)], 1, 3000),
+])
+def test_msda_forward_vs_oracle(dev, shapes, B, Nq):
+    value, ss, st, loc, aw = _msda_inputs(B, shapes, 8, 32, 4, Nq, seed=1)
+    want = ref.msda_core(value, ss, loc, aw)
+    got = ops.msda_forward(value.to(dev), ss.to(dev), st.to(dev), loc.to(dev), aw.to(dev)).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-4
+    got2 = ops.msda_forward_hostlevels(value.to(dev), shapes, _levels(shapes)[0], loc.to(dev),
+                                       aw.to(dev)).cpu()
+    assert torch.equal(got, got2)
+
+
+def test_msda_forward_loops_oracle_small(dev):
+    shapes = [(3, 5), (6, 10)]
+    value, ss, st, loc, aw = _msda_inputs(1, shapes, 2, 8, 3, 40, seed=2, spread=2.0)
+    want = ref.msda_core_loops(value, ss, loc, aw).float()
+    want2 = ref.msda_core(value, ss, loc, aw)
+    assert (want - want2).abs().max().item() <= 1e-5  # the two oracle statements agree
+    got = ops.msda_forward(value.to(dev), ss.to(dev), st.to(dev), loc.to(dev), aw.to(dev)).cpu()
+    assert (got - want).abs().max().item() <= 1e-5
+
+
+def test_msda_known_answer_one_hot(dev):
+    """offsets 0 + one-hot weight on (level l, point 0) == bilinear sample at the reference
+    point; at pixel centres that is the value itself."""
+    shapes = [(4, 4), (8, 8)]
+    starts, Nv = _levels(shapes)
+    g = torch.Generator().manual_seed(3)
+    value = torch.randn(1, Nv, 8, 32, generator=g)
+    h, w = shapes[1]
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    refp = torch.stack([(xs.flatten() + 0.5) / w, (ys.flatten() + 0.5) / h], -1)  # (64,2)
+    Nq = h * w
+    loc = refp[None, :, None, None, None, :].expand(1, Nq, 8, 2, 4, 2).contiguous()
+    aw = torch.zeros(1, Nq, 8, 2, 4)
+    aw[..., 1, 0] = 1.0
+    got = ops.msda_forward(value.to(dev), torch.tensor(shapes).to(dev), torch.tensor(starts).to(dev),
+                           loc.to(dev), aw.to(dev)).cpu()
+    want = value[:, starts[1]:starts[1] + Nq].reshape(1, Nq, 256)
+    assert (got - want).abs().max().item() <= 1e-6
+
+
+def test_msda_bf16_value(dev):
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    value, ss, st, loc, aw = _msda_inputs(2, shapes, 8, 32, 4, 1344, seed=4)
+    vb = value.bfloat16()
+    want = ref.msda_core(vb.float(), ss, loc, aw)
+    got = ops.msda_forward(vb.to(dev), ss.to(dev), st.to(dev), loc.to(dev), aw.to(dev)).cpu()
+    assert (got - want).abs().max().item() <= 1e-4  # same bf16-rounded values, f32 arithmetic
+
+
+def test_msda_fused_prologue(dev):
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    starts, Nv = _levels(shapes)
+    B, H, D, L, P = 2, 8, 32, 3, 4
+    Nq = Nv
+    g = torch.Generator().manual_seed(5)
+    value = torch.randn(B, Nv, H, D, generator=g)
+    raw = torch.randn(B, Nq, H * L * P * 3, generator=g)
+    raw[..., :H * L * P * 2] *= 2.0
+    refp = torch.rand(Nq, 2, generator=g)
+    off = raw[..., :H * L * P * 2].view(B, Nq, H, L, P, 2)
+    logit = raw[..., H * L * P * 2:].view(B, Nq, H, L * P)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = refp[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+    aw = logit.softmax(-1).view(B, Nq, H, L, P)
+    want = ref.msda_core(value, torch.tensor(shapes), loc, aw)
+    got = ops.msda_forward_fused(value.to(dev), shapes, starts, raw.to(dev), refp.to(dev), P).cpu()
+    assert (got - want).abs().max().item() <= 1e-4
+
+
+def test_msda_backward_vs_autograd(dev):
+    shapes = [(6, 6), (12, 12)]
+    value, ss, st, loc, aw = _msda_inputs(2, shapes, 4, 16, 4, 90, seed=6)
+    v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, aw))
+    out = ref.msda_core(v64, ss, l64, a64)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(7))
+    out.backward(go.double())
+    gv, gl, ga = ops.msda_backward(value.to(dev), ss.to(dev), st.to(dev), loc.to(dev), aw.to(dev),
+                                   go.to(dev))
+    assert (gv.cpu() - v64.grad.float()).abs().max().item() <= 1e-4
+    assert (ga.cpu() - a64.grad.float()).abs().max().item() <= 1e-4
+    # d/d(loc) is discontinuous at integer pixel coordinates; random inputs stay clear of them
+    assert (gl.cpu() - l64.grad.float()).abs().max().item() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,Q,H,W', [(2, 100, 32, 32), (1, 100, 20, 28), (2, 37, 16, 24), (1, 128, 64, 64)])
+def test_mask_logits_split_within_1e3(dev, B, Q, H, W):
+    g = torch.Generator().manual_seed(10)
+    embed = torch.randn(B, Q, 256, generator=g)
+    feat = torch.randn(B, 256, H, W, generator=g)
+    want = ref.mask_logits(embed.double(), feat.double())
+    packed = ops.pack_mask_feature(feat.to(dev), pool=1, split=True)
+    got, _ = ops.mask_logits(embed.to(dev), packed, want_logits=True)
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err <= 1e-3, err  # north_star: mask logits within 1e-3 (values are O(16) here)
+
+
+def test_mask_logits_bf16_mode(dev):
+    g = torch.Generator().manual_seed(11)
+    B, Q, H, W = 2, 100, 32, 48
+    embed = torch.randn(B, Q, 256, generator=g)
+    feat = torch.randn(B, 256, H, W, generator=g)
+    packed = ops.pack_mask_feature(feat.to(dev), pool=1, split=False)
+    got, _ = ops.mask_logits(embed.to(dev), packed, want_logits=True)
+    # exact oracle of the bf16 path: bf16-rounded operands, exact products, f32-class accumulation
+    want = ref.mask_logits(embed.bfloat16().double(), feat.bfloat16().double())
+    assert (got.cpu().double() - want).abs().max().item() <= 2e-4
+    # and against the unrounded reference: 2^-8 relative per operand
+    full = ref.mask_logits(embed.double(), feat.double())
+    bound = torch.einsum('bqc,bchw->bqhw', embed.abs().double(), feat.abs().double()) * 2 ** -7
+    assert ((got.cpu().double() - full).abs() <= bound).all()
+
+
+def test_mask_logits_transpose_detecting(dev):
+    """A = 'identity-like' embed with an ASYMMETRIC feature: catches row/col swaps of the MFMA C layout."""
+    B, Q, H, W = 1, 100, 8, 16
+    embed = torch.zeros(B, Q, 256)
+    for q in range(Q):
+        embed[0, q, q] = 1.0
+    feat = torch.arange(256 * H * W, dtype=torch.float32).view(1, 256, H, W) % 251
+    packed = ops.pack_mask_feature(feat.to(dev), pool=1, split=True)
+    got, _ = ops.mask_logits(embed.to(dev), packed)
+    assert torch.equal(got.cpu(), feat[:, :Q])
+
+
+@pytest.mark.parametrize('pool', [2, 4, 8])
+def test_attn_mask_bits_vs_reference_rule(dev, pool):
+    """bits from the pooled-feature GEMM == (sigmoid(interpolate(mask_pred)) < 0.5) of the reference,
+    except where the oracle's own resized logit is within 1e-4 of 0 (numerical ties)."""
+    g = torch.Generator().manual_seed(12)
+    B, Q, H, W = 2, 100, 64, 96
+    embed = torch.randn(B, Q, 256, generator=g)
+    feat = torch.randn(B, 256, H, W, generator=g)
+    size = (H // pool, W // pool)
+    mp = ref.mask_logits(embed, feat)
+    want = ref.attn_mask_from_logits(mp, size)
+    margin = ref.attn_mask_logits(mp, size).abs() > 1e-4
+    packed = ops.pack_mask_feature(feat.to(dev), pool=pool, split=True)
+    _, bits = ops.mask_logits(embed.to(dev), packed, want_logits=False, want_bits=True)
+    got = ops.unpack_bits(bits, size[0] * size[1]).cpu()
+    assert got.shape == want.shape
+    assert torch.equal(got[margin], want[margin])
+    assert margin.float().mean().item() > 0.999
+    # generic path (stored logits -> resize -> bits) gives the same answer
+    full, _ = ops.mask_logits(embed.to(dev), ops.pack_mask_feature(feat.to(dev), 1, True))
+    bits2 = ops.attn_mask_from_logits(full, size)
+    got2 = ops.unpack_bits(bits2, size[0] * size[1]).cpu()
+    assert torch.equal(got2[margin], want[margin])
+
+
+def test_fix_full_rows(dev):
+    g = torch.Generator().manual_seed(13)
+    npix = 20 * 28  # not a multiple of 32
+    mask = torch.rand(3, 50, npix, generator=g) < 0.5
+    mask[0, 3] = True
+    mask[2, 49] = True
+    mask[1, 7] = False
+    words = (npix + 31) // 32
+    padded = torch.zeros(3, 50, words * 32, dtype=torch.bool)
+    padded[..., :npix] = mask
+    w = (padded.view(3, 50, words, 32).long() << torch.arange(32)).sum(-1)
+    bits = w.to(torch.int64).where(w < 2 ** 31, w - 2 ** 32).to(torch.int32)
+    out = ops.attn_mask_fix_full_rows(bits.to(dev), npix)
+    got = ops.unpack_bits(out, npix).cpu()
+    want = ref.fix_full_rows(mask.clone())
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,Q,S', [(2, 100, 1024), (1, 100, 1050), (2, 37, 200), (1, 128, 4096)])
+def test_masked_xattn_vs_oracle(dev, B, Q, S):
+    g = torch.Generator().manual_seed(20)
+    E, H = 256, 8
+    q = torch.randn(B, Q, E, generator=g)
+    k = torch.randn(B, S, E, generator=g)
+    v = torch.randn(B, S, E, generator=g)
+    mask = torch.rand(B, Q, S, generator=g) < 0.6
+    mask[0, 1] = False                      # un-masked row
+    mask[0, 2] = True
+    mask[0, 2, S - 1] = False               # single visible key (the last one)
+    want = ref.masked_attention_core(q, k, v, mask, H)
+    words = (S + 31) // 32
+    padded = torch.zeros(B, Q, words * 32, dtype=torch.bool)
+    padded[..., :S] = mask
+    w = (padded.view(B, Q, words, 32).long() << torch.arange(32)).sum(-1)
+    bits = w.where(w < 2 ** 31, w - 2 ** 32).to(torch.int32)
+    kv = torch.cat([k, v], -1).contiguous()
+    got = ops.masked_xattn(q.to(dev), kv.to(dev), bits.to(dev), H).cpu()
+    assert (got - want).abs().max().item() <= 1e-4
+    got_nomask = ops.masked_xattn(q.to(dev), kv.to(dev), None, H).cpu()
+    want_nomask = ref.masked_attention_core(q, k, v, None, H)
+    assert (got_nomask - want_nomask).abs().max().item() <= 1e-4
+
+
+def test_masked_xattn_spiked_key(dev):
+    """forces the online-softmax rescale branch: one key dominates late in the stream."""
+    g = torch.Generator().manual_seed(21)
+    B, Q, S, E, H = 1, 64, 2048, 256, 8
+    q = torch.randn(B, Q, E, generator=g)
+    k = torch.randn(B, S, E, generator=g)
+    v = torch.randn(B, S, E, generator=g)
+    k[0, 1777] = q[0, 5] * 4.0
+    want = ref.masked_attention_core(q.double(), k.double(), v.double(), None, H).float()
+    got = ops.masked_xattn(q.to(dev), torch.cat([k, v], -1).to(dev), None, H).cpu()
+    assert (got - want).abs().max().item() <= 1e-4
+
+
+def test_masked_xattn_full_row_is_nan_like_reference(dev):
+    B, Q, S, E, H = 1, 4, 64, 256, 8
+    g = torch.Generator().manual_seed(22)
+    q, k, v = (torch.randn(B, n, E, generator=g) for n in (Q, S, S))
+    bits = torch.zeros(B, Q, 2, dtype=torch.int32)
+    bits[0, 1] = -1  # all 64 keys blocked
+    got = ops.masked_xattn(q.to(dev), torch.cat([k, v], -1).to(dev), bits.to(dev), H).cpu()
+    assert torch.isnan(got[0, 1]).all() and not torch.isnan(got[0, 0]).any()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_upsample_bilinear(dev):
+    g = torch.Generator().manual_seed(30)
+    x = torch.randn(3, 5, 20, 28, generator=g)
+    for size in [(80, 112), (50, 97), (20, 28), (13, 9)]:
+        want = torch.nn.functional.interpolate(x, size, mode='bilinear', align_corners=False)
+        got = ops.upsample_bilinear(x.to(dev), size).cpu()
+        assert (got - want).abs().max().item() <= 1e-5
+
+
+def test_rowwise_softmax_argmax(dev):
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(100, 66, generator=g) * 5
+    x[3, 10] = x[3, 40] = 30.0  # tie: first index wins (torch.max semantics)
+    prob, maxv, arg = ops.rowwise_softmax_argmax(x.to(dev))
+    want = x.softmax(-1)
+    wmax, warg = want.max(-1)
+    assert (prob.cpu() - want).abs().max().item() <= 1e-6
+    assert torch.equal(arg.cpu(), warg)
+    assert (maxv.cpu() - wmax).abs().max().item() <= 1e-6
