@@ -7,6 +7,12 @@ Product code only: HIP kernels (csrc/ -> lib/libcgg_hip.so, C ABI in include/cgg
 wrappers (ops.py) and the host-side mirror of the reference's register_module() interface.
 The CPU oracle lives in /oracle and is never imported from here.
 """
-from . import _lib, ops  # noqa: F401
+from . import _lib, ops, runtime  # noqa: F401
+from . import registry, config  # noqa: F401
+from . import (pixel_decoder, query_decoder, losses, assigner, bert_embeddings,  # noqa: F401
+               caption_transformer, mask2former_head, maskformer_fusion_head, backbones, detectors)
+from .config import Config  # noqa: F401
+from .registry import (BACKBONES, BBOX_ASSIGNERS, DETECTORS, HEADS, LOSSES, build_detector,  # noqa: F401
+                       build_head, build_loss)
 
 __version__ = '0.1.0'

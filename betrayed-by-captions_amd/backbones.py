@@ -1,0 +1,151 @@
+"""Backbone named by the reference configs: `type='ResNet', depth=50, out_indices=(0,1,2,3),
+frozen_stages, norm_cfg=BN(requires_grad=False), norm_eval=True, style='pytorch'`
+(configs/instance/coco_b48n17.py:17-26) -- [3P] mmdet ResNet restated in plain torch with the upstream
+parameter names (`conv1`, `bn1`, `layer{1-4}.N.{conv,bn}{1-3}`, `downsample.{0,1}`), so torchvision /
+mmdet ResNet checkpoints load unchanged. Convolutions run on MIOpen (bf16 autocast in throughput mode);
+the backbone is outside the hand-written-kernel scope of the hot path.
+"""
+import torch
+import torch.nn as nn
+
+from . import runtime
+from .registry import BACKBONES
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style='pytorch'):
+        super().__init__()
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style='pytorch'):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)),
+                     50: (Bottleneck, (3, 4, 6, 3)), 101: (Bottleneck, (3, 4, 23, 3)),
+                     152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch',
+                 deep_stem=False, avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True, pretrained=None, init_cfg=None):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        if deep_stem or avg_down or dcn is not None or plugins is not None or any(d != 1 for d in dilations):
+            raise NotImplementedError('only the plain ResNet variants used by the CGG configs')
+        block, stage_blocks = self.arch_settings[depth]
+        self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
+        self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+        self.init_cfg = init_cfg
+        stem = stem_channels or base_channels
+        self.conv1 = nn.Conv2d(in_channels, stem, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        inplanes = stem
+        self.res_layers = []
+        for i in range(num_stages):
+            planes = base_channels * 2**i
+            layers = []
+            for j in range(stage_blocks[i]):
+                stride = strides[i] if j == 0 else 1
+                down = None
+                if j == 0 and (stride != 1 or inplanes != planes * block.expansion):
+                    down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                                         nn.BatchNorm2d(planes * block.expansion))
+                layers.append(block(inplanes, planes, stride, down, style))
+                inplanes = planes * block.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+        if not norm_cfg.get('requires_grad', True):
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    for p in m.parameters():
+                        p.requires_grad = False
+        self._freeze_stages()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                nn.init.constant_(m.bn3.weight, 0)
+            elif isinstance(m, BasicBlock):
+                nn.init.constant_(m.bn2.weight, 0)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+    def forward(self, x):
+        outs = []
+        with runtime.autocast():
+            if runtime.is_bf16():
+                x = x.contiguous(memory_format=torch.channels_last)
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            for i, name in enumerate(self.res_layers):
+                x = getattr(self, name)(x)
+                if i in self.out_indices:
+                    outs.append(x)
+        return tuple(o.float().contiguous() for o in outs)

@@ -1,0 +1,186 @@
+"""Caption generation head: `type='CaptionTransformer'`
+(open_set/models/transformers/caption_tranformer.py:17-44 + transformers.py:9-267).
+
+A 4-layer post-norm transformer decoder over the query embeddings with a 768 -> 30522 generator.
+Parameter / buffer names reproduce the reference module tree:
+  position_encoder.psne_layer, transformer_decoder.decoders.N.{mha_layer.{qkv_layer,out_layer},
+  crx_layer.{to_qry,to_key,to_val,to_out}, ffn_layer.linears.{0,1}.0, layer_normalz.{mha,crx,ffn}.1},
+  generator  -- note `qkv_layer` packs per-head interleaved [q_h | k_h | v_h] (transformers.py:114-117).
+The arithmetic is a compact functional forward over those parameters (one fused attention helper for
+self and cross attention); GEMMs go through hipBLASLt (bf16 autocast in throughput mode).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import runtime
+from .registry import HEADS
+
+
+def sine_table(seq_length, dim):
+    """PositionalEncoding table of transformers.py:12-20: sin on even, cos on odd, 10000^((j - j%2)/dim)."""
+    pos = torch.arange(seq_length, dtype=torch.float64)[:, None]
+    j = torch.arange(dim, dtype=torch.float64)[None, :]
+    even = (j % 2 == 0)
+    ang = pos / (10000.0 ** ((j - j % 2) / dim))
+    return torch.where(even, ang.sin(), ang.cos()).float()
+
+
+class PositionalEncoding(nn.Module):
+
+    def __init__(self, seq_length, in_dim, drop_val=0.1):
+        super().__init__()
+        self.drop_layer = nn.Dropout(drop_val)
+        self.register_buffer('psne_layer', sine_table(seq_length, in_dim))
+
+    def forward(self, src):
+        return self.drop_layer(src + self.psne_layer[:src.shape[1]][None])
+
+
+def _attend(q, k, v, nb_heads, mask=None, key_padding_mask=None):
+    """q (B,Lq,H,d) k,v (B,Lk,H,d); mask (Lq,Lk) bool True=blocked; key_padding_mask (B,Lk) bool."""
+    d = q.shape[-1]
+    w = torch.einsum('bqhd,bkhd->bhqk', q, k) / math.sqrt(d)
+    if mask is not None:
+        w = w.masked_fill(mask, float('-inf'))
+    if key_padding_mask is not None:
+        w = w.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
+    w = torch.softmax(w.float(), dim=-1).to(v.dtype)
+    return torch.einsum('bhqk,bkhd->bqhd', w, v).flatten(2)
+
+
+class MultiHeadSelfAttention(nn.Module):
+
+    def __init__(self, in_dim, nb_heads):
+        super().__init__()
+        self.nbr_heads, self.heads_dim = nb_heads, in_dim // nb_heads
+        self.qkv_layer = nn.Linear(in_dim, 3 * in_dim)
+        self.out_layer = nn.Linear(in_dim, in_dim)
+
+    def forward(self, src, mask=None, key_padding_mask=None):
+        B, L, _ = src.shape
+        qkv = self.qkv_layer(src).view(B, L, self.nbr_heads, 3, self.heads_dim)
+        out = _attend(qkv[..., 0, :], qkv[..., 1, :], qkv[..., 2, :], self.nbr_heads, mask, key_padding_mask)
+        return self.out_layer(out)
+
+
+class MultiHeadCrossAttention(nn.Module):
+
+    def __init__(self, in_dim, nb_heads):
+        super().__init__()
+        self.nbr_heads, self.heads_dim = nb_heads, in_dim // nb_heads
+        self.to_qry = nn.Linear(in_dim, in_dim)
+        self.to_key = nn.Linear(in_dim, in_dim)
+        self.to_val = nn.Linear(in_dim, in_dim)
+        self.to_out = nn.Linear(in_dim, in_dim)
+
+    def forward(self, qry, key, val, mask=None, key_padding_mask=None):
+        B, Lq, _ = qry.shape
+        Lk = key.shape[1]
+        H, d = self.nbr_heads, self.heads_dim
+        out = _attend(self.to_qry(qry).view(B, Lq, H, d), self.to_key(key).view(B, Lk, H, d),
+                      self.to_val(val).view(B, Lk, H, d), H, mask, key_padding_mask)
+        return self.to_out(out)
+
+
+_ACTS = {0: nn.Identity, 1: nn.ReLU, 2: nn.GELU, 3: nn.Sigmoid, 4: nn.Tanh}
+
+
+class FeedForwardNetwork(nn.Module):
+    """linears[i] = Sequential(Linear, Dropout|Identity, activation) -- dropout BEFORE the activation
+    (transformers.py:43-47)."""
+
+    def __init__(self, layer_cfg, activations, drop_vals):
+        super().__init__()
+        self.linears = nn.ModuleList()
+        for i, (a, b) in enumerate(zip(layer_cfg[:-1], layer_cfg[1:])):
+            act = nn.Softmax(dim=-1) if activations[i] == 5 else _ACTS.get(activations[i], nn.Identity)()
+            self.linears.append(nn.Sequential(
+                nn.Linear(a, b), nn.Dropout(drop_vals[i]) if drop_vals[i] > 0.0 else nn.Identity(), act))
+
+    def forward(self, x):
+        for blk in self.linears:
+            x = blk(x)
+        return x
+
+
+def _norm_pair(in_dim, pre_norm):
+    return nn.ModuleList([nn.LayerNorm(in_dim) if pre_norm else nn.Identity(),
+                          nn.LayerNorm(in_dim) if not pre_norm else nn.Identity()])
+
+
+class DecoderBlock(nn.Module):
+
+    def __init__(self, in_dim, ff_dim, nb_heads, drop_val=0.1, pre_norm=False):
+        super().__init__()
+        assert in_dim % nb_heads == 0
+        self.mha_layer = MultiHeadSelfAttention(in_dim, nb_heads)
+        self.crx_layer = MultiHeadCrossAttention(in_dim, nb_heads)
+        self.ffn_layer = FeedForwardNetwork([in_dim, ff_dim, in_dim], [1, 0], [drop_val, 0.0])
+        self.dropout_layer = nn.ModuleDict({k: nn.Dropout(drop_val) for k in ('mha', 'crx', 'ffn')})
+        self.layer_normalz = nn.ModuleDict({k: _norm_pair(in_dim, pre_norm) for k in ('mha', 'crx', 'ffn')})
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        n, dr = self.layer_normalz, self.dropout_layer
+        x = n['mha'][0](tgt)
+        x = n['mha'][1](x + dr['mha'](self.mha_layer(x, tgt_mask, tgt_key_padding_mask)))
+        y = n['crx'][0](x)
+        y = n['crx'][1](y + dr['crx'](self.crx_layer(y, memory, memory, memory_mask, memory_key_padding_mask)))
+        z = n['ffn'][0](y)
+        # the FFN reads the un-normalised residual stream `y` (transformers.py:228-229); identical to
+        # `z` in post-norm mode, which is the only mode the configs use
+        return n['ffn'][1](z + dr['ffn'](self.ffn_layer(y)))
+
+
+class TransformerDecoder(nn.Module):
+
+    def __init__(self, nb_layers, in_dim, ff_dim, nb_heads, drop_val=0.1, pre_norm=False):
+        super().__init__()
+        self.decoders = nn.ModuleList(
+            [DecoderBlock(in_dim, ff_dim, nb_heads, drop_val, pre_norm) for _ in range(nb_layers)])
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        outs = []
+        for blk in self.decoders:
+            tgt = blk(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask)
+            outs.append(tgt)
+        return outs
+
+
+def build_mask(seq):
+    L = seq.shape[1]
+    return torch.ones(L, L, dtype=torch.bool).triu(1)
+
+
+def build_key_padding_mask(seq, pad_idx):
+    return seq == pad_idx
+
+
+@HEADS.register_module()
+class CaptionTransformer(nn.Module):
+    """forward(tgt (B,L,in), memory (B,Q,in), ...) -> (list of per-layer outputs, last-layer logits (B,L,V))."""
+
+    def __init__(self, nb_layers, input_dim, hidden_dim, ff_dim, nb_heads, drop_val, pre_norm, seq_length,
+                 nb_tokens):
+        super().__init__()
+        self.adapter = nn.Linear(input_dim, hidden_dim) if input_dim != hidden_dim else nn.Identity()
+        self.position_encoder = PositionalEncoding(seq_length, hidden_dim)
+        self.transformer_decoder = TransformerDecoder(nb_layers=nb_layers, in_dim=hidden_dim, ff_dim=ff_dim,
+                                                      nb_heads=nb_heads, drop_val=drop_val, pre_norm=pre_norm)
+        self.generator = nn.Linear(hidden_dim, nb_tokens)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        with runtime.autocast():
+            memory = self.adapter(memory)
+            tgt = self.position_encoder(tgt)
+            if tgt_mask is None:
+                tgt_mask = build_mask(tgt).to(tgt.device)
+            output = self.transformer_decoder(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
+                                              memory_key_padding_mask)
+            logits = self.generator(output[-1])
+        return output, logits.float()

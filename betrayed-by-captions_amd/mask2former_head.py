@@ -1,0 +1,701 @@
+"""`Mask2FormerHeadOpen` -- the reference's head (open_set/models/mask2former_head.py:33-980) on the
+MI355X kernels. Constructor signature, config keys, `state_dict` layout, method names and returned
+structures follow the reference; the execution is re-designed:
+
+  forward():  batch-first activations; mask_feature packed once per forward into the MFMA-operand
+              image (+ three 2x2-pooled images); every decoder layer's attention mask comes from a
+              GEMM over the POOLED image (interpolation is linear -> interp(E.F) == E.interp(F)),
+              bit-packed and shared by the 8 heads; full-resolution mask logits are produced only
+              for the outputs that are consumed (all 10 in training, the last one at test time);
+              K/V projections are single GEMMs with a position-bias matrix.
+  loss():     one batched device->host copy for all (layer x image) Hungarian problems, layer-invariant
+              all_gathers hoisted, the 10 `reduce_mean` scalars folded into one all-reduce.
+
+Line references in the method docstrings point at the reference implementation being restated.
+"""
+import copy
+import json
+import warnings
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, runtime
+from .assigner import get_uncertain_point_coords_with_randomness, point_sample
+from .bert_embeddings import BertEmbeddings
+from .config import ConfigDict, to_config_dict
+from .registry import (HEADS, build_assigner, build_head, build_loss, build_plugin_layer,
+                       build_positional_encoding, build_sampler, build_transformer_layer_sequence)
+
+BOS_TOKEN = 101
+EOS_TOKEN = 102
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _read_lines(path):
+    with open(path, 'r', encoding='utf-8') as f:
+        return f.read().split('\n')
+
+
+class LowResMasks:
+    """Mask logits kept at mask-feature resolution plus the size the reference would upsample them to
+    (mask2former_head.py:957-964). `upsampled()` materialises the reference tensor (HIP bilinear)."""
+
+    def __init__(self, logits, up_size):
+        self.logits = logits
+        self.up_size = (int(up_size[0]), int(up_size[1]))
+
+    def upsampled(self):
+        return ops.upsample_bilinear(self.logits.contiguous(), self.up_size)
+
+    def __len__(self):
+        return self.logits.shape[0]
+
+    def __getitem__(self, i):
+        return LowResMasks(self.logits[i], self.up_size)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class _MaskLogitsFn(torch.autograd.Function):
+    """einsum('bqc,bchw->bqhw') with the HIP MFMA forward; backward = the two transposed contractions
+    (library GEMMs on the device; round 1)."""
+
+    @staticmethod
+    def forward(ctx, embed, feat, packed):
+        ctx.save_for_backward(embed, feat)
+        out, _ = ops.mask_logits(embed.contiguous(), packed, want_logits=True)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        embed, feat = ctx.saved_tensors
+        g_e = torch.einsum('bqhw,bchw->bqc', go, feat)
+        g_f = torch.einsum('bqc,bqhw->bchw', embed, go)
+        return g_e, g_f, None
+
+
+@HEADS.register_module()
+class Mask2FormerHeadOpen(nn.Module):
+
+    def __init__(self, in_channels, feat_channels, out_channels, num_things_classes=80,
+                 num_stuff_classes=53, num_queries=100, num_transformer_feat_level=3, pixel_decoder=None,
+                 enforce_decoder_input_project=False, transformer_decoder=None, positional_encoding=None,
+                 v2l_head=None, caption_generator=None, loss_cls=None, loss_cls_emb=None,
+                 loss_grounding=None, loss_caption_generation=None, loss_caption_align=None,
+                 loss_mask=None, loss_dice=None, train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__()
+        pixel_decoder = to_config_dict(pixel_decoder)
+        transformer_decoder = to_config_dict(transformer_decoder)
+        self.num_things_classes = num_things_classes
+        self.num_stuff_classes = num_stuff_classes
+        self.num_classes = num_things_classes + num_stuff_classes
+        self.num_queries = num_queries
+        self.num_transformer_feat_level = num_transformer_feat_level
+        self.num_heads = transformer_decoder.transformerlayers.attn_cfgs.num_heads
+        self.num_transformer_decoder_layers = transformer_decoder.num_layers
+        assert pixel_decoder.encoder.transformerlayers.attn_cfgs.num_levels == num_transformer_feat_level
+        pixel_decoder_ = copy.deepcopy(pixel_decoder)
+        pixel_decoder_.update(in_channels=in_channels, feat_channels=feat_channels, out_channels=out_channels)
+        self.pixel_decoder = build_plugin_layer(pixel_decoder_)[1]
+        self.transformer_decoder = build_transformer_layer_sequence(transformer_decoder)
+        self.decoder_embed_dims = self.transformer_decoder.embed_dims
+        self.decoder_input_projs = nn.ModuleList()
+        for _ in range(num_transformer_feat_level):
+            if self.decoder_embed_dims != feat_channels or enforce_decoder_input_project:
+                self.decoder_input_projs.append(nn.Conv2d(feat_channels, self.decoder_embed_dims, kernel_size=1))
+            else:
+                self.decoder_input_projs.append(nn.Identity())
+        self.decoder_positional_encoding = build_positional_encoding(positional_encoding)
+        self.query_embed = nn.Embedding(self.num_queries, feat_channels)
+        self.query_feat = nn.Embedding(self.num_queries, feat_channels)
+        self.level_embed = nn.Embedding(self.num_transformer_feat_level, feat_channels)
+        self.cls_embed = nn.Linear(feat_channels, self.num_classes + 1)
+        self.mask_embed = nn.Sequential(
+            nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+            nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+            nn.Linear(feat_channels, out_channels))
+        self.feat_channels = feat_channels
+        self.v2l_head_cfg = v2l_head
+        self.caption_generator_cfg = caption_generator
+        self.test_cfg = to_config_dict(test_cfg) if test_cfg is not None else test_cfg
+        self.train_cfg = to_config_dict(train_cfg) if train_cfg is not None else train_cfg
+        if train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            self.sampler = build_sampler(self.train_cfg.sampler, context=self)
+            self.num_points = self.train_cfg.get('num_points', 12544)
+            self.oversample_ratio = self.train_cfg.get('oversample_ratio', 3.0)
+            self.importance_sample_ratio = self.train_cfg.get('importance_sample_ratio', 0.75)
+        self.class_weight = loss_cls['class_weight']
+        self.loss_cls = build_loss(loss_cls)
+        if loss_cls_emb is not None:
+            self.loss_cls_emb = build_loss(loss_cls_emb)
+        if loss_grounding is not None:
+            self.loss_grounding = build_loss(loss_grounding)
+        if loss_caption_generation is not None:
+            self.loss_caption_generation = build_loss(loss_caption_generation)
+        if loss_caption_align is not None:
+            self.loss_caption_align = build_loss(loss_caption_align)
+        self.loss_mask = build_loss(loss_mask)
+        self.loss_dice = build_loss(loss_dice)
+        self.point_hook = None  # callable(kind, shape, device) -> coords; pins the random draws in tests
+        self.init_kwargs(**kwargs)
+
+    # ------------------------------------------------------------------------------------------
+    def init_kwargs(self, **kwargs):
+        """mask2former_head.py:175-229."""
+        self.kwargs = kwargs
+        g = kwargs.get
+        self.class_agnostic = g('class_agnostic', False)
+        self.use_class_emb = g('use_class_emb', False)
+        self.use_caption = g('use_caption', False)
+        self.use_caption_generation = g('use_caption_generation', False)
+        self.use_caption_align = g('use_caption_align', False)
+        self.known_file = g('known_file', None)
+        self.unknown_file = g('unknown_file', None)
+        self.softmax_temperature = g('softmax_temperature', 10.0)
+        self.learnable_temperature = g('learnable_temperature', False)
+        self.pred_emb_norm = g('pred_emb_norm', False)
+        self.text_emb_norm = g('text_emb_norm', True)
+        self.freeze_pretrained = g('freeze_pretrained', False)
+        self.freeze_v2l = g('freeze_v2l', False)
+        self.loss_only_last = g('loss_only_last', False)
+        self.loss_aux_weight = g('loss_aux_weight', 1.0)
+        self.gen_only_obj_nouns = g('gen_only_obj_nouns', False)
+        self.gen_mask_obj_nouns = g('gen_mask_obj_nouns', False)
+        self.gen_replace_obj_nouns = g('gen_replace_obj_nouns', False)
+        if self.known_file is not None:
+            self.known_cat_names = _read_lines(self.known_file)
+        if self.unknown_file is not None:
+            self.unknown_cat_names = _read_lines(self.unknown_file)
+        if self.use_class_emb:
+            with open(kwargs['class_to_emb_file'], 'r') as f:
+                class_to_emb = json.load(f)
+            class_embs = torch.zeros((self.num_classes + 1, len(class_to_emb[0]['emb'])), dtype=torch.float)
+            i = 0
+            for class_dict in class_to_emb:
+                if self.known_file and class_dict['name'] not in self.known_cat_names:
+                    continue
+                if self.unknown_file and class_dict['name'] in self.unknown_cat_names:
+                    continue
+                class_embs[i, :] = torch.FloatTensor(class_dict['emb'])
+                i += 1
+            self.register_buffer('class_embs', class_embs)
+            self.v2l_transform = nn.Linear(self.feat_channels, class_embs.shape[1])
+        self.bert_embeddings = self.clip = None
+        if self.use_caption:
+            self.caption_emb_type = g('caption_emb_type', 'clip')
+            self.build_text_encoders(self.caption_emb_type)
+        if self.use_caption_generation:
+            self.caption_gen_emb_type = g('caption_gen_emb_type', 'bert')
+            self.caption_generator = build_head(self.caption_generator_cfg)
+            self.build_text_encoders(self.caption_gen_emb_type)
+        if self.learnable_temperature:
+            self.softmax_temperature = nn.Parameter(torch.tensor([self.softmax_temperature]), requires_grad=True)
+
+    def init_weights(self):
+        """mask2former_head.py:231-247."""
+        for m in self.decoder_input_projs:
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1, mode='fan_in', nonlinearity='leaky_relu')
+                nn.init.constant_(m.bias, 0)
+        self.pixel_decoder.init_weights()
+        for p in self.transformer_decoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+        if self.freeze_v2l:
+            for p in self.v2l_transform.parameters():
+                p.requires_grad = False
+        if self.freeze_pretrained:
+            self.freeze_params()
+
+    def build_text_encoders(self, emb_type):
+        """mask2former_head.py:249-260. BERT weights come from HF `bert-base-uncased` when they are
+        available locally; offline a synthetic table with the same shapes is used (benchmarks)."""
+        if emb_type == 'bert' and self.bert_embeddings is None:
+            bert = None
+            if not self.kwargs.get('synthetic_text_encoder', False):
+                try:
+                    import transformers
+                    bert = transformers.BertModel.from_pretrained('bert-base-uncased', local_files_only=True).eval()
+                except Exception as e:  # offline container / GPU box
+                    warnings.warn(f'bert-base-uncased weights unavailable ({type(e).__name__}); using a '
+                                  'synthetic embedding table of the same shape')
+            self.bert_embeddings = BertEmbeddings(bert) if bert is not None else BertEmbeddings.synthetic()
+            for p in self.bert_embeddings.parameters():
+                p.requires_grad = False
+        if emb_type == 'clip' and self.clip is None:
+            raise NotImplementedError("caption_emb_type='clip' needs the `clip` package (not shipped); "
+                                      "every reference config uses 'bert'")
+
+    def freeze_params(self):
+        self.decoder_input_projs.eval()
+        self.pixel_decoder.eval()
+        self.transformer_decoder.eval()
+        for mod in (self.decoder_input_projs, self.pixel_decoder, self.transformer_decoder):
+            for p in mod.parameters():
+                p.requires_grad = False
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward_head(self, decoder_out, mask_feature, attn_mask_target_size, packed=None, pooled=None,
+                     want_mask=True, want_attn=True):
+        """mask2former_head.py:711-761 on batch-first `decoder_out` (B,Q,C).
+        Returns (cls_pred, cls_emb_pred, mask_pred | None, attn bits (B,Q,words) int32 | None)."""
+        decoder_out = self.transformer_decoder.post_norm(decoder_out)
+        cls_pred = self.cls_embed(decoder_out)
+        cls_emb_pred = cls_pred
+        if self.use_class_emb:
+            cls_emb_pred = self.v2l_transform(decoder_out)
+            if self.pred_emb_norm:
+                cls_emb_pred = cls_emb_pred / cls_emb_pred.norm(dim=-1, keepdim=True)
+        mask_embed = self.mask_embed(decoder_out).contiguous()
+        split = not runtime.is_bf16()
+        mask_pred = None
+        if want_mask:
+            if packed is None:
+                packed = ops.pack_mask_feature(mask_feature.detach().contiguous(), 1, split)
+            if torch.is_grad_enabled() and (mask_embed.requires_grad or mask_feature.requires_grad):
+                mask_pred = _MaskLogitsFn.apply(mask_embed, mask_feature, packed)
+            else:
+                mask_pred, _ = ops.mask_logits(mask_embed, packed, want_logits=True)
+        bits = None
+        if want_attn:
+            H, W = mask_feature.shape[-2:]
+            h, w = int(attn_mask_target_size[0]), int(attn_mask_target_size[1])
+            s = H // h if h > 0 else 0
+            if h * s == H and w * s == W and s in (2, 4, 8):
+                if pooled is None:
+                    pooled = ops.pack_mask_feature(mask_feature.detach().contiguous(), s, split)
+                _, bits = ops.mask_logits(mask_embed.detach(), pooled, want_logits=False, want_bits=True)
+            else:  # generic size: resize the stored logits (still no x num_heads repeat)
+                if mask_pred is None:
+                    if packed is None:
+                        packed = ops.pack_mask_feature(mask_feature.detach().contiguous(), 1, split)
+                    full, _ = ops.mask_logits(mask_embed.detach(), packed, want_logits=True)
+                else:
+                    full = mask_pred.detach()
+                bits = ops.attn_mask_from_logits(full.contiguous(), (h, w))
+        return cls_pred, cls_emb_pred, mask_pred, bits
+
+    def _forward(self, feats, img_metas, all_masks=True):
+        B = len(img_metas)
+        mask_features, memorys = self.pixel_decoder(feats)
+        mask_features = mask_features.contiguous()
+        split = not runtime.is_bf16()
+        L = self.num_transformer_feat_level
+        H4, W4 = mask_features.shape[-2:]
+        mems, poss, sizes = [], [], []
+        for i in range(L):
+            m = self.decoder_input_projs[i](memorys[i])
+            h, w = m.shape[-2:]
+            sizes.append((int(h), int(w)))
+            mems.append((m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1)).contiguous())
+            poss.append(self.decoder_positional_encoding.flat_unpadded(int(h), int(w), m.device))
+        feat_d = mask_features.detach()
+        packed_full = ops.pack_mask_feature(feat_d, 1, split)
+        pooled = []
+        for (h, w) in sizes:
+            s = H4 // h
+            ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
+            pooled.append(ops.pack_mask_feature(feat_d, s, split) if ok else None)
+        layers = self.transformer_decoder.layers
+        # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
+        kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
+               for i in range(self.num_transformer_decoder_layers)]
+        query_feat = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
+        query_embed = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
+
+        cls_pred_list, cls_emb_pred_list, mask_pred_list = [], [], []
+        nl = self.num_transformer_decoder_layers
+        cls_pred, cls_emb_pred, mask_pred, bits = self.forward_head(
+            query_feat, mask_features, sizes[0], packed_full, pooled[0], want_mask=all_masks or nl == 0)
+        cls_pred_list.append(cls_pred)
+        cls_emb_pred_list.append(cls_emb_pred)
+        mask_pred_list.append(mask_pred)
+        for i in range(nl):
+            level_idx = i % L
+            # rows that mask every key are un-masked (mask2former_head.py:825-826)
+            ops.attn_mask_fix_full_rows(bits, sizes[level_idx][0] * sizes[level_idx][1])
+            layer = layers[i]
+            if tuple(layer.operation_order) == ('cross_attn', 'norm', 'self_attn', 'norm', 'ffn', 'norm'):
+                query_feat = layer.forward_fast(query_feat, query_embed, kvs[i], bits)
+            else:
+                raise NotImplementedError(f'operation_order {layer.operation_order} has no MI355X fast path')
+            last = i == nl - 1
+            nxt = (i + 1) % L
+            cls_pred, cls_emb_pred, mask_pred, bits = self.forward_head(
+                query_feat, mask_features, sizes[nxt], packed_full, pooled[nxt],
+                want_mask=all_masks or last, want_attn=not last)
+            cls_pred_list.append(cls_pred)
+            cls_emb_pred_list.append(cls_emb_pred)
+            mask_pred_list.append(mask_pred)
+        return cls_pred_list, cls_emb_pred_list, mask_pred_list
+
+    def forward(self, feats, img_metas):
+        """mask2former_head.py:763-849: 3 lists of (num_layers + 1) tensors:
+        cls (B,Q,K+1), emb (B,Q,d_l), mask logits (B,Q,h,w)."""
+        return self._forward(feats, img_metas, all_masks=True)
+
+    # ------------------------------------------------------------------------------------------
+    # training
+    # ------------------------------------------------------------------------------------------
+    def preprocess_gt(self, gt_labels_list, gt_masks_list, gt_semantic_segs, img_metas):
+        """[3P] MaskFormerHead.preprocess_gt -> preprocess_panoptic_gt.
+        gt_masks: tensors (n,H,W) or BitmapMasks-like objects with .pad(shape).to_tensor()."""
+        if gt_semantic_segs is None:
+            gt_semantic_segs = [None] * len(gt_labels_list)
+        labels_out, masks_out = [], []
+        for gt_labels, gt_masks, sem, meta in zip(gt_labels_list, gt_masks_list, gt_semantic_segs, img_metas):
+            pad_h, pad_w = meta['pad_shape'][:2]
+            if torch.is_tensor(gt_masks):
+                tm = gt_masks.to(device=gt_labels.device, dtype=torch.bool)
+                dh, dw = pad_h - tm.shape[-2], pad_w - tm.shape[-1]
+                if dh or dw:
+                    tm = F.pad(tm, (0, dw, 0, dh), value=False)
+            else:
+                tm = gt_masks.pad((pad_h, pad_w), pad_val=0).to_tensor(dtype=torch.bool, device=gt_labels.device)
+            if sem is None:
+                labels_out.append(gt_labels)
+                masks_out.append(tm.long())
+                continue
+            sem = sem.squeeze(0)
+            stuff_masks, stuff_labels = [], []
+            for label in torch.unique(sem, sorted=False):
+                if label < self.num_things_classes or label >= self.num_classes:
+                    continue
+                stuff_masks.append(sem == label)
+                stuff_labels.append(label)
+            if stuff_masks:
+                labels = torch.cat([gt_labels, torch.stack(stuff_labels, 0)], 0)
+                masks = torch.cat([tm, torch.stack(stuff_masks, 0)], 0)
+            else:
+                labels, masks = gt_labels, tm
+            labels_out.append(labels)
+            masks_out.append(masks.long())
+        return labels_out, masks_out
+
+    def _get_cls_emb_logits(self, cls_emb_preds):
+        """mask2former_head.py:631-648."""
+        return torch.matmul(cls_emb_preds, self.class_embs.t()) / self.softmax_temperature
+
+    def _rand(self, kind, shape, device):
+        if self.point_hook is not None:
+            return self.point_hook(kind, shape, device)
+        return torch.rand(*shape, device=device)
+
+    def _draw_points(self, device):
+        return self._rand('target', (1, self.num_points, 2), device)
+
+    def _target_inputs(self, cls_score, cls_emb_logit, mask_pred, gt_labels, gt_masks):
+        """mask2former_head.py:353-366: random points, sampled predictions and sampled GT masks."""
+        num_queries, num_gts = cls_score.shape[0], gt_labels.shape[0]
+        point_coords = self._draw_points(cls_score.device)
+        mask_points_pred = point_sample(mask_pred.unsqueeze(1), point_coords.repeat(num_queries, 1, 1)).squeeze(1)
+        gt_points_masks = point_sample(gt_masks.unsqueeze(1).float(), point_coords.repeat(num_gts, 1, 1)).squeeze(1)
+        return (cls_score, cls_emb_logit, mask_points_pred, gt_labels, gt_points_masks)
+
+    def _targets_from_assign(self, assign_result, mask_pred, gt_labels, gt_masks):
+        """mask2former_head.py:372-390."""
+        sampling_result = self.sampler.sample(assign_result, mask_pred, gt_masks)
+        pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
+        labels = gt_labels.new_full((self.num_queries, ), self.num_classes, dtype=torch.long)
+        labels[pos_inds] = gt_labels[sampling_result.pos_assigned_gt_inds]
+        label_weights = gt_labels.new_ones((self.num_queries, ))
+        mask_targets = gt_masks[sampling_result.pos_assigned_gt_inds]
+        mask_weights = mask_pred.new_zeros((self.num_queries, ))
+        mask_weights[pos_inds] = 1.0
+        return labels, label_weights, mask_targets, mask_weights, pos_inds, neg_inds
+
+    def _get_target_single(self, cls_score, cls_emb_logit, mask_pred, gt_labels, gt_masks, img_metas):
+        """mask2former_head.py:320-390 (one image, one decoder layer)."""
+        item = self._target_inputs(cls_score, cls_emb_logit, mask_pred, gt_labels, gt_masks)
+        assign_result = self.assigner.assign(*item, img_metas)
+        return self._targets_from_assign(assign_result, mask_pred, gt_labels, gt_masks)
+
+    def get_targets(self, cls_scores_list, cls_emb_logits_list, mask_preds_list, gt_labels_list,
+                    gt_masks_list, img_metas):
+        """mask2former_head.py:273-317, with ONE device->host copy for the whole image list."""
+        items = [self._target_inputs(c, e, m, gl, gm) for c, e, m, gl, gm in
+                 zip(cls_scores_list, cls_emb_logits_list, mask_preds_list, gt_labels_list, gt_masks_list)]
+        assigns = self.assigner.assign_batch(items)
+        res = [self._targets_from_assign(a, m, gl, gm)
+               for a, m, gl, gm in zip(assigns, mask_preds_list, gt_labels_list, gt_masks_list)]
+        labels_list, label_weights_list, mask_targets_list, mask_weights_list, pos_l, neg_l = map(list, zip(*res))
+        num_total_pos = sum(int(i.numel()) for i in pos_l)
+        num_total_neg = sum(int(i.numel()) for i in neg_l)
+        return labels_list, label_weights_list, mask_targets_list, mask_weights_list, num_total_pos, num_total_neg
+
+    def gather_captions_and_preds(self, gt_caption_embs_list, gt_caption_mask_list, cls_emb_preds):
+        """mask2former_head.py:650-684: all_gather of captions / masks / predictions; the local slice of
+        the predictions is re-inserted so it keeps its gradient (remote slices are constants)."""
+        batch_size = len(gt_caption_embs_list)
+        rank, world_size = get_dist_info()
+        embs = torch.stack(gt_caption_embs_list, dim=0)
+        mask = torch.stack(gt_caption_mask_list, dim=0)
+        if world_size == 1:
+            return embs, mask, cls_emb_preds
+        emb_l = [torch.zeros_like(embs) for _ in range(world_size)]
+        mask_l = [torch.zeros_like(mask) for _ in range(world_size)]
+        pred_l = [torch.zeros_like(cls_emb_preds) for _ in range(world_size)]
+        dist.all_gather(emb_l, embs.contiguous())
+        dist.all_gather(mask_l, mask.contiguous())
+        dist.all_gather(pred_l, cls_emb_preds.detach().contiguous())
+        all_preds = torch.cat(pred_l, dim=0)
+        all_preds[rank * batch_size:(rank + 1) * batch_size] = cls_emb_preds
+        return torch.cat(emb_l, dim=0), torch.cat(mask_l, dim=0), all_preds
+
+    def _gather_all_layers(self, embs_list, mask_list, all_preds):
+        """Same result per layer as `gather_captions_and_preds`, with 3 collectives per STEP."""
+        rank, world_size = get_dist_info()
+        embs = torch.stack(embs_list, dim=0)
+        mask = torch.stack(mask_list, dim=0)
+        if world_size == 1:
+            return [(embs, mask, p) for p in all_preds]
+        bs = embs.shape[0]
+        emb_l = [torch.zeros_like(embs) for _ in range(world_size)]
+        mask_l = [torch.zeros_like(mask) for _ in range(world_size)]
+        stacked = torch.stack([p.detach() for p in all_preds], dim=0).contiguous()   # (n,B,Q,d)
+        pred_l = [torch.zeros_like(stacked) for _ in range(world_size)]
+        dist.all_gather(emb_l, embs.contiguous())
+        dist.all_gather(mask_l, mask.contiguous())
+        dist.all_gather(pred_l, stacked)
+        all_embs, all_mask = torch.cat(emb_l, dim=0), torch.cat(mask_l, dim=0)
+        out = []
+        for li, p in enumerate(all_preds):
+            ap = torch.cat([pl[li] for pl in pred_l], dim=0)
+            ap[rank * bs:(rank + 1) * bs] = p
+            out.append((all_embs, all_mask, ap))
+        return out
+
+    def extract_word_embeddings(self, ids_list, mask_list, emb_type='bert'):
+        """mask2former_head.py:686-709."""
+        if emb_type != 'bert':
+            raise NotImplementedError("only emb_type='bert' (as in every reference config)")
+        embs_list = [self.bert_embeddings(ids, normalize=self.text_emb_norm) for ids in ids_list]
+        return embs_list, list(mask_list)
+
+    def loss_single(self, cls_scores, cls_emb_preds, mask_preds, gt_labels_list, gt_masks_list,
+                    gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list,
+                    gt_caption_nouns_ids_list, gt_caption_nouns_embs_list, gt_caption_nouns_mask_list,
+                    img_metas, num_total_masks=None, gathered=None, targets=None):
+        """mask2former_head.py:464-629 for one decoder layer. `num_total_masks` / `gathered` carry the
+        coalesced collectives prepared by `loss()`; when None they are computed here as the reference does."""
+        num_imgs = cls_scores.size(0)
+        cls_scores_list = [cls_scores[i] for i in range(num_imgs)]
+        if self.use_class_emb:
+            cls_emb_logits = self._get_cls_emb_logits(cls_emb_preds)
+            cls_emb_logits_list = [cls_emb_logits[i] for i in range(num_imgs)]
+        else:
+            cls_emb_logits_list = [None] * num_imgs
+        mask_preds_list = [mask_preds[i] for i in range(num_imgs)]
+        if targets is None:
+            targets = self.get_targets(cls_scores_list, cls_emb_logits_list, mask_preds_list,
+                                       gt_labels_list, gt_masks_list, img_metas)
+        labels_list, label_weights_list, mask_targets_list, mask_weights_list, num_total_pos, _ = targets
+        labels = torch.stack(labels_list, dim=0).flatten(0, 1)
+        label_weights = torch.stack(label_weights_list, dim=0).flatten(0, 1)
+        mask_targets = torch.cat(mask_targets_list, dim=0)
+        mask_weights = torch.stack(mask_weights_list, dim=0)
+
+        cls_scores = cls_scores.flatten(0, 1)
+        class_weight = cls_scores.new_tensor(self.class_weight)
+        avg = class_weight[labels].sum()
+        loss_cls = self.loss_cls(cls_scores, labels, label_weights, avg_factor=avg)
+        zero = loss_cls.new_tensor(0.0)
+
+        loss_cls_emb = zero
+        if self.use_class_emb:
+            loss_cls_emb = self.loss_cls_emb(cls_emb_logits.flatten(0, 1), labels, label_weights.float(),
+                                             avg_factor=avg)
+
+        loss_grounding = zero
+        if self.use_caption:
+            if gathered is None:
+                all_embs, all_mask, all_preds = self.gather_captions_and_preds(
+                    gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, cls_emb_preds)
+            else:
+                all_embs, all_mask, all_preds = gathered
+            loss_grounding = self.loss_grounding(all_preds, all_embs, all_mask, self.softmax_temperature)
+
+        loss_caption_generation = zero
+        if self.use_caption_generation:
+            gt_caption_embs = torch.stack(gt_caption_embs_list, dim=0)
+            gt_caption_masks = torch.stack(gt_caption_mask_list, dim=0).bool()
+            caption_logits = self.caption_generator(
+                tgt=gt_caption_embs[:, :-1, :], memory=cls_emb_preds,
+                tgt_key_padding_mask=torch.logical_not(gt_caption_masks[:, :-1]))[1].flatten(0, 1)
+            ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)
+            loss_caption_generation = self.loss_caption_generation(caption_logits, ids[:, 1:].flatten(0, 1))
+
+        loss_caption_align = zero
+        if self.use_caption_align:
+            loss_caption_align = self.loss_caption_align(
+                cls_emb_preds, torch.stack(gt_caption_nouns_embs_list, dim=0),
+                torch.stack(gt_caption_nouns_mask_list, dim=0).bool())
+
+        if num_total_masks is None:
+            num_total_masks = reduce_mean(cls_scores.new_tensor([num_total_pos]))
+            num_total_masks = max(num_total_masks, 1)
+
+        mask_preds = mask_preds[mask_weights > 0]
+        if mask_targets.shape[0] == 0:
+            loss_dice = mask_preds.sum()
+            loss_mask = mask_preds.sum()
+            return (loss_cls, loss_cls_emb, loss_grounding, loss_caption_generation, loss_caption_align,
+                    loss_mask, loss_dice)
+        with torch.no_grad():
+            points_coords = get_uncertain_point_coords_with_randomness(
+                mask_preds.unsqueeze(1), None, self.num_points, self.oversample_ratio,
+                self.importance_sample_ratio, rand_fn=self._rand)
+            mask_point_targets = point_sample(mask_targets.unsqueeze(1).float(), points_coords).squeeze(1)
+        mask_point_preds = point_sample(mask_preds.unsqueeze(1), points_coords).squeeze(1)
+        loss_dice = self.loss_dice(mask_point_preds, mask_point_targets, avg_factor=num_total_masks)
+        loss_mask = self.loss_mask(mask_point_preds.reshape(-1), mask_point_targets.reshape(-1),
+                                   avg_factor=num_total_masks * self.num_points)
+        return (loss_cls, loss_cls_emb, loss_grounding, loss_caption_generation, loss_caption_align,
+                loss_mask, loss_dice)
+
+    def _caption_targets(self, gt_caption_ids_list, gt_caption_nouns_ids_list):
+        """mask2former_head.py:561-577. With the default flags the reference's B x 35 `int(tensor)` host
+        loop is a no-op and is skipped; with a gen_* flag set it is reproduced (in place, as upstream)."""
+        if self.gen_only_obj_nouns or self.gen_mask_obj_nouns or self.gen_replace_obj_nouns:
+            for i in range(len(gt_caption_ids_list)):
+                ids = gt_caption_ids_list[i]
+                nouns = gt_caption_nouns_ids_list[i].cpu().numpy().tolist()
+                for j in range(len(ids)):
+                    if int(ids[j]) not in nouns:
+                        if self.gen_only_obj_nouns:
+                            ids[j] = 0
+                    else:
+                        if self.gen_mask_obj_nouns:
+                            ids[j] = 0
+                            break
+                        if self.gen_replace_obj_nouns:
+                            ids[j] = 4874  # 'object'
+        return torch.stack(gt_caption_ids_list, dim=0)
+
+    def loss(self, all_cls_scores, all_cls_emb_preds, all_mask_preds, gt_labels_list, gt_masks_list,
+             gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list, gt_caption_nouns_ids_list,
+             gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas):
+        """mask2former_head.py:393-462: 7 losses for the last layer + `d{i}.` copies for the others."""
+        n = len(all_cls_scores)
+        num_imgs = all_cls_scores[0].size(0)
+        # (1) Hungarian targets of ALL layers and images: one device->host copy (reference: n x B syncs)
+        emb_logits = [self._get_cls_emb_logits(e) if self.use_class_emb else None for e in all_cls_emb_preds]
+        items = []
+        for li in range(n):
+            for b in range(num_imgs):
+                items.append(self._target_inputs(
+                    all_cls_scores[li][b], emb_logits[li][b] if emb_logits[li] is not None else None,
+                    all_mask_preds[li][b], gt_labels_list[b], gt_masks_list[b]))
+        assigns = self.assigner.assign_batch(items)
+        targets, pos_counts = [], []
+        for li in range(n):
+            res = [self._targets_from_assign(assigns[li * num_imgs + b], all_mask_preds[li][b],
+                                             gt_labels_list[b], gt_masks_list[b]) for b in range(num_imgs)]
+            labels_l, lw_l, mt_l, mw_l, pos_l, neg_l = map(list, zip(*res))
+            targets.append((labels_l, lw_l, mt_l, mw_l, sum(int(i.numel()) for i in pos_l),
+                            sum(int(i.numel()) for i in neg_l)))
+            pos_counts.append(float(targets[-1][4]))
+        # (2) the n `reduce_mean` scalars (mask2former_head.py:591) as ONE all-reduce
+        ntm = reduce_mean(all_cls_scores[0].new_tensor(pos_counts)).clamp(min=1).tolist()
+        # (3) caption all_gathers: nouns/mask are layer-invariant -> once; predictions of all layers in
+        #     one all_gather (reference: 3 all_gathers per layer, :671-673)
+        gathered = [None] * n
+        if self.use_caption:
+            gathered = self._gather_all_layers(gt_caption_nouns_embs_list, gt_caption_nouns_mask_list,
+                                               all_cls_emb_preds)
+        results = []
+        for i in range(n):
+            results.append(self.loss_single(
+                all_cls_scores[i], all_cls_emb_preds[i], all_mask_preds[i], gt_labels_list, gt_masks_list,
+                gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list, gt_caption_nouns_ids_list,
+                gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas,
+                num_total_masks=ntm[i], gathered=gathered[i], targets=targets[i]))
+        names = ('loss_cls', 'loss_cls_emb', 'loss_grounding', 'loss_caption_generation',
+                 'loss_caption_align', 'loss_mask', 'loss_dice')
+        loss_dict = {k: v for k, v in zip(names, results[-1])}
+        if self.loss_only_last:
+            return loss_dict
+        for li, res in enumerate(results[:-1]):
+            for k, v in zip(names, res):
+                loss_dict[f'd{li}.{k}'] = v * self.loss_aux_weight
+        return loss_dict
+
+    def forward_train(self, feats, img_metas, gt_bboxes, gt_labels, gt_masks, gt_semantic_seg,
+                      gt_caption_ids, gt_caption_mask, gt_caption_nouns_ids, gt_caption_nouns_mask,
+                      gt_bboxes_ignore=None, **kwargs):
+        """mask2former_head.py:851-921."""
+        assert gt_bboxes_ignore is None
+        all_cls_scores, all_cls_emb_preds, all_mask_preds = self(feats, img_metas)
+        gt_labels, gt_masks = self.preprocess_gt(gt_labels, gt_masks, gt_semantic_seg, img_metas)
+        gt_caption_embs = gt_caption_nouns_embs = None
+        if self.use_caption_generation:
+            gt_caption_embs, gt_caption_mask = self.extract_word_embeddings(
+                gt_caption_ids, gt_caption_mask, self.caption_gen_emb_type)
+        if self.use_caption:
+            gt_caption_nouns_embs, gt_caption_nouns_mask = self.extract_word_embeddings(
+                gt_caption_nouns_ids, gt_caption_nouns_mask, self.caption_emb_type)
+        return self.loss(all_cls_scores, all_cls_emb_preds, all_mask_preds, gt_labels, gt_masks,
+                         gt_caption_ids, gt_caption_embs, gt_caption_mask, gt_caption_nouns_ids,
+                         gt_caption_nouns_embs, gt_caption_nouns_mask, img_metas)
+
+    # ------------------------------------------------------------------------------------------
+    # inference
+    # ------------------------------------------------------------------------------------------
+    def simple_test(self, feats, img_metas, **kwargs):
+        """mask2former_head.py:923-980. Returns (assigned_labels | cls logits, emb (B,Q,d_l),
+        LowResMasks, caption results, att). The mask logits stay at mask-feature resolution together
+        with the upsample target (`batch_input_shape`); the fusion head's HIP kernels resize on the fly,
+        `.upsampled()` gives the reference's (B,Q,H,W) tensor."""
+        all_cls_scores, all_cls_emb_preds, all_mask_preds = self._forward(feats, img_metas, all_masks=False)
+        mask_cls_results = all_cls_scores[-1]
+        mask_cls_emb_results = all_cls_emb_preds[-1]
+        mask_pred_results = all_mask_preds[-1]
+        assigned_labels = mask_cls_results
+        if kwargs.get('gt_labels', None) is not None:
+            cls_emb_logits = self._get_cls_emb_logits(mask_cls_emb_results)
+            gm = kwargs['gt_masks'][0][0]
+            pad = img_metas[0]['pad_shape'][:2]
+            if not torch.is_tensor(gm):
+                gm = gm.pad(pad, pad_val=0).to_tensor(dtype=torch.long, device=cls_emb_logits.device)
+            assigned_labels = self._get_target_single(mask_cls_results[0], cls_emb_logits[0],
+                                                      mask_pred_results[0], kwargs['gt_labels'][0][0],
+                                                      gm.long(), img_metas)[0]
+        img_shape = img_metas[0]['batch_input_shape']
+        if kwargs.get('img_shape', None):
+            img_shape = kwargs['img_shape']
+        masks = LowResMasks(mask_pred_results, (img_shape[0], img_shape[1]))
+        eval_types = self.test_cfg.get('eval_types', []) if self.test_cfg else []
+        with_caption = kwargs.get('with_caption', False) or ('cap_results' in eval_types)
+        caption_generation_results = None
+        if with_caption:
+            from .caption_search import beam_search
+            caption_generation_results = beam_search(self, mask_cls_emb_results, BOS_TOKEN, EOS_TOKEN,
+                                                     max_len=35, beam_width=7,
+                                                     logging=kwargs.get('logging', False))
+        att = None
+        if kwargs.get('with_att', False):
+            nouns_embs = self.bert_embeddings(kwargs['nouns_ids']).squeeze(0)
+            att = torch.matmul(mask_cls_emb_results[0], nouns_embs.t())
+        return assigned_labels, mask_cls_emb_results, masks, caption_generation_results, att
+
+
+def reduce_mean(tensor):
+    """[3P] mmdet reduce_mean: all_reduce(x / world); identity when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return tensor

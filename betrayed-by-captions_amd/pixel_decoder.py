@@ -1,0 +1,532 @@
+"""MSDeformAttn pixel decoder (the `pixel_decoder=dict(type='MSDeformAttnPixelDecoder', ...)` of
+configs/instance/coco_b48n17.py:38-70, built at open_set/models/mask2former_head.py:112-117 and called
+at :787) and the `[3P]` building blocks its config names: `DetrTransformerEncoder`,
+`BaseTransformerLayer`, `MultiScaleDeformableAttention`, `FFN`, `SinePositionalEncoding`.
+
+Parameter names follow the upstream mmcv 1.7.1 / mmdet 2.28.2 layout so a
+reference checkpoint's `state_dict` loads unchanged. The execution is MI355X-first:
+  * activations are batch-first (B, N, C) end to end (no seq-first permutes);
+  * per encoder layer the `sampling_offsets` and `attention_weights` linears run as ONE 256->288 GEMM
+    whose raw output feeds `cgg_msda_forward_hostlevels(fused=1)`: reference-point add, offset
+    normalisation and the softmax over levels*points happen in the HIP kernel prologue, so the
+    (B,N,8,3,4,2) locations / (B,N,8,3,4) weights are never written to HBM;
+  * sine positional encodings and reference points depend only on the level shapes -> cached.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, runtime
+from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL_ENCODING,
+                       TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
+                       build_feedforward_network, build_positional_encoding,
+                       build_transformer_layer, build_transformer_layer_sequence)
+
+
+# ------------------------------------------------------------------------------------------------
+def build_norm(cfg, num_features):
+    """(name, module) for the norm types the shipped configs use: GN / BN / LN."""
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    requires_grad = cfg.pop('requires_grad', True)
+    if t == 'GN':
+        m = nn.GroupNorm(cfg.pop('num_groups'), num_features, **cfg)
+        name = 'gn'
+    elif t in ('BN', 'BN2d'):
+        m = nn.BatchNorm2d(num_features, **cfg)
+        name = 'bn'
+    elif t == 'LN':
+        m = nn.LayerNorm(num_features, **cfg)
+        name = 'ln'
+    else:
+        raise KeyError(f'Unrecognized norm type {t}')
+    for p in m.parameters():
+        p.requires_grad = requires_grad
+    return name, m
+
+
+def build_act(cfg):
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    if t == 'ReLU':
+        return nn.ReLU(**cfg)
+    if t == 'GELU':
+        cfg.pop('inplace', None)
+        return nn.GELU(**cfg)
+    raise KeyError(f'Unrecognized activation type {t}')
+
+
+class ConvModule(nn.Module):
+    """conv (+ norm) (+ act) with the [3P] mmcv ConvModule attribute names: `.conv`, `.gn` / `.bn`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias='auto',
+                 norm_cfg=None, act_cfg=dict(type='ReLU')):
+        super().__init__()
+        if bias == 'auto':
+            bias = norm_cfg is None
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                              bias=bias)
+        self.norm_name = None
+        if norm_cfg is not None:
+            self.norm_name, norm = build_norm(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        self.activate = build_act(dict(act_cfg, inplace=True)) if act_cfg is not None else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm_name is not None:
+            x = getattr(self, self.norm_name)(x.float())
+        if self.activate is not None:
+            x = self.activate(x)
+        return x
+
+
+def _kaiming_uniform_a1(conv):
+    """[3P] caffe2_xavier_init: kaiming uniform, a=1, fan_in, leaky_relu; bias 0."""
+    nn.init.kaiming_uniform_(conv.weight, a=1, mode='fan_in', nonlinearity='leaky_relu')
+    if conv.bias is not None:
+        nn.init.constant_(conv.bias, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+@POSITIONAL_ENCODING.register_module()
+class SinePositionalEncoding(nn.Module):
+    """[3P] mmdet SinePositionalEncoding (DETR formula).
+    forward(mask (B,H,W) bool, True = padded) -> (B, 2*num_feats, H, W)."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6,
+                 offset=0., init_cfg=None):
+        super().__init__()
+        if normalize:
+            assert isinstance(scale, (float, int)), \
+                f'when normalize is set, scale should be provided and in float or int type, found {type(scale)}'
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+        self._cache = {}
+
+    def forward(self, mask):
+        mask = mask.to(torch.int)
+        not_mask = 1 - mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+        dim_t = torch.arange(self.num_feats, dtype=torch.float32, device=mask.device)
+        dim_t = self.temperature**(2 * torch.div(dim_t, 2, rounding_mode='floor') / self.num_feats)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        B, H, W = mask.size()
+        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+    def flat_unpadded(self, h, w, device):
+        """(h*w, 2*num_feats) encoding of an all-valid (h, w) map (batch independent); cached."""
+        key = (h, w, str(device))
+        pe = self._cache.get(key)
+        if pe is None:
+            m = torch.zeros((1, h, w), dtype=torch.bool, device=device)
+            pe = self.forward(m)[0].flatten(1).t().contiguous()
+            self._cache[key] = pe
+        return pe
+
+
+# ------------------------------------------------------------------------------------------------
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(nn.Module):
+    """[3P] mmcv FFN: Linear-act-drop x (num_fcs-1), Linear, drop; `identity + out`."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        assert num_fcs >= 2, f'num_fcs should be no less than 2. got {num_fcs}.'
+        self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
+        layers = []
+        in_channels = embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(in_channels, feedforward_channels), build_act(act_cfg),
+                                        nn.Dropout(ffn_drop)))
+            in_channels = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Dropout(dropout_layer['drop_prob']) if dropout_layer else nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        with runtime.autocast():
+            out = self.layers(x)
+        out = out.float()
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+@ATTENTION.register_module()
+class MultiScaleDeformableAttention(nn.Module):
+    """[3P] mmcv MultiScaleDeformableAttention on the HIP MSDeformAttn kernels."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}')
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Dropout(dropout)
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims, self.num_levels, self.num_heads, self.num_points = \
+            embed_dims, num_levels, num_heads, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid_init.view(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    # -- fast path used by MSDeformAttnPixelDecoder (batch-first, fused prologue, forward-only) ----
+    def forward_fused(self, src, src_pos, ref_points, level_hw, level_start):
+        """src (B,N,C) f32 (value input and identity), src_pos = src + pos (query input),
+        ref_points (N,2). Returns identity + dropout(output_proj(msda))."""
+        B, N, C = src.shape
+        H, D = self.num_heads, C // self.num_heads
+        w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        with runtime.autocast():
+            value = self.value_proj(src)
+        # offsets / logits decide WHERE to sample: keep them f32 in both precisions
+        offs_logits = F.linear(src_pos, w_cat, b_cat)
+        value = value.view(B, N, H, D)
+        if not runtime.is_bf16():
+            value = value.float()
+        if torch.is_grad_enabled() and (value.requires_grad or offs_logits.requires_grad):
+            # training: un-fused prologue in torch so autograd reaches the linears; the sampling core
+            # and its backward are still the HIP kernels (MultiScaleDeformableAttnFunction)
+            L, P = self.num_levels, self.num_points
+            n_off = H * L * P * 2
+            offs = offs_logits[..., :n_off].view(B, N, H, L, P, 2)
+            aw = offs_logits[..., n_off:].view(B, N, H, L * P).softmax(-1).view(B, N, H, L, P)
+            norm = offs_logits.new_tensor([[w, h] for h, w in level_hw])
+            loc = ref_points[None, :, None, None, None, :] + offs / norm[None, None, None, :, None, :]
+            shapes = torch.tensor(level_hw, dtype=torch.int64, device=src.device)
+            starts = torch.tensor(level_start, dtype=torch.int64, device=src.device)
+            out = ops.MultiScaleDeformableAttnFunction.apply(value.float().contiguous(), shapes, starts,
+                                                             loc.contiguous(), aw.contiguous(),
+                                                             self.im2col_step)
+        else:
+            out = ops.msda_forward_fused(value.contiguous(), level_hw, level_start,
+                                         offs_logits.contiguous(), ref_points, self.num_points)
+        with runtime.autocast():
+            out = self.output_proj(out)
+        return src + self.dropout(out.float())
+
+    # -- [3P] signature (seq-first unless batch_first); differentiable through the HIP autograd op --
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == num_value
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        sampling_offsets = self.sampling_offsets(query).view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        attention_weights = self.attention_weights(query).view(
+            bs, num_query, self.num_heads, self.num_levels * self.num_points)
+        attention_weights = attention_weights.softmax(-1).view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points)
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            sampling_locations = reference_points[:, :, None, :, None, :] \
+                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f'Last dim of reference_points must be 2 or 4, but get '
+                             f'{reference_points.shape[-1]} instead.')
+        output = ops.MultiScaleDeformableAttnFunction.apply(
+            value.contiguous(), spatial_shapes, level_start_index, sampling_locations.contiguous(),
+            attention_weights.contiguous(), self.im2col_step)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
+
+
+# ------------------------------------------------------------------------------------------------
+@TRANSFORMER_LAYER.register_module()
+class BaseTransformerLayer(nn.Module):
+    """[3P] mmcv BaseTransformerLayer: attentions / ffns / norms run in `operation_order`."""
+
+    def __init__(self, attn_cfgs=None, ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024,
+                                                     num_fcs=2, ffn_drop=0., act_cfg=dict(type='ReLU', inplace=True)),
+                 operation_order=None, norm_cfg=dict(type='LN'), init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        ffn_cfgs = dict(ffn_cfgs)
+        for ori_name, new_name in dict(feedforward_channels='feedforward_channels', ffn_dropout='ffn_drop',
+                                       ffn_num_fcs='num_fcs').items():
+            if ori_name in kwargs:
+                ffn_cfgs[new_name] = kwargs[ori_name]
+        assert set(operation_order) & {'self_attn', 'norm', 'ffn', 'cross_attn'} == set(operation_order), \
+            f"The operation_order of {self.__class__.__name__} should contains all four operation type " \
+            f"{['self_attn', 'norm', 'ffn', 'cross_attn']}"
+        num_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [dict(attn_cfgs) for _ in range(num_attn)]
+        else:
+            assert num_attn == len(attn_cfgs), \
+                f'The length of attn_cfg {num_attn} is not consistent with the number of attention' \
+                f'in operation_order {operation_order}.'
+        self.num_attn = num_attn
+        self.operation_order = operation_order
+        self.norm_cfg = norm_cfg
+        self.pre_norm = operation_order[0] == 'norm'
+        self.batch_first = batch_first
+        self.attentions = nn.ModuleList()
+        index = 0
+        for op in operation_order:
+            if op in ('self_attn', 'cross_attn'):
+                cfg = dict(attn_cfgs[index])
+                if 'batch_first' in cfg:
+                    assert self.batch_first == cfg['batch_first']
+                else:
+                    cfg['batch_first'] = self.batch_first
+                attention = build_attention(cfg)
+                attention.operation_name = op
+                self.attentions.append(attention)
+                index += 1
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = nn.ModuleList()
+        num_ffns = operation_order.count('ffn')
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [dict(ffn_cfgs) for _ in range(num_ffns)]
+        assert len(ffn_cfgs) == num_ffns
+        for i in range(num_ffns):
+            cfg = dict(ffn_cfgs[i])
+            cfg.setdefault('embed_dims', self.embed_dims)
+            assert cfg['embed_dims'] == self.embed_dims
+            self.ffns.append(build_feedforward_network(cfg, dict(type='FFN')))
+        self.norms = nn.ModuleList()
+        for _ in range(operation_order.count('norm')):
+            self.norms.append(build_norm(norm_cfg, self.embed_dims)[1])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None for _ in range(self.num_attn)]
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [attn_masks.clone() for _ in range(self.num_attn)]
+        else:
+            assert len(attn_masks) == self.num_attn, \
+                f'The length of attn_masks {len(attn_masks)} must be equal to the number of ' \
+                f'attention in operation_order {self.num_attn}'
+        for layer in self.operation_order:
+            if layer == 'self_attn':
+                temp_key = temp_value = query
+                query = self.attentions[attn_index](
+                    query, temp_key, temp_value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=query_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=query_key_padding_mask, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'norm':
+                query = self.norms[norm_index](query)
+                norm_index += 1
+            elif layer == 'cross_attn':
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=key_pos, attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
+                    **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query
+
+
+class TransformerLayerSequence(nn.Module):
+    """[3P] mmcv TransformerLayerSequence: `num_layers` copies of `transformerlayers`."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__()
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [dict(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, list) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList([build_transformer_layer(cfg) for cfg in transformerlayers])
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        for layer in self.layers:
+            query = layer(query, key, value, query_pos=query_pos, key_pos=key_pos, attn_masks=attn_masks,
+                          query_key_padding_mask=query_key_padding_mask, key_padding_mask=key_padding_mask,
+                          **kwargs)
+        return query
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DetrTransformerEncoder(TransformerLayerSequence):
+    """[3P] mmdet DetrTransformerEncoder: post_norm only when the layers are pre-norm."""
+
+    def __init__(self, *args, post_norm_cfg=dict(type='LN'), **kwargs):
+        super().__init__(*args, **kwargs)
+        if post_norm_cfg is not None:
+            self.post_norm = build_norm(post_norm_cfg, self.embed_dims)[1] if self.pre_norm else None
+        else:
+            assert not self.pre_norm, f'Use prenorm in {self.__class__.__name__},Please specify post_norm_cfg'
+            self.post_norm = None
+
+    def forward(self, *args, **kwargs):
+        x = super().forward(*args, **kwargs)
+        if self.post_norm is not None:
+            x = self.post_norm(x)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------
+@PLUGIN_LAYERS.register_module()
+class MSDeformAttnPixelDecoder(nn.Module):
+    """[3P] mmdet MSDeformAttnPixelDecoder.
+    forward(feats: 4 maps, strides 4..32) -> (mask_feature (B,C,H/4,W/4), [3 memories low->high res])."""
+
+    def __init__(self, in_channels=[256, 512, 1024, 2048], strides=[4, 8, 16, 32], feat_channels=256,
+                 out_channels=256, num_outs=3, norm_cfg=dict(type='GN', num_groups=32),
+                 act_cfg=dict(type='ReLU'), encoder=None, positional_encoding=dict(
+                     type='SinePositionalEncoding', num_feats=128, normalize=True), init_cfg=None):
+        super().__init__()
+        self.strides = strides
+        self.num_input_levels = len(in_channels)
+        self.num_encoder_levels = encoder['transformerlayers']['attn_cfgs']['num_levels']
+        assert self.num_encoder_levels >= 1, 'num_levels in attn_cfgs must be at least one'
+        self.input_convs = nn.ModuleList()
+        for i in range(self.num_input_levels - 1, self.num_input_levels - self.num_encoder_levels - 1, -1):
+            self.input_convs.append(ConvModule(in_channels[i], feat_channels, kernel_size=1,
+                                               norm_cfg=norm_cfg, act_cfg=None, bias=True))
+        self.encoder = build_transformer_layer_sequence(encoder)
+        self.postional_encoding = build_positional_encoding(positional_encoding)  # (sic) upstream name
+        self.level_encoding = nn.Embedding(self.num_encoder_levels, feat_channels)
+        self.lateral_convs = nn.ModuleList()
+        self.output_convs = nn.ModuleList()
+        self.use_bias = norm_cfg is None
+        for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
+            self.lateral_convs.append(ConvModule(in_channels[i], feat_channels, kernel_size=1,
+                                                 bias=self.use_bias, norm_cfg=norm_cfg, act_cfg=None))
+            self.output_convs.append(ConvModule(feat_channels, feat_channels, kernel_size=3, stride=1,
+                                                padding=1, bias=self.use_bias, norm_cfg=norm_cfg,
+                                                act_cfg=act_cfg))
+        self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        self.num_outs = num_outs
+        self._ref_cache = {}
+
+    def init_weights(self):
+        for i in range(self.num_encoder_levels):
+            nn.init.xavier_uniform_(self.input_convs[i].conv.weight, gain=1)
+            nn.init.constant_(self.input_convs[i].conv.bias, 0)
+        for i in range(self.num_input_levels - self.num_encoder_levels):
+            _kaiming_uniform_a1(self.lateral_convs[i].conv)
+            _kaiming_uniform_a1(self.output_convs[i].conv)
+        _kaiming_uniform_a1(self.mask_feature)
+        nn.init.normal_(self.level_encoding.weight, mean=0, std=1)
+        for p in self.encoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+        for layer in self.encoder.layers:
+            for attn in layer.attentions:
+                if isinstance(attn, MultiScaleDeformableAttention):
+                    attn.init_weights()
+
+    def _reference_points(self, level_hw, device):
+        """pixel centres ((x+.5)/w, (y+.5)/h), levels concatenated low->high res; (N,2)."""
+        key = (tuple(level_hw), str(device))
+        ref = self._ref_cache.get(key)
+        if ref is None:
+            pts = []
+            for h, w in level_hw:
+                ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
+                                        torch.arange(w, device=device, dtype=torch.float32), indexing='ij')
+                pts.append(torch.stack([(xs.flatten() + 0.5) / w, (ys.flatten() + 0.5) / h], -1))
+            ref = torch.cat(pts, 0).contiguous()
+            self._ref_cache[key] = ref
+        return ref
+
+    def forward(self, feats):
+        B = feats[0].shape[0]
+        dev = feats[0].device
+        srcs, poss, level_hw = [], [], []
+        for i in range(self.num_encoder_levels):
+            feat = feats[self.num_input_levels - i - 1]
+            with runtime.autocast():
+                proj = self.input_convs[i](feat)
+            h, w = feat.shape[-2:]
+            level_hw.append((int(h), int(w)))
+            srcs.append(proj.float().flatten(2).transpose(1, 2))                     # (B, hw, C)
+            poss.append(self.postional_encoding.flat_unpadded(int(h), int(w), dev)
+                        + self.level_encoding.weight[i][None])                      # (hw, C)
+        level_start, s = [], 0
+        for h, w in level_hw:
+            level_start.append(s)
+            s += h * w
+        src = torch.cat(srcs, 1).contiguous()      # (B, N, C)
+        pos = torch.cat(poss, 0)                   # (N, C)
+        ref = self._reference_points(level_hw, dev)
+        for layer in self.encoder.layers:
+            assert tuple(layer.operation_order) == ('self_attn', 'norm', 'ffn', 'norm'), \
+                'MSDeformAttnPixelDecoder fast path expects post-norm (self_attn, norm, ffn, norm) layers'
+            attn = layer.attentions[0]
+            src = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start)
+            src = layer.norms[0](src)
+            src = layer.ffns[0](src)
+            src = layer.norms[1](src)
+        outs = [x.transpose(1, 2).reshape(B, -1, h, w)
+                for x, (h, w) in zip(src.split([h * w for h, w in level_hw], dim=1), level_hw)]
+        for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
+            x = feats[i]
+            with runtime.autocast():
+                cur = self.lateral_convs[i](x)
+            y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
+            with runtime.autocast():
+                y = self.output_convs[i](y)
+            outs.append(y.float())
+        with runtime.autocast():
+            mask_feature = self.mask_feature(outs[-1])
+        return mask_feature.float(), outs[:self.num_outs]
