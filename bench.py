@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the CGG decoder + mask-prediction hot path on MI355X.
+
+A "step" = one forward of `Mask2FormerOpen.simple_test` (R50 backbone -> MSDeformAttn pixel decoder ->
+9-layer masked-attention query decoder -> mask logits -> open-vocabulary instance post-processing for
+all / novel / base class sets) over one synthetic COCO-shaped batch that is already resident in HBM;
+results stay on the device (BASELINE.json configs[1]: R50, 100 queries, 1024x1024, batch 2, forward-only).
+N > 1: one process per GPU (torch.distributed / RCCL only for the barrier), every rank runs its own
+replica on its own batch -> weak scaling, no data-path collective (inference: "replicas only").
+
+Prints ONE JSON line (rank 0). Extra objects:
+  roofline      -- the mask-logit kernel (einsum 'bqc,bchw->bqhw', cgg_mask_logits, full resolution),
+                   timed with events on the launch stream INSIDE the timed steps.
+  cpu_baseline  -- the oracle (torch CPU restatement of the reference path, kind "port") on one batch of the
+                   same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def build_model(args, dev):
+    import cgg_amd
+    from cgg_amd import registry, synthetic
+    cfg = synthetic.model_config(num_things=65, num_stuff=0, num_unknown=17, num_queries=args.queries, depth=50)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+        torch.manual_seed(0)
+        model.init_weights()
+    return cfg, model.to(dev).eval()
+
+
+def cpu_baseline(args, cfg, model, img_cpu):
+    """oracle path on the host: the SAME weights, one batch; backbone = the same plain-torch ResNet."""
+    import copy
+    from oracle import head as OH
+    from cgg_amd import synthetic
+    hc = copy.deepcopy(cfg['panoptic_head'])
+    hc.update(train_cfg=cfg['train_cfg'], test_cfg=cfg['test_cfg'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        orc = OH.OracleHead(**hc)
+    sd = {k: v.detach().cpu() for k, v in model.panoptic_head.state_dict().items()}
+    orc.load_state_dict(sd)
+    orc.eval()
+    import copy as _c
+    backbone = _c.deepcopy(model.backbone).cpu().eval()
+    fh = model.panoptic_fusion_head
+    embs = [fh.all_class_embs.cpu(), fh.novel_class_embs.cpu(), fh.base_class_embs.cpu()]
+    B, _, H, W = img_cpu.shape
+    metas = synthetic.img_metas(B, H, W)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        feats = backbone(img_cpu)
+        _, emb, up = orc.simple_test(list(feats), metas)
+        for b in range(B):
+            mp = OH.crop_rescale(up[b], metas[b], True)
+            for e in embs:
+                OH.instance_postprocess_emb(emb[b], mp, e, 100)
+    dt = time.perf_counter() - t0
+    return dict(value=B / dt, unit='images/sec', cores=threads, kind='port',
+                sample=f'1 step = {B} images {H}x{W}, full detector forward + instance post-processing '
+                       f'(torch CPU oracle, fp32, {threads} threads), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=2, help='images per GPU per step')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--queries', type=int, default=100)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--graph', type=int, default=0, help='replay the step from a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (the hot path has no CPU implementation)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    import cgg_amd
+    from cgg_amd import ops, runtime, synthetic
+    runtime.set_precision(args.precision)
+    torch.backends.cudnn.benchmark = True
+    cfg, model = build_model(args, dev)
+    B, H, W = args.batch, args.size, args.size
+    g = torch.Generator().manual_seed(1234 + rank)
+    img_cpu = torch.randn(B, 3, H, W, generator=g)
+    img = img_cpu.to(dev)
+    metas = synthetic.img_metas(B, H, W)
+
+    def step():
+        with torch.no_grad():
+            return model.simple_test(img, metas, rescale=True, device_results=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if args.graph:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
+        torch.cuda.synchronize()
+
+    ops.KERNEL_EVENTS = {} if graph is None else None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    events = ops.KERNEL_EVENTS or {}
+    ops.KERNEL_EVENTS = None
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- roofline of the mask-logit kernel (full resolution) ----
+    if not events.get('mask_logits_full'):
+        # graph mode: events cannot be recorded inside a replay -> time the same launch, same shapes, eagerly
+        feats = out  # noqa: F841
+        E = torch.randn(B, args.queries, 256, device=dev)
+        F_ = torch.randn(B, 256, H // 4, W // 4, device=dev)
+        packed = ops.pack_mask_feature(F_, 1, split=(args.precision == 'fp32'))
+        ops.KERNEL_EVENTS = events
+        for _ in range(args.steps):
+            ops.mask_logits(E, packed, want_logits=True)
+        ops.KERNEL_EVENTS = None
+    torch.cuda.synchronize()
+    ml = [s.elapsed_time(e) for s, e in events['mask_logits_full']]
+    ml_ms = sum(ml) / len(ml)
+    HW4 = (H // 4) * (W // 4)
+    Q = args.queries
+    in_bytes = 2 if args.precision == 'bf16' else 4       # packed bf16 (hi) or hi+lo = 4 B / element
+    alg_bytes = B * (256 * HW4 * in_bytes + Q * 256 * 4 + Q * HW4 * 4)
+    flops = 2.0 * B * Q * 256 * HW4
+    gbs = alg_bytes / (ml_ms * 1e-3) / 1e9
+    tfs = flops / (ml_ms * 1e-3) / 1e12
+    roofline = dict(bound='hbm', kernel='cgg_mask_logits_kernel', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=gbs / HBM_PEAK_GBS, traffic=None, launch_ms=ml_ms, launches_timed=len(ml),
+                    algorithmic_bytes=alg_bytes, tflops=tfs, frac_mfma_bf16_peak=tfs / MFMA_BF16_PEAK_TF)
+    extra = {}
+    if events.get('msda_fused'):
+        ms = [s.elapsed_time(e) for s, e in events['msda_fused']]
+        ms = sum(ms) / len(ms)
+        N = sum((H // s) * (W // s) for s in (8, 16, 32))
+        vb = 2 if args.precision == 'bf16' else 4
+        mbytes = B * N * (256 * vb + 288 * 4 + 256 * 4)
+        extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9)
+
+    if rank == 0:
+        res = dict(metric='images/sec (COCO-shaped 1024x1024, 100 queries, forward-only)',
+                   value=B * world * args.steps / dt, unit='images/sec', n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+                   scaling='weak', vs_baseline=None,
+                   dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
+                   config=dict(workload=f'configs[1]: R50 + {Q} queries, {H}x{W}, batch {B}/GPU, forward-only '
+                                        '(backbone + MSDeformAttn pixel decoder + 9-layer masked-attention '
+                                        'decoder + mask logits + instance post-processing, results on device)',
+                               global_batch=B * world, parallelism=f'replicas x{world}',
+                               precision=args.precision, hip_graph=bool(args.graph)),
+                   roofline=roofline, kernels=extra)
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(args, cfg, model, img_cpu)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -15,6 +15,27 @@ from ._lib import CGG_BF16, CGG_F32, CggError, check, dev_ptr, stream_ptr
 
 _WS_CACHE = {}
 
+# bench.py sets this to a dict to collect (start, end) torch.cuda.Event pairs around selected launches
+# (events are recorded on torch's current stream -- the stream the kernels are launched on).
+KERNEL_EVENTS = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+        self.on = KERNEL_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
+
+    def __enter__(self):
+        if self.on:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+
 
 def _lib_():
     return _lib.load()
@@ -80,10 +101,11 @@ def msda_forward_fused(value, level_hw, level_start, offs_logits, ref_points, nu
     out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
     hw = _int_array([v for pair in level_hw for v in pair])
     st = _int_array(level_start)
-    rc = _lib_().cgg_msda_forward_hostlevels(
-        dev_ptr(value, 'value'), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.float32), None,
-        dev_ptr(ref_points, 'ref_points', torch.float32), ld, dev_ptr(out), B, Nv, H, D, L, Nq, P, vdt,
-        1, stream_ptr(value.device))
+    with _timed('msda_fused'):
+        rc = _lib_().cgg_msda_forward_hostlevels(
+            dev_ptr(value, 'value'), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.float32), None,
+            dev_ptr(ref_points, 'ref_points', torch.float32), ld, dev_ptr(out), B, Nv, H, D, L, Nq, P, vdt,
+            1, stream_ptr(value.device))
     check(rc, 'cgg_msda_forward_hostlevels(fused)')
     return out
 
@@ -161,9 +183,11 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
         if want_logits else None
     bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device) \
         if want_bits else None
-    rc = _lib_().cgg_mask_logits(dev_ptr(embed, 'mask_embed', torch.float32), dev_ptr(packed.hi),
-                                 dev_ptr(packed.lo), dev_ptr(out), dev_ptr(bits), B, Q, C, packed.npix,
-                                 stream_ptr(embed.device))
+    tag = 'mask_logits_full' if want_logits else 'mask_logits_bits'
+    with _timed(tag):
+        rc = _lib_().cgg_mask_logits(dev_ptr(embed, 'mask_embed', torch.float32), dev_ptr(packed.hi),
+                                     dev_ptr(packed.lo), dev_ptr(out), dev_ptr(bits), B, Q, C, packed.npix,
+                                     stream_ptr(embed.device))
     check(rc, 'cgg_mask_logits')
     return out, bits
 
