@@ -59,9 +59,10 @@ def cpu_baseline(args, cfg, model, img_cpu):
     backbone = _c.deepcopy(model.backbone).cpu().eval()
     fh = model.panoptic_fusion_head
     embs = [fh.all_class_embs.cpu(), fh.novel_class_embs.cpu(), fh.base_class_embs.cpu()]
+    img_cpu = img_cpu[:1]                      # bounded sample: ONE image of the same workload
     B, _, H, W = img_cpu.shape
     metas = synthetic.img_metas(B, H, W)
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
     with torch.no_grad():
@@ -104,7 +105,6 @@ def main():
     import cgg_amd
     from cgg_amd import ops, runtime, synthetic
     runtime.set_precision(args.precision)
-    torch.backends.cudnn.benchmark = True
     cfg, model = build_model(args, dev)
     B, H, W = args.batch, args.size, args.size
     g = torch.Generator().manual_seed(1234 + rank)

@@ -142,6 +142,11 @@ class ResNet(nn.Module):
         outs = []
         with runtime.autocast():
             if runtime.is_bf16():
+                # MIOpen's bf16 solvers want NHWC activations AND NHWC filters (a mixed pair falls back
+                # to the naive kernels): convert the filters once, then feed NHWC input
+                if not getattr(self, '_channels_last', False):
+                    self.to(memory_format=torch.channels_last)
+                    self._channels_last = True
                 x = x.contiguous(memory_format=torch.channels_last)
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
             for i, name in enumerate(self.res_layers):

@@ -36,11 +36,11 @@ void cgg_set_error(const char* fmt, ...);
 static inline bool cgg_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- bf16 helpers (round-to-nearest-even, NaN preserved) ----------------------------------------
+// hardware conversion (the cast lowers to v_cvt_pk_bf16_f32 on gfx950, RNE); a software round costs
+// ~15 VALU per element and made the conversion-heavy prologues latency-bound
 __device__ __forceinline__ uint16_t cgg_f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
 }
 __device__ __forceinline__ float cgg_bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

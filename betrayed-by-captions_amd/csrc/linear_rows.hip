@@ -1,0 +1,179 @@
+// Skinny linear for the query side of the decoder: y[M,N] = act(x[M,K] W[N,K]^T + b) (+ res),  M = B*Q ~ 200.
+// Replaces the q/out projections, self-attention projections, FFN and head MLPs of
+// DetrTransformerDecoderLayer / forward_head (open_set/models/mask2former_head.py:734-746, 829-840) that a
+// BLAS library serves with a single 256x208 macro-tile workgroup (54 us per call measured on MI355X).
+//
+// Latency-bound, not roofline-bound: the whole problem is < 1 MB. Decomposition = (32-column n-tile,
+// 128-row m-block) per workgroup, one 32-row m-tile per wave; W tile lives in LDS as bf16 MFMA B fragments
+// (converted on the fly, K chunked by 512), x fragments go global -> registers -> bf16.
+// SPLIT = f32-class accuracy via 3 bf16 MFMAs on (hi, lo) operands; otherwise plain bf16.
+#include "cgg_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define LR_KC 256  // K chunk staged per pass (16 MFMA k-steps)
+
+__device__ __forceinline__ void lr_cvt8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo, bool split) {
+  float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  uint16_t h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (split) cgg_split_bf(v[e], h[e], l[e]);
+    else { h[e] = cgg_f2bf(v[e]); l[e] = 0; }
+  }
+  hi = u32x4{cgg_pack2(h[0], h[1]), cgg_pack2(h[2], h[3]), cgg_pack2(h[4], h[5]), cgg_pack2(h[6], h[7])};
+  lo = u32x4{cgg_pack2(l[0], l[1]), cgg_pack2(l[2], l[3]), cgg_pack2(l[4], l[5]), cgg_pack2(l[6], l[7])};
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void cgg_linear_rows_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy, int M, int N, int K, int relu) {
+  constexpr int STEPS = LR_KC / 16;
+  __shared__ __attribute__((aligned(16))) u32x4 w_hi[STEPS * 64];
+  __shared__ __attribute__((aligned(16))) u32x4 w_lo[SPLIT ? STEPS * 64 : 1];
+  const int n0 = blockIdx.x * 32;
+  const int m0 = blockIdx.y * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi5 = lane >> 5;
+  const int row = m0 + wave * 32 + j;            // A-operand row of this lane
+  const bool row_ok = row < M;
+  const bool wave_live = m0 + wave * 32 < M;     // wave-uniform
+  const float* xr = x + (size_t)(row_ok ? row : 0) * ldx + 8 * hi5;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += LR_KC) {
+    const int steps = min(LR_KC, K - k0) >> 4;
+    // ---- (1) issue ALL x loads of this chunk (latency overlaps the W staging below) ----
+    f32x4 xa[STEPS][2];
+#pragma unroll
+    for (int ks = 0; ks < STEPS; ++ks) {
+      if (wave_live && row_ok && ks < steps) {
+        xa[ks][0] = *reinterpret_cast<const f32x4*>(xr + k0 + ks * 16);
+        xa[ks][1] = *reinterpret_cast<const f32x4*>(xr + k0 + ks * 16 + 4);
+      } else {
+        xa[ks][0] = zero4;
+        xa[ks][1] = zero4;
+      }
+    }
+    // ---- (2) stage W[n0..n0+31][k0..k0+16*steps) as B fragments; loads first, then convert + store ----
+    //      slot (ks, lane) = W[n0 + (lane&31)][k0 + ks*16 + 8*(lane>>5) .. +7]
+    f32x4 wa[STEPS / 4][2];
+#pragma unroll
+    for (int it = 0; it < STEPS / 4; ++it) {
+      const int slot = tid + 256 * it;
+      const int l = slot & 63, ks = slot >> 6;
+      const int n = n0 + (l & 31);
+      if (ks < steps && n < N) {
+        const float* src = w + (size_t)n * K + k0 + ks * 16 + 8 * (l >> 5);
+        wa[it][0] = *reinterpret_cast<const f32x4*>(src);
+        wa[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      } else {
+        wa[it][0] = zero4;
+        wa[it][1] = zero4;
+      }
+    }
+    __syncthreads();  // previous chunk's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < STEPS / 4; ++it) {
+      u32x4 h, lo;
+      lr_cvt8(wa[it][0], wa[it][1], h, lo, SPLIT);
+      w_hi[tid + 256 * it] = h;
+      if (SPLIT) w_lo[tid + 256 * it] = lo;
+    }
+    __syncthreads();
+    if (!wave_live) continue;
+    // ---- (3) MFMA ----
+#pragma unroll
+    for (int ks = 0; ks < STEPS; ++ks) {
+      if (ks < steps) {
+        u32x4 ah, al;
+        lr_cvt8(xa[ks][0], xa[ks][1], ah, al, SPLIT);
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, ah);
+        const bf16x8 vbh = __builtin_bit_cast(bf16x8, w_hi[ks * 64 + lane]);
+        if (SPLIT) {
+          const bf16x8 val = __builtin_bit_cast(bf16x8, al);
+          const bf16x8 vbl = __builtin_bit_cast(bf16x8, w_lo[ks * 64 + lane]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbl, acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbh, acc, 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: acc[r] = y[m0 + wave*32 + (r&3) + 8*(r>>2) + 4*hi5][n0 + j]
+  const int n = n0 + j;
+  if (n < N && wave_live) {
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+      if (m < M) {
+        float v = acc[r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if (res) v += res[(size_t)m * ldr + n];
+        y[(size_t)m * ldy + n] = v;
+      }
+    }
+  }
+}
+
+// row-wise LayerNorm of y = a (+ b): one wave per row (N <= 4096), eps as nn.LayerNorm
+__global__ __launch_bounds__(256) void cgg_add_layernorm_kernel(const float* __restrict__ a,
+                                                                const float* __restrict__ b,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ y, int rows, int N,
+                                                                float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* ar = a + (size_t)row * N;
+  const float* br = b ? b + (size_t)row * N : nullptr;
+  float s = 0.f;
+  for (int i = lane; i < N; i += 64) s += ar[i] + (br ? br[i] : 0.f);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)N;
+  float v = 0.f;
+  for (int i = lane; i < N; i += 64) {
+    const float d = ar[i] + (br ? br[i] : 0.f) - mean;
+    v += d * d;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = rsqrtf(v / (float)N + eps);
+  for (int i = lane; i < N; i += 64) {
+    const float d = ar[i] + (br ? br[i] : 0.f) - mean;
+    y[(size_t)row * N + i] = d * rstd * gamma[i] + beta[i];
+  }
+}
+
+extern "C" int cgg_linear_rows(const float* x, int ldx, const float* w, const float* bias, const float* res,
+                               int ldr, float* y, int ldy, int M, int N, int K, int relu, int split,
+                               cgg_stream_t stream) {
+  CGG_REQUIRE(x && w && y, CGG_EINVAL, "cgg_linear_rows: null pointer");
+  CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "cgg_linear_rows: bad sizes");
+  CGG_REQUIRE(K % 16 == 0 && ldx % 4 == 0, CGG_EUNSUPPORTED, "cgg_linear_rows: K=%d (ldx=%d) must be a multiple of 16 (4)", K, ldx);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w), CGG_EALIGN, "cgg_linear_rows: x / w must be 16-B aligned");
+  dim3 grid((N + 31) / 32, (M + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (split)
+    hipLaunchKernelGGL(cgg_linear_rows_kernel<true>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
+  else
+    hipLaunchKernelGGL(cgg_linear_rows_kernel<false>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
+  CGG_CHECK_LAUNCH("cgg_linear_rows");
+  return CGG_OK;
+}
+
+extern "C" int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta,
+                                 float* y, int rows, int N, float eps, cgg_stream_t stream) {
+  CGG_REQUIRE(a && gamma && beta && y, CGG_EINVAL, "cgg_add_layernorm: null pointer");
+  CGG_REQUIRE(rows > 0 && N > 0, CGG_EINVAL, "cgg_add_layernorm: bad sizes");
+  hipLaunchKernelGGL(cgg_add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, b,
+                     gamma, beta, y, rows, N, eps);
+  CGG_CHECK_LAUNCH("cgg_add_layernorm");
+  return CGG_OK;
+}

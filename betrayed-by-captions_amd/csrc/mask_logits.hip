@@ -90,36 +90,36 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
   const int wave = tid >> 6;
 
   // ---- prologue: mask_embed[b] -> bf16 fragments in LDS ----
-  const float* eb = embed + (size_t)b * Q * C;
-  for (int slot = tid; slot < MT * KS * 64; slot += 512) {
-    const int l = slot & 63;
-    const int ks = (slot >> 6) % KS;
-    const int mt = slot / (KS * 64);
-    const int q = mt * 32 + (l & 31);
-    const int k0 = ks * 16 + 8 * (l >> 5);
-    float v[8];
-    if (q < Q) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(eb + (size_t)q * C + k0);
-      f32x4 x = src[0], y = src[1];
-      v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-      v[4] = y[0]; v[5] = y[1]; v[6] = y[2]; v[7] = y[3];
-    } else {
+  // Coalesced: thread t owns float4 number t, t+512, ... of the contiguous [Q, 256] block; ALL loads
+  // are issued before the first conversion (the old per-slot gather was a chain of dependent loads).
+  // float4 (q, c4) lands in slot (mt = q/32, ks = c4/4, lane = q%32 + 32*((c4/2)&1)), half (c4 & 1).
+  {
+    const f32x4* eb4 = reinterpret_cast<const f32x4*>(embed + (size_t)b * Q * C);
+    constexpr int NV = (MT * 32 * (C / 4) + 511) / 512;  // float4 per thread (rows padded to MT*32)
+    f32x4 ev[NV];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + 512 * i;
+      const int q = f / (C / 4);
+      ev[i] = (q < Q) ? eb4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    uint16_t h[8], lw[8];
+    uint2* a_hi2 = reinterpret_cast<uint2*>(a_hi);
+    uint2* a_lo2 = reinterpret_cast<uint2*>(a_lo);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (SPLIT) cgg_split_bf(v[e], h[e], lw[e]);
-      else h[e] = cgg_f2bf(v[e]);
-    }
-    u32x4 ph = {cgg_pack2(h[0], h[1]), cgg_pack2(h[2], h[3]), cgg_pack2(h[4], h[5]),
-                cgg_pack2(h[6], h[7])};
-    a_hi[slot] = ph;
-    if (SPLIT) {
-      u32x4 pl = {cgg_pack2(lw[0], lw[1]), cgg_pack2(lw[2], lw[3]), cgg_pack2(lw[4], lw[5]),
-                  cgg_pack2(lw[6], lw[7])};
-      a_lo[slot] = pl;
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + 512 * i;
+      const int q = f / (C / 4), c4 = f % (C / 4);
+      if (q < MT * 32) {
+        const int slot = ((q >> 5) * KS + (c4 >> 2)) * 64 + (q & 31) + 32 * ((c4 >> 1) & 1);
+        uint16_t h[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (SPLIT) cgg_split_bf(ev[i][e], h[e], lw[e]);
+          else h[e] = cgg_f2bf(ev[i][e]);
+        }
+        a_hi2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(h[0], h[1]), cgg_pack2(h[2], h[3]));
+        if (SPLIT) a_lo2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(lw[0], lw[1]), cgg_pack2(lw[2], lw[3]));
+      }
     }
   }
   __syncthreads();

@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) void cgg_upsample_kernel(const float* __restri
   y[(size_t)n * h * w + p] = cgg_bilerp(x + (size_t)n * H * W, W, ty, tx);
 }
 
-// instance masks: block = 256 consecutive output pixels of detection blockIdx.y
+// instance masks: thread = 16 consecutive output pixels (one 16-B mask store) of detection blockIdx.y;
+// block-level reduction, then ONE set of atomics per block (4096 pixels).
 // ws per detection: [0] f32 sum sigmoid*[m>0], [1] i32 count, [2..5] i32 xmin, ymin, xmax, ymax
+#define IM_PPT 16
 __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __restrict__ logits,
                                                                  const int32_t* __restrict__ sel,
                                                                  uint8_t* __restrict__ masks,
@@ -90,23 +92,34 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __
                                                                  ResizeGeom g) {
   const int i = blockIdx.y;
   const long long npix = (long long)g.out_h * g.out_w;
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * IM_PPT;
   const float* s = logits + (size_t)sel[i] * g.H * g.W;
   float sig = 0.f;
   int cnt = 0, xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
-  if (p < npix) {
-    const int oy = (int)(p / g.out_w), ox = (int)(p - (long long)oy * g.out_w);
-    const float v = cgg_resized_logit(s, g, oy, ox);
-    const bool on = v > 0.f;
-    masks[(size_t)i * npix + p] = on ? 1 : 0;
-    if (on) {
-      sig = cgg_sigmoid(v);
-      cnt = 1;
-      xmin = xmax = ox;
-      ymin = ymax = oy;
+  uint32_t packed[IM_PPT / 4] = {0u, 0u, 0u, 0u};
+  if (p0 < npix) {
+    int oy = (int)(p0 / g.out_w), ox = (int)(p0 - (long long)oy * g.out_w);
+#pragma unroll
+    for (int k = 0; k < IM_PPT; ++k) {
+      if (p0 + k < npix) {
+        const float v = cgg_resized_logit(s, g, oy, ox);
+        if (v > 0.f) {
+          packed[k >> 2] |= 1u << (8 * (k & 3));
+          sig += cgg_sigmoid(v);
+          cnt += 1;
+          xmin = min(xmin, ox); xmax = max(xmax, ox);
+          ymin = min(ymin, oy); ymax = max(ymax, oy);
+        }
+      }
+      if (++ox == g.out_w) { ox = 0; ++oy; }
+    }
+    uint8_t* dst = masks + (size_t)i * npix + p0;
+    if (p0 + IM_PPT <= npix && ((((size_t)i * npix + p0) & 15) == 0)) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    } else {
+      for (int k = 0; k < IM_PPT && p0 + k < npix; ++k) dst[k] = (packed[k >> 2] >> (8 * (k & 3))) & 0xff;
     }
   }
-  // wave reduce, then one atomic set per wave
   for (int o = 32; o > 0; o >>= 1) {
     sig += __shfl_xor(sig, o);
     cnt += __shfl_xor(cnt, o);
@@ -115,14 +128,30 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __
     xmax = max(xmax, __shfl_xor(xmax, o));
     ymax = max(ymax, __shfl_xor(ymax, o));
   }
-  if ((threadIdx.x & 63) == 0 && cnt > 0) {
-    int32_t* w = ws + (size_t)i * 8;
-    atomicAdd(reinterpret_cast<float*>(w), sig);
-    atomicAdd(w + 1, cnt);
-    atomicMin(w + 2, xmin);
-    atomicMin(w + 3, ymin);
-    atomicMax(w + 4, xmax);
-    atomicMax(w + 5, ymax);
+  __shared__ float s_sig[4];
+  __shared__ int s_i[4][5];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_sig[wave] = sig;
+    s_i[wave][0] = cnt; s_i[wave][1] = xmin; s_i[wave][2] = ymin; s_i[wave][3] = xmax; s_i[wave][4] = ymax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      sig += s_sig[w];
+      cnt += s_i[w][0];
+      xmin = min(xmin, s_i[w][1]); ymin = min(ymin, s_i[w][2]);
+      xmax = max(xmax, s_i[w][3]); ymax = max(ymax, s_i[w][4]);
+    }
+    if (cnt > 0) {
+      int32_t* w = ws + (size_t)i * 8;
+      atomicAdd(reinterpret_cast<float*>(w), sig);
+      atomicAdd(w + 1, cnt);
+      atomicMin(w + 2, xmin);
+      atomicMin(w + 3, ymin);
+      atomicMax(w + 4, xmax);
+      atomicMax(w + 5, ymax);
+    }
   }
 }
 
@@ -263,8 +292,9 @@ extern "C" int cgg_instance_masks(const float* logits, const int32_t* sel, uint8
   const ResizeGeom g = make_geom(H, W, up_h, up_w, crop_h, crop_w, out_h, out_w);
   hipLaunchKernelGGL(cgg_instance_init_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (int32_t*)ws, n);
   const long long npix = (long long)out_h * out_w;
-  hipLaunchKernelGGL(cgg_instance_masks_kernel, dim3((unsigned)((npix + 255) / 256), n), dim3(256), 0,
-                     s, logits, sel, masks, (int32_t*)ws, g);
+  const long long per_block = 256LL * IM_PPT;
+  hipLaunchKernelGGL(cgg_instance_masks_kernel, dim3((unsigned)((npix + per_block - 1) / per_block), n),
+                     dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
   hipLaunchKernelGGL(cgg_instance_final_kernel, dim3((n + 63) / 64), dim3(64), 0, s,
                      (const int32_t*)ws, mask_score, bbox, n);
   CGG_CHECK_LAUNCH("cgg_instance_masks");

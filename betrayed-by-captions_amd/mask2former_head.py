@@ -148,6 +148,7 @@ class Mask2FormerHeadOpen(nn.Module):
         self.loss_mask = build_loss(loss_mask)
         self.loss_dice = build_loss(loss_dice)
         self.point_hook = None  # callable(kind, shape, device) -> coords; pins the random draws in tests
+        self.attn_mask_hook = None  # callable(layer_idx, bits) -> bits; tests inject the oracle's masks
         self.init_kwargs(**kwargs)
 
     # ------------------------------------------------------------------------------------------
@@ -252,14 +253,18 @@ class Mask2FormerHeadOpen(nn.Module):
                      want_mask=True, want_attn=True):
         """mask2former_head.py:711-761 on batch-first `decoder_out` (B,Q,C).
         Returns (cls_pred, cls_emb_pred, mask_pred | None, attn bits (B,Q,words) int32 | None)."""
-        decoder_out = self.transformer_decoder.post_norm(decoder_out)
-        cls_pred = self.cls_embed(decoder_out)
+        from .query_decoder import residual_layernorm, small_linear
+        decoder_out = residual_layernorm(decoder_out.contiguous(), None, self.transformer_decoder.post_norm)
+        cls_pred = small_linear(decoder_out, self.cls_embed.weight, self.cls_embed.bias)
         cls_emb_pred = cls_pred
         if self.use_class_emb:
-            cls_emb_pred = self.v2l_transform(decoder_out)
+            cls_emb_pred = small_linear(decoder_out, self.v2l_transform.weight, self.v2l_transform.bias)
             if self.pred_emb_norm:
                 cls_emb_pred = cls_emb_pred / cls_emb_pred.norm(dim=-1, keepdim=True)
-        mask_embed = self.mask_embed(decoder_out).contiguous()
+        me = self.mask_embed
+        h = small_linear(decoder_out, me[0].weight, me[0].bias, relu=True)
+        h = small_linear(h, me[2].weight, me[2].bias, relu=True)
+        mask_embed = small_linear(h, me[4].weight, me[4].bias).contiguous()
         split = not runtime.is_bf16()
         mask_pred = None
         if want_mask:
@@ -325,6 +330,8 @@ class Mask2FormerHeadOpen(nn.Module):
         mask_pred_list.append(mask_pred)
         for i in range(nl):
             level_idx = i % L
+            if self.attn_mask_hook is not None:
+                bits = self.attn_mask_hook(i, bits)
             # rows that mask every key are un-masked (mask2former_head.py:825-826)
             ops.attn_mask_fix_full_rows(bits, sizes[level_idx][0] * sizes[level_idx][1])
             layer = layers[i]

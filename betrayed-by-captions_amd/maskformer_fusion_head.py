@@ -110,6 +110,16 @@ class MaskFormerFusionHeadOpen(nn.Module):
         out = tuple(int(v) for v in meta['ori_shape'][:2]) if rescale else crop
         return logits.contiguous(), up, crop, out
 
+    def _query_masks(self, geom):
+        logits, up, crop, out = geom
+        key = (logits.data_ptr(), logits._version, tuple(logits.shape), up, crop, out)
+        cache = getattr(self, '_qm_cache', None)
+        if cache is None or cache[0] != key:
+            sel = torch.arange(logits.shape[0], dtype=torch.int32, device=logits.device)
+            cache = (key, ops.instance_masks(logits, sel, up, crop, out))
+            self._qm_cache = cache
+        return cache[1]
+
     def _instances_from_scores(self, scores, geom):
         """:340-366 given per-query class scores (Q, n) (background column already dropped)."""
         logits, up, crop, out = geom
@@ -120,8 +130,12 @@ class MaskFormerFusionHeadOpen(nn.Module):
         scores_per_image, top_indices = flat.topk(k, sorted=False)
         labels_per_image = top_indices % n_cls
         query_indices = torch.div(top_indices, n_cls, rounding_mode='floor')
-        masks, mask_scores, bboxes = ops.instance_masks(logits, query_indices.to(torch.int32).contiguous(),
-                                                        up, crop, out)
+        # binary mask / mask score / bbox depend on the QUERY only: computed once per image for all Q
+        # queries and gathered per detection (the three eval types of a config re-use them)
+        qmasks, qscores, qboxes = self._query_masks(geom)
+        masks = qmasks.index_select(0, query_indices)
+        mask_scores = qscores.index_select(0, query_indices)
+        bboxes = qboxes.index_select(0, query_indices)
         return labels_per_image, scores_per_image, mask_scores, bboxes, masks
 
     def instance_postprocess_emb(self, mask_cls_emb, mask_pred, gt_cls_embs, meta=None, rescale=False):
@@ -220,6 +234,7 @@ class MaskFormerFusionHeadOpen(nn.Module):
         """:369-464 -> list (one dict per image) keyed by eval type."""
         eval_types = self.test_cfg.get('eval_types', [])
         rescale = kwargs.get('rescale', False)
+        self._qm_cache = None
         results = []
         for b, meta in enumerate(img_metas):
             mask_cls_result = mask_cls_results[b]

@@ -323,3 +323,53 @@ def rowwise_softmax_argmax(x, want_prob=True):
                                             dev_ptr(arg), rows, n, stream_ptr(x.device))
     check(rc, 'cgg_rowwise_softmax_argmax')
     return prob, maxv, arg
+
+
+# ------------------------------------------------------------------------------------------------
+# K7/K11  skinny linear / residual LayerNorm (query side of the decoder)
+# ------------------------------------------------------------------------------------------------
+def linear_rows(x, weight, bias=None, relu=False, res=None, split=True, out=None):
+    """x (..., K) f32 (last dim contiguous) @ weight (N,K)^T + bias -> (..., N) f32; optional ReLU, then + res."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    else:
+        y = out.reshape(-1, out.shape[-1]) if out.dim() != 2 else out
+        if y.stride(-1) != 1 or y.shape[0] != M or y.shape[1] != N or y.dtype != torch.float32:
+            raise CggError('linear_rows: bad `out` view')
+    r2 = None
+    if res is not None:
+        r2 = res.reshape(-1, N)
+        if r2.stride(-1) != 1:
+            r2 = r2.contiguous()
+    for t, nm in ((x2, 'x'), (weight, 'weight')):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise CggError(f'linear_rows: {nm} must be a float32 ROCm tensor')
+    if not weight.is_contiguous():
+        weight = weight.contiguous()
+    rc = _lib_().cgg_linear_rows(ctypes.c_void_p(x2.data_ptr()), x2.stride(0), dev_ptr(weight),
+                                 dev_ptr(bias, 'bias', torch.float32),
+                                 ctypes.c_void_p(r2.data_ptr()) if r2 is not None else None,
+                                 r2.stride(0) if r2 is not None else 0, ctypes.c_void_p(y.data_ptr()),
+                                 y.stride(0), M, N, K,
+                                 1 if relu else 0, 1 if split else 0, stream_ptr(x.device))
+    check(rc, 'cgg_linear_rows')
+    return y.view(*x.shape[:-1], N) if out is None else out
+
+
+def add_layernorm(a, b, gamma, beta, eps=1e-5):
+    """LayerNorm(a + b) over the last dim (b may be None)."""
+    N = a.shape[-1]
+    a2 = a.contiguous()
+    b2 = b.contiguous() if b is not None else None
+    y = torch.empty_like(a2)
+    rc = _lib_().cgg_add_layernorm(dev_ptr(a2, 'a', torch.float32), dev_ptr(b2, 'b', torch.float32),
+                                   dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
+                                   dev_ptr(y), a2.numel() // N, N, float(eps), stream_ptr(a.device))
+    check(rc, 'cgg_add_layernorm')
+    return y

@@ -75,7 +75,7 @@ class ConvModule(nn.Module):
         self.activate = build_act(dict(act_cfg, inplace=True)) if act_cfg is not None else None
 
     def forward(self, x):
-        x = self.conv(x)
+        x = self.conv(x.contiguous())
         if self.norm_name is not None:
             x = getattr(self, self.norm_name)(x.float())
         if self.activate is not None:
@@ -158,9 +158,14 @@ class FFN(nn.Module):
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
-        with runtime.autocast():
-            out = self.layers(x)
-        out = out.float()
+        if len(self.layers) == 3 and isinstance(self.layers[0][1], nn.ReLU) and self.layers[0][2].p == 0 \
+                and self.layers[2].p == 0:
+            h = torch.relu_(runtime.linear(x, self.layers[0][0].weight, self.layers[0][0].bias))
+            out = runtime.linear(h, self.layers[1].weight, self.layers[1].bias)
+        else:
+            with runtime.autocast():
+                out = self.layers(x)
+            out = out.float()
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:
@@ -214,13 +219,14 @@ class MultiScaleDeformableAttention(nn.Module):
         H, D = self.num_heads, C // self.num_heads
         w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        with runtime.autocast():
-            value = self.value_proj(src)
+        if runtime.is_bf16() and not torch.is_grad_enabled():
+            value = F.linear(src.to(torch.bfloat16), runtime.cast_cached(self.value_proj.weight),
+                             runtime.cast_cached(self.value_proj.bias))      # bf16 values for the gather
+        else:
+            value = runtime.linear(src, self.value_proj.weight, self.value_proj.bias)
         # offsets / logits decide WHERE to sample: keep them f32 in both precisions
         offs_logits = F.linear(src_pos, w_cat, b_cat)
         value = value.view(B, N, H, D)
-        if not runtime.is_bf16():
-            value = value.float()
         if torch.is_grad_enabled() and (value.requires_grad or offs_logits.requires_grad):
             # training: un-fused prologue in torch so autograd reaches the linears; the sampling core
             # and its backward are still the HIP kernels (MultiScaleDeformableAttnFunction)
@@ -238,9 +244,8 @@ class MultiScaleDeformableAttention(nn.Module):
         else:
             out = ops.msda_forward_fused(value.contiguous(), level_hw, level_start,
                                          offs_logits.contiguous(), ref_points, self.num_points)
-        with runtime.autocast():
-            out = self.output_proj(out)
-        return src + self.dropout(out.float())
+        out = runtime.linear(out, self.output_proj.weight, self.output_proj.bias)
+        return src + self.dropout(out)
 
     # -- [3P] signature (seq-first unless batch_first); differentiable through the HIP autograd op --
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
@@ -528,5 +533,5 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 y = self.output_convs[i](y)
             outs.append(y.float())
         with runtime.autocast():
-            mask_feature = self.mask_feature(outs[-1])
+            mask_feature = self.mask_feature(outs[-1].contiguous())
         return mask_feature.float(), outs[:self.num_outs]

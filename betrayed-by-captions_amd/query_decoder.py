@@ -22,6 +22,32 @@ from .pixel_decoder import BaseTransformerLayer, TransformerLayerSequence, build
 from .registry import ATTENTION, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 
 
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def small_linear(x, weight, bias=None, relu=False, res=None, out=None):
+    """Query-side linear (M = B*Q rows): the HIP skinny-GEMM kernel at inference; torch (autograd) in training."""
+    if _needs_grad(x, weight, bias, res):
+        y = F.linear(x, weight, bias)
+        if relu:
+            y = F.relu(y)
+        if res is not None:
+            y = y + res
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    return ops.linear_rows(x.float(), weight, bias, relu=relu, res=res, split=not runtime.is_bf16(), out=out)
+
+
+def residual_layernorm(x, res, norm):
+    """LayerNorm(x (+ res)) with nn.LayerNorm parameters."""
+    if _needs_grad(x, res, norm.weight):
+        return norm(x if res is None else x + res)
+    return ops.add_layernorm(x, res, norm.weight, norm.bias, norm.eps)
+
+
 def pack_bool_mask(mask):
     """bool (..., S) -> int32 bits (..., ceil(S/32)); bit i of word w = mask[32*w + i]. (torch ops)"""
     S = mask.shape[-1]
@@ -71,29 +97,29 @@ class MultiheadAttention(nn.Module):
             bias = torch.cat([kbias + b_kv[:E], b_kv[E:].expand(kbias.shape[0], E)], 1)  # (S,2C)
         else:
             bias = b_kv
-        with runtime.autocast():
-            kv = F.linear(mem, w_kv)
-        return (kv.float() + bias).contiguous()
+        kv = runtime.linear(mem, w_kv)
+        return (kv + bias).contiguous()
 
     def attend(self, query, query_pos, kv, bits):
         """query (B,Q,C) (+ query_pos) against projected kv; returns identity + out_proj(core)."""
         E = self.embed_dims
         q_in = query if query_pos is None else query + query_pos
-        q = F.linear(q_in, self.attn.in_proj_weight[:E], self.attn.in_proj_bias[:E])
+        q = small_linear(q_in, self.attn.in_proj_weight[:E], self.attn.in_proj_bias[:E])
         core = _xattn(q.contiguous(), kv, bits, self.num_heads)
-        out = F.linear(core, self.attn.out_proj.weight, self.attn.out_proj.bias)
-        return query + self.dropout_layer(self.proj_drop(out))
+        out = small_linear(core, self.attn.out_proj.weight, self.attn.out_proj.bias, res=query)
+        return out
 
     def self_attend(self, query, query_pos):
         E = self.embed_dims
         qk_in = query if query_pos is None else query + query_pos
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        qk = F.linear(qk_in, w[:2 * E], b[:2 * E])
-        v = F.linear(query, w[2 * E:], b[2 * E:])
-        kv = torch.cat([qk[..., E:], v], -1).contiguous()
-        core = _xattn(qk[..., :E].contiguous(), kv, None, self.num_heads)
-        out = F.linear(core, self.attn.out_proj.weight, self.attn.out_proj.bias)
-        return query + self.dropout_layer(self.proj_drop(out))
+        B, Q, _ = query.shape
+        q = small_linear(qk_in, w[:E], b[:E])
+        kv = torch.empty((B, Q, 2 * E), dtype=torch.float32, device=query.device)
+        small_linear(qk_in, w[E:2 * E], b[E:2 * E], out=kv.view(B * Q, 2 * E)[:, :E])
+        small_linear(query, w[2 * E:], b[2 * E:], out=kv.view(B * Q, 2 * E)[:, E:])
+        core = _xattn(q.contiguous(), kv, None, self.num_heads)
+        return small_linear(core, self.attn.out_proj.weight, self.attn.out_proj.bias, res=query)
 
     # ---- [3P] signature ----
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
@@ -194,13 +220,16 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         assert set(operation_order) == set(['self_attn', 'norm', 'cross_attn', 'ffn'])
 
     def forward_fast(self, query, query_pos, kv, bits):
-        """('cross_attn','norm','self_attn','norm','ffn','norm') on batch-first tensors."""
-        query = self.attentions[0].attend(query, query_pos, kv, bits)
-        query = self.norms[0](query)
-        query = self.attentions[1].self_attend(query, query_pos)
-        query = self.norms[1](query)
-        query = self.ffns[0](query)
-        return self.norms[2](query)
+        """('cross_attn','norm','self_attn','norm','ffn','norm') on batch-first tensors (dropouts are 0)."""
+        query = residual_layernorm(self.attentions[0].attend(query, query_pos, kv, bits), None, self.norms[0])
+        query = residual_layernorm(self.attentions[1].self_attend(query, query_pos), None, self.norms[1])
+        ffn = self.ffns[0]
+        if len(ffn.layers) == 3 and isinstance(ffn.layers[0][1], nn.ReLU) and ffn.add_identity:
+            h = small_linear(query, ffn.layers[0][0].weight, ffn.layers[0][0].bias, relu=True)
+            x = small_linear(h, ffn.layers[1].weight, ffn.layers[1].bias, res=query)
+        else:
+            x = ffn(query)
+        return residual_layernorm(x, None, self.norms[2])
 
 
 @TRANSFORMER_LAYER_SEQUENCE.register_module()

@@ -43,3 +43,30 @@ def autocast():
     if is_bf16():
         return torch.autocast(device_type='cuda', dtype=torch.bfloat16)
     return contextlib.nullcontext()
+
+
+_WCACHE = {}
+
+
+def cast_cached(p, dtype=torch.bfloat16):
+    """bf16 copy of a parameter, re-made only when the parameter changes (inference: made once)."""
+    key = (id(p), dtype)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == p._version and hit[1].device == p.device:
+        return hit[1]
+    t = p.detach().to(dtype)
+    _WCACHE[key] = (p._version, t)
+    return t
+
+
+def linear(x, weight, bias=None):
+    """Large-M library GEMM (hipBLASLt): f32 in parity mode, bf16 operands (f32 accumulate) in throughput
+    mode with the bf16 weight copy cached. Returns f32."""
+    import torch.nn.functional as F
+    if is_bf16() and not (torch.is_grad_enabled() and weight.requires_grad):
+        y = F.linear(x.to(torch.bfloat16), cast_cached(weight), cast_cached(bias) if bias is not None else None)
+        return y.float()
+    if is_bf16():
+        with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+            return F.linear(x, weight, bias).float()
+    return F.linear(x, weight, bias)

@@ -157,6 +157,20 @@ int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bit
                              int kv_dtype, cgg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K7/K11  Skinny linear + fused residual LayerNorm for the QUERY side of the decoder (M = B*Q ~ 200 rows):
+ * the q / out / self-attention projections and FFN of DetrTransformerDecoderLayer ([3P], called at
+ * open_set/models/mask2former_head.py:829-840) and the cls / v2l / mask_embed MLPs of forward_head (:734-746).
+ *   y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ res)      x row stride ldx, y row stride ldy, res stride ldr
+ *   relu != 0 applies ReLU before the residual add; split != 0 -> f32-class accuracy (3 bf16 MFMAs).
+ * Requires K % 16 == 0, ldx % 4 == 0.
+ * cgg_add_layernorm: y = LayerNorm(a (+ b)) * gamma + beta over the last dim N (b nullable).
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_linear_rows(const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr,
+                    float* y, int ldy, int M, int N, int K, int relu, int split, cgg_stream_t stream);
+int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* y,
+                      int rows, int N, float eps, cgg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K19  Inference tail.
  *
  * cgg_upsample_bilinear: F.interpolate(x, (h, w), 'bilinear', align_corners=False) for

@@ -328,6 +328,8 @@ class OracleHead(nn.Module):
                 emb = emb / emb.norm(dim=-1, keepdim=True)
         mask_pred = torch.einsum('bqc,bchw->bqhw', self.mask_embed(decoder_out), mask_feature)
         am = F.interpolate(mask_pred, size, mode='bilinear', align_corners=False)
+        if getattr(self, 'trace', None) is not None:      # test hook: resized logits + mask before the fix-up
+            self.trace['attn_logits'].append(am.flatten(2).detach().clone())
         am = am.flatten(2).unsqueeze(1).repeat((1, self.num_heads, 1, 1)).flatten(0, 1)
         return cls_pred, emb, mask_pred, (am.sigmoid() < 0.5).detach()
 

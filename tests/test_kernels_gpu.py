@@ -282,3 +282,40 @@ def test_rowwise_softmax_argmax(dev):
     assert (prob.cpu() - want).abs().max().item() <= 1e-6
     assert torch.equal(arg.cpu(), warg)
     assert (maxv.cpu() - wmax).abs().max().item() <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,K,N', [(200, 256, 256), (200, 256, 2048), (200, 2048, 256), (37, 256, 50), (300, 768, 768)])
+def test_linear_rows(dev, M, K, N):
+    g = torch.Generator().manual_seed(40)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    want = torch.relu(x.double() @ w.double().t() + b.double()) + r.double()
+    got = ops.linear_rows(x.to(dev), w.to(dev), b.to(dev), relu=True, res=r.to(dev), split=True).cpu()
+    assert (got.double() - want).abs().max().item() <= 1e-4     # f32-class (3x bf16 MFMA on split operands)
+    got16 = ops.linear_rows(x.to(dev), w.to(dev), b.to(dev), relu=False, res=None, split=False).cpu()
+    want16 = x.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+    assert (got16.double() - want16).abs().max().item() <= 1e-3
+    # strided output view (writes one half of a wider buffer)
+    buf = torch.zeros(M, 2 * N, device=dev)
+    ops.linear_rows(x.to(dev), w.to(dev), b.to(dev), split=True, out=buf[:, N:])
+    assert (buf[:, N:].cpu().double() - (x.double() @ w.double().t() + b.double())).abs().max().item() <= 1e-4
+    assert buf[:, :N].abs().max().item() == 0
+
+
+def test_add_layernorm(dev):
+    g = torch.Generator().manual_seed(41)
+    a = torch.randn(2, 100, 256, generator=g)
+    b = torch.randn(2, 100, 256, generator=g)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(256, generator=g))
+        ln.bias.copy_(torch.randn(256, generator=g))
+        want = ln(a + b)
+        want1 = ln(a)
+    got = ops.add_layernorm(a.to(dev), b.to(dev), ln.weight.to(dev), ln.bias.to(dev), ln.eps).cpu()
+    got1 = ops.add_layernorm(a.to(dev), None, ln.weight.to(dev), ln.bias.to(dev), ln.eps).cpu()
+    assert (got - want).abs().max().item() <= 1e-5
+    assert (got1 - want1).abs().max().item() <= 1e-5

@@ -53,3 +53,43 @@ def build_heads(cfg, seed=0):
         orc = OH.OracleHead(**hc)
     orc.load_state_dict(prod.state_dict())
     return prod.eval(), orc.eval()
+
+
+class MaskTeacher:
+    """Tie-aware parity harness for the decoder loop.
+
+    The attention mask is `resized logit < 0`: a logit within rounding distance of 0 may legitimately fall
+    on either side on different hardware, and one flipped key changes everything downstream. So parity is
+    split in two checks: (1) the product's own mask bits equal the oracle's wherever the oracle's logit is
+    farther than `margin` from 0; (2) with the ORACLE's masks injected into the product's decoder loop, every
+    output matches within the stated tolerance."""
+
+    def __init__(self, oracle_head, margin=1e-3):
+        self.orc = oracle_head
+        self.margin = margin
+        self.seen = []
+
+    def run_oracle(self, fn):
+        self.orc.trace = dict(attn_logits=[])
+        try:
+            out = fn()
+        finally:
+            self.logits = self.orc.trace['attn_logits']
+            self.orc.trace = None
+        return out
+
+    def hook(self, layer_idx, bits):
+        from cgg_amd.query_decoder import pack_bool_mask
+        from cgg_amd import ops
+        lg = self.logits[layer_idx]                       # (B, Q, S) oracle resized logits
+        S = lg.shape[-1]
+        mine = ops.unpack_bits(bits, S).cpu()
+        want = lg < 0
+        clear = lg.abs() > self.margin
+        self.seen.append((bool(torch.equal(mine[clear], want[clear])), float(clear.float().mean())))
+        return pack_bool_mask(want).to(bits.device).contiguous()
+
+    def check(self):
+        assert self.seen, 'hook never called'
+        assert all(ok for ok, _ in self.seen), self.seen
+        assert min(frac for _, frac in self.seen) > 0.98, self.seen
