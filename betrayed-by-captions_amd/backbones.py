@@ -138,7 +138,63 @@ class ResNet(nn.Module):
                     m.eval()
         return self
 
+    # ---- throughput-mode inference: BN folded into the convolutions, bf16 NHWC filters kept resident ----
+    def _folded(self):
+        """[(w, b)] per conv in execution order, bf16 channels_last, frozen BN folded in
+        (w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)). Rebuilt when any
+        parameter / buffer version changes."""
+        key = sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+        hit = self.__dict__.get('_fold_cache')
+        if hit is not None and hit[0] == key and hit[1][0][0].device == self.conv1.weight.device:
+            return hit[1]
+
+        def fold(conv, bn):
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            w = (conv.weight.detach().float() * s.view(-1, 1, 1, 1)).to(torch.bfloat16)
+            b = (bn.bias.detach().float() - bn.running_mean.detach().float() * s).to(torch.bfloat16)
+            return w.contiguous(memory_format=torch.channels_last), b
+
+        seq = [fold(self.conv1, self.bn1)]
+        for name in self.res_layers:
+            for blk in getattr(self, name):
+                if blk.downsample is not None:
+                    seq.append(fold(blk.downsample[0], blk.downsample[1]))
+                seq.append(fold(blk.conv1, blk.bn1))
+                seq.append(fold(blk.conv2, blk.bn2))
+                if isinstance(blk, Bottleneck):
+                    seq.append(fold(blk.conv3, blk.bn3))
+        self.__dict__['_fold_cache'] = (key, seq)
+        return seq
+
+    def _forward_folded(self, x):
+        import torch.nn.functional as F
+        seq = iter(self._folded())
+        x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last)
+        w, b = next(seq)
+        x = F.max_pool2d(F.relu_(F.conv2d(x, w, b, stride=2, padding=3)), 3, stride=2, padding=1)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk in getattr(self, name):
+                identity = x
+                if blk.downsample is not None:
+                    w, b = next(seq)
+                    identity = F.conv2d(x, w, b, stride=blk.downsample[0].stride)
+                w, b = next(seq)
+                y = F.relu_(F.conv2d(x, w, b, stride=blk.conv1.stride, padding=blk.conv1.padding))
+                w, b = next(seq)
+                y = F.conv2d(y, w, b, stride=blk.conv2.stride, padding=blk.conv2.padding)
+                if isinstance(blk, Bottleneck):
+                    w, b = next(seq)
+                    y = F.conv2d(F.relu_(y), w, b)
+                x = F.relu_(y + identity)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(o.float().contiguous() for o in outs)
+
     def forward(self, x):
+        frozen_bn = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        if runtime.is_bf16() and not torch.is_grad_enabled() and frozen_bn:
+            return self._forward_folded(x)
         outs = []
         with runtime.autocast():
             if runtime.is_bf16():

@@ -59,15 +59,43 @@ __device__ __forceinline__ MsdaTap cgg_msda_tap(float x, float y, int Hl, int Wl
   return t;
 }
 
+// per-lane channel slice: 16 bytes of the value row -> CPL = 4 (f32) or 8 (bf16) channels
+template <typename VT> struct MsdaVec;
+template <> struct MsdaVec<float> {
+  static constexpr int CPL = 4;
+  __device__ static __forceinline__ void fma(float (&acc)[4], float w, const float* p) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, v[c], acc[c]);
+  }
+};
+template <> struct MsdaVec<uint16_t> {
+  static constexpr int CPL = 8;
+  __device__ static __forceinline__ void fma(float (&acc)[8], float w, const uint16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t q[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[2 * c] = fmaf(w, __uint_as_float(q[c] << 16), acc[2 * c]);
+      acc[2 * c + 1] = fmaf(w, __uint_as_float(q[c] & 0xffff0000u), acc[2 * c + 1]);
+    }
+  }
+};
+
 // FUSED: offs_logits row = [H*L*P*2 raw offsets | H*L*P raw logits]; loc = ref + off/(W_l,H_l),
 // weights = softmax over L*P. Otherwise loc/attw are given (mmcv boundary).
-template <typename VT, int P_, bool FUSED>
+// P_ > 0: compile-time points per level: the P_*4 corner loads of one level are issued together (16 x 16 B
+// in flight per lane); the level loop stays rolled so the register footprint (~100 VGPR) keeps >= 4
+// waves per SIMD resident -- a fully unrolled 48-load body needs 256 VGPRs and halves the throughput.
+template <typename VT, int L_, int P_, bool FUSED>
 __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
     const VT* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ ref, int ld,
-    float* __restrict__ out, int Nv, int H, int D, int L, int Nq, int Prt, long long total) {
+    float* __restrict__ out, int Nv, int H, int D, int Lrt, int Nq, int Prt, long long total) {
+  constexpr int CPL = MsdaVec<VT>::CPL;
+  const int L = L_ > 0 ? L_ : Lrt;
   const int P = P_ > 0 ? P_ : Prt;
-  const int DQ = D >> 2;
+  const int DQ = D / CPL;
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
   const long long gid = (long long)bid * 256 + threadIdx.x;
   if (gid >= total) return;
@@ -77,7 +105,7 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
   const int b = (int)(bq / Nq);
   const int q = (int)(bq - (long long)b * Nq);
   const size_t rowstride = (size_t)H * D;
-  const VT* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * 4;
+  const VT* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
   const int LP = L * P;
 
   const float* lp;
@@ -99,29 +127,41 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
     wp = attw + ((size_t)bq * H + h) * LP;
   }
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+
+#pragma unroll 1
   for (int l = 0; l < L; ++l) {
     const int Hl = lv.h[l], Wl = lv.w[l];
     const VT* vl = vb + (size_t)lv.start[l] * rowstride;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int i = l * P + p;
-      float x = lp[2 * i], y = lp[2 * i + 1], w = wp[i];
-      if (FUSED) {
-        x = rx + x / (float)Wl;
-        y = ry + y / (float)Hl;
-        w = expf(w - smax) * sinv;
+    for (int p = 0; p < (P_ > 0 ? P_ : 1); ++p) {
+      for (int pp = (P_ > 0 ? p : 0); pp < (P_ > 0 ? p + 1 : P); ++pp) {
+        const int i = l * P + pp;
+        float x = lp[2 * i], y = lp[2 * i + 1], w = wp[i];
+        if (FUSED) {
+          x = rx + x / (float)Wl;
+          y = ry + y / (float)Hl;
+          w = expf(w - smax) * sinv;
+        }
+        const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
+        float s[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) s[c] = 0.f;
+        MsdaVec<VT>::fma(s, t.w00, vl + (size_t)t.o00 * rowstride);
+        MsdaVec<VT>::fma(s, t.w01, vl + (size_t)t.o01 * rowstride);
+        MsdaVec<VT>::fma(s, t.w10, vl + (size_t)t.o10 * rowstride);
+        MsdaVec<VT>::fma(s, t.w11, vl + (size_t)t.o11 * rowstride);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = fmaf(w, s[c], acc[c]);
       }
-      const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
-      const f32x4 v00 = cgg_ld4(vl + (size_t)t.o00 * rowstride);
-      const f32x4 v01 = cgg_ld4(vl + (size_t)t.o01 * rowstride);
-      const f32x4 v10 = cgg_ld4(vl + (size_t)t.o10 * rowstride);
-      const f32x4 v11 = cgg_ld4(vl + (size_t)t.o11 * rowstride);
-      const f32x4 s = t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
-      acc += w * s;
     }
   }
-  *reinterpret_cast<f32x4*>(out + (size_t)bq * rowstride + (size_t)h * D + cq * 4) = acc;
+  float* op = out + (size_t)bq * rowstride + (size_t)h * D + cq * CPL;
+#pragma unroll
+  for (int c = 0; c < CPL; c += 4)
+    *reinterpret_cast<f32x4*>(op + c) = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
 }
 
 // Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
@@ -263,17 +303,19 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
 static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float* loc,
                            const float* attw, const float* ref, int ld, float* out, int B, int Nv,
                            int H, int D, int L, int Nq, int P, int dtype, bool fused, hipStream_t s) {
-  const long long total = (long long)B * Nq * H * (D / 4);
+  const int cpl = dtype == CGG_F32 ? 4 : 8;
+  const long long total = (long long)B * Nq * H * (D / cpl);
   const int nblk = (int)((total + 255) / 256);
-#define CGG_MSDA_LAUNCH(VT, PT, FU)                                                              \
-  hipLaunchKernelGGL((cgg_msda_fwd_kernel<VT, PT, FU>), dim3(nblk), dim3(256), 0, s,             \
+#define CGG_MSDA_LAUNCH(VT, LT, PT, FU)                                                          \
+  hipLaunchKernelGGL((cgg_msda_fwd_kernel<VT, LT, PT, FU>), dim3(nblk), dim3(256), 0, s,         \
                      (const VT*)value, lv, loc, attw, ref, ld, out, Nv, H, D, L, Nq, P, total)
+  const bool st = (L == 3 && P == 4);  // the shipped configs: num_levels=3, num_points=4
   if (dtype == CGG_F32) {
-    if (fused) { if (P == 4) CGG_MSDA_LAUNCH(float, 4, true); else CGG_MSDA_LAUNCH(float, 0, true); }
-    else       { if (P == 4) CGG_MSDA_LAUNCH(float, 4, false); else CGG_MSDA_LAUNCH(float, 0, false); }
+    if (fused) { if (st) CGG_MSDA_LAUNCH(float, 3, 4, true); else CGG_MSDA_LAUNCH(float, 0, 0, true); }
+    else       { if (st) CGG_MSDA_LAUNCH(float, 3, 4, false); else CGG_MSDA_LAUNCH(float, 0, 0, false); }
   } else {
-    if (fused) { if (P == 4) CGG_MSDA_LAUNCH(uint16_t, 4, true); else CGG_MSDA_LAUNCH(uint16_t, 0, true); }
-    else       { if (P == 4) CGG_MSDA_LAUNCH(uint16_t, 4, false); else CGG_MSDA_LAUNCH(uint16_t, 0, false); }
+    if (fused) { if (st) CGG_MSDA_LAUNCH(uint16_t, 3, 4, true); else CGG_MSDA_LAUNCH(uint16_t, 0, 0, true); }
+    else       { if (st) CGG_MSDA_LAUNCH(uint16_t, 3, 4, false); else CGG_MSDA_LAUNCH(uint16_t, 0, 0, false); }
   }
 #undef CGG_MSDA_LAUNCH
   CGG_CHECK_LAUNCH("cgg_msda_forward");
@@ -285,7 +327,8 @@ static int msda_check(const char* who, const void* value, const void* a, const v
   CGG_REQUIRE(value && a && b_ && o, CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(B > 0 && Nv > 0 && H > 0 && D > 0 && L > 0 && Nq > 0 && P > 0, CGG_EINVAL,
               "%s: bad sizes", who);
-  CGG_REQUIRE(D % 4 == 0, CGG_EUNSUPPORTED, "%s: head dim D=%d must be a multiple of 4", who, D);
+  CGG_REQUIRE(D % (dtype == CGG_F32 ? 4 : 8) == 0, CGG_EUNSUPPORTED,
+              "%s: head dim D=%d must be a multiple of 4 (f32) / 8 (bf16)", who, D);
   CGG_REQUIRE(L <= 8, CGG_EUNSUPPORTED, "%s: L=%d levels (max 8)", who, L);
   CGG_REQUIRE(dtype == CGG_F32 || dtype == CGG_BF16, CGG_EUNSUPPORTED, "%s: dtype %d", who, dtype);
   CGG_REQUIRE(cgg_aligned16(value) && cgg_aligned16(o), CGG_EALIGN, "%s: value/out must be 16-B aligned", who);

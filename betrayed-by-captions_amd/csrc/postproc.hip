@@ -155,6 +155,92 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __
   }
 }
 
+// Fast path: one-stage resize by an INTEGER factor S (up == S * low-res, out == crop, out_w % 16 == 0).
+// src = (o + .5)/S - .5: the tap indices / fractions repeat with period S, so a thread that owns 16
+// consecutive output pixels needs only 16/S + 2 source columns of two source rows (12 loads for S = 4
+// instead of 64) and compile-time weights. Same association order as torch:
+// hy*(hx*a + lx*b) + ly*(hx*c + lx*d).
+template <int S>
+__global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float* __restrict__ logits,
+                                                                     const int32_t* __restrict__ sel,
+                                                                     uint8_t* __restrict__ masks,
+                                                                     int32_t* __restrict__ ws,
+                                                                     ResizeGeom g) {
+  constexpr int NC = IM_PPT / S + 2;  // source columns per thread
+  const int i = blockIdx.y;
+  const long long npix = (long long)g.out_h * g.out_w;
+  const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * IM_PPT;
+  const float* s = logits + (size_t)sel[i] * g.H * g.W;
+  float sig = 0.f;
+  int cnt = 0, xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
+  if (p0 < npix) {
+    const int oy = (int)(p0 / g.out_w), ox0 = (int)(p0 - (long long)oy * g.out_w);
+    const BiTap ty = cgg_bitap(oy, g.s1y, g.H);
+    const int m0 = ox0 / S;
+    float r0[NC], r1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = min(max(m0 - 1 + c, 0), g.W - 1);
+      r0[c] = s[(size_t)ty.i0 * g.W + col];
+      r1[c] = s[(size_t)ty.i1 * g.W + col];
+    }
+    uint32_t packed[IM_PPT / 4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < IM_PPT; ++k) {
+      constexpr float inv = 1.f / (float)S;
+      const int r = k % S, mrel = k / S;              // ox = S*(m0 + mrel) + r
+      const bool lowhalf = (2 * r + 1) < S;           // src < m  -> taps (m-1, m)
+      const int c0 = mrel + (lowhalf ? 0 : 1);        // index into r0/r1 (column m0-1+c0)
+      float l1 = ((float)r + 0.5f) * inv + (lowhalf ? 0.5f : -0.5f);
+      if (lowhalf && m0 + mrel == 0) l1 = 0.f;        // left border: src clamps to 0 (torch: lambda = 0)
+      const float l0 = 1.f - l1;
+      const float v = ty.l0 * (l0 * r0[c0] + l1 * r0[c0 + 1]) + ty.l1 * (l0 * r1[c0] + l1 * r1[c0 + 1]);
+      if (v > 0.f) {
+        const int ox = ox0 + k;
+        packed[k >> 2] |= 1u << (8 * (k & 3));
+        sig += cgg_sigmoid(v);
+        cnt += 1;
+        xmin = min(xmin, ox); xmax = max(xmax, ox);
+        ymin = min(ymin, oy); ymax = max(ymax, oy);
+      }
+    }
+    *reinterpret_cast<uint4*>(masks + (size_t)i * npix + p0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sig += __shfl_xor(sig, o);
+    cnt += __shfl_xor(cnt, o);
+    xmin = min(xmin, __shfl_xor(xmin, o));
+    ymin = min(ymin, __shfl_xor(ymin, o));
+    xmax = max(xmax, __shfl_xor(xmax, o));
+    ymax = max(ymax, __shfl_xor(ymax, o));
+  }
+  __shared__ float s_sig[4];
+  __shared__ int s_i[4][5];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_sig[wave] = sig;
+    s_i[wave][0] = cnt; s_i[wave][1] = xmin; s_i[wave][2] = ymin; s_i[wave][3] = xmax; s_i[wave][4] = ymax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      sig += s_sig[w];
+      cnt += s_i[w][0];
+      xmin = min(xmin, s_i[w][1]); ymin = min(ymin, s_i[w][2]);
+      xmax = max(xmax, s_i[w][3]); ymax = max(ymax, s_i[w][4]);
+    }
+    if (cnt > 0) {
+      int32_t* w = ws + (size_t)i * 8;
+      atomicAdd(reinterpret_cast<float*>(w), sig);
+      atomicAdd(w + 1, cnt);
+      atomicMin(w + 2, xmin);
+      atomicMin(w + 3, ymin);
+      atomicMax(w + 4, xmax);
+      atomicMax(w + 5, ymax);
+    }
+  }
+}
+
 __global__ void cgg_instance_init_kernel(int32_t* __restrict__ ws, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -293,8 +379,18 @@ extern "C" int cgg_instance_masks(const float* logits, const int32_t* sel, uint8
   hipLaunchKernelGGL(cgg_instance_init_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (int32_t*)ws, n);
   const long long npix = (long long)out_h * out_w;
   const long long per_block = 256LL * IM_PPT;
-  hipLaunchKernelGGL(cgg_instance_masks_kernel, dim3((unsigned)((npix + per_block - 1) / per_block), n),
-                     dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+  const dim3 grid((unsigned)((npix + per_block - 1) / per_block), n);
+  const int S = up_h / H;
+  const bool int_path = !g.two_stage && S * H == up_h && S * W == up_w && (out_w % IM_PPT) == 0 &&
+                        (((uintptr_t)masks) & 15) == 0;
+  if (int_path && S == 4)
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+  else if (int_path && S == 2)
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+  else if (int_path && S == 8)
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+  else
+    hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
   hipLaunchKernelGGL(cgg_instance_final_kernel, dim3((n + 63) / 64), dim3(64), 0, s,
                      (const int32_t*)ws, mask_score, bbox, n);
   CGG_CHECK_LAUNCH("cgg_instance_masks");

@@ -373,3 +373,18 @@ def add_layernorm(a, b, gamma, beta, eps=1e-5):
                                    dev_ptr(y), a2.numel() // N, N, float(eps), stream_ptr(a.device))
     check(rc, 'cgg_add_layernorm')
     return y
+
+
+def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
+    """x (B,C,H,W) f32 NCHW -> GroupNorm(groups)(x) (* gamma + beta) (+ ReLU)."""
+    B, C, H, W = x.shape
+    x = x.contiguous()
+    lib = _lib_()
+    nbytes = lib.cgg_group_norm_workspace_bytes(B, C, H, W, int(groups))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    rc = lib.cgg_group_norm(dev_ptr(x, 'x', torch.float32), dev_ptr(gamma, 'gamma', torch.float32),
+                            dev_ptr(beta, 'beta', torch.float32), dev_ptr(y), dev_ptr(ws), B, C, H, W,
+                            int(groups), float(eps), 1 if relu else 0, stream_ptr(x.device))
+    check(rc, 'cgg_group_norm')
+    return y

@@ -76,8 +76,16 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         x = self.conv(x.contiguous())
-        if self.norm_name is not None:
-            x = getattr(self, self.norm_name)(x.float())
+        norm = getattr(self, self.norm_name) if self.norm_name is not None else None
+        if isinstance(norm, nn.GroupNorm) and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
+            # inference: HIP GroupNorm (+ fused ReLU), full-chip two-pass reduction
+            relu = isinstance(self.activate, nn.ReLU)
+            x = ops.group_norm(x.float(), norm.weight, norm.bias, norm.num_groups, norm.eps, relu)
+            if self.activate is not None and not relu:
+                x = self.activate(x)
+            return x
+        if norm is not None:
+            x = norm(x.float())
         if self.activate is not None:
             x = self.activate(x)
         return x

@@ -170,6 +170,14 @@ int cgg_linear_rows(const float* x, int ldx, const float* w, const float* bias, 
 int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* y,
                       int rows, int N, float eps, cgg_stream_t stream);
 
+/* K9  GroupNorm (+ optional ReLU) of the pixel decoder ConvModules ([3P] MSDeformAttnPixelDecoder,
+ * norm_cfg=dict(type='GN', num_groups=32), configs/instance/coco_b48n17.py:40).
+ *   x, y [B, C, H, W] f32 NCHW; gamma, beta [C]; ws = cgg_group_norm_workspace_bytes(...) bytes.
+ * Requires C % groups == 0 (float4 path when H*W % 4 == 0).                                                    */
+int64_t cgg_group_norm_workspace_bytes(int B, int C, int H, int W, int groups);
+int cgg_group_norm(const float* x, const float* gamma, const float* beta, float* y, void* ws, int B, int C,
+                   int H, int W, int groups, float eps, int relu, cgg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K19  Inference tail.
  *

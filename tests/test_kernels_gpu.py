@@ -319,3 +319,40 @@ def test_add_layernorm(dev):
     got1 = ops.add_layernorm(a.to(dev), None, ln.weight.to(dev), ln.bias.to(dev), ln.eps).cpu()
     assert (got - want).abs().max().item() <= 1e-5
     assert (got1 - want1).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize('shape,relu', [((2, 256, 64, 64), False), ((1, 64, 20, 28), True), ((2, 256, 8, 8), False), ((1, 64, 5, 7), True)])
+def test_group_norm(dev, shape, relu):
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(shape, generator=g) * 3 + 1
+    gn = torch.nn.GroupNorm(32, shape[1])
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(shape[1], generator=g))
+        gn.bias.copy_(torch.randn(shape[1], generator=g))
+        want = gn(x)
+        if relu:
+            want = want.relu()
+    got = ops.group_norm(x.to(dev), gn.weight.to(dev), gn.bias.to(dev), 32, gn.eps, relu).cpu()
+    assert (got - want).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize('H,W,S,crop', [(32, 48, 4, None), (16, 16, 8, (120, 112)), (40, 24, 2, None), (25, 42, 4, (97, 160))])
+def test_instance_masks_integer_fast_path_matches_torch(dev, H, W, S, crop):
+    """fused upsample -> (>0) -> mask score -> bbox vs the reference formulation (F.interpolate + torch ops)."""
+    from oracle import head as OH
+    g = torch.Generator().manual_seed(43)
+    Q = 12
+    logits = torch.randn(Q, H, W, generator=g) * 3
+    up = (H * S, W * S)
+    crop = crop or up
+    sel = torch.tensor([3, 0, 7, 7, 11, 2], dtype=torch.int32)
+    masks, score, bbox = ops.instance_masks(logits.to(dev), sel.to(dev), up, crop, crop)
+    ref_up = torch.nn.functional.interpolate(logits[None], up, mode='bilinear', align_corners=False)[0]
+    ref_up = ref_up[:, :crop[0], :crop[1]][sel.long()]
+    wbin = ref_up > 0
+    near = ref_up.abs() < 1e-5
+    assert torch.equal(masks.cpu()[~near], wbin[~near])
+    wscore = (ref_up.sigmoid() * wbin).flatten(1).sum(1) / (wbin.flatten(1).sum(1) + 1e-6)
+    assert (score.cpu() - wscore).abs().max().item() <= 1e-5
+    if not near.any():
+        assert torch.equal(bbox.cpu(), OH.mask2bbox(wbin))
