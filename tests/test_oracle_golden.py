@@ -1,0 +1,232 @@
+"""CPU tests (-m "not gpu"): the oracle -- and the product's pure-host logic (losses, assigner, caption
+transformer, target / loss assembly) -- against the golden vectors produced by executing the reference's own
+files (tests/golden/make_golden.py). This is what PINS the oracle."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cgg_amd  # noqa: F401
+from cgg_amd import caption_transformer as P_ct
+from cgg_amd import losses as P_losses
+from cgg_amd import registry
+from cgg_amd.bert_embeddings import BertEmbeddings as P_Bert
+from oracle import head as OH
+
+from util import g4_inputs, g6_inputs, g7_inputs, head_cfg, randomize
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def gold(name):
+    z = np.load(os.path.join(GOLD, name), allow_pickle=False)
+    return {k: torch.from_numpy(z[k]) if z[k].dtype.kind in 'fiub' and z[k].shape != () else z[k] for k in z.files}
+
+
+# ---- G1 ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B', [1, 2, 4])
+def test_g1_grounding_loss(B):
+    z = gold('g1_grounding_loss.npz')
+    want = float(z[f'loss{B}'])
+    got_o = OH.grounding_loss(z[f'preds{B}'], z[f'embs{B}'], z[f'mask{B}'], 10.0)
+    got_p = P_losses.grounding_loss(z[f'preds{B}'], z[f'embs{B}'], z[f'mask{B}'], 10.0)
+    assert abs(float(got_o) - want) <= 1e-6 * max(1, abs(want))
+    assert abs(float(got_p) - want) <= 2e-5 * max(1, abs(want))   # one fused contraction vs B^2 bmm's
+    if B == 4:
+        assert int(z['mask4'][2].sum()) == 0                      # the zero-noun caption edge case is in there
+
+
+# ---- G2 ---------------------------------------------------------------------------------------------
+def test_g2_caption_transformer_and_bert_embeddings():
+    z = gold('g2_caption_transformer.npz')
+    cfg = json.loads(str(z['cfg']))
+    for cls in (OH.CaptionTransformer, P_ct.CaptionTransformer):
+        m = cls(**cfg).eval()
+        randomize(m, seed=int(z['seed']))
+        assert torch.allclose(m.position_encoder.psne_layer, z['psne'], atol=1e-6)
+        with torch.no_grad():
+            outs, logits = m(tgt=z['tgt'], memory=z['mem'], tgt_key_padding_mask=z['kpm'].bool())
+        assert (logits - z['logits']).abs().max().item() <= 1e-5, cls
+        assert (outs[-1] - z['last']).abs().max().item() <= 1e-5
+        assert (outs[0] - z['first']).abs().max().item() <= 1e-5
+    be = P_Bert(None, vocab_size=100, hidden_size=32)
+    with torch.no_grad():
+        be.word_embeddings.weight.copy_(z['bert_table'])
+        be.LayerNorm.weight.copy_(z['bert_ln_w'])
+        be.LayerNorm.bias.copy_(z['bert_ln_b'])
+        assert (be(z['bert_ids']) - z['bert_out']).abs().max().item() <= 1e-6
+    sd = P_ct.CaptionTransformer(**cfg).state_dict()
+    assert 'transformer_decoder.decoders.0.layer_normalz.mha.1.weight' in sd      # LN lives at index 1
+    assert sd['transformer_decoder.decoders.0.mha_layer.qkv_layer.weight'].shape == (3 * 64, 64)
+
+
+# ---- G3 / G4 ------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def oracle_head():
+    cfg, B, H, W, feats, metas, qf, mf = g4_inputs()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        orc = OH.OracleHead(**head_cfg(cfg)).eval()
+    randomize(orc, seed=0)
+    return cfg, orc
+
+
+def test_g4_oracle_head_forward_matches_reference(oracle_head):
+    cfg, orc = oracle_head
+    _, B, H, W, feats, metas, qf, mf = g4_inputs()
+    z = gold('g4_head_forward.npz')
+    with torch.no_grad():
+        c, e, m = orc.forward(feats, metas)
+        fc, fe, fm, fa = orc.forward_head(qf, mf, (4, 6))
+    assert (torch.stack(c) - z['cls']).abs().max().item() <= 1e-5
+    assert (torch.stack(e) - z['emb']).abs().max().item() <= 1e-5
+    assert (torch.stack(m) - z['mask']).abs().max().item() <= 1e-4
+    assert (fm - z['fh_mask']).abs().max().item() <= 1e-5
+    assert (fc - z['fh_cls']).abs().max().item() <= 1e-6 and (fe - z['fh_emb']).abs().max().item() <= 1e-6
+    assert torch.equal(fa, z['fh_attn'].bool())                   # (B*heads, Q, hw) attention mask, bit exact
+    assert fa.shape == (2 * 8, 8, 24)
+
+
+# ---- G5 / G6 ------------------------------------------------------------------------------------------
+class Replay:
+    """point_hook that replays the coordinates the reference drew (captured in the fixture)."""
+
+    def __init__(self, draws):
+        self.draws, self.i = draws, 0
+
+    def __call__(self, kind, shape, device):
+        d = self.draws[self.i]
+        self.i += 1
+        assert tuple(d.shape) == tuple(shape), (kind, d.shape, shape)
+        return d.to(device)
+
+
+def _product_head(cfg):
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ph = registry.build_head(head_cfg(cfg))
+    randomize(ph, seed=0)
+    return ph
+
+
+def test_g6_targets_and_losses_match_reference(oracle_head):
+    cfg, orc = oracle_head
+    _, B, H, W, feats, metas, _, _ = g4_inputs()
+    z = gold('g6_loss_single.npz')
+    g4 = gold('g4_head_forward.npz')
+    li = int(z['layer'])
+    cls, emb, mask = g4['cls'][li], g4['emb'][li], g4['mask'][li]
+    gt_labels, gt_masks, cap_ids, cap_mask, noun_ids, noun_mask = g6_inputs(H, W)
+    draws = [z[f'draw{i}'] for i in range(int(z['n_draws']))]
+    want = z['losses']
+
+    # oracle
+    orc.point_hook = Replay(draws)
+    orc.train()
+    for mod in orc.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    with torch.no_grad():
+        cap_embs, noun_embs = orc.word_embeddings(cap_ids), orc.word_embeddings(noun_ids)
+        got = orc.loss_single(cls, emb, mask, gt_labels, gt_masks, cap_ids, cap_embs, cap_mask, noun_embs, noun_mask)
+    got = torch.stack([g.reshape(()) for g in got])
+    assert (got - want).abs().max().item() <= 1e-5 * (1 + want.abs().max().item()), (got, want)
+    # one-image targets: indices bit exact
+    orc.point_hook = Replay([z['t_points']])
+    t = orc.get_target_single(cls[0], orc.cls_emb_logits(emb)[0], mask[0], gt_labels[0], gt_masks[0])
+    assert torch.equal(t[0], z['t_labels']) and torch.equal(t[4], z['t_pos']) and torch.equal(t[5], z['t_neg'])
+    assert torch.equal(t[3], z['t_mask_weights'])
+    orc.point_hook = None
+    orc.eval()
+
+    # product host logic (torch ops only: assigner, costs, losses, caption head) on the same tensors
+    ph = _product_head(cfg).train()
+    for mod in ph.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    ph.point_hook = Replay(draws)
+    with torch.no_grad():
+        pe, _ = ph.extract_word_embeddings(cap_ids, cap_mask, 'bert')
+        ne, _ = ph.extract_word_embeddings(noun_ids, noun_mask, 'bert')
+        pl = ph.loss_single(cls, emb, mask, gt_labels, gt_masks, [c.clone() for c in cap_ids], pe, cap_mask, noun_ids,
+                            ne, noun_mask, metas)
+    pl = torch.stack([g.reshape(()) for g in pl])
+    assert (pl - want).abs().max().item() <= 2e-5 * (1 + want.abs().max().item()), (pl, want)
+    ph.point_hook = Replay([z['t_points']])
+    pt = ph._get_target_single(cls[0], ph._get_cls_emb_logits(emb)[0], mask[0], gt_labels[0], gt_masks[0], metas)
+    assert torch.equal(pt[0], z['t_labels']) and torch.equal(pt[4], z['t_pos']) and torch.equal(pt[5], z['t_neg'])
+
+
+def test_loss_dict_keys_and_layer_batched_assignment(oracle_head):
+    """loss(): same keys / values as per-layer loss_single, with ONE batched Hungarian transfer."""
+    cfg, orc = oracle_head
+    _, B, H, W, feats, metas, _, _ = g4_inputs()
+    g4 = gold('g4_head_forward.npz')
+    gt_labels, gt_masks, cap_ids, cap_mask, noun_ids, noun_mask = g6_inputs(H, W)
+    ph = _product_head(cfg).train()
+    for mod in ph.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    n = g4['cls'].shape[0]
+    gen = torch.Generator().manual_seed(5)
+    P = ph.num_points
+    bank = {'target': [torch.rand(1, P, 2, generator=gen) for _ in range(n * B)],
+            'oversample': [torch.rand(3 + 2, 3 * P, 2, generator=gen) for _ in range(n)],
+            'random': [torch.rand(3 + 2, P - int(0.75 * P), 2, generator=gen) for _ in range(n)]}
+
+    def hook_factory():
+        idx = {k: 0 for k in bank}
+
+        def hook(kind, shape, device):
+            t = bank[kind][idx[kind]]
+            idx[kind] += 1
+            assert tuple(t.shape) == tuple(shape)
+            return t
+        return hook
+
+    with torch.no_grad():
+        ce, _ = ph.extract_word_embeddings(cap_ids, cap_mask, 'bert')
+        ne, _ = ph.extract_word_embeddings(noun_ids, noun_mask, 'bert')
+        ph.point_hook = hook_factory()
+        d = ph.loss(list(g4['cls']), list(g4['emb']), list(g4['mask']), gt_labels, gt_masks, cap_ids, ce, cap_mask,
+                    noun_ids, ne, noun_mask, metas)
+        ph.point_hook = hook_factory()
+        orc.point_hook = hook_factory()
+        orc.train()
+        for mod in orc.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        od = orc.loss(list(g4['cls']), list(g4['emb']), list(g4['mask']), gt_labels, gt_masks, cap_ids, cap_mask,
+                      noun_ids, noun_mask)
+        orc.point_hook = None
+        orc.eval()
+    names = ['loss_cls', 'loss_cls_emb', 'loss_grounding', 'loss_caption_generation', 'loss_caption_align',
+             'loss_mask', 'loss_dice']
+    assert list(d.keys())[:7] == names
+    assert set(d.keys()) == set(names) | {f'd{i}.{k}' for i in range(n - 1) for k in names}
+    for k in d:
+        assert abs(float(d[k]) - float(od[k])) <= 2e-5 * (1 + abs(float(od[k]))), (k, float(d[k]), float(od[k]))
+
+
+# ---- G7 ---------------------------------------------------------------------------------------------
+def test_g7_postprocess_oracle_matches_reference(oracle_head):
+    cfg, _ = oracle_head
+    z = gold('g7_postprocess.npz')
+    emb, mp, cls_embs, pemb = g7_inputs()
+    fcfg = dict(cfg['panoptic_fusion_head'])
+    fcfg.update(test_cfg=cfg['test_cfg'])
+    fh = registry.build_head(fcfg)            # buffers (class embedding tables) are host logic
+    for embs, suffix in ((fh.all_class_embs, ''), (fh.novel_class_embs, '_novel')):
+        lab, box, msk, qi, sc = OH.instance_postprocess_emb(emb, mp, embs, 20)
+        # top-k (sorted=False) order is unspecified: compare as sets keyed by (label, score)
+        o1 = torch.argsort(box[:, 4] * 1e3 + lab, stable=True)
+        o2 = torch.argsort(z['bboxes' + suffix][:, 4] * 1e3 + z['labels' + suffix], stable=True)
+        assert torch.equal(lab[o1], z['labels' + suffix][o2])
+        assert torch.allclose(box[o1], z['bboxes' + suffix][o2], atol=1e-6)
+        assert torch.equal(msk[o1], z['masks' + suffix][o2].bool())
+    pan = OH.panoptic_postprocess_emb(pemb, mp, cls_embs, 12, 8, 0.2, 0.5, True, 16)
+    assert torch.equal(pan, z['pan_seg'].to(torch.int32))
+    assert len(torch.unique(pan)) > 2

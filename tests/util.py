@@ -28,7 +28,9 @@ def randomize(module, seed=0, scale=None):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in sorted(module.named_parameters()):
-            if 'word_embeddings' in name:
+            if 'word_embeddings' in name:       # BERT table: N(0, 0.04^2), padding row 0 zero
+                p.copy_(torch.randn(p.shape, generator=g) * 0.04)
+                p[0].zero_()
                 continue
             if p.dim() > 1:
                 fan = p.shape[1] * (p[0][0].numel() if p.dim() > 2 else 1)
@@ -93,3 +95,52 @@ class MaskTeacher:
         assert self.seen, 'hook never called'
         assert all(ok for ok, _ in self.seen), self.seen
         assert min(frac for _, frac in self.seen) > 0.98, self.seen
+
+
+# ---- deterministic inputs shared by tests/golden/make_golden.py and the golden tests -----------------
+def g4_inputs():
+    """(cfg, B, H, W, feats, metas, fh_query, fh_feat) of the G3/G4 head fixtures."""
+    cfg = small_cfg(num_queries=8, vocab=120)
+    B, H, W = 2, 64, 96
+    g = torch.Generator().manual_seed(102)
+    feats = [torch.randn(B, c, H // s, W // s, generator=g) for c, s in zip((64, 128, 256, 512), (4, 8, 16, 32))]
+    metas = [dict(img_shape=(H, W, 3), ori_shape=(H, W, 3), pad_shape=(H, W, 3), batch_input_shape=(H, W))
+             for _ in range(B)]
+    qf = torch.randn(8, B, 256, generator=g)
+    mf = torch.randn(B, 256, 16, 24, generator=g)
+    return cfg, B, H, W, feats, metas, qf, mf
+
+
+def g6_inputs(H=64, W=96):
+    """ground truth of the G5/G6 target / loss fixtures."""
+    g = torch.Generator().manual_seed(103)
+    gt_labels = [torch.tensor([1, 4, 4]), torch.tensor([0, 6])]
+    gt_masks = []
+    for n in (3, 2):
+        m = torch.zeros(n, H, W, dtype=torch.long)
+        for i in range(n):
+            y0 = int(torch.randint(0, H - 20, (1,), generator=g))
+            x0 = int(torch.randint(0, W - 30, (1,), generator=g))
+            m[i, y0:y0 + 12 + 4 * i, x0:x0 + 20 + 3 * i] = 1
+        gt_masks.append(m)
+    cap_ids = [torch.tensor([101, 7, 9, 11, 102] + [0] * 30), torch.tensor([101, 5, 6, 102] + [0] * 31)]
+    cap_mask = [(c != 0).long() for c in cap_ids]
+    noun_ids = [torch.tensor([9, 11] + [0] * 33), torch.tensor([0] * 35)]       # second caption: no nouns
+    noun_mask = [(c != 0).long() for c in noun_ids]
+    return gt_labels, gt_masks, cap_ids, cap_mask, noun_ids, noun_mask
+
+
+def g7_inputs():
+    """query embeddings / blob-shaped mask logits of the G7 post-processing fixtures."""
+    g = torch.Generator().manual_seed(104)
+    Q, hh, ww = 8, 32, 48
+    emb = torch.randn(Q, 768, generator=g) * 0.05
+    ys = torch.arange(hh).view(1, hh, 1).float()
+    xs = torch.arange(ww).view(1, 1, ww).float()
+    cy, cx = torch.rand(Q, 1, 1, generator=g) * hh, torch.rand(Q, 1, 1, generator=g) * ww
+    r = 4 + torch.rand(Q, 1, 1, generator=g) * 6
+    mp = 6 - ((ys - cy)**2 + (xs - cx)**2) / r**2 * 6 + torch.randn(Q, hh, ww, generator=g) * 0.3
+    cls_embs = torch.randn(13, 64, generator=g)
+    cls_embs[-1] = 0
+    pemb = torch.randn(Q, 64, generator=g)
+    return emb, mp, cls_embs, pemb
