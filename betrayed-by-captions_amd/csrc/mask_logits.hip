@@ -69,15 +69,20 @@ __global__ __launch_bounds__(256) void cgg_pack_kernel(const float* __restrict__
 
 // -------------------------------------------------------------------------------------------------
 // mask logits. Workgroup = 8 waves sharing one image's mask_embed in LDS; each wave streams its own
-// 32-pixel tiles: 16 k-steps x MT m-tiles of v_mfma_f32_32x32x16_bf16 (x3 in SPLIT mode).
+// 32-pixel tiles: 16 k-steps x ceil(Q/32) m-tiles of v_mfma_f32_32x32x16_bf16 (x3 in SPLIT mode).
 //   A (LDS, fragment order): slot (mt, ks, lane) holds E[q = mt*32 + (lane&31)][k = ks*16 + 8*(lane>>5) ..+7]
 //   B (global, packed):      slot (t, ks, lane)  holds F[k = ks*16 + 8*(lane>>5) ..+7][p = t*32 + (lane&31)]
-//   D: acc[mt][r] = logit[q = mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)][p = t*32 + (lane&31)]
+//   D: acc[r] = logit[q = mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)][p = t*32 + (lane&31)]
+// Instruction diet: the first version unrolled all m-tiles (4 x 16 accumulators, 64 predicated stores with
+// 64-bit address math) = ~5.5k instructions and 40 KB of code per wave; at 2 waves/SIMD it was ISSUE-bound at
+// 2.5 TB/s whatever the memory system did. Here the B fragments of a tile stay in registers and the m-tile
+// loop is ROLLED (one 16-register accumulator, 16 MFMA + 16 ds_read_b128 + 16 stores per trip), every global
+// access is "uniform base + 32-bit lane offset", and row validity (q < Q) is a wave-uniform scalar compare.
 // -------------------------------------------------------------------------------------------------
-template <int MT, bool SPLIT>
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
     const float* __restrict__ embed, const u32x4* __restrict__ fhi, const u32x4* __restrict__ flo,
-    float* __restrict__ out, uint32_t* __restrict__ bits, int Q, int npix, int T) {
+    float* __restrict__ out, uint32_t* __restrict__ bits, int Q, int npix, int T, int MT) {
   constexpr int KS = 16;  // C = 256
   constexpr int C = KS * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -89,101 +94,148 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  // ---- prologue: mask_embed[b] -> bf16 fragments in LDS ----
-  // Coalesced: thread t owns float4 number t, t+512, ... of the contiguous [Q, 256] block; ALL loads
-  // are issued before the first conversion (the old per-slot gather was a chain of dependent loads).
-  // float4 (q, c4) lands in slot (mt = q/32, ks = c4/4, lane = q%32 + 32*((c4/2)&1)), half (c4 & 1).
-  {
-    const f32x4* eb4 = reinterpret_cast<const f32x4*>(embed + (size_t)b * Q * C);
-    constexpr int NV = (MT * 32 * (C / 4) + 511) / 512;  // float4 per thread (rows padded to MT*32)
-    f32x4 ev[NV];
+  const int hi5 = lane >> 5;
+  const int col = lane & 31;
+  const int tstride = gridDim.x * 8;
+  float* __restrict__ ob = out ? out + (size_t)b * Q * npix : nullptr;       // uniform
+  uint32_t* __restrict__ bb = bits ? bits + (size_t)b * Q * T : nullptr;     // uniform
+  const u32x4* __restrict__ fhb = fhi + (size_t)b * T * (KS * 64) + lane;
+  const u32x4* __restrict__ flb = SPLIT ? flo + (size_t)b * T * (KS * 64) + lane : nullptr;
+  int t = blockIdx.x * 8 + wave;
+
+  // ---- (0) request the first tile's B fragments BEFORE the prologue: their HBM latency hides under it ----
+  u32x4 bh[KS];
+  u32x4 bl[SPLIT ? KS : 1];
+  u32x4 bn[SPLIT ? 1 : KS];   // bf16 mode: second register set, next tile in flight while this one computes
+  if (t < T) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int f = tid + 512 * i;
-      const int q = f / (C / 4);
-      ev[i] = (q < Q) ? eb4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) bh[ks] = __builtin_nontemporal_load(fhb + (size_t)t * (KS * 64) + ks * 64);
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bl[ks] = __builtin_nontemporal_load(flb + (size_t)t * (KS * 64) + ks * 64);
     }
+  }
+
+  // ---- (1) prologue: mask_embed[b] -> bf16 fragments in LDS ----
+  // thread owns float4 number tid, tid+512, ... of the contiguous [Q, 256] block (coalesced); float4 (q, c4)
+  // lands in slot (mt = q/32, ks = c4/4, lane = q%32 + 32*((c4/2)&1)), half (c4 & 1). Rows >= Q are zero.
+  {
+    const f32x4* __restrict__ eb4 = reinterpret_cast<const f32x4*>(embed + (size_t)b * Q * C);
     uint2* a_hi2 = reinterpret_cast<uint2*>(a_hi);
     uint2* a_lo2 = reinterpret_cast<uint2*>(a_lo);
+    const int nf = MT * 32 * (C / 4);
+    const int nvalid = Q * (C / 4);
+    for (int f0 = tid; f0 < nf; f0 += 512 * 4) {
+      f32x4 ev[4];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int f = tid + 512 * i;
-      const int q = f / (C / 4), c4 = f % (C / 4);
-      if (q < MT * 32) {
-        const int slot = ((q >> 5) * KS + (c4 >> 2)) * 64 + (q & 31) + 32 * ((c4 >> 1) & 1);
-        uint16_t h[4], lw[4];
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + 512 * u;
+        ev[u] = (f < nvalid) ? eb4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (SPLIT) cgg_split_bf(ev[i][e], h[e], lw[e]);
-          else h[e] = cgg_f2bf(ev[i][e]);
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + 512 * u;
+        if (f < nf) {
+          const int q = f >> 6, c4 = f & 63;
+          const int slot = ((q >> 5) * KS + (c4 >> 2)) * 64 + (q & 31) + 32 * ((c4 >> 1) & 1);
+          uint16_t h[4], lw[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (SPLIT) cgg_split_bf(ev[u][e], h[e], lw[e]);
+            else h[e] = cgg_f2bf(ev[u][e]);
+          }
+          a_hi2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(h[0], h[1]), cgg_pack2(h[2], h[3]));
+          if (SPLIT) a_lo2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(lw[0], lw[1]), cgg_pack2(lw[2], lw[3]));
         }
-        a_hi2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(h[0], h[1]), cgg_pack2(h[2], h[3]));
-        if (SPLIT) a_lo2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(lw[0], lw[1]), cgg_pack2(lw[2], lw[3]));
       }
     }
   }
   __syncthreads();
 
-  const int hi5 = lane >> 5;
-  const int col = lane & 31;
-  const int tstride = gridDim.x * 8;
-  for (int t = blockIdx.x * 8 + wave; t < T; t += tstride) {
-    const size_t tbase = ((size_t)b * T + t) * (KS * 64) + lane;
-    u32x4 bh[KS];
-    u32x4 bl[SPLIT ? KS : 1];
+  // ---- (2) stream the tiles ----
+  // one tile: MT x (16 MFMA + 16 ds_read_b128 + 16 row stores); `cur` holds the tile's B fragments
+  auto do_tile = [&](const u32x4 (&cur)[KS], int tt) {
+    const bool ragged = (tt * 32 + 32 > npix);                               // wave-uniform, last tile only
+    const bool pin = tt * 32 + col < npix;
+    const unsigned lane_off = (unsigned)(4 * hi5) * (unsigned)npix + (unsigned)(tt * 32 + col);
+#pragma unroll 1
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x16 acc;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bh[ks] = __builtin_nontemporal_load(fhi + tbase + ks * 64);
-    if (SPLIT) {
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const u32x4* __restrict__ ah = a_hi + mt * (KS * 64) + lane;
+      const u32x4* __restrict__ al = a_lo + mt * (KS * 64) + lane;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) bl[ks] = __builtin_nontemporal_load(flo + tbase + ks * 64);
-    }
-    f32x16 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 vbh = __builtin_bit_cast(bf16x8, bh[ks]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8 vah = __builtin_bit_cast(bf16x8, a_hi[(mt * KS + ks) * 64 + lane]);
-        if (SPLIT) {
-          const bf16x8 val = __builtin_bit_cast(bf16x8, a_lo[(mt * KS + ks) * 64 + lane]);
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 vbh = __builtin_bit_cast(bf16x8, cur[ks]);
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, ah[ks * 64]);
+        if constexpr (SPLIT) {
+          const bf16x8 val = __builtin_bit_cast(bf16x8, al[ks * 64]);
           const bf16x8 vbl = __builtin_bit_cast(bf16x8, bl[ks]);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbl, acc[mt], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbl, acc, 0, 0, 0);
         }
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbh, acc[mt], 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbh, acc, 0, 0, 0);
+      }
+      const int rows_left = Q - mt * 32;                                     // uniform; >= 32 for full m-tiles
+      if (ob != nullptr) {
+        float* __restrict__ tile_row = ob + (size_t)(mt * 32) * npix;        // uniform
+        if (!ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ql = (r & 3) + 8 * (r >> 2);                           // compile-time local row (low half)
+            float* __restrict__ row = tile_row + (size_t)ql * npix;
+            // streamed output: nontemporal stores (+10 % on MI355X: 27.0 -> 24.5 us at configs[1])
+            if (ql + 4 < rows_left) __builtin_nontemporal_store(acc[r], row + lane_off);
+            else if (ql < rows_left) { if (hi5 == 0) __builtin_nontemporal_store(acc[r], row + lane_off); }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ql = (r & 3) + 8 * (r >> 2) + 4 * hi5;
+            if (ql < rows_left && pin) tile_row[(size_t)ql * npix + tt * 32 + col] = acc[r];
+          }
+        }
+      }
+      if (bb != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned long long m = __ballot(acc[r] < 0.f);
+          const int ql = (r & 3) + 8 * (r >> 2) + 4 * hi5;                   // lanes 0-31: row ql, 32-63: ql + 4
+          const uint32_t w = hi5 ? (uint32_t)(m >> 32) : (uint32_t)m;
+          if (col == 0 && ql < rows_left) bb[(size_t)(mt * 32 + ql) * T + tt] = w;
+        }
       }
     }
+  };
 
-    // ---- epilogue ----
-    const int p = t * 32 + col;
-    if (out != nullptr) {
-      const bool pin = p < npix;
+  if constexpr (SPLIT) {
+    while (t < T) {
+      do_tile(bh, t);
+      t += tstride;
+      if (t < T) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+        for (int ks = 0; ks < KS; ++ks) bh[ks] = __builtin_nontemporal_load(fhb + (size_t)t * (KS * 64) + ks * 64);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int q = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-          if (q < Q && pin) out[((size_t)b * Q + q) * npix + p] = acc[mt][r];
-        }
+        for (int ks = 0; ks < KS; ++ks) bl[ks] = __builtin_nontemporal_load(flb + (size_t)t * (KS * 64) + ks * 64);
       }
     }
-    if (bits != nullptr) {
+  } else {
+    while (t < T) {
+      const int tn = t + tstride;
+      if (tn < T) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned long long m = __ballot(acc[mt][r] < 0.f);
-          const int q0 = mt * 32 + (r & 3) + 8 * (r >> 2);
-          // lanes 0-31 carry row q0, lanes 32-63 row q0 + 4
-          if (lane == 0 && q0 < Q) bits[((size_t)b * Q + q0) * T + t] = (uint32_t)m;
-          if (lane == 32 && q0 + 4 < Q) bits[((size_t)b * Q + q0 + 4) * T + t] = (uint32_t)(m >> 32);
-        }
+        for (int ks = 0; ks < KS; ++ks) bn[ks] = __builtin_nontemporal_load(fhb + (size_t)tn * (KS * 64) + ks * 64);
       }
+      do_tile(bh, t);
+      if (tn >= T) break;
+      const int tnn = tn + tstride;
+      if (tnn < T) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bh[ks] = __builtin_nontemporal_load(fhb + (size_t)tnn * (KS * 64) + ks * 64);
+      }
+      do_tile(bn, tn);
+      t = tnn;
     }
   }
 }
@@ -266,17 +318,21 @@ extern "C" int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int 
   return CGG_OK;
 }
 
-template <int MT, bool SPLIT>
+template <bool SPLIT>
 static int launch_mask_logits(const float* embed, const void* hi, const void* lo, float* out,
                               uint32_t* bits, int B, int Q, int npix, hipStream_t s) {
+  const int MT = (Q + 31) / 32;
   const int T = (npix + 31) / 32;
   const size_t lds = (size_t)MT * 16 * 64 * 16 * (SPLIT ? 2 : 1);
-  // one workgroup per CU-slot; every wave gets >= 1 tile where possible
+  // ~one 8-wave workgroup per CU (two tiles per wave at 1024x1024); every wave gets >= 1 tile where possible
   int gx = (T + 7) / 8;
-  int cap = (512 + B - 1) / B;
+  int cap = (256 + B - 1) / B;
+#ifdef CGG_ML_HARNESS
+  if (getenv("CGG_ML_CAP")) cap = atoi(getenv("CGG_ML_CAP"));
+#endif
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
-  auto kern = cgg_mask_logits_kernel<MT, SPLIT>;
+  auto kern = cgg_mask_logits_kernel<SPLIT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -287,7 +343,7 @@ static int launch_mask_logits(const float* embed, const void* hi, const void* lo
     }
   }
   hipLaunchKernelGGL(kern, dim3(gx, B), dim3(512), lds, s, embed, (const u32x4*)hi,
-                     (const u32x4*)lo, out, bits, Q, npix, T);
+                     (const u32x4*)lo, out, bits, Q, npix, T, MT);
   CGG_CHECK_LAUNCH("cgg_mask_logits");
   return CGG_OK;
 }
@@ -304,24 +360,10 @@ extern "C" int cgg_mask_logits(const float* embed, const void* hi, const void* l
   const int mt = (Q + 31) / 32;
   if (lo) {
     CGG_REQUIRE(mt <= 4, CGG_EUNSUPPORTED, "cgg_mask_logits: split mode supports Q <= 128 (Q=%d)", Q);
-    switch (mt) {
-      case 1: return launch_mask_logits<1, true>(embed, hi, lo, out, bits, B, Q, npix, s);
-      case 2: return launch_mask_logits<2, true>(embed, hi, lo, out, bits, B, Q, npix, s);
-      case 3: return launch_mask_logits<3, true>(embed, hi, lo, out, bits, B, Q, npix, s);
-      default: return launch_mask_logits<4, true>(embed, hi, lo, out, bits, B, Q, npix, s);
-    }
+    return launch_mask_logits<true>(embed, hi, lo, out, bits, B, Q, npix, s);
   }
   CGG_REQUIRE(mt <= 8, CGG_EUNSUPPORTED, "cgg_mask_logits: Q <= 256 (Q=%d)", Q);
-  switch (mt) {
-    case 1: return launch_mask_logits<1, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    case 2: return launch_mask_logits<2, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    case 3: return launch_mask_logits<3, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    case 4: return launch_mask_logits<4, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    case 5: return launch_mask_logits<5, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    case 6: return launch_mask_logits<6, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    case 7: return launch_mask_logits<7, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-    default: return launch_mask_logits<8, false>(embed, hi, lo, out, bits, B, Q, npix, s);
-  }
+  return launch_mask_logits<false>(embed, hi, lo, out, bits, B, Q, npix, s);
 }
 
 extern "C" int cgg_attn_mask_fix_full_rows(uint32_t* bits, int rows, int npix, cgg_stream_t stream) {

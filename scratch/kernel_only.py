@@ -1,0 +1,28 @@
+"""Runs only the hot HIP kernels at BASELINE configs[1] shapes (for rocprofv3 --pmc passes)."""
+import sys, torch
+sys.path.insert(0, '.')
+import cgg_amd
+from cgg_amd import ops
+dev = 'cuda'
+B, Q, C, H, W = 2, 100, 256, 256, 256
+g = torch.Generator().manual_seed(0)
+E = torch.randn(B, Q, C, generator=g).to(dev)
+F_ = torch.randn(B, C, H, W, generator=g).to(dev)
+split = len(sys.argv) > 1 and sys.argv[1] == 'split'
+packed = ops.pack_mask_feature(F_, 1, split=split)
+for _ in range(20):
+    out, _ = ops.mask_logits(E, packed, want_logits=True)
+torch.cuda.synchronize()
+# MSDeformAttn (fused prologue) at 1024x1024: levels 32^2, 64^2, 128^2
+shapes = [(32, 32), (64, 64), (128, 128)]; starts = [0, 1024, 5120]; N = 21504
+raw = torch.randn(B, N, 288, generator=g); raw[..., :192] *= 2.0
+ref = []
+for h, w in shapes:
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')
+    ref.append(torch.stack([(xs.flatten() + .5) / w, (ys.flatten() + .5) / h], -1))
+ref = torch.cat(ref).to(dev); raw = raw.to(dev)
+v = torch.randn(B, N, 8, 32, generator=g).to(dev).to(torch.bfloat16)
+for _ in range(20):
+    ops.msda_forward_fused(v, shapes, starts, raw, ref, 4)
+torch.cuda.synchronize()
+print('done')
