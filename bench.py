@@ -21,7 +21,10 @@ import sys
 import time
 import warnings
 
-import torch
+# MIOpen's find step otherwise times its naive reference convolutions (15-30 ms each) on the first step
+os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
