@@ -115,9 +115,12 @@ class MultiheadAttention(nn.Module):
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         B, Q, _ = query.shape
         q = small_linear(qk_in, w[:E], b[:E])
-        kv = torch.empty((B, Q, 2 * E), dtype=torch.float32, device=query.device)
-        small_linear(qk_in, w[E:2 * E], b[E:2 * E], out=kv.view(B * Q, 2 * E)[:, :E])
-        small_linear(query, w[2 * E:], b[2 * E:], out=kv.view(B * Q, 2 * E)[:, E:])
+        if _needs_grad(query, w):
+            kv = torch.cat([small_linear(qk_in, w[E:2 * E], b[E:2 * E]), small_linear(query, w[2 * E:], b[2 * E:])], -1)
+        else:   # the two projections write the halves of one [K | V] buffer directly
+            kv = torch.empty((B, Q, 2 * E), dtype=torch.float32, device=query.device)
+            small_linear(qk_in, w[E:2 * E], b[E:2 * E], out=kv.view(B * Q, 2 * E)[:, :E])
+            small_linear(query, w[2 * E:], b[2 * E:], out=kv.view(B * Q, 2 * E)[:, E:])
         core = _xattn(q.contiguous(), kv, None, self.num_heads)
         return small_linear(core, self.attn.out_proj.weight, self.attn.out_proj.bias, res=query)
 

@@ -165,7 +165,7 @@ def train_batch(B, H, W, num_classes, max_inst=20, T=35, vocab=30522, seed=0, de
         Ltok = int(torch.randint(5, 21, (1,), generator=g))
         ids = torch.zeros(T, dtype=torch.long)
         ids[0] = 101
-        ids[1:1 + Ltok] = torch.randint(1000, vocab, (Ltok,), generator=g)
+        ids[1:1 + Ltok] = torch.randint(min(1000, vocab // 2), vocab, (Ltok,), generator=g)
         ids[1 + Ltok] = 102
         cmask = (ids != 0).long()
         nn_ = int(torch.randint(1, 7, (1,), generator=g))

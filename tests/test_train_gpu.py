@@ -1,0 +1,78 @@
+"""-m gpu: one training step of the head on the device (HIP forward kernels + autograd, HIP MSDeformAttn backward)
+against the oracle: the 7 x (layers+1) losses with the same weights, inputs and (pinned) random points, and finite,
+non-zero gradients reaching the sampling-offset / attention / mask-embedding / caption parameters."""
+import warnings
+
+import pytest
+import torch
+
+import cgg_amd  # noqa: F401
+from cgg_amd import synthetic
+
+from util import MaskTeacher, build_heads, small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+class Bank:
+    """deterministic random-point source shared by product (device) and oracle (cpu): per-kind call counters."""
+
+    def __init__(self, seed):
+        self.seed, self.count = seed, {}
+
+    def __call__(self, kind, shape, device):
+        i = self.count.get(kind, 0)
+        self.count[kind] = i + 1
+        g = torch.Generator().manual_seed(self.seed + 1000 * i + {'target': 1, 'oversample': 2, 'random': 3}[kind])
+        return torch.rand(*shape, generator=g).to(device)
+
+
+def test_forward_train_losses_and_gradients(dev):
+    cfg = small_cfg(num_queries=12, num_points=512)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prod, orc = build_heads(cfg)
+    prod = prod.to(dev).train()
+    orc.train()
+    for m in list(prod.modules()) + list(orc.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B, H, W = 2, 128, 160
+    feats = synthetic.backbone_feats(B, H, W, channels=(64, 128, 256, 512), seed=21)
+    metas = synthetic.img_metas(B, H, W)
+    batch = synthetic.train_batch(B, H, W, num_classes=cfg['panoptic_head']['num_things_classes'], max_inst=5,
+                                  vocab=500, seed=22)
+    # ---- oracle (cpu) ----
+    teacher = MaskTeacher(orc)
+    orc.point_hook = Bank(7)
+    with torch.no_grad():
+        oc, oe, om = teacher.run_oracle(lambda: orc.forward(feats, metas))
+        olosses = orc.loss(oc, oe, om, batch['gt_labels'], [m.long() for m in batch['gt_masks']],
+                           batch['gt_caption_ids'], batch['gt_caption_mask'], batch['gt_caption_nouns_ids'],
+                           batch['gt_caption_nouns_mask'])
+    # ---- product (device), oracle masks injected (tie-aware parity, see util.MaskTeacher) ----
+    prod.point_hook = Bank(7)
+    prod.attn_mask_hook = teacher.hook
+    to = lambda lst: [t.to(dev) for t in lst]   # noqa: E731
+    losses = prod.forward_train([f.to(dev).requires_grad_(True) for f in feats], metas, to(batch['gt_bboxes']),
+                                to(batch['gt_labels']), to(batch['gt_masks']), None, to(batch['gt_caption_ids']),
+                                to(batch['gt_caption_mask']), to(batch['gt_caption_nouns_ids']),
+                                to(batch['gt_caption_nouns_mask']))
+    prod.attn_mask_hook = None
+    teacher.check()
+    assert set(losses) == set(olosses)
+    for k in sorted(losses):
+        a, b = float(losses[k]), float(olosses[k])
+        assert abs(a - b) <= 2e-3 * (1 + abs(b)), (k, a, b)
+    total = sum(v for v in losses.values())
+    total.backward()
+    named = dict(prod.named_parameters())
+    for key in ['pixel_decoder.encoder.layers.0.attentions.0.sampling_offsets.weight',
+                'pixel_decoder.encoder.layers.1.attentions.0.attention_weights.weight',
+                'pixel_decoder.encoder.layers.0.attentions.0.value_proj.weight',
+                'transformer_decoder.layers.0.attentions.0.attn.in_proj_weight',
+                'transformer_decoder.layers.2.ffns.0.layers.1.weight', 'mask_embed.4.weight', 'v2l_transform.weight',
+                'query_feat.weight', 'caption_generator.generator.weight', 'pixel_decoder.mask_feature.weight']:
+        g = named[key].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, key
+    assert named['bert_embeddings.word_embeddings.weight'].grad is None        # frozen text encoder
