@@ -168,6 +168,75 @@ extern "C" int cgg_linear_rows(const float* x, int ldx, const float* w, const fl
   return CGG_OK;
 }
 
+// Encoder-stream variant (43 008 rows x 256 at configs[1]): y = LN(a + b) with b in bf16 (a library GEMM's
+// output) or f32, and up to three outputs written in the same pass so that no separate cast / add pass runs:
+//   y32 (f32 residual stream), y16 = bf16(y) (next GEMM's input), yp16 = bf16(y + pos[row % pos_rows])
+//   (the "query + query_pos" input of the next layer's sampling-offset GEMM). One wave per row, N == 256:
+//   each lane owns 4 consecutive channels (16-B loads / stores).
+template <typename BT>
+__global__ __launch_bounds__(256) void cgg_add_layernorm256_kernel(
+    const float* __restrict__ a, const BT* __restrict__ b, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ pos, int pos_rows, float* __restrict__ y32,
+    uint16_t* __restrict__ y16, uint16_t* __restrict__ yp16, int rows, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t off = (size_t)row * 256 + lane * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
+  if (b != nullptr) {
+    if (sizeof(BT) == 4) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(b) + off);
+      v += w;
+    } else {
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(b) + off);
+      v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+      v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+    }
+  }
+  float s = (v[0] + v[1]) + (v[2] + v[3]);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / 256.f);
+  f32x4 d = v - mean;
+  float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q * (1.f / 256.f) + eps);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + lane * 4);
+  f32x4 y = d * rstd * g + be;
+  if (y32) *reinterpret_cast<f32x4*>(y32 + off) = y;
+  if (y16) {
+    *reinterpret_cast<uint2*>(y16 + off) =
+        make_uint2(cgg_pack2(cgg_f2bf(y[0]), cgg_f2bf(y[1])), cgg_pack2(cgg_f2bf(y[2]), cgg_f2bf(y[3])));
+  }
+  if (yp16) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)(row % pos_rows) * 256 + lane * 4);
+    const f32x4 z = y + p;
+    *reinterpret_cast<uint2*>(yp16 + off) =
+        make_uint2(cgg_pack2(cgg_f2bf(z[0]), cgg_f2bf(z[1])), cgg_pack2(cgg_f2bf(z[2]), cgg_f2bf(z[3])));
+  }
+}
+
+extern "C" int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float* gamma,
+                                    const float* beta, const float* pos, int pos_rows, float* y32, void* y16,
+                                    void* yp16, int rows, int N, float eps, cgg_stream_t stream) {
+  CGG_REQUIRE(a && gamma && beta, CGG_EINVAL, "cgg_add_layernorm_ex: null pointer");
+  CGG_REQUIRE(y32 || y16 || yp16, CGG_EINVAL, "cgg_add_layernorm_ex: no output requested");
+  CGG_REQUIRE(rows > 0, CGG_EINVAL, "cgg_add_layernorm_ex: bad sizes");
+  CGG_REQUIRE(N == 256, CGG_EUNSUPPORTED, "cgg_add_layernorm_ex: N=%d (only 256 is built)", N);
+  CGG_REQUIRE(!yp16 || (pos && pos_rows > 0), CGG_EINVAL, "cgg_add_layernorm_ex: yp16 needs pos");
+  CGG_REQUIRE(b_dtype == CGG_F32 || b_dtype == CGG_BF16, CGG_EUNSUPPORTED, "cgg_add_layernorm_ex: b dtype %d", b_dtype);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4);
+  if (b_dtype == CGG_F32)
+    hipLaunchKernelGGL(cgg_add_layernorm256_kernel<float>, grid, dim3(256), 0, s, a, (const float*)b, gamma, beta,
+                       pos, pos_rows, y32, (uint16_t*)y16, (uint16_t*)yp16, rows, eps);
+  else
+    hipLaunchKernelGGL(cgg_add_layernorm256_kernel<uint16_t>, grid, dim3(256), 0, s, a, (const uint16_t*)b, gamma,
+                       beta, pos, pos_rows, y32, (uint16_t*)y16, (uint16_t*)yp16, rows, eps);
+  CGG_CHECK_LAUNCH("cgg_add_layernorm_ex");
+  return CGG_OK;
+}
+
 extern "C" int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta,
                                  float* y, int rows, int N, float eps, cgg_stream_t stream) {
   CGG_REQUIRE(a && gamma && beta && y, CGG_EINVAL, "cgg_add_layernorm: null pointer");

@@ -59,6 +59,9 @@ __device__ __forceinline__ MsdaTap cgg_msda_tap(float x, float y, int Hl, int Wl
   return t;
 }
 
+__device__ __forceinline__ float msda_x(float v) { return v; }
+__device__ __forceinline__ float msda_x(uint16_t v) { return cgg_bf2f(v); }
+
 // per-lane channel slice: 16 bytes of the value row -> CPL = 4 (f32) or 8 (bf16) channels
 template <typename VT> struct MsdaVec;
 template <> struct MsdaVec<float> {
@@ -87,11 +90,11 @@ template <> struct MsdaVec<uint16_t> {
 // P_ > 0: compile-time points per level: the P_*4 corner loads of one level are issued together (16 x 16 B
 // in flight per lane); the level loop stays rolled so the register footprint (~100 VGPR) keeps >= 4
 // waves per SIMD resident -- a fully unrolled 48-load body needs 256 VGPRs and halves the throughput.
-template <typename VT, int L_, int P_, bool FUSED>
+template <typename VT, int L_, int P_, bool FUSED, typename OT = float, typename XT = float>
 __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
-    const VT* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
-    const float* __restrict__ attw, const float* __restrict__ ref, int ld,
-    float* __restrict__ out, int Nv, int H, int D, int Lrt, int Nq, int Prt, long long total) {
+    const VT* __restrict__ value, MsdaLevels lv, const XT* __restrict__ loc,
+    const XT* __restrict__ attw, const float* __restrict__ ref, int ld,
+    OT* __restrict__ out, int Nv, int H, int D, int Lrt, int Nq, int Prt, long long total) {
   constexpr int CPL = MsdaVec<VT>::CPL;
   const int L = L_ > 0 ? L_ : Lrt;
   const int P = P_ > 0 ? P_ : Prt;
@@ -108,19 +111,19 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
   const VT* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
   const int LP = L * P;
 
-  const float* lp;
-  const float* wp;
+  const XT* lp;
+  const XT* wp;
   float rx = 0.f, ry = 0.f, smax = 0.f, sinv = 1.f;
   if (FUSED) {
-    const float* row = loc + (size_t)bq * ld;
+    const XT* row = loc + (size_t)bq * ld;
     lp = row + (size_t)h * LP * 2;
     wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
     rx = ref[2 * q];
     ry = ref[2 * q + 1];
-    smax = wp[0];
-    for (int i = 1; i < LP; ++i) smax = fmaxf(smax, wp[i]);
+    smax = msda_x(wp[0]);
+    for (int i = 1; i < LP; ++i) smax = fmaxf(smax, msda_x(wp[i]));
     float ssum = 0.f;
-    for (int i = 0; i < LP; ++i) ssum += expf(wp[i] - smax);
+    for (int i = 0; i < LP; ++i) ssum += expf(msda_x(wp[i]) - smax);
     sinv = 1.f / ssum;
   } else {
     lp = loc + ((size_t)bq * H + h) * LP * 2;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
     for (int p = 0; p < (P_ > 0 ? P_ : 1); ++p) {
       for (int pp = (P_ > 0 ? p : 0); pp < (P_ > 0 ? p + 1 : P); ++pp) {
         const int i = l * P + pp;
-        float x = lp[2 * i], y = lp[2 * i + 1], w = wp[i];
+        float x = msda_x(lp[2 * i]), y = msda_x(lp[2 * i + 1]), w = msda_x(wp[i]);
         if (FUSED) {
           x = rx + x / (float)Wl;
           y = ry + y / (float)Hl;
@@ -158,10 +161,17 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
       }
     }
   }
-  float* op = out + (size_t)bq * rowstride + (size_t)h * D + cq * CPL;
+  OT* op = out + (size_t)bq * rowstride + (size_t)h * D + cq * CPL;
+  if (sizeof(OT) == 4) {
 #pragma unroll
-  for (int c = 0; c < CPL; c += 4)
-    *reinterpret_cast<f32x4*>(op + c) = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+    for (int c = 0; c < CPL; c += 4)
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + c) = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPL; c += 4)
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(op) + c) =
+          make_uint2(cgg_pack2(cgg_f2bf(acc[c]), cgg_f2bf(acc[c + 1])), cgg_pack2(cgg_f2bf(acc[c + 2]), cgg_f2bf(acc[c + 3])));
+  }
 }
 
 // Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
@@ -419,5 +429,40 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
     hipLaunchKernelGGL(cgg_msda_bwd_kernel<0>, dim3(nblk), dim3(256), 0, s, value, lv, sampling_loc,
                        attn_weight, grad_out, grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
   CGG_CHECK_LAUNCH("cgg_msda_backward");
+  return CGG_OK;
+}
+
+// Throughput-mode encoder stream: bf16 value, bf16 raw [offsets | logits] rows (a bf16 GEMM's output), bf16 output
+// (the next GEMM's input). Level table from the host (graph-capturable). L == 3, P == 4 fast path or generic.
+extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* level_hw, const int32_t* level_start,
+                                           const void* offs_logits, int ld, const float* ref_points, void* out,
+                                           int B, int Nv, int H, int D, int L, int Nq, int P,
+                                           cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_forward_fused_bf16", value, offs_logits, ref_points, out, B, Nv, H, D, L, Nq, P,
+                      CGG_BF16);
+  if (rc) return rc;
+  CGG_REQUIRE(level_hw && level_start, CGG_EINVAL, "cgg_msda_forward_fused_bf16: null level table");
+  CGG_REQUIRE(ld >= H * L * P * 3, CGG_EINVAL, "cgg_msda_forward_fused_bf16: ld too small");
+  MsdaLevels lv;
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = level_start[l];
+    CGG_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0 && lv.start[l] >= 0 &&
+                    (long long)lv.start[l] + (long long)lv.h[l] * lv.w[l] <= Nv,
+                CGG_EINVAL, "cgg_msda_forward_fused_bf16: level %d does not fit Nv=%d", l, Nv);
+  }
+  const long long total = (long long)B * Nq * H * (D / 8);
+  const int nblk = (int)((total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (L == 3 && P == 4)
+    hipLaunchKernelGGL((cgg_msda_fwd_kernel<uint16_t, 3, 4, true, uint16_t, uint16_t>), dim3(nblk), dim3(256), 0, s,
+                       (const uint16_t*)value, lv, (const uint16_t*)offs_logits, (const uint16_t*)nullptr, ref_points,
+                       ld, (uint16_t*)out, Nv, H, D, L, Nq, P, total);
+  else
+    hipLaunchKernelGGL((cgg_msda_fwd_kernel<uint16_t, 0, 0, true, uint16_t, uint16_t>), dim3(nblk), dim3(256), 0, s,
+                       (const uint16_t*)value, lv, (const uint16_t*)offs_logits, (const uint16_t*)nullptr, ref_points,
+                       ld, (uint16_t*)out, Nv, H, D, L, Nq, P, total);
+  CGG_CHECK_LAUNCH("cgg_msda_forward_fused_bf16");
   return CGG_OK;
 }

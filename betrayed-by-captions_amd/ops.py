@@ -390,3 +390,41 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
                             int(groups), float(eps), 1 if relu else 0, stream_ptr(x.device))
     check(rc, 'cgg_group_norm')
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# throughput-mode encoder stream (bf16 activations between the library GEMMs, f32 residual stream)
+# ------------------------------------------------------------------------------------------------
+def msda_forward_fused_bf16(value, level_hw, level_start, offs_logits, ref_points, num_points):
+    """value (B,Nv,H,D) bf16, offs_logits (B,Nq,ld) bf16 raw [offsets | logits], ref_points (Nq,2) f32
+    -> (B,Nq,H*D) bf16."""
+    B, Nv, H, D = value.shape
+    _, Nq, ld = offs_logits.shape
+    out = torch.empty((B, Nq, H * D), dtype=torch.bfloat16, device=value.device)
+    hw = _int_array([v for pair in level_hw for v in pair])
+    st = _int_array(level_start)
+    with _timed('msda_fused'):
+        rc = _lib_().cgg_msda_forward_fused_bf16(
+            dev_ptr(value, 'value', torch.bfloat16), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.bfloat16),
+            ld, dev_ptr(ref_points, 'ref_points', torch.float32), dev_ptr(out), B, Nv, H, D, len(level_start), Nq,
+            int(num_points), stream_ptr(value.device))
+    check(rc, 'cgg_msda_forward_fused_bf16')
+    return out
+
+
+def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, want_bf16=True, want_pos=False):
+    """LN(a + b) over the last dim (256). a f32, b f32|bf16|None. Returns (y f32 | None, bf16(y) | None,
+    bf16(y + pos[row % len(pos)]) | None) from ONE pass."""
+    N = a.shape[-1]
+    rows = a.numel() // N
+    y32 = torch.empty_like(a) if want_f32 else None
+    y16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
+    yp16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_pos else None
+    bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
+    rc = _lib_().cgg_add_layernorm_ex(
+        dev_ptr(a, 'a', torch.float32), dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32),
+        dev_ptr(beta, 'beta', torch.float32), dev_ptr(pos, 'pos', torch.float32),
+        pos.shape[0] if pos is not None else 0, dev_ptr(y32), dev_ptr(y16), dev_ptr(yp16), rows, N, float(eps),
+        stream_ptr(a.device))
+    check(rc, 'cgg_add_layernorm_ex')
+    return y32, y16, yp16

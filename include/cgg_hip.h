@@ -86,6 +86,12 @@ int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
                                 float* out, int B, int Nv, int H, int D, int L, int Nq, int P,
                                 int value_dtype, int fused, cgg_stream_t stream);
 
+/* Throughput-mode encoder stream: value bf16, offs_logits bf16 (the raw output of ONE bf16 GEMM over
+ * [sampling_offsets; attention_weights]), out bf16 (input of the output_proj GEMM); host level table.    */
+int cgg_msda_forward_fused_bf16(const void* value, const int32_t* level_hw, const int32_t* level_start,
+                                const void* offs_logits, int ld, const float* ref_points, void* out, int B,
+                                int Nv, int H, int D, int L, int Nq, int P, cgg_stream_t stream);
+
 /* Backward of cgg_msda_forward (f32 value). grad_value / grad_loc / grad_attn must be ZEROED by the
  * caller and are accumulated in place (same contract as mmcv's ms_deform_attn_backward).           */
 int cgg_msda_backward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
@@ -169,6 +175,12 @@ int cgg_linear_rows(const float* x, int ldx, const float* w, const float* bias, 
                     float* y, int ldy, int M, int N, int K, int relu, int split, cgg_stream_t stream);
 int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* y,
                       int rows, int N, float eps, cgg_stream_t stream);
+
+/* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, b f32 or bf16 (nullable), with up
+ * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
+int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+                         const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
+                         float eps, cgg_stream_t stream);
 
 /* K9  GroupNorm (+ optional ReLU) of the pixel decoder ConvModules ([3P] MSDeformAttnPixelDecoder,
  * norm_cfg=dict(type='GN', num_groups=32), configs/instance/coco_b48n17.py:40).

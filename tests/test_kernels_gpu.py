@@ -356,3 +356,37 @@ def test_instance_masks_integer_fast_path_matches_torch(dev, H, W, S, crop):
     assert (score.cpu() - wscore).abs().max().item() <= 1e-5
     if not near.any():
         assert torch.equal(bbox.cpu(), OH.mask2bbox(wbin))
+
+
+def test_add_layernorm_stream_and_bf16_msda(dev):
+    g = torch.Generator().manual_seed(44)
+    a = torch.randn(2, 300, 256, generator=g)
+    b = torch.randn(2, 300, 256, generator=g)
+    pos = torch.randn(300, 256, generator=g)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(256, generator=g))
+        ln.bias.copy_(torch.randn(256, generator=g))
+        want = ln(a + b.bfloat16().float())
+    y32, y16, yp16 = ops.add_layernorm_stream(a.to(dev), b.to(dev).bfloat16(), ln.weight.to(dev), ln.bias.to(dev),
+                                              ln.eps, pos=pos.to(dev), want_pos=True)
+    assert (y32.cpu() - want).abs().max().item() <= 1e-5
+    assert torch.equal(y16.cpu(), y32.cpu().bfloat16())
+    assert torch.equal(yp16.cpu(), (y32.cpu() + pos[None]).bfloat16())
+    y32b, _, _ = ops.add_layernorm_stream(a.to(dev), b.to(dev), ln.weight.to(dev), ln.bias.to(dev), ln.eps,
+                                          want_bf16=False)
+    with torch.no_grad():
+        assert (y32b.cpu() - ln(a + b)).abs().max().item() <= 1e-5
+    # bf16 stream variant of the fused MSDeformAttn kernel == f32-output kernel on the same bf16 inputs, rounded
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    starts, Nv = _levels(shapes)
+    B, H, D, P = 2, 8, 32, 4
+    value = torch.randn(B, Nv, H, D, generator=g).bfloat16()
+    raw = torch.randn(B, Nv, 288, generator=g)
+    raw[..., :192] *= 2
+    raw = raw.bfloat16()
+    refp = torch.rand(Nv, 2, generator=g)
+    ref32 = ops.msda_forward_fused(value.to(dev), shapes, starts, raw.float().to(dev), refp.to(dev), P)
+    got = ops.msda_forward_fused_bf16(value.to(dev), shapes, starts, raw.to(dev), refp.to(dev), P)
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got.cpu(), ref32.cpu().bfloat16())
