@@ -8,7 +8,7 @@ the backbone is outside the hand-written-kernel scope of the hot path (SURVEY.md
 import torch
 import torch.nn as nn
 
-from . import runtime
+from . import ops, runtime
 from .registry import BACKBONES
 
 
@@ -151,8 +151,10 @@ class ResNet(nn.Module):
         def fold(conv, bn):
             s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
             w = (conv.weight.detach().float() * s.view(-1, 1, 1, 1)).to(torch.bfloat16)
-            b = (bn.bias.detach().float() - bn.running_mean.detach().float() * s).to(torch.bfloat16)
-            return w.contiguous(memory_format=torch.channels_last), b
+            b = (bn.bias.detach().float() - bn.running_mean.detach().float() * s).to(torch.bfloat16).contiguous()
+            if conv.kernel_size == (1, 1) and conv.groups == 1:
+                return None, b, w.flatten(1).contiguous()      # 1x1: a plain (Cout, Cin) GEMM weight
+            return w.contiguous(memory_format=torch.channels_last), b, None
 
         seq = [fold(self.conv1, self.bn1)]
         for name in self.res_layers:
@@ -166,30 +168,58 @@ class ResNet(nn.Module):
         self.__dict__['_fold_cache'] = (key, seq)
         return seq
 
+    @staticmethod
+    def _conv_nhwc(x, conv, folded, relu, res=None):
+        """One BN-folded convolution on a channel-last bf16 activation x (B, H, W, Cin) -> (B, H', W', Cout).
+        1x1 convolutions are plain GEMMs over the B*H*W rows (hipBLASLt with the bias / ReLU epilogue, instead of
+        MIOpen's split-K implicit GEMM + f32->bf16 cast pass); k x k ones go through MIOpen without bias and the
+        epilogue `act(y + bias + res)` is ONE in-place HIP pass (cgg_bias_act_nhwc)."""
+        import torch.nn.functional as F
+        w4, b, w2 = folded
+        if w2 is not None:
+            sh, sw = conv.stride
+            if sh > 1 or sw > 1:
+                x = x[:, ::sh, ::sw, :].contiguous()
+            x2 = x.reshape(-1, x.shape[-1])
+            if relu and res is None:
+                y = torch._addmm_activation(b, x2, w2.t())
+            else:
+                y = torch.addmm(b, x2, w2.t())
+            y = y.view(x.shape[0], x.shape[1], x.shape[2], -1)
+            if res is not None:
+                ops.bias_act_nhwc_(y, None, res, relu)
+            return y
+        y = F.conv2d(x.permute(0, 3, 1, 2), w4, None, stride=conv.stride, padding=conv.padding,
+                     dilation=conv.dilation, groups=conv.groups)
+        y = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        return ops.bias_act_nhwc_(y, b, res, relu)
+
     def _forward_folded(self, x):
         import torch.nn.functional as F
         seq = iter(self._folded())
-        x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last)
-        w, b = next(seq)
-        x = F.max_pool2d(F.relu_(F.conv2d(x, w, b, stride=2, padding=3)), 3, stride=2, padding=1)
+        x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        x = self._conv_nhwc(x, self.conv1, next(seq), True)
+        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, stride=2, padding=1)
+        x = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
                 identity = x
                 if blk.downsample is not None:
-                    w, b = next(seq)
-                    identity = F.conv2d(x, w, b, stride=blk.downsample[0].stride)
-                w, b = next(seq)
-                y = F.relu_(F.conv2d(x, w, b, stride=blk.conv1.stride, padding=blk.conv1.padding))
-                w, b = next(seq)
-                y = F.conv2d(y, w, b, stride=blk.conv2.stride, padding=blk.conv2.padding)
+                    identity = self._conv_nhwc(x, blk.downsample[0], next(seq), False)
+                y = self._conv_nhwc(x, blk.conv1, next(seq), True)
                 if isinstance(blk, Bottleneck):
-                    w, b = next(seq)
-                    y = F.conv2d(F.relu_(y), w, b)
-                x = F.relu_(y + identity)
+                    y = self._conv_nhwc(y, blk.conv2, next(seq), True)
+                    x = self._conv_nhwc(y, blk.conv3, next(seq), True, identity)
+                else:
+                    x = self._conv_nhwc(y, blk.conv2, next(seq), True, identity)
             if i in self.out_indices:
                 outs.append(x)
-        return tuple(o.float().contiguous() for o in outs)
+        res = []
+        for o in outs:      # (B, H, W, C) bf16 -> NCHW f32 in one transposing copy
+            B, H, W, C = o.shape
+            res.append(torch.empty((B, C, H, W), dtype=torch.float32, device=o.device).copy_(o.permute(0, 3, 1, 2)))
+        return tuple(res)
 
     def forward(self, x):
         frozen_bn = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))

@@ -428,3 +428,13 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
         stream_ptr(a.device))
     check(rc, 'cgg_add_layernorm_ex')
     return y32, y16, yp16
+
+
+def bias_act_nhwc_(y, bias=None, res=None, relu=True):
+    """In place on a channel-last bf16 activation `y` (..., C): y <- act(y + bias[C] + res)."""
+    C = y.shape[-1]
+    rc = _lib_().cgg_bias_act_nhwc(dev_ptr(y, 'y', torch.bfloat16), dev_ptr(bias, 'bias', torch.bfloat16),
+                                   dev_ptr(res, 'res', torch.bfloat16), y.numel() // C, C, int(bool(relu)),
+                                   stream_ptr(y.device))
+    check(rc, 'cgg_bias_act_nhwc')
+    return y

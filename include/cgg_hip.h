@@ -182,6 +182,13 @@ int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float
                          const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
                          float eps, cgg_stream_t stream);
 
+/* f3  Channel-last epilogue of the BN-folded backbone convolutions ([3P] mmdet ResNet Bottleneck tail
+ * `relu(bn3(conv3(x)) + identity)`, selected by configs/instance/coco_b48n17.py:17-26), in place:
+ *   y[rows, C] bf16 <- act(y + bias[C] + res[rows, C]);  bias, res bf16, nullable;  relu != 0 -> max(., 0).
+ * Requires C % 8 == 0 and 16-byte aligned pointers.                                                             */
+int cgg_bias_act_nhwc(void* y, const void* bias, const void* res, int64_t rows, int C, int relu,
+                      cgg_stream_t stream);
+
 /* K9  GroupNorm (+ optional ReLU) of the pixel decoder ConvModules ([3P] MSDeformAttnPixelDecoder,
  * norm_cfg=dict(type='GN', num_groups=32), configs/instance/coco_b48n17.py:40).
  *   x, y [B, C, H, W] f32 NCHW; gamma, beta [C]; ws = cgg_group_norm_workspace_bytes(...) bytes.

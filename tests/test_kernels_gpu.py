@@ -390,3 +390,45 @@ def test_add_layernorm_stream_and_bf16_msda(dev):
     got = ops.msda_forward_fused_bf16(value.to(dev), shapes, starts, raw.to(dev), refp.to(dev), P)
     assert got.dtype == torch.bfloat16
     assert torch.equal(got.cpu(), ref32.cpu().bfloat16())
+
+
+def test_bias_act_nhwc_and_folded_backbone(dev):
+    from cgg_amd import registry, runtime
+    g = torch.Generator().manual_seed(45)
+    y = torch.randn(2, 9, 7, 64, generator=g).bfloat16()
+    b = torch.randn(64, generator=g).bfloat16()
+    r = torch.randn(2, 9, 7, 64, generator=g).bfloat16()
+    for bias, res, relu in [(b, r, True), (b, None, True), (None, r, True), (b, r, False), (None, None, True)]:
+        want = y.clone()
+        if bias is not None:
+            want = want + bias
+        if res is not None:
+            want = want + res
+        if relu:
+            want = want.relu()
+        got = ops.bias_act_nhwc_(y.clone().to(dev), None if bias is None else bias.to(dev),
+                                 None if res is None else res.to(dev), relu)
+        assert torch.equal(got.cpu(), want), (bias is not None, res is not None, relu)
+    # throughput-mode ResNet (BN folded, 1x1 convs as GEMMs, fused epilogues) tracks the f32 module
+    for depth in (50, 18):
+        torch.manual_seed(3)
+        bb = registry.build_backbone(dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3),
+                                          frozen_stages=-1, norm_cfg=dict(type='BN', requires_grad=False),
+                                          norm_eval=True, style='pytorch'))
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.1)
+        bb = bb.to(dev).eval()
+        x = torch.randn(2, 3, 96, 128, generator=g).to(dev)
+        with torch.no_grad():
+            want = bb(x)
+            with runtime.precision_scope('bf16'):
+                got = bb(x)
+        for w, o in zip(want, got):
+            assert o.shape == w.shape and o.dtype == torch.float32 and o.is_contiguous()
+            scale = w.abs().max().item()
+            assert (o - w).abs().max().item() <= 0.06 * scale
+            assert (o - w).abs().mean().item() <= 0.01 * scale
