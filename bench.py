@@ -81,18 +81,77 @@ def cpu_baseline(args, cfg, model, img_cpu):
                        f'(torch CPU oracle, fp32, {threads} threads), {dt:.1f} s')
 
 
+def train_main(args, cfg, model, img, metas, dev, rank, world):
+    """configs[2]: one optimisation step = forward_train (all 10 layers' losses incl. grounding + caption
+    generation) -> backward with bucketed gradient all-reduce over RCCL overlapped -> clip -> AdamW step."""
+    import torch.distributed as dist
+    from cgg_amd import synthetic
+    from cgg_amd.train import GradReducer, build_optimizer, train_step
+    B, H, W = args.batch, args.size, args.size
+    model.train()
+    embed_multi = dict(lr_mult=1.0, decay_mult=0.0)
+    optimizer = build_optimizer(model, dict(          # configs/instance/coco_b48n17.py:270-286
+        type='AdamW', lr=1e-4, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999),
+        paramwise_cfg=dict(custom_keys={'backbone': dict(lr_mult=0.1, decay_mult=1.0), 'query_embed': embed_multi,
+                                        'query_feat': embed_multi, 'level_embed': embed_multi},
+                           norm_decay_mult=0.0)))
+    reducer = GradReducer(model, bucket_bytes=args.bucket_mb << 20)
+    nc = cfg['panoptic_head']['num_things_classes'] + cfg['panoptic_head']['num_stuff_classes']
+    batch = synthetic.train_batch(B, H, W, num_classes=nc, seed=77 + rank, device=dev)
+    data = dict(img=img, img_metas=metas, **batch)
+    clip = dict(max_norm=0.01, norm_type=2)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        logs = train_step(model, optimizer, reducer, data, clip)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = train_step(model, optimizer, reducer, data, clip)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        nparam = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        print(json.dumps(dict(
+            metric='images/sec (COCO-instance training step, 1024x1024, 100 queries)',
+            value=B * world * args.steps / dt, unit='images/sec', n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+            vs_baseline=None, dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
+            config=dict(workload=f'configs[2]: R50 + {args.queries} queries, {H}x{W}, batch {B}/GPU, training step '
+                                 '(forward_train with grounding + caption-generation losses, backward, gradient '
+                                 'all-reduce, clip, AdamW)',
+                        global_batch=B * world, parallelism=f'dp{world}', precision=args.precision,
+                        trainable_params=nparam, grad_buckets=len(reducer.buckets), bucket_mb=args.bucket_mb),
+            loss=logs.get('loss'), peak_mem_gb=torch.cuda.max_memory_allocated() / 2**30)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=2, help='images per GPU per step')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="infer = configs[1] (the metric's config); train = configs[2] training step")
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (2 infer / 16 train)')
+    ap.add_argument('--bucket-mb', type=int, default=64, help='gradient all-reduce bucket size (train)')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--queries', type=int, default=100)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--graph', type=int, default=0, help='replay the step from a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 2 if args.mode == 'infer' else 16
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -114,6 +173,9 @@ def main():
     img_cpu = torch.randn(B, 3, H, W, generator=g)
     img = img_cpu.to(dev)
     metas = synthetic.img_metas(B, H, W)
+
+    if args.mode == 'train':
+        return train_main(args, cfg, model, img, metas, dev, rank, world)
 
     def step():
         with torch.no_grad():
@@ -188,8 +250,8 @@ def main():
         ms = [s.elapsed_time(e) for s, e in events['msda_fused']]
         ms = sum(ms) / len(ms)
         N = sum((H // s) * (W // s) for s in (8, 16, 32))
-        vb = 2 if args.precision == 'bf16' else 4
-        mbytes = B * N * (256 * vb + 288 * 4 + 256 * 4)
+        vb = 2 if args.precision == 'bf16' else 4         # bf16 stream: value, offsets|logits and output are bf16
+        mbytes = B * N * (256 * vb + 288 * vb + 256 * vb)
         extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9)
 
     if rank == 0:

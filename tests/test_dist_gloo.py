@@ -71,6 +71,40 @@ def _worker(rank, world, port, ret):
         assert abs(logs['loss_a'] - 1.5) < 1e-6 and abs(logs['loss_b'] - 3.0) < 1e-6
         assert abs(logs['loss'] - 4.5) < 1e-6 and abs(float(total) - (1.0 + rank + 2.0 * (rank + 1))) < 1e-6
         assert total.requires_grad
+        # --- C1: bucketed, backward-overlapped gradient averaging == mean of the per-rank gradients ---
+        from cgg_amd.train import GradReducer, build_optimizer, clip_grad_norm_
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16),
+                                  torch.nn.LayerNorm(16), torch.nn.Linear(16, 4))
+        unused = torch.nn.Linear(3, 3)          # never touched by the loss
+        net.add_module('unused', unused)
+        xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+
+        def local_grads(r):
+            net.zero_grad(set_to_none=True)
+            net[4](net[3](net[2](net[1](net[0](xs[r]))))).square().sum().backward()
+            return [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        want = [local_grads(r) for r in range(world)]
+        net.zero_grad(set_to_none=True)
+        red = GradReducer(net, bucket_bytes=1024)          # tiny buckets -> several exchanges
+        assert len(red.buckets) > 2
+        for _ in range(2):                                  # second pass: buffers are re-armed and re-zeroed
+            red.zero_grad()
+            net[4](net[3](net[2](net[1](net[0](xs[rank]))))).square().sum().backward()
+            red.finish()
+            for i, p in enumerate(net.parameters()):
+                if want[0][i] is None:
+                    assert p.grad is not None and p.grad.abs().sum() == 0
+                else:
+                    mean = sum(w[i] for w in want) / world
+                    assert torch.allclose(p.grad, mean, atol=1e-6), i
+        total = clip_grad_norm_(red.flats(), 0.01)
+        ref = torch.sqrt(sum(((sum(w[i] for w in want) / world) ** 2).sum() for i in range(len(want[0]))
+                             if want[0][i] is not None))
+        assert torch.allclose(total, ref, atol=1e-5)
+        after = torch.sqrt(sum((f ** 2).sum() for f in red.flats()))
+        assert after <= 0.01 * (1 + 1e-4)
+        red.remove()
         dist.barrier()
         dist.destroy_process_group()
         ret[rank] = 'ok'

@@ -184,3 +184,29 @@ def test_synthetic_batch_contract():
     assert b['gt_caption_ids'][0].shape == (35,) and int(b['gt_caption_ids'][0][0]) == 101
     assert int((b['gt_caption_ids'][0] == 102).sum()) == 1
     assert torch.equal(b['gt_caption_mask'][0], (b['gt_caption_ids'][0] != 0).long())
+
+
+def test_build_optimizer_paramwise(detector):
+    """configs/instance/coco_b48n17.py:270-285: backbone lr x0.1, embeddings / norms without weight decay."""
+    from cgg_amd.train import build_optimizer
+    _, m = detector
+    embed_multi = dict(lr_mult=1.0, decay_mult=0.0)
+    opt = build_optimizer(m, dict(type='AdamW', lr=1e-4, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999),
+                                  paramwise_cfg=dict(custom_keys={'backbone': dict(lr_mult=0.1, decay_mult=1.0),
+                                                                  'query_embed': embed_multi,
+                                                                  'query_feat': embed_multi,
+                                                                  'level_embed': embed_multi},
+                                                     norm_decay_mult=0.0)))
+    where = {}
+    for g in opt.param_groups:
+        for p in g['params']:
+            where[id(p)] = (g['lr'], g['weight_decay'])
+    names = dict(m.named_parameters())
+    h = 'panoptic_head.'
+    assert where[id(names['backbone.layer4.0.conv1.weight'])] == (1e-5, 0.05)
+    assert where[id(names[h + 'query_embed.weight'])] == (1e-4, 0.0)
+    assert where[id(names[h + 'level_embed.weight'])] == (1e-4, 0.0)
+    assert where[id(names[h + 'transformer_decoder.post_norm.weight'])] == (1e-4, 0.0)
+    assert where[id(names[h + 'mask_embed.0.weight'])] == (1e-4, 0.05)
+    assert all(id(p) in where for p in m.parameters() if p.requires_grad)
+    assert not any(id(p) in where for p in m.parameters() if not p.requires_grad)
