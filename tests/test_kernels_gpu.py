@@ -129,6 +129,44 @@ def test_msda_backward_vs_autograd(dev):
     assert (gl.cpu() - l64.grad.float()).abs().max().item() <= 2e-3
 
 
+@pytest.mark.parametrize('shapes,H,D,P,spread', [
+    ([(8, 8), (16, 16), (32, 32)], 8, 32, 4, 0.0),      # local offsets: LDS-window path of the tiled kernel
+    ([(8, 8), (16, 16), (32, 32)], 8, 32, 4, 1.0),      # half of the taps far away: global-atomic path
+    ([(5, 7), (10, 14), (20, 28)], 2, 32, 4, 0.0),      # ragged pyramid, edge tiles
+    ([(6, 6), (12, 12)], 4, 16, 3, 0.3),                # generic P, two levels
+    ([(6, 6), (11, 12)], 4, 16, 4, 0.0),                # non-integer scale -> untiled kernel
+])
+def test_msda_backward_self_attention_tiled(dev, shapes, H, D, P, spread):
+    """Encoder case (queries == pixels of the pyramid): sampling locations = the query's own reference point +
+    a few pixels (what the trained offsets look like), optionally mixed with far-away samples."""
+    g = torch.Generator().manual_seed(60)
+    starts, Nv = _levels(shapes)
+    L, B = len(shapes), 2
+    value = torch.randn(B, Nv, H, D, generator=g)
+    refs = []
+    for (h, w) in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    refp = torch.cat(refs, 0)                                            # (Nv, 2) in (x, y)
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)  # (L, 2)
+    off = (torch.rand(B, Nv, H, L, P, 2, generator=g) - 0.5) * 9.0       # up to +-4.5 px in the level's units
+    loc = refp[None, :, None, None, None, :] + off / wh[None, None, None, :, None, :]
+    far = torch.rand(B, Nv, H, L, P, 1, generator=g) < 0.5 * spread
+    loc = torch.where(far, torch.rand(B, Nv, H, L, P, 2, generator=g) * 1.4 - 0.2, loc)
+    aw = torch.softmax(torch.randn(B, Nv, H, L * P, generator=g), -1).view(B, Nv, H, L, P)
+    ss = torch.tensor(shapes, dtype=torch.int64)
+    st = torch.tensor(starts, dtype=torch.int64)
+    v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, aw))
+    out = ref.msda_core(v64, ss, l64, a64)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.double())
+    gv, gl, ga = ops.msda_backward(value.to(dev), ss.to(dev), st.to(dev), loc.to(dev), aw.to(dev), go.to(dev))
+    assert (gv.cpu() - v64.grad.float()).abs().max().item() <= 2e-4
+    assert (ga.cpu() - a64.grad.float()).abs().max().item() <= 2e-4
+    d = (gl.cpu() - l64.grad.float()).abs()
+    assert d.max().item() <= 5e-3 * max(1.0, l64.grad.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B,Q,H,W', [(2, 100, 32, 32), (1, 100, 20, 28), (2, 37, 16, 24), (1, 128, 64, 64)])
 def test_mask_logits_split_within_1e3(dev, B, Q, H, W):
