@@ -277,26 +277,38 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
 // Tiled backward for the encoder's self-attention case (queries == the pixels of the value pyramid, integer
 // scale between levels): one block = (image-space tile, batch, head). The tile is c x c pixels of the coarsest
 // level and the co-located (c*s_l)^2 pixels of every finer level, so ALL its queries sample around the same
-// image region. grad_value is accumulated in LDS windows (tile footprint + R-pixel halo per level, f32,
-// ds_add_f32) and leaves the block ONCE per window element as line-coalesced global atomics; taps that fall
-// outside the windows (large learned offsets) go straight to global atomics, so the result does not depend on
-// the locality assumption -- only the speed does. At configs[2] shapes (16 x 21 504 queries x 8 heads x 48
-// taps) this cuts the L2 atomic requests ~60x vs one atomic per tap-channel (cgg_msda_bwd_kernel: 50 ms/layer).
+// image region. grad_value is accumulated in LDS windows (tile footprint + R-pixel halo per level) and leaves the
+// block ONCE per window element as line-coalesced global f32 atomics; taps that fall outside the windows (large
+// learned offsets) go straight to global atomics, so the result does not depend on the locality assumption --
+// only the speed does.
+//
+// The LDS accumulators are 64-bit FIXED POINT, not f32: measured on MI355X, ds_add_f32 retires ~0.3 lane-ops per
+// clock per CU (the f32 version of this kernel took 21.5 ms per layer at configs[2] shapes, 18 ms of it in the
+// LDS atomics) while ds_add_u64 runs at the integer rate (4.7 ms for the same work). Every contribution
+// x = corner_weight * attn_weight * grad_out is scaled by 2^k, k chosen per block from max|attn_weight| *
+// max|grad_out| over the tile so that the worst-case sum of all the tile's taps stays below 2^51, and converted
+// with the 1.5*2^52 magic-number add: resolution 2^-40 of the tile's largest contribution (finer than f32), and
+// the in-window sum is order-independent, i.e. deterministic. A tile whose bound is 0, Inf or NaN skips the
+// windows (all its taps use the global f32 atomics, which propagate non-finite values as the reference does).
 struct MsdaTilePlan {
   int c, R, tx, ty, ntile;
   int s[8];      // W_l / W_coarse
   int ww[8];     // window width  = c*s + 2R
-  int off[8];    // float offset of level l's window in LDS
-  int total_f;   // floats of LDS
+  int off[8];    // element offset of level l's window in LDS
+  int total;     // window elements (8 B each)
+  int kbase;     // 50 - ceil(log2(max taps per tile))
+  int nthreads;
 };
 
 template <int P_>
-__global__ __launch_bounds__(512) void cgg_msda_bwd_tiled_kernel(
+__global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
     const float* __restrict__ value, MsdaLevels lv, MsdaTilePlan pl, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ gout, float* __restrict__ gvalue,
     float* __restrict__ gloc, float* __restrict__ gattw, int Nv, int H, int D, int L, int Nq, int Prt) {
-  extern __shared__ __attribute__((aligned(16))) float win[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long win[];
+  __shared__ float red[2][16];
   const int P = P_ > 0 ? P_ : Prt;
+  constexpr int PC = P_ > 0 ? P_ : 1;   // points per load batch
   const int DQ = D >> 2;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
@@ -304,127 +316,212 @@ __global__ __launch_bounds__(512) void cgg_msda_bwd_tiled_kernel(
   const int h = (bid / pl.ntile) % H;
   const int b = bid / (pl.ntile * H);
   const int tyi = tile / pl.tx, txi = tile % pl.tx;
-  for (int i = tid; i < (pl.total_f >> 2); i += nth) reinterpret_cast<f32x4*>(win)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
+  for (int i = tid; i < pl.total; i += nth) win[i] = 0ull;
 
   const size_t rowstride = (size_t)H * D;
   const int LP = L * P;
-  for (int lq = 0; lq < L; ++lq) {
-    const int sq = pl.s[lq], Wq = lv.w[lq], Hq = lv.h[lq];
-    const int x0 = txi * pl.c * sq, y0 = tyi * pl.c * sq;
-    const int tw = min(pl.c * sq, Wq - x0), th = min(pl.c * sq, Hq - y0);
-    const int nslots = tw * th * DQ;
-    const int nround = (nslots + 63) & ~63;
-    for (int sl = tid; sl < nround; sl += nth) {      // wave-uniform trip count (nth % 64 == 0)
-      const bool live = sl < nslots;
-      const int qi = live ? sl / DQ : 0;
-      const int cq = sl % DQ;
-      const int n = lv.start[lq] + (y0 + qi / tw) * Wq + x0 + qi % tw;
-      const long long bq = (long long)b * Nq + n;
-      const size_t coff = (size_t)h * D + cq * 4;
-      const float* vb = value + (size_t)b * Nv * rowstride + coff;
-      float* gvb = gvalue + (size_t)b * Nv * rowstride + coff;
-      const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
-      const float* wp = attw + ((size_t)bq * H + h) * LP;
-      float* glp = gloc + ((size_t)bq * H + h) * LP * 2;
-      float* gwp = gattw + ((size_t)bq * H + h) * LP;
-      f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + coff);
-      if (!live) g = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int l = 0; l < L; ++l) {
-        const int Hl = lv.h[l], Wl = lv.w[l];
-        const float* vl = vb + (size_t)lv.start[l] * rowstride;
-        float* gvl = gvb + (size_t)lv.start[l] * rowstride;
-        const int ox = txi * pl.c * pl.s[l] - pl.R, oy = tyi * pl.c * pl.s[l] - pl.R;
-        const int ww = pl.ww[l];
-        float* wl = win + pl.off[l] + cq * 4;
-#pragma unroll
-        for (int p = 0; p < (P_ > 0 ? P_ : 1); ++p) {
-          for (int pp = (P_ > 0 ? p : 0); pp < (P_ > 0 ? p + 1 : P); ++pp) {
-            const int i = l * P + pp;
-            const float x = lp[2 * i], y = lp[2 * i + 1], w = wp[i];
-            const float him = y * (float)Hl - 0.5f, wim = x * (float)Wl - 0.5f;
-            const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
-            const float hf = floorf(him), wf = floorf(wim);
-            const int h0 = (int)hf, w0 = (int)wf;
-            const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
-            const bool vh0 = in && h0 >= 0, vh1 = in && (h0 + 1) <= Hl - 1;
-            const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wl - 1;
-            const bool k00 = vh0 && vw0, k01 = vh0 && vw1, k10 = vh1 && vw0, k11 = vh1 && vw1;
-            const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h0 + 1, 0), Hl - 1);
-            const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w0 + 1, 0), Wl - 1);
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v00 = k00 ? cgg_ld4(vl + (size_t)(ch0 * Wl + cw0) * rowstride) : z4;
-            const f32x4 v01 = k01 ? cgg_ld4(vl + (size_t)(ch0 * Wl + cw1) * rowstride) : z4;
-            const f32x4 v10 = k10 ? cgg_ld4(vl + (size_t)(ch1 * Wl + cw0) * rowstride) : z4;
-            const f32x4 v11 = k11 ? cgg_ld4(vl + (size_t)(ch1 * Wl + cw1) * rowstride) : z4;
-            float dotv = 0.f, dotx = 0.f, doty = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float val = hh * hw * v00[c] + hh * lw * v01[c] + lh * hw * v10[c] + lh * lw * v11[c];
-              const float dw = hh * (v01[c] - v00[c]) + lh * (v11[c] - v10[c]);
-              const float dh = hw * (v10[c] - v00[c]) + lw * (v11[c] - v01[c]);
-              dotv += val * g[c];
-              dotx += dw * g[c];
-              doty += dh * g[c];
-            }
-            for (int o = 1; o < DQ; o <<= 1) {
-              dotv += __shfl_xor(dotv, o);
-              dotx += __shfl_xor(dotx, o);
-              doty += __shfl_xor(doty, o);
-            }
-            if (live && cq == 0) {
-              gwp[i] += dotv;
-              glp[2 * i] += (float)Wl * w * dotx;
-              glp[2 * i + 1] += (float)Hl * w * doty;
-            }
-            if (live) {
-              const f32x4 wg = w * g;
-              const int wy0 = h0 - oy, wx0 = w0 - ox;      // window coords of corner (h0, w0)
-              const bool iy0 = (unsigned)wy0 < (unsigned)ww, iy1 = (unsigned)(wy0 + 1) < (unsigned)ww;
-              const bool ix0 = (unsigned)wx0 < (unsigned)ww, ix1 = (unsigned)(wx0 + 1) < (unsigned)ww;
-#define CGG_SCATTER(K, HY, WX, IY, IX, CH, CW, WT)                                         \
-  if (K) {                                                                                  \
-    const float cw_ = (WT);                                                                 \
-    if ((IY) && (IX)) {                                                                     \
-      float* d = wl + (size_t)((HY) * ww + (WX)) * D;                                       \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) atomicAdd(d + c, cw_ * wg[c]);          \
-    } else {                                                                                \
-      float* d = gvl + (size_t)((CH) * Wl + (CW)) * rowstride;                              \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) atomicAdd(d + c, cw_ * wg[c]);          \
-    }                                                                                       \
+  // slots of the tile, all query levels flattened: slot -> (query level, pixel in the tile rect, channel quad)
+  __shared__ int nsl[8], tw[8], x0[8], y0[8];
+  int nslots = 0;
+  for (int l = 0; l < L; ++l) {
+    const int e = pl.c * pl.s[l];
+    const int xx = txi * e, yy = tyi * e;
+    const int tww = min(e, lv.w[l] - xx);
+    const int ns = tww * min(e, lv.h[l] - yy) * DQ;
+    if (tid == 0) {
+      x0[l] = xx;
+      y0[l] = yy;
+      tw[l] = tww;
+      nsl[l] = ns;
+    }
+    nslots += ns;
   }
-              CGG_SCATTER(k00, wy0, wx0, iy0, ix0, ch0, cw0, hh * hw)
-              CGG_SCATTER(k01, wy0, wx0 + 1, iy0, ix1, ch0, cw1, hh * lw)
-              CGG_SCATTER(k10, wy0 + 1, wx0, iy1, ix0, ch1, cw0, lh * hw)
-              CGG_SCATTER(k11, wy0 + 1, wx0 + 1, iy1, ix1, ch1, cw1, lh * lw)
+  __syncthreads();
+  const int nround = (nslots + 63) & ~63;
+
+  // ---- pass 0: bound M >= |attn_weight * grad_out| over the tile -> fixed-point scale 2^k ----
+  float mg = 0.f, mw = 0.f;
+  bool bad = false;
+  for (int sl = tid; sl < nslots; sl += nth) {
+    int lq = 0, r = sl;
+    while (r >= nsl[lq]) { r -= nsl[lq]; ++lq; }
+    const int qi = r / DQ, cq = r % DQ;
+    const int n = lv.start[lq] + (y0[lq] + qi / tw[lq]) * lv.w[lq] + x0[lq] + qi % tw[lq];
+    const long long bq = (long long)b * Nq + n;
+    const f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + (size_t)h * D + cq * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mg = fmaxf(mg, fabsf(g[c]));
+      bad |= !(fabsf(g[c]) <= 3.0e38f);
+    }
+    const float* wp = attw + ((size_t)bq * H + h) * LP;
+    for (int i = cq; i < LP; i += DQ) {
+      mw = fmaxf(mw, fabsf(wp[i]));
+      bad |= !(fabsf(wp[i]) <= 3.0e38f);
+    }
+  }
+  if (bad) mg = __builtin_inff();
+  for (int o = 32; o > 0; o >>= 1) {
+    mg = fmaxf(mg, __shfl_xor(mg, o));
+    mw = fmaxf(mw, __shfl_xor(mw, o));
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = mg;
+    red[1][tid >> 6] = mw;
+  }
+  __syncthreads();   // also orders the window zero-fill before the first ds_add
+  mg = 0.f;
+  mw = 0.f;
+  for (int i = 0; i < (nth >> 6); ++i) {
+    mg = fmaxf(mg, red[0][i]);
+    mw = fmaxf(mw, red[1][i]);
+  }
+  const float M = mg * mw;
+  const bool use_lds = (M > 0.f) && (M <= 3.0e38f);
+  int kexp = 0;
+  if (use_lds) {
+    int e;
+    (void)frexpf(M, &e);              // M < 2^e
+    kexp = pl.kbase - e;              // |x * 2^k| < 2^kbase; sum over <= 2^(50-kbase) taps < 2^50
+  }
+  const double scale = ldexp(1.0, kexp);
+  const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
+
+  for (int sl = tid; sl < nround; sl += nth) {      // wave-uniform trip count (nth % 64 == 0)
+    const bool live = sl < nslots;
+    int lq = 0, r = live ? sl : 0;
+    while (r >= nsl[lq]) { r -= nsl[lq]; ++lq; }
+    const int qi = r / DQ, cq = r % DQ;
+    const int n = lv.start[lq] + (y0[lq] + qi / tw[lq]) * lv.w[lq] + x0[lq] + qi % tw[lq];
+    const long long bq = (long long)b * Nq + n;
+    const size_t coff = (size_t)h * D + cq * 4;
+    const float* vb = value + (size_t)b * Nv * rowstride + coff;
+    float* gvb = gvalue + (size_t)b * Nv * rowstride + coff;
+    const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
+    const float* wp = attw + ((size_t)bq * H + h) * LP;
+    float* glp = gloc + ((size_t)bq * H + h) * LP * 2;
+    float* gwp = gattw + ((size_t)bq * H + h) * LP;
+    f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + coff);
+    if (!live) g = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+      const int Hl = lv.h[l], Wl = lv.w[l];
+      const float* vl = vb + (size_t)lv.start[l] * rowstride;
+      float* gvl = gvb + (size_t)lv.start[l] * rowstride;
+      const int ox = txi * pl.c * pl.s[l] - pl.R, oy = tyi * pl.c * pl.s[l] - pl.R;
+      const int ww = use_lds ? pl.ww[l] : 0;           // ww == 0: every tap takes the global path
+      unsigned long long* wl = win + pl.off[l] + cq * 4;
+      // all P_ points of this level: geometry + the 4*P_ corner loads are issued before any use, so one
+      // L2 round trip covers the level instead of P_ dependent ones
+      for (int p0 = 0; p0 < P; p0 += PC) {
+        f32x4 v[PC][4];
+        float lh[PC], lw[PC], wt[PC];
+        int h0[PC], w0[PC];
+        bool k[PC][4];
+        int ro[PC][4];
+#pragma unroll
+        for (int p = 0; p < PC; ++p) {
+          const int i = l * P + p0 + p;
+          const float x = lp[2 * i], y = lp[2 * i + 1];
+          wt[p] = wp[i];
+          const float him = y * (float)Hl - 0.5f, wim = x * (float)Wl - 0.5f;
+          const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
+          const float hf = floorf(him), wf = floorf(wim);
+          h0[p] = (int)hf;
+          w0[p] = (int)wf;
+          lh[p] = him - hf;
+          lw[p] = wim - wf;
+          const bool vh0 = in && h0[p] >= 0, vh1 = in && (h0[p] + 1) <= Hl - 1;
+          const bool vw0 = w0[p] >= 0, vw1 = (w0[p] + 1) <= Wl - 1;
+          k[p][0] = vh0 && vw0; k[p][1] = vh0 && vw1; k[p][2] = vh1 && vw0; k[p][3] = vh1 && vw1;
+          const int ch0 = min(max(h0[p], 0), Hl - 1), ch1 = min(max(h0[p] + 1, 0), Hl - 1);
+          const int cw0 = min(max(w0[p], 0), Wl - 1), cw1 = min(max(w0[p] + 1, 0), Wl - 1);
+          ro[p][0] = ch0 * Wl + cw0; ro[p][1] = ch0 * Wl + cw1; ro[p][2] = ch1 * Wl + cw0; ro[p][3] = ch1 * Wl + cw1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[p][q] = cgg_ld4(vl + (size_t)ro[p][q] * rowstride);
+        }
+#pragma unroll
+        for (int p = 0; p < PC; ++p) {
+          const int i = l * P + p0 + p;
+          const float hh = 1.f - lh[p], hw = 1.f - lw[p];
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 v00 = k[p][0] ? v[p][0] : z4, v01 = k[p][1] ? v[p][1] : z4;
+          const f32x4 v10 = k[p][2] ? v[p][2] : z4, v11 = k[p][3] ? v[p][3] : z4;
+          float dotv = 0.f, dotx = 0.f, doty = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float val = hh * hw * v00[c] + hh * lw[p] * v01[c] + lh[p] * hw * v10[c] + lh[p] * lw[p] * v11[c];
+            const float dw = hh * (v01[c] - v00[c]) + lh[p] * (v11[c] - v10[c]);
+            const float dh = hw * (v10[c] - v00[c]) + lw[p] * (v11[c] - v01[c]);
+            dotv += val * g[c];
+            dotx += dw * g[c];
+            doty += dh * g[c];
+          }
+          for (int o = 1; o < DQ; o <<= 1) {
+            dotv += __shfl_xor(dotv, o);
+            dotx += __shfl_xor(dotx, o);
+            doty += __shfl_xor(doty, o);
+          }
+          if (live && cq == 0) {
+            // grad_loc / grad_attn follow the accumulate-into-prezeroed contract of the C ABI
+            gwp[i] += dotv;
+            glp[2 * i] += (float)Wl * wt[p] * dotx;
+            glp[2 * i + 1] += (float)Hl * wt[p] * doty;
+          }
+          if (live) {
+            const f32x4 wg = wt[p] * g;
+            double wgd[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wgd[c] = (double)wg[c] * scale;
+            const int wy0 = h0[p] - oy, wx0 = w0[p] - ox;      // window coords of corner (h0, w0)
+            const bool iy0 = (unsigned)wy0 < (unsigned)ww, iy1 = (unsigned)(wy0 + 1) < (unsigned)ww;
+            const bool ix0 = (unsigned)wx0 < (unsigned)ww, ix1 = (unsigned)(wx0 + 1) < (unsigned)ww;
+#define CGG_SCATTER(K, HY, WX, IY, IX, RO, WT)                                                         \
+  if (K) {                                                                                              \
+    const float cw_ = (WT);                                                                             \
+    if ((IY) && (IX)) {                                                                                 \
+      unsigned long long* d = wl + (size_t)((HY) * ww + (WX)) * D;                                      \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                   \
+        const double m_ = fma((double)cw_, wgd[c], kMagic);                                             \
+        atomicAdd(d + c, (unsigned long long)(__double_as_longlong(m_) - __double_as_longlong(kMagic))); \
+      }                                                                                                 \
+    } else {                                                                                            \
+      float* d = gvl + (size_t)(RO) * rowstride;                                                        \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) atomicAdd(d + c, cw_ * wg[c]);                      \
+    }                                                                                                   \
+  }
+            CGG_SCATTER(k[p][0], wy0, wx0, iy0, ix0, ro[p][0], hh * hw)
+            CGG_SCATTER(k[p][1], wy0, wx0 + 1, iy0, ix1, ro[p][1], hh * lw[p])
+            CGG_SCATTER(k[p][2], wy0 + 1, wx0, iy1, ix0, ro[p][2], lh[p] * hw)
+            CGG_SCATTER(k[p][3], wy0 + 1, wx0 + 1, iy1, ix1, ro[p][3], lh[p] * lw[p])
 #undef CGG_SCATTER
-            }
           }
         }
       }
     }
   }
   __syncthreads();
+  if (!use_lds) return;
   // flush: one global atomic per touched window element, 128-B lines per 32 lanes
+  const double inv = ldexp(1.0, -kexp);
   for (int l = 0; l < L; ++l) {
-    const int Hl = lv.h[l], Wl = lv.w[l], ww = pl.ww[l];
+    const int Wl = lv.w[l], ww = pl.ww[l];
     const int ox = txi * pl.c * pl.s[l] - pl.R, oy = tyi * pl.c * pl.s[l] - pl.R;
     float* gvl = gvalue + ((size_t)b * Nv + lv.start[l]) * rowstride + (size_t)h * D;
-    const float* wl = win + pl.off[l];
+    const unsigned long long* wl = win + pl.off[l];
     const int nf = ww * ww * D;
     for (int i = tid; i < nf; i += nth) {
-      const float v = wl[i];
-      if (v != 0.f) {
+      const long long a = (long long)wl[i];
+      if (a != 0) {
         const int px = i / D, ch = i - px * D;
-        const int iy = oy + px / ww, ix = ox + px % ww;      // inside the image whenever v != 0
-        atomicAdd(gvl + (size_t)(iy * Wl + ix) * rowstride + ch, v);
+        const int iy = oy + px / ww, ix = ox + px % ww;      // inside the image whenever a != 0
+        atomicAdd(gvl + (size_t)(iy * Wl + ix) * rowstride + ch, (float)((double)a * inv));
       }
     }
   }
 }
 
 // Choose (c, R) so that the windows fit in LDS; returns false if the pyramid is not tileable.
-static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int Nq, int Nv, MsdaTilePlan* pl) {
+static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, int Nv, MsdaTilePlan* pl) {
   if (Nq != Nv || L < 1 || L > 8) return false;
   int lc = 0;
   long long tot = 0;
@@ -437,23 +534,31 @@ static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int Nq, int Nv, M
     if (lv.w[l] % lv.w[lc] || lv.h[l] % lv.h[lc] || lv.w[l] / lv.w[lc] != lv.h[l] / lv.h[lc]) return false;
     pl->s[l] = lv.w[l] / lv.w[lc];
   }
-  const int cand[4][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 2}};
+  const int cand[4][2] = {{2, 4}, {2, 3}, {1, 3}, {1, 2}};
   for (int k = 0; k < 4; ++k) {
     const int c = cand[k][0], R = cand[k][1];
-    long long f = 0;
+    long long f = 0, nq = 0;
     for (int l = 0; l < L; ++l) {
       pl->ww[l] = c * pl->s[l] + 2 * R;
       pl->off[l] = (int)f;
       f += (long long)pl->ww[l] * pl->ww[l] * D;
+      nq += (long long)c * pl->s[l] * c * pl->s[l];
     }
-    if (f * 4 <= 128 * 1024) {
+    if (f * 8 <= 144 * 1024) {
       pl->c = c;
       pl->R = R;
       pl->tx = (lv.w[lc] + c - 1) / c;
       pl->ty = (lv.h[lc] + c - 1) / c;
       pl->ntile = pl->tx * pl->ty;
-      pl->total_f = (int)f;
-      return true;
+      pl->total = (int)f;
+      long long taps = nq * L * P;       // upper bound of contributions to one window element
+      int hr = 0;
+      while ((1ll << hr) < taps) ++hr;
+      pl->kbase = 50 - hr;
+      const long long slots = nq * (D / 4);
+      long long nt = (slots + 63) / 64 * 64;
+      pl->nthreads = (int)(nt < 64 ? 64 : (nt > 768 ? 768 : nt));
+      return pl->kbase >= 24;
     }
   }
   return false;
@@ -606,8 +711,8 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
   rc = msda_read_levels(spatial_shapes, level_start, L, Nv, s, &lv, "cgg_msda_backward");
   if (rc) return rc;
   MsdaTilePlan pl;
-  if (D % 4 == 0 && msda_tile_plan(lv, L, D, Nq, Nv, &pl)) {
-    const size_t lds = (size_t)pl.total_f * sizeof(float);
+  if (D % 4 == 0 && msda_tile_plan(lv, L, D, P, Nq, Nv, &pl)) {
+    const size_t lds = (size_t)pl.total * sizeof(unsigned long long);
     const int nblk = B * H * pl.ntile;
     auto kern = (P == 4) ? cgg_msda_bwd_tiled_kernel<4> : cgg_msda_bwd_tiled_kernel<0>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -615,7 +720,7 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
       cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
       return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, value, lv, pl, sampling_loc, attn_weight, grad_out,
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(pl.nthreads), lds, s, value, lv, pl, sampling_loc, attn_weight, grad_out,
                        grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P);
     CGG_CHECK_LAUNCH("cgg_msda_backward(tiled)");
     return CGG_OK;
