@@ -215,11 +215,9 @@ class ResNet(nn.Module):
                     x = self._conv_nhwc(y, blk.conv2, next(seq), True, identity)
             if i in self.out_indices:
                 outs.append(x)
-        res = []
-        for o in outs:      # (B, H, W, C) bf16 -> NCHW f32 in one transposing copy
-            B, H, W, C = o.shape
-            res.append(torch.empty((B, C, H, W), dtype=torch.float32, device=o.device).copy_(o.permute(0, 3, 1, 2)))
-        return tuple(res)
+        # (B, C, H, W)-shaped views of the channel-last bf16 activations: no copy, no cast. The pixel decoder's
+        # inference stream consumes them as they are; anything else can `.float().contiguous()` them.
+        return tuple(o.permute(0, 3, 1, 2) for o in outs)
 
     def forward(self, x):
         frozen_bn = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))

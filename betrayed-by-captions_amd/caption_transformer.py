@@ -151,9 +151,18 @@ class TransformerDecoder(nn.Module):
         return outs
 
 
+_CAUSAL = {}
+
+
 def build_mask(seq):
+    """Causal mask (True = blocked), cached per (length, device)."""
     L = seq.shape[1]
-    return torch.ones(L, L, dtype=torch.bool).triu(1)
+    key = (L, str(seq.device))
+    m = _CAUSAL.get(key)
+    if m is None:
+        m = torch.ones(L, L, dtype=torch.bool).triu(1).to(seq.device)
+        _CAUSAL[key] = m
+    return m
 
 
 def build_key_padding_mask(seq, pad_idx):

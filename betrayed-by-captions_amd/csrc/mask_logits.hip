@@ -67,6 +67,52 @@ __global__ __launch_bounds__(256) void cgg_pack_kernel(const float* __restrict__
   }
 }
 
+// pack from a channel-last bf16 map (the throughput-mode pixel decoder's mask_feature GEMM output):
+// [B, H, W, C] bf16 -> [B, T, C/8, 32, 8] bf16. A pure permutation of 16-byte chunks (plus the 2x2 mean when
+// pool > 1): one block = one 32-pixel tile; chunks are read pixel-major (512 contiguous bytes per pixel) and
+// written octet-major through LDS so that both sides move full lines.
+__global__ __launch_bounds__(256) void cgg_pack_nhwc_kernel(const uint4* __restrict__ feat, u32x4* __restrict__ hi,
+                                                            int KC, int H, int W, int pool, int Wp, int npix,
+                                                            int T) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 tile[];   // [KC][32]
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int n = KC * 32;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    const int pl = idx / KC, kc = idx - pl * KC;
+    const int p = t * 32 + pl;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (p < npix) {
+      if (pool == 1) {
+        const uint4 v = feat[((size_t)b * H * W + p) * KC + kc];
+        o = u32x4{v.x, v.y, v.z, v.w};
+      } else {
+        const int i = p / Wp, j = p - i * Wp;
+        const int r0 = pool * i + (pool >> 1) - 1, c0 = pool * j + (pool >> 1) - 1;
+        const size_t base = ((size_t)b * H * W + (size_t)r0 * W + c0) * KC + kc;
+        const uint4 v00 = feat[base], v01 = feat[base + KC];
+        const uint4 v10 = feat[base + (size_t)W * KC], v11 = feat[base + (size_t)W * KC + KC];
+        const uint32_t a[4] = {v00.x, v00.y, v00.z, v00.w}, c[4] = {v01.x, v01.y, v01.z, v01.w};
+        const uint32_t d[4] = {v10.x, v10.y, v10.z, v10.w}, e[4] = {v11.x, v11.y, v11.z, v11.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // same association order as the NCHW pack kernel / torch's bilinear with all lambdas == 0.5
+          const float lo = ((__uint_as_float(a[k] << 16) + __uint_as_float(c[k] << 16)) +
+                            (__uint_as_float(d[k] << 16) + __uint_as_float(e[k] << 16))) * 0.25f;
+          const float hh = ((__uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u)) +
+                            (__uint_as_float(d[k] & 0xffff0000u) + __uint_as_float(e[k] & 0xffff0000u))) * 0.25f;
+          r[k] = cgg_pack2(cgg_f2bf(lo), cgg_f2bf(hh));
+        }
+        o = u32x4{r[0], r[1], r[2], r[3]};
+      }
+    }
+    tile[kc * 32 + pl] = o;
+  }
+  __syncthreads();
+  u32x4* dst = hi + ((size_t)b * T + t) * n;
+  for (int idx = threadIdx.x; idx < n; idx += 256) dst[idx] = tile[idx];
+}
+
 // -------------------------------------------------------------------------------------------------
 // mask logits. Workgroup = 8 waves sharing one image's mask_embed in LDS; each wave streams its own
 // 32-pixel tiles: 16 k-steps x ceil(Q/32) m-tiles of v_mfma_f32_32x32x16_bf16 (x3 in SPLIT mode).
@@ -315,6 +361,24 @@ extern "C" int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int 
     hipLaunchKernelGGL(cgg_pack_kernel<false>, grid, dim3(256), 0, s, feat, (u32x4*)hi,
                        (u32x4*)nullptr, C, H, W, pool, Wp, npix, T);
   CGG_CHECK_LAUNCH("cgg_pack_mask_feature");
+  return CGG_OK;
+}
+
+extern "C" int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, int W, int pool,
+                                          cgg_stream_t stream) {
+  CGG_REQUIRE(feat && hi, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && pool >= 1, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: bad sizes");
+  CGG_REQUIRE(C % 8 == 0 && C <= 1024, CGG_EUNSUPPORTED, "cgg_pack_mask_feature_nhwc: C=%d", C);
+  CGG_REQUIRE(pool == 1 || (pool % 2 == 0 && H % pool == 0 && W % pool == 0), CGG_EUNSUPPORTED,
+              "cgg_pack_mask_feature_nhwc: pool=%d must be 1 or an even divisor of %dx%d", pool, H, W);
+  CGG_REQUIRE(cgg_aligned16(feat) && cgg_aligned16(hi), CGG_EALIGN, "cgg_pack_mask_feature_nhwc: alignment");
+  const int Hp = H / pool, Wp = W / pool;
+  const int npix = Hp * Wp;
+  const int T = (npix + 31) / 32;
+  const int KC = C / 8;
+  hipLaunchKernelGGL(cgg_pack_nhwc_kernel, dim3(T, B), dim3(256), (size_t)KC * 32 * 16, (hipStream_t)stream,
+                     (const uint4*)feat, (u32x4*)hi, KC, H, W, pool, Wp, npix, T);
+  CGG_CHECK_LAUNCH("cgg_pack_mask_feature_nhwc");
   return CGG_OK;
 }
 

@@ -118,3 +118,168 @@ extern "C" int cgg_group_norm(const float* x, const float* gamma, const float* b
   CGG_CHECK_LAUNCH("cgg_group_norm");
   return CGG_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Channel-last (NHWC) bf16 GroupNorm for the throughput-mode pixel decoder: x [B, HW, C] is the bf16 output of
+// a 1x1-conv GEMM / MIOpen NHWC conv; C / groups == 8, so ONE 16-byte vector is exactly one group of one pixel.
+//   stats : per (b, g) sum and sum of squares (f32 partials per thread, LDS tree, one atomic pair per block)
+//   apply : y = (x - mean) * rstd * gamma + beta [+ bilinear x2 up-sample of a low-res f32 NHWC map] [ReLU], with
+//           up to three outputs from the one pass:
+//             y32 f32, rows at b * y32_bstride (lets the three encoder levels land directly in the (B, N, 256)
+//                 residual stream `src` -- no flatten / transpose / cat),
+//             y16 = bf16(y) dense, yp16 = bf16(y + pos[p]) dense (the first encoder layer's GEMM inputs).
+// -------------------------------------------------------------------------------------------------
+#define GNH_PIX 64   // pixels per stats block
+
+__global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __restrict__ x, float* __restrict__ ws,
+                                                               int HW, int G) {
+  // thread t: group g = t % G (G <= 256 and 256 % G == 0), pixel lane = t / G
+  __shared__ float red[2][256];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int g = tid % G, pl = tid / G, PL = 256 / G;
+  const int p0 = blockIdx.x * GNH_PIX;
+  const int p1 = min(p0 + GNH_PIX, HW);
+  float s = 0.f, q = 0.f;
+  for (int p = p0 + pl; p < p1; p += PL) {
+    const uint4 v = x[((size_t)b * HW + p) * G + g];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+      s += lo + hi;
+      q += lo * lo + hi * hi;
+    }
+  }
+  red[0][tid] = s;
+  red[1][tid] = q;
+  __syncthreads();
+  if (tid < G) {
+    for (int k = 1; k < PL; ++k) {
+      s += red[0][tid + k * G];
+      q += red[1][tid + k * G];
+    }
+    atomicAdd(ws + ((size_t)b * G + g) * 2, s);
+    atomicAdd(ws + ((size_t)b * G + g) * 2 + 1, q);
+  }
+}
+
+__device__ __forceinline__ void gnh_unpack(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(w[k] << 16);
+    f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 gnh_pack(const float* f) {
+  return make_uint4(cgg_pack2(cgg_f2bf(f[0]), cgg_f2bf(f[1])), cgg_pack2(cgg_f2bf(f[2]), cgg_f2bf(f[3])),
+                    cgg_pack2(cgg_f2bf(f[4]), cgg_f2bf(f[5])), cgg_pack2(cgg_f2bf(f[6]), cgg_f2bf(f[7])));
+}
+
+template <bool UPADD>
+__global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
+    const uint4* __restrict__ x, const float* __restrict__ ws, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int HW, int G, float inv_n, float eps, int relu,
+    const float* __restrict__ lo, int lo_h, int lo_w, long long lo_bstride, int W,
+    float* __restrict__ y32, long long y32_bstride, uint4* __restrict__ y16, const float* __restrict__ pos,
+    uint4* __restrict__ yp16, long long y16_bstride) {
+  const int b = blockIdx.y;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // vector index inside the image
+  if (i >= (long long)HW * G) return;
+  const int p = (int)(i / G), g = (int)(i - (long long)p * G);
+  const float s = ws[((size_t)b * G + g) * 2], q = ws[((size_t)b * G + g) * 2 + 1];
+  const float mean = s * inv_n;
+  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
+  float f[8];
+  gnh_unpack(x[(size_t)b * HW * G + i], f);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 8), gb = *reinterpret_cast<const f32x4*>(gamma + g * 8 + 4);
+  const f32x4 ba = *reinterpret_cast<const f32x4*>(beta + g * 8), bb = *reinterpret_cast<const f32x4*>(beta + g * 8 + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[k] = (f[k] - mean) * rstd * ga[k] + ba[k];
+    f[k + 4] = (f[k + 4] - mean) * rstd * gb[k] + bb[k];
+  }
+  if (UPADD) {
+    // F.interpolate(lo, (2*lo_h.., ..), 'bilinear', align_corners=False) at (py, px); PyTorch's source index rule
+    const int H = HW / W;
+    const int py = p / W, px = p - py * W;
+    const float sy = fmaxf(((float)py + 0.5f) * ((float)lo_h / (float)H) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)px + 0.5f) * ((float)lo_w / (float)W) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, lo_h - 1), x1 = min(x0 + 1, lo_w - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* base = lo + (size_t)b * lo_bstride + g * 8;
+    const size_t C = (size_t)G * 8;
+    const float* r00 = base + ((size_t)y0 * lo_w + x0) * C;
+    const float* r01 = base + ((size_t)y0 * lo_w + x1) * C;
+    const float* r10 = base + ((size_t)y1 * lo_w + x0) * C;
+    const float* r11 = base + ((size_t)y1 * lo_w + x1) * C;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(r00 + 4 * h), c = *reinterpret_cast<const f32x4*>(r01 + 4 * h);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(r10 + 4 * h), e = *reinterpret_cast<const f32x4*>(r11 + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        f[4 * h + k] += (1.f - ly) * ((1.f - lx) * a[k] + lx * c[k]) + ly * ((1.f - lx) * d[k] + lx * e[k]);
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
+  }
+  if (y32) {
+    float* o = y32 + (size_t)b * y32_bstride + (size_t)i * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+  }
+  if (y16) y16[(size_t)b * y16_bstride + i] = gnh_pack(f);
+  if (yp16) {
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(pos + (size_t)i * 8), pb = *reinterpret_cast<const f32x4*>(pos + (size_t)i * 8 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] += pa[k];
+      f[k + 4] += pb[k];
+    }
+    yp16[(size_t)b * y16_bstride + i] = gnh_pack(f);
+  }
+}
+
+extern "C" int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, void* ws, int B, int HW,
+                                   int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
+                                   int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
+                                   const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
+  CGG_REQUIRE(x && gamma && beta && ws, CGG_EINVAL, "cgg_group_norm_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0, CGG_EINVAL, "cgg_group_norm_nhwc: bad sizes");
+  CGG_REQUIRE(C == groups * 8 && groups <= 256 && 256 % groups == 0, CGG_EUNSUPPORTED,
+              "cgg_group_norm_nhwc: needs C / groups == 8 and groups | 256 (C=%d, groups=%d)", C, groups);
+  CGG_REQUIRE(y32 || y16 || yp16, CGG_EINVAL, "cgg_group_norm_nhwc: no output requested");
+  CGG_REQUIRE(!yp16 || pos, CGG_EINVAL, "cgg_group_norm_nhwc: yp16 needs pos");
+  CGG_REQUIRE(!up_src || (W > 0 && HW % W == 0 && up_h > 0 && up_w > 0), CGG_EINVAL,
+              "cgg_group_norm_nhwc: bad up-sample geometry");
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(gamma) && cgg_aligned16(beta) && cgg_aligned16(up_src) &&
+                  cgg_aligned16(y32) && cgg_aligned16(y16) && cgg_aligned16(pos) && cgg_aligned16(yp16) &&
+                  y32_bstride % 4 == 0 && up_bstride % 4 == 0 && y16_bstride % 8 == 0,
+              CGG_EALIGN, "cgg_group_norm_nhwc: pointers / strides must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * groups * 2 * sizeof(float), s);
+  if (e != hipSuccess) {
+    cgg_set_error("cgg_group_norm_nhwc: memset failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel, dim3((HW + GNH_PIX - 1) / GNH_PIX, B), dim3(256), 0, s,
+                     (const uint4*)x, (float*)ws, HW, groups);
+  const long long nvec = (long long)HW * groups;
+  const dim3 grid((unsigned)((nvec + 255) / 256), B);
+  const float inv_n = 1.f / ((float)HW * 8.f);
+  if (up_src)
+    hipLaunchKernelGGL(cgg_gn_nhwc_apply_kernel<true>, grid, dim3(256), 0, s, (const uint4*)x, (const float*)ws,
+                       gamma, beta, HW, groups, inv_n, eps, relu, up_src, up_h, up_w, (long long)up_bstride, W, y32,
+                       (long long)y32_bstride, (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8));
+  else
+    hipLaunchKernelGGL(cgg_gn_nhwc_apply_kernel<false>, grid, dim3(256), 0, s, (const uint4*)x, (const float*)ws,
+                       gamma, beta, HW, groups, inv_n, eps, relu, (const float*)nullptr, 0, 0, 0ll, W, y32,
+                       (long long)y32_bstride, (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8));
+  CGG_CHECK_LAUNCH("cgg_group_norm_nhwc");
+  return CGG_OK;
+}

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import runtime
 from .registry import LOSSES
 
 _EPS32 = torch.finfo(torch.float32).eps
@@ -96,7 +97,7 @@ class _CEBase(nn.Module):
         reduction = reduction_override if reduction_override else self.reduction
         if ignore_index is None:
             ignore_index = self.ignore_index
-        cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        cw = runtime.const_tensor(self.class_weight, cls_score) if self.class_weight is not None else None
         if self.use_sigmoid:
             loss = _sigmoid_ce(cls_score, label, weight, reduction, avg_factor, cw, ignore_index,
                                self.avg_non_ignore)

@@ -270,13 +270,14 @@ class Mask2FormerHeadOpen(nn.Module):
         if want_mask:
             if packed is None:
                 packed = ops.pack_mask_feature(mask_feature.detach().contiguous(), 1, split)
-            if torch.is_grad_enabled() and (mask_embed.requires_grad or mask_feature.requires_grad):
+            if mask_feature is not None and torch.is_grad_enabled() and (mask_embed.requires_grad or
+                                                                         mask_feature.requires_grad):
                 mask_pred = _MaskLogitsFn.apply(mask_embed, mask_feature, packed)
             else:
                 mask_pred, _ = ops.mask_logits(mask_embed, packed, want_logits=True)
         bits = None
         if want_attn:
-            H, W = mask_feature.shape[-2:]
+            H, W = (packed.h, packed.w) if mask_feature is None else mask_feature.shape[-2:]
             h, w = int(attn_mask_target_size[0]), int(attn_mask_target_size[1])
             s = H // h if h > 0 else 0
             if h * s == H and w * s == W and s in (2, 4, 8):
@@ -295,25 +296,43 @@ class Mask2FormerHeadOpen(nn.Module):
 
     def _forward(self, feats, img_metas, all_masks=True):
         B = len(img_metas)
-        mask_features, memorys = self.pixel_decoder(feats)
-        mask_features = mask_features.contiguous()
-        split = not runtime.is_bf16()
         L = self.num_transformer_feat_level
-        H4, W4 = mask_features.shape[-2:]
-        mems, poss, sizes = [], [], []
-        for i in range(L):
-            m = self.decoder_input_projs[i](memorys[i])
-            h, w = m.shape[-2:]
-            sizes.append((int(h), int(w)))
-            mems.append((m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1)).contiguous())
-            poss.append(self.decoder_positional_encoding.flat_unpadded(int(h), int(w), m.device))
-        feat_d = mask_features.detach()
-        packed_full = ops.pack_mask_feature(feat_d, 1, split)
-        pooled = []
-        for (h, w) in sizes:
-            s = H4 // h
-            ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
-            pooled.append(ops.pack_mask_feature(feat_d, s, split) if ok else None)
+        pd = self.pixel_decoder
+        stream = (hasattr(pd, 'stream_ready') and pd.stream_ready(feats) and pd.num_outs >= L
+                  and all(isinstance(p, nn.Identity) for p in self.decoder_input_projs))
+        mems, poss, sizes, pooled = [], [], [], []
+        if stream:
+            # throughput-mode inference: channel-last bf16 all the way, mask_feature only ever exists packed
+            mf, memorys, level_hw = pd.forward_stream(feats)
+            mask_features = None
+            H4, W4 = int(mf.shape[1]), int(mf.shape[2])
+            for i in range(L):
+                sizes.append(level_hw[i])
+                mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
+                poss.append(self.decoder_positional_encoding.flat_unpadded(level_hw[i][0], level_hw[i][1], mf.device))
+            packed_full = ops.pack_mask_feature_nhwc(mf, 1)
+            for (h, w) in sizes:
+                s = H4 // h
+                ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
+                pooled.append(ops.pack_mask_feature_nhwc(mf, s) if ok else None)
+        else:
+            feats = [f.float().contiguous() if f.dtype != torch.float32 else f for f in feats]
+            mask_features, memorys = pd(feats)
+            mask_features = mask_features.contiguous()
+            split = not runtime.is_bf16()
+            H4, W4 = mask_features.shape[-2:]
+            for i in range(L):
+                m = self.decoder_input_projs[i](memorys[i])
+                h, w = m.shape[-2:]
+                sizes.append((int(h), int(w)))
+                mems.append((m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1)).contiguous())
+                poss.append(self.decoder_positional_encoding.flat_unpadded(int(h), int(w), m.device))
+            feat_d = mask_features.detach()
+            packed_full = ops.pack_mask_feature(feat_d, 1, split)
+            for (h, w) in sizes:
+                s = H4 // h
+                ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
+                pooled.append(ops.pack_mask_feature(feat_d, s, split) if ok else None)
         layers = self.transformer_decoder.layers
         # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
         kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
@@ -516,10 +535,10 @@ class Mask2FormerHeadOpen(nn.Module):
         mask_weights = torch.stack(mask_weights_list, dim=0)
 
         cls_scores = cls_scores.flatten(0, 1)
-        class_weight = cls_scores.new_tensor(self.class_weight)
+        class_weight = runtime.const_tensor(self.class_weight, cls_scores)
         avg = class_weight[labels].sum()
         loss_cls = self.loss_cls(cls_scores, labels, label_weights, avg_factor=avg)
-        zero = loss_cls.new_tensor(0.0)
+        zero = loss_cls.new_zeros(())
 
         loss_cls_emb = zero
         if self.use_class_emb:
@@ -616,7 +635,10 @@ class Mask2FormerHeadOpen(nn.Module):
                             sum(int(i.numel()) for i in neg_l)))
             pos_counts.append(float(targets[-1][4]))
         # (2) the n `reduce_mean` scalars (mask2former_head.py:591) as ONE all-reduce
-        ntm = reduce_mean(all_cls_scores[0].new_tensor(pos_counts)).clamp(min=1).tolist()
+        if dist.is_available() and dist.is_initialized():
+            ntm = reduce_mean(all_cls_scores[0].new_tensor(pos_counts)).clamp(min=1).tolist()
+        else:       # single process: the counts are already host numbers -> no device round trip
+            ntm = [max(c, 1.0) for c in pos_counts]
         # (3) caption all_gathers: nouns/mask are layer-invariant -> once; predictions of all layers in
         #     one all_gather (reference: 3 all_gathers per layer, :671-673)
         gathered = [None] * n

@@ -438,3 +438,51 @@ def bias_act_nhwc_(y, bias=None, res=None, relu=True):
                                    stream_ptr(y.device))
     check(rc, 'cgg_bias_act_nhwc')
     return y
+
+
+def _ptr_at(t, elem_offset=0):
+    """Raw device address `elem_offset` elements into tensor `t` (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CggError(f'tensor must live on a ROCm device (got {t.device})')
+    return ctypes.c_void_p(t.data_ptr() + int(elem_offset) * t.element_size())
+
+
+def group_norm_nhwc(x, gamma, beta, groups, eps, ws, relu=False, up=None, W=0, out32=None, out16=None, pos=None,
+                    outp16=None):
+    """GroupNorm of a channel-last bf16 activation x (B, HW, C), C / groups == 8 (see include/cgg_hip.h).
+      up     = (f32 tensor, element offset, batch stride, h, w): low-res NHWC map, bilinearly up-sampled and added
+      out32  = (f32 tensor, element offset, batch stride) destination of y
+      out16  / outp16 = (bf16 tensor, element offset, batch stride) destinations of bf16(y) / bf16(y + pos)
+      pos    = (f32 tensor, element offset) rows [HW, C]
+    Destinations are raw (tensor, offset, stride) triples so the three encoder levels can land directly inside the
+    (B, N, C) stream tensors."""
+    B, HW, C = x.shape
+    b16 = out16[2] if out16 is not None else (outp16[2] if outp16 is not None else 0)
+    if out16 is not None and outp16 is not None and out16[2] != outp16[2]:
+        raise CggError('group_norm_nhwc: out16 and outp16 must share the batch stride')
+    rc = _lib_().cgg_group_norm_nhwc(
+        dev_ptr(x, 'x', torch.bfloat16), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
+        dev_ptr(ws, 'ws', torch.float32), B, HW, C, int(groups), float(eps), int(bool(relu)),
+        _ptr_at(up[0], up[1]) if up is not None else None, up[3] if up is not None else 0,
+        up[4] if up is not None else 0, up[2] if up is not None else 0, int(W),
+        _ptr_at(out32[0], out32[1]) if out32 is not None else None, out32[2] if out32 is not None else 0,
+        _ptr_at(out16[0], out16[1]) if out16 is not None else None,
+        _ptr_at(pos[0], pos[1]) if pos is not None else None,
+        _ptr_at(outp16[0], outp16[1]) if outp16 is not None else None, b16, stream_ptr(x.device))
+    check(rc, 'cgg_group_norm_nhwc')
+
+
+def pack_mask_feature_nhwc(feat, pool=1):
+    """feat (B, H, W, C) bf16 channel-last -> PackedFeature (hi image only; throughput mode)."""
+    B, H, W, C = feat.shape
+    if H % pool or W % pool:
+        raise CggError(f'pack_mask_feature_nhwc: {H}x{W} not divisible by pool={pool}')
+    h, w = H // pool, W // pool
+    T = (h * w + 31) // 32
+    hi = torch.empty((B, T, C // 8, 32, 8), dtype=torch.bfloat16, device=feat.device)
+    rc = _lib_().cgg_pack_mask_feature_nhwc(dev_ptr(feat, 'mask_feature', torch.bfloat16), dev_ptr(hi), B, C, H, W,
+                                            int(pool), stream_ptr(feat.device))
+    check(rc, 'cgg_pack_mask_feature_nhwc')
+    return PackedFeature(hi, None, B, C, h, w)

@@ -509,15 +509,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 and isinstance(layer.attentions[0], MultiScaleDeformableAttention)
                 and layer.attentions[0].dropout.p == 0)
 
-    def _encoder_stream_bf16(self, src, pos, ref, level_hw, level_start):
+    def _encoder_stream_bf16(self, src, pos, ref, level_hw, level_start, x16=None, xp16=None):
         """Throughput-mode encoder: per layer 4 library GEMMs (bf16 in / bf16 out), the MSDeformAttn kernel
         (bf16 values, offsets, output), one in-place ReLU and TWO fused residual-LayerNorm passes that also emit the
         bf16 copies (`y`, `y + pos`) the next GEMMs read -- 9 launches per layer instead of ~25, and no separate
         cast / add / `query + pos` passes over the (B, 21504, 256) stream. The residual stream itself stays f32."""
         bf = torch.bfloat16
         cc = runtime.cast_cached
-        x16 = src.to(bf)
-        xp16 = (src + pos[None]).to(bf)
+        if x16 is None:
+            x16 = src.to(bf)
+            xp16 = (src + pos[None]).to(bf)
         B, N, C = src.shape
         n_layers = len(self.encoder.layers)
         for li, layer in enumerate(self.encoder.layers):
@@ -538,6 +539,101 @@ class MSDeformAttnPixelDecoder(nn.Module):
             src, x16, xp16 = ops.add_layernorm_stream(src, f16, n1.weight, n1.bias, n1.eps, pos=pos,
                                                       want_bf16=not last, want_pos=not last)
         return src
+
+    # ---- throughput-mode inference stream: channel-last bf16 from the backbone to the packed mask feature ----
+    def _pos_cached(self, level_hw, dev):
+        """(N, C) sine encoding + level embedding of the all-valid pyramid; rebuilt when level_encoding changes."""
+        key = (tuple(level_hw), str(dev), self.level_encoding.weight._version, self.level_encoding.weight.data_ptr())
+        hit = self.__dict__.get('_pos_cache')
+        if hit is None or hit[0] != key:
+            pos = torch.cat([self.postional_encoding.flat_unpadded(h, w, dev) + self.level_encoding.weight[i][None]
+                             for i, (h, w) in enumerate(level_hw)], 0).detach().contiguous()
+            hit = (key, pos)
+            self.__dict__['_pos_cache'] = hit
+        return hit[1]
+
+    def stream_ready(self, feats):
+        """True when `forward_stream` applies: throughput mode, no autograd, channel-last bf16 features (what the
+        BN-folded ResNet hands over), GN-32 over 256 channels, post-norm ReLU encoder layers, one FPN level."""
+        if not runtime.is_bf16() or torch.is_grad_enabled():
+            return False
+        if self.num_input_levels - self.num_encoder_levels != 1 or self.mask_feature.out_channels != 256:
+            return False
+        for f in feats:
+            if not (f.is_cuda and f.dtype == torch.bfloat16 and f.dim() == 4
+                    and f.permute(0, 2, 3, 1).is_contiguous()):
+                return False
+        for cm in list(self.input_convs) + list(self.lateral_convs) + list(self.output_convs):
+            gn = getattr(cm, cm.norm_name, None) if cm.norm_name else None
+            if not isinstance(gn, nn.GroupNorm) or gn.num_channels != 256 or gn.num_groups != 32:
+                return False
+        if not isinstance(self.output_convs[0].activate, nn.ReLU) or self.input_convs[0].activate is not None:
+            return False
+        return all(tuple(l.operation_order) == ('self_attn', 'norm', 'ffn', 'norm') and self._stream_ok(l)
+                   for l in self.encoder.layers)
+
+    @staticmethod
+    def _gemm1x1(x2, conv):
+        w = runtime.cast_cached(conv.weight).flatten(1)
+        if conv.bias is not None:
+            return torch.addmm(runtime.cast_cached(conv.bias), x2, w.t())
+        return torch.mm(x2, w.t())
+
+    def forward_stream(self, feats):
+        """-> (mask_feature (B, H4, W4, C) bf16 channel-last, [memories (B, hw_l, C) f32 low->high res], level sizes).
+        1x1 convolutions are GEMMs on the (B*H*W, C) views, every GroupNorm is the channel-last HIP kernel, the three
+        encoder inputs are normalised straight INTO the (B, N, C) residual stream (plus the bf16 `x`, `x + pos` copies
+        the first layer's GEMMs read), the FPN `cur + up-sample(out)` is the GroupNorm's epilogue, and only the 3x3
+        output convolution goes through MIOpen."""
+        B = feats[0].shape[0]
+        dev = feats[0].device
+        C = 256
+        level_hw = []
+        for i in range(self.num_encoder_levels):
+            f = feats[self.num_input_levels - i - 1]
+            level_hw.append((int(f.shape[2]), int(f.shape[3])))
+        level_start, N = [], 0
+        for h, w in level_hw:
+            level_start.append(N)
+            N += h * w
+        pos = self._pos_cached(level_hw, dev)
+        ref = self._reference_points(level_hw, dev)
+        src = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        x16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
+        xp16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
+        ws = torch.empty((B * 32 * 2,), dtype=torch.float32, device=dev)
+        for i in range(self.num_encoder_levels):
+            f = feats[self.num_input_levels - i - 1]
+            h, w = level_hw[i]
+            cm = self.input_convs[i]
+            y = self._gemm1x1(f.permute(0, 2, 3, 1).reshape(B * h * w, f.shape[1]), cm.conv).view(B, h * w, C)
+            gn = getattr(cm, cm.norm_name)
+            off = level_start[i] * C
+            ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, out32=(src, off, N * C),
+                                out16=(x16, off, N * C), pos=(pos, off), outp16=(xp16, off, N * C))
+        src = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start, x16, xp16)
+        mems = [src[:, s0:s0 + h * w, :] for s0, (h, w) in zip(level_start, level_hw)]
+        # FPN: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN + ReLU
+        f = feats[0]
+        H4, W4 = int(f.shape[2]), int(f.shape[3])
+        lat, outc = self.lateral_convs[0], self.output_convs[0]
+        y = self._gemm1x1(f.permute(0, 2, 3, 1).reshape(B * H4 * W4, f.shape[1]), lat.conv).view(B, H4 * W4, C)
+        gn = getattr(lat, lat.norm_name)
+        z = torch.empty((B, H4, W4, C), dtype=torch.bfloat16, device=dev)
+        hl, wl = level_hw[-1]
+        ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, up=(src, level_start[-1] * C, N * C, hl, wl), W=W4,
+                            out16=(z, 0, H4 * W4 * C))
+        w3 = runtime.cast_cached(outc.conv.weight)
+        if not w3.is_contiguous(memory_format=torch.channels_last):
+            w3 = w3.contiguous(memory_format=torch.channels_last)
+            runtime.cast_cache_replace(outc.conv.weight, w3)
+        y = F.conv2d(z.permute(0, 3, 1, 2), w3, None if outc.conv.bias is None else runtime.cast_cached(outc.conv.bias),
+                     padding=1)
+        y = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(B, H4 * W4, C)
+        gn = getattr(outc, outc.norm_name)
+        ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, relu=True, out16=(z, 0, H4 * W4 * C))
+        mf = self._gemm1x1(z.view(B * H4 * W4, C), self.mask_feature).view(B, H4, W4, -1)
+        return mf, mems, level_hw
 
     def forward(self, feats):
         B = feats[0].shape[0]

@@ -8,6 +8,7 @@ precision:
             under bf16 autocast); softmax / normalisation / accumulation stay f32.
 """
 import contextlib
+import weakref
 
 import torch
 
@@ -48,15 +49,31 @@ def autocast():
 _WCACHE = {}
 
 
+def _wkey(p, dtype):
+    return (p.data_ptr(), tuple(p.shape), tuple(p.stride()), dtype)
+
+
 def cast_cached(p, dtype=torch.bfloat16):
-    """bf16 copy of a parameter, re-made only when the parameter changes (inference: made once)."""
-    key = (id(p), dtype)
+    """bf16 copy of a parameter (or of a VIEW of one, e.g. `in_proj_weight[E:]`), re-made only when the parameter
+    changes (inference: made once). Keyed by the slice's address / geometry and validated against a weak
+    reference to the owning parameter -- `id()` of a temporary view is recycled by Python and must not be a key."""
+    base = p._base if p._base is not None else p
+    key = _wkey(p, dtype)
     hit = _WCACHE.get(key)
-    if hit is not None and hit[0] == p._version and hit[1].device == p.device:
-        return hit[1]
-    t = p.detach().to(dtype)
-    _WCACHE[key] = (p._version, t)
+    if hit is not None and hit[0]() is base and hit[1] == base._version and hit[2].device == p.device:
+        return hit[2]
+    if len(_WCACHE) > 8192:
+        for k in [k for k, v in _WCACHE.items() if v[0]() is None]:
+            del _WCACHE[k]
+    t = p.detach().to(dtype).contiguous()
+    _WCACHE[key] = (weakref.ref(base), base._version, t)
     return t
+
+
+def cast_cache_replace(p, t, dtype=torch.bfloat16):
+    """Swap the cached low-precision copy of `p` for a re-laid-out one (e.g. channels_last conv filters)."""
+    base = p._base if p._base is not None else p
+    _WCACHE[_wkey(p, dtype)] = (weakref.ref(base), base._version, t)
 
 
 def linear(x, weight, bias=None):
@@ -70,3 +87,17 @@ def linear(x, weight, bias=None):
         with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
             return F.linear(x, weight, bias).float()
     return F.linear(x, weight, bias)
+
+
+_CONST = {}
+
+
+def const_tensor(values, like):
+    """Device tensor of a python constant (list / tuple / scalar), cached per (values, dtype, device): building it
+    with `new_tensor` every call is a pageable host->device copy, i.e. a stream synchronisation."""
+    key = (tuple(values) if isinstance(values, (list, tuple)) else values, like.dtype, str(like.device))
+    t = _CONST.get(key)
+    if t is None:
+        t = like.new_tensor(values)
+        _CONST[key] = t
+    return t

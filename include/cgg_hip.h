@@ -182,6 +182,21 @@ int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float
                          const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
                          float eps, cgg_stream_t stream);
 
+/* Throughput-mode (bf16, channel-last) variants used by the pixel decoder's inference stream.
+ * cgg_group_norm_nhwc: GroupNorm over x [B, HW, C] bf16 with C / groups == 8 ([3P] MSDeformAttnPixelDecoder
+ *   input_convs / lateral_convs / output_convs, norm_cfg GN-32), y = (x - mean) * rstd * gamma + beta
+ *   (+ bilinear up-sample of up_src [B, up_h, up_w, C] f32 to the (HW / W, W) grid -- the FPN `cur +
+ *   F.interpolate(outs[-1])` step) (+ ReLU); outputs (each nullable, at least one): y32 f32 with batch stride
+ *   y32_bstride elements (writes straight into the (B, N, C) encoder stream), y16 = bf16(y) and yp16 =
+ *   bf16(y + pos), pos [HW, C] f32, both with batch stride y16_bstride elements. ws: B * groups * 2 floats of scratch.
+ * cgg_pack_mask_feature_nhwc: cgg_pack_mask_feature for a [B, H, W, C] bf16 map (hi image only).              */
+int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C,
+                        int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
+                        int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16, const float* pos,
+                        void* yp16, int64_t y16_bstride, cgg_stream_t stream);
+int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, int W, int pool,
+                               cgg_stream_t stream);
+
 /* f3  Channel-last epilogue of the BN-folded backbone convolutions ([3P] mmdet ResNet Bottleneck tail
  * `relu(bn3(conv3(x)) + identity)`, selected by configs/instance/coco_b48n17.py:17-26), in place:
  *   y[rows, C] bf16 <- act(y + bias[C] + res[rows, C]);  bias, res bf16, nullable;  relu != 0 -> max(., 0).

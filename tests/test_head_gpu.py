@@ -4,6 +4,8 @@ seeded inputs and the same weights.
 Tolerances: mask logits 1e-3 absolute (north_star) in fp32 ('split') mode; class / embedding outputs 1e-3;
 assignment indices (argmax class, top-k (query, class) sets, panoptic ids) exact.
 """
+import warnings
+
 import pytest
 import torch
 
@@ -166,3 +168,44 @@ def test_bf16_mode_runs_and_is_close(dev, heads):
     assert err.max().item() <= 0.05 * scale + 0.05, (err.max().item(), scale)
     assert err.mean().item() <= 0.01 * scale, (err.mean().item(), scale)
     assert all(ok for ok, _ in teacher.seen), teacher.seen   # own bits agree away from |logit| < 0.5
+
+
+def test_stream_path_matches_module_path(dev):
+    """Throughput-mode inference stream (channel-last bf16 features -> packed mask feature, GEMM 1x1 convs, HIP
+    NHWC GroupNorm) against the module-by-module bf16 path on the same weights and features."""
+    from cgg_amd import registry
+    from util import head_cfg, randomize
+    cfg = small_cfg(num_queries=20, depth=50)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        head = registry.build_head(head_cfg(cfg))
+    randomize(head, seed=5)
+    head = head.to(dev).eval()
+    B, H, W = 2, 128, 160
+    feats = synthetic.backbone_feats(B, H, W, channels=(256, 512, 1024, 2048), seed=3)
+    feats16 = [f.to(dev).bfloat16().contiguous(memory_format=torch.channels_last) for f in feats]
+    feats32 = [f.float() for f in feats16]
+    metas = synthetic.img_metas(B, H, W)
+    with torch.no_grad(), runtime.precision_scope('bf16'):
+        assert head.pixel_decoder.stream_ready(feats16)
+        assert not head.pixel_decoder.stream_ready(feats32)
+        # a bf16 logit that lands on the other side of 0 flips an attention-mask bit and the two decoders drift
+        # apart, so the module path's masks are replayed into the stream path (as util.MaskTeacher does)
+        rec = {}
+        head.attn_mask_hook = lambda i, bits: rec.setdefault(i, bits.clone())
+        c2, e2, m2 = head._forward(feats32, metas, all_masks=False)
+        head.attn_mask_hook = lambda i, bits: rec[i].clone()
+        c1, e1, m1 = head._forward(feats16, metas, all_masks=False)
+        head.attn_mask_hook = None
+        # pixel decoder outputs on their own
+        mf, mems, sizes = head.pixel_decoder.forward_stream(feats16)
+        mf2, mems2 = head.pixel_decoder(feats32)
+    a, b = mf.float().permute(0, 3, 1, 2), mf2
+    assert (a - b).abs().max().item() <= 0.05 * b.abs().max().item()
+    assert (a - b).abs().mean().item() <= 0.01 * b.abs().max().item()
+    for x, y in zip(mems, mems2):
+        y = y.flatten(2).transpose(1, 2)
+        assert (x - y).abs().max().item() <= 0.05 * y.abs().max().item()
+    s = m2[-1].abs().max().item()
+    assert (m1[-1] - m2[-1]).abs().mean().item() <= 0.02 * s
+    assert (e1[-1] - e2[-1]).abs().mean().item() <= 0.02 * e2[-1].abs().max().item()

@@ -210,3 +210,20 @@ def test_build_optimizer_paramwise(detector):
     assert where[id(names[h + 'mask_embed.0.weight'])] == (1e-4, 0.05)
     assert all(id(p) in where for p in m.parameters() if p.requires_grad)
     assert not any(id(p) in where for p in m.parameters() if not p.requires_grad)
+
+
+def test_cast_cached_views_and_versions():
+    """The low-precision weight cache is keyed by the slice's address, not by id() of a temporary view."""
+    from cgg_amd import runtime
+    w = torch.nn.Parameter(torch.arange(24, dtype=torch.float32).view(6, 4))
+    for _ in range(50):                      # temporaries are freed and their ids recycled between calls
+        a = runtime.cast_cached(w[:2])
+        b = runtime.cast_cached(w[2:4])
+        c = runtime.cast_cached(w[4:])
+        assert torch.equal(a.float(), w[:2]) and torch.equal(b.float(), w[2:4]) and torch.equal(c.float(), w[4:])
+    assert runtime.cast_cached(w[:2]) is a              # cached
+    with torch.no_grad():
+        w.add_(1.0)                                     # optimizer-style in-place update bumps the version
+    assert torch.equal(runtime.cast_cached(w[:2]).float(), w[:2].detach())
+    w2 = torch.nn.Parameter(torch.zeros(6, 4))
+    assert torch.equal(runtime.cast_cached(w2[:2]).float(), torch.zeros(2, 4))

@@ -466,7 +466,54 @@ def test_bias_act_nhwc_and_folded_backbone(dev):
             with runtime.precision_scope('bf16'):
                 got = bb(x)
         for w, o in zip(want, got):
-            assert o.shape == w.shape and o.dtype == torch.float32 and o.is_contiguous()
+            # throughput mode hands over (B, C, H, W)-shaped views of channel-last bf16 activations
+            assert o.shape == w.shape and o.dtype == torch.bfloat16 and o.permute(0, 2, 3, 1).is_contiguous()
+            o = o.float()
             scale = w.abs().max().item()
             assert (o - w).abs().max().item() <= 0.06 * scale
             assert (o - w).abs().mean().item() <= 0.01 * scale
+
+
+def test_group_norm_nhwc_and_pack_nhwc(dev):
+    g = torch.Generator().manual_seed(46)
+    B, H, W, C = 2, 12, 20, 256
+    x = (torch.randn(B, H * W, C, generator=g) * 2 + 0.3).bfloat16()
+    gn = torch.nn.GroupNorm(32, C)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+    lo = torch.randn(B, H // 2, W // 2, C, generator=g)
+    pos = torch.randn(H * W, C, generator=g)
+    with torch.no_grad():
+        base = gn(x.float().view(B, H, W, C).permute(0, 3, 1, 2))                       # NCHW
+        up = torch.nn.functional.interpolate(lo.permute(0, 3, 1, 2), size=(H, W), mode='bilinear',
+                                             align_corners=False)
+    ws = torch.empty(B * 64, device=dev)
+    # (a) plain GN -> f32 into a strided (B, N, C) stream at a row offset, bf16 copy, bf16(y + pos)
+    N, row0 = H * W + 37, 21
+    y32 = torch.zeros(B, N, C, device=dev)
+    y16 = torch.zeros(B, N, C, device=dev, dtype=torch.bfloat16)
+    yp16 = torch.zeros(B, N, C, device=dev, dtype=torch.bfloat16)
+    ops.group_norm_nhwc(x.to(dev), gn.weight.to(dev), gn.bias.to(dev), 32, gn.eps, ws,
+                        out32=(y32, row0 * C, N * C), out16=(y16, row0 * C, N * C), pos=(pos.to(dev), 0),
+                        outp16=(yp16, row0 * C, N * C))
+    want = base.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    got = y32[:, row0:row0 + H * W].cpu()
+    assert (got - want).abs().max().item() <= 2e-4
+    assert y32[:, :row0].abs().sum().item() == 0 and y32[:, row0 + H * W:].abs().sum().item() == 0
+    assert torch.equal(y16[:, row0:row0 + H * W].cpu(), got.bfloat16())
+    assert torch.equal(yp16[:, row0:row0 + H * W].cpu(), (got + pos[None]).bfloat16())
+    # (b) GN + up-sample-add + ReLU -> bf16
+    z = torch.empty(B, H * W, C, device=dev, dtype=torch.bfloat16)
+    ops.group_norm_nhwc(x.to(dev), gn.weight.to(dev), gn.bias.to(dev), 32, gn.eps, ws, relu=True,
+                        up=(lo.to(dev), 0, (H // 2) * (W // 2) * C, H // 2, W // 2), W=W, out16=(z, 0, H * W * C))
+    want = (base + up).relu().permute(0, 2, 3, 1).reshape(B, H * W, C)
+    assert (z.cpu().float() - want).abs().max().item() <= 0.02 * want.abs().max().item()
+    assert (z.cpu().float() - want).abs().mean().item() <= 2e-3 * want.abs().max().item()
+    # (c) channel-last pack == NCHW pack of the same values
+    f = torch.randn(B, 16, 24, C, generator=g).bfloat16()
+    for pool in (1, 2, 4, 8):
+        a = ops.pack_mask_feature_nhwc(f.to(dev), pool)
+        b = ops.pack_mask_feature(f.float().permute(0, 3, 1, 2).contiguous().to(dev), pool, split=False)
+        assert (a.h, a.w, a.npix) == (b.h, b.w, b.npix)
+        assert torch.equal(a.hi.cpu().view(torch.int16), b.hi.cpu().view(torch.int16)), pool
