@@ -138,12 +138,22 @@ class ResNet(nn.Module):
                     m.eval()
         return self
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() replace buffer objects: drop the folded-weight caches that reference them
+        self.__dict__.pop('_fold_tensors', None)
+        self.__dict__.pop('_fold_cache', None)
+        return super()._apply(fn, *args, **kwargs)
+
     # ---- throughput-mode inference: BN folded into the convolutions, bf16 NHWC filters kept resident ----
     def _folded(self):
         """[(w, b)] per conv in execution order, bf16 channels_last, frozen BN folded in
         (w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)). Rebuilt when any
         parameter / buffer version changes."""
-        key = sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+        tensors = self.__dict__.get('_fold_tensors')
+        if tensors is None:       # walking the module tree costs ~1 ms per forward; the tensor objects are stable
+            tensors = list(self.parameters()) + list(self.buffers())
+            self.__dict__['_fold_tensors'] = tensors
+        key = sum(t._version for t in tensors)
         hit = self.__dict__.get('_fold_cache')
         if hit is not None and hit[0] == key and hit[1][0][0].device == self.conv1.weight.device:
             return hit[1]

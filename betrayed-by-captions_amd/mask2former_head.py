@@ -294,6 +294,77 @@ class Mask2FormerHeadOpen(nn.Module):
                 bits = ops.attn_mask_from_logits(full.contiguous(), (h, w))
         return cls_pred, cls_emb_pred, mask_pred, bits
 
+    def _head_stream(self, d, sizes_next, packed_full, pooled_next, want_mask, want_attn, last):
+        """forward_head (mask2former_head.py:711-761) on post-normed rows d (M = B*Q, C): cls_embed, v2l_transform and
+        mask_embed[0] run as ONE GEMM over concatenated packed weights (ReLU on the mask-MLP columns only)."""
+        B, Q = packed_full.B, d.shape[0] // packed_full.B
+        me = self.mask_embed
+        lr = ops.linear_rows_bf16
+        ws = (me[0].weight,) + ((self.v2l_transform.weight,) if self.use_class_emb else ()) + (self.cls_embed.weight,)
+        bs = (me[0].bias,) + ((self.v2l_transform.bias,) if self.use_class_emb else ()) + (self.cls_embed.bias,)
+        wcat, bcat, Nc = runtime.packed_cached(ws, bs)
+        C = me[0].weight.shape[0]
+        ld = (Nc + 31) // 32 * 32
+        big = torch.empty((d.shape[0], ld), dtype=torch.float32, device=d.device)[:, :Nc]
+        lr(d, wcat, Nc, bcat, relu_cols=C, out=big)
+        o = C
+        cls_emb_pred = None
+        if self.use_class_emb:
+            De = self.v2l_transform.weight.shape[0]
+            cls_emb_pred = big[:, o:o + De].reshape(B, Q, De) if last else big[:, o:o + De].unflatten(0, (B, Q))
+            o += De
+        cls_pred = big[:, o:].reshape(B, Q, -1) if last else big[:, o:].unflatten(0, (B, Q))
+        if cls_emb_pred is None:
+            cls_emb_pred = cls_pred
+        elif self.pred_emb_norm:
+            cls_emb_pred = cls_emb_pred / cls_emb_pred.norm(dim=-1, keepdim=True)
+        w1, b1, _ = runtime.packed_cached((me[2].weight,), (me[2].bias,))
+        w2, b2, N2 = runtime.packed_cached((me[4].weight,), (me[4].bias,))
+        h = lr(big[:, :C], w1, me[2].weight.shape[0], b1, relu_cols=me[2].weight.shape[0])
+        mask_embed = lr(h, w2, N2, b2).view(B, Q, N2)
+        mask_pred = None
+        if want_mask:
+            mask_pred, _ = ops.mask_logits(mask_embed, packed_full, want_logits=True)
+        bits = None
+        if want_attn:
+            if pooled_next is not None:
+                _, bits = ops.mask_logits(mask_embed, pooled_next, want_logits=False, want_bits=True)
+            else:
+                full = mask_pred if mask_pred is not None else ops.mask_logits(mask_embed, packed_full)[0]
+                bits = ops.attn_mask_from_logits(full.contiguous(), (int(sizes_next[0]), int(sizes_next[1])))
+        return cls_pred, cls_emb_pred, mask_pred, bits
+
+    def _decode_stream(self, B, kvs, sizes, packed_full, pooled, all_masks):
+        """The 1 + 9 forward_head calls and 9 decoder layers of mask2former_head.py:808-847 on (B*Q, C) rows."""
+        layers = self.transformer_decoder.layers
+        nl = self.num_transformer_decoder_layers
+        L = self.num_transformer_feat_level
+        pn = self.transformer_decoder.post_norm
+        pos = self.query_embed.weight.detach()
+        Q, C = pos.shape
+        qf = self.query_feat.weight.detach()
+        x = qf.unsqueeze(0).expand(B, -1, -1).reshape(B * Q, C)
+        xp = (qf + pos).unsqueeze(0).expand(B, -1, -1).reshape(B * Q, C)
+        d = ops.layernorm_chain(x, (pn.weight, pn.bias, pn.eps))[0]
+        outs = ([], [], [])
+        res = self._head_stream(d, sizes[0], packed_full, pooled[0], all_masks or nl == 0, nl > 0, nl == 0)
+        bits = res[3]
+        for k in range(3):
+            outs[k].append(res[k])
+        for i in range(nl):
+            li = i % L
+            if self.attn_mask_hook is not None:
+                bits = self.attn_mask_hook(i, bits)
+            ops.attn_mask_fix_full_rows(bits, sizes[li][0] * sizes[li][1])
+            x, xp, d = layers[i].forward_stream(x, xp, pos, kvs[i], bits, pn)
+            last = i == nl - 1
+            nxt = (i + 1) % L
+            res = self._head_stream(d, sizes[nxt], packed_full, pooled[nxt], all_masks or last, not last, last)
+            bits = res[3]
+            for k in range(3):
+                outs[k].append(res[k])
+        return outs
+
     def _forward(self, feats, img_metas, all_masks=True):
         B = len(img_metas)
         L = self.num_transformer_feat_level
@@ -337,6 +408,10 @@ class Mask2FormerHeadOpen(nn.Module):
         # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
         kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
                for i in range(self.num_transformer_decoder_layers)]
+        if (runtime.is_bf16() and not torch.is_grad_enabled() and packed_full.lo is None
+                and self.transformer_decoder.post_norm is not None and all(l.stream_ready() for l in layers)
+                and self.query_embed.weight.shape[1] % 32 == 0):
+            return self._decode_stream(B, kvs, sizes, packed_full, pooled, all_masks)
         query_feat = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
 

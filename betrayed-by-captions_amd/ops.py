@@ -486,3 +486,66 @@ def pack_mask_feature_nhwc(feat, pool=1):
                                             int(pool), stream_ptr(feat.device))
     check(rc, 'cgg_pack_mask_feature_nhwc')
     return PackedFeature(hi, None, B, C, h, w)
+
+
+# ------------------------------------------------------------------------------------------------
+# throughput-mode query-side linear (packed bf16 weights, fused LayerNorm / `+ pos` / split-K)
+# ------------------------------------------------------------------------------------------------
+def pack_linear_weight(weight):
+    """weight (N, K) f32 -> opaque packed bf16 buffer for `linear_rows_bf16` (uint8 tensor)."""
+    N, K = weight.shape
+    nbytes = _lib_().cgg_linear_rows_packed_bytes(N, K)
+    if nbytes <= 0:
+        raise CggError(f'pack_linear_weight: unsupported shape {tuple(weight.shape)} (K % 16)')
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+    w = weight.detach().float().contiguous()
+    rc = _lib_().cgg_linear_rows_pack(dev_ptr(w, 'weight', torch.float32), dev_ptr(out), N, K,
+                                      stream_ptr(weight.device))
+    check(rc, 'cgg_linear_rows_pack')
+    return out
+
+
+def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, pos=None, want_pos=False, ksplit=1,
+                     out=None):
+    """x (M, K) f32 rows (row stride free, last dim contiguous) @ packed weight -> y (M, N) f32.
+    ln = (gamma, beta, eps) fuses a LayerNorm over the N <= 256 outputs; pos (rows, N) with want_pos returns
+    (y, y + pos[row % rows]). `out` may be a 2-D view with its own row stride."""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda:
+        raise CggError('linear_rows_bf16: x must be a 2-D float32 ROCm tensor with a contiguous last dim')
+    M, K = x.shape
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
+        raise CggError('linear_rows_bf16: bad `out` view')
+    if res is not None and (res.dim() != 2 or res.stride(1) != 1 or res.shape != (M, N)):
+        raise CggError('linear_rows_bf16: bad `res` view')
+    yp = torch.empty((M, N), dtype=torch.float32, device=x.device) if want_pos else None
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    rc = _lib_().cgg_linear_rows_bf16(
+        ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+        ctypes.c_void_p(res.data_ptr()) if res is not None else None, res.stride(0) if res is not None else 0,
+        ctypes.c_void_p(y.data_ptr()), y.stride(0), dev_ptr(g, 'gamma', torch.float32),
+        dev_ptr(b, 'beta', torch.float32), float(eps), dev_ptr(pos, 'pos', torch.float32) if want_pos else None,
+        pos.shape[0] if want_pos else 0, dev_ptr(yp), N if want_pos else 0, M, N, K, int(relu_cols), int(ksplit),
+        stream_ptr(x.device))
+    check(rc, 'cgg_linear_rows_bf16')
+    return (y, yp) if want_pos else y
+
+
+def layernorm_chain(a, norm_a, pos=None, norm_b=None):
+    """a (M, N) f32 -> (y = LN_a(a), yp = y + pos[row % len(pos)] | None, z = LN_b(y) | None); norm_* are
+    (gamma, beta, eps) triples."""
+    M, N = a.shape
+    if a.stride(1) != 1:
+        raise CggError('layernorm_chain: last dim must be contiguous')
+    y = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    yp = torch.empty_like(y) if pos is not None else None
+    z = torch.empty_like(y) if norm_b is not None else None
+    gb, bb, eb = norm_b if norm_b is not None else (None, None, 0.0)
+    rc = _lib_().cgg_layernorm_chain(
+        ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(norm_a[0], 'gamma', torch.float32),
+        dev_ptr(norm_a[1], 'beta', torch.float32), float(norm_a[2]), dev_ptr(pos, 'pos', torch.float32),
+        pos.shape[0] if pos is not None else 0, dev_ptr(gb, 'gamma_b', torch.float32),
+        dev_ptr(bb, 'beta_b', torch.float32), float(eb), dev_ptr(y), dev_ptr(yp), dev_ptr(z), M, N,
+        stream_ptr(a.device))
+    check(rc, 'cgg_layernorm_chain')
+    return y, yp, z

@@ -222,6 +222,50 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         assert len(operation_order) == 6
         assert set(operation_order) == set(['self_attn', 'norm', 'cross_attn', 'ffn'])
 
+    def stream_ready(self):
+        ffn = self.ffns[0]
+        return (tuple(self.operation_order) == ('cross_attn', 'norm', 'self_attn', 'norm', 'ffn', 'norm')
+                and len(ffn.layers) == 3 and isinstance(ffn.layers[0][1], nn.ReLU) and ffn.add_identity
+                and self.embed_dims <= 256 and self.embed_dims % 32 == 0)
+
+    def forward_stream(self, x, xp, pos, kv, bits, post_norm=None):
+        """Throughput-mode layer on 2-D rows: x, xp = x + pos (M = B*Q, C) f32; pos (Q, C). Every projection is
+        `cgg_linear_rows_bf16` on pre-packed bf16 weights; the three post-norm LayerNorms, the residual adds and the
+        `+ query_pos` adds run in GEMM epilogues / one LayerNorm-chain pass. Returns (x', x' + pos, post_norm(x'))."""
+        ca, sa = self.attentions
+        E = self.embed_dims
+        M = x.shape[0]
+        B = kv.shape[0]
+        Q = M // B
+        H = ca.num_heads
+        pk = runtime.packed_cached
+        lr = ops.linear_rows_bf16
+        n0, n1, n2 = self.norms
+        w, b = ca.attn.in_proj_weight, ca.attn.in_proj_bias
+        wq, bq, _ = pk((w[:E],), (b[:E],))
+        q = lr(xp, wq, E, bq)
+        core = ops.masked_xattn(q.view(B, Q, E), kv, bits, H).view(M, E)
+        wo, bo, _ = pk((ca.attn.out_proj.weight,), (ca.attn.out_proj.bias,))
+        x1, x1p = lr(core, wo, E, bo, res=x, ln=(n0.weight, n0.bias, n0.eps), pos=pos, want_pos=True)
+        w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
+        wq, bq, _ = pk((w[:E],), (b[:E],))
+        wk, bk, _ = pk((w[E:2 * E],), (b[E:2 * E],))
+        wv, bv, _ = pk((w[2 * E:],), (b[2 * E:],))
+        q2 = lr(x1p, wq, E, bq)
+        kv2 = torch.empty((M, 2 * E), dtype=torch.float32, device=x.device)
+        lr(x1p, wk, E, bk, out=kv2[:, :E])
+        lr(x1, wv, E, bv, out=kv2[:, E:])
+        core2 = ops.masked_xattn(q2.view(B, Q, E), kv2.view(B, Q, 2 * E), None, sa.num_heads).view(M, E)
+        wo, bo, _ = pk((sa.attn.out_proj.weight,), (sa.attn.out_proj.bias,))
+        x2 = lr(core2, wo, E, bo, res=x1, ln=(n1.weight, n1.bias, n1.eps))
+        ffn = self.ffns[0]
+        w1, b1, F1 = pk((ffn.layers[0][0].weight,), (ffn.layers[0][0].bias,))
+        w2, b2, _ = pk((ffn.layers[1].weight,), (ffn.layers[1].bias,))
+        h = lr(x2, w1, F1, b1, relu_cols=F1)
+        t = lr(h, w2, E, b2, res=x2, ksplit=8 if F1 >= 1024 else 1)
+        return ops.layernorm_chain(t, (n2.weight, n2.bias, n2.eps), pos,
+                                   None if post_norm is None else (post_norm.weight, post_norm.bias, post_norm.eps))
+
     def forward_fast(self, query, query_pos, kv, bits):
         """('cross_attn','norm','self_attn','norm','ffn','norm') on batch-first tensors (dropouts are 0)."""
         query = residual_layernorm(self.attentions[0].attend(query, query_pos, kv, bits), None, self.norms[0])

@@ -101,3 +101,31 @@ def const_tensor(values, like):
         t = like.new_tensor(values)
         _CONST[key] = t
     return t
+
+
+_PCACHE = {}
+
+
+def packed_cached(weights, biases=None):
+    """(packed bf16 MFMA-fragment image of cat(weights, 0), cat(biases) | None, N) for `ops.linear_rows_bf16`, cached
+    like `cast_cached` (slice address + geometry, validated by weak references / versions of the owning
+    parameters). `weights` is a tuple of (N_i, K) tensors (parameters or views of parameters)."""
+    from . import ops
+    allp = tuple(weights) + tuple(b for b in (biases or ()) if b is not None)
+    bases = [t._base if t._base is not None else t for t in allp]
+    key = tuple(_wkey(t, 'packed') for t in allp)
+    hit = _PCACHE.get(key)
+    if hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and \
+            hit[1] == tuple(b._version for b in bases) and hit[2].device == weights[0].device:
+        return hit[2], hit[3], hit[4]
+    if len(_PCACHE) > 4096:
+        for k in [k for k, v in _PCACHE.items() if any(r() is None for r in v[0])]:
+            del _PCACHE[k]
+    w = torch.cat([t.detach().float() for t in weights], 0) if len(weights) > 1 else weights[0].detach().float()
+    packed = ops.pack_linear_weight(w.contiguous())
+    bias = None
+    if biases is not None:
+        bias = torch.cat([b.detach().float() for b in biases], 0).contiguous() if len(biases) > 1 \
+            else biases[0].detach().float().contiguous()
+    _PCACHE[key] = ([weakref.ref(b) for b in bases], tuple(b._version for b in bases), packed, bias, int(w.shape[0]))
+    return packed, bias, int(w.shape[0])

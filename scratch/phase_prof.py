@@ -13,8 +13,8 @@ phase = 'backbone'
 agg = collections.OrderedDict()
 for r in step:
     n = r['Kernel_Name']
-    if phase == 'backbone' and 'cgg_gn_partial' in n: phase = 'pixel_decoder'
-    elif phase == 'pixel_decoder' and 'cgg_pack_kernel' in n: phase = 'query_decoder'
+    if phase == 'backbone' and ('cgg_gn_partial' in n or 'cgg_gn_nhwc_stats' in n): phase = 'pixel_decoder'
+    elif phase == 'pixel_decoder' and ('cgg_pack_kernel' in n or 'cgg_pack_nhwc' in n): phase = 'query_decoder'
     elif phase == 'query_decoder' and ('upsample' in n or 'softmax' in n.lower() and 'cgg' not in n and False): phase = 'postproc'
     d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
     a = agg.setdefault(phase, collections.defaultdict(lambda: [0, 0]))

@@ -517,3 +517,68 @@ def test_group_norm_nhwc_and_pack_nhwc(dev):
         b = ops.pack_mask_feature(f.float().permute(0, 3, 1, 2).contiguous().to(dev), pool, split=False)
         assert (a.h, a.w, a.npix) == (b.h, b.w, b.npix)
         assert torch.equal(a.hi.cpu().view(torch.int16), b.hi.cpu().view(torch.int16)), pool
+
+
+@pytest.mark.parametrize('M,N,K', [(200, 256, 256), (37, 49, 256), (200, 2048, 256), (130, 1073, 256), (200, 256, 2048)])
+def test_linear_rows_bf16_variants(dev, M, N, K):
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    packed = ops.pack_linear_weight(w.to(dev))
+    xb, wb = x.bfloat16().double(), w.bfloat16().double()       # the kernel's operands, exact products
+    base = (xb @ wb.t() + b.double())
+    tol = 2e-3 * (1 + base.abs().max().item())
+    # plain + ReLU on the first 32 columns + residual
+    y = ops.linear_rows_bf16(x.to(dev), packed, N, b.to(dev), res=res.to(dev), relu_cols=32)
+    want = base.clone()
+    want[:, :32] = want[:, :32].relu()
+    want = want + res.double()
+    assert (y.cpu().double() - want).abs().max().item() <= tol
+    # strided input / output views
+    xs = torch.zeros(M, K + 8, device=dev)[:, :K]
+    xs.copy_(x)
+    out = torch.zeros(M, N + 5, device=dev)[:, :N] if (N + 5) % 1 == 0 else None
+    ops.linear_rows_bf16(xs, packed, N, b.to(dev), out=out)
+    assert (out.cpu().double() - base).abs().max().item() <= tol
+    # split-K
+    if K >= 512:
+        y = ops.linear_rows_bf16(x.to(dev), packed, N, b.to(dev), res=res.to(dev), ksplit=8)
+        assert (y.cpu().double() - (base + res.double())).abs().max().item() <= tol
+    # fused LayerNorm + `y + pos`
+    if N <= 256:
+        ln = torch.nn.LayerNorm(N)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(N, generator=g))
+            ln.bias.copy_(torch.randn(N, generator=g))
+        pos = torch.randn(7, N, generator=g)
+        y, yp = ops.linear_rows_bf16(x.to(dev), packed, N, b.to(dev), res=res.to(dev),
+                                     ln=(ln.weight.to(dev), ln.bias.to(dev), ln.eps), pos=pos.to(dev), want_pos=True)
+        with torch.no_grad():
+            want = ln((base + res.double()).float())
+        assert (y.cpu() - want).abs().max().item() <= 5e-3
+        assert torch.equal(yp.cpu(), y.cpu() + pos[torch.arange(M) % 7])
+
+
+def test_layernorm_chain(dev):
+    g = torch.Generator().manual_seed(48)
+    a = torch.randn(201, 264, generator=g)[:, :256]
+    la, lb = torch.nn.LayerNorm(256), torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        for m in (la, lb):
+            m.weight.copy_(torch.randn(256, generator=g))
+            m.bias.copy_(torch.randn(256, generator=g))
+    pos = torch.randn(67, 256, generator=g)
+    ad = torch.zeros(201, 264, device=dev)[:, :256]
+    ad.copy_(a)
+    y, yp, z = ops.layernorm_chain(ad, (la.weight.to(dev), la.bias.to(dev), la.eps), pos.to(dev),
+                                   (lb.weight.to(dev), lb.bias.to(dev), lb.eps))
+    with torch.no_grad():
+        wy = la(a)
+        wz = lb(wy)
+    assert (y.cpu() - wy).abs().max().item() <= 1e-5
+    assert torch.equal(yp.cpu(), y.cpu() + pos[torch.arange(201) % 67])
+    assert (z.cpu() - wz).abs().max().item() <= 2e-5
+    y2, yp2, z2 = ops.layernorm_chain(ad, (la.weight.to(dev), la.bias.to(dev), la.eps))
+    assert yp2 is None and z2 is None and torch.equal(y2, y)
