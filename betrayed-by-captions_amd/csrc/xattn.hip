@@ -160,6 +160,132 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// bf16 throughput path. K is [B, S, H*D] bf16 (key-major) and V arrives TRANSPOSED, vt [B, H*D, S] bf16
+// (the value projection is computed as Wv x mem^T, so no kernel ever transposes anything):
+//   S^T = K Q^T : A = K  -> lane (key j, 8 head-dims) is one 16-byte load straight from global,
+//                 B = Q^T (bf16 of the pre-scaled f32 query, held in registers for the whole chunk)
+//   O^T = V^T P^T: A = V^T -> lane (dim j, keys {0..3, 8..11} + 4*hi of the 16-key step) = two 8-byte loads
+//                 of its vt row; B = P^T = the S^T accumulators rounded to bf16, no data movement.
+// No LDS for K / V at all (only the mask words); the 4 waves of a workgroup (4 query tiles of one head) re-read
+// the same 4 KiB of K / V per 32 keys from L1. Same partial / combine protocol as the f32 kernel.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cgg_xattn_partial_bf16(
+    const float* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vt,
+    const uint32_t* __restrict__ bits, float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S,
+    int words, int KC, int nchunks, float scale) {
+  constexpr int D = 32;
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int HD = H * D;
+  const int s_begin = chunk * KC;
+  const int s_end = min(S, s_begin + KC);
+  const int cw = KC / 32, cws = cw + 1;
+  const int nmt = (Q + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* Ms = reinterpret_cast<uint32_t*>(smem_raw);   // [nmt*32][cws]
+  for (int i = tid; i < nmt * 32 * cw; i += 256) {
+    const int qq = i / cw, w = i - qq * cw;
+    const int gw = s_begin / 32 + w;
+    uint32_t m = 0u;
+    if (bits != nullptr && qq < Q && gw < words) m = bits[((size_t)b * Q + qq) * words + gw];
+    Ms[qq * cws + w] = m;
+  }
+  __syncthreads();
+  if (wave >= nmt) return;
+
+  const int qi = wave * 32 + j;
+  bf16x8 qb[2];
+  {
+    const bool ok = qi < Q;
+    const float* qp = q + ((size_t)b * Q + (ok ? qi : 0)) * HD + h * D + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * ks), c = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+      uint16_t t[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t[e] = cgg_f2bf(ok ? a[e] * scale : 0.f);
+        t[4 + e] = cgg_f2bf(ok ? c[e] * scale : 0.f);
+      }
+      const uint4 u = make_uint4(cgg_pack2(t[0], t[1]), cgg_pack2(t[2], t[3]), cgg_pack2(t[4], t[5]), cgg_pack2(t[6], t[7]));
+      qb[ks] = __builtin_bit_cast(bf16x8, u);
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+
+  const uint16_t* kb = k + (size_t)b * S * HD + h * D + 8 * hi;          // + key * HD + 16 * ks
+  const uint16_t* vb = vt + ((size_t)b * HD + h * D + j) * S + 4 * hi;   // + key0 + 16 * t (+ 8)
+  const int s_cap = S - 4;                                                // last legal 4-key group start
+  for (int s0 = s_begin; s0 < s_end; s0 += 32) {
+    const int key = min(s0 + j, S - 1);
+    const uint4 k0 = *reinterpret_cast<const uint4*>(kb + (size_t)key * HD);
+    const uint4 k1 = *reinterpret_cast<const uint4*>(kb + (size_t)key * HD + 16);
+    uint2 v[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      v[2 * t] = *reinterpret_cast<const uint2*>(vb + min(s0 + 16 * t, s_cap - 4 * hi));
+      v[2 * t + 1] = *reinterpret_cast<const uint2*>(vb + min(s0 + 16 * t + 8, s_cap - 4 * hi));
+    }
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0), qb[0], sc, 0, 0, 0);
+    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1), qb[1], sc, 0, 0, 0);
+    const uint32_t mw = Ms[qi * cws + ((s0 - s_begin) >> 5)];
+    float rmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ki = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const bool blocked = ((mw >> ki) & 1u) || (s0 + ki >= s_end);
+      sc[r] = blocked ? -INFINITY : sc[r];
+      rmax = fmaxf(rmax, sc[r]);
+    }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+    const float m_new = fmaxf(m_run, rmax);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = expf(m_run - m_use);
+    float psum = 0.f;
+    uint16_t pb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(sc[r] - m_use);
+      psum += p;
+      pb[r] = cgg_f2bf(p);
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // a clamped V address only ever pairs with p == 0 (blocked tail keys); V is finite, so 0 * V == 0
+      const uint4 va = make_uint4(v[2 * t].x, v[2 * t].y, v[2 * t + 1].x, v[2 * t + 1].y);
+      const uint4 pp = make_uint4(cgg_pack2(pb[8 * t], pb[8 * t + 1]), cgg_pack2(pb[8 * t + 2], pb[8 * t + 3]),
+                                  cgg_pack2(pb[8 * t + 4], pb[8 * t + 5]), cgg_pack2(pb[8 * t + 6], pb[8 * t + 7]));
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pp), o, 0, 0, 0);
+    }
+  }
+  if (qi < Q) {
+    const size_t base = (((size_t)b * H + h) * nchunks + chunk) * Q + qi;
+    float* op = ws_o + base * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 vv = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hi) = vv;
+    }
+    if (hi == 0) {
+      ws_ml[base * 2] = m_run;
+      ws_ml[base * 2 + 1] = l_run;
+    }
+  }
+}
+
 // combine the per-chunk partials: thread = (b, q, h, d)
 __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict__ ws_o,
                                                          const float* __restrict__ ws_ml,
@@ -233,5 +359,33 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
   hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o,
                      ws_ml, out, B, Q, H, D, nch);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
+  return CGG_OK;
+}
+
+extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits,
+                                             float* out, void* ws, int B, int Q, int H, int D, int S, float scale,
+                                             cgg_stream_t stream) {
+  CGG_REQUIRE(q && k && vt && out && ws, CGG_EINVAL, "cgg_masked_xattn_forward_bf16: null pointer");
+  CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_forward_bf16: bad sizes");
+  CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward_bf16: head dim %d (only 32 is built)", D);
+  CGG_REQUIRE(Q <= 128, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward_bf16: Q=%d > 128", Q);
+  CGG_REQUIRE(S % 4 == 0 && S >= 8, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward_bf16: S=%d must be a multiple of 4", S);
+  CGG_REQUIRE(cgg_aligned16(q) && cgg_aligned16(k) && cgg_aligned16(vt) && cgg_aligned16(ws), CGG_EALIGN,
+              "cgg_masked_xattn_forward_bf16: q / k / vt / ws must be 16-B aligned");
+  int KC, nch;
+  xattn_plan(B, H, S, &KC, &nch);
+  const int words = (S + 31) / 32;
+  const int nmt = (Q + 31) / 32;
+  float* ws_o = (float*)ws;
+  float* ws_ml = ws_o + (size_t)B * H * nch * Q * D;
+  const size_t lds = (size_t)nmt * 32 * (KC / 32 + 1) * 4;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, H, B), dim3(256), lds, s, q, (const uint16_t*)k,
+                     (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale);
+  CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(partial)");
+  const long long total = (long long)B * Q * H * D;
+  hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o, ws_ml, out, B,
+                     Q, H, D, nch);
+  CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(combine)");
   return CGG_OK;
 }

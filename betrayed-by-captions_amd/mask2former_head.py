@@ -405,13 +405,22 @@ class Mask2FormerHeadOpen(nn.Module):
                 ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
                 pooled.append(ops.pack_mask_feature(feat_d, s, split) if ok else None)
         layers = self.transformer_decoder.layers
-        # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
-        kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
-               for i in range(self.num_transformer_decoder_layers)]
         if (runtime.is_bf16() and not torch.is_grad_enabled() and packed_full.lo is None
                 and self.transformer_decoder.post_norm is not None and all(l.stream_ready() for l in layers)
                 and self.query_embed.weight.shape[1] % 32 == 0):
+            if all(h * w % 4 == 0 and h * w >= 8 for h, w in sizes) and \
+                    all(l.attentions[0].embed_dims // l.attentions[0].num_heads == 32 for l in layers):
+                m16 = [m.to(torch.bfloat16) for m in mems]
+                mp16 = [(m + p[None]).to(torch.bfloat16) for m, p in zip(mems, poss)]
+                kvs = [layers[i].attentions[0].project_kv_bf16(m16[i % L], mp16[i % L])
+                       for i in range(self.num_transformer_decoder_layers)]
+            else:
+                kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
+                       for i in range(self.num_transformer_decoder_layers)]
             return self._decode_stream(B, kvs, sizes, packed_full, pooled, all_masks)
+        # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
+        kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
+               for i in range(self.num_transformer_decoder_layers)]
         query_feat = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
 

@@ -238,7 +238,7 @@ def masked_xattn(q, kv, bits, num_heads, scale=None):
         scale = 1.0 / math.sqrt(D)
     lib = _lib_()
     nbytes = lib.cgg_masked_xattn_workspace_bytes(B, Q, H, D, S)
-    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+    key = (q.device.index, stream_ptr(q.device).value)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
@@ -549,3 +549,29 @@ def layernorm_chain(a, norm_a, pos=None, norm_b=None):
         stream_ptr(a.device))
     check(rc, 'cgg_layernorm_chain')
     return y, yp, z
+
+
+def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
+    """q (B,Q,E) f32; k (B,S,E) bf16; vt (B,E,S) bf16 (value projection, transposed); bits as `masked_xattn`."""
+    B, Q, E = q.shape
+    S = k.shape[1]
+    H = int(num_heads)
+    D = E // H
+    if tuple(k.shape) != (B, S, E) or tuple(vt.shape) != (B, E, S):
+        raise CggError(f'masked_xattn_bf16: k {tuple(k.shape)} / vt {tuple(vt.shape)} do not match q {tuple(q.shape)}')
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    lib = _lib_()
+    nbytes = lib.cgg_masked_xattn_workspace_bytes(B, Q, H, D, S)
+    key = (q.device.index, stream_ptr(q.device).value)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
+        _WS_CACHE[key] = ws
+    out = torch.empty((B, Q, E), dtype=torch.float32, device=q.device)
+    rc = lib.cgg_masked_xattn_forward_bf16(dev_ptr(q, 'q', torch.float32), dev_ptr(k, 'k', torch.bfloat16),
+                                           dev_ptr(vt, 'vt', torch.bfloat16), dev_ptr(bits, 'bits', torch.int32),
+                                           dev_ptr(out), dev_ptr(ws), B, Q, H, D, S, float(scale),
+                                           stream_ptr(q.device))
+    check(rc, 'cgg_masked_xattn_forward_bf16')
+    return out

@@ -100,6 +100,16 @@ class MultiheadAttention(nn.Module):
         kv = runtime.linear(mem, w_kv)
         return (kv + bias).contiguous()
 
+    def project_kv_bf16(self, mem16, mempos16):
+        """Throughput-mode K / V for `cgg_masked_xattn_forward_bf16`: k = (mem + pos) Wk^T + b_k as (B,S,E) bf16 and
+        the value projection TRANSPOSED, vt = Wv mem^T (B,E,S) bf16, with b_v left to the output projection."""
+        E = self.embed_dims
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        cc = runtime.cast_cached
+        k = F.linear(mempos16, cc(w[E:2 * E]), cc(b[E:2 * E]))
+        vt = torch.matmul(cc(w[2 * E:]), mem16.transpose(1, 2))
+        return k, vt
+
     def attend(self, query, query_pos, kv, bits):
         """query (B,Q,C) (+ query_pos) against projected kv; returns identity + out_proj(core)."""
         E = self.embed_dims
@@ -235,7 +245,7 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         ca, sa = self.attentions
         E = self.embed_dims
         M = x.shape[0]
-        B = kv.shape[0]
+        B = (kv[0] if isinstance(kv, tuple) else kv).shape[0]
         Q = M // B
         H = ca.num_heads
         pk = runtime.packed_cached
@@ -244,8 +254,15 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         w, b = ca.attn.in_proj_weight, ca.attn.in_proj_bias
         wq, bq, _ = pk((w[:E],), (b[:E],))
         q = lr(xp, wq, E, bq)
-        core = ops.masked_xattn(q.view(B, Q, E), kv, bits, H).view(M, E)
         wo, bo, _ = pk((ca.attn.out_proj.weight,), (ca.attn.out_proj.bias,))
+        if isinstance(kv, tuple):
+            # bf16 K and transposed V (see project_kv_bf16): the value bias is folded through the softmax
+            # (rows sum to 1) into the output projection's bias, bo' = bo + Wo b_v
+            core = ops.masked_xattn_bf16(q.view(B, Q, E), kv[0], kv[1], bits, H).view(M, E)
+            ow, ob = ca.attn.out_proj.weight, ca.attn.out_proj.bias
+            bo = runtime.derived_cached('xattn_bo', (ow, ob, b), lambda: (ob + ow @ b[2 * E:]).float().contiguous())
+        else:
+            core = ops.masked_xattn(q.view(B, Q, E), kv, bits, H).view(M, E)
         x1, x1p = lr(core, wo, E, bo, res=x, ln=(n0.weight, n0.bias, n0.eps), pos=pos, want_pos=True)
         w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
         wq, bq, _ = pk((w[:E],), (b[:E],))

@@ -129,3 +129,22 @@ def packed_cached(weights, biases=None):
             else biases[0].detach().float().contiguous()
     _PCACHE[key] = ([weakref.ref(b) for b in bases], tuple(b._version for b in bases), packed, bias, int(w.shape[0]))
     return packed, bias, int(w.shape[0])
+
+
+_DCACHE = {}
+
+
+def derived_cached(tag, tensors, fn):
+    """Cache `fn()` (any tensor derived from parameters, e.g. a folded bias) until one of `tensors` changes."""
+    bases = [t._base if t._base is not None else t for t in tensors]
+    key = (tag,) + tuple(_wkey(t, None) for t in tensors)
+    hit = _DCACHE.get(key)
+    if hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and hit[1] == tuple(b._version for b in bases):
+        return hit[2]
+    if len(_DCACHE) > 4096:
+        for k in [k for k, v in _DCACHE.items() if any(r() is None for r in v[0])]:
+            del _DCACHE[k]
+    with torch.no_grad():
+        val = fn()
+    _DCACHE[key] = ([weakref.ref(b) for b in bases], tuple(b._version for b in bases), val)
+    return val

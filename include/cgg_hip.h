@@ -161,6 +161,11 @@ int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, int S);
 int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bits, float* out,
                              void* ws, int B, int Q, int H, int D, int S, float scale,
                              int kv_dtype, cgg_stream_t stream);
+/* Throughput-mode variant: k [B, S, H*D] bf16 and the value projection TRANSPOSED, vt [B, H*D, S] bf16 (computed
+ * as Wv x mem^T by the caller), bf16 MFMA for both contractions, f32 softmax statistics and accumulation.
+ * Same mask / output / workspace contract. Requires D == 32, Q <= 128, S % 4 == 0.                              */
+int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits, float* out,
+                                  void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7/K11  Skinny linear + fused residual LayerNorm for the QUERY side of the decoder (M = B*Q ~ 200 rows):

@@ -582,3 +582,29 @@ def test_layernorm_chain(dev):
     assert (z.cpu() - wz).abs().max().item() <= 2e-5
     y2, yp2, z2 = ops.layernorm_chain(ad, (la.weight.to(dev), la.bias.to(dev), la.eps))
     assert yp2 is None and z2 is None and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize('B,Q,S', [(2, 100, 1024), (1, 37, 36), (2, 100, 4100), (1, 128, 16384)])
+def test_masked_xattn_bf16_vs_f32_kernel(dev, B, Q, S):
+    """bf16 K / transposed-V kernel against the f32 kernel on the same (bf16-representable) K, V and mask."""
+    g = torch.Generator().manual_seed(49)
+    H, D = 8, 32
+    E = H * D
+    q = torch.randn(B, Q, E, generator=g)
+    k = torch.randn(B, S, E, generator=g).bfloat16()
+    v = torch.randn(B, S, E, generator=g).bfloat16()
+    mask = torch.rand(B, Q, S, generator=g) < 0.6
+    mask[:, 0] = True                      # an all-blocked row ...
+    from cgg_amd.query_decoder import pack_bool_mask
+    bits = pack_bool_mask(mask).to(dev)
+    ops.attn_mask_fix_full_rows(bits, S)   # ... is un-masked, as the head does
+    kv = torch.cat([k.float(), v.float()], -1).to(dev)
+    want = ops.masked_xattn(q.to(dev), kv, bits, H)
+    got = ops.masked_xattn_bf16(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev), bits, H)
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 0.03 * scale
+    assert (got - want).abs().mean().item() <= 4e-3 * scale
+    got2 = ops.masked_xattn_bf16(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev), None, H)
+    want2 = ops.masked_xattn(q.to(dev), kv, None, H)
+    assert (got2 - want2).abs().max().item() <= 0.03 * want2.abs().max().item()
