@@ -129,7 +129,7 @@ extern "C" int cgg_group_norm(const float* x, const float* gamma, const float* b
 //                 residual stream `src` -- no flatten / transpose / cat),
 //             y16 = bf16(y) dense, yp16 = bf16(y + pos[p]) dense (the first encoder layer's GEMM inputs).
 // -------------------------------------------------------------------------------------------------
-#define GNH_PIX 64   // pixels per stats block
+#define GNH_PIX 512  // pixels per stats block (128 blocks per 256x256 image; 2 atomics per group per block)
 
 __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __restrict__ x, float* __restrict__ ws,
                                                                int HW, int G) {

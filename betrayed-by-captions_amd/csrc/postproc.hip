@@ -166,45 +166,67 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
                                                                      uint8_t* __restrict__ masks,
                                                                      int32_t* __restrict__ ws,
                                                                      ResizeGeom g) {
+  // thread = a 16-wide x S-tall block of output pixels = source row m (and its neighbours m-1, m+1) x
+  // 16/S + 2 source columns: 3 * NC loads feed 16 * S pixels. (The first version gave each thread ONE output
+  // row: 2 * NC dependent loads for 16 pixels left the kernel latency-bound at ~0.5 TB/s of mask bytes.)
   constexpr int NC = IM_PPT / S + 2;  // source columns per thread
   const int i = blockIdx.y;
+  const int tiles_x = g.out_w / IM_PPT;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // tile index: (m, x-tile)
+  const long long ntile = (long long)((g.out_h + S - 1) / S) * tiles_x;
   const long long npix = (long long)g.out_h * g.out_w;
-  const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * IM_PPT;
   const float* s = logits + (size_t)sel[i] * g.H * g.W;
   float sig = 0.f;
   int cnt = 0, xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
-  if (p0 < npix) {
-    const int oy = (int)(p0 / g.out_w), ox0 = (int)(p0 - (long long)oy * g.out_w);
-    const BiTap ty = cgg_bitap(oy, g.s1y, g.H);
+  if (t < ntile) {
+    const int m = (int)(t / tiles_x), ox0 = (int)(t - (long long)m * tiles_x) * IM_PPT;
     const int m0 = ox0 / S;
-    float r0[NC], r1[NC];
+    const int rm = max(m - 1, 0), rp = min(m + 1, g.H - 1);
+    float ra[NC], rb[NC], rc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int col = min(max(m0 - 1 + c, 0), g.W - 1);
-      r0[c] = s[(size_t)ty.i0 * g.W + col];
-      r1[c] = s[(size_t)ty.i1 * g.W + col];
+      ra[c] = s[(size_t)rm * g.W + col];
+      rb[c] = s[(size_t)m * g.W + col];
+      rc[c] = s[(size_t)rp * g.W + col];
     }
-    uint32_t packed[IM_PPT / 4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < IM_PPT; ++k) {
+    for (int ry = 0; ry < S; ++ry) {
       constexpr float inv = 1.f / (float)S;
-      const int r = k % S, mrel = k / S;              // ox = S*(m0 + mrel) + r
-      const bool lowhalf = (2 * r + 1) < S;           // src < m  -> taps (m-1, m)
-      const int c0 = mrel + (lowhalf ? 0 : 1);        // index into r0/r1 (column m0-1+c0)
-      float l1 = ((float)r + 0.5f) * inv + (lowhalf ? 0.5f : -0.5f);
-      if (lowhalf && m0 + mrel == 0) l1 = 0.f;        // left border: src clamps to 0 (torch: lambda = 0)
-      const float l0 = 1.f - l1;
-      const float v = ty.l0 * (l0 * r0[c0] + l1 * r0[c0 + 1]) + ty.l1 * (l0 * r1[c0] + l1 * r1[c0 + 1]);
-      if (v > 0.f) {
-        const int ox = ox0 + k;
-        packed[k >> 2] |= 1u << (8 * (k & 3));
-        sig += cgg_sigmoid(v);
-        cnt += 1;
-        xmin = min(xmin, ox); xmax = max(xmax, ox);
-        ymin = min(ymin, oy); ymax = max(ymax, oy);
+      const int oy = S * m + ry;
+      if (oy >= g.out_h) break;
+      const bool lowy = (2 * ry + 1) < S;             // src row < m -> taps (m-1, m), else (m, m+1)
+      float ly1 = ((float)ry + 0.5f) * inv + (lowy ? 0.5f : -0.5f);
+      if (lowy && m == 0) ly1 = 0.f;                  // top border: src clamps to 0 (torch: lambda = 0)
+      const float ly0 = 1.f - ly1;
+      uint32_t packed[IM_PPT / 4] = {0u, 0u, 0u, 0u};
+      uint32_t run = 0u;
+#pragma unroll
+      for (int k = 0; k < IM_PPT; ++k) {
+        const int r = k % S, mrel = k / S;              // ox = S*(m0 + mrel) + r
+        const bool lowhalf = (2 * r + 1) < S;           // src < m  -> taps (m-1, m)
+        const int c0 = mrel + (lowhalf ? 0 : 1);        // index into the row arrays (column m0-1+c0)
+        float l1 = ((float)r + 0.5f) * inv + (lowhalf ? 0.5f : -0.5f);
+        if (lowhalf && m0 + mrel == 0) l1 = 0.f;        // left border
+        const float l0 = 1.f - l1;
+        const float top = lowy ? (l0 * ra[c0] + l1 * ra[c0 + 1]) : (l0 * rb[c0] + l1 * rb[c0 + 1]);
+        const float bot = lowy ? (l0 * rb[c0] + l1 * rb[c0 + 1]) : (l0 * rc[c0] + l1 * rc[c0 + 1]);
+        const float v = ly0 * top + ly1 * bot;
+        const bool on = v > 0.f;
+        run |= (on ? 1u : 0u) << k;
+        packed[k >> 2] |= (on ? 1u : 0u) << (8 * (k & 3));
+        sig += on ? __frcp_rn(1.f + __expf(-v)) : 0.f;
       }
+      if (run) {
+        cnt += __popc(run);
+        xmin = min(xmin, ox0 + (__ffs(run) - 1));
+        xmax = max(xmax, ox0 + (31 - __clz(run)));
+        ymin = min(ymin, oy);
+        ymax = max(ymax, oy);
+      }
+      *reinterpret_cast<uint4*>(masks + (size_t)i * npix + (size_t)oy * g.out_w + ox0) =
+          make_uint4(packed[0], packed[1], packed[2], packed[3]);
     }
-    *reinterpret_cast<uint4*>(masks + (size_t)i * npix + p0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     sig += __shfl_xor(sig, o);
@@ -383,12 +405,14 @@ extern "C" int cgg_instance_masks(const float* logits, const int32_t* sel, uint8
   const int S = up_h / H;
   const bool int_path = !g.two_stage && S * H == up_h && S * W == up_w && (out_w % IM_PPT) == 0 &&
                         (((uintptr_t)masks) & 15) == 0;
+  const long long ntile = (long long)((out_h + S - 1) / S) * (out_w / IM_PPT);   // one thread per 16 x S block
+  const dim3 tgrid((unsigned)((ntile + 255) / 256), n);
   if (int_path && S == 4)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
   else if (int_path && S == 2)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
   else if (int_path && S == 8)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
   else
     hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
   hipLaunchKernelGGL(cgg_instance_final_kernel, dim3((n + 63) / 64), dim3(64), 0, s,
