@@ -524,8 +524,11 @@ class MSDeformAttnPixelDecoder(nn.Module):
         for li, layer in enumerate(self.encoder.layers):
             attn = layer.attentions[0]
             H, D = attn.num_heads, C // attn.num_heads
-            w_cat = torch.cat([cc(attn.sampling_offsets.weight), cc(attn.attention_weights.weight)], 0)
-            b_cat = torch.cat([cc(attn.sampling_offsets.bias), cc(attn.attention_weights.bias)], 0)
+            so, aw = attn.sampling_offsets, attn.attention_weights
+            w_cat = runtime.derived_cached('msda_wcat', (so.weight, aw.weight),
+                                           lambda: torch.cat([so.weight, aw.weight], 0).to(bf).contiguous())
+            b_cat = runtime.derived_cached('msda_bcat', (so.bias, aw.bias),
+                                           lambda: torch.cat([so.bias, aw.bias], 0).to(bf).contiguous())
             value = F.linear(x16, cc(attn.value_proj.weight), cc(attn.value_proj.bias)).view(B, N, H, D)
             offs = F.linear(xp16, w_cat, b_cat)
             a16 = ops.msda_forward_fused_bf16(value, level_hw, level_start, offs, ref, attn.num_points)
@@ -533,7 +536,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             n0, n1 = layer.norms
             src, x16, _ = ops.add_layernorm_stream(src, o16, n0.weight, n0.bias, n0.eps)
             ffn = layer.ffns[0]
-            h16 = torch.relu_(F.linear(x16, cc(ffn.layers[0][0].weight), cc(ffn.layers[0][0].bias)))
+            # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a separate pass over the (B, N, 1024) hidden
+            h16 = torch._addmm_activation(cc(ffn.layers[0][0].bias), x16.view(B * N, C),
+                                          cc(ffn.layers[0][0].weight).t()).view(B, N, -1)
             f16 = F.linear(h16, cc(ffn.layers[1].weight), cc(ffn.layers[1].bias))
             last = li == n_layers - 1
             src, x16, xp16 = ops.add_layernorm_stream(src, f16, n1.weight, n1.bias, n1.eps, pos=pos,
