@@ -231,7 +231,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         frozen_bn = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
-        if runtime.is_bf16() and not torch.is_grad_enabled() and frozen_bn:
+        if runtime.is_bf16() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda:
             return self._forward_folded(x)
         outs = []
         with runtime.autocast():

@@ -1,6 +1,6 @@
 """Runs only the hot HIP kernels at BASELINE configs[1] shapes (for rocprofv3 --pmc passes)."""
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import cgg_amd
 from cgg_amd import ops
 dev = 'cuda'
@@ -24,5 +24,9 @@ ref = torch.cat(ref).to(dev); raw = raw.to(dev)
 v = torch.randn(B, N, 8, 32, generator=g).to(dev).to(torch.bfloat16)
 for _ in range(20):
     ops.msda_forward_fused(v, shapes, starts, raw, ref, 4)
+torch.cuda.synchronize()
+raw16 = raw.to(torch.bfloat16)
+for _ in range(20):      # the encoder-stream variant the bench runs: bf16 value / offsets / output
+    ops.msda_forward_fused_bf16(v, shapes, starts, raw16, ref, 4)
 torch.cuda.synchronize()
 print('done')
