@@ -151,6 +151,10 @@ def main():
     ap.add_argument('--graph', type=int, default=1,
                     help='1: capture the step once and replay it from a hipGraph (default; the eager step is '
                          'host-bound at ~530 launches); 0: eager launches')
+    ap.add_argument('--pipeline', type=int, default=1,
+                    help='1 (with --graph 1): two-stage software pipeline across steps -- encode (backbone + pixel '
+                         'decoder + K/V) of step k+1 overlaps decode (query decoder + post-processing) of step k on '
+                         'two HIP streams; 0: one graph per step, replayed back to back')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     if args.batch is None:
@@ -194,7 +198,22 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
-    if args.graph:
+    pipe = None
+    if args.graph and args.pipeline:
+        try:
+            from cgg_amd.pipeline import TwoStagePipeline
+            pipe = TwoStagePipeline(model, img, metas, rescale=True, device_results=True)
+            for _ in range(2):
+                pipe.submit(img)
+            pipe.flush()
+            torch.cuda.synchronize()
+        except Exception as e:
+            print(f'bench.py: two-stage pipeline setup failed ({type(e).__name__}: {e}); falling back to one graph '
+                  'per step', file=sys.stderr)
+            pipe = None
+            args.pipeline = 0
+            torch.cuda.synchronize()
+    if args.graph and pipe is None:
         try:
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
@@ -213,14 +232,18 @@ def main():
             args.graph = 0
             torch.cuda.synchronize()
 
-    ops.KERNEL_EVENTS = {} if graph is None else None
+    ops.KERNEL_EVENTS = {} if (graph is None and pipe is None) else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is not None:
+        if pipe is not None:
+            pipe.submit(img)
+        elif graph is not None:
             graph.replay()
         else:
             out = step()
+    if pipe is not None:
+        pipe.flush()          # every submitted step is complete before the closing barrier + synchronize
     barrier()
     dt = time.perf_counter() - t0
     events = ops.KERNEL_EVENTS or {}
@@ -287,7 +310,9 @@ def main():
                                         '(backbone + MSDeformAttn pixel decoder + 9-layer masked-attention '
                                         'decoder + mask logits + instance post-processing, results on device)',
                                global_batch=B * world, parallelism=f'replicas x{world}',
-                               precision=args.precision, hip_graph=bool(args.graph)),
+                               precision=args.precision, hip_graph=bool(args.graph),
+                               pipeline=('2-stage software pipeline across steps (encode of step k+1 || decode of '
+                                         'step k, 2 HIP streams, 2 buffer slots)') if pipe is not None else 'none'),
                    roofline=roofline, kernels=extra)
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args, cfg, model, img_cpu)

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
     smax = msda_x(wp[0]);
     for (int i = 1; i < LP; ++i) smax = fmaxf(smax, msda_x(wp[i]));
     float ssum = 0.f;
-    for (int i = 0; i < LP; ++i) ssum += expf(msda_x(wp[i]) - smax);
+    for (int i = 0; i < LP; ++i) ssum += __expf(msda_x(wp[i]) - smax);
     sinv = 1.f / ssum;
   } else {
     lp = loc + ((size_t)bq * H + h) * LP * 2;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
         if (FUSED) {
           x = rx + x / (float)Wl;
           y = ry + y / (float)Hl;
-          w = expf(w - smax) * sinv;
+          w = __expf(w - smax) * sinv;      // v_exp_f32 path: the libm expf costs ~15 VALU, 24 of them per lane
         }
         const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
         float s[CPL];

@@ -142,7 +142,7 @@ class MaskFormerOpen(nn.Module):
     def simple_test(self, imgs, img_metas, **kwargs):
         """maskformer.py:135-219. `device_results=True` (this build's extension) returns the fusion
         head's device tensors and skips the per-mask `.cpu().numpy()` conversion of :205-208."""
-        feats = self.extract_feat(imgs)
+        feats = None if kwargs.get('encoded') is not None else self.extract_feat(imgs)
         assigned_labels, mask_cls_emb_results, mask_pred_results, caption_results, att = \
             self.panoptic_head.simple_test(feats, img_metas, **kwargs)
         results = self.panoptic_fusion_head.simple_test(assigned_labels, mask_cls_emb_results,
@@ -179,6 +179,16 @@ class MaskFormerOpen(nn.Module):
                 results[i]['visual'] = (mask_cls_emb_results.squeeze().cpu().numpy(),
                                         assigned_labels.cpu().numpy())
         return results
+
+    # ---- two-stage serving split (this build's extension; see pipeline.TwoStagePipeline) ----
+    def stage_encode(self, imgs):
+        """backbone + pixel decoder + K/V projections + packed mask feature: the throughput-bound, query-independent
+        part of `simple_test`."""
+        return self.panoptic_head._encode(self.extract_feat(imgs))
+
+    def stage_decode(self, encoded, img_metas, **kwargs):
+        """query decoder + mask logits + post-processing on the output of `stage_encode`."""
+        return self.simple_test(None, img_metas, encoded=encoded, **kwargs)
 
     def aug_test(self, imgs, img_metas, **kwargs):
         raise NotImplementedError

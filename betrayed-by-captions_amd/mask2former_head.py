@@ -365,8 +365,15 @@ class Mask2FormerHeadOpen(nn.Module):
                 outs[k].append(res[k])
         return outs
 
-    def _forward(self, feats, img_metas, all_masks=True):
-        B = len(img_metas)
+    def _forward(self, feats, img_metas, all_masks=True, encoded=None):
+        enc = encoded if encoded is not None else self._encode(feats)
+        return self._decode(enc, len(img_metas), all_masks)
+
+    def _encode(self, feats):
+        """The query-INDEPENDENT half of mask2former_head.py:763-849: pixel decoder, per-level memories, the packed
+        mask feature (full + pooled images) and the K / V projections of all decoder layers. Everything here is
+        throughput-bound (GEMMs, convolutions, gathers); `_decode` is the latency-bound query side. Splitting them lets
+        a serving loop overlap `_decode` of batch k with `_encode` of batch k+1 (pipeline.TwoStagePipeline)."""
         L = self.num_transformer_feat_level
         pd = self.pixel_decoder
         stream = (hasattr(pd, 'stream_ready') and pd.stream_ready(feats) and pd.num_outs >= L
@@ -417,10 +424,21 @@ class Mask2FormerHeadOpen(nn.Module):
             else:
                 kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
                        for i in range(self.num_transformer_decoder_layers)]
-            return self._decode_stream(B, kvs, sizes, packed_full, pooled, all_masks)
+            return dict(stream=True, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled, mask_features=None)
         # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
         kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
                for i in range(self.num_transformer_decoder_layers)]
+        return dict(stream=False, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled,
+                    mask_features=mask_features)
+
+    def _decode(self, enc, B, all_masks=True):
+        """The query side: 1 + 9 `forward_head` calls and the 9 decoder layers on the encoded memories."""
+        kvs, sizes, packed_full, pooled = enc['kvs'], enc['sizes'], enc['packed_full'], enc['pooled']
+        mask_features = enc['mask_features']
+        L = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
+        if enc['stream']:
+            return self._decode_stream(B, kvs, sizes, packed_full, pooled, all_masks)
         query_feat = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
 
@@ -772,7 +790,8 @@ class Mask2FormerHeadOpen(nn.Module):
         LowResMasks, caption results, att). The mask logits stay at mask-feature resolution together
         with the upsample target (`batch_input_shape`); the fusion head's HIP kernels resize on the fly,
         `.upsampled()` gives the reference's (B,Q,H,W) tensor."""
-        all_cls_scores, all_cls_emb_preds, all_mask_preds = self._forward(feats, img_metas, all_masks=False)
+        all_cls_scores, all_cls_emb_preds, all_mask_preds = self._forward(feats, img_metas, all_masks=False,
+                                                                          encoded=kwargs.get('encoded'))
         mask_cls_results = all_cls_scores[-1]
         mask_cls_emb_results = all_cls_emb_preds[-1]
         mask_pred_results = all_mask_preds[-1]

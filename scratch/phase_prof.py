@@ -1,7 +1,8 @@
 """Per-phase kernel time of the last bench step in a rocprofv3 kernel trace.
 usage: phase_prof.py <dir> [n_top]"""
 import csv, collections, sys, glob
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]

@@ -1,6 +1,7 @@
 """Top kernels by total time in the last fraction of a trace. usage: top_prof.py <dir> [frac=0.3] [n=40]"""
 import csv, collections, sys, glob
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3

@@ -209,3 +209,49 @@ def test_stream_path_matches_module_path(dev):
     s = m2[-1].abs().max().item()
     assert (m1[-1] - m2[-1]).abs().mean().item() <= 0.02 * s
     assert (e1[-1] - e2[-1]).abs().mean().item() <= 0.02 * e2[-1].abs().max().item()
+
+
+def test_two_stage_pipeline(dev):
+    """pipeline.TwoStagePipeline (encode of batch k+1 overlapped with decode of batch k, two hipGraphs per slot on two
+    streams) returns what the plain sequential `simple_test` returns, batch after batch."""
+    from cgg_amd.pipeline import TwoStagePipeline
+    from util import randomize
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+    randomize(model, seed=9)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.fill_(1.0)
+            m.running_mean.zero_()
+    model = model.to(dev).eval()
+    B, H, W = 2, 128, 192
+    metas = synthetic.img_metas(B, H, W)
+    g = torch.Generator().manual_seed(11)
+    imgs = [torch.randn(B, 3, H, W, generator=g).to(dev) for _ in range(5)]
+    with torch.no_grad(), runtime.precision_scope('bf16'):
+        want = []
+        for im in imgs:
+            res = model.simple_test(im, metas, rescale=True, device_results=True)
+            want.append([{k: tuple(t.clone() for t in v) for k, v in r.items()} for r in res])
+        torch.cuda.synchronize()
+        pipe = TwoStagePipeline(model, imgs[0], metas, rescale=True, device_results=True)
+        got = []
+        for im in imgs:
+            slot = pipe.submit(im)
+            res = pipe.wait(slot)          # stream-ordered: the clones below run after this batch's decode
+            got.append([{k: tuple(t.clone() for t in v) for k, v in r.items()} for r in res])
+        pipe.flush()
+        torch.cuda.synchronize()
+    for w_b, g_b in zip(want, got):
+        for w_img, g_img in zip(w_b, g_b):
+            assert set(w_img) == set(g_img)
+            for k in w_img:
+                wl, wb, wm = w_img[k]
+                gl, gb, gm = g_img[k]
+                # same detections up to f32 atomics order in the GroupNorm statistics: compare as sets of (label, box)
+                assert sorted(wl.cpu().tolist()) == sorted(gl.cpu().tolist())
+                assert abs(wb[:, 4].sum().item() - gb[:, 4].sum().item()) <= 1e-2 * max(1.0, wb[:, 4].sum().item())
+                assert abs(int(wm.sum()) - int(gm.sum())) <= 0.002 * wm.numel()
