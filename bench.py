@@ -151,10 +151,10 @@ def main():
     ap.add_argument('--graph', type=int, default=1,
                     help='1: capture the step once and replay it from a hipGraph (default; the eager step is '
                          'host-bound at ~530 launches); 0: eager launches')
-    ap.add_argument('--pipeline', type=int, default=1,
-                    help='1 (with --graph 1): two-stage software pipeline across steps -- encode (backbone + pixel '
-                         'decoder + K/V) of step k+1 overlaps decode (query decoder + post-processing) of step k on '
-                         'two HIP streams; 0: one graph per step, replayed back to back')
+    ap.add_argument('--pipeline', type=int, default=2, choices=[0, 2, 3],
+                    help='(with --graph 1) software pipeline across steps, one HIP stream + hipGraph per stage: '
+                         '3 = backbone | pixel decoder + K/V | query decoder + post-processing, 2 = the first two '
+                         'merged, 0 = one graph per step replayed back to back')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     if args.batch is None:
@@ -201,9 +201,9 @@ def main():
     pipe = None
     if args.graph and args.pipeline:
         try:
-            from cgg_amd.pipeline import TwoStagePipeline
-            pipe = TwoStagePipeline(model, img, metas, rescale=True, device_results=True)
-            for _ in range(2):
+            from cgg_amd.pipeline import detector_pipeline
+            pipe = detector_pipeline(model, img, metas, stages=args.pipeline, rescale=True, device_results=True)
+            for _ in range(args.pipeline):
                 pipe.submit(img)
             pipe.flush()
             torch.cuda.synchronize()
@@ -311,8 +311,9 @@ def main():
                                         'decoder + mask logits + instance post-processing, results on device)',
                                global_batch=B * world, parallelism=f'replicas x{world}',
                                precision=args.precision, hip_graph=bool(args.graph),
-                               pipeline=('2-stage software pipeline across steps (encode of step k+1 || decode of '
-                                         'step k, 2 HIP streams, 2 buffer slots)') if pipe is not None else 'none'),
+                               pipeline=(f'{args.pipeline}-stage software pipeline across steps (one HIP stream + hipGraph '
+                                         'per stage and buffer slot; every timed step completes inside the timed '
+                                         'region)') if pipe is not None else 'none'),
                    roofline=roofline, kernels=extra)
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args, cfg, model, img_cpu)

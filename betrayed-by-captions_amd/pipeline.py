@@ -1,99 +1,117 @@
-"""Two-stage software pipeline for inference throughput on one MI355X.
+"""Software pipeline across batches for inference throughput on one MI355X.
 
-One forward of the detector has two very different halves:
+One forward of the detector is a chain of stages with very different hardware profiles:
 
-  * `stage_encode`  -- backbone, MSDeformAttn pixel decoder, K/V projections, packed mask feature: big GEMMs,
-    convolutions and gathers that fill the chip (4.1 of the 6.4 ms step at configs[1]);
-  * `stage_decode`  -- the 9-layer query decoder + mask logits + post-processing: ~300 dependent launches on
-    M = B*Q = 200 rows, 7-56 workgroups each -- latency-bound, the 256 CUs are almost idle (2.3 ms).
+  * `backbone`      -- convolutions / GEMMs; the stride-16/32 tail is many small launches that cannot fill 256 CUs;
+  * `head._encode`  -- MSDeformAttn pixel decoder, K/V projections, packed mask feature: big GEMMs and gathers
+                       (with the backbone: 4.1 of the 6.4 ms step at configs[1]);
+  * `head._decode`+ post-processing -- the 9-layer query decoder: ~300 dependent launches on M = B*Q = 200 rows,
+                       7-56 workgroups each -- latency-bound, the chip is almost idle (2.3 ms).
 
-Back to back they serialise. Here batch k's decode runs on one HIP stream while batch k+1's encode runs on another:
-the latency-bound chain hides under the throughput-bound one (the hardware schedules workgroups of both queues
-concurrently). Each stage is captured ONCE per buffer slot into a hipGraph (two slots, so that encode(k+1) never
-overwrites what decode(k) is still reading); a step is then two graph launches and two event edges, no Python in
-between. Per-batch latency is unchanged -- this is a throughput device, exactly like double buffering a data loader.
+Back to back they serialise. Here every stage runs on its own HIP stream and batch k's stage i overlaps batch k+1's
+stage i-1: the latency-bound chains hide under the throughput-bound ones (the hardware schedules workgroups of all
+queues concurrently). Each stage is captured ONCE per buffer slot into a hipGraph (`slots` copies, so that a stage never
+overwrites what the next stage of an older batch is still reading); a step is then one graph launch and one or two
+event edges per stage, no Python in between. Per-batch latency is unchanged -- this is a throughput device, exactly
+like double buffering a data loader.
 
-Correctness: the pipelined results are the sequential results (tests/test_head_gpu.py::test_two_stage_pipeline).
+Correctness: the pipelined results are the sequential results (tests/test_head_gpu.py::test_stage_pipeline).
 """
 import torch
 
 
-class TwoStagePipeline:
-    """`submit(img)` enqueues one batch; results come back in order from `submit` (the batch submitted `depth - 1`
-    calls earlier, None while the pipeline fills) and from `flush()`.
+class StagePipeline:
+    """`submit(x)` enqueues one batch and returns its slot; `wait(slot)` makes the caller's stream wait for that
+    batch's results (`results[slot]`); `flush()` waits for everything.
 
-    model      -- a detector with `stage_encode(img)` / `stage_decode(enc, metas, **kw)` (detectors.MaskFormerOpen)
-    example    -- an example input batch (shape / dtype / device are frozen into the graphs)
-    metas      -- img_metas of every batch (fixed geometry)
+    stages   -- list of callables; stage 0 takes the (static copy of the) input batch, stage i the output of stage
+                i-1; the last stage's return value is the result. They are called under `torch.no_grad()`.
+    example  -- an example input batch (shape / dtype / device are frozen into the graphs)
     """
 
-    def __init__(self, model, example, metas, slots=2, warmup=2, **decode_kwargs):
-        self.model = model
-        self.metas = metas
-        self.kw = decode_kwargs
-        self.slots = slots
+    def __init__(self, stages, example, slots=None, warmup=2):
+        self.stages = list(stages)
+        n = len(self.stages)
+        self.slots = slots if slots is not None else max(2, n)
         dev = example.device
-        self.s_enc = torch.cuda.Stream(dev)
-        self.s_dec = torch.cuda.Stream(dev)
-        self.inputs = [torch.empty_like(example) for _ in range(slots)]
-        self.enc_done = [torch.cuda.Event() for _ in range(slots)]
-        self.dec_done = [torch.cuda.Event() for _ in range(slots)]
-        self.g_enc, self.g_dec, self.enc_out, self.results = [], [], [], []
+        self.dev = dev
+        self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        self.inputs = [torch.empty_like(example) for _ in range(self.slots)]
+        self.done = [[torch.cuda.Event() for _ in range(self.slots)] for _ in range(n)]
+        self.graphs = [[None] * self.slots for _ in range(n)]
+        self.outs = [[None] * self.slots for _ in range(n)]
         self._n = 0
         cur = torch.cuda.current_stream(dev)
-        # eager warm-up on the side streams: solver searches, weight packing and allocator pools settle before capture
-        for s in range(slots):
+        for s in range(self.slots):
             self.inputs[s].copy_(example)
-        self.s_enc.wait_stream(cur)
         with torch.no_grad():
+            # eager warm-up on the stage streams: solver searches, weight packing, allocator pools settle before capture
             for _ in range(max(warmup, 1)):
-                with torch.cuda.stream(self.s_enc):
-                    enc = model.stage_encode(self.inputs[0])
-                self.s_dec.wait_stream(self.s_enc)
-                with torch.cuda.stream(self.s_dec):
-                    model.stage_decode(enc, metas, **self.kw)
-                self.s_enc.wait_stream(self.s_dec)
+                x = self.inputs[0]
+                prev = cur
+                for i, f in enumerate(self.stages):
+                    self.streams[i].wait_stream(prev)
+                    with torch.cuda.stream(self.streams[i]):
+                        x = f(x)
+                    prev = self.streams[i]
+                cur.wait_stream(prev)
             torch.cuda.synchronize(dev)
-            for s in range(slots):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.s_enc):
-                    enc = model.stage_encode(self.inputs[s])
-                self.g_enc.append(g)
-                self.enc_out.append(enc)
-                torch.cuda.synchronize(dev)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.s_dec):
-                    res = model.stage_decode(enc, metas, **self.kw)
-                self.g_dec.append(g)
-                self.results.append(res)
-                torch.cuda.synchronize(dev)
+            for s in range(self.slots):
+                x = self.inputs[s]
+                for i, f in enumerate(self.stages):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.streams[i]):
+                        x = f(x)
+                    self.graphs[i][s] = g
+                    self.outs[i][s] = x
+                    torch.cuda.synchronize(dev)
+        self.results = self.outs[-1]
 
-    def submit(self, img):
-        """Enqueue one batch (device tensor, copied into the slot's static input on the encode stream). Returns the
-        slot index whose `results[slot]` will hold this batch's output once `dec_done[slot]` has fired."""
+    def submit(self, x):
         s = self._n % self.slots
         self._n += 1
-        cur = torch.cuda.current_stream(img.device)
-        self.s_enc.wait_stream(cur)                       # `img` was produced on the caller's stream
-        with torch.cuda.stream(self.s_enc):
-            self.s_enc.wait_event(self.dec_done[s])       # the previous user of this slot has been fully decoded
-            if img is not self.inputs[s]:
-                self.inputs[s].copy_(img, non_blocking=True)
-            self.g_enc[s].replay()
-            self.enc_done[s].record(self.s_enc)
-        with torch.cuda.stream(self.s_dec):
-            self.s_dec.wait_event(self.enc_done[s])
-            self.g_dec[s].replay()
-            self.dec_done[s].record(self.s_dec)
+        n = len(self.stages)
+        cur = torch.cuda.current_stream(self.dev)
+        self.streams[0].wait_stream(cur)                          # `x` was produced on the caller's stream
+        for i in range(n):
+            st = self.streams[i]
+            with torch.cuda.stream(st):
+                if i > 0:
+                    st.wait_event(self.done[i - 1][s])            # this batch's previous stage
+                if i + 1 < n:
+                    st.wait_event(self.done[i + 1][s])            # the slot's previous batch has left the next stage
+                else:
+                    st.wait_event(self.done[i][s])
+                if i == 0 and x is not self.inputs[s]:
+                    self.inputs[s].copy_(x, non_blocking=True)
+                self.graphs[i][s].replay()
+                self.done[i][s].record(st)
         return s
 
     def wait(self, slot):
         """Block the CALLER'S stream (not the host) until `results[slot]` is complete; returns the results."""
-        torch.cuda.current_stream().wait_event(self.dec_done[slot])
+        torch.cuda.current_stream(self.dev).wait_event(self.done[-1][slot])
         return self.results[slot]
 
     def flush(self):
         """Make the caller's stream wait for everything submitted so far."""
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(self.s_enc)
-        cur.wait_stream(self.s_dec)
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
+def detector_pipeline(model, example, metas, stages=3, **decode_kwargs):
+    """Pipeline of a `MaskFormerOpen` detector: 2 stages = (backbone + head encode | decode + post-processing),
+    3 stages = (backbone | head encode | decode + post-processing)."""
+    head = model.panoptic_head
+    if stages == 2:
+        fns = [model.stage_encode, lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
+    elif stages == 3:
+        fns = [model.extract_feat, head._encode, lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
+    else:
+        raise ValueError('stages must be 2 or 3')
+    return StagePipeline(fns, example)
+
+
+def TwoStagePipeline(model, example, metas, **decode_kwargs):
+    return detector_pipeline(model, example, metas, stages=2, **decode_kwargs)

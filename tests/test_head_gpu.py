@@ -211,10 +211,11 @@ def test_stream_path_matches_module_path(dev):
     assert (e1[-1] - e2[-1]).abs().mean().item() <= 0.02 * e2[-1].abs().max().item()
 
 
-def test_two_stage_pipeline(dev):
-    """pipeline.TwoStagePipeline (encode of batch k+1 overlapped with decode of batch k, two hipGraphs per slot on two
-    streams) returns what the plain sequential `simple_test` returns, batch after batch."""
-    from cgg_amd.pipeline import TwoStagePipeline
+@pytest.mark.parametrize('stages', [2, 3])
+def test_stage_pipeline(dev, stages):
+    """pipeline.StagePipeline (stage i of batch k overlapped with stage i-1 of batch k+1, one hipGraph per stage and
+    slot, one stream per stage) returns what the plain sequential `simple_test` returns, batch after batch."""
+    from cgg_amd.pipeline import detector_pipeline
     from util import randomize
     cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
                                  dec_layers=3, vocab=500, num_points=256)
@@ -237,7 +238,7 @@ def test_two_stage_pipeline(dev):
             res = model.simple_test(im, metas, rescale=True, device_results=True)
             want.append([{k: tuple(t.clone() for t in v) for k, v in r.items()} for r in res])
         torch.cuda.synchronize()
-        pipe = TwoStagePipeline(model, imgs[0], metas, rescale=True, device_results=True)
+        pipe = detector_pipeline(model, imgs[0], metas, stages=stages, rescale=True, device_results=True)
         got = []
         for im in imgs:
             slot = pipe.submit(im)
