@@ -22,7 +22,8 @@ import time
 import warnings
 
 # MIOpen's find step otherwise times its naive reference convolutions (15-30 ms each) on the first step
-os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
+for _k in ('FWD', 'BWD', 'WRW'):
+    os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + _k, '0')
 
 import torch  # noqa: E402
 

@@ -564,6 +564,97 @@ class Mask2FormerHeadOpen(nn.Module):
         num_total_neg = sum(int(i.numel()) for i in neg_l)
         return labels_list, label_weights_list, mask_targets_list, mask_weights_list, num_total_pos, num_total_neg
 
+    # ---- batched targets: the whole (layers x images) matching problem with O(images) launches ----
+    def _fast_targets_ok(self):
+        from .assigner import (ClassificationCost, CrossEntropyLossCost, DiceCost, MaskHungarianAssignerOpen,
+                               MaskPseudoSampler)
+        a = self.assigner
+        return (type(a) is MaskHungarianAssignerOpen and type(self.sampler) is MaskPseudoSampler
+                and type(a.cls_cost) is ClassificationCost and type(a.cls_emb_cost) is ClassificationCost
+                and type(a.mask_cost) is CrossEntropyLossCost and type(a.dice_cost) is DiceCost)
+
+    def _targets_batched(self, all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f):
+        """`_get_target_single` (mask2former_head.py:320-390) for every (layer, image) at once.
+        The reference runs 2 point-samplings, 4 cost terms, a device->host sync and ~10 indexing kernels per
+        (layer, image): 160 times at configs[2]. Here: predictions are sampled per LAYER (all images in one
+        grid_sample), ground truth per IMAGE (all layers' points in one grid_sample on the float masks that are
+        converted once per step), the cost matrices of an image's 10 layers are batched matmuls, ONE transfer
+        brings all costs to the host for scipy's Hungarian solver, ONE transfer takes the targets back.
+        Random points are drawn in the reference's order (layer-major, then image) so pinned draws line up.
+        Returns per layer: (labels (B,Q) long, mask_weights (B,Q) f32, pos_b, pos_g (npos,) long, num_pos)."""
+        from .assigner import linear_sum_assignment
+        n, B, Q = len(all_cls_scores), all_cls_scores[0].shape[0], all_cls_scores[0].shape[1]
+        dev = all_cls_scores[0].device
+        P = self.num_points
+        a = self.assigner
+        if self.point_hook is None:
+            pts = torch.rand((n, B, P, 2), device=dev)
+        else:
+            pts = torch.stack([torch.cat([self._draw_points(dev) for _ in range(B)], 0) for _ in range(n)], 0)
+        with torch.no_grad():
+            pred_pts = torch.stack([point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)  # (n,B,Q,P)
+            costs, shapes = [], []
+            for b in range(B):
+                G = int(gt_labels_list[b].shape[0])
+                shapes.append(G)
+                if G == 0:
+                    continue
+                gl = gt_labels_list[b]
+                t = point_sample(gt_f[b][None], pts[:, b].reshape(1, n * P, 2))[0]          # (G, n*P)
+                t = t.view(G, n, P).permute(1, 0, 2).contiguous()                             # (n, G, P)
+                x = pred_pts[:, b].float()                                                    # (n, Q, P)
+                cost = 0
+                if a.cls_cost.weight != 0:
+                    cs = torch.stack([c[b] for c in all_cls_scores], 0)
+                    cost = cost + (-cs.detach().softmax(-1)[..., gl] * a.cls_cost.weight)
+                if a.cls_emb_cost.weight != 0 and emb_logits[0] is not None:
+                    es = torch.stack([e[b] for e in emb_logits], 0)
+                    cost = cost + (-es.detach().softmax(-1)[..., gl] * a.cls_emb_cost.weight)
+                if a.mask_cost.weight != 0:
+                    pos = F.binary_cross_entropy_with_logits(x, torch.ones_like(x), reduction='none')
+                    neg = F.binary_cross_entropy_with_logits(x, torch.zeros_like(x), reduction='none')
+                    tt = t.transpose(1, 2)
+                    c = torch.bmm(pos, tt) + torch.bmm(neg, 1 - tt)
+                    cost = cost + c / P * a.mask_cost.weight
+                if a.dice_cost.weight != 0:
+                    dc = a.dice_cost
+                    xx = x.sigmoid() if dc.pred_act else x
+                    num = 2 * torch.bmm(xx, t.transpose(1, 2))
+                    if dc.naive_dice:
+                        den = xx.sum(-1)[:, :, None] + t.sum(-1)[:, None, :]
+                    else:
+                        den = xx.pow(2).sum(-1)[:, :, None] + t.pow(2).sum(-1)[:, None, :]
+                    cost = cost + (1 - (num + dc.eps) / (den + dc.eps)) * dc.weight
+                costs.append(cost.float().reshape(-1))                                        # (n*Q*G,)
+            flat = torch.cat(costs).cpu().numpy() if costs else None                          # the ONE sync
+        import numpy as np
+        labels_np = np.full((n, B, Q), self.num_classes, dtype=np.int64)
+        weights_np = np.zeros((n, B, Q), dtype=np.float32)
+        gl_host = [g.cpu().numpy() if s else None for g, s in zip(gt_labels_list, shapes)] if costs else []
+        pos_b = [[] for _ in range(n)]
+        pos_g = [[] for _ in range(n)]
+        off = 0
+        for b in range(B):
+            G = shapes[b]
+            if G == 0:
+                continue
+            cm = flat[off:off + n * Q * G].reshape(n, Q, G)
+            off += n * Q * G
+            for li in range(n):
+                rows, cols = linear_sum_assignment(cm[li])
+                order = np.argsort(rows)                     # positives in ascending query order (sampler: unique())
+                rows, cols = rows[order], cols[order]
+                labels_np[li, b, rows] = gl_host[b][cols]
+                weights_np[li, b, rows] = 1.0
+                pos_b[li].extend([b] * len(rows))
+                pos_g[li].extend(cols.tolist())
+        labels = torch.from_numpy(labels_np).to(dev, non_blocking=True)
+        weights = torch.from_numpy(weights_np).to(dev, non_blocking=True)
+        out = []
+        for li in range(n):
+            out.append((labels[li], weights[li], pos_b[li], pos_g[li], len(pos_b[li])))
+        return out
+
     def gather_captions_and_preds(self, gt_caption_embs_list, gt_caption_mask_list, cls_emb_preds):
         """mask2former_head.py:650-684: all_gather of captions / masks / predictions; the local slice of
         the predictions is re-inserted so it keeps its gradient (remote slices are constants)."""
@@ -616,25 +707,32 @@ class Mask2FormerHeadOpen(nn.Module):
     def loss_single(self, cls_scores, cls_emb_preds, mask_preds, gt_labels_list, gt_masks_list,
                     gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list,
                     gt_caption_nouns_ids_list, gt_caption_nouns_embs_list, gt_caption_nouns_mask_list,
-                    img_metas, num_total_masks=None, gathered=None, targets=None):
+                    img_metas, num_total_masks=None, gathered=None, targets=None, fast=None):
         """mask2former_head.py:464-629 for one decoder layer. `num_total_masks` / `gathered` carry the
         coalesced collectives prepared by `loss()`; when None they are computed here as the reference does."""
         num_imgs = cls_scores.size(0)
-        cls_scores_list = [cls_scores[i] for i in range(num_imgs)]
-        if self.use_class_emb:
-            cls_emb_logits = self._get_cls_emb_logits(cls_emb_preds)
-            cls_emb_logits_list = [cls_emb_logits[i] for i in range(num_imgs)]
+        pos_b = pos_g = gt_f = cap_loss = None
+        if fast is not None:
+            (labels2, mask_weights, pos_b, pos_g, num_total_pos), gt_f, cls_emb_logits, cap_loss = fast
+            labels = labels2.flatten(0, 1)
+            label_weights = torch.ones_like(labels)
+            mask_targets = None
         else:
-            cls_emb_logits_list = [None] * num_imgs
-        mask_preds_list = [mask_preds[i] for i in range(num_imgs)]
-        if targets is None:
-            targets = self.get_targets(cls_scores_list, cls_emb_logits_list, mask_preds_list,
-                                       gt_labels_list, gt_masks_list, img_metas)
-        labels_list, label_weights_list, mask_targets_list, mask_weights_list, num_total_pos, _ = targets
-        labels = torch.stack(labels_list, dim=0).flatten(0, 1)
-        label_weights = torch.stack(label_weights_list, dim=0).flatten(0, 1)
-        mask_targets = torch.cat(mask_targets_list, dim=0)
-        mask_weights = torch.stack(mask_weights_list, dim=0)
+            cls_scores_list = [cls_scores[i] for i in range(num_imgs)]
+            if self.use_class_emb:
+                cls_emb_logits = self._get_cls_emb_logits(cls_emb_preds)
+                cls_emb_logits_list = [cls_emb_logits[i] for i in range(num_imgs)]
+            else:
+                cls_emb_logits_list = [None] * num_imgs
+            mask_preds_list = [mask_preds[i] for i in range(num_imgs)]
+            if targets is None:
+                targets = self.get_targets(cls_scores_list, cls_emb_logits_list, mask_preds_list,
+                                           gt_labels_list, gt_masks_list, img_metas)
+            labels_list, label_weights_list, mask_targets_list, mask_weights_list, num_total_pos, _ = targets
+            labels = torch.stack(labels_list, dim=0).flatten(0, 1)
+            label_weights = torch.stack(label_weights_list, dim=0).flatten(0, 1)
+            mask_targets = torch.cat(mask_targets_list, dim=0)
+            mask_weights = torch.stack(mask_weights_list, dim=0)
 
         cls_scores = cls_scores.flatten(0, 1)
         class_weight = runtime.const_tensor(self.class_weight, cls_scores)
@@ -657,7 +755,9 @@ class Mask2FormerHeadOpen(nn.Module):
             loss_grounding = self.loss_grounding(all_preds, all_embs, all_mask, self.softmax_temperature)
 
         loss_caption_generation = zero
-        if self.use_caption_generation:
+        if self.use_caption_generation and cap_loss is not None:
+            loss_caption_generation = cap_loss
+        elif self.use_caption_generation:
             gt_caption_embs = torch.stack(gt_caption_embs_list, dim=0)
             gt_caption_masks = torch.stack(gt_caption_mask_list, dim=0).bool()
             caption_logits = self.caption_generator(
@@ -677,7 +777,7 @@ class Mask2FormerHeadOpen(nn.Module):
             num_total_masks = max(num_total_masks, 1)
 
         mask_preds = mask_preds[mask_weights > 0]
-        if mask_targets.shape[0] == 0:
+        if (len(pos_b) if fast is not None else mask_targets.shape[0]) == 0:
             loss_dice = mask_preds.sum()
             loss_mask = mask_preds.sum()
             return (loss_cls, loss_cls_emb, loss_grounding, loss_caption_generation, loss_caption_align,
@@ -686,7 +786,24 @@ class Mask2FormerHeadOpen(nn.Module):
             points_coords = get_uncertain_point_coords_with_randomness(
                 mask_preds.unsqueeze(1), None, self.num_points, self.oversample_ratio,
                 self.importance_sample_ratio, rand_fn=self._rand)
-            mask_point_targets = point_sample(mask_targets.unsqueeze(1).float(), points_coords).squeeze(1)
+            if fast is not None:
+                # positives are ordered image-major (boolean indexing above): sample each image's float GT masks
+                # at its positives' points and pick the assigned mask -- no (npos, H, W) gather / float pass
+                Pn = points_coords.shape[1]
+                chunks, j0 = [], 0
+                while j0 < len(pos_b):
+                    b = pos_b[j0]
+                    j1 = j0
+                    while j1 < len(pos_b) and pos_b[j1] == b:
+                        j1 += 1
+                    g_idx = torch.tensor(pos_g[j0:j1], dtype=torch.long, device=points_coords.device)
+                    smp = point_sample(gt_f[b][None], points_coords[j0:j1].reshape(1, (j1 - j0) * Pn, 2))[0]
+                    smp = smp.view(-1, j1 - j0, Pn)                                   # (G, npos_b, P)
+                    chunks.append(smp[g_idx, torch.arange(j1 - j0, device=smp.device)])
+                    j0 = j1
+                mask_point_targets = torch.cat(chunks, 0)
+            else:
+                mask_point_targets = point_sample(mask_targets.unsqueeze(1).float(), points_coords).squeeze(1)
         mask_point_preds = point_sample(mask_preds.unsqueeze(1), points_coords).squeeze(1)
         loss_dice = self.loss_dice(mask_point_preds, mask_point_targets, avg_factor=num_total_masks)
         loss_mask = self.loss_mask(mask_point_preds.reshape(-1), mask_point_targets.reshape(-1),
@@ -719,8 +836,13 @@ class Mask2FormerHeadOpen(nn.Module):
         """mask2former_head.py:393-462: 7 losses for the last layer + `d{i}.` copies for the others."""
         n = len(all_cls_scores)
         num_imgs = all_cls_scores[0].size(0)
-        # (1) Hungarian targets of ALL layers and images: one device->host copy (reference: n x B syncs)
         emb_logits = [self._get_cls_emb_logits(e) if self.use_class_emb else None for e in all_cls_emb_preds]
+        if self._fast_targets_ok() and not getattr(self, 'force_reference_targets', False):
+            return self._loss_batched(all_cls_scores, all_cls_emb_preds, emb_logits, all_mask_preds, gt_labels_list,
+                                      gt_masks_list, gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list,
+                                      gt_caption_nouns_ids_list, gt_caption_nouns_embs_list,
+                                      gt_caption_nouns_mask_list, img_metas)
+        # (1) Hungarian targets of ALL layers and images: one device->host copy (reference: n x B syncs)
         items = []
         for li in range(n):
             for b in range(num_imgs):
@@ -754,6 +876,54 @@ class Mask2FormerHeadOpen(nn.Module):
                 gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list, gt_caption_nouns_ids_list,
                 gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas,
                 num_total_masks=ntm[i], gathered=gathered[i], targets=targets[i]))
+        names = ('loss_cls', 'loss_cls_emb', 'loss_grounding', 'loss_caption_generation',
+                 'loss_caption_align', 'loss_mask', 'loss_dice')
+        loss_dict = {k: v for k, v in zip(names, results[-1])}
+        if self.loss_only_last:
+            return loss_dict
+        for li, res in enumerate(results[:-1]):
+            for k, v in zip(names, res):
+                loss_dict[f'd{li}.{k}'] = v * self.loss_aux_weight
+        return loss_dict
+
+    def _loss_batched(self, all_cls_scores, all_cls_emb_preds, emb_logits, all_mask_preds, gt_labels_list,
+                      gt_masks_list, gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list,
+                      gt_caption_nouns_ids_list, gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas):
+        """`loss` (mask2former_head.py:393-462) with the per-(layer, image) work batched: targets by
+        `_targets_batched`, the caption generator ONCE for all layers (the reference runs its 4-block transformer and
+        the 30 522-way generator 10 times on the same targets), ground-truth masks sampled at the loss points per
+        image instead of gathered at full resolution per positive. Loss values are the reference's."""
+        n = len(all_cls_scores)
+        B = all_cls_scores[0].size(0)
+        gt_f = [gm.float() for gm in gt_masks_list]        # (G, H, W) once per step
+        targets = self._targets_batched(all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f)
+        pos_counts = [float(t[4]) for t in targets]
+        if dist.is_available() and dist.is_initialized():
+            ntm = reduce_mean(all_cls_scores[0].new_tensor(pos_counts)).clamp(min=1).tolist()
+        else:
+            ntm = [max(c, 1.0) for c in pos_counts]
+        gathered = [None] * n
+        if self.use_caption:
+            gathered = self._gather_all_layers(gt_caption_nouns_embs_list, gt_caption_nouns_mask_list,
+                                               all_cls_emb_preds)
+        cap_losses = [None] * n
+        if self.use_caption_generation:
+            emb = torch.stack(gt_caption_embs_list, dim=0)
+            msk = torch.stack(gt_caption_mask_list, dim=0).bool()
+            T1 = emb.shape[1] - 1
+            logits = self.caption_generator(
+                tgt=emb[:, :-1, :].repeat(n, 1, 1), memory=torch.cat(list(all_cls_emb_preds), 0),
+                tgt_key_padding_mask=torch.logical_not(msk[:, :-1]).repeat(n, 1))[1]         # (n*B, T-1, V)
+            ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)[:, 1:].flatten(0, 1)
+            logits = logits.view(n, B * T1, -1)
+            cap_losses = [self.loss_caption_generation(logits[li], ids) for li in range(n)]
+        results = []
+        for li in range(n):
+            results.append(self.loss_single(
+                all_cls_scores[li], all_cls_emb_preds[li], all_mask_preds[li], gt_labels_list, gt_masks_list,
+                gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list, gt_caption_nouns_ids_list,
+                gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas, num_total_masks=ntm[li],
+                gathered=gathered[li], fast=(targets[li], gt_f, emb_logits[li], cap_losses[li])))
         names = ('loss_cls', 'loss_cls_emb', 'loss_grounding', 'loss_caption_generation',
                  'loss_caption_align', 'loss_mask', 'loss_dice')
         loss_dict = {k: v for k, v in zip(names, results[-1])}
