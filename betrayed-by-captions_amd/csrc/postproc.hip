@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
         const bool on = v > 0.f;
         run |= (on ? 1u : 0u) << k;
         packed[k >> 2] |= (on ? 1u : 0u) << (8 * (k & 3));
-        sig += on ? __frcp_rn(1.f + __expf(-v)) : 0.f;
+        // sigmoid as v_exp_f32 + v_rcp_f32 (1 ulp each): `1.f / x` and __frcp_rn expand to the 10-instruction IEEE
+        // division sequence, which made this kernel VALU-bound at 45 instructions per pixel
+        sig += on ? __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)) : 0.f;
       }
       if (run) {
         cnt += __popc(run);
