@@ -179,6 +179,11 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
     B, Q, C = embed.shape
     if B != packed.B or C != packed.C:
         raise CggError(f'mask_logits: embed {tuple(embed.shape)} vs packed B={packed.B} C={packed.C}')
+    if packed.lo is not None and Q > 128:      # 3-MFMA (hi, lo) mode keeps <= 4 query tiles in LDS: split the queries
+        parts = [mask_logits(embed[:, s:s + 128].contiguous(), packed, want_logits, want_bits)
+                 for s in range(0, Q, 128)]
+        return (torch.cat([p[0] for p in parts], 1) if want_logits else None,
+                torch.cat([p[1] for p in parts], 1) if want_bits else None)
     out = torch.empty((B, Q, packed.h, packed.w), dtype=torch.float32, device=embed.device) \
         if want_logits else None
     bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device) \
@@ -227,6 +232,10 @@ def masked_xattn(q, kv, bits, num_heads, scale=None):
     """q (B,Q,E) f32 projected queries; kv (B,S,2E) f32 [K|V] projected; bits (B,Q,ceil(S/32)) int32
     (bit set = blocked) or None -> (B,Q,E) f32 = softmax(q k^T * scale + mask) v, per head."""
     B, Q, E = q.shape
+    if Q > 128:     # the kernels hold <= 4 query tiles per workgroup: split the (independent) queries
+        return torch.cat([masked_xattn(q[:, s:s + 128].contiguous(), kv,
+                                       None if bits is None else bits[:, s:s + 128].contiguous(), num_heads, scale)
+                          for s in range(0, Q, 128)], 1)
     S = kv.shape[1]
     H = int(num_heads)
     D = E // H
@@ -554,6 +563,10 @@ def layernorm_chain(a, norm_a, pos=None, norm_b=None):
 def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
     """q (B,Q,E) f32; k (B,S,E) bf16; vt (B,E,S) bf16 (value projection, transposed); bits as `masked_xattn`."""
     B, Q, E = q.shape
+    if Q > 128:
+        return torch.cat([masked_xattn_bf16(q[:, s:s + 128].contiguous(), k, vt,
+                                            None if bits is None else bits[:, s:s + 128].contiguous(), num_heads,
+                                            scale) for s in range(0, Q, 128)], 1)
     S = k.shape[1]
     H = int(num_heads)
     D = E // H

@@ -256,3 +256,31 @@ def test_stage_pipeline(dev, stages):
                 assert sorted(wl.cpu().tolist()) == sorted(gl.cpu().tolist())
                 assert abs(wb[:, 4].sum().item() - gb[:, 4].sum().item()) <= 1e-2 * max(1.0, wb[:, 4].sum().item())
                 assert abs(int(wm.sum()) - int(gm.sum())) <= 0.002 * wm.numel()
+
+
+def test_head_200_queries(dev):
+    """BASELINE configs[3] uses 200 queries: the attention / split mask-logit kernels tile 128 queries per launch and
+    the wrappers split larger query sets. Parity mode vs the oracle with its masks injected, then a throughput-mode run."""
+    cfg = small_cfg(num_queries=200, depth=50)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prod, orc = build_heads(cfg)
+    prod = prod.to(dev).eval()
+    orc.eval()
+    B, H, W = 1, 96, 128
+    feats = synthetic.backbone_feats(B, H, W, channels=(256, 512, 1024, 2048), seed=13)
+    metas = synthetic.img_metas(B, H, W)
+    teacher = MaskTeacher(orc)
+    with torch.no_grad():
+        oc, oe, om = teacher.run_oracle(lambda: orc.forward(feats, metas))
+        prod.attn_mask_hook = teacher.hook
+        pc, pe, pm = prod.forward([f.to(dev) for f in feats], metas)
+        prod.attn_mask_hook = None
+    teacher.check()
+    assert pm[-1].shape == (B, 200, H // 4, W // 4)
+    assert (pm[-1].cpu() - om[-1]).abs().max().item() <= 1e-3
+    assert (pe[-1].cpu() - oe[-1]).abs().max().item() <= 1e-3
+    with torch.no_grad(), runtime.precision_scope('bf16'):
+        f16 = [f.to(dev).bfloat16().contiguous(memory_format=torch.channels_last) for f in feats]
+        c, e, m = prod._forward(f16, metas, all_masks=False)
+    assert torch.isfinite(m[-1]).all() and m[-1].shape == (B, 200, H // 4, W // 4)
