@@ -83,6 +83,29 @@ def cpu_baseline(args, cfg, model, img_cpu):
                        f'(torch CPU oracle, fp32, {threads} threads), {dt:.1f} s')
 
 
+def pmc_traffic(kernel, B, H, W):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_pmc_{fetch,write}_*.csv:
+    separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of scratch/kernel_only.py at configs[1] shapes). Units are KB;
+    FETCH_SIZE is doubled (gfx950 tallies 128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md "HBM").
+    Counters cannot be collected from inside this process, so the value is only reported for the shapes they were
+    collected at; otherwise null."""
+    import csv
+    if (B, H, W) != (2, 1024, 1024):
+        return None, None
+    tot = {}
+    for name, cnt, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
+        path = os.path.join(ROOT, 'profiles', f'r1_pmc_{name}_counter_collection.csv')
+        if not os.path.exists(path):
+            return None, None
+        vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
+                if kernel in r['Kernel_Name'] and r['Counter_Name'] == cnt]
+        if not vals:
+            return None, None
+        tot[cnt] = sum(vals) / len(vals) * 1024.0 * mult
+    return tot['FETCH_SIZE'] + tot['WRITE_SIZE'], ('profiles/r1_pmc_{fetch,write}_counter_collection.csv: separate '
+                                                   'rocprofv3 --pmc passes; FETCH_SIZE x2 (gfx950 correction), KB units')
+
+
 def train_main(args, cfg, model, img, metas, dev, rank, world):
     """configs[2]: one optimisation step = forward_train (all 10 layers' losses incl. grounding + caption
     generation) -> backward with bucketed gradient all-reduce over RCCL overlapped -> clip -> AdamW step."""
@@ -288,8 +311,9 @@ def main():
     flops = 2.0 * B * Q * 256 * HW4
     gbs = alg_bytes / (ml_ms * 1e-3) / 1e9
     tfs = flops / (ml_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic('cgg_mask_logits_kernel', B, H, W)
     roofline = dict(bound='hbm', kernel='cgg_mask_logits_kernel', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=gbs / HBM_PEAK_GBS, traffic=None, launch_ms=ml_ms, launches_timed=len(ml),
+                    frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, launch_ms=ml_ms, launches_timed=len(ml),
                     algorithmic_bytes=alg_bytes, tflops=tfs, frac_mfma_bf16_peak=tfs / MFMA_BF16_PEAK_TF,
                     timed=timed_how, event_pair_overhead_ms=ev_over, launch_ms_raw=ml_raw_ms)
     extra = {}
