@@ -393,6 +393,66 @@ def main():
     npz('g7_postprocess.npz', labels=lab, bboxes=box, masks=msk, labels_novel=labn, bboxes_novel=boxn, masks_novel=mskn,
         pan_seg=pan)
 
+    g8_beam_search()
+
+
+class _StubTokenizer:
+    """stands in for BertTokenizer (no vocabulary file offline): ids -> 'i0 i1 ...'."""
+
+    @classmethod
+    def from_pretrained(cls, *a, **k):
+        return cls()
+
+    def decode(self, ids):
+        return ' '.join(str(int(i)) for i in ids)
+
+
+def g8_beam_search():
+    """G8: the reference's beam_search (open_set/utils/eval/inference.py) over the reference's CaptionTransformer."""
+    import transformers
+    from util import randomize
+    ct = ref_import('open_set.models.transformers.caption_tranformer')
+    inf = ref_import('open_set.utils.eval.inference')
+    transformers.BertTokenizer = _StubTokenizer
+    cap_cfg = dict(nb_layers=2, input_dim=32, hidden_dim=32, ff_dim=32, nb_heads=4, drop_val=0.1, pre_norm=False,
+                   seq_length=12, nb_tokens=30)
+    out = dict(cfg=json.dumps(cap_cfg))
+    case = 0
+    # NB the reference crashes when exactly ONE live sequence remains (`get_ids_embedding` squeezes the batch
+    # dimension away, inference.py:80); such seeds are skipped -- the fixture holds runs the reference completes
+    for seed in range(21, 80):
+        if case == 5:
+            break
+        beam, max_len = [(3, 8), (4, 10), (2, 6), (5, 12), (3, 10)][case]
+        gen = ct.CaptionTransformer(**cap_cfg).eval()
+        randomize(gen, seed=seed)
+        with torch.no_grad():
+            gen.generator.bias[2] += 1.0 + 0.5 * case        # make EOS reachable so that sequences finish
+        sb = StubBert(30, 32)
+        randomize(sb.embeddings.word_embeddings, seed=seed + 100)
+        randomize(sb.embeddings.LayerNorm, seed=seed + 200)
+        be = ref_import('open_set.models.utils.bert_embeddings').BertEmbeddings(sb)
+        model = types.SimpleNamespace(bert_embeddings=be, caption_generator=gen)
+        mem = torch.randn(1, 7, 32, generator=torch.Generator().manual_seed(seed + 300))
+        try:
+            with torch.no_grad():
+                sent = inf.beam_search(model, mem, 1, 2, max_len=max_len, beam_width=beam)
+        except ValueError:
+            continue
+        if not sent:
+            continue
+        out[f'mem{case}'] = mem
+        out[f'params{case}'] = np.array([seed, beam, max_len, case])
+        out[f'sentence{case}'] = np.array(sent)
+        print('G8 case', case, 'seed', seed, repr(sent))
+        case += 1
+    out['n_cases'] = np.array(case)
+    npz('g8_beam_search.npz', **out)
+
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'g8':
+        install_shim()
+        g8_beam_search()
+    else:
+        main()

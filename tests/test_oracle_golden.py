@@ -230,3 +230,32 @@ def test_g7_postprocess_oracle_matches_reference(oracle_head):
     pan = OH.panoptic_postprocess_emb(pemb, mp, cls_embs, 12, 8, 0.2, 0.5, True, 16)
     assert torch.equal(pan, z['pan_seg'].to(torch.int32))
     assert len(torch.unique(pan)) > 2
+
+
+# ---- G8 -------------------------------------------------------------------------------------------------
+class _StubTokenizer:
+    def decode(self, ids):
+        return ' '.join(str(int(i)) for i in ids)
+
+
+def test_g8_beam_search_matches_reference():
+    """cgg_amd.caption_search.beam_search == the reference's beam_search (run by path in make_golden.py) on the runs
+    the reference completes (it crashes when a single live sequence remains; the product does not)."""
+    import types
+    from cgg_amd.caption_search import beam_search
+    z = gold('g8_beam_search.npz')
+    cfg = json.loads(str(z['cfg']))
+    for case in range(int(z['n_cases'])):
+        seed, beam, max_len, c = [int(v) for v in z[f'params{case}']]
+        gen = P_ct.CaptionTransformer(**cfg).eval()
+        randomize(gen, seed=seed)
+        with torch.no_grad():
+            gen.generator.bias[2] += 1.0 + 0.5 * c
+        be = P_Bert(None, vocab_size=30, hidden_size=32)
+        randomize(be.word_embeddings, seed=seed + 100)
+        randomize(be.LayerNorm, seed=seed + 200)
+        head = types.SimpleNamespace(bert_embeddings=be, caption_generator=gen)
+        got = beam_search(head, z[f'mem{case}'], 1, 2, max_len=max_len, beam_width=beam, tokenizer=_StubTokenizer())
+        assert got == str(z[f'sentence{case}']), (case, got, str(z[f'sentence{case}']))
+        ids = beam_search(head, z[f'mem{case}'], 1, 2, max_len=max_len, beam_width=beam, return_ids=True)
+        assert ids[0] == 1 and ids[-1] == 2 and ' '.join(map(str, ids))[1:-1] == got
