@@ -38,7 +38,8 @@ def test_registry_contract():
         R.build(dict(x=1))
     # the names the reference registers, under the registries it registers them in
     for reg, names in ((registry.DETECTORS, ['Mask2FormerOpen', 'MaskFormerOpen']),
-                       (registry.HEADS, ['Mask2FormerHeadOpen', 'MaskFormerFusionHeadOpen', 'CaptionTransformer']),
+                       (registry.HEADS, ['Mask2FormerHeadOpen', 'MaskFormerFusionHeadOpen', 'CaptionTransformer',
+                                        'V2lTranformHead']),
                        (registry.LOSSES, ['GroundingLoss', 'CrossEntropyLossOpen', 'CrossEntropyLoss', 'DiceLoss']),
                        (registry.BBOX_ASSIGNERS, ['MaskHungarianAssignerOpen']),
                        (registry.PLUGIN_LAYERS, ['MSDeformAttnPixelDecoder']),
