@@ -1,15 +1,23 @@
 #!/bin/bash
-# Runs on the GPU box: rocprofv3 kernel stats of the bench command + separate PMC passes of the hot kernels.
+# Runs on the GPU box: rocprofv3 kernel stats of the bench command + separate PMC passes of the hot kernels + bench lines.
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/r1
-mkdir -p $O
+rm -rf $O && mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+cp $(find /tmp/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+python3 $R/scratch/hot_launches.py /tmp/stats > $O/hot_kernel_launches.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/scratch/kernel_only.py > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/scratch/kernel_only.py > /dev/null 2>&1
+  cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_$c.csv
 done
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 $R/scratch/kernel_only.py > $O/pmc_l2.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/pmc_l2 -- python3 $R/scratch/kernel_only.py > /dev/null 2>&1
+cp $(find /tmp/pmc_l2 -name "*counter_collection.csv" | head -1) $O/pmc_l2.csv
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench_line.err
-find $O -name "*.csv" | head -20
-tail -c 600 $O/bench_line.json
+python bench.py --pipeline 0 --no-cpu-baseline > $O/bench_line_nopipeline.json 2>> $O/bench_line.err
+python bench.py --graph 0 --no-cpu-baseline > $O/bench_line_eager.json 2>> $O/bench_line.err
+python bench.py --mode train --steps 5 --warmup 3 > $O/bench_train_line.json 2>> $O/bench_line.err
+ls -la $O
+tail -c 400 $O/bench_line.json
