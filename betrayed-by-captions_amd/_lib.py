@@ -46,6 +46,7 @@ PROTOTYPES = {
     'cgg_msda_forward_fused_bf16': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 7 + [_c_vp]),
     'cgg_add_layernorm_ex': (_c_int, [_c_vp, _c_vp, _c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 +
                              [_c_int, _c_int, _c_f, _c_vp]),
+    'cgg_group_norm_nhwc_workspace_bytes': (_c_i64, [_c_int] * 3),
     'cgg_group_norm_nhwc': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,
                                        _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_pack_mask_feature_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),

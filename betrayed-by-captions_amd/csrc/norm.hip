@@ -129,17 +129,17 @@ extern "C" int cgg_group_norm(const float* x, const float* gamma, const float* b
 //                 residual stream `src` -- no flatten / transpose / cat),
 //             y16 = bf16(y) dense, yp16 = bf16(y + pos[p]) dense (the first encoder layer's GEMM inputs).
 // -------------------------------------------------------------------------------------------------
-#define GNH_PIX 512  // pixels per stats block (128 blocks per 256x256 image; 2 atomics per group per block)
+#define GNH_PIX 64   // pixels per stats block (1024 blocks per 256x256 image; partials are reduced by a second kernel)
 
 __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __restrict__ x, float* __restrict__ ws,
-                                                               int HW, int G) {
+                                                               int HW, int G, int ppb, int B_G2_floats) {
   // thread t: group g = t % G (G <= 256 and 256 % G == 0), pixel lane = t / G
   __shared__ float red[2][256];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int g = tid % G, pl = tid / G, PL = 256 / G;
-  const int p0 = blockIdx.x * GNH_PIX;
-  const int p1 = min(p0 + GNH_PIX, HW);
+  const int p0 = blockIdx.x * ppb;
+  const int p1 = min(p0 + ppb, HW);
   float s = 0.f, q = 0.f;
   for (int p = p0 + pl; p < p1; p += PL) {
     const uint4 v = x[((size_t)b * HW + p) * G + g];
@@ -159,8 +159,32 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __r
       s += red[0][tid + k * G];
       q += red[1][tid + k * G];
     }
-    atomicAdd(ws + ((size_t)b * G + g) * 2, s);
-    atomicAdd(ws + ((size_t)b * G + g) * 2 + 1, q);
+    // per-block partials (no atomics: 512 blocks hammering 64 addresses made this pass 3x slower than the read)
+    float* part = ws + (size_t)B_G2_floats + (((size_t)b * gridDim.x + blockIdx.x) * G + g) * 2;
+    part[0] = s;
+    part[1] = q;
+  }
+}
+
+// second level: one 64-lane wave per (b, g) sums the per-block partials -> ws[b][g][2]
+__global__ __launch_bounds__(64) void cgg_gn_nhwc_reduce_kernel(float* __restrict__ ws, int B_G2_floats, int nblk, int G,
+                                                               int B) {
+  const int i = blockIdx.x;                  // (b, g)
+  const int b = i / G, g = i - b * G;
+  const float* part = ws + B_G2_floats + ((size_t)b * nblk * G + g) * 2;
+  float s = 0.f, q = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + (size_t)k * G * 2);
+    s += v.x;
+    q += v.y;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (threadIdx.x == 0) {
+    ws[(size_t)i * 2] = s;
+    ws[(size_t)i * 2 + 1] = q;
   }
 }
 
@@ -245,6 +269,12 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
   }
 }
 
+extern "C" int64_t cgg_group_norm_nhwc_workspace_bytes(int B, int HW, int groups) {
+  if (B <= 0 || HW <= 0 || groups <= 0) return 0;
+  const int64_t nblk = (HW + GNH_PIX - 1) / GNH_PIX;
+  return ((int64_t)B * groups * 2 + (int64_t)B * nblk * groups * 2) * (int64_t)sizeof(float);
+}
+
 extern "C" int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, void* ws, int B, int HW,
                                    int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
                                    int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
@@ -262,13 +292,11 @@ extern "C" int cgg_group_norm_nhwc(const void* x, const float* gamma, const floa
                   y32_bstride % 4 == 0 && up_bstride % 4 == 0 && y16_bstride % 8 == 0,
               CGG_EALIGN, "cgg_group_norm_nhwc: pointers / strides must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * groups * 2 * sizeof(float), s);
-  if (e != hipSuccess) {
-    cgg_set_error("cgg_group_norm_nhwc: memset failed: %s", hipGetErrorString(e));
-    return (int)e;
-  }
-  hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel, dim3((HW + GNH_PIX - 1) / GNH_PIX, B), dim3(256), 0, s,
-                     (const uint4*)x, (float*)ws, HW, groups);
+  const int nblk = (HW + GNH_PIX - 1) / GNH_PIX;
+  const int head = B * groups * 2;        // ws = [B][G][2] totals, then [B][nblk][G][2] per-block partials
+  hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel, dim3(nblk, B), dim3(256), 0, s, (const uint4*)x, (float*)ws, HW, groups,
+                     GNH_PIX, head);
+  hipLaunchKernelGGL(cgg_gn_nhwc_reduce_kernel, dim3(B * groups), dim3(64), 0, s, (float*)ws, head, nblk, groups, B);
   const long long nvec = (long long)HW * groups;
   const dim3 grid((unsigned)((nvec + 255) / 256), B);
   const float inv_n = 1.f / ((float)HW * 8.f);

@@ -458,6 +458,12 @@ def _ptr_at(t, elem_offset=0):
     return ctypes.c_void_p(t.data_ptr() + int(elem_offset) * t.element_size())
 
 
+def group_norm_nhwc_workspace(B, HW, groups, device):
+    """f32 scratch for `group_norm_nhwc` (totals + per-block partial sums)."""
+    n = _lib_().cgg_group_norm_nhwc_workspace_bytes(int(B), int(HW), int(groups))
+    return torch.empty((max(n // 4, 1),), dtype=torch.float32, device=device)
+
+
 def group_norm_nhwc(x, gamma, beta, groups, eps, ws, relu=False, up=None, W=0, out32=None, out16=None, pos=None,
                     outp16=None):
     """GroupNorm of a channel-last bf16 activation x (B, HW, C), C / groups == 8 (see include/cgg_hip.h).
@@ -468,6 +474,9 @@ def group_norm_nhwc(x, gamma, beta, groups, eps, ws, relu=False, up=None, W=0, o
     Destinations are raw (tensor, offset, stride) triples so the three encoder levels can land directly inside the
     (B, N, C) stream tensors."""
     B, HW, C = x.shape
+    need = _lib_().cgg_group_norm_nhwc_workspace_bytes(B, HW, int(groups))
+    if ws is None or ws.numel() * ws.element_size() < need:
+        raise CggError(f'group_norm_nhwc: workspace too small ({need} bytes needed; see group_norm_nhwc_workspace)')
     b16 = out16[2] if out16 is not None else (outp16[2] if outp16 is not None else 0)
     if out16 is not None and outp16 is not None and out16[2] != outp16[2]:
         raise CggError('group_norm_nhwc: out16 and outp16 must share the batch stride')

@@ -606,7 +606,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         src = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         x16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
         xp16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
-        ws = torch.empty((B * 32 * 2,), dtype=torch.float32, device=dev)
+        ws = ops.group_norm_nhwc_workspace(B, int(feats[0].shape[2]) * int(feats[0].shape[3]), 32, dev)   # largest map
         for i in range(self.num_encoder_levels):
             f = feats[self.num_input_levels - i - 1]
             h, w = level_hw[i]

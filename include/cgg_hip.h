@@ -216,8 +216,10 @@ int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float
  *   (+ bilinear up-sample of up_src [B, up_h, up_w, C] f32 to the (HW / W, W) grid -- the FPN `cur +
  *   F.interpolate(outs[-1])` step) (+ ReLU); outputs (each nullable, at least one): y32 f32 with batch stride
  *   y32_bstride elements (writes straight into the (B, N, C) encoder stream), y16 = bf16(y) and yp16 =
- *   bf16(y + pos), pos [HW, C] f32, both with batch stride y16_bstride elements. ws: B * groups * 2 floats of scratch.
+ *   bf16(y + pos), pos [HW, C] f32, both with batch stride y16_bstride elements. ws:
+ *   cgg_group_norm_nhwc_workspace_bytes(B, HW, groups) bytes of scratch (per-block partial sums, no atomics).
  * cgg_pack_mask_feature_nhwc: cgg_pack_mask_feature for a [B, H, W, C] bf16 map (hi image only).              */
+int64_t cgg_group_norm_nhwc_workspace_bytes(int B, int HW, int groups);
 int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C,
                         int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
                         int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16, const float* pos,

@@ -488,7 +488,7 @@ def test_group_norm_nhwc_and_pack_nhwc(dev):
         base = gn(x.float().view(B, H, W, C).permute(0, 3, 1, 2))                       # NCHW
         up = torch.nn.functional.interpolate(lo.permute(0, 3, 1, 2), size=(H, W), mode='bilinear',
                                              align_corners=False)
-    ws = torch.empty(B * 64, device=dev)
+    ws = ops.group_norm_nhwc_workspace(B, H * W, 32, dev)
     # (a) plain GN -> f32 into a strided (B, N, C) stream at a row offset, bf16 copy, bf16(y + pos)
     N, row0 = H * W + 37, 21
     y32 = torch.zeros(B, N, C, device=dev)
