@@ -9,8 +9,8 @@
 //   * because a workgroup owns complete rows when N == 256, the residual add + LayerNorm run in the epilogue
 //     (two-pass mean / variance over LDS), and a second output `y + pos` (the next projection's input) is written
 //     in the same pass -- the separate LayerNorm and add launches disappear;
-//   * K can be split over gridDim.z (f32 atomics into a zeroed output) so the K = 2048 projection uses 56
-//     workgroups instead of 7;
+//   * K can be split over gridDim.z (one partial plane per split, summed in fixed order by the following
+//     LayerNorm-chain kernel: deterministic, no atomics) so the K = 2048 projection uses 56 workgroups instead of 7;
 //   * ReLU can be limited to the first `relu_cols` columns, which lets cls_embed / v2l_transform / mask_embed[0]
 //     (open_set/models/mask2former_head.py:734-746) run as ONE GEMM over concatenated weights.
 #include "cgg_common.h"
@@ -112,11 +112,14 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
     }
   }
   if (ksplit > 1) {
+    // split-K: every split writes its own partial plane y[z][M][ldy] with plain stores; the consumer
+    // (cgg_layernorm_chain, nsum = ksplit) adds the planes in a fixed order -> deterministic, no atomics, no memset
     if (col_ok) {
+      float* yz = y + (size_t)blockIdx.z * M * ldy;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-        if (m < M) atomicAdd(y + (size_t)m * ldy + n, v[r]);
+        if (m < M) yz[(size_t)m * ldy + n] = v[r];
       }
     }
     return;
@@ -197,7 +200,8 @@ __global__ __launch_bounds__(256) void cgg_ln_chain_kernel(const float* __restri
                                                           float eps_a, const float* __restrict__ pos, int pos_rows,
                                                           const float* __restrict__ gb, const float* __restrict__ bb,
                                                           float eps_b, float* __restrict__ y, float* __restrict__ yp,
-                                                          float* __restrict__ z, int rows, int N) {
+                                                          float* __restrict__ z, int rows, int N, int nsum,
+                                                          long long plane) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -207,7 +211,11 @@ __global__ __launch_bounds__(256) void cgg_ln_chain_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = lane + 64 * k;
-    v[k] = i < nv ? *reinterpret_cast<const f32x4*>(a + (size_t)row * lda + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < nv) {
+      for (int p = 0; p < nsum; ++p)             // split-K planes, fixed order
+        v[k] += *reinterpret_cast<const f32x4*>(a + (size_t)p * plane + (size_t)row * lda + 4 * i);
+    }
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   const float inv_n = 1.f / (float)N;
@@ -252,8 +260,8 @@ __global__ __launch_bounds__(256) void cgg_ln_chain_kernel(const float* __restri
 
 extern "C" int cgg_layernorm_chain(const float* a, int lda, const float* gamma_a, const float* beta_a, float eps_a,
                                    const float* pos, int pos_rows, const float* gamma_b, const float* beta_b,
-                                   float eps_b, float* y, float* yp, float* z, int rows, int N,
-                                   cgg_stream_t stream) {
+                                   float eps_b, float* y, float* yp, float* z, int rows, int N, int nsum,
+                                   int64_t plane, cgg_stream_t stream) {
   CGG_REQUIRE(a && gamma_a && beta_a && y, CGG_EINVAL, "cgg_layernorm_chain: null pointer");
   CGG_REQUIRE(rows > 0 && N > 0 && N % 4 == 0 && N <= 1024 && lda % 4 == 0, CGG_EUNSUPPORTED,
               "cgg_layernorm_chain: N=%d lda=%d", N, lda);
@@ -263,7 +271,8 @@ extern "C" int cgg_layernorm_chain(const float* a, int lda, const float* gamma_a
                   cgg_aligned16(gamma_a) && cgg_aligned16(beta_a) && cgg_aligned16(gamma_b) && cgg_aligned16(beta_b),
               CGG_EALIGN, "cgg_layernorm_chain: alignment");
   hipLaunchKernelGGL(cgg_ln_chain_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, lda, gamma_a,
-                     beta_a, eps_a, pos, pos_rows, gamma_b, beta_b, eps_b, y, yp, z, rows, N);
+                     beta_a, eps_a, pos, pos_rows, gamma_b, beta_b, eps_b, y, yp, z, rows, N, nsum < 1 ? 1 : nsum,
+                     (long long)plane);
   CGG_CHECK_LAUNCH("cgg_layernorm_chain");
   return CGG_OK;
 }
@@ -298,13 +307,6 @@ extern "C" int cgg_linear_rows_bf16(const float* x, int ldx, const void* w_packe
   CGG_REQUIRE(!yp || (pos && pos_rows > 0 && ksplit == 1), CGG_EINVAL, "cgg_linear_rows_bf16: yp needs pos, no split");
   CGG_REQUIRE(ksplit == 1 || relu_cols == 0, CGG_EUNSUPPORTED, "cgg_linear_rows_bf16: no ReLU with a K split");
   hipStream_t s = (hipStream_t)stream;
-  if (ksplit > 1) {
-    hipError_t e = hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
-    if (e != hipSuccess) {
-      cgg_set_error("cgg_linear_rows_bf16: memset failed: %s", hipGetErrorString(e));
-      return (int)e;
-    }
-  }
   dim3 grid((N + 255) / 256, (M + 31) / 32, ksplit);
   if (ln)
     hipLaunchKernelGGL(cgg_lr2_kernel<true>, grid, dim3(512), 0, s, x, ldx, (const u32x4*)w_packed, bias, res, ldr, y,

@@ -527,10 +527,21 @@ def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, po
                      out=None):
     """x (M, K) f32 rows (row stride free, last dim contiguous) @ packed weight -> y (M, N) f32.
     ln = (gamma, beta, eps) fuses a LayerNorm over the N <= 256 outputs; pos (rows, N) with want_pos returns
-    (y, y + pos[row % rows]). `out` may be a 2-D view with its own row stride."""
+    (y, y + pos[row % rows]). `out` may be a 2-D view with its own row stride. ksplit > 1 returns the (ksplit, M, N)
+    split-K partial planes (bias / res in plane 0) for `layernorm_chain` to add."""
     if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda:
         raise CggError('linear_rows_bf16: x must be a 2-D float32 ROCm tensor with a contiguous last dim')
     M, K = x.shape
+    if ksplit > 1:
+        if out is not None or want_pos or ln is not None or relu_cols:
+            raise CggError('linear_rows_bf16: split-K returns (ksplit, M, N) partial planes; no out / ln / pos / relu')
+        y = torch.empty((int(ksplit), M, N), dtype=torch.float32, device=x.device)
+        rc = _lib_().cgg_linear_rows_bf16(
+            ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+            ctypes.c_void_p(res.data_ptr()) if res is not None else None, res.stride(0) if res is not None else 0,
+            dev_ptr(y), N, None, None, 0.0, None, 0, None, 0, M, N, K, 0, int(ksplit), stream_ptr(x.device))
+        check(rc, 'cgg_linear_rows_bf16(split-K)')
+        return y
     y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x.device)
     if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
         raise CggError('linear_rows_bf16: bad `out` view')
@@ -552,6 +563,12 @@ def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, po
 def layernorm_chain(a, norm_a, pos=None, norm_b=None):
     """a (M, N) f32 -> (y = LN_a(a), yp = y + pos[row % len(pos)] | None, z = LN_b(y) | None); norm_* are
     (gamma, beta, eps) triples."""
+    nsum, plane = 1, 0
+    if a.dim() == 3:                       # split-K partial planes (nsum, M, N): summed in the kernel, fixed order
+        if not a.is_contiguous():
+            raise CggError('layernorm_chain: partial planes must be contiguous')
+        nsum, plane = a.shape[0], a.shape[1] * a.shape[2]
+        a = a[0]
     M, N = a.shape
     if a.stride(1) != 1:
         raise CggError('layernorm_chain: last dim must be contiguous')
@@ -563,8 +580,8 @@ def layernorm_chain(a, norm_a, pos=None, norm_b=None):
         ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(norm_a[0], 'gamma', torch.float32),
         dev_ptr(norm_a[1], 'beta', torch.float32), float(norm_a[2]), dev_ptr(pos, 'pos', torch.float32),
         pos.shape[0] if pos is not None else 0, dev_ptr(gb, 'gamma_b', torch.float32),
-        dev_ptr(bb, 'beta_b', torch.float32), float(eb), dev_ptr(y), dev_ptr(yp), dev_ptr(z), M, N,
-        stream_ptr(a.device))
+        dev_ptr(bb, 'beta_b', torch.float32), float(eb), dev_ptr(y), dev_ptr(yp), dev_ptr(z), M, N, int(nsum),
+        int(plane), stream_ptr(a.device))
     check(rc, 'cgg_layernorm_chain')
     return y, yp, z
 

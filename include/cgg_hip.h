@@ -186,8 +186,9 @@ int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const 
  *   y[M,N] = x[M,K] @ W^T + bias; ReLU on columns < relu_cols; + res[M,N];
  *   ln_gamma != NULL (N <= 256): y = LayerNorm(y) * gamma + beta in the epilogue;
  *   yp != NULL: yp = y + pos[row % pos_rows] (pos [pos_rows, N]) written in the same pass;
- *   ksplit > 1: K is split over ksplit workgroups that accumulate into y with f32 atomics (y is zeroed first;
- *   no ReLU / LayerNorm / yp in that mode).
+ *   ksplit > 1: K is split over ksplit workgroups; split z writes its partial sums to the plane y + z * M * ldy
+ *   (y must hold ksplit planes; bias / res go into plane 0; no ReLU / LayerNorm / yp in that mode) and the consumer
+ *   adds the planes (cgg_layernorm_chain with nsum = ksplit) -- deterministic, no atomics.
  * Replaces, per decoder layer, the q/k/v/out projections, FFN, the three post-norm LayerNorms and the `x + pos`
  * adds of DetrTransformerDecoderLayer ([3P]; open_set/models/mask2former_head.py:829-840) and the cls / v2l /
  * mask_embed MLPs of forward_head (:734-746). Requires K % 16 == 0, ldx % 4 == 0.                               */
@@ -198,11 +199,13 @@ int cgg_linear_rows_bf16(const float* x, int ldx, const void* w_packed, const fl
                          const float* pos, int pos_rows, float* yp, int ldyp, int M, int N, int K, int relu_cols,
                          int ksplit, cgg_stream_t stream);
 
-/* y = LN_a(a) ; yp = y + pos[row % pos_rows] (nullable) ; z = LN_b(y) (nullable): the decoder layer's last norm, the
- * next layer's `query + query_pos`, and the head's post_norm (mask2former_head.py:734) in one pass. N <= 1024.   */
+/* y = LN_a(sum_{p < nsum} a[p * plane + ...]) ; yp = y + pos[row % pos_rows] (nullable) ; z = LN_b(y) (nullable): the
+ * decoder layer's last norm (fed by the nsum split-K planes of cgg_linear_rows_bf16), the next layer's `query +
+ * query_pos`, and the head's post_norm (mask2former_head.py:734) in one pass. N <= 1024.                          */
 int cgg_layernorm_chain(const float* a, int lda, const float* gamma_a, const float* beta_a, float eps_a,
                         const float* pos, int pos_rows, const float* gamma_b, const float* beta_b, float eps_b,
-                        float* y, float* yp, float* z, int rows, int N, cgg_stream_t stream);
+                        float* y, float* yp, float* z, int rows, int N, int nsum, int64_t plane,
+                        cgg_stream_t stream);
 
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, b f32 or bf16 (nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */

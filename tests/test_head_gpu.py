@@ -252,10 +252,11 @@ def test_stage_pipeline(dev, stages):
             for k in w_img:
                 wl, wb, wm = w_img[k]
                 gl, gb, gm = g_img[k]
-                # same detections up to f32 atomics order in the GroupNorm statistics: compare as sets of (label, box)
+                # the forward is deterministic (no atomics on its data path; only the mask-score reduction uses f32
+                # atomics): same detections, same masks, scores equal to rounding
                 assert sorted(wl.cpu().tolist()) == sorted(gl.cpu().tolist())
-                assert abs(wb[:, 4].sum().item() - gb[:, 4].sum().item()) <= 1e-2 * max(1.0, wb[:, 4].sum().item())
-                assert abs(int(wm.sum()) - int(gm.sum())) <= 0.002 * wm.numel()
+                assert abs(wb[:, 4].sum().item() - gb[:, 4].sum().item()) <= 1e-4 * max(1.0, wb[:, 4].sum().item())
+                assert int(wm.sum()) == int(gm.sum())
 
 
 def test_head_200_queries(dev):

@@ -544,8 +544,16 @@ def test_linear_rows_bf16_variants(dev, M, N, K):
     assert (out.cpu().double() - base).abs().max().item() <= tol
     # split-K
     if K >= 512:
-        y = ops.linear_rows_bf16(x.to(dev), packed, N, b.to(dev), res=res.to(dev), ksplit=8)
-        assert (y.cpu().double() - (base + res.double())).abs().max().item() <= tol
+        planes = ops.linear_rows_bf16(x.to(dev), packed, N, b.to(dev), res=res.to(dev), ksplit=8)
+        assert planes.shape == (8, M, N)
+        assert (planes.sum(0).cpu().double() - (base + res.double())).abs().max().item() <= tol
+        again = ops.linear_rows_bf16(x.to(dev), packed, N, b.to(dev), res=res.to(dev), ksplit=8)
+        assert torch.equal(planes, again)                       # no atomics: bit-reproducible
+        if N % 4 == 0 and N <= 1024:
+            ln2 = torch.nn.LayerNorm(N)
+            yy, _, _ = ops.layernorm_chain(planes, (ln2.weight.to(dev), ln2.bias.to(dev), ln2.eps))
+            with torch.no_grad():
+                assert (yy.cpu() - ln2(planes.sum(0).cpu())).abs().max().item() <= 1e-4
     # fused LayerNorm + `y + pos`
     if N <= 256:
         ln = torch.nn.LayerNorm(N)
