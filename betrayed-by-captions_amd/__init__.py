@@ -11,7 +11,7 @@ from . import _lib, ops, runtime  # noqa: F401
 from . import registry, config  # noqa: F401
 from . import (pixel_decoder, query_decoder, losses, assigner, bert_embeddings,  # noqa: F401
                caption_transformer, mask2former_head, maskformer_fusion_head, backbones, detectors,
-               v2l_head, caption_search, pipeline, train)
+               v2l_head, caption_search, pipeline, train, swin)
 from .config import Config  # noqa: F401
 from .registry import (BACKBONES, BBOX_ASSIGNERS, DETECTORS, HEADS, LOSSES, build_detector,  # noqa: F401
                        build_head, build_loss)

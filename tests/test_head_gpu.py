@@ -305,3 +305,37 @@ def test_simple_test_with_caption_beam_search(dev, heads):
         ids_cpu = beam_search(cpu_head, emb.cpu(), 101, 102, max_len=35, beam_width=7, return_ids=True)
     assert out[3] is not None
     assert isinstance(ids_dev, list) and ids_dev == ids_cpu
+
+
+def test_swin_b_200_queries_detector(dev):
+    """BASELINE configs[3] plumbing: Swin-B backbone (in_channels 128..1024) + 200 queries through the throughput-mode
+    stream (channel-last bf16 hand-over, packed mask feature, bf16 attention) and through parity mode."""
+    import copy
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=200, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    cfg = copy.deepcopy(cfg)
+    cfg['backbone'] = dict(type='SwinTransformer', embed_dims=128, depths=(2, 2, 6, 2), num_heads=(4, 8, 16, 32),
+                           window_size=7, mlp_ratio=4, out_indices=(0, 1, 2, 3), drop_path_rate=0.3, patch_norm=True)
+    cfg['panoptic_head']['in_channels'] = [128, 256, 512, 1024]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+        torch.manual_seed(0)
+        model.init_weights()
+    model = model.to(dev).eval()
+    B, H, W = 1, 224, 288
+    img = torch.randn(B, 3, H, W, device=dev)
+    metas = synthetic.img_metas(B, H, W)
+    with torch.no_grad():
+        f32 = model.extract_feat(img)
+        assert [tuple(f.shape[1:]) for f in f32] == [(128, 56, 72), (256, 28, 36), (512, 14, 18), (1024, 7, 9)]
+        res32 = model.simple_test(img, metas, rescale=True, device_results=True)
+        with runtime.precision_scope('bf16'):
+            f16 = model.extract_feat(img)
+            assert all(f.dtype == torch.bfloat16 for f in f16) and model.panoptic_head.pixel_decoder.stream_ready(f16)
+            for a, b in zip(f16, f32):
+                assert (a.float() - b).abs().max().item() <= 0.08 * b.abs().max().item()
+            res16 = model.simple_test(img, metas, rescale=True, device_results=True)
+    for r in (res32, res16):
+        labels, boxes, masks = r[0]['all_results']
+        assert masks.shape[1:] == (H, W) and torch.isfinite(boxes).all()
