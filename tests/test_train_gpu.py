@@ -76,3 +76,48 @@ def test_forward_train_losses_and_gradients(dev):
         g = named[key].grad
         assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, key
     assert named['bert_embeddings.word_embeddings.weight'].grad is None        # frozen text encoder
+
+
+def test_batched_loss_path_equals_per_item_path_incl_empty_image(dev):
+    """`_loss_batched` (targets of all layers x images batched, caption generator once, GT sampled per image) gives the
+    losses of the per-(layer, image) path of the reference -- same pinned random points -- also when one image of the
+    batch has NO ground-truth instance and another has a single one."""
+    cfg = small_cfg(num_queries=12, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prod, _ = build_heads(cfg)
+    prod = prod.to(dev).train()
+    for m in prod.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B, H, W = 3, 96, 128
+    feats = [f.to(dev) for f in synthetic.backbone_feats(B, H, W, channels=(64, 128, 256, 512), seed=31)]
+    metas = synthetic.img_metas(B, H, W)
+    batch = synthetic.train_batch(B, H, W, num_classes=cfg['panoptic_head']['num_things_classes'], max_inst=4,
+                                  vocab=500, seed=32, device=dev)
+    batch['gt_labels'][1] = batch['gt_labels'][1][:0]            # image 1: no instance at all
+    batch['gt_masks'][1] = batch['gt_masks'][1][:0]
+    batch['gt_bboxes'][1] = batch['gt_bboxes'][1][:0]
+    batch['gt_labels'][2] = batch['gt_labels'][2][:1]            # image 2: exactly one
+    batch['gt_masks'][2] = batch['gt_masks'][2][:1]
+    batch['gt_bboxes'][2] = batch['gt_bboxes'][2][:1]
+
+    def run(reference_path):
+        prod.point_hook = Bank(5)
+        prod.force_reference_targets = reference_path
+        prod.zero_grad(set_to_none=True)
+        losses = prod.forward_train(feats, metas, batch['gt_bboxes'], batch['gt_labels'], batch['gt_masks'], None,
+                                    batch['gt_caption_ids'], batch['gt_caption_mask'], batch['gt_caption_nouns_ids'],
+                                    batch['gt_caption_nouns_mask'])
+        sum(losses.values()).backward()
+        g = prod.mask_embed[4].weight.grad.clone()
+        return {k: float(v) for k, v in losses.items()}, g
+
+    fast, g_fast = run(False)
+    slow, g_slow = run(True)
+    prod.point_hook = None
+    prod.force_reference_targets = False
+    assert set(fast) == set(slow)
+    for k in sorted(fast):
+        assert abs(fast[k] - slow[k]) <= 1e-4 * (1 + abs(slow[k])), (k, fast[k], slow[k])
+    assert (g_fast - g_slow).abs().max().item() <= 1e-4 * (1 + g_slow.abs().max().item())
