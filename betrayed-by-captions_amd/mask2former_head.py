@@ -66,6 +66,52 @@ class LowResMasks:
             yield self[i]
 
 
+class LazyMasks:
+    """Training-time stand-in for one layer's (B, Q, h, w) `mask_pred`: keeps the factors of the einsum
+    (mask2former_head.py:748) instead of its 100-query result. The loss only ever reads mask logits (a) at 12 544 shared
+    random points for the matching cost and (b) at full resolution for the handful of MATCHED queries, and sampling is
+    linear -- sample(E F) = E sample(F) -- so neither needs the full tensor: (a) is one grid_sample of
+    the mask feature + a (Q x C) x (C x P) product, (b) an einsum over the positives only. The forward / backward of
+    the 10 full einsums (2 x 53.7 GFLOP f32 and 0.7 GB of gradient traffic per layer at configs[2]) disappears."""
+
+    def __init__(self, mask_embed, mask_feature):
+        self.mask_embed, self.mask_feature = mask_embed, mask_feature        # (B, Q, C), (B, C, h, w)
+
+    @property
+    def shape(self):
+        B, Q, _ = self.mask_embed.shape
+        return (B, Q) + tuple(self.mask_feature.shape[-2:])
+
+    def sample_points(self, points):
+        """points (B, P, 2) in [0, 1] -> logits of all queries at the points, (B, Q, P); no autograd."""
+        with torch.no_grad():
+            fs = point_sample(self.mask_feature.detach(), points)             # (B, C, P)
+            return torch.bmm(self.mask_embed.detach().float(), fs.float())
+
+    def select(self, pos):
+        """`mask_pred[weights > 0]` (mask2former_head.py:597) for the positives described by `pos` (device index tensors
+        b / q / r = slot inside the image, host int pm = max positives per image): full-resolution logits (n_pos, h, w),
+        image-major like boolean indexing; differentiable w.r.t. mask_embed and mask_feature. The positives are packed
+        into a zero-padded (B, pm, C) operand so that ONE batched product serves the whole layer."""
+        B, Q, C = self.mask_embed.shape
+        h, w = self.mask_feature.shape[-2:]
+        pm = int(pos['pm'])
+        if pm == 0:
+            return self.mask_embed.new_zeros((0, h, w)) + 0 * self.mask_embed.sum() + 0 * self.mask_feature.sum()
+        bi, qi, ri = pos['b'], pos['q'], pos['r']
+        ep = self.mask_embed.new_zeros((B, pm, C)).index_put((bi, ri), self.mask_embed[bi, qi])
+        full = torch.bmm(ep, self.mask_feature.flatten(2).to(ep.dtype))         # (B, pm, h*w)
+        return full[bi, ri].view(-1, h, w)
+
+    def select_by_weights(self, weights):
+        """same from a (B, Q) weight map (host round trip for the index set)."""
+        sel = weights > 0
+        bi, qi = torch.nonzero(sel, as_tuple=True)
+        rank = (torch.cumsum(sel.long(), 1) - 1)[bi, qi]
+        pm = int(sel.sum(1).max()) if sel.numel() else 0
+        return self.select(dict(b=bi, q=qi, r=rank, pm=pm))
+
+
 class _MaskLogitsFn(torch.autograd.Function):
     """einsum('bqc,bchw->bqhw') with the HIP MFMA forward; backward = the two transposed contractions
     (library GEMMs on the device; round 1)."""
@@ -272,7 +318,10 @@ class Mask2FormerHeadOpen(nn.Module):
                 packed = ops.pack_mask_feature(mask_feature.detach().contiguous(), 1, split)
             if mask_feature is not None and torch.is_grad_enabled() and (mask_embed.requires_grad or
                                                                          mask_feature.requires_grad):
-                mask_pred = _MaskLogitsFn.apply(mask_embed, mask_feature, packed)
+                if getattr(self, '_lazy_masks', False):
+                    mask_pred = LazyMasks(mask_embed, mask_feature)
+                else:
+                    mask_pred = _MaskLogitsFn.apply(mask_embed, mask_feature, packed)
             else:
                 mask_pred, _ = ops.mask_logits(mask_embed, packed, want_logits=True)
         bits = None
@@ -285,7 +334,7 @@ class Mask2FormerHeadOpen(nn.Module):
                     pooled = ops.pack_mask_feature(mask_feature.detach().contiguous(), s, split)
                 _, bits = ops.mask_logits(mask_embed.detach(), pooled, want_logits=False, want_bits=True)
             else:  # generic size: resize the stored logits (still no x num_heads repeat)
-                if mask_pred is None:
+                if mask_pred is None or isinstance(mask_pred, LazyMasks):
                     if packed is None:
                         packed = ops.pack_mask_feature(mask_feature.detach().contiguous(), 1, split)
                     full, _ = ops.mask_logits(mask_embed.detach(), packed, want_logits=True)
@@ -592,7 +641,8 @@ class Mask2FormerHeadOpen(nn.Module):
         else:
             pts = torch.stack([torch.cat([self._draw_points(dev) for _ in range(B)], 0) for _ in range(n)], 0)
         with torch.no_grad():
-            pred_pts = torch.stack([point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)  # (n,B,Q,P)
+            pred_pts = torch.stack([all_mask_preds[li].sample_points(pts[li]) if isinstance(all_mask_preds[li], LazyMasks)
+                                    else point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)
             costs, shapes = [], []
             for b in range(B):
                 G = int(gt_labels_list[b].shape[0])
@@ -633,6 +683,8 @@ class Mask2FormerHeadOpen(nn.Module):
         gl_host = [g.cpu().numpy() if s else None for g, s in zip(gt_labels_list, shapes)] if costs else []
         pos_b = [[] for _ in range(n)]
         pos_g = [[] for _ in range(n)]
+        pos_q = [[] for _ in range(n)]
+        pos_r = [[] for _ in range(n)]          # rank of the positive inside its image (padded-batch slot)
         off = 0
         for b in range(B):
             G = shapes[b]
@@ -648,11 +700,20 @@ class Mask2FormerHeadOpen(nn.Module):
                 weights_np[li, b, rows] = 1.0
                 pos_b[li].extend([b] * len(rows))
                 pos_g[li].extend(cols.tolist())
+                pos_q[li].extend(rows.tolist())
+                pos_r[li].extend(range(len(rows)))
         labels = torch.from_numpy(labels_np).to(dev, non_blocking=True)
         weights = torch.from_numpy(weights_np).to(dev, non_blocking=True)
-        out = []
+        # positives of all layers as ONE index tensor (rows: image, query, gt, slot) -> one H2D
+        flat_idx = np.array([sum(pos_b, []), sum(pos_q, []), sum(pos_g, []), sum(pos_r, [])], dtype=np.int64).reshape(4, -1)
+        idx_dev = torch.from_numpy(flat_idx).to(dev, non_blocking=True)
+        out, o = [], 0
         for li in range(n):
-            out.append((labels[li], weights[li], pos_b[li], pos_g[li], len(pos_b[li])))
+            k = len(pos_b[li])
+            pm = max((pos_b[li].count(b) for b in set(pos_b[li])), default=0)
+            devi = dict(b=idx_dev[0, o:o + k], q=idx_dev[1, o:o + k], g=idx_dev[2, o:o + k], r=idx_dev[3, o:o + k], pm=pm)
+            out.append((labels[li], weights[li], pos_b[li], pos_g[li], k, devi))
+            o += k
         return out
 
     def gather_captions_and_preds(self, gt_caption_embs_list, gt_caption_mask_list, cls_emb_preds):
@@ -713,7 +774,7 @@ class Mask2FormerHeadOpen(nn.Module):
         num_imgs = cls_scores.size(0)
         pos_b = pos_g = gt_f = cap_loss = None
         if fast is not None:
-            (labels2, mask_weights, pos_b, pos_g, num_total_pos), gt_f, cls_emb_logits, cap_loss = fast
+            (labels2, mask_weights, pos_b, pos_g, num_total_pos, pos_dev), gt_f, cls_emb_logits, cap_loss = fast
             labels = labels2.flatten(0, 1)
             label_weights = torch.ones_like(labels)
             mask_targets = None
@@ -776,7 +837,10 @@ class Mask2FormerHeadOpen(nn.Module):
             num_total_masks = reduce_mean(cls_scores.new_tensor([num_total_pos]))
             num_total_masks = max(num_total_masks, 1)
 
-        mask_preds = mask_preds[mask_weights > 0]
+        if isinstance(mask_preds, LazyMasks):
+            mask_preds = mask_preds.select(pos_dev) if fast is not None else mask_preds.select_by_weights(mask_weights)
+        else:
+            mask_preds = mask_preds[mask_weights > 0]
         if (len(pos_b) if fast is not None else mask_targets.shape[0]) == 0:
             loss_dice = mask_preds.sum()
             loss_mask = mask_preds.sum()
@@ -796,7 +860,7 @@ class Mask2FormerHeadOpen(nn.Module):
                     j1 = j0
                     while j1 < len(pos_b) and pos_b[j1] == b:
                         j1 += 1
-                    g_idx = torch.tensor(pos_g[j0:j1], dtype=torch.long, device=points_coords.device)
+                    g_idx = pos_dev['g'][j0:j1]
                     smp = point_sample(gt_f[b][None], points_coords[j0:j1].reshape(1, (j1 - j0) * Pn, 2))[0]
                     smp = smp.view(-1, j1 - j0, Pn)                                   # (G, npos_b, P)
                     chunks.append(smp[g_idx, torch.arange(j1 - j0, device=smp.device)])
@@ -939,7 +1003,11 @@ class Mask2FormerHeadOpen(nn.Module):
                       gt_bboxes_ignore=None, **kwargs):
         """mask2former_head.py:851-921."""
         assert gt_bboxes_ignore is None
-        all_cls_scores, all_cls_emb_preds, all_mask_preds = self(feats, img_metas)
+        self._lazy_masks = self._fast_targets_ok() and not getattr(self, 'force_reference_targets', False)
+        try:
+            all_cls_scores, all_cls_emb_preds, all_mask_preds = self(feats, img_metas)
+        finally:
+            self._lazy_masks = False
         gt_labels, gt_masks = self.preprocess_gt(gt_labels, gt_masks, gt_semantic_seg, img_metas)
         gt_caption_embs = gt_caption_nouns_embs = None
         if self.use_caption_generation:
