@@ -170,13 +170,18 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
 // No LDS for K / V at all (only the mask words); the 4 waves of a workgroup (4 query tiles of one head) re-read
 // the same 4 KiB of K / V per 32 keys from L1. Same partial / combine protocol as the f32 kernel.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cgg_xattn_partial_bf16(
+__global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     const float* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vt,
     const uint32_t* __restrict__ bits, float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S,
     int words, int KC, int nchunks, float scale) {
   constexpr int D = 32;
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 8 waves = 2 ADJACENT heads x 4 query tiles: a 128-byte line of K holds the 64-byte slices of two heads, so
+  // pairing them in one workgroup makes every fetched line fully useful (one head per workgroup re-fetched each
+  // line from L2 for its neighbour: 43 -> 3x us at S = 16 384)
+  const int chunk = blockIdx.x, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int wave = wave8 & 3;
+  const int h = blockIdx.y * 2 + (wave8 >> 2);
   const int j = lane & 31, hi = lane >> 5;
   const int HD = H * D;
   const int s_begin = chunk * KC;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_bf16(
   const int nmt = (Q + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* Ms = reinterpret_cast<uint32_t*>(smem_raw);   // [nmt*32][cws]
-  for (int i = tid; i < nmt * 32 * cw; i += 256) {
+  for (int i = tid; i < nmt * 32 * cw; i += 512) {
     const int qq = i / cw, w = i - qq * cw;
     const int gw = s_begin / 32 + w;
     uint32_t m = 0u;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_bf16(
     Ms[qq * cws + w] = m;
   }
   __syncthreads();
-  if (wave >= nmt) return;
+  if (wave >= nmt || h >= H) return;
 
   const int qi = wave * 32 + j;
   bf16x8 qb[2];
@@ -380,7 +385,7 @@ extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, cons
   float* ws_ml = ws_o + (size_t)B * H * nch * Q * D;
   const size_t lds = (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, H, B), dim3(256), lds, s, q, (const uint16_t*)k,
+  hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, (H + 1) / 2, B), dim3(512), lds, s, q, (const uint16_t*)k,
                      (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(partial)");
   const long long total = (long long)B * Q * H * D;
