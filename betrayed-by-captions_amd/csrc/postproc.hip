@@ -85,15 +85,27 @@ __global__ __launch_bounds__(256) void cgg_upsample_kernel(const float* __restri
 // block-level reduction, then ONE set of atomics per block (4096 pixels).
 // ws per detection: [0] f32 sum sigmoid*[m>0], [1] i32 count, [2..5] i32 xmin, ymin, xmax, ymax
 #define IM_PPT 16
+// Multi-destination mode (dest_off != nullptr): instance i IS query i and its mask is written to every slot
+// dest_slot[dest_off[i] .. dest_off[i+1]) of `masks` -- the detections of all evaluation types that picked this query --
+// so each query's mask is interpolated once and no gather pass over the (n, H, W) masks follows. Queries nobody
+// picked exit immediately.
 __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __restrict__ logits,
                                                                  const int32_t* __restrict__ sel,
                                                                  uint8_t* __restrict__ masks,
                                                                  int32_t* __restrict__ ws,
-                                                                 ResizeGeom g) {
+                                                                 ResizeGeom g,
+                                                                 const int32_t* __restrict__ dest_off,
+                                                                 const int32_t* __restrict__ dest_slot) {
   const int i = blockIdx.y;
+  int d0 = i, d1 = i + 1;
+  if (dest_off != nullptr) {
+    d0 = dest_off[i];
+    d1 = dest_off[i + 1];
+    if (d0 == d1) return;                                  // block-uniform
+  }
   const long long npix = (long long)g.out_h * g.out_w;
   const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * IM_PPT;
-  const float* s = logits + (size_t)sel[i] * g.H * g.W;
+  const float* s = logits + (size_t)(dest_off != nullptr ? i : sel[i]) * g.H * g.W;
   float sig = 0.f;
   int cnt = 0, xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
   uint32_t packed[IM_PPT / 4] = {0u, 0u, 0u, 0u};
@@ -113,11 +125,14 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __
       }
       if (++ox == g.out_w) { ox = 0; ++oy; }
     }
-    uint8_t* dst = masks + (size_t)i * npix + p0;
-    if (p0 + IM_PPT <= npix && ((((size_t)i * npix + p0) & 15) == 0)) {
-      *reinterpret_cast<uint4*>(dst) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-    } else {
-      for (int k = 0; k < IM_PPT && p0 + k < npix; ++k) dst[k] = (packed[k >> 2] >> (8 * (k & 3))) & 0xff;
+    for (int d = d0; d < d1; ++d) {
+      const size_t slot = dest_off != nullptr ? (size_t)dest_slot[d] : (size_t)i;
+      uint8_t* dst = masks + slot * npix + p0;
+      if (p0 + IM_PPT <= npix && (((slot * npix + p0) & 15) == 0)) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+      } else {
+        for (int k = 0; k < IM_PPT && p0 + k < npix; ++k) dst[k] = (packed[k >> 2] >> (8 * (k & 3))) & 0xff;
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -165,7 +180,9 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
                                                                      const int32_t* __restrict__ sel,
                                                                      uint8_t* __restrict__ masks,
                                                                      int32_t* __restrict__ ws,
-                                                                     ResizeGeom g) {
+                                                                     ResizeGeom g,
+                                                                     const int32_t* __restrict__ dest_off,
+                                                                     const int32_t* __restrict__ dest_slot) {
   // thread = a 16-wide x S-tall block of output pixels = source row m (and its neighbours m-1, m+1) x
   // 16/S + 2 source columns: 3 * NC loads feed 16 * S pixels. (The first version gave each thread ONE output
   // row: 2 * NC dependent loads for 16 pixels left the kernel latency-bound at ~0.5 TB/s of mask bytes.)
@@ -175,7 +192,13 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // tile index: (m, x-tile)
   const long long ntile = (long long)((g.out_h + S - 1) / S) * tiles_x;
   const long long npix = (long long)g.out_h * g.out_w;
-  const float* s = logits + (size_t)sel[i] * g.H * g.W;
+  int d0 = i, d1 = i + 1;
+  if (dest_off != nullptr) {
+    d0 = dest_off[i];
+    d1 = dest_off[i + 1];
+    if (d0 == d1) return;                                  // block-uniform: nobody picked this query
+  }
+  const float* s = logits + (size_t)(dest_off != nullptr ? i : sel[i]) * g.H * g.W;
   float sig = 0.f;
   int cnt = 0, xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
   if (t < ntile) {
@@ -226,8 +249,11 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
         ymin = min(ymin, oy);
         ymax = max(ymax, oy);
       }
-      *reinterpret_cast<uint4*>(masks + (size_t)i * npix + (size_t)oy * g.out_w + ox0) =
-          make_uint4(packed[0], packed[1], packed[2], packed[3]);
+      const uint4 pk = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+      for (int d = d0; d < d1; ++d) {
+        const size_t slot = dest_off != nullptr ? (size_t)dest_slot[d] : (size_t)i;
+        *reinterpret_cast<uint4*>(masks + slot * npix + (size_t)oy * g.out_w + ox0) = pk;
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -388,11 +414,34 @@ extern "C" int cgg_upsample_bilinear(const float* x, float* y, int N, int H, int
   return CGG_OK;
 }
 
+static int instance_masks_launch(const float* logits, const int32_t* sel, const int32_t* dest_off,
+                                 const int32_t* dest_slot, uint8_t* masks, float* mask_score, float* bbox, void* ws,
+                                 int Q, int H, int W, int up_h, int up_w, int crop_h, int crop_w, int out_h, int out_w,
+                                 int n, cgg_stream_t stream);
+
 extern "C" int cgg_instance_masks(const float* logits, const int32_t* sel, uint8_t* masks,
                                   float* mask_score, float* bbox, void* ws, int Q, int H, int W,
                                   int up_h, int up_w, int crop_h, int crop_w, int out_h, int out_w,
                                   int n, cgg_stream_t stream) {
-  CGG_REQUIRE(logits && sel && masks && mask_score && bbox && ws, CGG_EINVAL,
+  CGG_REQUIRE(sel != nullptr, CGG_EINVAL, "cgg_instance_masks: null pointer");
+  return instance_masks_launch(logits, sel, nullptr, nullptr, masks, mask_score, bbox, ws, Q, H, W, up_h, up_w, crop_h,
+                               crop_w, out_h, out_w, n, stream);
+}
+
+extern "C" int cgg_instance_masks_multi(const float* logits, const int32_t* dest_off, const int32_t* dest_slot,
+                                        uint8_t* masks, float* mask_score, float* bbox, void* ws, int Q, int H, int W,
+                                        int up_h, int up_w, int crop_h, int crop_w, int out_h, int out_w,
+                                        cgg_stream_t stream) {
+  CGG_REQUIRE(dest_off && dest_slot, CGG_EINVAL, "cgg_instance_masks_multi: null pointer");
+  return instance_masks_launch(logits, nullptr, dest_off, dest_slot, masks, mask_score, bbox, ws, Q, H, W, up_h, up_w,
+                               crop_h, crop_w, out_h, out_w, Q, stream);
+}
+
+static int instance_masks_launch(const float* logits, const int32_t* sel, const int32_t* dest_off,
+                                 const int32_t* dest_slot, uint8_t* masks, float* mask_score, float* bbox, void* ws,
+                                 int Q, int H, int W, int up_h, int up_w, int crop_h, int crop_w, int out_h, int out_w,
+                                 int n, cgg_stream_t stream) {
+  CGG_REQUIRE(logits && masks && mask_score && bbox && ws, CGG_EINVAL,
               "cgg_instance_masks: null pointer");
   CGG_REQUIRE(Q > 0 && H > 0 && W > 0 && up_h > 0 && up_w > 0 && out_h > 0 && out_w > 0 && n > 0,
               CGG_EINVAL, "cgg_instance_masks: bad sizes");
@@ -410,13 +459,13 @@ extern "C" int cgg_instance_masks(const float* logits, const int32_t* sel, uint8
   const long long ntile = (long long)((out_h + S - 1) / S) * (out_w / IM_PPT);   // one thread per 16 x S block
   const dim3 tgrid((unsigned)((ntile + 255) / 256), n);
   if (int_path && S == 4)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
   else if (int_path && S == 2)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
   else if (int_path && S == 8)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
   else
-    hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g);
+    hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
   hipLaunchKernelGGL(cgg_instance_final_kernel, dim3((n + 63) / 64), dim3(64), 0, s,
                      (const int32_t*)ws, mask_score, bbox, n);
   CGG_CHECK_LAUNCH("cgg_instance_masks");

@@ -110,19 +110,9 @@ class MaskFormerFusionHeadOpen(nn.Module):
         out = tuple(int(v) for v in meta['ori_shape'][:2]) if rescale else crop
         return logits.contiguous(), up, crop, out
 
-    def _query_masks(self, geom):
-        logits, up, crop, out = geom
-        key = (logits.data_ptr(), logits._version, tuple(logits.shape), up, crop, out)
-        cache = getattr(self, '_qm_cache', None)
-        if cache is None or cache[0] != key:
-            sel = torch.arange(logits.shape[0], dtype=torch.int32, device=logits.device)
-            cache = (key, ops.instance_masks(logits, sel, up, crop, out))
-            self._qm_cache = cache
-        return cache[1]
-
-    def _instances_from_scores(self, scores, geom):
-        """:340-366 given per-query class scores (Q, n) (background column already dropped)."""
-        logits, up, crop, out = geom
+    def _topk(self, scores):
+        """:340-347 given per-query class scores (Q, n) (background column already dropped):
+        (labels, class scores, query indices) of the `max_per_image` best (query, class) pairs."""
         max_per_image = self.test_cfg.get('max_per_image', 100)
         n_cls = scores.shape[-1]
         flat = scores.flatten(0, 1)
@@ -130,35 +120,40 @@ class MaskFormerFusionHeadOpen(nn.Module):
         scores_per_image, top_indices = flat.topk(k, sorted=False)
         labels_per_image = top_indices % n_cls
         query_indices = torch.div(top_indices, n_cls, rounding_mode='floor')
-        # binary mask / mask score / bbox depend on the QUERY only: computed once per image for all Q
-        # queries and gathered per detection (the three eval types of a config re-use them)
-        qmasks, qscores, qboxes = self._query_masks(geom)
-        masks = qmasks.index_select(0, query_indices)
-        mask_scores = qscores.index_select(0, query_indices)
-        bboxes = qboxes.index_select(0, query_indices)
-        return labels_per_image, scores_per_image, mask_scores, bboxes, masks
+        return labels_per_image, scores_per_image, query_indices
+
+    def _instances_multi(self, picks, geom):
+        """:349-363 for SEVERAL evaluation types of one image at once: picks = [(labels, class scores, query indices)];
+        binary mask / mask score / bbox depend on the QUERY only, so every picked query's mask is interpolated once
+        (`cgg_instance_masks_multi`) and stored straight into each type's detection slots -- no per-type gather pass
+        over (n, H, W) masks. Returns [(labels, bboxes (n,5), masks (n,H,W) bool)] in the order of `picks`."""
+        logits, up, crop, out = geom
+        masks_l, qscores, qboxes = ops.instance_masks_multi(logits, [p[2] for p in picks], up, crop, out)
+        res = []
+        for (labels, cls_scores, qidx), masks in zip(picks, masks_l):
+            det_scores = cls_scores * qscores.index_select(0, qidx)
+            res.append((labels, torch.cat([qboxes.index_select(0, qidx), det_scores[:, None]], dim=-1), masks))
+        return res
+
+    def _geom_or_identity(self, mask_pred, meta, rescale):
+        if meta is not None:
+            return self._geom(mask_pred, meta, rescale)
+        hw = tuple(mask_pred.shape[-2:])
+        return mask_pred.contiguous(), hw, hw, hw
 
     def instance_postprocess_emb(self, mask_cls_emb, mask_pred, gt_cls_embs, meta=None, rescale=False):
         """:317-366 -> (labels (n,), bboxes (n,5) [x0,y0,x1,y1,score], masks (n,H,W) bool)."""
-        geom = self._geom(mask_pred, meta, rescale) if meta is not None else \
-            (mask_pred.contiguous(), tuple(mask_pred.shape[-2:]), tuple(mask_pred.shape[-2:]),
-             tuple(mask_pred.shape[-2:]))
+        geom = self._geom_or_identity(mask_pred, meta, rescale)
         scores = self.get_cls_emb_scores(mask_cls_emb, gt_cls_embs)[:, :-1]
-        labels, cls_scores, mask_scores, bboxes, masks = self._instances_from_scores(scores, geom)
-        det_scores = cls_scores * mask_scores
-        return labels, torch.cat([bboxes, det_scores[:, None]], dim=-1), masks
+        return self._instances_multi([self._topk(scores)], geom)[0]
 
     def instance_postprocess(self, mask_cls, mask_pred, meta=None, rescale=False):
         """:245-295 (closed-set variant on the classification logits)."""
-        geom = self._geom(mask_pred, meta, rescale) if meta is not None else \
-            (mask_pred.contiguous(), tuple(mask_pred.shape[-2:]), tuple(mask_pred.shape[-2:]),
-             tuple(mask_pred.shape[-2:]))
+        geom = self._geom_or_identity(mask_pred, meta, rescale)
         prob, _, _ = ops.rowwise_softmax_argmax(mask_cls.contiguous(), want_prob=True)
-        labels, cls_scores, mask_scores, bboxes, masks = self._instances_from_scores(prob[:, :-1], geom)
+        labels, bboxes, masks = self._instances_multi([self._topk(prob[:, :-1])], geom)[0]
         is_thing = labels < self.num_things_classes
-        labels, cls_scores, mask_scores = labels[is_thing], cls_scores[is_thing], mask_scores[is_thing]
-        bboxes, masks = bboxes[is_thing], masks[is_thing]
-        return labels, torch.cat([bboxes, (cls_scores * mask_scores)[:, None]], dim=-1), masks
+        return labels[is_thing], bboxes[is_thing], masks[is_thing]
 
     def _panoptic_from_scores(self, scores, labels, geom, defer_stuff):
         """shared body of :77-159 (defer_stuff=True) and :161-225 (False)."""
@@ -234,23 +229,26 @@ class MaskFormerFusionHeadOpen(nn.Module):
         """:369-464 -> list (one dict per image) keyed by eval type."""
         eval_types = self.test_cfg.get('eval_types', [])
         rescale = kwargs.get('rescale', False)
-        self._qm_cache = None
         results = []
         for b, meta in enumerate(img_metas):
             mask_cls_result = mask_cls_results[b]
             emb = mask_cls_emb_results[b]
             mp = mask_pred_results[b]
             result = dict()
-            if 'all_results' in eval_types:
-                if self.panoptic_mode:
-                    result['panoptic_all_results'] = self.panoptic_postprocess_emb(
-                        emb, mp, self.all_class_embs, meta, rescale)
-                else:
-                    result['all_results'] = self.instance_postprocess_emb(emb, mp, self.all_class_embs, meta, rescale)
-            if 'novel_results' in eval_types:
-                result['novel_results'] = self.instance_postprocess_emb(emb, mp, self.novel_class_embs, meta, rescale)
-            if 'base_results' in eval_types:
-                result['base_results'] = self.instance_postprocess_emb(emb, mp, self.base_class_embs, meta, rescale)
+            if 'all_results' in eval_types and self.panoptic_mode:
+                result['panoptic_all_results'] = self.panoptic_postprocess_emb(
+                    emb, mp, self.all_class_embs, meta, rescale)
+            # the embedding-based instance types of this image share ONE mask pass (same reference semantics as three
+            # instance_postprocess_emb calls, :385-400)
+            todo = [(key, embs) for key, embs in (('all_results', getattr(self, 'all_class_embs', None)),
+                                                  ('novel_results', getattr(self, 'novel_class_embs', None)),
+                                                  ('base_results', getattr(self, 'base_class_embs', None)))
+                    if key in eval_types and not (key == 'all_results' and self.panoptic_mode)]
+            if todo:
+                geom = self._geom(mp, meta, rescale)
+                picks = [self._topk(self.get_cls_emb_scores(emb, embs)[:, :-1]) for _, embs in todo]
+                for (key, _), r in zip(todo, self._instances_multi(picks, geom)):
+                    result[key] = r
             if 'ins_results' in eval_types:
                 result['ins_results'] = self.instance_postprocess(mask_cls_result, mp, meta, rescale)
             if 'pan_results' in eval_types:

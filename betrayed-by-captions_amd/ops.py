@@ -614,3 +614,37 @@ def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
                                            stream_ptr(q.device))
     check(rc, 'cgg_masked_xattn_forward_bf16')
     return out
+
+
+def instance_masks_multi(logits, index_lists, up_size, crop_size, out_size):
+    """logits (Q,H,W) f32 low-res; index_lists = [query indices (n_t,) long, ...] (one per evaluation type)
+    -> ([masks (n_t,oh,ow) bool ...], mask_score (Q,), bbox (Q,4)). Every picked query's mask is interpolated ONCE and
+    written to all its detections; score / bbox are per QUERY (index them with the query indices)."""
+    Q, H, W = logits.shape
+    oh, ow = int(out_size[0]), int(out_size[1])
+    dev = logits.device
+    sizes = [int(ix.numel()) for ix in index_lists]
+    total = sum(sizes)
+    score = torch.empty((Q,), dtype=torch.float32, device=dev)
+    bbox = torch.empty((Q, 4), dtype=torch.float32, device=dev)
+    masks = torch.empty((total, oh, ow), dtype=torch.uint8, device=dev)
+    if total == 0:
+        return [masks[:0].view(torch.bool) for _ in sizes], score, bbox
+    cat = torch.cat([ix.reshape(-1) for ix in index_lists]) if len(index_lists) > 1 else index_lists[0].reshape(-1)
+    order = torch.argsort(cat, stable=True).to(torch.int32)
+    # (torch.bincount synchronises to size its output -> not capturable in a hipGraph; scatter_add is)
+    counts = torch.zeros((Q,), dtype=torch.int32, device=dev).scatter_add_(
+        0, cat, torch.ones_like(cat, dtype=torch.int32))
+    off = torch.zeros((Q + 1,), dtype=torch.int32, device=dev)
+    off[1:] = torch.cumsum(counts, 0)
+    ws = torch.empty((Q, 8), dtype=torch.int32, device=dev)
+    rc = _lib_().cgg_instance_masks_multi(dev_ptr(logits, 'logits', torch.float32), dev_ptr(off), dev_ptr(order),
+                                          dev_ptr(masks), dev_ptr(score), dev_ptr(bbox), dev_ptr(ws), Q, H, W,
+                                          int(up_size[0]), int(up_size[1]), int(crop_size[0]), int(crop_size[1]), oh,
+                                          ow, stream_ptr(dev))
+    check(rc, 'cgg_instance_masks_multi')
+    out, o = [], 0
+    for n in sizes:
+        out.append(masks[o:o + n].view(torch.bool))
+        o += n
+    return out, score, bbox

@@ -277,6 +277,13 @@ int cgg_upsample_bilinear(const float* x, float* y, int N, int H, int W, int h, 
 int cgg_instance_masks(const float* logits, const int32_t* sel, uint8_t* masks, float* mask_score,
                        float* bbox, void* ws, int Q, int H, int W, int up_h, int up_w, int crop_h,
                        int crop_w, int out_h, int out_w, int n, cgg_stream_t stream);
+/* Multi-destination variant for the three evaluation types of one image (all / novel / base class sets,
+ * maskformer_fusion_head.py:385-400): instance i is QUERY i (no `sel`), its mask is interpolated once and stored to every
+ * slot dest_slot[dest_off[i] .. dest_off[i+1]) of masks [n_slots, out_h, out_w]; queries with no slot are skipped.
+ * mask_score [Q], bbox [Q, 4] are per query (undefined for skipped queries); ws: Q * 32 bytes.                    */
+int cgg_instance_masks_multi(const float* logits, const int32_t* dest_off, const int32_t* dest_slot, uint8_t* masks,
+                             float* mask_score, float* bbox, void* ws, int Q, int H, int W, int up_h, int up_w,
+                             int crop_h, int crop_w, int out_h, int out_w, cgg_stream_t stream);
 int cgg_panoptic_argmax(const float* logits, const int32_t* keep, const float* score, int32_t* ids,
                         uint8_t* win_half, int32_t* counts, int Q, int H, int W, int up_h, int up_w,
                         int crop_h, int crop_w, int out_h, int out_w, int n, cgg_stream_t stream);

@@ -616,3 +616,20 @@ def test_masked_xattn_bf16_vs_f32_kernel(dev, B, Q, S):
     got2 = ops.masked_xattn_bf16(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev), None, H)
     want2 = ops.masked_xattn(q.to(dev), kv, None, H)
     assert (got2 - want2).abs().max().item() <= 0.03 * want2.abs().max().item()
+
+
+@pytest.mark.parametrize('up,crop,out', [((64, 96), (64, 96), (64, 96)), ((64, 96), (60, 90), (60, 90)),
+                                         ((64, 96), (60, 90), (75, 110))])
+def test_instance_masks_multi_equals_per_type_calls(dev, up, crop, out):
+    """one mask pass writing every evaluation type's detection slots == one `instance_masks` call per type."""
+    g = torch.Generator().manual_seed(63)
+    Q, H, W = 23, 16, 24
+    logits = (torch.randn(Q, H, W, generator=g) * 3).to(dev)
+    lists = [torch.randint(0, Q, (n,), generator=g).to(dev) for n in (17, 5, 0, 30)]
+    lists[1][:] = 7                                    # one query picked several times inside a type
+    masks_l, qs, qb = ops.instance_masks_multi(logits, lists, up, crop, out)
+    for ix, m in zip(lists, masks_l):
+        wm, ws_, wb = ops.instance_masks(logits, ix.to(torch.int32), up, crop, out)
+        assert m.shape == wm.shape and torch.equal(m, wm)
+        if ix.numel():
+            assert torch.allclose(qs[ix], ws_, rtol=1e-6, atol=1e-7) and torch.equal(qb[ix], wb)
