@@ -50,6 +50,7 @@ PROTOTYPES = {
     'cgg_group_norm_nhwc': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,
                                        _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_pack_mask_feature_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
+    'cgg_bias_relu_maxpool_nhwc': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_bias_act_nhwc': (_c_int, [_c_vp] * 3 + [_c_i64, _c_int, _c_int, _c_vp]),
     'cgg_group_norm_workspace_bytes': (_c_i64, [_c_int] * 5),
     'cgg_group_norm': (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),

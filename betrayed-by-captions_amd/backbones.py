@@ -208,9 +208,16 @@ class ResNet(nn.Module):
         import torch.nn.functional as F
         seq = iter(self._folded())
         x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last).permute(0, 2, 3, 1)
-        x = self._conv_nhwc(x, self.conv1, next(seq), True)
-        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, stride=2, padding=1)
-        x = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        mp = self.maxpool
+        if (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False):
+            # conv -> (+bias, ReLU, 3x3/s2 max-pool) in one HIP pass over the raw convolution output
+            w4, b, _ = next(seq)
+            y = F.conv2d(x.permute(0, 3, 1, 2), w4, None, stride=self.conv1.stride, padding=self.conv1.padding)
+            y = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+            x = ops.bias_relu_maxpool_nhwc(y, b)
+        else:
+            x = self._conv_nhwc(x, self.conv1, next(seq), True)
+            x = mp(x.permute(0, 3, 1, 2)).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):

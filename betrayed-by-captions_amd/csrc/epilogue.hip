@@ -66,3 +66,67 @@ extern "C" int cgg_bias_act_nhwc(void* y, const void* bias, const void* res, int
   CGG_CHECK_LAUNCH("cgg_bias_act_nhwc");
   return 0;
 }
+
+// Stem tail of the BN-folded ResNet: relu(conv + bias) followed by MaxPool2d(3, stride 2, padding 1) in ONE pass over
+// the channel-last bf16 convolution output. max and (+ bias, ReLU) commute (both are monotone per channel), so the
+// kernel pools the raw convolution output and applies bias + ReLU to the pooled value: the 67-MB stem activation is
+// read once and never rewritten (library sequence: bias/ReLU pass 22 us + max_pool 44 us at configs[1]).
+__global__ __launch_bounds__(256) void cgg_bias_relu_maxpool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ bias,
+                                                                   uint4* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                                   int c8, long long nvec) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // output vector: (b, oy, ox, c8)
+  if (i >= nvec) return;
+  const int c = (int)(i % c8);
+  long long p = i / c8;
+  const int ox = (int)(p % Wo);
+  p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int b = (int)(p / Ho);
+  float m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = -__builtin_inff();
+  const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = y0 + dy;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = x0 + dx;
+      if (ix < 0 || ix >= W) continue;
+      const uint4 v = x[(((size_t)b * H + iy) * W + ix) * c8 + c];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        m[2 * k] = fmaxf(m[2 * k], cgg_bf2f((uint16_t)(w[k] & 0xffffu)));
+        m[2 * k + 1] = fmaxf(m[2 * k + 1], cgg_bf2f((uint16_t)(w[k] >> 16)));
+      }
+    }
+  }
+  const uint4 bv = bias[c];
+  const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // same rounding as the library sequence: bf16(conv + bias), then ReLU
+    const float lo = fmaxf(cgg_bf2f(cgg_f2bf(m[2 * k] + cgg_bf2f((uint16_t)(bw[k] & 0xffffu)))), 0.f);
+    const float hi = fmaxf(cgg_bf2f(cgg_f2bf(m[2 * k + 1] + cgg_bf2f((uint16_t)(bw[k] >> 16)))), 0.f);
+    o[k] = cgg_pack2(cgg_f2bf(lo), cgg_f2bf(hi));
+  }
+  y[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,
+                                          cgg_stream_t stream) {
+  CGG_REQUIRE(x && bias && y, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc: bad sizes");
+  CGG_REQUIRE(C % 8 == 0, CGG_EUNSUPPORTED, "cgg_bias_relu_maxpool_nhwc: C %% 8 != 0 (C=%d)", C);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(bias) && cgg_aligned16(y), CGG_EALIGN,
+              "cgg_bias_relu_maxpool_nhwc: pointers must be 16-byte aligned");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long nvec = (long long)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(cgg_bias_relu_maxpool_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, (const uint4*)bias, (uint4*)y, H, W, Ho, Wo, C / 8, nvec);
+  CGG_CHECK_LAUNCH("cgg_bias_relu_maxpool_nhwc");
+  return 0;
+}

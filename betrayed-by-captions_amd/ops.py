@@ -648,3 +648,14 @@ def instance_masks_multi(logits, index_lists, up_size, crop_size, out_size):
         out.append(masks[o:o + n].view(torch.bool))
         o += n
     return out, score, bbox
+
+
+def bias_relu_maxpool_nhwc(x, bias):
+    """x (B, H, W, C) channel-last bf16 raw convolution output -> relu(maxpool3x3/s2/p1(x) + bias) (B, Ho, Wo, C)."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    rc = _lib_().cgg_bias_relu_maxpool_nhwc(dev_ptr(x, 'x', torch.bfloat16), dev_ptr(bias, 'bias', torch.bfloat16),
+                                            dev_ptr(y), B, H, W, C, stream_ptr(x.device))
+    check(rc, 'cgg_bias_relu_maxpool_nhwc')
+    return y

@@ -237,6 +237,11 @@ int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, 
 int cgg_bias_act_nhwc(void* y, const void* bias, const void* res, int64_t rows, int C, int relu,
                       cgg_stream_t stream);
 
+/* Stem tail of the BN-folded [3P] mmdet ResNet (`maxpool(relu(bn1(conv1(x))))`), channel-last bf16, one pass:
+ *   y[B, Ho, Wo, C] = relu(maxpool3x3/s2/p1(x[B, H, W, C]) + bias[C]),  Ho = (H - 1) / 2 + 1 (same for W).          */
+int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,
+                               cgg_stream_t stream);
+
 /* K9  GroupNorm (+ optional ReLU) of the pixel decoder ConvModules ([3P] MSDeformAttnPixelDecoder,
  * norm_cfg=dict(type='GN', num_groups=32), configs/instance/coco_b48n17.py:40).
  *   x, y [B, C, H, W] f32 NCHW; gamma, beta [C]; ws = cgg_group_norm_workspace_bytes(...) bytes.

@@ -633,3 +633,13 @@ def test_instance_masks_multi_equals_per_type_calls(dev, up, crop, out):
         assert m.shape == wm.shape and torch.equal(m, wm)
         if ix.numel():
             assert torch.allclose(qs[ix], ws_, rtol=1e-6, atol=1e-7) and torch.equal(qb[ix], wb)
+
+
+def test_bias_relu_maxpool_nhwc(dev):
+    g = torch.Generator().manual_seed(64)
+    for (B, H, W, C) in [(2, 18, 22, 64), (1, 7, 9, 8)]:
+        x = torch.randn(B, H, W, C, generator=g).bfloat16()
+        b = torch.randn(C, generator=g).bfloat16()
+        want = torch.nn.functional.max_pool2d((x + b).relu().permute(0, 3, 1, 2).float(), 3, stride=2, padding=1)
+        got = ops.bias_relu_maxpool_nhwc(x.to(dev), b.to(dev))
+        assert torch.equal(got.cpu().float(), want.permute(0, 2, 3, 1))
