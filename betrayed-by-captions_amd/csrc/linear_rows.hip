@@ -237,6 +237,87 @@ extern "C" int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, 
   return CGG_OK;
 }
 
+// Last encoder layer of the inference stream: the query decoder's K / V projections read `memory_l + level_embed_l`
+// (V) and `memory_l + level_embed_l + decoder_pos_l` (K) per level (mask2former_head.py:795-812). Both bf16 operands
+// are produced here, by the LayerNorm that finishes the memory, written LEVEL-MAJOR ([level][batch][hw_l][256]) so each
+// level is one contiguous (B * hw_l, 256) GEMM operand:  m16 = bf16(y + shift[s]),  mp16 = bf16((y + shift[s]) + pos[s]).
+struct LnKvLevels { int n; int start[9]; };
+
+template <typename BT>
+__global__ __launch_bounds__(256) void cgg_add_layernorm256_kv_kernel(
+    const float* __restrict__ a, const BT* __restrict__ b, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ shift, const float* __restrict__ pos, int S, int B,
+    LnKvLevels lv, float* __restrict__ y32, uint16_t* __restrict__ m16, uint16_t* __restrict__ mp16, int rows, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t off = (size_t)row * 256 + lane * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
+  if (b != nullptr) {
+    if (sizeof(BT) == 4) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(b) + off);
+      v += w;
+    } else {
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(b) + off);
+      v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+      v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+    }
+  }
+  float s = (v[0] + v[1]) + (v[2] + v[3]);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / 256.f);
+  f32x4 d = v - mean;
+  float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q * (1.f / 256.f) + eps);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + lane * 4);
+  f32x4 y = d * rstd * g + be;
+  if (y32) *reinterpret_cast<f32x4*>(y32 + off) = y;
+  const int bi = row / S, si = row - bi * S;
+  int l = 0;
+  while (l + 1 < lv.n && si >= lv.start[l + 1]) ++l;
+  const int hw = lv.start[l + 1] - lv.start[l];
+  const size_t orow = (size_t)B * lv.start[l] + (size_t)bi * hw + (si - lv.start[l]);
+  const size_t ooff = orow * 256 + lane * 4;
+  const f32x4 m = y + *reinterpret_cast<const f32x4*>(shift + (size_t)si * 256 + lane * 4);
+  *reinterpret_cast<uint2*>(m16 + ooff) =
+      make_uint2(cgg_pack2(cgg_f2bf(m[0]), cgg_f2bf(m[1])), cgg_pack2(cgg_f2bf(m[2]), cgg_f2bf(m[3])));
+  const f32x4 z = m + *reinterpret_cast<const f32x4*>(pos + (size_t)si * 256 + lane * 4);
+  *reinterpret_cast<uint2*>(mp16 + ooff) =
+      make_uint2(cgg_pack2(cgg_f2bf(z[0]), cgg_f2bf(z[1])), cgg_pack2(cgg_f2bf(z[2]), cgg_f2bf(z[3])));
+}
+
+extern "C" int cgg_add_layernorm_kv(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+                                    const float* shift, const float* pos, int S, const int* level_start_host,
+                                    int n_levels, float* y32, void* m16, void* mp16, int rows, int N, float eps,
+                                    cgg_stream_t stream) {
+  CGG_REQUIRE(a && gamma && beta && shift && pos && m16 && mp16 && level_start_host, CGG_EINVAL,
+              "cgg_add_layernorm_kv: null pointer");
+  CGG_REQUIRE(rows > 0 && S > 0 && rows % S == 0, CGG_EINVAL, "cgg_add_layernorm_kv: rows=%d not a multiple of S=%d", rows, S);
+  CGG_REQUIRE(N == 256, CGG_EUNSUPPORTED, "cgg_add_layernorm_kv: N=%d (only 256 is built)", N);
+  CGG_REQUIRE(n_levels >= 1 && n_levels <= 8, CGG_EUNSUPPORTED, "cgg_add_layernorm_kv: n_levels=%d (1..8)", n_levels);
+  CGG_REQUIRE(b_dtype == CGG_F32 || b_dtype == CGG_BF16, CGG_EUNSUPPORTED, "cgg_add_layernorm_kv: b dtype %d", b_dtype);
+  LnKvLevels lv;
+  lv.n = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    lv.start[l] = level_start_host[l];
+    CGG_REQUIRE(lv.start[l] >= 0 && lv.start[l] < S && (l == 0 ? lv.start[l] == 0 : lv.start[l] > lv.start[l - 1]),
+                CGG_EINVAL, "cgg_add_layernorm_kv: level_start must start at 0 and increase (level %d: %d)", l, lv.start[l]);
+  }
+  lv.start[n_levels] = S;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4);
+  if (b_dtype == CGG_F32)
+    hipLaunchKernelGGL(cgg_add_layernorm256_kv_kernel<float>, grid, dim3(256), 0, s, a, (const float*)b, gamma, beta,
+                       shift, pos, S, rows / S, lv, y32, (uint16_t*)m16, (uint16_t*)mp16, rows, eps);
+  else
+    hipLaunchKernelGGL(cgg_add_layernorm256_kv_kernel<uint16_t>, grid, dim3(256), 0, s, a, (const uint16_t*)b, gamma,
+                       beta, shift, pos, S, rows / S, lv, y32, (uint16_t*)m16, (uint16_t*)mp16, rows, eps);
+  CGG_CHECK_LAUNCH("cgg_add_layernorm_kv");
+  return CGG_OK;
+}
+
 extern "C" int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta,
                                  float* y, int rows, int N, float eps, cgg_stream_t stream) {
   CGG_REQUIRE(a && gamma && beta && y, CGG_EINVAL, "cgg_add_layernorm: null pointer");

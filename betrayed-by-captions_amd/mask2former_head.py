@@ -418,6 +418,26 @@ class Mask2FormerHeadOpen(nn.Module):
         enc = encoded if encoded is not None else self._encode(feats)
         return self._decode(enc, len(img_metas), all_masks)
 
+    def _kv_bf16_ok(self):
+        """Throughput-mode decode (bf16 K / V, `forward_stream` layers) is available."""
+        layers = self.transformer_decoder.layers
+        return (runtime.is_bf16() and not torch.is_grad_enabled() and self.transformer_decoder.post_norm is not None
+                and all(l.stream_ready() for l in layers) and self.query_embed.weight.shape[1] % 32 == 0)
+
+    def _kv_tables(self, level_hw, dev):
+        """(shift, pos) (N, C) f32 for `cgg_add_layernorm_kv`: level_embed_l broadcast over level l's rows and the
+        decoder's sine encoding of every level (:795-812); rebuilt when level_embed changes."""
+        w = self.level_embed.weight
+        key = (tuple(level_hw), str(dev), w._version, w.data_ptr())
+        hit = self.__dict__.get('_kv_table_cache')
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                shift = torch.cat([w[i].view(1, -1).expand(h * wd, -1) for i, (h, wd) in enumerate(level_hw)], 0)
+                pos = torch.cat([self.decoder_positional_encoding.flat_unpadded(h, wd, dev) for h, wd in level_hw], 0)
+                hit = (key, shift.float().contiguous(), pos.float().contiguous())
+            self.__dict__['_kv_table_cache'] = hit
+        return hit[1], hit[2]
+
     def _encode(self, feats):
         """The query-INDEPENDENT half of mask2former_head.py:763-849: pixel decoder, per-level memories, the packed
         mask feature (full + pooled images) and the K / V projections of all decoder layers. Everything here is
@@ -430,13 +450,23 @@ class Mask2FormerHeadOpen(nn.Module):
         mems, poss, sizes, pooled = [], [], [], []
         if stream:
             # throughput-mode inference: channel-last bf16 all the way, mask_feature only ever exists packed
-            mf, memorys, level_hw = pd.forward_stream(feats)
+            layers = self.transformer_decoder.layers
+            lv = [(int(f.shape[2]), int(f.shape[3])) for f in list(feats)[::-1][:L]]
+            kv_fused = (self._kv_bf16_ok() and pd.num_encoder_levels == L and len(feats) == pd.num_input_levels
+                        and all(h * w % 4 == 0 and h * w >= 8 for h, w in lv)
+                        and all(l.attentions[0].embed_dims // l.attentions[0].num_heads == 32 for l in layers))
+            kv16 = None
+            if kv_fused:
+                mf, memorys, level_hw, kv16 = pd.forward_stream(feats, kv_tables=self._kv_tables)
+            else:
+                mf, memorys, level_hw = pd.forward_stream(feats)
             mask_features = None
             H4, W4 = int(mf.shape[1]), int(mf.shape[2])
             for i in range(L):
                 sizes.append(level_hw[i])
-                mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
-                poss.append(self.decoder_positional_encoding.flat_unpadded(level_hw[i][0], level_hw[i][1], mf.device))
+                if kv16 is None:
+                    mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
+                    poss.append(self.decoder_positional_encoding.flat_unpadded(level_hw[i][0], level_hw[i][1], mf.device))
             packed_full = ops.pack_mask_feature_nhwc(mf, 1)
             for (h, w) in sizes:
                 s = H4 // h
@@ -461,10 +491,11 @@ class Mask2FormerHeadOpen(nn.Module):
                 ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
                 pooled.append(ops.pack_mask_feature(feat_d, s, split) if ok else None)
         layers = self.transformer_decoder.layers
-        if (runtime.is_bf16() and not torch.is_grad_enabled() and packed_full.lo is None
-                and self.transformer_decoder.post_norm is not None and all(l.stream_ready() for l in layers)
-                and self.query_embed.weight.shape[1] % 32 == 0):
-            if all(h * w % 4 == 0 and h * w >= 8 for h, w in sizes) and \
+        if self._kv_bf16_ok() and packed_full.lo is None:
+            if stream and kv16 is not None:
+                kvs = [layers[i].attentions[0].project_kv_bf16(kv16[i % L][0], kv16[i % L][1])
+                       for i in range(self.num_transformer_decoder_layers)]
+            elif all(h * w % 4 == 0 and h * w >= 8 for h, w in sizes) and \
                     all(l.attentions[0].embed_dims // l.attentions[0].num_heads == 32 for l in layers):
                 m16 = [m.to(torch.bfloat16) for m in mems]
                 mp16 = [(m + p[None]).to(torch.bfloat16) for m, p in zip(mems, poss)]

@@ -439,6 +439,25 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
     return y32, y16, yp16
 
 
+def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=True):
+    """Last encoder LayerNorm of the inference stream: y = LN(a + b) (a (B, S, 256) f32, b f32|bf16|None) plus the
+    query decoder's K / V operands m16 = bf16(y + shift[s]), mp16 = bf16(y + shift[s] + pos[s]) (shift, pos (S, 256)
+    f32), both LEVEL-MAJOR: (B * S, 256) with level l = rows [B * start_l, B * start_{l+1}) laid out (B, hw_l, 256).
+    Returns (y f32 | None, m16, mp16)."""
+    B, S, N = a.shape
+    y32 = torch.empty_like(a) if want_f32 else None
+    m16 = torch.empty((B * S, N), dtype=torch.bfloat16, device=a.device)
+    mp16 = torch.empty((B * S, N), dtype=torch.bfloat16, device=a.device)
+    bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
+    rc = _lib_().cgg_add_layernorm_kv(
+        dev_ptr(a, 'a', torch.float32), dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32),
+        dev_ptr(beta, 'beta', torch.float32), dev_ptr(shift, 'shift', torch.float32), dev_ptr(pos, 'pos', torch.float32),
+        S, _int_array(level_start), len(level_start), dev_ptr(y32), dev_ptr(m16), dev_ptr(mp16), B * S, N, float(eps),
+        stream_ptr(a.device))
+    check(rc, 'cgg_add_layernorm_kv')
+    return y32, m16, mp16
+
+
 def bias_act_nhwc_(y, bias=None, res=None, relu=True):
     """In place on a channel-last bf16 activation `y` (..., C): y <- act(y + bias[C] + res)."""
     C = y.shape[-1]

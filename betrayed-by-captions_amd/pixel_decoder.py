@@ -509,7 +509,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 and isinstance(layer.attentions[0], MultiScaleDeformableAttention)
                 and layer.attentions[0].dropout.p == 0)
 
-    def _encoder_stream_bf16(self, src, pos, ref, level_hw, level_start, x16=None, xp16=None):
+    def _encoder_stream_bf16(self, src, pos, ref, level_hw, level_start, x16=None, xp16=None, kv_tables=None):
         """Throughput-mode encoder: per layer 4 library GEMMs (bf16 in / bf16 out), the MSDeformAttn kernel
         (bf16 values, offsets, output), one in-place ReLU and TWO fused residual-LayerNorm passes that also emit the
         bf16 copies (`y`, `y + pos`) the next GEMMs read -- 9 launches per layer instead of ~25, and no separate
@@ -541,9 +541,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                           cc(ffn.layers[0][0].weight).t()).view(B, N, -1)
             f16 = F.linear(h16, cc(ffn.layers[1].weight), cc(ffn.layers[1].bias))
             last = li == n_layers - 1
+            if last and kv_tables is not None:
+                # the memory's last LayerNorm also emits the query decoder's bf16 K / V operands (level-major)
+                src, m16, mp16 = ops.add_layernorm_kv(src, f16, n1.weight, n1.bias, n1.eps, kv_tables[0], kv_tables[1],
+                                                      level_start)
+                return src, (m16, mp16)
             src, x16, xp16 = ops.add_layernorm_stream(src, f16, n1.weight, n1.bias, n1.eps, pos=pos,
                                                       want_bf16=not last, want_pos=not last)
-        return src
+        return src if kv_tables is None else (src, None)
 
     # ---- throughput-mode inference stream: channel-last bf16 from the backbone to the packed mask feature ----
     def _pos_cached(self, level_hw, dev):
@@ -584,8 +589,11 @@ class MSDeformAttnPixelDecoder(nn.Module):
             return torch.addmm(runtime.cast_cached(conv.bias), x2, w.t())
         return torch.mm(x2, w.t())
 
-    def forward_stream(self, feats):
+    def forward_stream(self, feats, kv_tables=None):
         """-> (mask_feature (B, H4, W4, C) bf16 channel-last, [memories (B, hw_l, C) f32 low->high res], level sizes).
+        `kv_tables(level_hw, device) -> (shift, pos)` ((N, C) f32 each): when given, a 4th value is returned, the
+        per-level bf16 pairs (memory_l + shift_l, memory_l + shift_l + pos_l), each (B, hw_l, C) contiguous, written by
+        the last encoder LayerNorm (`cgg_add_layernorm_kv`) instead of by 12 add / cast passes afterwards.
         1x1 convolutions are GEMMs on the (B*H*W, C) views, every GroupNorm is the channel-last HIP kernel, the three
         encoder inputs are normalised straight INTO the (B, N, C) residual stream (plus the bf16 `x`, `x + pos` copies
         the first layer's GEMMs read), the FPN `cur + up-sample(out)` is the GroupNorm's epilogue, and only the 3x3
@@ -616,7 +624,15 @@ class MSDeformAttnPixelDecoder(nn.Module):
             off = level_start[i] * C
             ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, out32=(src, off, N * C),
                                 out16=(x16, off, N * C), pos=(pos, off), outp16=(xp16, off, N * C))
-        src = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start, x16, xp16)
+        kv16 = None
+        if kv_tables is not None:
+            src, kv = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start, x16, xp16,
+                                                kv_tables(level_hw, dev))
+            if kv is not None:
+                kv16 = [(kv[0][B * s0:B * (s0 + h * w)].view(B, h * w, C), kv[1][B * s0:B * (s0 + h * w)].view(B, h * w, C))
+                        for s0, (h, w) in zip(level_start, level_hw)]
+        else:
+            src = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start, x16, xp16)
         mems = [src[:, s0:s0 + h * w, :] for s0, (h, w) in zip(level_start, level_hw)]
         # FPN: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN + ReLU
         f = feats[0]
@@ -638,6 +654,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
         gn = getattr(outc, outc.norm_name)
         ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, relu=True, out16=(z, 0, H4 * W4 * C))
         mf = self._gemm1x1(z.view(B * H4 * W4, C), self.mask_feature).view(B, H4, W4, -1)
+        if kv_tables is not None:
+            return mf, mems, level_hw, kv16
         return mf, mems, level_hw
 
     def forward(self, feats):

@@ -213,6 +213,15 @@ int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float
                          const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
                          float eps, cgg_stream_t stream);
 
+/* Last encoder layer of the stream: y = LN(a + b) as above (y32 nullable) plus the two bf16 operands of the query
+ * decoder's K / V projections (mask2former_head.py:795-812), written LEVEL-MAJOR -- [level][batch][hw_l][256], level l =
+ * rows level_start[l] .. level_start[l+1] of each batch's S rows -- so that every level is one contiguous GEMM operand:
+ *   m16 = bf16(y + shift[s]),  mp16 = bf16((y + shift[s]) + pos[s]),  s = row % S;  shift, pos: [S, 256] f32.
+ * level_start_host: n_levels ints on the HOST (start[0] == 0, increasing, < S).                                   */
+int cgg_add_layernorm_kv(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+                         const float* shift, const float* pos, int S, const int* level_start_host, int n_levels,
+                         float* y32, void* m16, void* mp16, int rows, int N, float eps, cgg_stream_t stream);
+
 /* Throughput-mode (bf16, channel-last) variants used by the pixel decoder's inference stream.
  * cgg_group_norm_nhwc: GroupNorm over x [B, HW, C] bf16 with C / groups == 8 ([3P] MSDeformAttnPixelDecoder
  *   input_convs / lateral_convs / output_convs, norm_cfg GN-32), y = (x - mean) * rstd * gamma + beta

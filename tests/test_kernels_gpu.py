@@ -643,3 +643,29 @@ def test_bias_relu_maxpool_nhwc(dev):
         want = torch.nn.functional.max_pool2d((x + b).relu().permute(0, 3, 1, 2).float(), 3, stride=2, padding=1)
         got = ops.bias_relu_maxpool_nhwc(x.to(dev), b.to(dev))
         assert torch.equal(got.cpu().float(), want.permute(0, 2, 3, 1))
+
+
+def test_add_layernorm_kv_level_major(dev):
+    g = torch.Generator().manual_seed(65)
+    B, C = 2, 256
+    level_hw = [(2, 4), (4, 4), (8, 6)]
+    starts, S = [], 0
+    for h, w in level_hw:
+        starts.append(S)
+        S += h * w
+    a = torch.randn(B, S, C, generator=g)
+    b = torch.randn(B, S, C, generator=g).bfloat16()
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    shift, pos = torch.randn(S, C, generator=g), torch.randn(S, C, generator=g)
+    y = torch.nn.functional.layer_norm(a + b.float(), (C,), gamma, beta, 1e-5)
+    y32, m16, mp16 = ops.add_layernorm_kv(a.to(dev), b.to(dev), gamma.to(dev), beta.to(dev), 1e-5, shift.to(dev),
+                                          pos.to(dev), starts)
+    assert torch.allclose(y32.cpu(), y, atol=2e-5, rtol=1e-5)
+    y = y32.cpu()
+    for l, (h, w) in enumerate(level_hw):
+        s0, n = starts[l], h * w
+        got_m = m16[B * s0:B * (s0 + n)].view(B, n, C).cpu()
+        got_p = mp16[B * s0:B * (s0 + n)].view(B, n, C).cpu()
+        m = y[:, s0:s0 + n] + shift[s0:s0 + n]
+        assert torch.equal(got_m, m.bfloat16())
+        assert torch.equal(got_p, (m + pos[s0:s0 + n]).bfloat16())
