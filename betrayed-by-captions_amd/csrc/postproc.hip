@@ -437,6 +437,28 @@ extern "C" int cgg_instance_masks_multi(const float* logits, const int32_t* dest
                                crop_h, crop_w, out_h, out_w, Q, stream);
 }
 
+// the mask pass itself (between the workspace init and the per-instance finalisation)
+static void instance_masks_dispatch(const float* logits, const int32_t* sel, const int32_t* dest_off,
+                                    const int32_t* dest_slot, uint8_t* masks, int32_t* ws, const ResizeGeom& g, int H, int W,
+                                    int up_h, int up_w, int out_h, int out_w, int n, hipStream_t s) {
+  const long long npix = (long long)out_h * out_w;
+  const long long per_block = 256LL * IM_PPT;
+  const dim3 grid((unsigned)((npix + per_block - 1) / per_block), n);
+  const int S = up_h / H;
+  const bool int_path = !g.two_stage && S * H == up_h && S * W == up_w && (out_w % IM_PPT) == 0 &&
+                        (((uintptr_t)masks) & 15) == 0;
+  const long long ntile = (long long)((out_h + S - 1) / S) * (out_w / IM_PPT);   // one thread per 16 x S block
+  const dim3 tgrid((unsigned)((ntile + 255) / 256), n);
+  if (int_path && S == 4)
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+  else if (int_path && S == 2)
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+  else if (int_path && S == 8)
+    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+  else
+    hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+}
+
 static int instance_masks_launch(const float* logits, const int32_t* sel, const int32_t* dest_off,
                                  const int32_t* dest_slot, uint8_t* masks, float* mask_score, float* bbox, void* ws,
                                  int Q, int H, int W, int up_h, int up_w, int crop_h, int crop_w, int out_h, int out_w,
@@ -450,25 +472,243 @@ static int instance_masks_launch(const float* logits, const int32_t* sel, const 
   hipStream_t s = (hipStream_t)stream;
   const ResizeGeom g = make_geom(H, W, up_h, up_w, crop_h, crop_w, out_h, out_w);
   hipLaunchKernelGGL(cgg_instance_init_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (int32_t*)ws, n);
-  const long long npix = (long long)out_h * out_w;
-  const long long per_block = 256LL * IM_PPT;
-  const dim3 grid((unsigned)((npix + per_block - 1) / per_block), n);
-  const int S = up_h / H;
-  const bool int_path = !g.two_stage && S * H == up_h && S * W == up_w && (out_w % IM_PPT) == 0 &&
-                        (((uintptr_t)masks) & 15) == 0;
-  const long long ntile = (long long)((out_h + S - 1) / S) * (out_w / IM_PPT);   // one thread per 16 x S block
-  const dim3 tgrid((unsigned)((ntile + 255) / 256), n);
-  if (int_path && S == 4)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
-  else if (int_path && S == 2)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
-  else if (int_path && S == 8)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, tgrid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
-  else
-    hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, (int32_t*)ws, g, dest_off, dest_slot);
+  instance_masks_dispatch(logits, sel, dest_off, dest_slot, masks, (int32_t*)ws, g, H, W, up_h, up_w, out_h, out_w, n, s);
   hipLaunchKernelGGL(cgg_instance_final_kernel, dim3((n + 63) / 64), dim3(64), 0, s,
                      (const int32_t*)ws, mask_score, bbox, n);
   CGG_CHECK_LAUNCH("cgg_instance_masks");
+  return CGG_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Open-vocabulary instance tail in four launches per image (maskformer_fusion_head.py:317-363 for every evaluation
+// type at once): (query, class) picks straight from the class-embedding dot products, the slot plan of the
+// multi-destination mask pass, the mask pass, and the per-detection boxes / scores.
+
+struct ClsTypes { int n; int col0[8]; int ncols[8]; };
+
+// One workgroup per (evaluation type, image). dots [B*Q, ld]: row q of image b holds emb_q . E_c for the concatenated
+// class tables; type t owns columns col0[t] .. col0[t]+ncols[t], the last of them the background ("void") class.
+//   prob = softmax over the type's columns (same arithmetic, lane order and reductions as cgg_softmax_argmax_kernel),
+//   background column dropped (:340), then the k best of the Q*(ncols-1) (query, class) pairs (:342-347).
+// torch.topk(sorted=False) leaves the order (and the choice among equal scores) unspecified; here both are fixed:
+// descending score, ties by ascending flat index q*(ncols-1)+c. Selection = 4-pass byte radix select on the float bits
+// (probabilities are >= 0, so the unsigned order is the float order) + a bitonic sort of the <= 1024 winners.
+__global__ __launch_bounds__(256) void cgg_class_topk_kernel(const float* __restrict__ dots, int ld, int Q, ClsTypes ty,
+                                                             int k, int kpad, int64_t* __restrict__ labels,
+                                                             float* __restrict__ scores, int64_t* __restrict__ qidx) {
+  extern __shared__ unsigned char smem_raw[];
+  const int t = blockIdx.x, b = blockIdx.y, T = ty.n;
+  const int nc = ty.ncols[t], n = nc - 1, M = Q * n;
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);        // [kpad]
+  uint32_t* prob = reinterpret_cast<uint32_t*>(cand + kpad);                          // [M] float bits
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sel_prefix, sel_remaining, ncand;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- softmax rows (one wavefront per row) ----
+  for (int q = wave; q < Q; q += 4) {
+    const float* xr = dots + ((size_t)b * Q + q) * ld + ty.col0[t];
+    float m = -INFINITY;
+    for (int i = lane; i < nc; i += 64) m = fmaxf(m, xr[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int i = lane; i < nc; i += 64) sum += expf(xr[i] - m);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < n; i += 64) prob[q * n + i] = __float_as_uint(expf(xr[i] - m) * inv);
+  }
+  if (tid == 0) { sel_prefix = 0u; sel_remaining = (uint32_t)k; ncand = 0u; }
+  for (int i = tid; i < kpad; i += 256) cand[i] = 0ull;
+  __syncthreads();
+  // ---- radix select: bits of the k-th largest value, and how many values equal to it belong to the top k ----
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0u;
+    __syncthreads();
+    const uint32_t prefix = sel_prefix;
+    for (int i = tid; i < M; i += 256) {
+      const uint32_t v = prob[i];
+      if (pass == 0 || (v >> (shift + 8)) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t rem = sel_remaining;
+      int bin = 255;
+      for (; bin > 0; --bin) {
+        const uint32_t c = hist[bin];
+        if (c >= rem) break;
+        rem -= c;
+      }
+      sel_prefix = (prefix << 8) | (uint32_t)bin;
+      sel_remaining = rem;
+    }
+    __syncthreads();
+  }
+  const uint32_t thr = sel_prefix, need_eq = sel_remaining;
+  // ---- winners: everything above the threshold, plus the first need_eq values equal to it in flat-index order ----
+  // (ordered: each thread owns a contiguous index range; exclusive scan of the per-thread counts of equal values)
+  const int chunk = (M + 255) / 256;
+  const int i0 = min(tid * chunk, M), i1 = min(i0 + chunk, M);
+  uint32_t my_eq = 0;
+  for (int i = i0; i < i1; ++i) my_eq += prob[i] == thr ? 1u : 0u;
+  hist[tid] = my_eq;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
+  }
+  __syncthreads();
+  uint32_t eq_rank = hist[tid];
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t v = prob[i];
+    bool take = v > thr;
+    if (v == thr) { take = eq_rank < need_eq; ++eq_rank; }
+    if (take) {
+      const uint32_t pos = atomicAdd(&ncand, 1u);
+      if (pos < (uint32_t)kpad) cand[pos] = ((unsigned long long)v << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort, descending on (score bits, ~index) ----
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (kpad >> 1); i += 256) {
+        const int lo = 2 * i - (i & (stride - 1));          // index with bit `stride` clear
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = cand[lo], c = cand[hi];
+        if ((a < c) == desc) { cand[lo] = c; cand[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  const size_t out0 = ((size_t)b * T + t) * k;
+  for (int j = tid; j < k; j += 256) {
+    const unsigned long long key = cand[j];
+    const uint32_t idx = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
+    scores[out0 + j] = __uint_as_float((uint32_t)(key >> 32));
+    labels[out0 + j] = (int64_t)(idx % (uint32_t)n);
+    qidx[out0 + j] = (int64_t)(idx / (uint32_t)n);
+  }
+}
+
+extern "C" int cgg_class_topk(const float* dots, int ld, int B, int Q, int n_types, const int* col0_host,
+                              const int* ncols_host, int k, int64_t* labels, float* scores, int64_t* qidx,
+                              cgg_stream_t stream) {
+  CGG_REQUIRE(dots && col0_host && ncols_host && labels && scores && qidx, CGG_EINVAL, "cgg_class_topk: null pointer");
+  CGG_REQUIRE(B > 0 && Q > 0 && ld > 0 && k > 0, CGG_EINVAL, "cgg_class_topk: bad sizes");
+  CGG_REQUIRE(n_types >= 1 && n_types <= 8, CGG_EUNSUPPORTED, "cgg_class_topk: n_types=%d (1..8)", n_types);
+  CGG_REQUIRE(k <= 1024, CGG_EUNSUPPORTED, "cgg_class_topk: k=%d > 1024", k);
+  ClsTypes ty;
+  ty.n = n_types;
+  int max_m = 0;
+  for (int t = 0; t < n_types; ++t) {
+    ty.col0[t] = col0_host[t];
+    ty.ncols[t] = ncols_host[t];
+    CGG_REQUIRE(ty.ncols[t] >= 2 && ty.col0[t] >= 0 && ty.col0[t] + ty.ncols[t] <= ld, CGG_EINVAL,
+                "cgg_class_topk: type %d columns [%d, +%d) outside ld=%d", t, ty.col0[t], ty.ncols[t], ld);
+    const long long m = (long long)Q * (ty.ncols[t] - 1);
+    CGG_REQUIRE(m >= k, CGG_EINVAL, "cgg_class_topk: type %d has %lld (query, class) pairs < k=%d", t, m, k);
+    CGG_REQUIRE(m <= 14336, CGG_EUNSUPPORTED, "cgg_class_topk: type %d has %lld pairs (> 14336 do not fit LDS)", t, m);
+    max_m = max(max_m, (int)m);
+  }
+  int kpad = 2;
+  while (kpad < k) kpad <<= 1;
+  const size_t lds = (size_t)kpad * 8 + (size_t)max_m * 4;
+  hipLaunchKernelGGL(cgg_class_topk_kernel, dim3(n_types, B), dim3(256), lds, (hipStream_t)stream, dots, ld, Q, ty, k, kpad,
+                     labels, scores, qidx);
+  CGG_CHECK_LAUNCH("cgg_class_topk");
+  return CGG_OK;
+}
+
+// workspace init + slot plan: dest_off[q] .. dest_off[q+1] list (in pick order) the detections that picked query q.
+// ws = [Q*8 stats | Q+1 dest_off | n_picks dest_slot] int32.
+__global__ __launch_bounds__(256) void cgg_instance_plan_kernel(const int64_t* __restrict__ qidx, int n_picks, int Q,
+                                                                int32_t* __restrict__ ws) {
+  extern __shared__ int32_t pq[];                 // [n_picks] query of every pick, then [Q + 1] offsets
+  int32_t* off = pq + n_picks;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Q; i += 256) {
+    int32_t* w = ws + (size_t)i * 8;
+    w[0] = 0; w[1] = 0; w[2] = 0x7fffffff; w[3] = 0x7fffffff; w[4] = -1; w[5] = -1; w[6] = 0; w[7] = 0;
+    off[i] = 0;
+  }
+  for (int j = tid; j < n_picks; j += 256) {
+    const long long q = qidx[j];
+    pq[j] = (q >= 0 && q < Q) ? (int32_t)q : -1;
+  }
+  __syncthreads();
+  for (int j = tid; j < n_picks; j += 256)
+    if (pq[j] >= 0) atomicAdd(&off[pq[j]], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int q = 0; q < Q; ++q) { const int c = off[q]; off[q] = run; run += c; }
+    off[Q] = run;
+  }
+  __syncthreads();
+  int32_t* g_off = ws + (size_t)Q * 8;
+  int32_t* g_slot = g_off + Q + 1;
+  for (int q = tid; q <= Q; q += 256) g_off[q] = off[q];
+  for (int q = tid; q < Q; q += 256) {
+    int w = off[q];
+    const int end = off[q + 1];
+    for (int j = 0; j < n_picks && w < end; ++j)
+      if (pq[j] == q) g_slot[w++] = j;
+  }
+}
+
+// per-query mask score / box (cgg_instance_final_kernel) followed by the per-detection rows (:349-363):
+// bboxes[j] = (box of query qidx[j], cls_score[j] * mask_score[qidx[j]]).
+__global__ __launch_bounds__(256) void cgg_instance_final_picks_kernel(const int32_t* __restrict__ ws,
+                                                                       const int64_t* __restrict__ qidx,
+                                                                       const float* __restrict__ cls_scores, int n_picks,
+                                                                       int Q, float* __restrict__ bboxes) {
+  extern __shared__ float qs[];                    // [Q][5]: x0, y0, x1, y1, mask score
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Q; i += 256) {
+    const int32_t* w = ws + (size_t)i * 8;
+    const float sum = __int_as_float(w[0]);
+    const int cnt = w[1];
+    qs[5 * i + 4] = sum / ((float)cnt + 1e-6f);
+    if (cnt > 0) {
+      qs[5 * i] = (float)w[2]; qs[5 * i + 1] = (float)w[3]; qs[5 * i + 2] = (float)(w[4] + 1); qs[5 * i + 3] = (float)(w[5] + 1);
+    } else {
+      qs[5 * i] = qs[5 * i + 1] = qs[5 * i + 2] = qs[5 * i + 3] = 0.f;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n_picks; j += 256) {
+    const long long q = qidx[j];
+    float* o = bboxes + (size_t)j * 5;
+    if (q < 0 || q >= Q) { o[0] = o[1] = o[2] = o[3] = o[4] = 0.f; continue; }
+    o[0] = qs[5 * q]; o[1] = qs[5 * q + 1]; o[2] = qs[5 * q + 2]; o[3] = qs[5 * q + 3];
+    o[4] = cls_scores[j] * qs[5 * q + 4];
+  }
+}
+
+extern "C" int64_t cgg_instance_masks_picks_workspace_bytes(int Q, int n_picks) {
+  return (int64_t)(((size_t)Q * 8 + (size_t)Q + 1 + (size_t)n_picks) * sizeof(int32_t));
+}
+
+extern "C" int cgg_instance_masks_picks(const float* logits, const int64_t* qidx, const float* cls_scores, int n_picks,
+                                        uint8_t* masks, float* bboxes, void* ws, int Q, int H, int W, int up_h, int up_w,
+                                        int crop_h, int crop_w, int out_h, int out_w, cgg_stream_t stream) {
+  CGG_REQUIRE(logits && qidx && cls_scores && masks && bboxes && ws, CGG_EINVAL, "cgg_instance_masks_picks: null pointer");
+  CGG_REQUIRE(Q > 0 && H > 0 && W > 0 && up_h > 0 && up_w > 0 && out_h > 0 && out_w > 0 && n_picks > 0, CGG_EINVAL,
+              "cgg_instance_masks_picks: bad sizes");
+  CGG_REQUIRE(crop_h > 0 && crop_h <= up_h && crop_w > 0 && crop_w <= up_w, CGG_EINVAL,
+              "cgg_instance_masks_picks: crop %dx%d outside %dx%d", crop_h, crop_w, up_h, up_w);
+  CGG_REQUIRE((size_t)(n_picks + Q + 1) * 4 <= 60000 && (size_t)Q * 20 <= 60000, CGG_EUNSUPPORTED,
+              "cgg_instance_masks_picks: Q=%d, n_picks=%d do not fit LDS", Q, n_picks);
+  hipStream_t s = (hipStream_t)stream;
+  const ResizeGeom g = make_geom(H, W, up_h, up_w, crop_h, crop_w, out_h, out_w);
+  int32_t* wsi = (int32_t*)ws;
+  hipLaunchKernelGGL(cgg_instance_plan_kernel, dim3(1), dim3(256), (size_t)(n_picks + Q + 1) * 4, s, qidx, n_picks, Q, wsi);
+  instance_masks_dispatch(logits, nullptr, wsi + (size_t)Q * 8, wsi + (size_t)Q * 9 + 1, masks, wsi, g, H, W, up_h, up_w,
+                          out_h, out_w, Q, s);
+  hipLaunchKernelGGL(cgg_instance_final_picks_kernel, dim3(1), dim3(256), (size_t)Q * 20, s, (const int32_t*)wsi, qidx,
+                     cls_scores, n_picks, Q, bboxes);
+  CGG_CHECK_LAUNCH("cgg_instance_masks_picks");
   return CGG_OK;
 }
 

@@ -181,10 +181,11 @@ class MaskFormerOpen(nn.Module):
         return results
 
     # ---- two-stage serving split (this build's extension; see pipeline.TwoStagePipeline) ----
-    def stage_encode(self, imgs):
+    def stage_encode(self, imgs, defer_tail=False):
         """backbone + pixel decoder + K/V projections + packed mask feature: the throughput-bound, query-independent
-        part of `simple_test`."""
-        return self.panoptic_head._encode(self.extract_feat(imgs))
+        part of `simple_test`. `defer_tail` leaves the K/V projections and the mask-feature packing to `stage_decode`
+        (stage balancing for the pipeline)."""
+        return self.panoptic_head._encode(self.extract_feat(imgs), defer_tail=defer_tail)
 
     def stage_decode(self, encoded, img_metas, **kwargs):
         """query decoder + mask logits + post-processing on the output of `stage_encode`."""

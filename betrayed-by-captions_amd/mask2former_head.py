@@ -418,6 +418,22 @@ class Mask2FormerHeadOpen(nn.Module):
         enc = encoded if encoded is not None else self._encode(feats)
         return self._decode(enc, len(img_metas), all_masks)
 
+    def _finish_encode(self, enc):
+        """The tail of `_encode` for a deferred stream encoding: packed (full + pooled) mask feature and K / V."""
+        mf, kv16, sizes = enc['mf'], enc['kv16'], enc['sizes']
+        L = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
+        H4, W4 = int(mf.shape[1]), int(mf.shape[2])
+        packed_full = ops.pack_mask_feature_nhwc(mf, 1)
+        pooled = []
+        for (h, w) in sizes:
+            s = H4 // h
+            ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
+            pooled.append(ops.pack_mask_feature_nhwc(mf, s) if ok else None)
+        kvs = [layers[i].attentions[0].project_kv_bf16(kv16[i % L][0], kv16[i % L][1])
+               for i in range(self.num_transformer_decoder_layers)]
+        return dict(stream=True, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled, mask_features=None)
+
     def _kv_bf16_ok(self):
         """Throughput-mode decode (bf16 K / V, `forward_stream` layers) is available."""
         layers = self.transformer_decoder.layers
@@ -438,7 +454,7 @@ class Mask2FormerHeadOpen(nn.Module):
             self.__dict__['_kv_table_cache'] = hit
         return hit[1], hit[2]
 
-    def _encode(self, feats):
+    def _encode(self, feats, defer_tail=False):
         """The query-INDEPENDENT half of mask2former_head.py:763-849: pixel decoder, per-level memories, the packed
         mask feature (full + pooled images) and the K / V projections of all decoder layers. Everything here is
         throughput-bound (GEMMs, convolutions, gathers); `_decode` is the latency-bound query side. Splitting them lets
@@ -462,6 +478,10 @@ class Mask2FormerHeadOpen(nn.Module):
                 mf, memorys, level_hw = pd.forward_stream(feats)
             mask_features = None
             H4, W4 = int(mf.shape[1]), int(mf.shape[2])
+            if kv16 is not None and defer_tail:
+                # pipeline balancing: the packed mask features and the 18 K / V projections (0.25 ms of throughput-type
+                # work) run at the head of the decode stage instead (`_finish_encode`)
+                return dict(stream=True, deferred=True, mf=mf, kv16=kv16, sizes=[level_hw[i] for i in range(L)])
             for i in range(L):
                 sizes.append(level_hw[i])
                 if kv16 is None:
@@ -513,6 +533,8 @@ class Mask2FormerHeadOpen(nn.Module):
 
     def _decode(self, enc, B, all_masks=True):
         """The query side: 1 + 9 `forward_head` calls and the 9 decoder layers on the encoded memories."""
+        if enc.get('deferred'):
+            enc = self._finish_encode(enc)
         kvs, sizes, packed_full, pooled = enc['kvs'], enc['sizes'], enc['packed_full'], enc['pooled']
         mask_features = enc['mask_features']
         L = self.num_transformer_feat_level

@@ -122,6 +122,23 @@ class MaskFormerFusionHeadOpen(nn.Module):
         query_indices = torch.div(top_indices, n_cls, rounding_mode='floor')
         return labels_per_image, scores_per_image, query_indices
 
+    def _batch_picks(self, emb_results, tables):
+        """:297-347 for the whole batch and all evaluation types: ONE GEMM against the concatenated class tables and one
+        `cgg_class_topk` launch -> (labels, class scores, query indices), each (B, T, k); None when the shapes are
+        outside the kernel's limits (the per-type torch path then runs)."""
+        if not (torch.is_tensor(emb_results) and emb_results.dim() == 3 and emb_results.is_cuda):
+            return None
+        B, Q, D = emb_results.shape
+        ncols = [int(e.shape[0]) for e in tables]
+        k = self.test_cfg.get('max_per_image', 100)
+        if not ops.class_topk_supported(Q, ncols, k):
+            return None
+        from . import runtime
+        cat = runtime.derived_cached('fusion_cls_cat', tuple(tables), lambda: torch.cat(list(tables), 0).float().contiguous())
+        dots = torch.matmul(emb_results.reshape(B * Q, D).float(), cat.t())
+        col0 = [sum(ncols[:t]) for t in range(len(ncols))]
+        return ops.class_topk(dots, B, col0, ncols, k)
+
     def _instances_multi(self, picks, geom):
         """:349-363 for SEVERAL evaluation types of one image at once: picks = [(labels, class scores, query indices)];
         binary mask / mask score / bbox depend on the QUERY only, so every picked query's mask is interpolated once
@@ -230,6 +247,11 @@ class MaskFormerFusionHeadOpen(nn.Module):
         eval_types = self.test_cfg.get('eval_types', [])
         rescale = kwargs.get('rescale', False)
         results = []
+        todo = [(key, embs) for key, embs in (('all_results', getattr(self, 'all_class_embs', None)),
+                                              ('novel_results', getattr(self, 'novel_class_embs', None)),
+                                              ('base_results', getattr(self, 'base_class_embs', None)))
+                if key in eval_types and not (key == 'all_results' and self.panoptic_mode)]
+        batch_picks = self._batch_picks(mask_cls_emb_results, [e for _, e in todo]) if todo else None
         for b, meta in enumerate(img_metas):
             mask_cls_result = mask_cls_results[b]
             emb = mask_cls_emb_results[b]
@@ -240,11 +262,15 @@ class MaskFormerFusionHeadOpen(nn.Module):
                     emb, mp, self.all_class_embs, meta, rescale)
             # the embedding-based instance types of this image share ONE mask pass (same reference semantics as three
             # instance_postprocess_emb calls, :385-400)
-            todo = [(key, embs) for key, embs in (('all_results', getattr(self, 'all_class_embs', None)),
-                                                  ('novel_results', getattr(self, 'novel_class_embs', None)),
-                                                  ('base_results', getattr(self, 'base_class_embs', None)))
-                    if key in eval_types and not (key == 'all_results' and self.panoptic_mode)]
-            if todo:
+            if todo and batch_picks is not None:
+                # 4 launches per image: slot plan, one mask pass for all types, per-detection boxes / scores
+                labels, cls_scores, qidx = batch_picks
+                logits, up, crop, out = self._geom(mp, meta, rescale)
+                masks, bboxes = ops.instance_masks_picks(logits, qidx[b].reshape(-1), cls_scores[b].reshape(-1), up, crop, out)
+                k = labels.shape[-1]
+                for t, (key, _) in enumerate(todo):
+                    result[key] = (labels[b, t], bboxes[t * k:(t + 1) * k], masks[t * k:(t + 1) * k])
+            elif todo:
                 geom = self._geom(mp, meta, rescale)
                 picks = [self._topk(self.get_cls_emb_scores(emb, embs)[:, :-1]) for _, embs in todo]
                 for (key, _), r in zip(todo, self._instances_multi(picks, geom)):

@@ -669,6 +669,44 @@ def instance_masks_multi(logits, index_lists, up_size, crop_size, out_size):
     return out, score, bbox
 
 
+def class_topk(dots, B, col0, ncols, k):
+    """dots (B*Q, ld) f32 class-embedding dot products against concatenated class tables; evaluation type t owns columns
+    col0[t] .. col0[t]+ncols[t] (last = background). -> (labels, scores, query indices), each (B, T, k): the k best
+    (query, class) pairs of softmax(dots_t)[:, :-1], descending score (ties: ascending flat index)."""
+    rows, ld = dots.shape
+    Q, T = rows // B, len(col0)
+    dev = dots.device
+    labels = torch.empty((B, T, k), dtype=torch.int64, device=dev)
+    qidx = torch.empty((B, T, k), dtype=torch.int64, device=dev)
+    scores = torch.empty((B, T, k), dtype=torch.float32, device=dev)
+    rc = _lib_().cgg_class_topk(dev_ptr(dots, 'dots', torch.float32), ld, B, Q, T, _int_array(col0), _int_array(ncols),
+                                int(k), dev_ptr(labels), dev_ptr(scores), dev_ptr(qidx), stream_ptr(dev))
+    check(rc, 'cgg_class_topk')
+    return labels, scores, qidx
+
+
+def class_topk_supported(Q, ncols, k):
+    return 0 < k <= 1024 and 1 <= len(ncols) <= 8 and all(n >= 2 and k <= Q * (n - 1) <= 14336 for n in ncols)
+
+
+def instance_masks_picks(logits, qidx, cls_scores, up_size, crop_size, out_size):
+    """logits (Q,H,W) f32 low-res; qidx (n,) long / cls_scores (n,) f32: the picks of ALL evaluation types of one image
+    -> masks (n,oh,ow) bool, bboxes (n,5) f32 = (box of the picked query, class score x mask score)."""
+    Q, H, W = logits.shape
+    oh, ow = int(out_size[0]), int(out_size[1])
+    dev = logits.device
+    n = int(qidx.numel())
+    masks = torch.empty((n, oh, ow), dtype=torch.uint8, device=dev)
+    bboxes = torch.empty((n, 5), dtype=torch.float32, device=dev)
+    ws = torch.empty((int(_lib_().cgg_instance_masks_picks_workspace_bytes(Q, n)) + 3) // 4, dtype=torch.int32, device=dev)
+    rc = _lib_().cgg_instance_masks_picks(dev_ptr(logits, 'logits', torch.float32), dev_ptr(qidx, 'qidx', torch.int64),
+                                          dev_ptr(cls_scores, 'cls_scores', torch.float32), n, dev_ptr(masks),
+                                          dev_ptr(bboxes), dev_ptr(ws), Q, H, W, int(up_size[0]), int(up_size[1]),
+                                          int(crop_size[0]), int(crop_size[1]), oh, ow, stream_ptr(dev))
+    check(rc, 'cgg_instance_masks_picks')
+    return masks.view(torch.bool), bboxes
+
+
 def bias_relu_maxpool_nhwc(x, bias):
     """x (B, H, W, C) channel-last bf16 raw convolution output -> relu(maxpool3x3/s2/p1(x) + bias) (B, Ho, Wo, C)."""
     B, H, W, C = x.shape

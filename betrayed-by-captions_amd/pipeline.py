@@ -100,14 +100,17 @@ class StagePipeline:
             cur.wait_stream(st)
 
 
-def detector_pipeline(model, example, metas, stages=3, **decode_kwargs):
+def detector_pipeline(model, example, metas, stages=3, defer_tail=True, **decode_kwargs):
     """Pipeline of a `MaskFormerOpen` detector: 2 stages = (backbone + head encode | decode + post-processing),
-    3 stages = (backbone | head encode | decode + post-processing)."""
+    3 stages = (backbone | head encode | decode + post-processing). `defer_tail` moves the K / V projections and the
+    mask-feature packing from the encode stage (the longer one) to the head of the decode stage."""
     head = model.panoptic_head
     if stages == 2:
-        fns = [model.stage_encode, lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
+        fns = [lambda x: model.stage_encode(x, defer_tail=defer_tail),
+               lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
     elif stages == 3:
-        fns = [model.extract_feat, head._encode, lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
+        fns = [model.extract_feat, lambda f: head._encode(f, defer_tail=defer_tail),
+               lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
     else:
         raise ValueError('stages must be 2 or 3')
     return StagePipeline(fns, example)

@@ -298,6 +298,26 @@ int cgg_instance_masks(const float* logits, const int32_t* sel, uint8_t* masks, 
 int cgg_instance_masks_multi(const float* logits, const int32_t* dest_off, const int32_t* dest_slot, uint8_t* masks,
                              float* mask_score, float* bbox, void* ws, int Q, int H, int W, int up_h, int up_w,
                              int crop_h, int crop_w, int out_h, int out_w, cgg_stream_t stream);
+
+/* Open-vocabulary (query, class) picks of MaskFormerFusionHeadOpen.instance_postprocess_emb
+ * (open_set/models/maskformer_fusion_head.py:297-347) for all evaluation types and images in one launch.
+ * dots [B*Q, ld] f32 = class-embedding predictions x concatenated class tables; type t owns columns
+ * col0[t] .. col0[t] + ncols[t], the last one being the background class: prob = softmax over the type's columns,
+ * background dropped, then the k best of the Q * (ncols[t] - 1) pairs. Outputs [B, n_types, k]: labels (class),
+ * scores (class probability), qidx (query). topk(sorted=False) leaves order / ties open; here: descending score, ties
+ * by ascending flat index. col0_host / ncols_host: n_types ints on the HOST. Limits: k <= 1024, Q * (ncols-1) in
+ * [k, 14336], n_types <= 8 (CGG_EUNSUPPORTED otherwise).                                                        */
+int cgg_class_topk(const float* dots, int ld, int B, int Q, int n_types, const int* col0_host, const int* ncols_host,
+                   int k, int64_t* labels, float* scores, int64_t* qidx, cgg_stream_t stream);
+
+/* The rest of :349-363 for ONE image and all its picks (all evaluation types concatenated): every picked query's mask
+ * is interpolated once and stored into each detection slot that picked it (as cgg_instance_masks_multi, the slot plan
+ * now built on the device), then bboxes[j] = (box of query qidx[j], cls_scores[j] * mask_score[qidx[j]]).
+ * masks [n_picks, out_h, out_w] u8, bboxes [n_picks, 5] f32, ws: cgg_instance_masks_picks_workspace_bytes(Q, n_picks). */
+int64_t cgg_instance_masks_picks_workspace_bytes(int Q, int n_picks);
+int cgg_instance_masks_picks(const float* logits, const int64_t* qidx, const float* cls_scores, int n_picks,
+                             uint8_t* masks, float* bboxes, void* ws, int Q, int H, int W, int up_h, int up_w,
+                             int crop_h, int crop_w, int out_h, int out_w, cgg_stream_t stream);
 int cgg_panoptic_argmax(const float* logits, const int32_t* keep, const float* score, int32_t* ids,
                         uint8_t* win_half, int32_t* counts, int Q, int H, int W, int up_h, int up_w,
                         int crop_h, int crop_w, int out_h, int out_w, int n, cgg_stream_t stream);

@@ -669,3 +669,37 @@ def test_add_layernorm_kv_level_major(dev):
         m = y[:, s0:s0 + n] + shift[s0:s0 + n]
         assert torch.equal(got_m, m.bfloat16())
         assert torch.equal(got_p, (m + pos[s0:s0 + n]).bfloat16())
+
+
+def test_class_topk_matches_softmax_topk(dev):
+    g = torch.Generator().manual_seed(66)
+    B, Q, k = 2, 100, 100
+    ncols = [66, 18, 50]
+    col0 = [0, 66, 84]
+    dots = (torch.randn(B * Q, sum(ncols), generator=g) * 3).to(dev)
+    dots[5, 3] = dots[7, 3] = dots[9, 70] = 9.0          # some exact ties in the input
+    labels, scores, qidx = ops.class_topk(dots, B, col0, ncols, k)
+    for b in range(B):
+        for t, (c0, nc) in enumerate(zip(col0, ncols)):
+            prob, _, _ = ops.rowwise_softmax_argmax(dots[b * Q:(b + 1) * Q, c0:c0 + nc].contiguous(), want_prob=True)
+            flat = prob[:, :-1].flatten()
+            want_s, want_i = flat.sort(descending=True, stable=True)
+            want_s, want_i = want_s[:k], want_i[:k]
+            assert torch.equal(scores[b, t], want_s)
+            # order: descending score, ties by ascending flat index == stable descending sort
+            assert torch.equal(labels[b, t] + qidx[b, t] * (nc - 1), want_i)
+
+
+def test_instance_masks_picks_matches_multi(dev):
+    g = torch.Generator().manual_seed(67)
+    Q, H, W = 20, 24, 32
+    logits = (torch.randn(Q, H, W, generator=g) * 3).to(dev)
+    picks = [torch.randint(0, Q, (16,), generator=g), torch.randint(0, Q, (16,), generator=g)]
+    cls_scores = torch.rand(32, generator=g).to(dev)
+    qidx = torch.cat(picks).to(dev)
+    up, crop, out = (96, 128), (90, 120), (90, 120)
+    masks, bboxes = ops.instance_masks_picks(logits, qidx, cls_scores, up, crop, out)
+    masks_l, qscores, qboxes = ops.instance_masks_multi(logits, [p.to(dev) for p in picks], up, crop, out)
+    assert torch.equal(masks, torch.cat(masks_l))
+    assert torch.equal(bboxes[:, :4], qboxes[qidx])
+    assert torch.allclose(bboxes[:, 4], cls_scores * qscores[qidx], rtol=2e-6, atol=0)
