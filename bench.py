@@ -175,7 +175,7 @@ def main():
     ap.add_argument('--graph', type=int, default=1,
                     help='1: capture the step once and replay it from a hipGraph (default; the eager step is '
                          'host-bound at ~530 launches); 0: eager launches')
-    ap.add_argument('--defer-tail', type=int, default=1, choices=[0, 1],
+    ap.add_argument('--defer-tail', type=int, default=1, choices=[0, 1, 2],
                     help='pipeline stage balancing: K/V projections + mask-feature packing run in the decode stage')
     ap.add_argument('--pipeline', type=int, default=2, choices=[0, 2, 3],
                     help='(with --graph 1) software pipeline across steps, one HIP stream + hipGraph per stage: '
@@ -228,7 +228,7 @@ def main():
     if args.graph and args.pipeline:
         try:
             from cgg_amd.pipeline import detector_pipeline
-            pipe = detector_pipeline(model, img, metas, stages=args.pipeline, defer_tail=bool(args.defer_tail),
+            pipe = detector_pipeline(model, img, metas, stages=args.pipeline, defer_tail=args.defer_tail,
                                      rescale=True, device_results=True)
             for _ in range(args.pipeline):
                 pipe.submit(img)

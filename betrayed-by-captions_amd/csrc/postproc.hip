@@ -486,108 +486,157 @@ static int instance_masks_launch(const float* logits, const int32_t* sel, const 
 
 struct ClsTypes { int n; int col0[8]; int ncols[8]; };
 
-// One workgroup per (evaluation type, image). dots [B*Q, ld]: row q of image b holds emb_q . E_c for the concatenated
-// class tables; type t owns columns col0[t] .. col0[t]+ncols[t], the last of them the background ("void") class.
+// One workgroup (16 wavefronts) per (evaluation type, image). dots [B*Q, ld]: row q of image b holds emb_q . E_c for
+// the concatenated class tables; type t owns columns col0[t] .. col0[t]+ncols[t], the last of them the background class.
 //   prob = softmax over the type's columns (same arithmetic, lane order and reductions as cgg_softmax_argmax_kernel),
 //   background column dropped (:340), then the k best of the Q*(ncols-1) (query, class) pairs (:342-347).
 // torch.topk(sorted=False) leaves the order (and the choice among equal scores) unspecified; here both are fixed:
 // descending score, ties by ascending flat index q*(ncols-1)+c. Selection = 4-pass byte radix select on the float bits
-// (probabilities are >= 0, so the unsigned order is the float order) + a bitonic sort of the <= 1024 winners.
-__global__ __launch_bounds__(256) void cgg_class_topk_kernel(const float* __restrict__ dots, int ld, int Q, ClsTypes ty,
-                                                             int k, int kpad, int64_t* __restrict__ labels,
-                                                             float* __restrict__ scores, int64_t* __restrict__ qidx) {
+// (probabilities are >= 0, so the unsigned order is the float order); the k winners are ordered by rank counting.
+// Everything that would be a serial single-thread loop over LDS (64+ clocks per dependent access) is a wavefront scan.
+#define CT_WAVES 16
+
+// exclusive prefix sum over n ints in LDS by ONE wavefront (in place); returns the total
+__device__ __forceinline__ uint32_t cgg_wave_excl_scan(uint32_t* a, int n, int lane) {
+  uint32_t carry = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const uint32_t c = i < n ? a[i] : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(inc, o);
+      if (lane >= o) inc += up;
+    }
+    if (i < n) a[i] = carry + inc - c;
+    carry += __shfl(inc, 63);
+  }
+  return carry;
+}
+
+__global__ __launch_bounds__(64 * CT_WAVES) void cgg_class_topk_kernel(const float* __restrict__ dots, int ld, int Q,
+                                                                       ClsTypes ty, int k, int64_t* __restrict__ labels,
+                                                                       float* __restrict__ scores,
+                                                                       int64_t* __restrict__ qidx) {
   extern __shared__ unsigned char smem_raw[];
   const int t = blockIdx.x, b = blockIdx.y, T = ty.n;
   const int nc = ty.ncols[t], n = nc - 1, M = Q * n;
-  unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);        // [kpad]
-  uint32_t* prob = reinterpret_cast<uint32_t*>(cand + kpad);                          // [M] float bits
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);        // [k]
+  uint32_t* prob = reinterpret_cast<uint32_t*>(cand + k);                             // [M] float bits, row-major (q, c)
+  uint32_t* rowcnt = prob + M;                                                        // [Q]
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sel_prefix, sel_remaining, ncand;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- softmax rows (one wavefront per row) ----
-  for (int q = wave; q < Q; q += 4) {
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // ---- softmax rows (one wavefront per row; up to 256 columns live in registers) ----
+  for (int q = wave; q < Q; q += CT_WAVES) {
     const float* xr = dots + ((size_t)b * Q + q) * ld + ty.col0[t];
-    float m = -INFINITY;
-    for (int i = lane; i < nc; i += 64) m = fmaxf(m, xr[i]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    float sum = 0.f;
-    for (int i = lane; i < nc; i += 64) sum += expf(xr[i] - m);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float inv = 1.f / sum;
-    for (int i = lane; i < n; i += 64) prob[q * n + i] = __float_as_uint(expf(xr[i] - m) * inv);
+    if (nc <= 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = lane + 64 * u < nc ? xr[lane + 64 * u] : -INFINITY;
+      float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = expf(v[u] - m);
+        if (lane + 64 * u < nc) sum += v[u];
+      }
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < n) prob[q * n + lane + 64 * u] = __float_as_uint(v[u] * inv);
+    } else {
+      float m = -INFINITY;
+      for (int i = lane; i < nc; i += 64) m = fmaxf(m, xr[i]);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+      for (int i = lane; i < nc; i += 64) sum += expf(xr[i] - m);
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float inv = 1.f / sum;
+      for (int i = lane; i < n; i += 64) prob[q * n + i] = __float_as_uint(expf(xr[i] - m) * inv);
+    }
   }
   if (tid == 0) { sel_prefix = 0u; sel_remaining = (uint32_t)k; ncand = 0u; }
-  for (int i = tid; i < kpad; i += 256) cand[i] = 0ull;
   __syncthreads();
   // ---- radix select: bits of the k-th largest value, and how many values equal to it belong to the top k ----
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    hist[tid] = 0u;
+    if (tid < 256) hist[tid] = 0u;
     __syncthreads();
     const uint32_t prefix = sel_prefix;
-    for (int i = tid; i < M; i += 256) {
+    for (int i = tid; i < M; i += 64 * CT_WAVES) {
       const uint32_t v = prob[i];
       if (pass == 0 || (v >> (shift + 8)) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t rem = sel_remaining;
-      int bin = 255;
-      for (; bin > 0; --bin) {
-        const uint32_t c = hist[bin];
-        if (c >= rem) break;
-        rem -= c;
+    if (wave == 0) {
+      // lane owns bins 4*lane .. 4*lane+3; `above` = count in all higher bins
+      const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const uint32_t mine = c0 + c1 + c2 + c3;
+      uint32_t suf = mine;                                       // inclusive suffix sum over lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t dn = __shfl_down(suf, o);
+        if (lane + o < 64) suf += dn;
       }
-      sel_prefix = (prefix << 8) | (uint32_t)bin;
-      sel_remaining = rem;
+      const uint32_t above = suf - mine, rem = sel_remaining;
+      if (above < rem && rem <= suf) {                            // exactly one lane
+        uint32_t r = rem - above;
+        int bin;
+        if (c3 >= r) bin = 3;
+        else if (c3 + c2 >= r) { bin = 2; r -= c3; }
+        else if (c3 + c2 + c1 >= r) { bin = 1; r -= c3 + c2; }
+        else { bin = 0; r -= c3 + c2 + c1; }
+        sel_prefix = (prefix << 8) | (uint32_t)(4 * lane + bin);
+        sel_remaining = r;
+      }
     }
     __syncthreads();
   }
   const uint32_t thr = sel_prefix, need_eq = sel_remaining;
   // ---- winners: everything above the threshold, plus the first need_eq values equal to it in flat-index order ----
-  // (ordered: each thread owns a contiguous index range; exclusive scan of the per-thread counts of equal values)
-  const int chunk = (M + 255) / 256;
-  const int i0 = min(tid * chunk, M), i1 = min(i0 + chunk, M);
-  uint32_t my_eq = 0;
-  for (int i = i0; i < i1; ++i) my_eq += prob[i] == thr ? 1u : 0u;
-  hist[tid] = my_eq;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 256; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
-  }
-  __syncthreads();
-  uint32_t eq_rank = hist[tid];
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t v = prob[i];
-    bool take = v > thr;
-    if (v == thr) { take = eq_rank < need_eq; ++eq_rank; }
-    if (take) {
-      const uint32_t pos = atomicAdd(&ncand, 1u);
-      if (pos < (uint32_t)kpad) cand[pos] = ((unsigned long long)v << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+  for (int q = wave; q < Q; q += CT_WAVES) {
+    uint32_t c = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const bool eq = i0 + lane < n && prob[q * n + i0 + lane] == thr;
+      c += (uint32_t)__popcll(__ballot(eq));
     }
+    if (lane == 0) rowcnt[q] = c;
   }
   __syncthreads();
-  // ---- bitonic sort, descending on (score bits, ~index) ----
-  for (int size = 2; size <= kpad; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < (kpad >> 1); i += 256) {
-        const int lo = 2 * i - (i & (stride - 1));          // index with bit `stride` clear
-        const int hi = lo + stride;
-        const bool desc = (lo & size) == 0;
-        const unsigned long long a = cand[lo], c = cand[hi];
-        if ((a < c) == desc) { cand[lo] = c; cand[hi] = a; }
+  if (wave == 0) cgg_wave_excl_scan(rowcnt, Q, lane);
+  __syncthreads();
+  for (int q = wave; q < Q; q += CT_WAVES) {
+    uint32_t base = rowcnt[q];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int c = i0 + lane;
+      const uint32_t v = c < n ? prob[q * n + c] : 0u;
+      const bool eq = c < n && v == thr;
+      const unsigned long long mask = __ballot(eq);
+      const uint32_t rank = base + (uint32_t)__popcll(mask & lt_mask);
+      if (c < n && (v > thr || (eq && rank < need_eq))) {
+        const uint32_t pos = atomicAdd(&ncand, 1u);
+        if (pos < (uint32_t)k)
+          cand[pos] = ((unsigned long long)v << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(q * n + c));
       }
-      __syncthreads();
+      base += (uint32_t)__popcll(mask);
     }
   }
+  __syncthreads();
+  // ---- order: rank of a winner = number of winners with a larger (score bits, ~index) key (keys are unique) ----
   const size_t out0 = ((size_t)b * T + t) * k;
-  for (int j = tid; j < k; j += 256) {
+  for (int j = tid; j < k; j += 64 * CT_WAVES) {
     const unsigned long long key = cand[j];
+    int rank = 0;
+#pragma unroll 8
+    for (int i = 0; i < k; ++i) rank += cand[i] > key ? 1 : 0;
     const uint32_t idx = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
-    scores[out0 + j] = __uint_as_float((uint32_t)(key >> 32));
-    labels[out0 + j] = (int64_t)(idx % (uint32_t)n);
-    qidx[out0 + j] = (int64_t)(idx / (uint32_t)n);
+    scores[out0 + rank] = __uint_as_float((uint32_t)(key >> 32));
+    labels[out0 + rank] = (int64_t)(idx % (uint32_t)n);
+    qidx[out0 + rank] = (int64_t)(idx / (uint32_t)n);
   }
 }
 
@@ -608,14 +657,14 @@ extern "C" int cgg_class_topk(const float* dots, int ld, int B, int Q, int n_typ
                 "cgg_class_topk: type %d columns [%d, +%d) outside ld=%d", t, ty.col0[t], ty.ncols[t], ld);
     const long long m = (long long)Q * (ty.ncols[t] - 1);
     CGG_REQUIRE(m >= k, CGG_EINVAL, "cgg_class_topk: type %d has %lld (query, class) pairs < k=%d", t, m, k);
-    CGG_REQUIRE(m <= 14336, CGG_EUNSUPPORTED, "cgg_class_topk: type %d has %lld pairs (> 14336 do not fit LDS)", t, m);
-    max_m = max(max_m, (int)m);
+    CGG_REQUIRE(m <= (1 << 20), CGG_EUNSUPPORTED, "cgg_class_topk: type %d has %lld pairs", t, m);
+    if ((int)m > max_m) max_m = (int)m;
   }
-  int kpad = 2;
-  while (kpad < k) kpad <<= 1;
-  const size_t lds = (size_t)kpad * 8 + (size_t)max_m * 4;
-  hipLaunchKernelGGL(cgg_class_topk_kernel, dim3(n_types, B), dim3(256), lds, (hipStream_t)stream, dots, ld, Q, ty, k, kpad,
-                     labels, scores, qidx);
+  const size_t lds = (size_t)k * 8 + (size_t)max_m * 4 + (size_t)Q * 4;
+  CGG_REQUIRE(lds <= 62 * 1024, CGG_EUNSUPPORTED, "cgg_class_topk: Q=%d x %d classes, k=%d need %zu B of LDS (> 62 KiB)", Q,
+              max_m / Q, k, lds);
+  hipLaunchKernelGGL(cgg_class_topk_kernel, dim3(n_types, B), dim3(64 * CT_WAVES), lds, (hipStream_t)stream, dots, ld, Q,
+                     ty, k, labels, scores, qidx);
   CGG_CHECK_LAUNCH("cgg_class_topk");
   return CGG_OK;
 }
@@ -625,35 +674,36 @@ extern "C" int cgg_class_topk(const float* dots, int ld, int B, int Q, int n_typ
 __global__ __launch_bounds__(256) void cgg_instance_plan_kernel(const int64_t* __restrict__ qidx, int n_picks, int Q,
                                                                 int32_t* __restrict__ ws) {
   extern __shared__ int32_t pq[];                 // [n_picks] query of every pick, then [Q + 1] offsets
-  int32_t* off = pq + n_picks;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < Q; i += 256) {
-    int32_t* w = ws + (size_t)i * 8;
-    w[0] = 0; w[1] = 0; w[2] = 0x7fffffff; w[3] = 0x7fffffff; w[4] = -1; w[5] = -1; w[6] = 0; w[7] = 0;
-    off[i] = 0;
-  }
+  uint32_t* off = reinterpret_cast<uint32_t*>(pq + n_picks);
+  const int tid = threadIdx.x, lane = tid & 63;
   for (int j = tid; j < n_picks; j += 256) {
     const long long q = qidx[j];
     pq[j] = (q >= 0 && q < Q) ? (int32_t)q : -1;
   }
+  for (int i = tid; i < Q; i += 256) {
+    int32_t* w = ws + (size_t)i * 8;
+    w[0] = 0; w[1] = 0; w[2] = 0x7fffffff; w[3] = 0x7fffffff; w[4] = -1; w[5] = -1; w[6] = 0; w[7] = 0;
+    off[i] = 0u;
+  }
   __syncthreads();
   for (int j = tid; j < n_picks; j += 256)
-    if (pq[j] >= 0) atomicAdd(&off[pq[j]], 1);
+    if (pq[j] >= 0) atomicAdd(&off[pq[j]], 1u);
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int q = 0; q < Q; ++q) { const int c = off[q]; off[q] = run; run += c; }
-    off[Q] = run;
+  if (tid < 64) {
+    const uint32_t total = cgg_wave_excl_scan(off, Q, lane);
+    if (lane == 0) off[Q] = total;
   }
   __syncthreads();
   int32_t* g_off = ws + (size_t)Q * 8;
   int32_t* g_slot = g_off + Q + 1;
-  for (int q = tid; q <= Q; q += 256) g_off[q] = off[q];
-  for (int q = tid; q < Q; q += 256) {
-    int w = off[q];
-    const int end = off[q + 1];
-    for (int j = 0; j < n_picks && w < end; ++j)
-      if (pq[j] == q) g_slot[w++] = j;
+  for (int q = tid; q <= Q; q += 256) g_off[q] = (int32_t)off[q];
+  for (int j = tid; j < n_picks; j += 256) {
+    const int q = pq[j];
+    if (q < 0) continue;
+    int r = 0;                                     // picks of the same query before this one
+#pragma unroll 8
+    for (int i = 0; i < j; ++i) r += pq[i] == q ? 1 : 0;
+    g_slot[off[q] + r] = j;
   }
 }
 

@@ -420,7 +420,8 @@ class Mask2FormerHeadOpen(nn.Module):
 
     def _finish_encode(self, enc):
         """The tail of `_encode` for a deferred stream encoding: packed (full + pooled) mask feature and K / V."""
-        mf, kv16, sizes = enc['mf'], enc['kv16'], enc['sizes']
+        kv16, sizes = enc['kv16'], enc['sizes']
+        mf = enc['mf'] if 'mf' in enc else self.pixel_decoder.stream_fpn(*enc['fpn'])
         L = self.num_transformer_feat_level
         layers = self.transformer_decoder.layers
         H4, W4 = int(mf.shape[1]), int(mf.shape[2])
@@ -473,7 +474,10 @@ class Mask2FormerHeadOpen(nn.Module):
                         and all(l.attentions[0].embed_dims // l.attentions[0].num_heads == 32 for l in layers))
             kv16 = None
             if kv_fused:
-                mf, memorys, level_hw, kv16 = pd.forward_stream(feats, kv_tables=self._kv_tables)
+                mf, memorys, level_hw, kv16 = pd.forward_stream(feats, kv_tables=self._kv_tables,
+                                                                defer_fpn=defer_tail == 2)
+                if defer_tail == 2:
+                    return dict(stream=True, deferred=True, fpn=mf, kv16=kv16, sizes=[level_hw[i] for i in range(L)])
             else:
                 mf, memorys, level_hw = pd.forward_stream(feats)
             mask_features = None

@@ -135,7 +135,10 @@ class MaskFormerFusionHeadOpen(nn.Module):
             return None
         from . import runtime
         cat = runtime.derived_cached('fusion_cls_cat', tuple(tables), lambda: torch.cat(list(tables), 0).float().contiguous())
-        dots = torch.matmul(emb_results.reshape(B * Q, D).float(), cat.t())
+        x = emb_results.reshape(B * Q, D).float()
+        # 200 x 134 x 768: a BLAS library serves this with ONE workgroup (119 us measured); the skinny-linear kernel
+        # (3 bf16 MFMAs on hi/lo operands, f32-class accuracy) spreads it over 10
+        dots = ops.linear_rows(x, cat, split=True) if D % 16 == 0 else torch.matmul(x, cat.t())
         col0 = [sum(ncols[:t]) for t in range(len(ncols))]
         return ops.class_topk(dots, B, col0, ncols, k)
 

@@ -686,7 +686,8 @@ def class_topk(dots, B, col0, ncols, k):
 
 
 def class_topk_supported(Q, ncols, k):
-    return 0 < k <= 1024 and 1 <= len(ncols) <= 8 and all(n >= 2 and k <= Q * (n - 1) <= 14336 for n in ncols)
+    return (0 < k <= 1024 and 1 <= len(ncols) <= 8 and all(n >= 2 and k <= Q * (n - 1) for n in ncols)
+            and 8 * k + 4 * Q * (max(ncols) - 1) + 4 * Q <= 62 * 1024)
 
 
 def instance_masks_picks(logits, qidx, cls_scores, up_size, crop_size, out_size):

@@ -29,13 +29,16 @@ class StagePipeline:
     example  -- an example input batch (shape / dtype / device are frozen into the graphs)
     """
 
-    def __init__(self, stages, example, slots=None, warmup=2):
+    def __init__(self, stages, example, slots=None, warmup=2, priorities=None):
         self.stages = list(stages)
         n = len(self.stages)
         self.slots = slots if slots is not None else max(2, n)
         dev = example.device
         self.dev = dev
-        self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        import os
+        if priorities is None and os.environ.get('CGG_PIPE_PRIO'):
+            priorities = [int(v) for v in os.environ['CGG_PIPE_PRIO'].split(',')]
+        self.streams = [torch.cuda.Stream(dev, priority=(priorities[i] if priorities else 0)) for i in range(n)]
         self.inputs = [torch.empty_like(example) for _ in range(self.slots)]
         self.done = [[torch.cuda.Event() for _ in range(self.slots)] for _ in range(n)]
         self.graphs = [[None] * self.slots for _ in range(n)]

@@ -589,7 +589,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             return torch.addmm(runtime.cast_cached(conv.bias), x2, w.t())
         return torch.mm(x2, w.t())
 
-    def forward_stream(self, feats, kv_tables=None):
+    def forward_stream(self, feats, kv_tables=None, defer_fpn=False):
         """-> (mask_feature (B, H4, W4, C) bf16 channel-last, [memories (B, hw_l, C) f32 low->high res], level sizes).
         `kv_tables(level_hw, device) -> (shift, pos)` ((N, C) f32 each): when given, a 4th value is returned, the
         per-level bf16 pairs (memory_l + shift_l, memory_l + shift_l + pos_l), each (B, hw_l, C) contiguous, written by
@@ -634,15 +634,27 @@ class MSDeformAttnPixelDecoder(nn.Module):
         else:
             src = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start, x16, xp16)
         mems = [src[:, s0:s0 + h * w, :] for s0, (h, w) in zip(level_start, level_hw)]
+        if defer_fpn:        # the caller runs `stream_fpn(*fpn_args)` later (pipeline stage balancing)
+            fpn_args = (feats[0], src, level_hw[-1], level_start[-1], N)
+            return fpn_args, mems, level_hw, kv16
+        mf = self.stream_fpn(feats[0], src, level_hw[-1], level_start[-1], N)
+        if kv_tables is not None:
+            return mf, mems, level_hw, kv16
+        return mf, mems, level_hw
+
+    def stream_fpn(self, f, src, last_hw, last_start, N):
+        """The FPN half of `forward_stream`: stride-4 feature `f` + the finest encoder level of `src` (B, N, C) f32 ->
+        mask_feature (B, H4, W4, C) bf16 channel-last."""
+        B, dev, C = f.shape[0], f.device, 256
+        ws = ops.group_norm_nhwc_workspace(B, int(f.shape[2]) * int(f.shape[3]), 32, dev)
         # FPN: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN + ReLU
-        f = feats[0]
         H4, W4 = int(f.shape[2]), int(f.shape[3])
         lat, outc = self.lateral_convs[0], self.output_convs[0]
         y = self._gemm1x1(f.permute(0, 2, 3, 1).reshape(B * H4 * W4, f.shape[1]), lat.conv).view(B, H4 * W4, C)
         gn = getattr(lat, lat.norm_name)
         z = torch.empty((B, H4, W4, C), dtype=torch.bfloat16, device=dev)
-        hl, wl = level_hw[-1]
-        ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, up=(src, level_start[-1] * C, N * C, hl, wl), W=W4,
+        hl, wl = last_hw
+        ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, up=(src, last_start * C, N * C, hl, wl), W=W4,
                             out16=(z, 0, H4 * W4 * C))
         w3 = runtime.cast_cached(outc.conv.weight)
         if not w3.is_contiguous(memory_format=torch.channels_last):
@@ -653,10 +665,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         y = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(B, H4 * W4, C)
         gn = getattr(outc, outc.norm_name)
         ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, relu=True, out16=(z, 0, H4 * W4 * C))
-        mf = self._gemm1x1(z.view(B * H4 * W4, C), self.mask_feature).view(B, H4, W4, -1)
-        if kv_tables is not None:
-            return mf, mems, level_hw, kv16
-        return mf, mems, level_hw
+        return self._gemm1x1(z.view(B * H4 * W4, C), self.mask_feature).view(B, H4, W4, -1)
 
     def forward(self, feats):
         B = feats[0].shape[0]

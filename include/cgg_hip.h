@@ -305,8 +305,8 @@ int cgg_instance_masks_multi(const float* logits, const int32_t* dest_off, const
  * col0[t] .. col0[t] + ncols[t], the last one being the background class: prob = softmax over the type's columns,
  * background dropped, then the k best of the Q * (ncols[t] - 1) pairs. Outputs [B, n_types, k]: labels (class),
  * scores (class probability), qidx (query). topk(sorted=False) leaves order / ties open; here: descending score, ties
- * by ascending flat index. col0_host / ncols_host: n_types ints on the HOST. Limits: k <= 1024, Q * (ncols-1) in
- * [k, 14336], n_types <= 8 (CGG_EUNSUPPORTED otherwise).                                                        */
+ * by ascending flat index. col0_host / ncols_host: n_types ints on the HOST. Limits: k <= 1024, n_types <= 8,
+ * k <= Q * (ncols-1), 8k + 4Q * max(ncols-1) + 4Q <= 62 KiB of LDS (CGG_EUNSUPPORTED otherwise).                 */
 int cgg_class_topk(const float* dots, int ld, int B, int Q, int n_types, const int* col0_host, const int* ncols_host,
                    int k, int64_t* labels, float* scores, int64_t* qidx, cgg_stream_t stream);
 
