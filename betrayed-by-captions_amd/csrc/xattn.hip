@@ -26,7 +26,7 @@ __device__ __forceinline__ int xa_kswz(int key, int slot) { return slot ^ ((key 
 __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
     const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
     float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S, int words, int KC,
-    int nchunks, float scale) {
+    int nchunks, float scale, float* __restrict__ out_direct) {
   constexpr int D = 32;
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,7 +145,15 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
   }
 
   // ---- partials out: lane (j, hi) holds O[q = qi][d = (r&3) + 8*(r>>2) + 4*hi] ----
-  if (wave_live && qi < Q) {
+  if (wave_live && qi < Q && out_direct != nullptr) {
+    // single chunk: the combine step degenerates to o / l (l == 0 -> NaN, as the reference's all-masked row)
+    float* op = out_direct + ((size_t)b * Q + qi) * HD + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {o[4 * g] / l_run, o[4 * g + 1] / l_run, o[4 * g + 2] / l_run, o[4 * g + 3] / l_run};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hi) = v;
+    }
+  } else if (wave_live && qi < Q) {
     const size_t base = (((size_t)b * H + h) * nchunks + chunk) * Q + qi;
     float* op = ws_o + base * D;
 #pragma unroll
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
 __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     const float* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vt,
     const uint32_t* __restrict__ bits, float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S,
-    int words, int KC, int nchunks, float scale) {
+    int words, int KC, int nchunks, float scale, float* __restrict__ out_direct) {
   constexpr int D = 32;
   // 8 waves = 2 ADJACENT heads x 4 query tiles: a 128-byte line of K holds the 64-byte slices of two heads, so
   // pairing them in one workgroup makes every fetched line fully useful (one head per workgroup re-fetched each
@@ -276,7 +284,14 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pp), o, 0, 0, 0);
     }
   }
-  if (qi < Q) {
+  if (qi < Q && out_direct != nullptr) {
+    float* op = out_direct + ((size_t)b * Q + qi) * (H * D) + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 vv = {o[4 * g] / l_run, o[4 * g + 1] / l_run, o[4 * g + 2] / l_run, o[4 * g + 3] / l_run};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hi) = vv;
+    }
+  } else if (qi < Q) {
     const size_t base = (((size_t)b * H + h) * nchunks + chunk) * Q + qi;
     float* op = ws_o + base * D;
 #pragma unroll
@@ -317,11 +332,67 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict
   out[((size_t)b * Q + qq) * (H * D) + h * D + d] = num / den;  // den == 0 -> NaN, as the reference
 }
 
+// Same result, one wavefront per (b, h, q) row, for nchunks <= 64: lane c first owns chunk c's (max, sum) -- the
+// softmax rescale factors come from two wavefront reductions instead of two serial loops of dependent loads -- then
+// lane (d, half) accumulates O over the chunks of its parity, 4 independent loads in flight per lane.
+__global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __restrict__ ws_o,
+                                                              const float* __restrict__ ws_ml,
+                                                              float* __restrict__ out, int B, int Q, int H,
+                                                              int nchunks) {
+  constexpr int D = 32;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, h, q) flattened as ((b*H + h)*Q + q)
+  const int lane = threadIdx.x & 63;
+  if (row >= B * H * Q) return;
+  const int qq = row % Q, bh = row / Q;
+  const size_t r0 = (size_t)bh * nchunks * Q + qq;               // chunk c -> row r0 + c*Q of the workspace
+  float mc = -INFINITY, lc = 0.f;
+  if (lane < nchunks) {
+    const float2 ml = *reinterpret_cast<const float2*>(ws_ml + (r0 + (size_t)lane * Q) * 2);
+    mc = ml.x;
+    lc = ml.y;
+  }
+  float M = mc;
+  for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+  const float f = (mc == -INFINITY) ? 0.f : expf(mc - M);
+  float den = f * lc;
+  for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+  const int d = lane & 31, half = lane >> 5;
+  float num = 0.f;
+  int c = half;
+  for (; c + 6 < nchunks; c += 8) {
+    const float v0 = ws_o[(r0 + (size_t)c * Q) * D + d], v1 = ws_o[(r0 + (size_t)(c + 2) * Q) * D + d];
+    const float v2 = ws_o[(r0 + (size_t)(c + 4) * Q) * D + d], v3 = ws_o[(r0 + (size_t)(c + 6) * Q) * D + d];
+    num += __shfl(f, c) * v0;
+    num += __shfl(f, c + 2) * v1;
+    num += __shfl(f, c + 4) * v2;
+    num += __shfl(f, c + 6) * v3;
+  }
+  for (; c < nchunks; c += 2) num += __shfl(f, c) * ws_o[(r0 + (size_t)c * Q) * D + d];
+  num += __shfl_xor(num, 32);
+  if (half == 0) {
+    const int b = bh / H, h = bh - b * H;
+    out[((size_t)b * Q + qq) * (H * D) + h * D + d] = num / den;   // den == 0 -> NaN, as the reference
+  }
+}
+
+static void xattn_combine_launch(const float* ws_o, const float* ws_ml, float* out, int B, int Q, int H, int D, int nch,
+                                 hipStream_t s) {
+  if (nch <= 64 && D == 32) {
+    const int rows = B * H * Q;
+    hipLaunchKernelGGL(cgg_xattn_combine_wave, dim3((rows + 3) / 4), dim3(256), 0, s, ws_o, ws_ml, out, B, Q, H, nch);
+  } else {
+    const long long total = (long long)B * Q * H * D;
+    hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o, ws_ml, out, B,
+                       Q, H, D, nch);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 static void xattn_plan(int B, int H, int S, int* KC, int* nchunks) {
   // aim at ~2 workgroups per CU; chunk = multiple of XA_TK keys, at most 1024 (mask LDS budget)
   int want = (512 + B * H - 1) / (B * H);
   int tiles = (S + XA_TK - 1) / XA_TK;
+  if (tiles <= 4) want = 1;             // self-attention over ~100 queries: one chunk, no combine launch
   if (want > tiles) want = tiles;
   if (want < 1) want = 1;
   int tpc = (tiles + want - 1) / want;  // tiles per chunk
@@ -358,11 +429,9 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
   const size_t lds = (size_t)2 * XA_TK * D * sizeof(float) + (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
-                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale);
+                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
-  const long long total = (long long)B * Q * H * D;
-  hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o,
-                     ws_ml, out, B, Q, H, D, nch);
+  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
   return CGG_OK;
 }
@@ -386,11 +455,9 @@ extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, cons
   const size_t lds = (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, (H + 1) / 2, B), dim3(512), lds, s, q, (const uint16_t*)k,
-                     (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale);
+                     (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(partial)");
-  const long long total = (long long)B * Q * H * D;
-  hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o, ws_ml, out, B,
-                     Q, H, D, nch);
+  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(combine)");
   return CGG_OK;
 }
