@@ -24,8 +24,14 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
     const float* __restrict__ x, int ldx, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ pos, int pos_rows,
-    float* __restrict__ yp, int ldyp, int M, int N, int K, int relu_cols) {
+    float* __restrict__ yp, int ldyp, int M, int N, int K, int relu_cols, const float* __restrict__ x2, int ldx2,
+    int x2_col, float* __restrict__ y2, int ldy2, int y2_col) {
   constexpr int STEPS = LR2_KC / 16;
+  // fused projections over concatenated weights (self-attention q | k | v): 256-column blocks from x2_col on read
+  // the second input, blocks from y2_col on write the second output (both multiples of 256 -> workgroup-uniform)
+  if (x2 != nullptr && (int)blockIdx.x * 256 >= x2_col) { x = x2; ldx = ldx2; }
+  int ncol0 = 0;
+  if (y2 != nullptr && (int)blockIdx.x * 256 >= y2_col) { y = y2; ldy = ldy2; ncol0 = y2_col; }
   __shared__ __attribute__((aligned(16))) u32x4 a_frag[STEPS * 64];
   __shared__ float red[8][32];
   __shared__ float stat[2][32];
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-        if (m < M) yz[(size_t)m * ldy + n] = v[r];
+        if (m < M) yz[(size_t)m * ldy + n - ncol0] = v[r];
       }
     }
     return;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
       if (m < M) {
-        y[(size_t)m * ldy + n] = v[r];
+        y[(size_t)m * ldy + n - ncol0] = v[r];
         if (yp) yp[(size_t)m * ldyp + n] = v[r] + posv[r];
       }
     }
@@ -295,8 +301,13 @@ extern "C" int cgg_linear_rows_pack(const float* w, void* packed, int N, int K, 
 extern "C" int cgg_linear_rows_bf16(const float* x, int ldx, const void* w_packed, const float* bias,
                                     const float* res, int ldr, float* y, int ldy, const float* ln_gamma,
                                     const float* ln_beta, float ln_eps, const float* pos, int pos_rows, float* yp,
-                                    int ldyp, int M, int N, int K, int relu_cols, int ksplit, cgg_stream_t stream) {
+                                    int ldyp, int M, int N, int K, int relu_cols, int ksplit, const float* x2, int ldx2,
+                                    int x2_col, float* y2, int ldy2, int y2_col, cgg_stream_t stream) {
   CGG_REQUIRE(x && w_packed && y, CGG_EINVAL, "cgg_linear_rows_bf16: null pointer");
+  CGG_REQUIRE(!x2 || (x2_col > 0 && x2_col % 256 == 0 && ldx2 % 4 == 0 && cgg_aligned16(x2)), CGG_EUNSUPPORTED,
+              "cgg_linear_rows_bf16: x2_col=%d must be a positive multiple of 256 (ldx2=%d)", x2_col, ldx2);
+  CGG_REQUIRE(!y2 || (y2_col > 0 && y2_col % 256 == 0), CGG_EUNSUPPORTED,
+              "cgg_linear_rows_bf16: y2_col=%d must be a positive multiple of 256", y2_col);
   CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "cgg_linear_rows_bf16: bad sizes");
   CGG_REQUIRE(K % 16 == 0 && ldx % 4 == 0, CGG_EUNSUPPORTED, "cgg_linear_rows_bf16: K=%d ldx=%d", K, ldx);
   CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w_packed), CGG_EALIGN, "cgg_linear_rows_bf16: alignment");
@@ -310,10 +321,10 @@ extern "C" int cgg_linear_rows_bf16(const float* x, int ldx, const void* w_packe
   dim3 grid((N + 255) / 256, (M + 31) / 32, ksplit);
   if (ln)
     hipLaunchKernelGGL(cgg_lr2_kernel<true>, grid, dim3(512), 0, s, x, ldx, (const u32x4*)w_packed, bias, res, ldr, y,
-                       ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols);
+                       ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols, x2, ldx2, x2_col, y2, ldy2, y2_col);
   else
     hipLaunchKernelGGL(cgg_lr2_kernel<false>, grid, dim3(512), 0, s, x, ldx, (const u32x4*)w_packed, bias, res, ldr, y,
-                       ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols);
+                       ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols, x2, ldx2, x2_col, y2, ldy2, y2_col);
   CGG_CHECK_LAUNCH("cgg_linear_rows_bf16");
   return CGG_OK;
 }

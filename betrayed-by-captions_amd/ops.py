@@ -558,7 +558,8 @@ def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, po
         rc = _lib_().cgg_linear_rows_bf16(
             ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
             ctypes.c_void_p(res.data_ptr()) if res is not None else None, res.stride(0) if res is not None else 0,
-            dev_ptr(y), N, None, None, 0.0, None, 0, None, 0, M, N, K, 0, int(ksplit), stream_ptr(x.device))
+            dev_ptr(y), N, None, None, 0.0, None, 0, None, 0, M, N, K, 0, int(ksplit), None, 0, 0, None, 0, 0,
+            stream_ptr(x.device))
         check(rc, 'cgg_linear_rows_bf16(split-K)')
         return y
     y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x.device)
@@ -574,9 +575,28 @@ def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, po
         ctypes.c_void_p(y.data_ptr()), y.stride(0), dev_ptr(g, 'gamma', torch.float32),
         dev_ptr(b, 'beta', torch.float32), float(eps), dev_ptr(pos, 'pos', torch.float32) if want_pos else None,
         pos.shape[0] if want_pos else 0, dev_ptr(yp), N if want_pos else 0, M, N, K, int(relu_cols), int(ksplit),
-        stream_ptr(x.device))
+        None, 0, 0, None, 0, 0, stream_ptr(x.device))
     check(rc, 'cgg_linear_rows_bf16')
     return (y, yp) if want_pos else y
+
+
+def linear_rows_bf16_qkv(xqk, xv, packed, bias, E):
+    """Self-attention projections as ONE launch over the concatenated packed [Wq; Wk; Wv] (3E x E, E % 256 == 0):
+    q, k from xqk (= query + query_pos), v from xv (= query); all (M, E) f32 rows -> (q (M, E), kv (M, 2E))."""
+    M, K = xqk.shape
+    for t in (xqk, xv):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32 or not t.is_cuda or t.shape != (M, K):
+            raise CggError('linear_rows_bf16_qkv: inputs must be matching 2-D float32 ROCm tensors')
+    if E % 256:
+        raise CggError('linear_rows_bf16_qkv: E must be a multiple of 256')
+    q = torch.empty((M, E), dtype=torch.float32, device=xqk.device)
+    kv = torch.empty((M, 2 * E), dtype=torch.float32, device=xqk.device)
+    rc = _lib_().cgg_linear_rows_bf16(
+        ctypes.c_void_p(xqk.data_ptr()), xqk.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), None, 0,
+        dev_ptr(q), E, None, None, 0.0, None, 0, None, 0, M, 3 * E, K, 0, 1,
+        ctypes.c_void_p(xv.data_ptr()), xv.stride(0), 2 * E, dev_ptr(kv), 2 * E, E, stream_ptr(xqk.device))
+    check(rc, 'cgg_linear_rows_bf16(qkv)')
+    return q, kv
 
 
 def layernorm_chain(a, norm_a, pos=None, norm_b=None):

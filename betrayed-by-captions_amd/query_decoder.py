@@ -265,13 +265,18 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
             core = ops.masked_xattn(q.view(B, Q, E), kv, bits, H).view(M, E)
         x1, x1p = lr(core, wo, E, bo, res=x, ln=(n0.weight, n0.bias, n0.eps), pos=pos, want_pos=True)
         w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
-        wq, bq, _ = pk((w[:E],), (b[:E],))
-        wk, bk, _ = pk((w[E:2 * E],), (b[E:2 * E],))
-        wv, bv, _ = pk((w[2 * E:],), (b[2 * E:],))
-        q2 = lr(x1p, wq, E, bq)
-        kv2 = torch.empty((M, 2 * E), dtype=torch.float32, device=x.device)
-        lr(x1p, wk, E, bk, out=kv2[:, :E])
-        lr(x1, wv, E, bv, out=kv2[:, E:])
+        if E % 256 == 0:
+            # in_proj_weight is already [Wq; Wk; Wv]: one launch, q | k read x1 + pos, v reads x1
+            wqkv, bqkv, _ = pk((w,), (b,))
+            q2, kv2 = ops.linear_rows_bf16_qkv(x1p, x1, wqkv, bqkv, E)
+        else:
+            wq, bq, _ = pk((w[:E],), (b[:E],))
+            wk, bk, _ = pk((w[E:2 * E],), (b[E:2 * E],))
+            wv, bv, _ = pk((w[2 * E:],), (b[2 * E:],))
+            q2 = lr(x1p, wq, E, bq)
+            kv2 = torch.empty((M, 2 * E), dtype=torch.float32, device=x.device)
+            lr(x1p, wk, E, bk, out=kv2[:, :E])
+            lr(x1, wv, E, bv, out=kv2[:, E:])
         core2 = ops.masked_xattn(q2.view(B, Q, E), kv2.view(B, Q, 2 * E), None, sa.num_heads).view(M, E)
         wo, bo, _ = pk((sa.attn.out_proj.weight,), (sa.attn.out_proj.bias,))
         x2 = lr(core2, wo, E, bo, res=x1, ln=(n1.weight, n1.bias, n1.eps))

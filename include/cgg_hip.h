@@ -189,6 +189,9 @@ int cgg_add_layernorm(const float* a, const float* b, const float* gamma, const 
  *   ksplit > 1: K is split over ksplit workgroups; split z writes its partial sums to the plane y + z * M * ldy
  *   (y must hold ksplit planes; bias / res go into plane 0; no ReLU / LayerNorm / yp in that mode) and the consumer
  *   adds the planes (cgg_layernorm_chain with nsum = ksplit) -- deterministic, no atomics.
+ *   x2 != NULL: output columns >= x2_col are computed from x2 [M, K] (row stride ldx2) instead of x, and
+ *   y2 != NULL: output columns >= y2_col are stored to y2[m * ldy2 + (n - y2_col)] (x2_col, y2_col multiples of 256):
+ *   the self-attention q | k | v projections (q, k from `query + query_pos`, v from `query`) as ONE launch.
  * Replaces, per decoder layer, the q/k/v/out projections, FFN, the three post-norm LayerNorms and the `x + pos`
  * adds of DetrTransformerDecoderLayer ([3P]; open_set/models/mask2former_head.py:829-840) and the cls / v2l /
  * mask_embed MLPs of forward_head (:734-746). Requires K % 16 == 0, ldx % 4 == 0.                               */
@@ -197,7 +200,8 @@ int cgg_linear_rows_pack(const float* w, void* packed, int N, int K, cgg_stream_
 int cgg_linear_rows_bf16(const float* x, int ldx, const void* w_packed, const float* bias, const float* res,
                          int ldr, float* y, int ldy, const float* ln_gamma, const float* ln_beta, float ln_eps,
                          const float* pos, int pos_rows, float* yp, int ldyp, int M, int N, int K, int relu_cols,
-                         int ksplit, cgg_stream_t stream);
+                         int ksplit, const float* x2, int ldx2, int x2_col, float* y2, int ldy2, int y2_col,
+                         cgg_stream_t stream);
 
 /* y = LN_a(sum_{p < nsum} a[p * plane + ...]) ; yp = y + pos[row % pos_rows] (nullable) ; z = LN_b(y) (nullable): the
  * decoder layer's last norm (fed by the nsum split-K planes of cgg_linear_rows_bf16), the next layer's `query +
