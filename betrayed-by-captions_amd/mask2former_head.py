@@ -392,6 +392,8 @@ class Mask2FormerHeadOpen(nn.Module):
         pos = self.query_embed.weight.detach()
         Q, C = pos.shape
         qf = self.query_feat.weight.detach()
+        if not all_masks and nl > 0 and self._lean_decode_ok(C):
+            return self._decode_stream_lean(B, kvs, sizes, packed_full, pooled)
         x = qf.unsqueeze(0).expand(B, -1, -1).reshape(B * Q, C)
         xp = (qf + pos).unsqueeze(0).expand(B, -1, -1).reshape(B * Q, C)
         d = ops.layernorm_chain(x, (pn.weight, pn.bias, pn.eps))[0]
@@ -412,6 +414,83 @@ class Mask2FormerHeadOpen(nn.Module):
             bits = res[3]
             for k in range(3):
                 outs[k].append(res[k])
+        return outs
+
+    def _lean_decode_ok(self, C):
+        me = self.mask_embed
+        layers = self.transformer_decoder.layers
+        return (C == 256 and self.attn_mask_hook is None and len(me) == 5
+                and all(tuple(m.weight.shape) == (C, C) for m in (me[0], me[2], me[4]))
+                and all(l.attentions[0].embed_dims == C for l in layers))
+
+    def _decode_stream_lean(self, B, kvs, sizes, packed_full, pooled):
+        """Inference-only decode (`all_masks=False`): the intermediate layers' class / caption-embedding predictions
+        are never read (simple_test takes [-1], maskformer_open.py:161-178), so between two layers only the attention
+        mask of the next one is produced: FFN planes -> `cgg_decoder_tail_bf16` (norm, post_norm, mask MLP, next query
+        projection) -> mask bits. Everything before the first cross-attention depends on the weights alone (query_feat,
+        query_embed, post_norm, mask_embed, layer 0's query projection) and is cached. Returns the same lists as
+        `_decode_stream` with None for the skipped intermediate entries."""
+        layers = self.transformer_decoder.layers
+        nl = self.num_transformer_decoder_layers
+        L = self.num_transformer_feat_level
+        pn = self.transformer_decoder.post_norm
+        pos = self.query_embed.weight.detach()
+        Q, C = pos.shape
+        qf = self.query_feat.weight
+        me = self.mask_embed
+        pk = runtime.packed_cached
+        mlp = pk((me[0].weight,), (me[0].bias,))[:2] + pk((me[2].weight,), (me[2].bias,))[:2] + \
+            pk((me[4].weight,), (me[4].bias,))[:2]
+        pnorm = (pn.weight, pn.bias, pn.eps)
+
+        def qproj(i):
+            a = layers[i].attentions[0].attn
+            return pk((a.in_proj_weight[:C],), (a.in_proj_bias[:C],))[:2]
+
+        def consts():
+            x = qf.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Q, C).contiguous()
+            xp = (qf.detach() + pos).unsqueeze(0).expand(B, -1, -1).reshape(B * Q, C).contiguous()
+            d = ops.layernorm_chain(x, pnorm)[0]
+            lr = ops.linear_rows_bf16
+            h = lr(d, mlp[0], C, mlp[1], relu_cols=C)
+            h = lr(h, mlp[2], C, mlp[3], relu_cols=C)
+            m0 = lr(h, mlp[4], C, mlp[5])
+            wq0, bq0 = qproj(0)
+            q0 = lr(xp, wq0, C, bq0)
+            return x, m0, q0
+
+        a0 = layers[0].attentions[0].attn
+        x, m0, q = runtime.derived_cached(
+            'lean_decode_consts_%d' % B,
+            (qf, self.query_embed.weight, pn.weight, pn.bias, me[0].weight, me[0].bias, me[2].weight, me[2].bias,
+             me[4].weight, me[4].bias, a0.in_proj_weight, a0.in_proj_bias), consts)
+        outs = ([None], [None], [None])
+        _, bits = ops.mask_logits(m0.view(B, Q, C), pooled[0], want_logits=False, want_bits=True) \
+            if pooled[0] is not None else (None, None)
+        if bits is None:
+            full = ops.mask_logits(m0.view(B, Q, C), packed_full)[0]
+            bits = ops.attn_mask_from_logits(full.contiguous(), (int(sizes[0][0]), int(sizes[0][1])))
+        for i in range(nl):
+            li = i % L
+            ops.attn_mask_fix_full_rows(bits, sizes[li][0] * sizes[li][1])
+            last = i == nl - 1
+            n2 = layers[i].norms[2]
+            if last:
+                x, _, d = layers[i].forward_stream(x, None, pos, kvs[i], bits, pn, q=q)
+                res = self._head_stream(d, sizes[0], packed_full, pooled[0], True, False, True)
+                for k in range(3):
+                    outs[k].append(res[k])
+                break
+            t = layers[i].forward_stream(x, None, pos, kvs[i], bits, pn, q=q, raw=True)
+            x, _, m, q = ops.decoder_tail(t, (n2.weight, n2.bias, n2.eps), pos, pnorm, mlp, qproj(i + 1))
+            nxt = (i + 1) % L
+            if pooled[nxt] is not None:
+                _, bits = ops.mask_logits(m.view(B, Q, C), pooled[nxt], want_logits=False, want_bits=True)
+            else:
+                full = ops.mask_logits(m.view(B, Q, C), packed_full)[0]
+                bits = ops.attn_mask_from_logits(full.contiguous(), (int(sizes[nxt][0]), int(sizes[nxt][1])))
+            for k in range(3):
+                outs[k].append(None)
         return outs
 
     def _forward(self, feats, img_metas, all_masks=True, encoded=None):

@@ -625,6 +625,30 @@ def layernorm_chain(a, norm_a, pos=None, norm_b=None):
     return y, yp, z
 
 
+def decoder_tail(planes, norm_a, pos, norm_b, mlp, qproj=None, want_pos=False):
+    """planes (nsum, M, 256) f32 (FFN split-K partials, bias + residual in plane 0) -> (y = LN_a(sum), y + pos | None,
+    mask_embed = MLP3(LN_b(y)), qn = Wq (y + pos) + bq | None). norm_* = (gamma, beta, eps); mlp = (w1, b1, w2, b2, w3, b3)
+    and qproj = (wq, bq) with weights packed by `pack_linear_weight` (256 x 256)."""
+    if planes.dim() != 3 or not planes.is_contiguous() or planes.dtype != torch.float32:
+        raise CggError('decoder_tail: planes must be a contiguous (nsum, M, C) float32 tensor')
+    nsum, M, C = planes.shape
+    dev = planes.device
+    y = torch.empty((M, C), dtype=torch.float32, device=dev)
+    yp = torch.empty_like(y) if want_pos else None
+    me = torch.empty_like(y)
+    qn = torch.empty_like(y) if qproj is not None else None
+    wq, bq = qproj if qproj is not None else (None, None)
+    rc = _lib_().cgg_decoder_tail_bf16(
+        dev_ptr(planes), nsum, M * C, C, dev_ptr(norm_a[0], 'gamma_a', torch.float32),
+        dev_ptr(norm_a[1], 'beta_a', torch.float32), float(norm_a[2]), dev_ptr(pos, 'pos', torch.float32), pos.shape[0],
+        dev_ptr(norm_b[0], 'gamma_b', torch.float32), dev_ptr(norm_b[1], 'beta_b', torch.float32), float(norm_b[2]),
+        dev_ptr(mlp[0]), dev_ptr(mlp[1], 'b1', torch.float32), dev_ptr(mlp[2]), dev_ptr(mlp[3], 'b2', torch.float32),
+        dev_ptr(mlp[4]), dev_ptr(mlp[5], 'b3', torch.float32), dev_ptr(wq), dev_ptr(bq, 'bq', torch.float32),
+        dev_ptr(y), dev_ptr(yp), dev_ptr(me), dev_ptr(qn), M, C, stream_ptr(dev))
+    check(rc, 'cgg_decoder_tail_bf16')
+    return y, yp, me, qn
+
+
 def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
     """q (B,Q,E) f32; k (B,S,E) bf16; vt (B,E,S) bf16 (value projection, transposed); bits as `masked_xattn`."""
     B, Q, E = q.shape

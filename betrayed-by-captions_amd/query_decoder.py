@@ -238,10 +238,13 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
                 and len(ffn.layers) == 3 and isinstance(ffn.layers[0][1], nn.ReLU) and ffn.add_identity
                 and self.embed_dims <= 256 and self.embed_dims % 32 == 0)
 
-    def forward_stream(self, x, xp, pos, kv, bits, post_norm=None):
+    def forward_stream(self, x, xp, pos, kv, bits, post_norm=None, q=None, raw=False):
         """Throughput-mode layer on 2-D rows: x, xp = x + pos (M = B*Q, C) f32; pos (Q, C). Every projection is
         `cgg_linear_rows_bf16` on pre-packed bf16 weights; the three post-norm LayerNorms, the residual adds and the
-        `+ query_pos` adds run in GEMM epilogues / one LayerNorm-chain pass. Returns (x', x' + pos, post_norm(x'))."""
+        `+ query_pos` adds run in GEMM epilogues / one LayerNorm-chain pass. Returns (x', x' + pos, post_norm(x')).
+        `q` = the cross-attention query projection if the previous layer's tail kernel already made it (xp is then
+        unused); `raw` returns the FFN output (+ residual) BEFORE the last norm -- split-K planes (n, M, C) -- for
+        `ops.decoder_tail` to finish."""
         ca, sa = self.attentions
         E = self.embed_dims
         M = x.shape[0]
@@ -252,8 +255,9 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         lr = ops.linear_rows_bf16
         n0, n1, n2 = self.norms
         w, b = ca.attn.in_proj_weight, ca.attn.in_proj_bias
-        wq, bq, _ = pk((w[:E],), (b[:E],))
-        q = lr(xp, wq, E, bq)
+        if q is None:
+            wq, bq, _ = pk((w[:E],), (b[:E],))
+            q = lr(xp, wq, E, bq)
         wo, bo, _ = pk((ca.attn.out_proj.weight,), (ca.attn.out_proj.bias,))
         if isinstance(kv, tuple):
             # bf16 K and transposed V (see project_kv_bf16): the value bias is folded through the softmax
@@ -285,6 +289,8 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         w2, b2, _ = pk((ffn.layers[1].weight,), (ffn.layers[1].bias,))
         h = lr(x2, w1, F1, b1, relu_cols=F1)
         t = lr(h, w2, E, b2, res=x2, ksplit=8 if F1 >= 1024 else 1)
+        if raw:
+            return t if t.dim() == 3 else t.unsqueeze(0)
         return ops.layernorm_chain(t, (n2.weight, n2.bias, n2.eps), pos,
                                    None if post_norm is None else (post_norm.weight, post_norm.bias, post_norm.eps))
 

@@ -211,6 +211,18 @@ int cgg_layernorm_chain(const float* a, int lda, const float* gamma_a, const flo
                         float* y, float* yp, float* z, int rows, int N, int nsum, int64_t plane,
                         cgg_stream_t stream);
 
+/* Tail of one query-decoder layer in ONE launch (C == 256), on the FFN's split-K planes [nsum][M][ld] (bias and
+ * residual already in plane 0):  y = LN_a(sum planes) (the layer's last norm; [3P] DetrTransformerDecoderLayer),
+ * yp = y + pos[row % pos_rows] (nullable), z = LN_b(y) (decoder post_norm, mask2former_head.py:734),
+ * mask_embed = W3 relu(W2 relu(W1 z + b1) + b2) + b3 (:741-746) and, when wq != NULL, qn = Wq (y + pos) + bq -- the next
+ * layer's cross-attention query projection (:829). w1 / w2 / w3 / wq: 256 x 256 weights packed by cgg_linear_rows_pack.
+ * Same arithmetic per stage as cgg_layernorm_chain + 4 x cgg_linear_rows_bf16 (bf16 operands, f32 accumulate).     */
+int cgg_decoder_tail_bf16(const float* planes, int nsum, int64_t plane_stride, int ld, const float* gamma_a,
+                          const float* beta_a, float eps_a, const float* pos, int pos_rows, const float* gamma_b,
+                          const float* beta_b, float eps_b, const void* w1, const float* b1, const void* w2,
+                          const float* b2, const void* w3, const float* b3, const void* wq, const float* bq, float* y,
+                          float* yp, float* mask_embed, float* qn, int M, int C, cgg_stream_t stream);
+
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, b f32 or bf16 (nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
 int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,

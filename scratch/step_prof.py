@@ -4,7 +4,7 @@ f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-mark = sys.argv[2] if len(sys.argv) > 2 else 'cgg_instance_final_kernel'
+mark = sys.argv[2] if len(sys.argv) > 2 else 'cgg_instance_final'
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 im = [i for i, n in enumerate(names) if mark in n]
 s0 = im[-per - 1] + 1

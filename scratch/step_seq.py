@@ -3,7 +3,7 @@ import csv, sys, glob, os
 f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-mark = sys.argv[2] if len(sys.argv) > 2 else 'cgg_instance_final_kernel'
+mark = sys.argv[2] if len(sys.argv) > 2 else 'cgg_instance_final'
 im = [i for i, r in enumerate(rows) if mark in r['Kernel_Name']]
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 step = rows[im[-per - 1] + 1: im[-1] + 1]

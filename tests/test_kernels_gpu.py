@@ -703,3 +703,38 @@ def test_instance_masks_picks_matches_multi(dev):
     assert torch.equal(masks, torch.cat(masks_l))
     assert torch.equal(bboxes[:, :4], qboxes[qidx])
     assert torch.allclose(bboxes[:, 4], cls_scores * qscores[qidx], rtol=2e-6, atol=0)
+
+
+def test_decoder_tail_matches_the_launch_chain(dev):
+    """cgg_decoder_tail_bf16 == cgg_layernorm_chain + 3 x cgg_linear_rows_bf16 (mask MLP) + the query projection."""
+    g = torch.Generator().manual_seed(68)
+    M, C, Q, nsum = 200, 256, 100, 8
+    planes = (torch.randn(nsum, M, C, generator=g) * 0.5).to(dev)
+    pos = torch.randn(Q, C, generator=g).to(dev)
+    na = (torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev), 1e-5)
+    nb = (torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev), 1e-5)
+    ws = [(torch.randn(C, C, generator=g) / 16).to(dev) for _ in range(4)]
+    bs = [torch.randn(C, generator=g).to(dev) for _ in range(4)]
+    pk = [ops.pack_linear_weight(w) for w in ws]
+    y, yp, me, qn = ops.decoder_tail(planes, na, pos, nb, (pk[0], bs[0], pk[1], bs[1], pk[2], bs[2]), (pk[3], bs[3]),
+                                     want_pos=True)
+    y0, yp0, z0 = ops.layernorm_chain(planes, na, pos, nb)
+    h = ops.linear_rows_bf16(z0, pk[0], C, bs[0], relu_cols=C)
+    h = ops.linear_rows_bf16(h, pk[1], C, bs[1], relu_cols=C)
+    me0 = ops.linear_rows_bf16(h, pk[2], C, bs[2])
+    qn0 = ops.linear_rows_bf16(yp0, pk[3], C, bs[3])
+    # same arithmetic per stage, different (but fixed) reduction order inside the LayerNorms
+    assert torch.allclose(y, y0, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(yp, yp0, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(me, me0, atol=3e-2, rtol=2e-2)       # bf16 roundings of near-identical inputs may flip
+    assert torch.allclose(qn, qn0, atol=3e-2, rtol=2e-2)
+    # and against plain f32 math
+    yr = torch.nn.functional.layer_norm(planes.sum(0), (C,), na[0], na[1], 1e-5)
+    zr = torch.nn.functional.layer_norm(yr, (C,), nb[0], nb[1], 1e-5)
+    mr = torch.relu(torch.relu(zr @ ws[0].t() + bs[0]) @ ws[1].t() + bs[1]) @ ws[2].t() + bs[2]
+    assert torch.allclose(y, yr, atol=1e-4, rtol=1e-4)
+    assert (me - mr).abs().max() < 0.05 * mr.abs().max()
+    assert (qn - ((yr + pos.repeat(M // Q, 1)) @ ws[3].t() + bs[3])).abs().max() < 0.05 * qn.abs().max()
+    # deterministic
+    y2, _, me2, qn2 = ops.decoder_tail(planes, na, pos, nb, (pk[0], bs[0], pk[1], bs[1], pk[2], bs[2]), (pk[3], bs[3]))
+    assert torch.equal(y, y2) and torch.equal(me, me2) and torch.equal(qn, qn2)
