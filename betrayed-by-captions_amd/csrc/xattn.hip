@@ -306,6 +306,140 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
   }
 }
 
+// Self-attention of the query decoder in throughput mode (mask2former_head.py:832-836): S = Q <= 128 keys, no mask,
+// q [M, ldq] and kv = [k | v] [M, ldkv] f32 rows straight from the fused q|k|v projection. One workgroup per (head,
+// image), one wavefront per 32-query tile, no LDS: the whole K / V of a head is 2 x 12.5 KiB, every load of a wave is
+// issued before the first MFMA. Same tile algebra as cgg_xattn_partial_bf16 (S^T = K Q^T so a lane owns one query's
+// softmax; the P operand's key permutation is matched by the V gather); bf16 operands, f32 accumulation / softmax.
+__global__ __launch_bounds__(256) void cgg_self_attn_small_kernel(const float* __restrict__ q, int ldq,
+                                                                  const float* __restrict__ kv, int ldkv,
+                                                                  float* __restrict__ out, int Q, int H, float scale) {
+  constexpr int D = 32;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int E = H * D, S = Q;
+  if (wave * 32 >= Q) return;
+  const int qi = wave * 32 + j;
+  const bool q_ok = qi < Q;
+  const float* qp = q + ((size_t)b * Q + (q_ok ? qi : 0)) * ldq + h * D + 8 * hi;
+  const float* kbase = kv + (size_t)b * Q * ldkv + h * D;
+  const float* vbase = kbase + E;
+  f32x4 qf[4], kf[4][4];
+  float vf[4][16];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[2 * ks] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+    qf[2 * ks + 1] = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+  }
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int s0 = 32 * st;
+    if (s0 < S) {                                           // wave-uniform
+      const float* kp = kbase + (size_t)min(s0 + j, S - 1) * ldkv + 8 * hi;
+      kf[st][0] = *reinterpret_cast<const f32x4*>(kp);
+      kf[st][1] = *reinterpret_cast<const f32x4*>(kp + 4);
+      kf[st][2] = *reinterpret_cast<const f32x4*>(kp + 16);
+      kf[st][3] = *reinterpret_cast<const f32x4*>(kp + 20);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        vf[st][r] = vbase[(size_t)min(key, S - 1) * ldkv + j];
+      }
+    }
+  }
+  bf16x8 qb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const f32x4 a = qf[2 * ks], c = qf[2 * ks + 1];
+    const uint4 u = make_uint4(cgg_pack2(cgg_f2bf(q_ok ? a[0] * scale : 0.f), cgg_f2bf(q_ok ? a[1] * scale : 0.f)),
+                               cgg_pack2(cgg_f2bf(q_ok ? a[2] * scale : 0.f), cgg_f2bf(q_ok ? a[3] * scale : 0.f)),
+                               cgg_pack2(cgg_f2bf(q_ok ? c[0] * scale : 0.f), cgg_f2bf(q_ok ? c[1] * scale : 0.f)),
+                               cgg_pack2(cgg_f2bf(q_ok ? c[2] * scale : 0.f), cgg_f2bf(q_ok ? c[3] * scale : 0.f)));
+    qb[ks] = __builtin_bit_cast(bf16x8, u);
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int s0 = 32 * st;
+    if (s0 < S) {
+      bf16x8 kb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const f32x4 a = kf[st][2 * ks], c = kf[st][2 * ks + 1];
+        const uint4 u = make_uint4(cgg_pack2(cgg_f2bf(a[0]), cgg_f2bf(a[1])), cgg_pack2(cgg_f2bf(a[2]), cgg_f2bf(a[3])),
+                                   cgg_pack2(cgg_f2bf(c[0]), cgg_f2bf(c[1])), cgg_pack2(cgg_f2bf(c[2]), cgg_f2bf(c[3])));
+        kb[ks] = __builtin_bit_cast(bf16x8, u);
+      }
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qb[0], sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[1], qb[1], sc, 0, 0, 0);
+      float rmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ki = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        sc[r] = (s0 + ki >= S) ? -INFINITY : sc[r];
+        rmax = fmaxf(rmax, sc[r]);
+      }
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+      const float m_new = fmaxf(m_run, rmax);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = expf(m_run - m_use);
+      float psum = 0.f;
+      uint16_t pb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(sc[r] - m_use);
+        psum += p;
+        pb[r] = cgg_f2bf(p);
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint4 va = make_uint4(cgg_pack2(cgg_f2bf(vf[st][8 * t]), cgg_f2bf(vf[st][8 * t + 1])),
+                                    cgg_pack2(cgg_f2bf(vf[st][8 * t + 2]), cgg_f2bf(vf[st][8 * t + 3])),
+                                    cgg_pack2(cgg_f2bf(vf[st][8 * t + 4]), cgg_f2bf(vf[st][8 * t + 5])),
+                                    cgg_pack2(cgg_f2bf(vf[st][8 * t + 6]), cgg_f2bf(vf[st][8 * t + 7])));
+        const uint4 pp = make_uint4(cgg_pack2(pb[8 * t], pb[8 * t + 1]), cgg_pack2(pb[8 * t + 2], pb[8 * t + 3]),
+                                    cgg_pack2(pb[8 * t + 4], pb[8 * t + 5]), cgg_pack2(pb[8 * t + 6], pb[8 * t + 7]));
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pp), o, 0, 0, 0);
+      }
+    }
+  }
+  if (q_ok) {
+    float* op = out + ((size_t)b * Q + qi) * E + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 vv = {o[4 * g] / l_run, o[4 * g + 1] / l_run, o[4 * g + 2] / l_run, o[4 * g + 3] / l_run};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hi) = vv;
+    }
+  }
+}
+
+extern "C" int cgg_self_attn_rows_bf16(const float* q, int ldq, const float* kv, int ldkv, float* out, int B, int Q,
+                                       int H, int D, float scale, cgg_stream_t stream) {
+  CGG_REQUIRE(q && kv && out, CGG_EINVAL, "cgg_self_attn_rows_bf16: null pointer");
+  CGG_REQUIRE(B > 0 && Q > 0 && H > 0, CGG_EINVAL, "cgg_self_attn_rows_bf16: bad sizes");
+  CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_self_attn_rows_bf16: head dim %d (only 32 is built)", D);
+  CGG_REQUIRE(Q <= 128, CGG_EUNSUPPORTED, "cgg_self_attn_rows_bf16: Q=%d > 128", Q);
+  CGG_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldq >= H * D && ldkv >= 2 * H * D && cgg_aligned16(q) && cgg_aligned16(kv) &&
+                  cgg_aligned16(out),
+              CGG_EALIGN, "cgg_self_attn_rows_bf16: 16-B aligned rows required (ldq=%d ldkv=%d)", ldq, ldkv);
+  hipLaunchKernelGGL(cgg_self_attn_small_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, q, ldq, kv, ldkv, out, Q,
+                     H, scale);
+  CGG_CHECK_LAUNCH("cgg_self_attn_rows_bf16");
+  return CGG_OK;
+}
+
 // combine the per-chunk partials: thread = (b, q, h, d)
 __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict__ ws_o,
                                                          const float* __restrict__ ws_ml,

@@ -625,6 +625,20 @@ def layernorm_chain(a, norm_a, pos=None, norm_b=None):
     return y, yp, z
 
 
+def self_attn_rows_bf16(q, kv, B, num_heads, scale=None):
+    """q (M, E), kv (M, 2E) f32 rows (M = B*Q, Q <= 128, head dim 32) -> softmax(scale q k^T) v, (M, E) f32."""
+    M, E = q.shape
+    D = E // num_heads
+    if q.stride(1) != 1 or kv.stride(1) != 1 or kv.shape != (M, 2 * E) or q.dtype != torch.float32 or kv.dtype != torch.float32:
+        raise CggError('self_attn_rows_bf16: q (M, E) / kv (M, 2E) float32 rows expected')
+    out = torch.empty((M, E), dtype=torch.float32, device=q.device)
+    rc = _lib_().cgg_self_attn_rows_bf16(ctypes.c_void_p(q.data_ptr()), q.stride(0), ctypes.c_void_p(kv.data_ptr()),
+                                         kv.stride(0), dev_ptr(out), B, M // B, num_heads, D,
+                                         float(scale if scale is not None else D ** -0.5), stream_ptr(q.device))
+    check(rc, 'cgg_self_attn_rows_bf16')
+    return out
+
+
 def decoder_tail(planes, norm_a, pos, norm_b, mlp, qproj=None, want_pos=False):
     """planes (nsum, M, 256) f32 (FFN split-K partials, bias + residual in plane 0) -> (y = LN_a(sum), y + pos | None,
     mask_embed = MLP3(LN_b(y)), qn = Wq (y + pos) + bq | None). norm_* = (gamma, beta, eps); mlp = (w1, b1, w2, b2, w3, b3)

@@ -281,7 +281,10 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
             kv2 = torch.empty((M, 2 * E), dtype=torch.float32, device=x.device)
             lr(x1p, wk, E, bk, out=kv2[:, :E])
             lr(x1, wv, E, bv, out=kv2[:, E:])
-        core2 = ops.masked_xattn(q2.view(B, Q, E), kv2.view(B, Q, 2 * E), None, sa.num_heads).view(M, E)
+        if Q <= 128 and E // sa.num_heads == 32:
+            core2 = ops.self_attn_rows_bf16(q2, kv2, B, sa.num_heads)
+        else:
+            core2 = ops.masked_xattn(q2.view(B, Q, E), kv2.view(B, Q, 2 * E), None, sa.num_heads).view(M, E)
         wo, bo, _ = pk((sa.attn.out_proj.weight,), (sa.attn.out_proj.bias,))
         x2 = lr(core2, wo, E, bo, res=x1, ln=(n1.weight, n1.bias, n1.eps))
         ffn = self.ffns[0]

@@ -167,6 +167,12 @@ int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bit
 int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits, float* out,
                                   void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream);
 
+/* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
+ * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =
+ * softmax(scale q k^T) v per head. bf16 MFMA operands, f32 accumulation and softmax; D == 32.                       */
+int cgg_self_attn_rows_bf16(const float* q, int ldq, const float* kv, int ldkv, float* out, int B, int Q, int H, int D,
+                            float scale, cgg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K7/K11  Skinny linear + fused residual LayerNorm for the QUERY side of the decoder (M = B*Q ~ 200 rows):
  * the q / out / self-attention projections and FFN of DetrTransformerDecoderLayer ([3P], called at

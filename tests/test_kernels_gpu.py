@@ -738,3 +738,18 @@ def test_decoder_tail_matches_the_launch_chain(dev):
     # deterministic
     y2, _, me2, qn2 = ops.decoder_tail(planes, na, pos, nb, (pk[0], bs[0], pk[1], bs[1], pk[2], bs[2]), (pk[3], bs[3]))
     assert torch.equal(y, y2) and torch.equal(me, me2) and torch.equal(qn, qn2)
+
+
+def test_self_attn_rows_bf16(dev):
+    g = torch.Generator().manual_seed(69)
+    for (B, Q, H) in [(2, 100, 8), (1, 37, 8), (3, 128, 4)]:
+        E = 32 * H
+        q = torch.randn(B * Q, E, generator=g).to(dev)
+        kv = torch.randn(B * Q, 2 * E, generator=g).to(dev)
+        got = ops.self_attn_rows_bf16(q, kv, B, H)
+        qh = q.view(B, Q, H, 32).transpose(1, 2)
+        kh = kv[:, :E].reshape(B, Q, H, 32).transpose(1, 2)
+        vh = kv[:, E:].reshape(B, Q, H, 32).transpose(1, 2)
+        want = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * Q, E)
+        assert (got - want).abs().max() < 2e-2, (got - want).abs().max()      # bf16 operands, f32 accumulation
+        assert torch.isfinite(got).all()
