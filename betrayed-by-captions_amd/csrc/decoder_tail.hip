@@ -18,9 +18,10 @@ struct DtLds {
   u32x4 frag[3][DT_STEPS * 64];     // three 32 x 256 bf16 A-fragment images (16 KiB each)
 };
 
-__device__ __forceinline__ void dt_load_b(u32x4 (&bf)[DT_STEPS], const u32x4* __restrict__ wp, int wave, int lane) {
+// B fragments of n-tile `nt` (32 output columns) of a packed [N/32][16][64] weight
+__device__ __forceinline__ void dt_load_b(u32x4 (&bf)[DT_STEPS], const u32x4* __restrict__ wp, int nt, int lane) {
 #pragma unroll
-  for (int s = 0; s < DT_STEPS; ++s) bf[s] = wp[((size_t)wave * DT_STEPS + s) * 64 + lane];
+  for (int s = 0; s < DT_STEPS; ++s) bf[s] = wp[((size_t)nt * DT_STEPS + s) * 64 + lane];
 }
 
 __device__ __forceinline__ void dt_mma(f32x16& acc, const u32x4* __restrict__ a_frag, const u32x4 (&bf)[DT_STEPS], int lane) {
@@ -175,5 +176,135 @@ extern "C" int cgg_decoder_tail_bf16(const float* planes, int nsum, int64_t plan
                      (const u32x4*)w1, b1, (const u32x4*)w2, b2, (const u32x4*)w3, b3, (const u32x4*)wq, bq, y, yp,
                      mask_embed, qn, M);
   CGG_CHECK_LAUNCH("cgg_decoder_tail_bf16");
+  return CGG_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Middle of a decoder layer: attention output projection + residual + post-norm LayerNorm, and (cross-attention
+// only) the self-attention's fused q | k | v projection of the normalised rows -- one launch instead of
+// cgg_linear_rows_bf16(LN epilogue) + cgg_linear_rows_bf16(q|k|v):
+//   x1 = LN(core Wo^T + bo + res);   q = (x1 + pos) Wq^T + bq;  k = (x1 + pos) Wk^T + bk;  v = x1 Wv^T + bv.
+// The LayerNorm runs row-major (one wavefront per row, shuffle reductions: the arithmetic of cgg_ln_chain_kernel) on an
+// f32 LDS tile of the projection, not as the two-pass cross-wave reduction in MFMA layout of cgg_lr2_kernel<true>.
+#define DM_TS 260          // f32 tile row stride (floats): rows r and r+4 of one store land in different banks
+
+struct DmLds {
+  u32x4 frag0[DT_STEPS * 64];           // core, later bf16(x1 + pos)
+  union {
+    float tile[32 * DM_TS];             // projection + bias + residual, f32
+    u32x4 frag1[DT_STEPS * 64];         // bf16(x1), written after every wave has left the tile
+  };
+};
+
+__global__ __launch_bounds__(512) void cgg_decoder_mid_kernel(
+    const float* __restrict__ core, int ldc, const u32x4* __restrict__ wo, const float* __restrict__ bo,
+    const float* __restrict__ res, int ldr, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const float* __restrict__ pos, int pos_rows, const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
+    float* __restrict__ x1, float* __restrict__ qo, float* __restrict__ kvo, int M) {
+  __shared__ DmLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi5 = lane >> 5;
+  const int m0 = blockIdx.x * 32;
+  const int n = wave * 32 + j;
+  const int fslot = ((lane >> 2) * 64 + ((lane >> 1) & 1) * 32) * 8 + 4 * (lane & 1);   // see cgg_decoder_tail_kernel
+
+  // ---- A: attention output rows -> bf16 A fragments; residual / bias / Wo in flight meanwhile ----
+  f32x4 cr[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int m = m0 + 4 * wave + rr;
+    cr[rr] = m < M ? *reinterpret_cast<const f32x4*>(core + (size_t)m * ldc + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4 bf[DT_STEPS];
+  dt_load_b(bf, wo, wave, lane);
+  const float bias_o = bo[n];
+  float rv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+    rv[r] = m < M ? res[(size_t)m * ldr + n] : 0.f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    uint16_t* f16 = reinterpret_cast<uint16_t*>(L.frag0) + fslot + (4 * wave + rr) * 8;
+    *reinterpret_cast<uint2*>(f16) = make_uint2(cgg_pack2(cgg_f2bf(cr[rr][0]), cgg_f2bf(cr[rr][1])),
+                                                cgg_pack2(cgg_f2bf(cr[rr][2]), cgg_f2bf(cr[rr][3])));
+  }
+  __syncthreads();
+  // ---- B: projection + bias + residual -> f32 tile ----
+  f32x16 acc;
+  dt_mma(acc, L.frag0, bf, lane);
+  if (wqkv) dt_load_b(bf, wqkv, wave, lane);                  // q tile of this wave
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi5;
+    L.tile[row * DM_TS + n] = acc[r] + bias_o + rv[r];
+  }
+  __syncthreads();
+  // ---- C: row-major LayerNorm; x1 -> global, bf16(x1 + pos) -> frag0, bf16(x1) kept for frag1 ----
+  uint2 keep[4];
+  {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * lane), be = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
+    constexpr float inv_n = 1.f / (float)DT_C;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * wave + rr, m = m0 + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&L.tile[row * DM_TS + 4 * lane]);
+      float sm = (v[0] + v[1]) + (v[2] + v[3]);
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+      const float mean = sm * inv_n;
+      const f32x4 d = v - mean;
+      float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      const float rstd = rsqrtf(q * inv_n + eps);
+      v = d * rstd * g + be;
+      keep[rr] = make_uint2(cgg_pack2(cgg_f2bf(v[0]), cgg_f2bf(v[1])), cgg_pack2(cgg_f2bf(v[2]), cgg_f2bf(v[3])));
+      if (m < M) *reinterpret_cast<f32x4*>(x1 + (size_t)m * DT_C + 4 * lane) = v;
+      if (wqkv) {
+        f32x4 xp = v;
+        if (m < M) xp += *reinterpret_cast<const f32x4*>(pos + (size_t)(m % pos_rows) * DT_C + 4 * lane);
+        uint16_t* f16 = reinterpret_cast<uint16_t*>(L.frag0) + fslot + row * 8;
+        *reinterpret_cast<uint2*>(f16) =
+            make_uint2(cgg_pack2(cgg_f2bf(xp[0]), cgg_f2bf(xp[1])), cgg_pack2(cgg_f2bf(xp[2]), cgg_f2bf(xp[3])));
+      }
+    }
+  }
+  if (!wqkv) return;
+  __syncthreads();                                            // every wave has read its tile rows
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(L.frag1) + fslot + (4 * wave + rr) * 8) = keep[rr];
+  __syncthreads();
+  // ---- D: q | k from x1 + pos, v from x1 (this wave's 32-column tile of each) ----
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    dt_mma(acc, c < 2 ? L.frag0 : L.frag1, bf, lane);
+    if (c < 2) dt_load_b(bf, wqkv, 8 * (c + 1) + wave, lane);
+    const float bias = bqkv[c * DT_C + n];
+    float* dst = c == 0 ? qo : kvo + (c - 1) * DT_C;
+    const int ldd = c == 0 ? DT_C : 2 * DT_C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+      if (m < M) dst[(size_t)m * ldd + n] = acc[r] + bias;
+    }
+  }
+}
+
+extern "C" int cgg_decoder_mid_bf16(const float* core, int ldc, const void* wo, const float* bo, const float* res, int ldr,
+                                    const float* gamma, const float* beta, float eps, const float* pos, int pos_rows,
+                                    const void* wqkv, const float* bqkv, float* x1, float* q, float* kv, int M, int C,
+                                    cgg_stream_t stream) {
+  CGG_REQUIRE(core && wo && bo && res && gamma && beta && x1, CGG_EINVAL, "cgg_decoder_mid_bf16: null pointer");
+  CGG_REQUIRE(C == DT_C, CGG_EUNSUPPORTED, "cgg_decoder_mid_bf16: C=%d (only 256 is built)", C);
+  CGG_REQUIRE(M > 0 && ldc >= C && ldr >= C && ldc % 4 == 0, CGG_EINVAL, "cgg_decoder_mid_bf16: bad sizes");
+  CGG_REQUIRE(!wqkv || (bqkv && q && kv && pos && pos_rows > 0), CGG_EINVAL,
+              "cgg_decoder_mid_bf16: the q|k|v stage needs bqkv, q, kv and pos");
+  CGG_REQUIRE(cgg_aligned16(core) && cgg_aligned16(wo) && cgg_aligned16(wqkv) && cgg_aligned16(x1) && cgg_aligned16(pos) &&
+                  cgg_aligned16(gamma) && cgg_aligned16(beta),
+              CGG_EALIGN, "cgg_decoder_mid_bf16: 16-B alignment");
+  hipLaunchKernelGGL(cgg_decoder_mid_kernel, dim3((M + 31) / 32), dim3(512), 0, (hipStream_t)stream, core, ldc,
+                     (const u32x4*)wo, bo, res, ldr, gamma, beta, eps, pos, pos_rows, (const u32x4*)wqkv, bqkv, x1, q, kv, M);
+  CGG_CHECK_LAUNCH("cgg_decoder_mid_bf16");
   return CGG_OK;
 }

@@ -625,6 +625,31 @@ def layernorm_chain(a, norm_a, pos=None, norm_b=None):
     return y, yp, z
 
 
+def decoder_mid(core, wo, bo, res, norm, pos=None, qkv=None):
+    """x1 = LN(core @ Wo^T + bo + res) on (M, 256) f32 rows; with qkv = (packed [Wq; Wk; Wv], bias (768,)) and pos (Q, 256)
+    also q = (x1 + pos) Wq^T + bq (M, 256) and kv = [(x1 + pos) Wk^T + bk | x1 Wv^T + bv] (M, 512). -> (x1, q, kv)."""
+    M, C = core.shape
+    for t in (core, res):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32 or t.shape != (M, C):
+            raise CggError('decoder_mid: core / res must be matching (M, C) float32 rows')
+    dev = core.device
+    x1 = torch.empty((M, C), dtype=torch.float32, device=dev)
+    q = kv = None
+    wqkv = bqkv = None
+    if qkv is not None:
+        wqkv, bqkv = qkv
+        q = torch.empty((M, C), dtype=torch.float32, device=dev)
+        kv = torch.empty((M, 2 * C), dtype=torch.float32, device=dev)
+    rc = _lib_().cgg_decoder_mid_bf16(
+        ctypes.c_void_p(core.data_ptr()), core.stride(0), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32),
+        ctypes.c_void_p(res.data_ptr()), res.stride(0), dev_ptr(norm[0], 'gamma', torch.float32),
+        dev_ptr(norm[1], 'beta', torch.float32), float(norm[2]), dev_ptr(pos, 'pos', torch.float32),
+        pos.shape[0] if pos is not None else 0, dev_ptr(wqkv), dev_ptr(bqkv, 'bqkv', torch.float32), dev_ptr(x1),
+        dev_ptr(q), dev_ptr(kv), M, C, stream_ptr(dev))
+    check(rc, 'cgg_decoder_mid_bf16')
+    return x1, q, kv
+
+
 def self_attn_rows_bf16(q, kv, B, num_heads, scale=None):
     """q (M, E), kv (M, 2E) f32 rows (M = B*Q, Q <= 128, head dim 32) -> softmax(scale q k^T) v, (M, E) f32."""
     M, E = q.shape

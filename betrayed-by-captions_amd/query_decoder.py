@@ -267,9 +267,17 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
             bo = runtime.derived_cached('xattn_bo', (ow, ob, b), lambda: (ob + ow @ b[2 * E:]).float().contiguous())
         else:
             core = ops.masked_xattn(q.view(B, Q, E), kv, bits, H).view(M, E)
-        x1, x1p = lr(core, wo, E, bo, res=x, ln=(n0.weight, n0.bias, n0.eps), pos=pos, want_pos=True)
         w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
-        if E % 256 == 0:
+        fused_mid = E == 256 and core.stride(1) == 1
+        if fused_mid:
+            # out-proj + residual + LayerNorm + the self-attention's q | k | v projection: one launch
+            wqkv, bqkv, _ = pk((w,), (b,))
+            x1, q2, kv2 = ops.decoder_mid(core, wo, bo, x, (n0.weight, n0.bias, n0.eps), pos, (wqkv, bqkv))
+        else:
+            x1, x1p = lr(core, wo, E, bo, res=x, ln=(n0.weight, n0.bias, n0.eps), pos=pos, want_pos=True)
+        if fused_mid:
+            pass
+        elif E % 256 == 0:
             # in_proj_weight is already [Wq; Wk; Wv]: one launch, q | k read x1 + pos, v reads x1
             wqkv, bqkv, _ = pk((w,), (b,))
             q2, kv2 = ops.linear_rows_bf16_qkv(x1p, x1, wqkv, bqkv, E)
@@ -286,7 +294,10 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         else:
             core2 = ops.masked_xattn(q2.view(B, Q, E), kv2.view(B, Q, 2 * E), None, sa.num_heads).view(M, E)
         wo, bo, _ = pk((sa.attn.out_proj.weight,), (sa.attn.out_proj.bias,))
-        x2 = lr(core2, wo, E, bo, res=x1, ln=(n1.weight, n1.bias, n1.eps))
+        if fused_mid:
+            x2 = ops.decoder_mid(core2, wo, bo, x1, (n1.weight, n1.bias, n1.eps))[0]
+        else:
+            x2 = lr(core2, wo, E, bo, res=x1, ln=(n1.weight, n1.bias, n1.eps))
         ffn = self.ffns[0]
         w1, b1, F1 = pk((ffn.layers[0][0].weight,), (ffn.layers[0][0].bias,))
         w2, b2, _ = pk((ffn.layers[1].weight,), (ffn.layers[1].bias,))

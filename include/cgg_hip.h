@@ -229,6 +229,15 @@ int cgg_decoder_tail_bf16(const float* planes, int nsum, int64_t plane_stride, i
                           const float* b2, const void* w3, const float* b3, const void* wq, const float* bq, float* y,
                           float* yp, float* mask_embed, float* qn, int M, int C, cgg_stream_t stream);
 
+/* Middle of a query-decoder layer in ONE launch (C == 256): x1 = LayerNorm(core Wo^T + bo + res) (attention output
+ * projection, residual, post-norm; [3P] DetrTransformerDecoderLayer) and, when wqkv != NULL, the self-attention's fused
+ * projection of the result: q = (x1 + pos) Wq^T + bq -> q [M, 256]; [k | v] = [(x1 + pos) Wk^T + bk | x1 Wv^T + bv] ->
+ * kv [M, 512]. wo: 256 x 256, wqkv: 768 x 256 ([Wq; Wk; Wv] = in_proj_weight), packed by cgg_linear_rows_pack.    */
+int cgg_decoder_mid_bf16(const float* core, int ldc, const void* wo, const float* bo, const float* res, int ldr,
+                         const float* gamma, const float* beta, float eps, const float* pos, int pos_rows,
+                         const void* wqkv, const float* bqkv, float* x1, float* q, float* kv, int M, int C,
+                         cgg_stream_t stream);
+
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, b f32 or bf16 (nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
 int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,

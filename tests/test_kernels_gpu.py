@@ -753,3 +753,24 @@ def test_self_attn_rows_bf16(dev):
         want = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * Q, E)
         assert (got - want).abs().max() < 2e-2, (got - want).abs().max()      # bf16 operands, f32 accumulation
         assert torch.isfinite(got).all()
+
+
+def test_decoder_mid_matches_the_launch_chain(dev):
+    g = torch.Generator().manual_seed(70)
+    M, C, Q = 200, 256, 100
+    core = torch.randn(M, C, generator=g).to(dev)
+    res = torch.randn(M, C, generator=g).to(dev)
+    pos = torch.randn(Q, C, generator=g).to(dev)
+    norm = (torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev), 1e-5)
+    wo, bo = (torch.randn(C, C, generator=g) / 16).to(dev), torch.randn(C, generator=g).to(dev)
+    wqkv, bqkv = (torch.randn(3 * C, C, generator=g) / 16).to(dev), torch.randn(3 * C, generator=g).to(dev)
+    pwo, pqkv = ops.pack_linear_weight(wo), ops.pack_linear_weight(wqkv)
+    x1, q, kv = ops.decoder_mid(core, pwo, bo, res, norm, pos, (pqkv, bqkv))
+    x1_0, x1p_0 = ops.linear_rows_bf16(core, pwo, C, bo, res=res, ln=norm, pos=pos, want_pos=True)
+    q0, kv0 = ops.linear_rows_bf16_qkv(x1p_0, x1_0, pqkv, bqkv, C)
+    assert torch.allclose(x1, x1_0, atol=3e-5, rtol=1e-5)
+    assert torch.allclose(q, q0, atol=3e-2, rtol=2e-2) and torch.allclose(kv, kv0, atol=3e-2, rtol=2e-2)
+    ref = torch.nn.functional.layer_norm(core @ wo.t() + bo + res, (C,), norm[0], norm[1], 1e-5)
+    assert (x1 - ref).abs().max() < 0.05
+    only = ops.decoder_mid(core, pwo, bo, res, norm)
+    assert only[1] is None and torch.equal(only[0], x1)
