@@ -50,9 +50,9 @@ PROTOTYPES = {
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
     'cgg_msda_forward_fused_bf16': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 7 + [_c_vp]),
-    'cgg_add_layernorm_kv': (_c_int, [_c_vp, _c_vp, _c_int] + [_c_vp] * 4 + [_c_int, _c_vp, _c_int] + [_c_vp] * 3 +
+    'cgg_add_layernorm_kv': (_c_int, [_c_vp, _c_int, _c_vp, _c_int] + [_c_vp] * 4 + [_c_int, _c_vp, _c_int] + [_c_vp] * 3 +
                              [_c_int, _c_int, _c_f, _c_vp]),
-    'cgg_add_layernorm_ex': (_c_int, [_c_vp, _c_vp, _c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 +
+    'cgg_add_layernorm_ex': (_c_int, [_c_vp, _c_int, _c_vp, _c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 +
                              [_c_int, _c_int, _c_f, _c_vp]),
     'cgg_group_norm_nhwc_workspace_bytes': (_c_i64, [_c_int] * 3),
     'cgg_group_norm_nhwc': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,

@@ -173,26 +173,24 @@ extern "C" int cgg_linear_rows(const float* x, int ldx, const float* w, const fl
 //   y32 (f32 residual stream), y16 = bf16(y) (next GEMM's input), yp16 = bf16(y + pos[row % pos_rows])
 //   (the "query + query_pos" input of the next layer's sampling-offset GEMM). One wave per row, N == 256:
 //   each lane owns 4 consecutive channels (16-B loads / stores).
-template <typename BT>
+__device__ __forceinline__ f32x4 cgg_ln_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 cgg_ln_load4(const uint16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+}
+
+template <typename AT, typename BT>
 __global__ __launch_bounds__(256) void cgg_add_layernorm256_kernel(
-    const float* __restrict__ a, const BT* __restrict__ b, const float* __restrict__ gamma,
+    const AT* __restrict__ a, const BT* __restrict__ b, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ pos, int pos_rows, float* __restrict__ y32,
     uint16_t* __restrict__ y16, uint16_t* __restrict__ yp16, int rows, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const size_t off = (size_t)row * 256 + lane * 4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
-  if (b != nullptr) {
-    if (sizeof(BT) == 4) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(b) + off);
-      v += w;
-    } else {
-      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(b) + off);
-      v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-      v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-    }
-  }
+  f32x4 v = cgg_ln_load4(a + off);
+  if (b != nullptr) v += cgg_ln_load4(b + off);
   float s = (v[0] + v[1]) + (v[2] + v[3]);
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float mean = s * (1.f / 256.f);
@@ -216,7 +214,20 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm256_kernel(
   }
 }
 
-extern "C" int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float* gamma,
+template <typename AT>
+static void add_layernorm_ex_launch(const AT* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+                                    const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, float eps,
+                                    hipStream_t s) {
+  dim3 grid((rows + 3) / 4);
+  if (b_dtype == CGG_F32)
+    hipLaunchKernelGGL((cgg_add_layernorm256_kernel<AT, float>), grid, dim3(256), 0, s, a, (const float*)b, gamma, beta,
+                       pos, pos_rows, y32, (uint16_t*)y16, (uint16_t*)yp16, rows, eps);
+  else
+    hipLaunchKernelGGL((cgg_add_layernorm256_kernel<AT, uint16_t>), grid, dim3(256), 0, s, a, (const uint16_t*)b, gamma,
+                       beta, pos, pos_rows, y32, (uint16_t*)y16, (uint16_t*)yp16, rows, eps);
+}
+
+extern "C" int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma,
                                     const float* beta, const float* pos, int pos_rows, float* y32, void* y16,
                                     void* yp16, int rows, int N, float eps, cgg_stream_t stream) {
   CGG_REQUIRE(a && gamma && beta, CGG_EINVAL, "cgg_add_layernorm_ex: null pointer");
@@ -224,15 +235,13 @@ extern "C" int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, 
   CGG_REQUIRE(rows > 0, CGG_EINVAL, "cgg_add_layernorm_ex: bad sizes");
   CGG_REQUIRE(N == 256, CGG_EUNSUPPORTED, "cgg_add_layernorm_ex: N=%d (only 256 is built)", N);
   CGG_REQUIRE(!yp16 || (pos && pos_rows > 0), CGG_EINVAL, "cgg_add_layernorm_ex: yp16 needs pos");
-  CGG_REQUIRE(b_dtype == CGG_F32 || b_dtype == CGG_BF16, CGG_EUNSUPPORTED, "cgg_add_layernorm_ex: b dtype %d", b_dtype);
+  CGG_REQUIRE((a_dtype == CGG_F32 || a_dtype == CGG_BF16) && (b_dtype == CGG_F32 || b_dtype == CGG_BF16),
+              CGG_EUNSUPPORTED, "cgg_add_layernorm_ex: a / b dtype %d / %d", a_dtype, b_dtype);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((rows + 3) / 4);
-  if (b_dtype == CGG_F32)
-    hipLaunchKernelGGL(cgg_add_layernorm256_kernel<float>, grid, dim3(256), 0, s, a, (const float*)b, gamma, beta,
-                       pos, pos_rows, y32, (uint16_t*)y16, (uint16_t*)yp16, rows, eps);
+  if (a_dtype == CGG_F32)
+    add_layernorm_ex_launch((const float*)a, b, b_dtype, gamma, beta, pos, pos_rows, y32, y16, yp16, rows, eps, s);
   else
-    hipLaunchKernelGGL(cgg_add_layernorm256_kernel<uint16_t>, grid, dim3(256), 0, s, a, (const uint16_t*)b, gamma,
-                       beta, pos, pos_rows, y32, (uint16_t*)y16, (uint16_t*)yp16, rows, eps);
+    add_layernorm_ex_launch((const uint16_t*)a, b, b_dtype, gamma, beta, pos, pos_rows, y32, y16, yp16, rows, eps, s);
   CGG_CHECK_LAUNCH("cgg_add_layernorm_ex");
   return CGG_OK;
 }
@@ -243,26 +252,17 @@ extern "C" int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, 
 // level is one contiguous (B * hw_l, 256) GEMM operand:  m16 = bf16(y + shift[s]),  mp16 = bf16((y + shift[s]) + pos[s]).
 struct LnKvLevels { int n; int start[9]; };
 
-template <typename BT>
+template <typename AT, typename BT>
 __global__ __launch_bounds__(256) void cgg_add_layernorm256_kv_kernel(
-    const float* __restrict__ a, const BT* __restrict__ b, const float* __restrict__ gamma,
+    const AT* __restrict__ a, const BT* __restrict__ b, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ shift, const float* __restrict__ pos, int S, int B,
     LnKvLevels lv, float* __restrict__ y32, uint16_t* __restrict__ m16, uint16_t* __restrict__ mp16, int rows, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const size_t off = (size_t)row * 256 + lane * 4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
-  if (b != nullptr) {
-    if (sizeof(BT) == 4) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(b) + off);
-      v += w;
-    } else {
-      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(b) + off);
-      v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-      v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-    }
-  }
+  f32x4 v = cgg_ln_load4(a + off);
+  if (b != nullptr) v += cgg_ln_load4(b + off);
   float s = (v[0] + v[1]) + (v[2] + v[3]);
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float mean = s * (1.f / 256.f);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm256_kv_kernel(
       make_uint2(cgg_pack2(cgg_f2bf(z[0]), cgg_f2bf(z[1])), cgg_pack2(cgg_f2bf(z[2]), cgg_f2bf(z[3])));
 }
 
-extern "C" int cgg_add_layernorm_kv(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+extern "C" int cgg_add_layernorm_kv(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma, const float* beta,
                                     const float* shift, const float* pos, int S, const int* level_start_host,
                                     int n_levels, float* y32, void* m16, void* mp16, int rows, int N, float eps,
                                     cgg_stream_t stream) {
@@ -306,14 +306,17 @@ extern "C" int cgg_add_layernorm_kv(const float* a, const void* b, int b_dtype, 
                 CGG_EINVAL, "cgg_add_layernorm_kv: level_start must start at 0 and increase (level %d: %d)", l, lv.start[l]);
   }
   lv.start[n_levels] = S;
+  CGG_REQUIRE(a_dtype == CGG_F32 || a_dtype == CGG_BF16, CGG_EUNSUPPORTED, "cgg_add_layernorm_kv: a dtype %d", a_dtype);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4);
-  if (b_dtype == CGG_F32)
-    hipLaunchKernelGGL(cgg_add_layernorm256_kv_kernel<float>, grid, dim3(256), 0, s, a, (const float*)b, gamma, beta,
-                       shift, pos, S, rows / S, lv, y32, (uint16_t*)m16, (uint16_t*)mp16, rows, eps);
-  else
-    hipLaunchKernelGGL(cgg_add_layernorm256_kv_kernel<uint16_t>, grid, dim3(256), 0, s, a, (const uint16_t*)b, gamma,
-                       beta, shift, pos, S, rows / S, lv, y32, (uint16_t*)m16, (uint16_t*)mp16, rows, eps);
+#define CGG_LNKV_LAUNCH(AT, BT)                                                                                          \
+  hipLaunchKernelGGL((cgg_add_layernorm256_kv_kernel<AT, BT>), grid, dim3(256), 0, s, (const AT*)a, (const BT*)b, gamma, \
+                     beta, shift, pos, S, rows / S, lv, y32, (uint16_t*)m16, (uint16_t*)mp16, rows, eps)
+  if (a_dtype == CGG_F32 && b_dtype == CGG_F32) CGG_LNKV_LAUNCH(float, float);
+  else if (a_dtype == CGG_F32) CGG_LNKV_LAUNCH(float, uint16_t);
+  else if (b_dtype == CGG_F32) CGG_LNKV_LAUNCH(uint16_t, float);
+  else CGG_LNKV_LAUNCH(uint16_t, uint16_t);
+#undef CGG_LNKV_LAUNCH
   CGG_CHECK_LAUNCH("cgg_add_layernorm_kv");
   return CGG_OK;
 }

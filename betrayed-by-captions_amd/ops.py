@@ -426,12 +426,13 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
     bf16(y + pos[row % len(pos)]) | None) from ONE pass."""
     N = a.shape[-1]
     rows = a.numel() // N
-    y32 = torch.empty_like(a) if want_f32 else None
+    y32 = torch.empty(a.shape, dtype=torch.float32, device=a.device) if want_f32 else None
     y16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
     yp16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_pos else None
+    adt = CGG_BF16 if a.dtype == torch.bfloat16 else CGG_F32
     bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
     rc = _lib_().cgg_add_layernorm_ex(
-        dev_ptr(a, 'a', torch.float32), dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32),
+        dev_ptr(a, 'a'), adt, dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32),
         dev_ptr(beta, 'beta', torch.float32), dev_ptr(pos, 'pos', torch.float32),
         pos.shape[0] if pos is not None else 0, dev_ptr(y32), dev_ptr(y16), dev_ptr(yp16), rows, N, float(eps),
         stream_ptr(a.device))
@@ -445,12 +446,13 @@ def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=T
     f32), both LEVEL-MAJOR: (B * S, 256) with level l = rows [B * start_l, B * start_{l+1}) laid out (B, hw_l, 256).
     Returns (y f32 | None, m16, mp16)."""
     B, S, N = a.shape
-    y32 = torch.empty_like(a) if want_f32 else None
+    y32 = torch.empty(a.shape, dtype=torch.float32, device=a.device) if want_f32 else None
     m16 = torch.empty((B * S, N), dtype=torch.bfloat16, device=a.device)
     mp16 = torch.empty((B * S, N), dtype=torch.bfloat16, device=a.device)
+    adt = CGG_BF16 if a.dtype == torch.bfloat16 else CGG_F32
     bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
     rc = _lib_().cgg_add_layernorm_kv(
-        dev_ptr(a, 'a', torch.float32), dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32),
+        dev_ptr(a, 'a'), adt, dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32),
         dev_ptr(beta, 'beta', torch.float32), dev_ptr(shift, 'shift', torch.float32), dev_ptr(pos, 'pos', torch.float32),
         S, _int_array(level_start), len(level_start), dev_ptr(y32), dev_ptr(m16), dev_ptr(mp16), B * S, N, float(eps),
         stream_ptr(a.device))

@@ -469,6 +469,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                                 act_cfg=act_cfg))
         self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1, stride=1, padding=0)
         self.num_outs = num_outs
+        # throughput-mode (bf16) encoder stream: keep the residual between LayerNorms in bf16 (the rows the GEMMs read
+        # anyway) instead of a separate f32 copy; False restores the f32 residual stream
+        import os
+        self.stream_residual_bf16 = not os.environ.get('CGG_STREAM_RES_F32')
         self._ref_cache = {}
 
     def init_weights(self):
@@ -534,7 +538,12 @@ class MSDeformAttnPixelDecoder(nn.Module):
             a16 = ops.msda_forward_fused_bf16(value, level_hw, level_start, offs, ref, attn.num_points)
             o16 = F.linear(a16, cc(attn.output_proj.weight), cc(attn.output_proj.bias))
             n0, n1 = layer.norms
-            src, x16, _ = ops.add_layernorm_stream(src, o16, n0.weight, n0.bias, n0.eps)
+            if self.stream_residual_bf16:
+                # residual stream in bf16: the LayerNorm reads the same bf16 rows the GEMMs read (66 instead of 132 MB)
+                _, x16, _ = ops.add_layernorm_stream(x16, o16, n0.weight, n0.bias, n0.eps, want_f32=False)
+                src = x16
+            else:
+                src, x16, _ = ops.add_layernorm_stream(src, o16, n0.weight, n0.bias, n0.eps)
             ffn = layer.ffns[0]
             # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a separate pass over the (B, N, 1024) hidden
             h16 = torch._addmm_activation(cc(ffn.layers[0][0].bias), x16.view(B * N, C),
@@ -547,6 +556,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                                       level_start)
                 return src, (m16, mp16)
             src, x16, xp16 = ops.add_layernorm_stream(src, f16, n1.weight, n1.bias, n1.eps, pos=pos,
+                                                      want_f32=last or not self.stream_residual_bf16,
                                                       want_bf16=not last, want_pos=not last)
         return src if kv_tables is None else (src, None)
 

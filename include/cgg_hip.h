@@ -238,9 +238,9 @@ int cgg_decoder_mid_bf16(const float* core, int ldc, const void* wo, const float
                          const void* wqkv, const float* bqkv, float* x1, float* q, float* kv, int M, int C,
                          cgg_stream_t stream);
 
-/* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, b f32 or bf16 (nullable), with up
+/* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
-int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma, const float* beta,
                          const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
                          float eps, cgg_stream_t stream);
 
@@ -249,7 +249,7 @@ int cgg_add_layernorm_ex(const float* a, const void* b, int b_dtype, const float
  * rows level_start[l] .. level_start[l+1] of each batch's S rows -- so that every level is one contiguous GEMM operand:
  *   m16 = bf16(y + shift[s]),  mp16 = bf16((y + shift[s]) + pos[s]),  s = row % S;  shift, pos: [S, 256] f32.
  * level_start_host: n_levels ints on the HOST (start[0] == 0, increasing, < S).                                   */
-int cgg_add_layernorm_kv(const float* a, const void* b, int b_dtype, const float* gamma, const float* beta,
+int cgg_add_layernorm_kv(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma, const float* beta,
                          const float* shift, const float* pos, int S, const int* level_start_host, int n_levels,
                          float* y32, void* m16, void* mp16, int rows, int N, float eps, cgg_stream_t stream);
 

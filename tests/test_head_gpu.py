@@ -339,3 +339,27 @@ def test_swin_b_200_queries_detector(dev):
     for r in (res32, res16):
         labels, boxes, masks = r[0]['all_results']
         assert masks.shape[1:] == (H, W) and torch.isfinite(boxes).all()
+
+
+def test_lean_decode_equals_full_decode(dev):
+    """Inference-only decode (cgg_decoder_tail_bf16 between layers, cached weight-only prologue, intermediate class
+    heads skipped) returns the final predictions of the full stream decode on the same encoding."""
+    from cgg_amd import registry
+    from util import head_cfg, randomize
+    cfg = small_cfg(num_queries=20, depth=50)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        head = registry.build_head(head_cfg(cfg))
+    randomize(head, seed=6)
+    head = head.to(dev).eval()
+    B, H, W = 2, 128, 160
+    feats = synthetic.backbone_feats(B, H, W, channels=(256, 512, 1024, 2048), seed=4)
+    feats16 = [f.to(dev).bfloat16().contiguous(memory_format=torch.channels_last) for f in feats]
+    with torch.no_grad(), runtime.precision_scope('bf16'):
+        enc = head._encode(feats16)
+        assert enc['stream'] and head._lean_decode_ok(256)
+        full = head._decode_stream(B, enc['kvs'], enc['sizes'], enc['packed_full'], enc['pooled'], True)
+        lean = head._decode_stream(B, enc['kvs'], enc['sizes'], enc['packed_full'], enc['pooled'], False)
+    assert all(v is None for v in lean[2][:-1]) and len(lean[2]) == len(full[2])
+    for k in range(3):
+        assert torch.equal(lean[k][-1], full[k][-1])
