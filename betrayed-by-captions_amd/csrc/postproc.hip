@@ -249,10 +249,11 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
         ymin = min(ymin, oy);
         ymax = max(ymax, oy);
       }
-      const uint4 pk = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+      const u32x4_t pkv = {packed[0], packed[1], packed[2], packed[3]};
       for (int d = d0; d < d1; ++d) {
         const size_t slot = dest_off != nullptr ? (size_t)dest_slot[d] : (size_t)i;
-        *reinterpret_cast<uint4*>(masks + slot * npix + (size_t)oy * g.out_w + ox0) = pk;
+        __builtin_nontemporal_store(pkv, reinterpret_cast<u32x4_t*>(masks + slot * npix + (size_t)oy * g.out_w + ox0));
       }
     }
   }
