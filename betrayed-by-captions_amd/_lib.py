@@ -47,6 +47,7 @@ PROTOTYPES = {
     'cgg_self_attn_rows_bf16': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 4 + [_c_f, _c_vp]),
     'cgg_decoder_mid_bf16': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int] +
                              [_c_vp] * 5 + [_c_int, _c_int, _c_vp]),
+    'cgg_decoder_ffn_bf16': (_c_int, [_c_vp, _c_int] + [_c_vp] * 5 + [_c_int] * 3 + [_c_vp]),
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
     'cgg_msda_forward_fused_bf16': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 7 + [_c_vp]),

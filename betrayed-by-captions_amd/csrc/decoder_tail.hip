@@ -308,3 +308,75 @@ extern "C" int cgg_decoder_mid_bf16(const float* core, int ldc, const void* wo, 
   CGG_CHECK_LAUNCH("cgg_decoder_mid_bf16");
   return CGG_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// The decoder layer's FFN (256 -> F -> 256, ReLU) as ONE launch: workgroup (cb, rb) computes the 32 x 256 block
+// h[rb, 256 cb ..] = relu(x W1^T + b1) and multiplies it straight away with the matching K-slice of W2 -- the
+// split-K partition of the second projection IS the column partition of the first, so no workgroup ever needs another
+// one's hidden block and h never leaves LDS. Output = F / 256 partial planes [cb][M][256] (b2 and the residual x in
+// plane 0), summed in fixed order by cgg_decoder_tail_bf16 / cgg_layernorm_chain: deterministic, no atomics.
+__global__ __launch_bounds__(512) void cgg_decoder_ffn_kernel(const float* __restrict__ x, int ldx,
+                                                              const u32x4* __restrict__ w1, const float* __restrict__ b1,
+                                                              const u32x4* __restrict__ w2, const float* __restrict__ b2,
+                                                              float* __restrict__ planes, int M, int F) {
+  __shared__ __attribute__((aligned(16))) u32x4 frag[2][DT_STEPS * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi5 = lane >> 5;
+  const int cb = blockIdx.x, m0 = blockIdx.y * 32;
+  const int n = wave * 32 + j;
+  const int fslot = ((lane >> 2) * 64 + ((lane >> 1) & 1) * 32) * 8 + 4 * (lane & 1);
+  f32x4 xr[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int m = m0 + 4 * wave + rr;
+    xr[rr] = m < M ? *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4 bf[DT_STEPS];
+  dt_load_b(bf, w1, cb * 8 + wave, lane);                     // W1 rows 256 cb + 32 wave .. (K = 256: 16 k-steps)
+  const float bias1 = b1[cb * DT_C + n];
+  const float bias2 = cb == 0 ? b2[n] : 0.f;
+  float rv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+    rv[r] = (cb == 0 && m < M) ? x[(size_t)m * ldx + n] : 0.f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    uint16_t* f16 = reinterpret_cast<uint16_t*>(frag[0]) + fslot + (4 * wave + rr) * 8;
+    *reinterpret_cast<uint2*>(f16) = make_uint2(cgg_pack2(cgg_f2bf(xr[rr][0]), cgg_f2bf(xr[rr][1])),
+                                                cgg_pack2(cgg_f2bf(xr[rr][2]), cgg_f2bf(xr[rr][3])));
+  }
+  __syncthreads();
+  f32x16 acc;
+  dt_mma(acc, frag[0], bf, lane);
+  // W2 [256, F] packed [8 n-tiles][F / 16 k-steps][64]: this workgroup's K-slice = k-steps 16 cb .. 16 cb + 15
+  const int KS2 = F >> 4;
+#pragma unroll
+  for (int s = 0; s < DT_STEPS; ++s) bf[s] = w2[((size_t)wave * KS2 + cb * DT_STEPS + s) * 64 + lane];
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias1, 0.f);
+  dt_store_frag(frag[1], v, wave, j, hi5);
+  __syncthreads();
+  dt_mma(acc, frag[1], bf, lane);
+  float* out = planes + (size_t)cb * M * DT_C;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+    if (m < M) out[(size_t)m * DT_C + n] = acc[r] + bias2 + rv[r];
+  }
+}
+
+extern "C" int cgg_decoder_ffn_bf16(const float* x, int ldx, const void* w1, const float* b1, const void* w2,
+                                    const float* b2, float* planes, int M, int C, int F, cgg_stream_t stream) {
+  CGG_REQUIRE(x && w1 && b1 && w2 && b2 && planes, CGG_EINVAL, "cgg_decoder_ffn_bf16: null pointer");
+  CGG_REQUIRE(C == DT_C, CGG_EUNSUPPORTED, "cgg_decoder_ffn_bf16: C=%d (only 256 is built)", C);
+  CGG_REQUIRE(M > 0 && F >= 256 && F % 256 == 0 && ldx >= C && ldx % 4 == 0, CGG_EUNSUPPORTED,
+              "cgg_decoder_ffn_bf16: F=%d must be a multiple of 256 (ldx=%d)", F, ldx);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w1) && cgg_aligned16(w2), CGG_EALIGN, "cgg_decoder_ffn_bf16: alignment");
+  hipLaunchKernelGGL(cgg_decoder_ffn_kernel, dim3(F / 256, (M + 31) / 32), dim3(512), 0, (hipStream_t)stream, x, ldx,
+                     (const u32x4*)w1, b1, (const u32x4*)w2, b2, planes, M, F);
+  CGG_CHECK_LAUNCH("cgg_decoder_ffn_bf16");
+  return CGG_OK;
+}

@@ -652,6 +652,20 @@ def decoder_mid(core, wo, bo, res, norm, pos=None, qkv=None):
     return x1, q, kv
 
 
+def decoder_ffn(x, w1, b1, w2, b2, F):
+    """x (M, 256) f32 rows -> (F / 256, M, 256) partial planes of x + relu(x W1^T + b1) W2^T + b2 (sum them in plane
+    order: `decoder_tail` / `layernorm_chain`). w1 (F x 256), w2 (256 x F) packed by `pack_linear_weight`."""
+    M, C = x.shape
+    if x.stride(1) != 1 or x.dtype != torch.float32 or F % 256:
+        raise CggError('decoder_ffn: x must be (M, C) float32 rows and F a multiple of 256')
+    planes = torch.empty((F // 256, M, C), dtype=torch.float32, device=x.device)
+    rc = _lib_().cgg_decoder_ffn_bf16(ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(w1),
+                                      dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2), dev_ptr(b2, 'b2', torch.float32),
+                                      dev_ptr(planes), M, C, int(F), stream_ptr(x.device))
+    check(rc, 'cgg_decoder_ffn_bf16')
+    return planes
+
+
 def self_attn_rows_bf16(q, kv, B, num_heads, scale=None):
     """q (M, E), kv (M, 2E) f32 rows (M = B*Q, Q <= 128, head dim 32) -> softmax(scale q k^T) v, (M, E) f32."""
     M, E = q.shape

@@ -301,8 +301,11 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         ffn = self.ffns[0]
         w1, b1, F1 = pk((ffn.layers[0][0].weight,), (ffn.layers[0][0].bias,))
         w2, b2, _ = pk((ffn.layers[1].weight,), (ffn.layers[1].bias,))
-        h = lr(x2, w1, F1, b1, relu_cols=F1)
-        t = lr(h, w2, E, b2, res=x2, ksplit=8 if F1 >= 1024 else 1)
+        if E == 256 and F1 % 256 == 0 and x2.stride(1) == 1:
+            t = ops.decoder_ffn(x2, w1, b1, w2, b2, F1)          # both projections, hidden block in LDS
+        else:
+            h = lr(x2, w1, F1, b1, relu_cols=F1)
+            t = lr(h, w2, E, b2, res=x2, ksplit=8 if F1 >= 1024 else 1)
         if raw:
             return t if t.dim() == 3 else t.unsqueeze(0)
         return ops.layernorm_chain(t, (n2.weight, n2.bias, n2.eps), pos,

@@ -238,6 +238,14 @@ int cgg_decoder_mid_bf16(const float* core, int ldc, const void* wo, const float
                          const void* wqkv, const float* bqkv, float* x1, float* q, float* kv, int M, int C,
                          cgg_stream_t stream);
 
+/* The decoder layer's FFN ([3P] mmcv FFN: Linear(256, F) - ReLU - Linear(F, 256), + identity) in ONE launch: the split-K
+ * partition of the second projection is the column partition of the first, so each workgroup keeps its 32 x 256 hidden
+ * block in LDS. planes [F / 256][M][256] f32: partial sums of x + (relu(x W1^T + b1)) W2^T + b2 (b2 and x in plane 0),
+ * to be added in plane order by cgg_decoder_tail_bf16 / cgg_layernorm_chain. w1: F x 256, w2: 256 x F, packed by
+ * cgg_linear_rows_pack; F % 256 == 0.                                                                              */
+int cgg_decoder_ffn_bf16(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                         float* planes, int M, int C, int F, cgg_stream_t stream);
+
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
 int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma, const float* beta,

@@ -774,3 +774,20 @@ def test_decoder_mid_matches_the_launch_chain(dev):
     assert (x1 - ref).abs().max() < 0.05
     only = ops.decoder_mid(core, pwo, bo, res, norm)
     assert only[1] is None and torch.equal(only[0], x1)
+
+
+def test_decoder_ffn_matches_the_two_launches(dev):
+    g = torch.Generator().manual_seed(71)
+    M, C, F = 200, 256, 2048
+    x = torch.randn(M, C, generator=g).to(dev)
+    w1, b1 = (torch.randn(F, C, generator=g) / 16).to(dev), torch.randn(F, generator=g).to(dev)
+    w2, b2 = (torch.randn(C, F, generator=g) / 45).to(dev), torch.randn(C, generator=g).to(dev)
+    p1, p2 = ops.pack_linear_weight(w1), ops.pack_linear_weight(w2)
+    planes = ops.decoder_ffn(x, p1, b1, p2, b2, F)
+    assert planes.shape == (F // 256, M, C)
+    h = ops.linear_rows_bf16(x, p1, F, b1, relu_cols=F)
+    want = ops.linear_rows_bf16(h, p2, C, b2, res=x, ksplit=8)
+    # same bf16 operands, same per-plane K ranges -> the planes themselves agree exactly
+    assert torch.equal(planes, want)
+    ref = x + torch.relu(x @ w1.t() + b1) @ w2.t() + b2
+    assert (planes.sum(0) - ref).abs().max() < 0.05 * ref.abs().max()
