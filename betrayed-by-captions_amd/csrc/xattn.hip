@@ -209,6 +209,10 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
   if (wave >= nmt || h >= H) return;
 
   const int qi = wave * 32 + j;
+  // VALU diet (the kernel is issue-bound, not memory-bound): scores live in the log2 domain (log2 e folded into the
+  // query scale -> one v_exp_f32 per probability, no multiply), the (max, sum) partials are written in that domain and
+  // cgg_xattn_combine_wave(log2 = 1) rescales with exp2; the chunk tail is folded into the mask word once per step
+  const float scale2 = scale * 1.44269504088896341f;
   bf16x8 qb[2];
   {
     const bool ok = qi < Q;
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
       uint16_t t[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        t[e] = cgg_f2bf(ok ? a[e] * scale : 0.f);
-        t[4 + e] = cgg_f2bf(ok ? c[e] * scale : 0.f);
+        t[e] = cgg_f2bf(ok ? a[e] * scale2 : 0.f);
+        t[4 + e] = cgg_f2bf(ok ? c[e] * scale2 : 0.f);
       }
       const uint4 u = make_uint4(cgg_pack2(t[0], t[1]), cgg_pack2(t[2], t[3]), cgg_pack2(t[4], t[5]), cgg_pack2(t[6], t[7]));
       qb[ks] = __builtin_bit_cast(bf16x8, u);
@@ -249,24 +253,24 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0), qb[0], sc, 0, 0, 0);
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1), qb[1], sc, 0, 0, 0);
-    const uint32_t mw = Ms[qi * cws + ((s0 - s_begin) >> 5)];
+    uint32_t mw = Ms[qi * cws + ((s0 - s_begin) >> 5)];
+    if (s0 + 32 > s_end) mw |= ~0u << (s_end - s0);            // keys past the chunk end (last step only)
+    mw >>= 4 * hi;                                               // this lane's keys: bits (r&3) + 8 (r>>2)
     float rmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ki = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const bool blocked = ((mw >> ki) & 1u) || (s0 + ki >= s_end);
-      sc[r] = blocked ? -INFINITY : sc[r];
+      sc[r] = (mw & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : sc[r];
       rmax = fmaxf(rmax, sc[r]);
     }
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
     const float m_new = fmaxf(m_run, rmax);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = expf(m_run - m_use);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
     float psum = 0.f;
     uint16_t pb[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = expf(sc[r] - m_use);
+      const float p = __builtin_amdgcn_exp2f(sc[r] - m_use);
       psum += p;
       pb[r] = cgg_f2bf(p);
     }
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict
 __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __restrict__ ws_o,
                                                               const float* __restrict__ ws_ml,
                                                               float* __restrict__ out, int B, int Q, int H,
-                                                              int nchunks) {
+                                                              int nchunks, int log2_domain) {
   constexpr int D = 32;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, h, q) flattened as ((b*H + h)*Q + q)
   const int lane = threadIdx.x & 63;
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __res
   }
   float M = mc;
   for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
-  const float f = (mc == -INFINITY) ? 0.f : expf(mc - M);
+  const float f = (mc == -INFINITY) ? 0.f : (log2_domain ? __builtin_amdgcn_exp2f(mc - M) : expf(mc - M));
   float den = f * lc;
   for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
   const int d = lane & 31, half = lane >> 5;
@@ -509,16 +513,20 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __res
   }
 }
 
-static void xattn_combine_launch(const float* ws_o, const float* ws_ml, float* out, int B, int Q, int H, int D, int nch,
-                                 hipStream_t s) {
+static int xattn_combine_launch(const float* ws_o, const float* ws_ml, float* out, int B, int Q, int H, int D, int nch,
+                                hipStream_t s, int log2_domain) {
   if (nch <= 64 && D == 32) {
     const int rows = B * H * Q;
-    hipLaunchKernelGGL(cgg_xattn_combine_wave, dim3((rows + 3) / 4), dim3(256), 0, s, ws_o, ws_ml, out, B, Q, H, nch);
+    hipLaunchKernelGGL(cgg_xattn_combine_wave, dim3((rows + 3) / 4), dim3(256), 0, s, ws_o, ws_ml, out, B, Q, H, nch,
+                       log2_domain);
+  } else if (log2_domain) {
+    return -1;                           // callers keep nch <= 64 for the log2-domain kernel
   } else {
     const long long total = (long long)B * Q * H * D;
     hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o, ws_ml, out, B,
                        Q, H, D, nch);
   }
+  return 0;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -565,7 +573,7 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
   hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
                      bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
-  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s);
+  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 0);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
   return CGG_OK;
 }
@@ -591,7 +599,10 @@ extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, cons
   hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, (H + 1) / 2, B), dim3(512), lds, s, q, (const uint16_t*)k,
                      (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(partial)");
-  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s);
+  if (nch > 1) {
+    CGG_REQUIRE(xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 1) == 0, CGG_EUNSUPPORTED,
+                "cgg_masked_xattn_forward_bf16: %d key chunks (> 64)", nch);
+  }
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(combine)");
   return CGG_OK;
 }
