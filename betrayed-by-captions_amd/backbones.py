@@ -5,6 +5,8 @@ parameter names (`conv1`, `bn1`, `layer{1-4}.N.{conv,bn}{1-3}`, `downsample.{0,1
 mmdet ResNet checkpoints load unchanged. Convolutions run on MIOpen (bf16 autocast in throughput mode);
 the backbone is outside the hand-written-kernel scope of the hot path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -191,6 +193,12 @@ class ResNet(nn.Module):
             if sh > 1 or sw > 1:
                 x = x[:, ::sh, ::sw, :].contiguous()
             x2 = x.reshape(-1, x.shape[-1])
+            if res is not None:
+                r2 = res.reshape(-1, res.shape[-1])
+                if r2.is_contiguous() and x2.is_contiguous() and w2.is_contiguous():
+                    # relu(x W^T + b + identity) as one hipBLASLt call (residual via beta = 1)
+                    y = ops.gemm_bias_res_act_bf16(x2, w2, b, r2, relu)
+                    return y.view(x.shape[0], x.shape[1], x.shape[2], -1)
             if relu and res is None:
                 y = torch._addmm_activation(b, x2, w2.t())
             else:

@@ -816,3 +816,34 @@ def bias_relu_maxpool_nhwc(x, bias):
                                             dev_ptr(y), B, H, W, C, stream_ptr(x.device))
     check(rc, 'cgg_bias_relu_maxpool_nhwc')
     return y
+
+
+_BLASLT_READY = False
+
+
+def _blaslt_init():
+    """dlopen the hipBLASLt copy torch itself uses (one library instance per process)."""
+    global _BLASLT_READY
+    if not _BLASLT_READY:
+        import os
+        cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libhipblaslt.so')
+        path = cand if os.path.exists(cand) else 'libhipblaslt.so'
+        check(_lib_().cgg_blaslt_init(path.encode()), 'cgg_blaslt_init')
+        _BLASLT_READY = True
+
+
+def gemm_bias_res_act_bf16(x, w, bias, res=None, relu=True):
+    """y = act(x @ w^T + bias + res): x (M, K), w (N, K), bias (N,), res (M, N) bf16 contiguous -> (M, N) bf16, one
+    hipBLASLt call (residual through beta = 1, bias + ReLU in the epilogue)."""
+    _blaslt_init()
+    M, K = x.shape
+    N = w.shape[0]
+    for t, n in ((x, 'x'), (w, 'w'), (res, 'res')):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous()):
+            raise CggError('gemm_bias_res_act_bf16: %s must be a contiguous bfloat16 tensor' % n)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    rc = _lib_().cgg_gemm_bias_res_act_bf16(dev_ptr(x, 'x', torch.bfloat16), dev_ptr(w, 'w', torch.bfloat16),
+                                            dev_ptr(bias, 'bias', torch.bfloat16), dev_ptr(res), dev_ptr(y), M, N, K,
+                                            int(bool(relu)), stream_ptr(x.device))
+    check(rc, 'cgg_gemm_bias_res_act_bf16')
+    return y

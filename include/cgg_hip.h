@@ -33,6 +33,7 @@ extern "C" {
 #define CGG_EINVAL (-1)       /* bad argument (null pointer, non-positive size, ...)            */
 #define CGG_EUNSUPPORTED (-2) /* shape / dtype combination this build has no kernel for        */
 #define CGG_EALIGN (-3)       /* pointer not aligned as the kernel requires (16 B)             */
+#define CGG_ELIBRARY (-4)     /* a vendor library call (hipBLASLt) failed                      */
 
 /* dtype tags */
 #define CGG_F32 0
@@ -284,6 +285,15 @@ int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, 
  * Requires C % 8 == 0 and 16-byte aligned pointers.                                                             */
 int cgg_bias_act_nhwc(void* y, const void* bias, const void* res, int64_t rows, int C, int relu,
                       cgg_stream_t stream);
+
+/* Library GEMM with the residual epilogue ATen does not expose, for `relu(conv3(x) + identity)` of a BN-folded
+ * [3P] mmdet ResNet Bottleneck (1x1 convolution on channel-last bf16 rows):
+ *   y[M, N] = act(x[M, K] w[N, K]^T + bias[N] + res[M, N])   (bf16 in / out, f32 accumulation; res nullable; relu 0/1)
+ * = ONE hipBLASLt matmul (beta = 1, HIPBLASLT_EPILOGUE_RELU_BIAS). cgg_blaslt_init(path) dlopens the hipBLASLt copy the
+ * process already uses (NULL / "" = "libhipblaslt.so") and must be called once before.                              */
+int cgg_blaslt_init(const char* libpath);
+int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int M, int N,
+                               int K, int relu, cgg_stream_t stream);
 
 /* Stem tail of the BN-folded [3P] mmdet ResNet (`maxpool(relu(bn1(conv1(x))))`), channel-last bf16, one pass:
  *   y[B, Ho, Wo, C] = relu(maxpool3x3/s2/p1(x[B, H, W, C]) + bias[C]),  Ho = (H - 1) / 2 + 1 (same for W).          */

@@ -791,3 +791,17 @@ def test_decoder_ffn_matches_the_two_launches(dev):
     assert torch.equal(planes, want)
     ref = x + torch.relu(x @ w1.t() + b1) @ w2.t() + b2
     assert (planes.sum(0) - ref).abs().max() < 0.05 * ref.abs().max()
+
+
+def test_gemm_bias_res_act_bf16(dev):
+    g = torch.Generator().manual_seed(72)
+    for (M, N, K, relu, has_res) in [(1024, 256, 64, True, True), (520, 512, 128, False, True), (256, 64, 256, True, False)]:
+        x = torch.randn(M, K, generator=g).bfloat16().to(dev)
+        w = (torch.randn(N, K, generator=g) / 8).bfloat16().to(dev)
+        b = torch.randn(N, generator=g).bfloat16().to(dev)
+        r = torch.randn(M, N, generator=g).bfloat16().to(dev) if has_res else None
+        got = ops.gemm_bias_res_act_bf16(x, w, b, r, relu)
+        want = x.float() @ w.float().t() + b.float() + (r.float() if has_res else 0)
+        if relu:
+            want = want.relu()
+        assert (got.float() - want).abs().max() <= 0.02 * want.abs().max() + 0.02
