@@ -60,6 +60,8 @@ PROTOTYPES = {
                                        _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_pack_mask_feature_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_blaslt_init': (_c_int, [ctypes.c_char_p]),
+    'cgg_blaslt_set_tuning': (_c_int, [_c_int]),
+    'cgg_blaslt_last_tuning': (_c_int, [_c_vp, _c_vp]),
     'cgg_gemm_bias_res_act_bf16': (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     'cgg_bias_relu_maxpool_nhwc': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_bias_act_nhwc': (_c_int, [_c_vp] * 3 + [_c_i64, _c_int, _c_int, _c_vp]),

@@ -39,7 +39,9 @@ struct LtPlan {
 
 LtApi g_lt;
 std::mutex g_lt_mutex;
-std::map<std::tuple<int, int, int, int, int>, LtPlan> g_plans;   // (M, N, K, relu, has_res)
+int g_tune_candidates = 1;        // > 1: time that many heuristic candidates at first use of a shape (outside captures)
+float g_last_tune_us[2] = {0.f, 0.f};   // (heuristic top-1, chosen) of the most recent tuning, for reporting
+std::map<std::tuple<int, int, int, int, int>, LtPlan> g_plans;   // (M, N, K, relu + 2 has_bias, has_res)
 
 template <typename F>
 bool lt_sym(F& f, const char* name) {
@@ -74,7 +76,8 @@ extern "C" int cgg_blaslt_init(const char* libpath) {
 // y[M, N] = act(x[M, K] w[N, K]^T + bias[N] + res[M, N]); all bf16, row-major, f32 accumulation. res nullable.
 extern "C" int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int M,
                                           int N, int K, int relu, cgg_stream_t stream) {
-  CGG_REQUIRE(x && w && bias && y, CGG_EINVAL, "cgg_gemm_bias_res_act_bf16: null pointer");
+  CGG_REQUIRE(x && w && y, CGG_EINVAL, "cgg_gemm_bias_res_act_bf16: null pointer");
+  CGG_REQUIRE(bias || !relu, CGG_EUNSUPPORTED, "cgg_gemm_bias_res_act_bf16: ReLU without bias is not built");
   CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "cgg_gemm_bias_res_act_bf16: bad sizes");
   CGG_REQUIRE(g_lt.handle != nullptr, CGG_EINVAL, "cgg_gemm_bias_res_act_bf16: call cgg_blaslt_init first");
   CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w) && cgg_aligned16(res) && cgg_aligned16(y) && K % 8 == 0 && N % 8 == 0,
@@ -82,7 +85,7 @@ extern "C" int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const vo
   LtPlan plan;
   {
     std::lock_guard<std::mutex> lock(g_lt_mutex);
-    const auto key = std::make_tuple(M, N, K, relu ? 1 : 0, res ? 1 : 0);
+    const auto key = std::make_tuple(M, N, K, (relu ? 1 : 0) + (bias ? 2 : 0), res ? 1 : 0);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
       // column-major view: D^T (N x M, ld N) = op_T(W as K x N, ld K) * (x^T as K x M, ld K)
@@ -91,7 +94,7 @@ extern "C" int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const vo
       const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
       ok = ok && g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
       ok = ok && g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
-      const uint32_t epi = relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
+      const uint32_t epi = !bias ? HIPBLASLT_EPILOGUE_DEFAULT : (relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS);
       ok = ok && g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS;
       const int32_t bias_type = HIP_R_16BF;
       ok = ok && g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)) ==
@@ -102,22 +105,53 @@ extern "C" int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const vo
       ok = ok && g_lt.LayoutCreate(&p.d, HIP_R_16BF, N, M, N) == HIPBLAS_STATUS_SUCCESS;
       CGG_REQUIRE(ok, CGG_ELIBRARY, "cgg_gemm_bias_res_act_bf16: hipBLASLt descriptor setup failed");
       // the heuristic needs the bias pointer attribute to be present to pick a bias-capable solution
-      ok = g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
+      if (bias) ok = g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
       hipblasLtMatmulPreference_t pref;
       ok = ok && g_lt.PrefCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
       const uint64_t wsmax = g_lt.workspace_bytes;
       ok = ok && g_lt.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax)) == HIPBLAS_STATUS_SUCCESS;
-      hipblasLtMatmulHeuristicResult_t heur[1];
+      constexpr int MAXC = 32;
+      hipblasLtMatmulHeuristicResult_t heur[MAXC];
       int found = 0;
-      ok = ok && g_lt.Heuristic(g_lt.handle, p.desc, p.a, p.b, p.c, p.d, pref, 1, heur, &found) == HIPBLAS_STATUS_SUCCESS;
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+      const int want = (cap == hipStreamCaptureStatusNone) ? (g_tune_candidates < 1 ? 1 : (g_tune_candidates > MAXC ? MAXC : g_tune_candidates)) : 1;
+      ok = ok && g_lt.Heuristic(g_lt.handle, p.desc, p.a, p.b, p.c, p.d, pref, want, heur, &found) == HIPBLAS_STATUS_SUCCESS;
       CGG_REQUIRE(ok && found > 0, CGG_EUNSUPPORTED, "cgg_gemm_bias_res_act_bf16: no hipBLASLt solution for %dx%dx%d", M, N, K);
-      p.algo = heur[0].algo;
-      p.ws = heur[0].workspaceSize;
+      int best = 0;
+      if (found > 1) {
+        // the library's ranking is a model; the shapes here are few and fixed, so measure: 2 warm + 5 timed launches each
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        const float alpha = 1.f, beta = res ? 1.f : 0.f;
+        float best_ms = 1e30f;
+        for (int c = 0; c < found; ++c) {
+          if (heur[c].state != HIPBLAS_STATUS_SUCCESS || heur[c].workspaceSize > g_lt.workspace_bytes) continue;
+          bool good = true;
+          for (int it = 0; it < 7 && good; ++it) {
+            if (it == 2) (void)hipEventRecord(e0, (hipStream_t)stream);
+            good = g_lt.Matmul(g_lt.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, res ? res : y, p.c, y, p.d, &heur[c].algo,
+                               g_lt.workspace, g_lt.workspace_bytes, (hipStream_t)stream) == HIPBLAS_STATUS_SUCCESS;
+          }
+          (void)hipEventRecord(e1, (hipStream_t)stream);
+          (void)hipEventSynchronize(e1);
+          float ms = 0.f;
+          if (!good || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+          if (c == 0) g_last_tune_us[0] = ms * 200.f;
+          if (ms < best_ms) { best_ms = ms; best = c; }
+        }
+        g_last_tune_us[1] = best_ms * 200.f;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+      }
+      p.algo = heur[best].algo;
+      p.ws = heur[best].workspaceSize;
       it = g_plans.emplace(key, p).first;
     }
     plan = it->second;
     // the bias pointer is an attribute of the (shared) descriptor: set it under the lock, launch under the lock
-    const bool ok = g_lt.DescSet(plan.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
+    const bool ok = !bias || g_lt.DescSet(plan.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
     CGG_REQUIRE(ok, CGG_ELIBRARY, "cgg_gemm_bias_res_act_bf16: bias pointer");
     const float alpha = 1.f, beta = res ? 1.f : 0.f;
     const hipblasStatus_t st =
@@ -125,5 +159,19 @@ extern "C" int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const vo
                     &plan.algo, g_lt.workspace, g_lt.workspace_bytes, (hipStream_t)stream);
     CGG_REQUIRE(st == HIPBLAS_STATUS_SUCCESS, CGG_ELIBRARY, "cgg_gemm_bias_res_act_bf16: hipblasLtMatmul status %d", (int)st);
   }
+  return CGG_OK;
+}
+
+// n > 1: at the first (non-captured) use of a shape, time the first n heuristic candidates and keep the fastest.
+extern "C" int cgg_blaslt_set_tuning(int n_candidates) {
+  std::lock_guard<std::mutex> lock(g_lt_mutex);
+  g_tune_candidates = n_candidates;
+  return CGG_OK;
+}
+
+// (heuristic top-1 us, chosen us) of the most recent tuning run
+extern "C" int cgg_blaslt_last_tuning(float* top1_us, float* chosen_us) {
+  if (top1_us) *top1_us = g_last_tune_us[0];
+  if (chosen_us) *chosen_us = g_last_tune_us[1];
   return CGG_OK;
 }

@@ -829,7 +829,14 @@ def _blaslt_init():
         cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libhipblaslt.so')
         path = cand if os.path.exists(cand) else 'libhipblaslt.so'
         check(_lib_().cgg_blaslt_init(path.encode()), 'cgg_blaslt_init')
+        check(_lib_().cgg_blaslt_set_tuning(int(os.environ.get('CGG_GEMM_TUNE', '1'))), 'cgg_blaslt_set_tuning')
         _BLASLT_READY = True
+
+
+def blaslt_last_tuning():
+    a, b = ctypes.c_float(0), ctypes.c_float(0)
+    _lib_().cgg_blaslt_last_tuning(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def gemm_bias_res_act_bf16(x, w, bias, res=None, relu=True):
@@ -838,12 +845,12 @@ def gemm_bias_res_act_bf16(x, w, bias, res=None, relu=True):
     _blaslt_init()
     M, K = x.shape
     N = w.shape[0]
-    for t, n in ((x, 'x'), (w, 'w'), (res, 'res')):
+    for t, n in ((x, 'x'), (w, 'w'), (res, 'res'), (bias, 'bias')):
         if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous()):
             raise CggError('gemm_bias_res_act_bf16: %s must be a contiguous bfloat16 tensor' % n)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     rc = _lib_().cgg_gemm_bias_res_act_bf16(dev_ptr(x, 'x', torch.bfloat16), dev_ptr(w, 'w', torch.bfloat16),
-                                            dev_ptr(bias, 'bias', torch.bfloat16), dev_ptr(res), dev_ptr(y), M, N, K,
+                                            dev_ptr(bias), dev_ptr(res), dev_ptr(y), M, N, K,
                                             int(bool(relu)), stream_ptr(x.device))
     check(rc, 'cgg_gemm_bias_res_act_bf16')
     return y

@@ -288,10 +288,14 @@ int cgg_bias_act_nhwc(void* y, const void* bias, const void* res, int64_t rows, 
 
 /* Library GEMM with the residual epilogue ATen does not expose, for `relu(conv3(x) + identity)` of a BN-folded
  * [3P] mmdet ResNet Bottleneck (1x1 convolution on channel-last bf16 rows):
- *   y[M, N] = act(x[M, K] w[N, K]^T + bias[N] + res[M, N])   (bf16 in / out, f32 accumulation; res nullable; relu 0/1)
+ *   y[M, N] = act(x[M, K] w[N, K]^T + bias[N] + res[M, N])   (bf16 in / out, f32 accumulation; bias, res nullable; relu 0/1)
  * = ONE hipBLASLt matmul (beta = 1, HIPBLASLT_EPILOGUE_RELU_BIAS). cgg_blaslt_init(path) dlopens the hipBLASLt copy the
  * process already uses (NULL / "" = "libhipblaslt.so") and must be called once before.                              */
 int cgg_blaslt_init(const char* libpath);
+/* cgg_blaslt_set_tuning(n > 1): at the first use of a shape outside a stream capture, time the first n heuristic
+ * candidates (2 warm + 5 timed launches each) and keep the fastest; cgg_blaslt_last_tuning reports (top-1, chosen) us. */
+int cgg_blaslt_set_tuning(int n_candidates);
+int cgg_blaslt_last_tuning(float* top1_us, float* chosen_us);
 int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int M, int N,
                                int K, int relu, cgg_stream_t stream);
 
