@@ -130,3 +130,38 @@ extern "C" int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void*
   CGG_CHECK_LAUNCH("cgg_bias_relu_maxpool_nhwc");
   return 0;
 }
+
+// im2col for a 3x3 / padding 1 convolution on a channel-last bf16 map: rows = output pixels, columns = (ky, kx, c).
+// Deep ResNet stages (64^2 / 32^2 maps, 256-512 channels) have too few output tiles for the implicit-GEMM convolution
+// kernels (45-54 us for 9.7 GFLOP at configs[1]); as an explicit [M, 9C] x [9C, Cout] library GEMM with the bias + ReLU
+// epilogue they take 18-20 us, and the patch matrix is only 19-38 MB.
+__global__ __launch_bounds__(256) void cgg_im2col3x3_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int H, int W,
+                                                           int Ho, int Wo, int c8, int stride, long long nvec) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // (b, oy, ox, tap, c8)
+  if (i >= nvec) return;
+  const int c = (int)(i % c8);
+  long long p = i / c8;
+  const int tap = (int)(p % 9);
+  p /= 9;
+  const int ox = (int)(p % Wo);
+  p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int b = (int)(p / Ho);
+  const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * H + iy) * W + ix) * c8 + c];
+  y[i] = v;
+}
+
+extern "C" int cgg_im2col3x3_nhwc(const void* x, void* y, int B, int H, int W, int C, int stride, cgg_stream_t stream) {
+  CGG_REQUIRE(x && y, CGG_EINVAL, "cgg_im2col3x3_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), CGG_EINVAL, "cgg_im2col3x3_nhwc: bad sizes");
+  CGG_REQUIRE(C % 8 == 0, CGG_EUNSUPPORTED, "cgg_im2col3x3_nhwc: C %% 8 != 0 (C=%d)", C);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(y), CGG_EALIGN, "cgg_im2col3x3_nhwc: pointers must be 16-byte aligned");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long nvec = (long long)B * Ho * Wo * 9 * (C / 8);
+  hipLaunchKernelGGL(cgg_im2col3x3_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, (uint4*)y, H, W, Ho, Wo, C / 8, stride, nvec);
+  CGG_CHECK_LAUNCH("cgg_im2col3x3_nhwc");
+  return 0;
+}

@@ -829,7 +829,7 @@ def _blaslt_init():
         cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libhipblaslt.so')
         path = cand if os.path.exists(cand) else 'libhipblaslt.so'
         check(_lib_().cgg_blaslt_init(path.encode()), 'cgg_blaslt_init')
-        check(_lib_().cgg_blaslt_set_tuning(int(os.environ.get('CGG_GEMM_TUNE', '1'))), 'cgg_blaslt_set_tuning')
+        check(_lib_().cgg_blaslt_set_tuning(int(os.environ.get('CGG_GEMM_TUNE', '16'))), 'cgg_blaslt_set_tuning')
         _BLASLT_READY = True
 
 
@@ -854,3 +854,16 @@ def gemm_bias_res_act_bf16(x, w, bias, res=None, relu=True):
                                             int(bool(relu)), stream_ptr(x.device))
     check(rc, 'cgg_gemm_bias_res_act_bf16')
     return y
+
+
+def im2col3x3_nhwc(x, stride=1):
+    """x (B, H, W, C) channel-last bf16 -> patch matrix (B * Ho * Wo, 9 * C) of a 3x3 / padding-1 convolution, columns
+    ordered (ky, kx, c); returns (matrix, Ho, Wo)."""
+    B, H, W, C = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        raise CggError('im2col3x3_nhwc: x must be a contiguous (B, H, W, C) bfloat16 tensor')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B * Ho * Wo, 9 * C), dtype=torch.bfloat16, device=x.device)
+    check(_lib_().cgg_im2col3x3_nhwc(dev_ptr(x), dev_ptr(y), B, H, W, C, int(stride), stream_ptr(x.device)),
+          'cgg_im2col3x3_nhwc')
+    return y, Ho, Wo

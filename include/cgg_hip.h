@@ -299,6 +299,12 @@ int cgg_blaslt_last_tuning(float* top1_us, float* chosen_us);
 int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const void* bias, const void* res, void* y, int M, int N,
                                int K, int relu, cgg_stream_t stream);
 
+/* Patch matrix of a 3x3 / padding 1 / stride 1|2 convolution on a channel-last bf16 map x[B, H, W, C]:
+ * y[B * Ho * Wo, 9 * C], column (ky * 3 + kx) * C + c = x[b, oy * stride + ky - 1, ox * stride + kx - 1, c] (0 outside),
+ * Ho = (H - 1) / stride + 1. With cgg_gemm_bias_res_act_bf16 it replaces the 3x3 convolutions of the deep stages of the
+ * BN-folded [3P] mmdet ResNet (conv2 of the Bottlenecks of layer3 / layer4).                                        */
+int cgg_im2col3x3_nhwc(const void* x, void* y, int B, int H, int W, int C, int stride, cgg_stream_t stream);
+
 /* Stem tail of the BN-folded [3P] mmdet ResNet (`maxpool(relu(bn1(conv1(x))))`), channel-last bf16, one pass:
  *   y[B, Ho, Wo, C] = relu(maxpool3x3/s2/p1(x[B, H, W, C]) + bias[C]),  Ho = (H - 1) / 2 + 1 (same for W).          */
 int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,

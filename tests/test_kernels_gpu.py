@@ -805,3 +805,19 @@ def test_gemm_bias_res_act_bf16(dev):
         if relu:
             want = want.relu()
         assert (got.float() - want).abs().max() <= 0.02 * want.abs().max() + 0.02
+
+
+def test_im2col3x3_gemm_equals_conv(dev):
+    g = torch.Generator().manual_seed(73)
+    for (B, H, W, C, Co, st) in [(2, 16, 20, 32, 64, 1), (1, 17, 13, 16, 32, 2)]:
+        x = torch.randn(B, H, W, C, generator=g).bfloat16().to(dev)
+        w = (torch.randn(Co, C, 3, 3, generator=g) / 8).bfloat16().to(dev)
+        b = torch.randn(Co, generator=g).bfloat16().to(dev)
+        cols, Ho, Wo = ops.im2col3x3_nhwc(x, st)
+        ref_cols = torch.nn.functional.unfold(x.permute(0, 3, 1, 2).float(), 3, padding=1, stride=st)   # (B, C*9, L)
+        ref_cols = ref_cols.view(B, C, 9, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, 9 * C)
+        assert torch.equal(cols.float(), ref_cols)
+        y = ops.gemm_bias_res_act_bf16(cols, w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous(), b, None, True)
+        want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), stride=st, padding=1).relu()
+        want = want.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co)
+        assert (y.float() - want).abs().max() <= 0.02 * want.abs().max() + 0.02
