@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
 __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     const float* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vt,
     const uint32_t* __restrict__ bits, float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S,
-    int words, int KC, int nchunks, float scale, float* __restrict__ out_direct) {
+    int words, int KC, int nchunks, float scale, float* __restrict__ out_direct, int ldk, long long vt_bstride) {
   constexpr int D = 32;
   // 8 waves = 2 ADJACENT heads x 4 query tiles: a 128-byte line of K holds the 64-byte slices of two heads, so
   // pairing them in one workgroup makes every fetched line fully useful (one head per workgroup re-fetched each
@@ -235,13 +235,15 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
 
-  const uint16_t* kb = k + (size_t)b * S * HD + h * D + 8 * hi;          // + key * HD + 16 * ks
-  const uint16_t* vb = vt + ((size_t)b * HD + h * D + j) * S + 4 * hi;   // + key0 + 16 * t (+ 8)
+  // K rows may be a column slice of a wider projection (row stride ldk), vt one row block of a taller one (batch
+  // stride vt_bstride): the K / V projections of all decoder layers that read one level are a single GEMM each
+  const uint16_t* kb = k + (size_t)b * S * ldk + h * D + 8 * hi;         // + key * ldk + 16 * ks
+  const uint16_t* vb = vt + (size_t)b * vt_bstride + (size_t)(h * D + j) * S + 4 * hi;   // + key0 + 16 * t (+ 8)
   const int s_cap = S - 4;                                                // last legal 4-key group start
   for (int s0 = s_begin; s0 < s_end; s0 += 32) {
     const int key = min(s0 + j, S - 1);
-    const uint4 k0 = *reinterpret_cast<const uint4*>(kb + (size_t)key * HD);
-    const uint4 k1 = *reinterpret_cast<const uint4*>(kb + (size_t)key * HD + 16);
+    const uint4 k0 = *reinterpret_cast<const uint4*>(kb + (size_t)key * ldk);
+    const uint4 k1 = *reinterpret_cast<const uint4*>(kb + (size_t)key * ldk + 16);
     uint2 v[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -580,7 +582,11 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
 
 extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits,
                                              float* out, void* ws, int B, int Q, int H, int D, int S, float scale,
-                                             cgg_stream_t stream) {
+                                             int ldk, int64_t vt_bstride, cgg_stream_t stream) {
+  if (ldk <= 0) ldk = H * D;
+  if (vt_bstride <= 0) vt_bstride = (int64_t)H * D * S;
+  CGG_REQUIRE(ldk >= H * D && ldk % 8 == 0 && vt_bstride >= (int64_t)H * D * S && vt_bstride % 4 == 0, CGG_EINVAL,
+              "cgg_masked_xattn_forward_bf16: ldk=%d / vt_bstride=%lld", ldk, (long long)vt_bstride);
   CGG_REQUIRE(q && k && vt && out && ws, CGG_EINVAL, "cgg_masked_xattn_forward_bf16: null pointer");
   CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_forward_bf16: bad sizes");
   CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward_bf16: head dim %d (only 32 is built)", D);
@@ -597,7 +603,8 @@ extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, cons
   const size_t lds = (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, (H + 1) / 2, B), dim3(512), lds, s, q, (const uint16_t*)k,
-                     (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr);
+                     (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, ldk,
+                     (long long)vt_bstride);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(partial)");
   if (nch > 1) {
     CGG_REQUIRE(xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 1) == 0, CGG_EUNSUPPORTED,

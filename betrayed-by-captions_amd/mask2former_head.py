@@ -510,9 +510,32 @@ class Mask2FormerHeadOpen(nn.Module):
             s = H4 // h
             ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
             pooled.append(ops.pack_mask_feature_nhwc(mf, s) if ok else None)
-        kvs = [layers[i].attentions[0].project_kv_bf16(kv16[i % L][0], kv16[i % L][1])
-               for i in range(self.num_transformer_decoder_layers)]
+        kvs = self._project_kv_levels(kv16)
         return dict(stream=True, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled, mask_features=None)
+
+    def _project_kv_levels(self, kv16):
+        """K / V of all decoder layers from the per-level bf16 operands (m16, mp16): the layers that read level l
+        (l, l + L, ...) share their input, so their key projections are ONE GEMM against the stacked [Wk_i] (and the
+        transposed value projections one batched GEMM against the stacked [Wv_i]); each layer then gets a column slice
+        of k and a row block of vt (`cgg_masked_xattn_forward_bf16` takes the strides). 6 launches instead of 18."""
+        L = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
+        nl = self.num_transformer_decoder_layers
+        E = layers[0].attentions[0].embed_dims
+        kvs = [None] * nl
+        for l in range(min(L, nl)):
+            idx = list(range(l, nl, L))
+            ws = tuple(layers[i].attentions[0].attn.in_proj_weight for i in idx)
+            bs = tuple(layers[i].attentions[0].attn.in_proj_bias for i in idx)
+            wk = runtime.derived_cached('kv_levels_wk', ws, lambda: torch.cat([w[E:2 * E] for w in ws], 0).to(torch.bfloat16).contiguous())
+            bk = runtime.derived_cached('kv_levels_bk', bs, lambda: torch.cat([b[E:2 * E] for b in bs], 0).to(torch.bfloat16).contiguous())
+            wv = runtime.derived_cached('kv_levels_wv', ws, lambda: torch.cat([w[2 * E:] for w in ws], 0).to(torch.bfloat16).contiguous())
+            m16, mp16 = kv16[l]
+            k_all = F.linear(mp16, wk, bk)                               # (B, hw, n E)
+            vt_all = torch.matmul(wv, m16.transpose(1, 2))               # (B, n E, hw)
+            for j, i in enumerate(idx):
+                kvs[i] = (k_all[:, :, j * E:(j + 1) * E], vt_all[:, j * E:(j + 1) * E, :])
+        return kvs
 
     def _kv_bf16_ok(self):
         """Throughput-mode decode (bf16 K / V, `forward_stream` layers) is available."""
@@ -596,8 +619,7 @@ class Mask2FormerHeadOpen(nn.Module):
         layers = self.transformer_decoder.layers
         if self._kv_bf16_ok() and packed_full.lo is None:
             if stream and kv16 is not None:
-                kvs = [layers[i].attentions[0].project_kv_bf16(kv16[i % L][0], kv16[i % L][1])
-                       for i in range(self.num_transformer_decoder_layers)]
+                kvs = self._project_kv_levels(kv16)
             elif all(h * w % 4 == 0 and h * w >= 8 for h, w in sizes) and \
                     all(l.attentions[0].embed_dims // l.attentions[0].num_heads == 32 for l in layers):
                 m16 = [m.to(torch.bfloat16) for m in mems]

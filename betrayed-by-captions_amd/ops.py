@@ -716,6 +716,11 @@ def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
     D = E // H
     if tuple(k.shape) != (B, S, E) or tuple(vt.shape) != (B, E, S):
         raise CggError(f'masked_xattn_bf16: k {tuple(k.shape)} / vt {tuple(vt.shape)} do not match q {tuple(q.shape)}')
+    # k may be a column slice of a wider (B, S, n*E) projection, vt a row block of a taller (B, n*E, S) one
+    if k.stride(2) != 1 or k.stride(0) != S * k.stride(1) or vt.stride(2) != 1 or vt.stride(1) != S or \
+            k.dtype != torch.bfloat16 or vt.dtype != torch.bfloat16:
+        raise CggError('masked_xattn_bf16: unsupported k / vt strides or dtype')
+    ldk, vtb = k.stride(1), vt.stride(0)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _lib_()
@@ -726,9 +731,9 @@ def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
         _WS_CACHE[key] = ws
     out = torch.empty((B, Q, E), dtype=torch.float32, device=q.device)
-    rc = lib.cgg_masked_xattn_forward_bf16(dev_ptr(q, 'q', torch.float32), dev_ptr(k, 'k', torch.bfloat16),
-                                           dev_ptr(vt, 'vt', torch.bfloat16), dev_ptr(bits, 'bits', torch.int32),
-                                           dev_ptr(out), dev_ptr(ws), B, Q, H, D, S, float(scale),
+    rc = lib.cgg_masked_xattn_forward_bf16(dev_ptr(q, 'q', torch.float32), ctypes.c_void_p(k.data_ptr()),
+                                           ctypes.c_void_p(vt.data_ptr()), dev_ptr(bits, 'bits', torch.int32),
+                                           dev_ptr(out), dev_ptr(ws), B, Q, H, D, S, float(scale), int(ldk), int(vtb),
                                            stream_ptr(q.device))
     check(rc, 'cgg_masked_xattn_forward_bf16')
     return out

@@ -164,9 +164,12 @@ int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bit
                              int kv_dtype, cgg_stream_t stream);
 /* Throughput-mode variant: k [B, S, H*D] bf16 and the value projection TRANSPOSED, vt [B, H*D, S] bf16 (computed
  * as Wv x mem^T by the caller), bf16 MFMA for both contractions, f32 softmax statistics and accumulation.
- * Same mask / output / workspace contract. Requires D == 32, Q <= 128, S % 4 == 0.                              */
+ * Same mask / output / workspace contract. Requires D == 32, Q <= 128, S % 4 == 0.
+ * ldk = row stride of k in elements (0 = H*D), vt_bstride = batch stride of vt in elements (0 = H*D*S): k may be a column
+ * slice and vt a row block of the merged projection of all decoder layers that read the same level.              */
 int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits, float* out,
-                                  void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream);
+                                  void* ws, int B, int Q, int H, int D, int S, float scale, int ldk, int64_t vt_bstride,
+                                  cgg_stream_t stream);
 
 /* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
  * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =
