@@ -227,9 +227,18 @@ class ResNet(nn.Module):
     def _forward_folded(self, x):
         import torch.nn.functional as F
         seq = iter(self._folded())
-        x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last).permute(0, 2, 3, 1)
         mp = self.maxpool
-        if (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False):
+        pool_ok = (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False)
+        c1 = self.conv1
+        if (pool_ok and x.dtype == torch.float32 and x.is_contiguous() and tuple(c1.weight.shape) == (64, 3, 7, 7)
+                and tuple(c1.stride) == (2, 2) and tuple(c1.padding) == (3, 3) and tuple(c1.dilation) == (1, 1)):
+            # stem: hand-written MFMA convolution straight from the f32 NCHW image + (bias, ReLU, max-pool) pass
+            w4, b, _ = next(seq)
+            packed = runtime.derived_cached('stem_packed', (w4,), lambda: ops.pack_stem_weight(w4))
+            x = ops.bias_relu_maxpool_nhwc(ops.stem_conv7x7(x, packed), b)
+            return self._forward_folded_layers(x, seq)
+        x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        if pool_ok:
             # conv -> (+bias, ReLU, 3x3/s2 max-pool) in one HIP pass over the raw convolution output
             w4, b, _ = next(seq)
             y = F.conv2d(x.permute(0, 3, 1, 2), w4, None, stride=self.conv1.stride, padding=self.conv1.padding)
@@ -238,6 +247,9 @@ class ResNet(nn.Module):
         else:
             x = self._conv_nhwc(x, self.conv1, next(seq), True)
             x = mp(x.permute(0, 3, 1, 2)).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        return self._forward_folded_layers(x, seq)
+
+    def _forward_folded_layers(self, x, seq):
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):

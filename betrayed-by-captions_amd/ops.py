@@ -872,3 +872,28 @@ def im2col3x3_nhwc(x, stride=1):
     check(_lib_().cgg_im2col3x3_nhwc(dev_ptr(x), dev_ptr(y), B, H, W, C, int(stride), stream_ptr(x.device)),
           'cgg_im2col3x3_nhwc')
     return y, Ho, Wo
+
+
+def pack_stem_weight(w):
+    """w (64, 3, 7, 7) (BN already folded) -> bf16 MFMA A fragments for `stem_conv7x7` (uint8 tensor)."""
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise CggError(f'pack_stem_weight: expected (64, 3, 7, 7), got {tuple(w.shape)}')
+    wk = torch.zeros((64, 7, 8, 3), dtype=torch.float32, device=w.device)      # (cout, ky, kx padded to 8, c)
+    wk[:, :, :7, :] = w.detach().float().permute(0, 2, 3, 1)
+    wk = torch.cat([wk.reshape(64, 168), torch.zeros((64, 8), dtype=torch.float32, device=w.device)], 1)   # K = 176
+    frag = wk.view(2, 32, 11, 2, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16)    # (mt, ks, hi, j, e)
+    out = frag.view(torch.uint8).reshape(-1)
+    assert out.numel() == _lib_().cgg_stem_conv7x7_packed_bytes()
+    return out
+
+
+def stem_conv7x7(img, packed):
+    """img (B, 3, H, W) f32 NCHW -> raw 7x7 / stride-2 / padding-3 convolution (B, Ho, Wo, 64) bf16 channel-last."""
+    B, C, H, W = img.shape
+    if C != 3 or img.dtype != torch.float32 or not img.is_contiguous():
+        raise CggError('stem_conv7x7: img must be a contiguous (B, 3, H, W) float32 tensor')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, 64), dtype=torch.bfloat16, device=img.device)
+    check(_lib_().cgg_stem_conv7x7_nchw(dev_ptr(img), dev_ptr(packed), dev_ptr(y), B, H, W, stream_ptr(img.device)),
+          'cgg_stem_conv7x7_nchw')
+    return y

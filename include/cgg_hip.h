@@ -308,6 +308,13 @@ int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const void* bias, c
  * BN-folded [3P] mmdet ResNet (conv2 of the Bottlenecks of layer3 / layer4).                                        */
 int cgg_im2col3x3_nhwc(const void* x, void* y, int B, int H, int W, int C, int stride, cgg_stream_t stream);
 
+/* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
+ * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),
+ * Ho = (H - 1) / 2 + 1. w_packed: cgg_stem_conv7x7_packed_bytes() bytes, bf16 MFMA A fragments
+ * [2 m-tiles][11 k-steps][64 lanes][8] of W[64, 176] with k = ky * 24 + kx * 3 + c (zero elsewhere).              */
+int64_t cgg_stem_conv7x7_packed_bytes(void);
+int cgg_stem_conv7x7_nchw(const float* img, const void* w_packed, void* out, int B, int H, int W, cgg_stream_t stream);
+
 /* Stem tail of the BN-folded [3P] mmdet ResNet (`maxpool(relu(bn1(conv1(x))))`), channel-last bf16, one pass:
  *   y[B, Ho, Wo, C] = relu(maxpool3x3/s2/p1(x[B, H, W, C]) + bias[C]),  Ho = (H - 1) / 2 + 1 (same for W).          */
 int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,

@@ -821,3 +821,16 @@ def test_im2col3x3_gemm_equals_conv(dev):
         want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), stride=st, padding=1).relu()
         want = want.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co)
         assert (y.float() - want).abs().max() <= 0.02 * want.abs().max() + 0.02
+
+
+def test_stem_conv7x7_matches_conv2d(dev):
+    g = torch.Generator().manual_seed(74)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 8).to(dev)
+    packed = ops.pack_stem_weight(w)
+    for (B, H, W) in [(2, 64, 96), (1, 50, 70), (1, 17, 33)]:            # incl. ragged tiles and odd sizes
+        img = torch.randn(B, 3, H, W, generator=g).to(dev)
+        got = ops.stem_conv7x7(img, packed)
+        want = torch.nn.functional.conv2d(img.bfloat16().float(), w.bfloat16().float(), None, stride=2, padding=3)
+        assert got.shape == (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64)
+        err = (got.float().permute(0, 3, 1, 2) - want).abs().max().item()
+        assert err <= 0.02 * want.abs().max().item() + 0.02, err
