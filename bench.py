@@ -177,7 +177,7 @@ def main():
                          'host-bound at ~530 launches); 0: eager launches')
     ap.add_argument('--defer-tail', type=int, default=1, choices=[0, 1, 2],
                     help='pipeline stage balancing: K/V projections + mask-feature packing run in the decode stage')
-    ap.add_argument('--pipeline', type=int, default=2, choices=[0, 2, 3],
+    ap.add_argument('--pipeline', type=int, default=2, choices=[0, 2, 3, 4],
                     help='(with --graph 1) software pipeline across steps, one HIP stream + hipGraph per stage: '
                          '3 = backbone | pixel decoder + K/V | query decoder + post-processing, 2 = the first two '
                          'merged, 0 = one graph per step replayed back to back')

@@ -191,6 +191,16 @@ class MaskFormerOpen(nn.Module):
         """query decoder + mask logits + post-processing on the output of `stage_encode`."""
         return self.simple_test(None, img_metas, encoded=encoded, **kwargs)
 
+    def stage_head(self, encoded, img_metas, **kwargs):
+        """query decoder only (the narrow, latency-bound part): the head's `simple_test` outputs."""
+        return self.panoptic_head.simple_test(None, img_metas, encoded=encoded, **kwargs)
+
+    def stage_post(self, head_out, img_metas, **kwargs):
+        """fusion-head post-processing (wide kernels again) on `stage_head`'s outputs; device results."""
+        assigned_labels, mask_cls_emb_results, mask_pred_results, _, _ = head_out
+        return self.panoptic_fusion_head.simple_test(assigned_labels, mask_cls_emb_results, mask_pred_results,
+                                                     img_metas, **kwargs)
+
     def aug_test(self, imgs, img_metas, **kwargs):
         raise NotImplementedError
 

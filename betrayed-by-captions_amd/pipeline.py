@@ -114,8 +114,12 @@ def detector_pipeline(model, example, metas, stages=3, defer_tail=True, **decode
     elif stages == 3:
         fns = [model.extract_feat, lambda f: head._encode(f, defer_tail=defer_tail),
                lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
+    elif stages == 4:      # encode | query decoder | post-processing (device results only)
+        fns = [lambda x: model.stage_encode(x, defer_tail=defer_tail),
+               lambda enc: model.stage_head(enc, metas, **decode_kwargs),
+               lambda out: model.stage_post(out, metas, **decode_kwargs)]
     else:
-        raise ValueError('stages must be 2 or 3')
+        raise ValueError('stages must be 2, 3 or 4')
     return StagePipeline(fns, example)
 
 
