@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
 __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     const float* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vt,
     const uint32_t* __restrict__ bits, float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S,
-    int words, int KC, int nchunks, float scale, float* __restrict__ out_direct, int ldk, long long vt_bstride) {
+    int words, int KC, int nchunks, float scale, float* __restrict__ out_direct, int ldk, long long vt_bstride,
+    int auto_unmask) {
   constexpr int D = 32;
   // 8 waves = 2 ADJACENT heads x 4 query tiles: a 128-byte line of K holds the 64-byte slices of two heads, so
   // pairing them in one workgroup makes every fetched line fully useful (one head per workgroup re-fetched each
@@ -209,6 +210,23 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
   if (wave >= nmt || h >= H) return;
 
   const int qi = wave * 32 + j;
+  // auto_unmask: a query whose mask blocks EVERY key attends to all of them (mask2former_head.py:825-826). Whether
+  // that holds is only known across chunks, so a chunk that finds its slice of the row fully blocked processes it
+  // UNMASKED and marks its partial as provisional (negative sum); the combine kernel keeps provisional partials only if
+  // all chunks of the row are provisional, and drops them otherwise -- exact, and the separate
+  // cgg_attn_mask_fix_full_rows launch before every layer disappears.
+  bool row_open = false;
+  if (auto_unmask && bits != nullptr && qi < Q) {
+    uint32_t all = ~0u;
+    for (int w = 0; w < cw; ++w) {
+      const int gw = s_begin / 32 + w;
+      uint32_t m = Ms[qi * cws + w];
+      if (gw >= words) m = ~0u;                                           // past the last key
+      else if (gw == words - 1 && (S & 31)) m |= ~0u << (S & 31);         // invalid tail bits of the last word
+      all &= m;
+    }
+    row_open = all == ~0u;
+  }
   // VALU diet (the kernel is issue-bound, not memory-bound): scores live in the log2 domain (log2 e folded into the
   // query scale -> one v_exp_f32 per probability, no multiply), the (max, sum) partials are written in that domain and
   // cgg_xattn_combine_wave(log2 = 1) rescales with exp2; the chunk tail is folded into the mask word once per step
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0), qb[0], sc, 0, 0, 0);
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1), qb[1], sc, 0, 0, 0);
-    uint32_t mw = Ms[qi * cws + ((s0 - s_begin) >> 5)];
+    uint32_t mw = row_open ? 0u : Ms[qi * cws + ((s0 - s_begin) >> 5)];
     if (s0 + 32 > s_end) mw |= ~0u << (s_end - s0);            // keys past the chunk end (last step only)
     mw >>= 4 * hi;                                               // this lane's keys: bits (r&3) + 8 (r>>2)
     float rmax = -INFINITY;
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(512) void cgg_xattn_partial_bf16(
     }
     if (hi == 0) {
       ws_ml[base * 2] = m_run;
-      ws_ml[base * 2 + 1] = l_run;
+      ws_ml[base * 2 + 1] = row_open ? -l_run : l_run;         // negative sum = provisional (unmasked) partial
     }
   }
 }
@@ -491,6 +509,13 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __res
     mc = ml.x;
     lc = ml.y;
   }
+  // provisional partials (negative sum, see cgg_xattn_partial_bf16): valid only if every chunk of the row is one
+  const bool prov = lc < 0.f;
+  const bool any_firm = __ballot(lane < nchunks && !prov) != 0ull;
+  if (prov) {
+    if (any_firm) { mc = -INFINITY; lc = 0.f; }
+    else lc = -lc;
+  }
   float M = mc;
   for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
   const float f = (mc == -INFINITY) ? 0.f : (log2_domain ? __builtin_amdgcn_exp2f(mc - M) : expf(mc - M));
@@ -582,7 +607,7 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
 
 extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits,
                                              float* out, void* ws, int B, int Q, int H, int D, int S, float scale,
-                                             int ldk, int64_t vt_bstride, cgg_stream_t stream) {
+                                             int ldk, int64_t vt_bstride, int auto_unmask, cgg_stream_t stream) {
   if (ldk <= 0) ldk = H * D;
   if (vt_bstride <= 0) vt_bstride = (int64_t)H * D * S;
   CGG_REQUIRE(ldk >= H * D && ldk % 8 == 0 && vt_bstride >= (int64_t)H * D * S && vt_bstride % 4 == 0, CGG_EINVAL,
@@ -604,7 +629,7 @@ extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, cons
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(cgg_xattn_partial_bf16, dim3(nch, (H + 1) / 2, B), dim3(512), lds, s, q, (const uint16_t*)k,
                      (const uint16_t*)vt, bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, ldk,
-                     (long long)vt_bstride);
+                     (long long)vt_bstride, auto_unmask);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward_bf16(partial)");
   if (nch > 1) {
     CGG_REQUIRE(xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 1) == 0, CGG_EUNSUPPORTED,

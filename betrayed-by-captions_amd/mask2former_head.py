@@ -471,17 +471,16 @@ class Mask2FormerHeadOpen(nn.Module):
             full = ops.mask_logits(m0.view(B, Q, C), packed_full)[0]
             bits = ops.attn_mask_from_logits(full.contiguous(), (int(sizes[0][0]), int(sizes[0][1])))
         for i in range(nl):
-            li = i % L
-            ops.attn_mask_fix_full_rows(bits, sizes[li][0] * sizes[li][1])
+            # rows that mask every key are un-masked (:825-826) inside the attention kernels (fix_rows)
             last = i == nl - 1
             n2 = layers[i].norms[2]
             if last:
-                x, _, d = layers[i].forward_stream(x, None, pos, kvs[i], bits, pn, q=q)
+                x, _, d = layers[i].forward_stream(x, None, pos, kvs[i], bits, pn, q=q, fix_rows=True)
                 res = self._head_stream(d, sizes[0], packed_full, pooled[0], True, False, True)
                 for k in range(3):
                     outs[k].append(res[k])
                 break
-            t = layers[i].forward_stream(x, None, pos, kvs[i], bits, pn, q=q, raw=True)
+            t = layers[i].forward_stream(x, None, pos, kvs[i], bits, pn, q=q, raw=True, fix_rows=True)
             x, _, m, q = ops.decoder_tail(t, (n2.weight, n2.bias, n2.eps), pos, pnorm, mlp, qproj(i + 1))
             nxt = (i + 1) % L
             if pooled[nxt] is not None:

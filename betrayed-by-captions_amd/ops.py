@@ -704,13 +704,15 @@ def decoder_tail(planes, norm_a, pos, norm_b, mlp, qproj=None, want_pos=False):
     return y, yp, me, qn
 
 
-def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
-    """q (B,Q,E) f32; k (B,S,E) bf16; vt (B,E,S) bf16 (value projection, transposed); bits as `masked_xattn`."""
+def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None, fix_full_rows=False):
+    """q (B,Q,E) f32; k (B,S,E) bf16; vt (B,E,S) bf16 (value projection, transposed); bits as `masked_xattn`.
+    fix_full_rows: rows whose mask blocks every key attend to all keys (what `attn_mask_fix_full_rows` does to `bits`
+    beforehand), decided inside the kernels; `bits` itself is not modified."""
     B, Q, E = q.shape
     if Q > 128:
         return torch.cat([masked_xattn_bf16(q[:, s:s + 128].contiguous(), k, vt,
                                             None if bits is None else bits[:, s:s + 128].contiguous(), num_heads,
-                                            scale) for s in range(0, Q, 128)], 1)
+                                            scale, fix_full_rows) for s in range(0, Q, 128)], 1)
     S = k.shape[1]
     H = int(num_heads)
     D = E // H
@@ -734,7 +736,7 @@ def masked_xattn_bf16(q, k, vt, bits, num_heads, scale=None):
     rc = lib.cgg_masked_xattn_forward_bf16(dev_ptr(q, 'q', torch.float32), ctypes.c_void_p(k.data_ptr()),
                                            ctypes.c_void_p(vt.data_ptr()), dev_ptr(bits, 'bits', torch.int32),
                                            dev_ptr(out), dev_ptr(ws), B, Q, H, D, S, float(scale), int(ldk), int(vtb),
-                                           stream_ptr(q.device))
+                                           int(bool(fix_full_rows)), stream_ptr(q.device))
     check(rc, 'cgg_masked_xattn_forward_bf16')
     return out
 

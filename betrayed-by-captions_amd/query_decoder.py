@@ -238,7 +238,7 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
                 and len(ffn.layers) == 3 and isinstance(ffn.layers[0][1], nn.ReLU) and ffn.add_identity
                 and self.embed_dims <= 256 and self.embed_dims % 32 == 0)
 
-    def forward_stream(self, x, xp, pos, kv, bits, post_norm=None, q=None, raw=False):
+    def forward_stream(self, x, xp, pos, kv, bits, post_norm=None, q=None, raw=False, fix_rows=False):
         """Throughput-mode layer on 2-D rows: x, xp = x + pos (M = B*Q, C) f32; pos (Q, C). Every projection is
         `cgg_linear_rows_bf16` on pre-packed bf16 weights; the three post-norm LayerNorms, the residual adds and the
         `+ query_pos` adds run in GEMM epilogues / one LayerNorm-chain pass. Returns (x', x' + pos, post_norm(x')).
@@ -262,10 +262,12 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
         if isinstance(kv, tuple):
             # bf16 K and transposed V (see project_kv_bf16): the value bias is folded through the softmax
             # (rows sum to 1) into the output projection's bias, bo' = bo + Wo b_v
-            core = ops.masked_xattn_bf16(q.view(B, Q, E), kv[0], kv[1], bits, H).view(M, E)
+            core = ops.masked_xattn_bf16(q.view(B, Q, E), kv[0], kv[1], bits, H, fix_full_rows=fix_rows).view(M, E)
             ow, ob = ca.attn.out_proj.weight, ca.attn.out_proj.bias
             bo = runtime.derived_cached('xattn_bo', (ow, ob, b), lambda: (ob + ow @ b[2 * E:]).float().contiguous())
         else:
+            if fix_rows:
+                ops.attn_mask_fix_full_rows(bits, kv.shape[1])
             core = ops.masked_xattn(q.view(B, Q, E), kv, bits, H).view(M, E)
         w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
         fused_mid = E == 256 and core.stride(1) == 1

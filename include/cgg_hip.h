@@ -166,10 +166,12 @@ int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bit
  * as Wv x mem^T by the caller), bf16 MFMA for both contractions, f32 softmax statistics and accumulation.
  * Same mask / output / workspace contract. Requires D == 32, Q <= 128, S % 4 == 0.
  * ldk = row stride of k in elements (0 = H*D), vt_bstride = batch stride of vt in elements (0 = H*D*S): k may be a column
- * slice and vt a row block of the merged projection of all decoder layers that read the same level.              */
+ * slice and vt a row block of the merged projection of all decoder layers that read the same level.
+ * auto_unmask != 0: a query row whose mask blocks all S keys attends to all of them (mask2former_head.py:825-826) without
+ * a prior cgg_attn_mask_fix_full_rows launch; `bits` is left untouched.                                            */
 int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits, float* out,
                                   void* ws, int B, int Q, int H, int D, int S, float scale, int ldk, int64_t vt_bstride,
-                                  cgg_stream_t stream);
+                                  int auto_unmask, cgg_stream_t stream);
 
 /* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
  * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =

@@ -834,3 +834,26 @@ def test_stem_conv7x7_matches_conv2d(dev):
         assert got.shape == (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64)
         err = (got.float().permute(0, 3, 1, 2) - want).abs().max().item()
         assert err <= 0.02 * want.abs().max().item() + 0.02, err
+
+
+def test_xattn_bf16_auto_unmask_equals_fix_full_rows(dev):
+    """fix_full_rows=True (decided inside the partial / combine kernels) == clearing fully-masked rows beforehand."""
+    from cgg_amd.query_decoder import pack_bool_mask
+    g = torch.Generator().manual_seed(75)
+    B, Q, H, E = 2, 100, 8, 256
+    for S in (1024, 4096, 1000):
+        q = torch.randn(B, Q, E, generator=g).to(dev)
+        k = torch.randn(B, S, E, generator=g).bfloat16().to(dev)
+        vt = torch.randn(B, E, S, generator=g).bfloat16().to(dev)
+        mask = torch.rand(B, Q, S, generator=g) < 0.6
+        mask[0, 3] = True                      # blocked everywhere -> attends to everything
+        mask[1, 77] = True
+        mask[0, 5, :S // 2] = True             # blocked in whole chunks only -> those chunks must be dropped
+        mask[1, 9, S // 4:] = True
+        bits = pack_bool_mask(mask.to(dev))
+        got = ops.masked_xattn_bf16(q, k, vt, bits.clone(), H, fix_full_rows=True)
+        fixed = bits.clone()
+        ops.attn_mask_fix_full_rows(fixed, S)
+        want = ops.masked_xattn_bf16(q, k, vt, fixed, H)
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, want)
