@@ -71,11 +71,18 @@ __global__ __launch_bounds__(256) void cgg_pack_kernel(const float* __restrict__
 // [B, H, W, C] bf16 -> [B, T, C/8, 32, 8] bf16. A pure permutation of 16-byte chunks (plus the 2x2 mean when
 // pool > 1): one block = one 32-pixel tile; chunks are read pixel-major (512 contiguous bytes per pixel) and
 // written octet-major through LDS so that both sides move full lines.
-__global__ __launch_bounds__(256) void cgg_pack_nhwc_kernel(const uint4* __restrict__ feat, u32x4* __restrict__ hi,
-                                                            int KC, int H, int W, int pool, int Wp, int npix,
-                                                            int T) {
+struct PackJobs { int n; int pool[4]; int Wp[4]; int npix[4]; int T[4]; int t0[4]; u32x4* hi[4]; };
+
+// up to 4 packed images (full resolution + the pooled ones the decoder levels need) from ONE launch: a block's tile
+// index selects the job
+__global__ __launch_bounds__(256) void cgg_pack_nhwc_kernel(const uint4* __restrict__ feat, PackJobs jobs, int KC, int H,
+                                                            int W) {
   extern __shared__ __attribute__((aligned(16))) u32x4 tile[];   // [KC][32]
-  const int t = blockIdx.x, b = blockIdx.y;
+  int job = 0;
+  while (job + 1 < jobs.n && (int)blockIdx.x >= jobs.t0[job + 1]) ++job;
+  const int t = blockIdx.x - jobs.t0[job], b = blockIdx.y;
+  const int pool = jobs.pool[job], Wp = jobs.Wp[job], npix = jobs.npix[job], T = jobs.T[job];
+  u32x4* __restrict__ hi = jobs.hi[job];
   const int n = KC * 32;
   for (int idx = threadIdx.x; idx < n; idx += 256) {
     const int pl = idx / KC, kc = idx - pl * KC;
@@ -364,22 +371,41 @@ extern "C" int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int 
   return CGG_OK;
 }
 
-extern "C" int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, int W, int pool,
-                                          cgg_stream_t stream) {
-  CGG_REQUIRE(feat && hi, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: null pointer");
-  CGG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && pool >= 1, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: bad sizes");
+extern "C" int cgg_pack_mask_feature_nhwc_multi(const void* feat, void* const* hi_host, const int* pools_host, int n,
+                                                int B, int C, int H, int W, cgg_stream_t stream) {
+  CGG_REQUIRE(feat && hi_host && pools_host, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && n >= 1 && n <= 4, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: bad sizes");
   CGG_REQUIRE(C % 8 == 0 && C <= 1024, CGG_EUNSUPPORTED, "cgg_pack_mask_feature_nhwc: C=%d", C);
-  CGG_REQUIRE(pool == 1 || (pool % 2 == 0 && H % pool == 0 && W % pool == 0), CGG_EUNSUPPORTED,
-              "cgg_pack_mask_feature_nhwc: pool=%d must be 1 or an even divisor of %dx%d", pool, H, W);
-  CGG_REQUIRE(cgg_aligned16(feat) && cgg_aligned16(hi), CGG_EALIGN, "cgg_pack_mask_feature_nhwc: alignment");
-  const int Hp = H / pool, Wp = W / pool;
-  const int npix = Hp * Wp;
-  const int T = (npix + 31) / 32;
+  CGG_REQUIRE(cgg_aligned16(feat), CGG_EALIGN, "cgg_pack_mask_feature_nhwc: alignment");
+  PackJobs jobs;
+  jobs.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int pool = pools_host[i];
+    CGG_REQUIRE(pool == 1 || (pool >= 2 && pool % 2 == 0 && H % pool == 0 && W % pool == 0), CGG_EUNSUPPORTED,
+                "cgg_pack_mask_feature_nhwc: pool=%d must be 1 or an even divisor of %dx%d", pool, H, W);
+    CGG_REQUIRE(hi_host[i] && cgg_aligned16(hi_host[i]), CGG_EALIGN, "cgg_pack_mask_feature_nhwc: output %d", i);
+    const int Hp = H / pool, Wp = W / pool;
+    jobs.pool[i] = pool;
+    jobs.Wp[i] = Wp;
+    jobs.npix[i] = Hp * Wp;
+    jobs.T[i] = (Hp * Wp + 31) / 32;
+    jobs.t0[i] = total;
+    jobs.hi[i] = (u32x4*)hi_host[i];
+    total += jobs.T[i];
+  }
   const int KC = C / 8;
-  hipLaunchKernelGGL(cgg_pack_nhwc_kernel, dim3(T, B), dim3(256), (size_t)KC * 32 * 16, (hipStream_t)stream,
-                     (const uint4*)feat, (u32x4*)hi, KC, H, W, pool, Wp, npix, T);
+  hipLaunchKernelGGL(cgg_pack_nhwc_kernel, dim3(total, B), dim3(256), (size_t)KC * 32 * 16, (hipStream_t)stream,
+                     (const uint4*)feat, jobs, KC, H, W);
   CGG_CHECK_LAUNCH("cgg_pack_mask_feature_nhwc");
   return CGG_OK;
+}
+
+extern "C" int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, int W, int pool,
+                                          cgg_stream_t stream) {
+  CGG_REQUIRE(pool >= 1, CGG_EINVAL, "cgg_pack_mask_feature_nhwc: bad sizes");
+  void* his[1] = {hi};
+  return cgg_pack_mask_feature_nhwc_multi(feat, his, &pool, 1, B, C, H, W, stream);
 }
 
 template <bool SPLIT>

@@ -496,6 +496,21 @@ class Mask2FormerHeadOpen(nn.Module):
         enc = encoded if encoded is not None else self._encode(feats)
         return self._decode(enc, len(img_metas), all_masks)
 
+    @staticmethod
+    def _pack_stream(mf, sizes):
+        """Packed full-resolution mask feature + the pooled images of the decoder levels, one launch when possible."""
+        H4, W4 = int(mf.shape[1]), int(mf.shape[2])
+        pools = []
+        for (h, w) in sizes:
+            s = H4 // h
+            pools.append(s if (h * s == H4 and w * s == W4 and s in (2, 4, 8)) else None)
+        uniq = [1] + sorted({p for p in pools if p is not None})
+        if len(uniq) <= 4:
+            packed = dict(zip(uniq, ops.pack_mask_feature_nhwc_multi(mf, uniq)))
+        else:
+            packed = {p: ops.pack_mask_feature_nhwc(mf, p) for p in uniq}
+        return packed[1], [packed[p] if p is not None else None for p in pools]
+
     def _finish_encode(self, enc):
         """The tail of `_encode` for a deferred stream encoding: packed (full + pooled) mask feature and K / V."""
         kv16, sizes = enc['kv16'], enc['sizes']
@@ -503,12 +518,7 @@ class Mask2FormerHeadOpen(nn.Module):
         L = self.num_transformer_feat_level
         layers = self.transformer_decoder.layers
         H4, W4 = int(mf.shape[1]), int(mf.shape[2])
-        packed_full = ops.pack_mask_feature_nhwc(mf, 1)
-        pooled = []
-        for (h, w) in sizes:
-            s = H4 // h
-            ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
-            pooled.append(ops.pack_mask_feature_nhwc(mf, s) if ok else None)
+        packed_full, pooled = self._pack_stream(mf, sizes)
         kvs = self._project_kv_levels(kv16)
         return dict(stream=True, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled, mask_features=None)
 
@@ -592,11 +602,7 @@ class Mask2FormerHeadOpen(nn.Module):
                 if kv16 is None:
                     mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
                     poss.append(self.decoder_positional_encoding.flat_unpadded(level_hw[i][0], level_hw[i][1], mf.device))
-            packed_full = ops.pack_mask_feature_nhwc(mf, 1)
-            for (h, w) in sizes:
-                s = H4 // h
-                ok = h * s == H4 and w * s == W4 and s in (2, 4, 8)
-                pooled.append(ops.pack_mask_feature_nhwc(mf, s) if ok else None)
+            packed_full, pooled = self._pack_stream(mf, sizes)
         else:
             feats = [f.float().contiguous() if f.dtype != torch.float32 else f for f in feats]
             mask_features, memorys = pd(feats)

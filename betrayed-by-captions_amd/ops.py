@@ -527,6 +527,25 @@ def pack_mask_feature_nhwc(feat, pool=1):
     return PackedFeature(hi, None, B, C, h, w)
 
 
+def pack_mask_feature_nhwc_multi(feat, pools):
+    """feat (B, H, W, C) bf16 channel-last -> [PackedFeature for each pool in `pools`] (<= 4) from ONE launch."""
+    B, H, W, C = feat.shape
+    outs, ptrs = [], []
+    for pool in pools:
+        if H % pool or W % pool:
+            raise CggError(f'pack_mask_feature_nhwc: {H}x{W} not divisible by pool={pool}')
+        h, w = H // pool, W // pool
+        hi = torch.empty((B, (h * w + 31) // 32, C // 8, 32, 8), dtype=torch.bfloat16, device=feat.device)
+        outs.append(PackedFeature(hi, None, B, C, h, w))
+        ptrs.append(hi.data_ptr())
+    n = len(pools)
+    rc = _lib_().cgg_pack_mask_feature_nhwc_multi(dev_ptr(feat, 'mask_feature', torch.bfloat16),
+                                                  (ctypes.c_void_p * n)(*ptrs), _int_array([int(p) for p in pools]), n,
+                                                  B, C, H, W, stream_ptr(feat.device))
+    check(rc, 'cgg_pack_mask_feature_nhwc_multi')
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------
 # throughput-mode query-side linear (packed bf16 weights, fused LayerNorm / `+ pos` / split-K)
 # ------------------------------------------------------------------------------------------------

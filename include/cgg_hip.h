@@ -283,6 +283,10 @@ int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, vo
                         void* yp16, int64_t y16_bstride, cgg_stream_t stream);
 int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int C, int H, int W, int pool,
                                cgg_stream_t stream);
+/* Same, up to 4 packed images from one launch (the full-resolution image and the pooled ones of the decoder levels):
+ * hi_host[i] receives the pool = pools_host[i] image; both arrays (n <= 4 entries) live on the HOST.              */
+int cgg_pack_mask_feature_nhwc_multi(const void* feat, void* const* hi_host, const int* pools_host, int n, int B, int C,
+                                     int H, int W, cgg_stream_t stream);
 
 /* f3  Channel-last epilogue of the BN-folded backbone convolutions ([3P] mmdet ResNet Bottleneck tail
  * `relu(bn3(conv3(x)) + identity)`, selected by configs/instance/coco_b48n17.py:17-26), in place:

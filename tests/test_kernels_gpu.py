@@ -857,3 +857,13 @@ def test_xattn_bf16_auto_unmask_equals_fix_full_rows(dev):
         want = ops.masked_xattn_bf16(q, k, vt, fixed, H)
         assert torch.isfinite(got).all()
         assert torch.equal(got, want)
+
+
+def test_pack_mask_feature_nhwc_multi_equals_single(dev):
+    g = torch.Generator().manual_seed(76)
+    mf = torch.randn(2, 32, 48, 256, generator=g).bfloat16().to(dev)
+    pools = [1, 2, 4, 8]
+    multi = ops.pack_mask_feature_nhwc_multi(mf, pools)
+    for p, m in zip(pools, multi):
+        one = ops.pack_mask_feature_nhwc(mf, p)
+        assert (m.h, m.w) == (one.h, one.w) and torch.equal(m.hi, one.hi)
