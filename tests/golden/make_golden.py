@@ -14,6 +14,8 @@ How the reference code is made to run without mmcv / mmdet / clip (none installe
     loss weighting, matching and index logic in the fixtures are the REFERENCE'S, the leaf arithmetic is the
     oracle's (torch primitives).
   * Weights are not stored: both sides call tests/util.randomize(module, seed) (deterministic CPU RNG).
+  * G9 -- open_set/datasets/pipelines/formatting.py (OpenFormatBundle) is executed by path with a recording stand-in for
+    mmcv.parallel.DataContainer; the fixture holds the raw samples and what the reference wrapped.
   * `torch.rand` is wrapped while the reference runs so the random point coordinates it draws are captured
     into the fixture (CPU and GPU RNG streams differ; parity tests replay the captured coordinates).
 """
@@ -450,9 +452,84 @@ def g8_beam_search():
     npz('g8_beam_search.npz', **out)
 
 
+class _RecDC:
+    """stand-in for mmcv.parallel.DataContainer: records what the reference asks for."""
+
+    def __init__(self, data, stack=False, padding_value=0, cpu_only=False, pad_dims=2):
+        self.data, self.stack, self.padding_value, self.cpu_only, self.pad_dims = data, stack, padding_value, cpu_only, pad_dims
+
+
+def g9_samples():
+    """seeded raw samples (what the pipeline hands to the bundle); shared with tests/test_host_logic.py."""
+    out = []
+    for case, (H, W, n, gray, seg, caps) in enumerate([(11, 13, 3, False, True, True), (8, 9, 0, False, False, True),
+                                                       (7, 5, 2, True, True, False)]):
+        rng = np.random.RandomState(900 + case)
+        img = rng.randint(0, 256, (H, W) if gray else (H, W, 3)).astype(np.uint8)
+        if case == 1:
+            img = rng.rand(H, W, 3).astype(np.float32)            # already float: no cast
+        r = dict(img=img, filename=f'im{case}.jpg', ori_shape=img.shape, img_shape=img.shape, flip=False,
+                 gt_bboxes=(rng.rand(n, 4) * 10).astype(np.float32), gt_labels=rng.randint(0, 48, (n,)).astype(np.int64),
+                 gt_masks=rng.randint(0, 2, (n, H, W)).astype(np.uint8))
+        if seg:
+            r['gt_semantic_seg'] = rng.randint(0, 134, (H, W)).astype(np.uint8)
+        if caps:
+            r['gt_caption_ids'] = rng.randint(0, 30522, (35,)).astype(np.int64)
+            r['gt_caption_mask'] = (rng.rand(35) < 0.5).astype(np.int64)
+            r['gt_caption_nouns_ids'] = [int(v) for v in rng.randint(0, 30522, (35,))]      # a python list
+            r['gt_caption_nouns_mask'] = (rng.rand(35) < 0.3).astype(np.int64)
+        if case == 2:
+            r['pad_shape'] = (16, 16)                               # a pipeline that already padded: default not applied
+            r['gt_bboxes_ignore'] = np.zeros((0, 4), dtype=np.float32)
+        out.append(r)
+    return out
+
+
+def g9_format_bundle():
+    """G9: the reference's OpenFormatBundle (open_set/datasets/pipelines/formatting.py) on seeded samples."""
+    import importlib.util
+    mmcv = sys.modules['mmcv']
+    mmcv.is_str = lambda x: isinstance(x, str)
+    sys.modules['mmcv.parallel'].DataContainer = _RecDC
+    _mod('mmdet.datasets.builder', PIPELINES=_Registry('pipeline'))
+    spec = importlib.util.spec_from_file_location('ref_formatting', os.path.join(REF, 'open_set/datasets/pipelines/formatting.py'))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    out = {}
+    for case, raw in enumerate(g9_samples()):
+        # inputs travel with the fixture
+        meta = {}
+        for k, v in raw.items():
+            if isinstance(v, np.ndarray):
+                out[f'c{case}_raw_{k}'] = v
+            else:
+                meta[k] = v
+        out[f'c{case}_raw_meta'] = np.array(json.dumps(meta))
+        res = ref.OpenFormatBundle()(dict(raw))
+        keys = []
+        for k, v in res.items():
+            if isinstance(v, _RecDC):
+                keys.append(k)
+                d = v.data
+                out[f'c{case}_{k}_data'] = d.numpy() if torch.is_tensor(d) else np.asarray(d)
+                out[f'c{case}_{k}_dtype'] = np.array(str(d.dtype) if torch.is_tensor(d) else 'object')
+                out[f'c{case}_{k}_attrs'] = np.array([int(v.stack), int(v.padding_value), int(v.cpu_only), int(v.pad_dims)])
+        out[f'c{case}_keys'] = np.array(keys)
+        out[f'c{case}_pad_shape'] = np.array(res['pad_shape'])
+        out[f'c{case}_scale_factor'] = np.array(res['scale_factor'])
+        out[f'c{case}_norm_mean'] = res['img_norm_cfg']['mean']
+        out[f'c{case}_norm_std'] = res['img_norm_cfg']['std']
+        print('G9 case', case, keys)
+    out['n_cases'] = np.array(3)
+    npz('g9_format_bundle.npz', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g8':
         install_shim()
         g8_beam_search()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'g9':
+        install_shim()
+        g9_format_bundle()
     else:
         main()

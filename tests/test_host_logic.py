@@ -268,3 +268,58 @@ def test_swin_backbone_contract():
         tok2 = tok.view(1, 14, 14, 32).roll(7, dims=2).reshape(1, 196, 32)
         y2 = blk(tok2, (14, 14)).view(1, 14, 14, 32)
     assert torch.allclose(y.roll(7, dims=2), y2, atol=1e-5)
+
+
+def test_collate_follows_datacontainer_rules():
+    """data_contract.collate: stacked fields are padded at the end to the group maximum with their padding value,
+    plain fields become per-sample lists, cpu-only ones stay objects; to_forward_kwargs unwraps one GPU group."""
+    import numpy as np
+    from cgg_amd.data_contract import OpenFormatBundle, collate, collect, to_forward_kwargs
+    rng = np.random.RandomState(3)
+    samples = []
+    for (H, W, n) in [(6, 9, 2), (8, 7, 1), (5, 5, 3), (8, 9, 0)]:
+        r = dict(img=rng.randint(0, 255, (H, W, 3)).astype(np.uint8), img_shape=(H, W, 3), ori_shape=(H, W, 3),
+                 gt_bboxes=rng.rand(n, 4).astype(np.float32), gt_labels=rng.randint(0, 5, (n,)).astype(np.int64),
+                 gt_masks=rng.randint(0, 2, (n, H, W)).astype(np.uint8),
+                 gt_semantic_seg=rng.randint(0, 5, (H, W)).astype(np.uint8),
+                 gt_caption_ids=rng.randint(0, 100, (35,)).astype(np.int64))
+        r = OpenFormatBundle()(r)
+        samples.append(collect(r, ['img', 'gt_bboxes', 'gt_labels', 'gt_masks', 'gt_semantic_seg', 'gt_caption_ids']))
+    batch = collate(samples, samples_per_gpu=2)
+    img = batch['img']
+    assert img.stack and len(img.data) == 2
+    assert tuple(img.data[0].shape) == (2, 3, 8, 9) and tuple(img.data[1].shape) == (2, 3, 8, 9)
+    assert img.data[0].dtype == torch.float32
+    assert torch.equal(img.data[0][0, :, :6, :9], samples[0]['img'].data) and float(img.data[0][0, :, 6:, :].abs().sum()) == 0
+    seg = batch['gt_semantic_seg'].data[0]
+    assert tuple(seg.shape) == (2, 1, 8, 9) and int(seg[1, 0, 0, 8]) == 255 and int(seg[0, 0, 7, 0]) == 255
+    assert [tuple(t.shape) for t in batch['gt_bboxes'].data[1]] == [(3, 4), (0, 4)]
+    assert batch['gt_masks'].cpu_only and batch['gt_masks'].data[0][1].shape == (1, 8, 7)
+    assert batch['img_metas'].data[1][0]['img_shape'] == (5, 5, 3) and batch['img_metas'].data[0][0]['pad_shape'] == (6, 9, 3)
+    kw = to_forward_kwargs(batch, device='cpu', group=1)
+    assert tuple(kw['img'].shape) == (2, 3, 8, 9) and len(kw['gt_labels']) == 2 and len(kw['img_metas']) == 2
+    assert kw['gt_masks'][0].dtype == torch.uint8 and tuple(kw['gt_masks'][0].shape) == (3, 5, 5)
+    assert tuple(kw['gt_caption_ids'][1].shape) == (35,)
+
+
+def test_checkpoint_roundtrip_and_key_compat(tmp_path):
+    """checkpoint.load_checkpoint: mmcv-runner layout, DataParallel prefix, mismatch reporting."""
+    from cgg_amd.checkpoint import load_checkpoint, load_state_dict, save_checkpoint
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(4, 2))
+    other = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(4, 2))
+    f = save_checkpoint(net, str(tmp_path / 'w' / 'latest.pth'), meta=dict(CLASSES=('a', 'b')))
+    ck = load_checkpoint(other, f, strict=True)
+    assert ck['meta']['CLASSES'] == ('a', 'b')
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), other.state_dict().values()))
+    wrapped = {'state_dict': {'module.' + k: v + 1 for k, v in net.state_dict().items() if v.dtype.is_floating_point}}
+    load_checkpoint(other, wrapped)
+    assert torch.equal(other[0].weight, net[0].weight + 1)
+    bad = dict(net.state_dict())
+    bad['2.weight'] = torch.zeros(3, 4)
+    bad['extra'] = torch.zeros(1)
+    del bad['0.bias']
+    msgs = []
+    missing, unexpected, mismatched = load_state_dict(other, bad, logger=type('L', (), {'warning': staticmethod(msgs.append)}))
+    assert missing == ['0.bias'] and unexpected == ['extra'] and mismatched[0][0] == '2.weight' and msgs
+    with pytest.raises(RuntimeError):
+        load_state_dict(other, bad, strict=True)

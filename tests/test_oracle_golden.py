@@ -259,3 +259,34 @@ def test_g8_beam_search_matches_reference():
         assert got == str(z[f'sentence{case}']), (case, got, str(z[f'sentence{case}']))
         ids = beam_search(head, z[f'mem{case}'], 1, 2, max_len=max_len, beam_width=beam, return_ids=True)
         assert ids[0] == 1 and ids[-1] == 2 and ' '.join(map(str, ids))[1:-1] == got
+
+
+def test_g9_open_format_bundle_matches_reference():
+    """G9: OpenFormatBundle (data contract on the input side) vs the reference's own class run by path."""
+    import json
+    from cgg_amd.data_contract import DataContainer, OpenFormatBundle
+    z = np.load(os.path.join(GOLD, 'g9_format_bundle.npz'), allow_pickle=False)
+    for case in range(int(z['n_cases'])):
+        raw = {}
+        meta = json.loads(str(z[f'c{case}_raw_meta']))
+        for k in z.files:
+            pre = f'c{case}_raw_'
+            if k.startswith(pre) and k != pre + 'meta':
+                raw[k[len(pre):]] = z[k]
+        for k, v in meta.items():
+            raw[k] = tuple(v) if k in ('ori_shape', 'img_shape', 'pad_shape') else v
+        res = OpenFormatBundle()(dict(raw))
+        keys = [k for k, v in res.items() if isinstance(v, DataContainer)]
+        assert sorted(keys) == sorted(str(k) for k in z[f'c{case}_keys'])   # (dict order follows the raw sample's)
+        for k in keys:
+            v = res[k]
+            want = z[f'c{case}_{k}_data']
+            got = v.data.numpy() if torch.is_tensor(v.data) else np.asarray(v.data)
+            assert got.shape == want.shape and np.array_equal(got, want), (case, k)
+            if torch.is_tensor(v.data):
+                assert str(v.data.dtype) == str(z[f'c{case}_{k}_dtype']), (case, k)
+            assert [int(v.stack), int(v.padding_value), int(v.cpu_only), int(v.pad_dims)] == z[f'c{case}_{k}_attrs'].tolist()
+        assert tuple(res['pad_shape']) == tuple(z[f'c{case}_pad_shape'].tolist())
+        assert float(res['scale_factor']) == float(z[f'c{case}_scale_factor'])
+        assert np.array_equal(res['img_norm_cfg']['mean'], z[f'c{case}_norm_mean'])
+        assert np.array_equal(res['img_norm_cfg']['std'], z[f'c{case}_norm_std'])
