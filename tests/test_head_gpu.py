@@ -4,6 +4,7 @@ seeded inputs and the same weights.
 Tolerances: mask logits 1e-3 absolute (north_star) in fp32 ('split') mode; class / embedding outputs 1e-3;
 assignment indices (argmax class, top-k (query, class) sets, panoptic ids) exact.
 """
+import os
 import warnings
 
 import pytest
@@ -363,3 +364,40 @@ def test_lean_decode_equals_full_decode(dev):
     assert all(v is None for v in lean[2][:-1]) and len(lean[2]) == len(full[2])
     for k in range(3):
         assert torch.equal(lean[k][-1], full[k][-1])
+
+
+def test_test_driver_pipeline_equals_sequential(dev, tmp_path):
+    """tools/test.py: config + mmcv-layout checkpoint -> results pickle; the pipelined bf16 serving loop returns what
+    the sequential loop returns (same detections / masks per image)."""
+    import importlib.util
+    import pickle
+    import sys
+    from cgg_amd.checkpoint import save_checkpoint
+    from util import randomize
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+    randomize(model, seed=21)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.fill_(1.0)
+            m.running_mean.zero_()
+    ck = save_checkpoint(model, str(tmp_path / 'w.pth'), meta=dict(CLASSES=tuple(f'c{i}' for i in range(10))))
+    cfg_file = tmp_path / 'tiny.py'
+    cfg_file.write_text('model = ' + repr(cfg) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    spec = importlib.util.spec_from_file_location('cgg_tools_test', os.path.join(root, 'tools', 'test.py'))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    out = str(tmp_path / 'r.pkl')
+    a = drv.main([str(cfg_file), ck, '--out', out, '--num-images', '7', '--synthetic', '128'])
+    b = drv.main([str(cfg_file), ck, '--num-images', '7', '--synthetic', '128', '--no-pipeline'])
+    assert len(a) == 7 and len(b) == 7 and len(pickle.load(open(out, 'rb'))) == 7
+    for ra, rb in zip(a, b):
+        assert set(ra) == set(rb)
+        for k in ra:
+            assert sorted(ra[k][0].tolist()) == sorted(rb[k][0].tolist())
+            assert int(ra[k][2].sum()) == int(rb[k][2].sum())

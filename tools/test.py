@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""Minimal inference driver with the command line of the reference's tools/test.py: config + checkpoint -> detector from
+the registry -> `simple_test` over a stream of images -> results pickle (`--out`), one process per GPU under
+`--launcher pytorch` (images are sharded by rank, results gathered on rank 0). COCO evaluation (`--eval`) needs the
+dataset classes, which are out of this build's scope: the option is accepted and reported as unavailable.
+
+Throughput mode (`--precision bf16`, default) serves through `pipeline.StagePipeline` (hipGraph per stage, encode of batch
+k+1 overlapped with decode of batch k); `--precision fp32` is the parity path of the reference semantics.
+
+    python tools/test.py CONFIG CHECKPOINT --out results.pkl --num-images 64 --synthetic 1024
+"""
+import argparse
+import importlib
+import json
+import os
+import pickle
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+import cgg_amd              # noqa: E402,F401
+from cgg_amd import registry, runtime, synthetic                          # noqa: E402
+from cgg_amd.checkpoint import load_checkpoint                            # noqa: E402
+from cgg_amd.config import Config                                          # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='test (and eval) a model')
+    p.add_argument('config', help='test config file path')
+    p.add_argument('checkpoint', help='checkpoint file ("none": keep the initialisation)')
+    p.add_argument('--work-dir', help='the directory to save the metrics file')
+    p.add_argument('--out', help='output result file in pickle format')
+    p.add_argument('--fuse-conv-bn', action='store_true', help='accepted: the bf16 path always folds BN into the convs')
+    p.add_argument('--gpu-id', type=int, default=0)
+    p.add_argument('--eval', type=str, nargs='+', help='evaluation metrics (needs the dataset classes: unavailable here)')
+    p.add_argument('--cfg-options', nargs='+', default=None, help='key=value overrides merged into the config')
+    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    # this build's additions
+    p.add_argument('--num-images', type=int, default=16)
+    p.add_argument('--samples-per-gpu', type=int, default=2)
+    p.add_argument('--synthetic', type=int, default=1024, help='synthetic image size (H = W) when --data is not given')
+    p.add_argument('--data', default=None, help='pkg.module:function -> iterable of (img (3,H,W) float tensor, img_meta)')
+    p.add_argument('--precision', default='bf16', choices=['fp32', 'bf16'])
+    p.add_argument('--no-pipeline', action='store_true', help='plain sequential simple_test (no graphs / overlap)')
+    args = p.parse_args(argv)
+    os.environ.setdefault('LOCAL_RANK', str(args.local_rank))
+    return args
+
+
+def synthetic_images(n, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    meta = synthetic.img_metas(1, size, size)[0]
+    for i in range(n):
+        yield torch.randn(3, size, size, generator=g), dict(meta, filename=f'synthetic_{i}.jpg')
+
+
+def to_numpy(result):
+    """device results {type: (labels, bboxes (n,5), masks (n,H,W) bool)} -> numpy, one copy per tensor."""
+    out = {}
+    for key, val in result.items():
+        out[key] = tuple(v.detach().cpu().numpy() if torch.is_tensor(v) else v for v in val) \
+            if isinstance(val, (tuple, list)) else (val.detach().cpu().numpy() if torch.is_tensor(val) else val)
+    return out
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    cfg = Config.fromfile(args.config)
+    if args.cfg_options:
+        from train import _parse_value  # noqa: F401  (same directory)
+        cfg.merge_from_dict({k: _parse_value(v) for k, v in (kv.split('=', 1) for kv in args.cfg_options)})
+    distributed = args.launcher == 'pytorch'
+    if distributed:
+        import torch.distributed as dist
+        local = int(os.environ['LOCAL_RANK'])
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend='nccl')
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        local, rank, world = args.gpu_id, 0, 1
+        torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    model = registry.build_detector(cfg.model, test_cfg=cfg.get('test_cfg'))
+    meta = {}
+    if args.checkpoint and args.checkpoint.lower() != 'none':
+        meta = load_checkpoint(model, args.checkpoint, map_location='cpu').get('meta', {})
+    if 'CLASSES' in meta:
+        model.CLASSES = meta['CLASSES']
+    model = model.to(device).eval()
+    if args.eval:
+        print('--eval: dataset classes / COCO evaluation are outside this build; results are written with --out', flush=True)
+
+    if args.data:
+        mod, fn = args.data.split(':')
+        stream = getattr(importlib.import_module(mod), fn)(cfg, rank, world)
+    else:
+        stream = (s for i, s in enumerate(synthetic_images(args.num_images, args.synthetic, seed=11)) if i % world == rank)
+
+    B = args.samples_per_gpu
+    results, pending = [], []
+    n_img, t0 = 0, None
+    pipe = None
+    with torch.no_grad(), runtime.precision_scope(args.precision):
+        group = []
+
+        def run(group):
+            nonlocal pipe, t0, n_img
+            imgs = torch.stack([g[0] for g in group]).to(device, non_blocking=True)
+            metas = [dict(g[1], batch_input_shape=tuple(imgs.shape[-2:])) for g in group]
+            use_pipe = (not args.no_pipeline and args.precision == 'bf16' and len(group) == B
+                        and all(m['img_shape'] == metas[0]['img_shape'] and m['ori_shape'] == metas[0]['ori_shape'] for m in metas))
+            if use_pipe:
+                if pipe is None or pipe.inputs[0].shape != imgs.shape or pipe.meta_key != (metas[0]['img_shape'], metas[0]['ori_shape']):
+                    from cgg_amd.pipeline import detector_pipeline
+                    pipe = detector_pipeline(model, imgs, metas, stages=2, rescale=True, device_results=True)
+                    pipe.meta_key = (metas[0]['img_shape'], metas[0]['ori_shape'])
+                    torch.cuda.synchronize()
+                    t0, n_img = time.perf_counter(), 0
+                slot = pipe.submit(imgs)
+                # results of the PREVIOUS batch are copied out while this one runs (slot buffers are reused 2 batches later)
+                if pending:
+                    results.extend(to_numpy(r) for r in pipe.wait(pending.pop()))
+                pending.append(slot)
+            else:
+                if t0 is None:
+                    t0 = time.perf_counter()
+                results.extend(to_numpy(r) for r in model.simple_test(imgs, metas, rescale=True, device_results=True))
+            n_img += len(group)
+
+        for sample in stream:
+            group.append(sample)
+            if len(group) == B:
+                run(group)
+                group = []
+        if pending:
+            results.extend(to_numpy(r) for r in pipe.wait(pending.pop()))
+        if group:
+            saved, args.no_pipeline = args.no_pipeline, True
+            run(group)
+            args.no_pipeline = saved
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - (t0 or time.perf_counter())
+    if distributed:
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(results, gathered, dst=0)
+        if rank == 0:
+            results = [r for part in gathered for r in part]
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(images=len(results), images_per_sec_this_rank=round(n_img / max(dt, 1e-9), 1),
+                              precision=args.precision, pipeline=pipe is not None)), flush=True)
+        if args.out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+            with open(args.out, 'wb') as f:
+                pickle.dump(results, f)
+    return results
+
+
+if __name__ == '__main__':
+    main()
