@@ -3,7 +3,8 @@ with the [3P] mmdet match costs / sampler / point-sampling helpers its config na
 (configs/instance/coco_b48n17.py:165-177; semantics in SURVEY.md A6-A8).
 
 The cost matrix stays f32 (assignment indices must be bit-exact with the reference CPU path); the
-solve is scipy's `linear_sum_assignment` on the host exactly like the reference (:126-131).
+solve runs on the host like the reference's scipy `linear_sum_assignment` (:126-131), in the C++ solver of the
+extension (`cgg_linear_sum_assignment_f32`: same algorithm, scan order and tie rule -> same indices).
 `assign_batch` batches the device->host copies of a whole (layers x images) step into one transfer.
 """
 import torch
@@ -11,10 +12,13 @@ import torch.nn.functional as F
 
 from .registry import BBOX_ASSIGNERS, BBOX_SAMPLERS, MATCH_COST, build_match_cost
 
-try:
-    from scipy.optimize import linear_sum_assignment
-except ImportError:  # pragma: no cover
-    linear_sum_assignment = None
+from . import ops
+
+
+def linear_sum_assignment(cost):
+    """scipy.optimize.linear_sum_assignment's contract (and indices) from the C++ solver in libcgg_hip.so."""
+    rows, cols = ops.linear_sum_assignment_batch([torch.as_tensor(cost)])[0]
+    return rows.numpy(), cols.numpy()
 
 
 # ---- [3P] mmcv.ops.point_sample / mmdet point utilities -------------------------------------------
@@ -200,8 +204,6 @@ class MaskHungarianAssignerOpen:
                 gt_inds[:] = 0
             return AssignResult(num_gt, gt_inds, None, labels=labels)
         cost = self.cost_matrix(cls_pred, cls_emb_pred, mask_pred, gt_labels, gt_mask)
-        if linear_sum_assignment is None:
-            raise ImportError('Please run "pip install scipy" to install scipy first.')
         rows, cols = linear_sum_assignment(cost.detach().cpu())
         return self._result_from_match(num_gt, num_query, rows, cols, gt_labels, mask_pred)
 
@@ -221,10 +223,10 @@ class MaskHungarianAssignerOpen:
             todo.append((i, num_query, num_gt))
         if todo:
             flat = torch.cat(costs).cpu()
-            off = 0
+            mats, off = [], 0
             for (i, nq, ng) in todo:
-                c = flat[off:off + nq * ng].view(nq, ng)
+                mats.append(flat[off:off + nq * ng].view(nq, ng))
                 off += nq * ng
-                rows, cols = linear_sum_assignment(c)
-                results[i] = self._result_from_match(ng, nq, rows, cols, items[i][3], items[i][2])
+            for (i, nq, ng), (rows, cols) in zip(todo, ops.linear_sum_assignment_batch(mats)):
+                results[i] = self._result_from_match(ng, nq, rows.numpy(), cols.numpy(), items[i][3], items[i][2])
         return results

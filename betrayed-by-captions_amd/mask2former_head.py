@@ -794,7 +794,6 @@ class Mask2FormerHeadOpen(nn.Module):
         brings all costs to the host for scipy's Hungarian solver, ONE transfer takes the targets back.
         Random points are drawn in the reference's order (layer-major, then image) so pinned draws line up.
         Returns per layer: (labels (B,Q) long, mask_weights (B,Q) f32, pos_b, pos_g (npos,) long, num_pos)."""
-        from .assigner import linear_sum_assignment
         n, B, Q = len(all_cls_scores), all_cls_scores[0].shape[0], all_cls_scores[0].shape[1]
         dev = all_cls_scores[0].device
         P = self.num_points
@@ -839,7 +838,7 @@ class Mask2FormerHeadOpen(nn.Module):
                         den = xx.pow(2).sum(-1)[:, :, None] + t.pow(2).sum(-1)[:, None, :]
                     cost = cost + (1 - (num + dc.eps) / (den + dc.eps)) * dc.weight
                 costs.append(cost.float().reshape(-1))                                        # (n*Q*G,)
-            flat = torch.cat(costs).cpu().numpy() if costs else None                          # the ONE sync
+            flat = torch.cat(costs).cpu() if costs else None                                  # the ONE sync
         import numpy as np
         labels_np = np.full((n, B, Q), self.num_classes, dtype=np.int64)
         weights_np = np.zeros((n, B, Q), dtype=np.float32)
@@ -848,15 +847,21 @@ class Mask2FormerHeadOpen(nn.Module):
         pos_g = [[] for _ in range(n)]
         pos_q = [[] for _ in range(n)]
         pos_r = [[] for _ in range(n)]          # rank of the positive inside its image (padded-batch slot)
-        off = 0
+        # every (image, layer) problem of the step in ONE call of the C++ solver (scipy-identical indices)
+        mats, off = [], 0
+        for b in range(B):
+            G = shapes[b]
+            if G:
+                cm = flat[off:off + n * Q * G].view(n, Q, G)
+                off += n * Q * G
+                mats.extend(cm[li] for li in range(n))
+        solved = iter(ops.linear_sum_assignment_batch(mats))
         for b in range(B):
             G = shapes[b]
             if G == 0:
                 continue
-            cm = flat[off:off + n * Q * G].reshape(n, Q, G)
-            off += n * Q * G
             for li in range(n):
-                rows, cols = linear_sum_assignment(cm[li])
+                rows, cols = (t.numpy() for t in next(solved))
                 order = np.argsort(rows)                     # positives in ascending query order (sampler: unique())
                 rows, cols = rows[order], cols[order]
                 labels_np[li, b, rows] = gl_host[b][cols]

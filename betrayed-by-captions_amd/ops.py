@@ -918,3 +918,27 @@ def stem_conv7x7(img, packed):
     check(_lib_().cgg_stem_conv7x7_nchw(dev_ptr(img), dev_ptr(packed), dev_ptr(y), B, H, W, stream_ptr(img.device)),
           'cgg_stem_conv7x7_nchw')
     return y
+
+
+def linear_sum_assignment_batch(costs):
+    """costs: list of 2-D float32 CPU tensors -> list of (rows, cols) int64 CPU tensors; every problem of a step in ONE
+    call into the C++ solver (same indices as scipy.optimize.linear_sum_assignment, incl. ties)."""
+    if not costs:
+        return []
+    flat = torch.cat([c.detach().to(device='cpu', dtype=torch.float32).contiguous().reshape(-1) for c in costs]) \
+        if len(costs) > 1 else costs[0].detach().to(device='cpu', dtype=torch.float32).contiguous().reshape(-1)
+    nr = [int(c.shape[0]) for c in costs]
+    nc = [int(c.shape[1]) for c in costs]
+    sizes = [min(a, b) for a, b in zip(nr, nc)]
+    total = sum(sizes)
+    rows = torch.empty((max(total, 1),), dtype=torch.int64)
+    cols = torch.empty((max(total, 1),), dtype=torch.int64)
+    rc = _lib_().cgg_linear_sum_assignment_f32(ctypes.c_void_p(flat.data_ptr()) if flat.numel() else None, len(costs),
+                                               _int_array(nr), _int_array(nc), ctypes.c_void_p(rows.data_ptr()),
+                                               ctypes.c_void_p(cols.data_ptr()))
+    check(rc, 'cgg_linear_sum_assignment_f32')
+    out, o = [], 0
+    for n in sizes:
+        out.append((rows[o:o + n], cols[o:o + n]))
+        o += n
+    return out

@@ -314,6 +314,14 @@ int cgg_gemm_bias_res_act_bf16(const void* x, const void* w, const void* bias, c
  * BN-folded [3P] mmdet ResNet (conv2 of the Bottlenecks of layer3 / layer4).                                        */
 int cgg_im2col3x3_nhwc(const void* x, void* y, int B, int H, int W, int C, int stride, cgg_stream_t stream);
 
+/* HOST function (no GPU work): rectangular linear sum assignment of n_problems f32 cost matrices (row-major, concatenated;
+ * problem p is nr[p] x nc[p]) -- the Hungarian matching of open_set/assigners/mask_hungarian_assigner.py:126-131, which the
+ * reference solves one matrix at a time with scipy.optimize.linear_sum_assignment. Same algorithm (Crouse 2016), scan order
+ * and tie rule as scipy, so the INDICES agree, not only the cost. rows / cols: min(nr[p], nc[p]) pairs per problem,
+ * concatenated, rows ascending. CGG_EINVAL for NaN / -inf entries, CGG_EUNSUPPORTED for an infeasible matrix.         */
+int cgg_linear_sum_assignment_f32(const float* cost, int n_problems, const int* nr, const int* nc, int64_t* rows,
+                                  int64_t* cols);
+
 /* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
  * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),
  * Ho = (H - 1) / 2 + 1. w_packed: cgg_stem_conv7x7_packed_bytes() bytes, bf16 MFMA A fragments

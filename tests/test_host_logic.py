@@ -323,3 +323,34 @@ def test_checkpoint_roundtrip_and_key_compat(tmp_path):
     assert missing == ['0.bias'] and unexpected == ['extra'] and mismatched[0][0] == '2.weight' and msgs
     with pytest.raises(RuntimeError):
         load_state_dict(other, bad, strict=True)
+
+
+def test_cpp_linear_sum_assignment_equals_scipy():
+    """cgg_linear_sum_assignment_f32 (host code in the C-ABI library) returns scipy's INDICES: random rectangular
+    matrices both ways, heavy ties (integer costs), constant matrices, single rows / columns, +inf entries."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from cgg_amd import ops
+    rng = np.random.RandomState(0)
+    mats = []
+    for _ in range(60):
+        nr, nc = rng.randint(1, 40), rng.randint(1, 40)
+        mats.append(rng.randn(nr, nc).astype(np.float32))
+    for _ in range(60):                                   # ties everywhere
+        nr, nc = rng.randint(1, 25), rng.randint(1, 25)
+        mats.append(rng.randint(0, 3, (nr, nc)).astype(np.float32))
+    mats += [np.zeros((5, 9), np.float32), np.ones((9, 5), np.float32), np.zeros((1, 7), np.float32),
+             np.zeros((7, 1), np.float32), rng.rand(100, 13).astype(np.float32), rng.rand(100, 1).astype(np.float32)]
+    m = rng.rand(6, 8).astype(np.float32)
+    m[m < 0.3] = np.inf                                   # forbidden pairs, still feasible
+    m[:, 0] = 0.5
+    mats.append(m)
+    got = ops.linear_sum_assignment_batch([torch.from_numpy(x) for x in mats])
+    for x, (r, c) in zip(mats, got):
+        wr, wc = linear_sum_assignment(x)
+        assert r.tolist() == wr.tolist() and c.tolist() == wc.tolist(), x.shape
+    assert ops.linear_sum_assignment_batch([]) == []
+    with pytest.raises(Exception):
+        ops.linear_sum_assignment_batch([torch.tensor([[float('nan'), 1.0]])])
+    with pytest.raises(Exception):
+        ops.linear_sum_assignment_batch([torch.full((2, 2), float('inf'))])
