@@ -14,6 +14,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/pmc_l2 -- python3 $R/scratch/kernel_only.py > /dev/null 2>&1
 cp $(find /tmp/pmc_l2 -name "*counter_collection.csv" | head -1) $O/pmc_l2.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python3 $R/scratch/kernel_only.py > /dev/null 2>&1
+cp $(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1) $O/pmc_sq.csv
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 python bench.py --pipeline 0 --no-cpu-baseline > $O/bench_line_nopipeline.json 2>> $O/bench_line.err

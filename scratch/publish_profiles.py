@@ -5,7 +5,7 @@ R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 src, dst = os.path.join(R, 'gpurun_out', 'r1'), os.path.join(R, 'profiles')
 pairs = {'kernel_stats.csv': 'r1_bench_kernel_stats.csv', 'hot_kernel_launches.txt': 'r1_hot_kernel_launches.txt',
          'pmc_FETCH_SIZE.csv': 'r1_pmc_fetch_counter_collection.csv', 'pmc_WRITE_SIZE.csv': 'r1_pmc_write_counter_collection.csv',
-         'pmc_l2.csv': 'r1_pmc_l2_counter_collection.csv', 'bench_line.json': 'r1_bench_line.json',
+         'pmc_l2.csv': 'r1_pmc_l2_counter_collection.csv', 'pmc_sq.csv': 'r1_pmc_sq_counter_collection.csv', 'bench_line.json': 'r1_bench_line.json',
          'bench_line_nopipeline.json': 'r1_bench_line_nopipeline.json', 'bench_line_eager.json': 'r1_bench_line_eager.json',
          'bench_train_line.json': 'r1_bench_train_line.json'}
 for a, b in pairs.items():
