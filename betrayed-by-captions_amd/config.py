@@ -141,3 +141,19 @@ class Config:
                 d[int(keys[-1])] = to_config_dict(v)
             else:
                 d[keys[-1]] = to_config_dict(v)
+
+
+def parse_option_value(v):
+    """`--cfg-options key=value` values ([3P] mmcv DictAction): int / float / bool / None, "[a,b]" / "(a,b)" lists and
+    comma-separated lists; anything else stays a string."""
+    import json
+    for cast in (int, float):
+        try:
+            return cast(v)
+        except ValueError:
+            pass
+    if v in ('True', 'False', 'None'):
+        return {'True': True, 'False': False, 'None': None}[v]
+    if v.startswith(('[', '(')):
+        return json.loads(v.replace('(', '[').replace(')', ']').replace("'", '"'))
+    return [parse_option_value(x) for x in v.split(',')] if ',' in v else v

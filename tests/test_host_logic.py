@@ -354,3 +354,13 @@ def test_cpp_linear_sum_assignment_equals_scipy():
         ops.linear_sum_assignment_batch([torch.tensor([[float('nan'), 1.0]])])
     with pytest.raises(Exception):
         ops.linear_sum_assignment_batch([torch.full((2, 2), float('inf'))])
+
+
+def test_cfg_option_values():
+    from cgg_amd.config import Config, parse_option_value
+    assert parse_option_value('3') == 3 and parse_option_value('2e-4') == 2e-4 and parse_option_value('True') is True
+    assert parse_option_value('[1,2]') == [1, 2] and parse_option_value('(0.9,0.999)') == [0.9, 0.999]
+    assert parse_option_value('a,b') == ['a', 'b'] and parse_option_value('AdamW') == 'AdamW'
+    cfg = Config(dict(optimizer=dict(lr=1e-4, betas=(0.9, 0.999)), model=dict(layers=[dict(k=1), dict(k=2)])))
+    cfg.merge_from_dict({'optimizer.lr': parse_option_value('2e-4'), 'model.layers.1.k': parse_option_value('7')})
+    assert cfg.optimizer.lr == 2e-4 and cfg.model.layers[1].k == 7

@@ -27,7 +27,7 @@ import torch                # noqa: E402
 import cgg_amd              # noqa: E402,F401
 from cgg_amd import registry, runtime, synthetic                          # noqa: E402
 from cgg_amd.checkpoint import load_checkpoint                            # noqa: E402
-from cgg_amd.config import Config                                          # noqa: E402
+from cgg_amd.config import Config, parse_option_value                     # noqa: E402
 
 
 def parse_args(argv=None):
@@ -74,8 +74,7 @@ def main(argv=None):
     args = parse_args(argv)
     cfg = Config.fromfile(args.config)
     if args.cfg_options:
-        from train import _parse_value  # noqa: F401  (same directory)
-        cfg.merge_from_dict({k: _parse_value(v) for k, v in (kv.split('=', 1) for kv in args.cfg_options)})
+        cfg.merge_from_dict({k: parse_option_value(v) for k, v in (kv.split('=', 1) for kv in args.cfg_options)})
     distributed = args.launcher == 'pytorch'
     if distributed:
         import torch.distributed as dist

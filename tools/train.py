@@ -27,22 +27,9 @@ import torch                # noqa: E402
 import cgg_amd              # noqa: E402,F401
 from cgg_amd import registry, runtime, synthetic                                        # noqa: E402
 from cgg_amd.checkpoint import load_checkpoint, save_checkpoint                         # noqa: E402
-from cgg_amd.config import Config                                                        # noqa: E402
+from cgg_amd.config import Config, parse_option_value                                   # noqa: E402
 from cgg_amd.data_contract import OpenFormatBundle, collate, collect, to_forward_kwargs  # noqa: E402
 from cgg_amd.train import GradReducer, build_optimizer, train_step                       # noqa: E402
-
-
-def _parse_value(v):
-    for cast in (int, float):
-        try:
-            return cast(v)
-        except ValueError:
-            pass
-    if v in ('True', 'False', 'None'):
-        return {'True': True, 'False': False, 'None': None}[v]
-    if v.startswith(('[', '(')):
-        return json.loads(v.replace('(', '[').replace(')', ']').replace("'", '"'))
-    return [_parse_value(x) for x in v.split(',')] if ',' in v else v
 
 
 def parse_args(argv=None):
@@ -110,7 +97,7 @@ def main(argv=None):
     args = parse_args(argv)
     cfg = Config.fromfile(args.config)
     if args.cfg_options:
-        cfg.merge_from_dict({k: _parse_value(v) for k, v in (kv.split('=', 1) for kv in args.cfg_options)})
+        cfg.merge_from_dict({k: parse_option_value(v) for k, v in (kv.split('=', 1) for kv in args.cfg_options)})
     distributed = args.launcher == 'pytorch'
     if distributed:
         import torch.distributed as dist
