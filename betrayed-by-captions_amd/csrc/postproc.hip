@@ -809,3 +809,56 @@ extern "C" int cgg_rowwise_softmax_argmax(const float* x, float* prob, float* ma
   CGG_CHECK_LAUNCH("cgg_rowwise_softmax_argmax");
   return CGG_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Point sampling of a CHANNEL-LAST f32 map (training: the mask feature at the matching points of all decoder layers;
+// sample(E F) = E sample(F), mask2former_head.py:357-366 / [3P] mmcv.ops.point_sample = F.grid_sample(points * 2 - 1,
+// bilinear, zeros, align_corners=False)). ATen's grid_sampler_2d walks the C = 256 channel planes of an NCHW tensor per
+// point (4 scattered 4-byte loads per channel); here a point's 4 taps are 4 contiguous C * 4-byte rows and C / 4 lanes
+// share the geometry. Same coordinate arithmetic and accumulation order as the ATen kernel (unnormalise ((g + 1) * size - 1)
+// / 2 on g = 2 p - 1; nw, ne, sw, se).
+__global__ __launch_bounds__(256) void cgg_point_sample_nhwc_kernel(const float* __restrict__ feat, const float* __restrict__ pts,
+                                                                   float* __restrict__ out, int H, int W, int C4, int P,
+                                                                   long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // (b, p, c4)
+  if (i >= total) return;
+  const int c4 = (int)(i % C4);
+  const long long bp = i / C4;
+  const int b = (int)(bp / P);
+  const float px = pts[bp * 2], py = pts[bp * 2 + 1];
+  const float gx = __fsub_rn(__fmul_rn(px, 2.0f), 1.0f), gy = __fsub_rn(__fmul_rn(py, 2.0f), 1.0f);
+  const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 2.f);
+  const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 2.f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = __fsub_rn(ix, fx), ty = __fsub_rn(iy, fy);             // ix - ix_nw, iy - iy_nw
+  const float ux = __fsub_rn(__fadd_rn(fx, 1.f), ix), uy = __fsub_rn(__fadd_rn(fy, 1.f), iy);   // ix_se - ix, iy_se - iy
+  const float wnw = __fmul_rn(ux, uy), wne = __fmul_rn(tx, uy), wsw = __fmul_rn(ux, ty), wse = __fmul_rn(tx, ty);
+  const f32x4* fb = reinterpret_cast<const f32x4*>(feat) + (size_t)b * H * W * C4 + c4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+  f32x4 v;
+  if (xin0 && yin0) { v = fb[((size_t)y0 * W + x0) * C4];
+    acc[0] = fmaf(v[0], wnw, acc[0]); acc[1] = fmaf(v[1], wnw, acc[1]); acc[2] = fmaf(v[2], wnw, acc[2]); acc[3] = fmaf(v[3], wnw, acc[3]); }
+  if (xin1 && yin0) { v = fb[((size_t)y0 * W + x0 + 1) * C4];
+    acc[0] = fmaf(v[0], wne, acc[0]); acc[1] = fmaf(v[1], wne, acc[1]); acc[2] = fmaf(v[2], wne, acc[2]); acc[3] = fmaf(v[3], wne, acc[3]); }
+  if (xin0 && yin1) { v = fb[((size_t)(y0 + 1) * W + x0) * C4];
+    acc[0] = fmaf(v[0], wsw, acc[0]); acc[1] = fmaf(v[1], wsw, acc[1]); acc[2] = fmaf(v[2], wsw, acc[2]); acc[3] = fmaf(v[3], wsw, acc[3]); }
+  if (xin1 && yin1) { v = fb[((size_t)(y0 + 1) * W + x0 + 1) * C4];
+    acc[0] = fmaf(v[0], wse, acc[0]); acc[1] = fmaf(v[1], wse, acc[1]); acc[2] = fmaf(v[2], wse, acc[2]); acc[3] = fmaf(v[3], wse, acc[3]); }
+  reinterpret_cast<f32x4*>(out)[i] = acc;
+}
+
+extern "C" int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
+                                     cgg_stream_t stream) {
+  CGG_REQUIRE(feat && pts && out, CGG_EINVAL, "cgg_point_sample_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && P > 0, CGG_EINVAL, "cgg_point_sample_nhwc: bad sizes");
+  CGG_REQUIRE(C % 4 == 0, CGG_EUNSUPPORTED, "cgg_point_sample_nhwc: C %% 4 != 0 (C=%d)", C);
+  CGG_REQUIRE(cgg_aligned16(feat) && cgg_aligned16(out), CGG_EALIGN, "cgg_point_sample_nhwc: alignment");
+  const long long total = (long long)B * P * (C / 4);
+  hipLaunchKernelGGL(cgg_point_sample_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     feat, pts, out, H, W, C / 4, P, total);
+  CGG_CHECK_LAUNCH("cgg_point_sample_nhwc");
+  return CGG_OK;
+}

@@ -14,6 +14,7 @@ structures follow the reference; the execution is re-designed:
 Line references in the method docstrings point at the reference implementation being restated.
 """
 import copy
+import os
 import json
 import warnings
 
@@ -803,8 +804,18 @@ class Mask2FormerHeadOpen(nn.Module):
         else:
             pts = torch.stack([torch.cat([self._draw_points(dev) for _ in range(B)], 0) for _ in range(n)], 0)
         with torch.no_grad():
-            pred_pts = torch.stack([all_mask_preds[li].sample_points(pts[li]) if isinstance(all_mask_preds[li], LazyMasks)
-                                    else point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)
+            mf0 = all_mask_preds[0].mask_feature if isinstance(all_mask_preds[0], LazyMasks) else None
+            if (mf0 is not None and mf0.is_cuda and mf0.dtype == torch.float32 and mf0.shape[1] % 4 == 0
+                    and all(isinstance(m, LazyMasks) and m.mask_feature is mf0 for m in all_mask_preds)):
+                # all layers share the mask feature: ONE channel-last sampling pass at the n * P points of every image,
+                # then a (Q x C) x (C x P) product per layer (sample(E F) = E sample(F))
+                fs = ops.point_sample_nhwc(mf0.detach().permute(0, 2, 3, 1).contiguous(),
+                                           pts.permute(1, 0, 2, 3).reshape(B, n * P, 2))           # (B, n*P, C)
+                pred_pts = torch.stack([torch.bmm(all_mask_preds[li].mask_embed.detach().float(),
+                                                  fs[:, li * P:(li + 1) * P].transpose(1, 2)) for li in range(n)], 0)
+            else:
+                pred_pts = torch.stack([all_mask_preds[li].sample_points(pts[li]) if isinstance(all_mask_preds[li], LazyMasks)
+                                        else point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)
             costs, shapes = [], []
             for b in range(B):
                 G = int(gt_labels_list[b].shape[0])

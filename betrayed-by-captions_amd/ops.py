@@ -942,3 +942,17 @@ def linear_sum_assignment_batch(costs):
         out.append((rows[o:o + n], cols[o:o + n]))
         o += n
     return out
+
+
+def point_sample_nhwc(feat, points):
+    """feat (B, H, W, C) f32 channel-last, points (B, P, 2) in [0, 1] (x, y) -> (B, P, C): [3P] mmcv point_sample
+    (grid_sample bilinear / zeros / align_corners=False) with the layout that makes a point's taps contiguous rows."""
+    B, H, W, C = feat.shape
+    P = points.shape[1]
+    if feat.dtype != torch.float32 or not feat.is_contiguous() or points.dtype != torch.float32 or tuple(points.shape) != (B, P, 2):
+        raise CggError('point_sample_nhwc: feat (B, H, W, C) contiguous float32, points (B, P, 2) float32 expected')
+    pts = points.contiguous()
+    out = torch.empty((B, P, C), dtype=torch.float32, device=feat.device)
+    check(_lib_().cgg_point_sample_nhwc(dev_ptr(feat), dev_ptr(pts), dev_ptr(out), B, H, W, C, P, stream_ptr(feat.device)),
+          'cgg_point_sample_nhwc')
+    return out

@@ -322,6 +322,12 @@ int cgg_im2col3x3_nhwc(const void* x, void* y, int B, int H, int W, int C, int s
 int cgg_linear_sum_assignment_f32(const float* cost, int n_problems, const int* nr, const int* nc, int64_t* rows,
                                   int64_t* cols);
 
+/* [3P] mmcv.ops.point_sample (= F.grid_sample(2 p - 1, bilinear, zeros, align_corners=False)) on a CHANNEL-LAST f32 map:
+ * out[b, p, :] = bilinear sample of feat[b] (H, W, C) at pts[b, p] = (x, y) in [0, 1]; taps outside the map contribute 0.
+ * Used for sample(E F) = E sample(F) at the matching points of all decoder layers (mask2former_head.py:357-366). C % 4 == 0. */
+int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
+                          cgg_stream_t stream);
+
 /* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
  * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),
  * Ho = (H - 1) / 2 + 1. w_packed: cgg_stem_conv7x7_packed_bytes() bytes, bf16 MFMA A fragments

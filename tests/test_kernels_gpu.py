@@ -867,3 +867,15 @@ def test_pack_mask_feature_nhwc_multi_equals_single(dev):
     for p, m in zip(pools, multi):
         one = ops.pack_mask_feature_nhwc(mf, p)
         assert (m.h, m.w) == (one.h, one.w) and torch.equal(m.hi, one.hi)
+
+
+def test_point_sample_nhwc_matches_grid_sample(dev):
+    g = torch.Generator().manual_seed(77)
+    B, C, H, W, P = 2, 64, 24, 40, 500
+    feat = torch.randn(B, C, H, W, generator=g).to(dev)
+    pts = torch.rand(B, P, 2, generator=g).to(dev)
+    pts[0, :4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.999, 0.001], [0.5, 0.5]])      # borders: zero padding taps
+    got = ops.point_sample_nhwc(feat.permute(0, 2, 3, 1).contiguous(), pts)
+    want = torch.nn.functional.grid_sample(feat, (pts * 2.0 - 1.0).unsqueeze(2), align_corners=False).squeeze(3)   # (B, C, P)
+    assert torch.allclose(got, want.transpose(1, 2), atol=1e-6, rtol=1e-6)
+    assert (got == want.transpose(1, 2)).float().mean() > 0.99          # same arithmetic: bitwise on (nearly) all samples
