@@ -78,7 +78,7 @@ PROTOTYPES = {
     'cgg_instance_masks_multi': (_c_int, [_c_vp] * 7 + [_c_int] * 9 + [_c_vp]),
     'cgg_class_topk': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int] + [_c_vp] * 4),
     'cgg_instance_masks_picks_workspace_bytes': (_c_i64, [_c_int, _c_int]),
-    'cgg_instance_masks_picks': (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_int] * 9 + [_c_vp]),
+    'cgg_instance_masks_picks': (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_int] * 10 + [_c_vp]),
     'cgg_panoptic_argmax': (_c_int, [_c_vp] * 6 + [_c_int] * 10 + [_c_vp]),
     'cgg_panoptic_paint': (_c_int, [_c_vp] * 5 + [_c_i64, _c_int, _c_vp]),
     'cgg_rowwise_softmax_argmax': (_c_int, [_c_vp] * 4 + [_c_int, _c_int, _c_vp]),

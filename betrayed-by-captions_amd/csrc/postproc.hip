@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_kernel(const float* __
 // consecutive output pixels needs only 16/S + 2 source columns of two source rows (12 loads for S = 4
 // instead of 64) and compile-time weights. Same association order as torch:
 // hy*(hx*a + lx*b) + ly*(hx*c + lx*d).
-template <int S>
+// BITS: the masks leave bit-packed, [slot][out_h][out_w / 8] bytes with pixel x in bit (x & 7) of byte x >> 3 (numpy
+// unpackbits(bitorder='little')): 8x fewer bytes to write and, for host-side consumers, to copy over PCIe.
+template <int S, bool BITS>
 __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float* __restrict__ logits,
                                                                      const int32_t* __restrict__ sel,
                                                                      uint8_t* __restrict__ masks,
@@ -253,7 +255,10 @@ __global__ __launch_bounds__(256) void cgg_instance_masks_int_kernel(const float
       const u32x4_t pkv = {packed[0], packed[1], packed[2], packed[3]};
       for (int d = d0; d < d1; ++d) {
         const size_t slot = dest_off != nullptr ? (size_t)dest_slot[d] : (size_t)i;
-        __builtin_nontemporal_store(pkv, reinterpret_cast<u32x4_t*>(masks + slot * npix + (size_t)oy * g.out_w + ox0));
+        if (BITS)
+          reinterpret_cast<uint16_t*>(masks)[(slot * npix + (size_t)oy * g.out_w + ox0) >> 4] = (uint16_t)run;
+        else
+          __builtin_nontemporal_store(pkv, reinterpret_cast<u32x4_t*>(masks + slot * npix + (size_t)oy * g.out_w + ox0));
       }
     }
   }
@@ -439,9 +444,9 @@ extern "C" int cgg_instance_masks_multi(const float* logits, const int32_t* dest
 }
 
 // the mask pass itself (between the workspace init and the per-instance finalisation)
-static void instance_masks_dispatch(const float* logits, const int32_t* sel, const int32_t* dest_off,
+static bool instance_masks_dispatch(const float* logits, const int32_t* sel, const int32_t* dest_off,
                                     const int32_t* dest_slot, uint8_t* masks, int32_t* ws, const ResizeGeom& g, int H, int W,
-                                    int up_h, int up_w, int out_h, int out_w, int n, hipStream_t s) {
+                                    int up_h, int up_w, int out_h, int out_w, int n, hipStream_t s, bool bits = false) {
   const long long npix = (long long)out_h * out_w;
   const long long per_block = 256LL * IM_PPT;
   const dim3 grid((unsigned)((npix + per_block - 1) / per_block), n);
@@ -450,14 +455,25 @@ static void instance_masks_dispatch(const float* logits, const int32_t* sel, con
                         (((uintptr_t)masks) & 15) == 0;
   const long long ntile = (long long)((out_h + S - 1) / S) * (out_w / IM_PPT);   // one thread per 16 x S block
   const dim3 tgrid((unsigned)((ntile + 255) / 256), n);
+  if (bits) {
+    if (!(int_path && (S == 2 || S == 4 || S == 8))) return false;     // bit-packed output: integer-scale path only
+    if (S == 4)
+      hipLaunchKernelGGL((cgg_instance_masks_int_kernel<4, true>), tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+    else if (S == 2)
+      hipLaunchKernelGGL((cgg_instance_masks_int_kernel<2, true>), tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+    else
+      hipLaunchKernelGGL((cgg_instance_masks_int_kernel<8, true>), tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+    return true;
+  }
   if (int_path && S == 4)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<4>, tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+    hipLaunchKernelGGL((cgg_instance_masks_int_kernel<4, false>), tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
   else if (int_path && S == 2)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<2>, tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+    hipLaunchKernelGGL((cgg_instance_masks_int_kernel<2, false>), tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
   else if (int_path && S == 8)
-    hipLaunchKernelGGL(cgg_instance_masks_int_kernel<8>, tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+    hipLaunchKernelGGL((cgg_instance_masks_int_kernel<8, false>), tgrid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
   else
     hipLaunchKernelGGL(cgg_instance_masks_kernel, grid, dim3(256), 0, s, logits, sel, masks, ws, g, dest_off, dest_slot);
+  return true;
 }
 
 static int instance_masks_launch(const float* logits, const int32_t* sel, const int32_t* dest_off,
@@ -743,7 +759,7 @@ extern "C" int64_t cgg_instance_masks_picks_workspace_bytes(int Q, int n_picks) 
 
 extern "C" int cgg_instance_masks_picks(const float* logits, const int64_t* qidx, const float* cls_scores, int n_picks,
                                         uint8_t* masks, float* bboxes, void* ws, int Q, int H, int W, int up_h, int up_w,
-                                        int crop_h, int crop_w, int out_h, int out_w, cgg_stream_t stream) {
+                                        int crop_h, int crop_w, int out_h, int out_w, int bitpack, cgg_stream_t stream) {
   CGG_REQUIRE(logits && qidx && cls_scores && masks && bboxes && ws, CGG_EINVAL, "cgg_instance_masks_picks: null pointer");
   CGG_REQUIRE(Q > 0 && H > 0 && W > 0 && up_h > 0 && up_w > 0 && out_h > 0 && out_w > 0 && n_picks > 0, CGG_EINVAL,
               "cgg_instance_masks_picks: bad sizes");
@@ -755,8 +771,10 @@ extern "C" int cgg_instance_masks_picks(const float* logits, const int64_t* qidx
   const ResizeGeom g = make_geom(H, W, up_h, up_w, crop_h, crop_w, out_h, out_w);
   int32_t* wsi = (int32_t*)ws;
   hipLaunchKernelGGL(cgg_instance_plan_kernel, dim3(1), dim3(256), (size_t)(n_picks + Q + 1) * 4, s, qidx, n_picks, Q, wsi);
-  instance_masks_dispatch(logits, nullptr, wsi + (size_t)Q * 8, wsi + (size_t)Q * 9 + 1, masks, wsi, g, H, W, up_h, up_w,
-                          out_h, out_w, Q, s);
+  const bool ok = instance_masks_dispatch(logits, nullptr, wsi + (size_t)Q * 8, wsi + (size_t)Q * 9 + 1, masks, wsi, g, H, W,
+                                          up_h, up_w, out_h, out_w, Q, s, bitpack != 0);
+  CGG_REQUIRE(ok, CGG_EUNSUPPORTED,
+              "cgg_instance_masks_picks: bit-packed masks need an integer up-scale of 2 / 4 / 8, no second resize and out_w %% 16 == 0");
   hipLaunchKernelGGL(cgg_instance_final_picks_kernel, dim3(1), dim3(256), (size_t)Q * 20, s, (const int32_t*)wsi, qidx,
                      cls_scores, n_picks, Q, bboxes);
   CGG_CHECK_LAUNCH("cgg_instance_masks_picks");

@@ -145,9 +145,10 @@ class MaskFormerOpen(nn.Module):
         feats = None if kwargs.get('encoded') is not None else self.extract_feat(imgs)
         assigned_labels, mask_cls_emb_results, mask_pred_results, caption_results, att = \
             self.panoptic_head.simple_test(feats, img_metas, **kwargs)
+        host = not kwargs.get('device_results', False)
         results = self.panoptic_fusion_head.simple_test(assigned_labels, mask_cls_emb_results,
                                                         mask_pred_results, img_metas, **kwargs)
-        if kwargs.get('device_results', False):
+        if not host:
             return results
         fh = self.panoptic_fusion_head
         for i in range(len(results)):
@@ -167,6 +168,8 @@ class MaskFormerOpen(nn.Module):
                     labels_per_image, bboxes, mask_pred_binary = results[i][res_type]
                     bbox_results = bbox2result(bboxes, labels_per_image, pred_classes)
                     masks_np = mask_pred_binary.detach().cpu().numpy()      # ONE copy for all masks
+                    if masks_np.dtype == np.uint8:      # `mask_bits=True` was requested: (n, H, W / 8) -> the reference's bool
+                        masks_np = np.unpackbits(masks_np, axis=-1, bitorder='little').view(np.bool_)
                     mask_results = [[] for _ in range(pred_classes)]
                     for j, label in enumerate(labels_per_image.detach().cpu().tolist()):
                         mask_results[label].append(masks_np[j])

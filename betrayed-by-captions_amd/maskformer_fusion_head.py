@@ -269,7 +269,11 @@ class MaskFormerFusionHeadOpen(nn.Module):
                 # 4 launches per image: slot plan, one mask pass for all types, per-detection boxes / scores
                 labels, cls_scores, qidx = batch_picks
                 logits, up, crop, out = self._geom(mp, meta, rescale)
-                masks, bboxes = ops.instance_masks_picks(logits, qidx[b].reshape(-1), cls_scores[b].reshape(-1), up, crop, out)
+                # mask_bits (this build's extension): masks come back bit-packed, (n, H, W / 8) uint8 with pixel x in bit
+                # x & 7 -- 8x fewer bytes for a host-side consumer to copy; callers unpack (detectors.simple_test does)
+                bits = bool(kwargs.get('mask_bits', False)) and ops.instance_masks_bitpack_ok(logits.shape[-2:], up, crop, out)
+                masks, bboxes = ops.instance_masks_picks(logits, qidx[b].reshape(-1), cls_scores[b].reshape(-1), up, crop,
+                                                         out, bitpack=bits)
                 k = labels.shape[-1]
                 for t, (key, _) in enumerate(todo):
                     result[key] = (labels[b, t], bboxes[t * k:(t + 1) * k], masks[t * k:(t + 1) * k])

@@ -815,22 +815,32 @@ def class_topk_supported(Q, ncols, k):
             and 8 * k + 4 * Q * (max(ncols) - 1) + 4 * Q <= 62 * 1024)
 
 
-def instance_masks_picks(logits, qidx, cls_scores, up_size, crop_size, out_size):
+def instance_masks_picks(logits, qidx, cls_scores, up_size, crop_size, out_size, bitpack=False):
     """logits (Q,H,W) f32 low-res; qidx (n,) long / cls_scores (n,) f32: the picks of ALL evaluation types of one image
     -> masks (n,oh,ow) bool, bboxes (n,5) f32 = (box of the picked query, class score x mask score)."""
     Q, H, W = logits.shape
     oh, ow = int(out_size[0]), int(out_size[1])
     dev = logits.device
     n = int(qidx.numel())
-    masks = torch.empty((n, oh, ow), dtype=torch.uint8, device=dev)
+    if bitpack and ow % 16:
+        raise CggError('instance_masks_picks: bit-packed masks need out_w % 16 == 0')
+    masks = torch.empty((n, oh, ow // 8 if bitpack else ow), dtype=torch.uint8, device=dev)
     bboxes = torch.empty((n, 5), dtype=torch.float32, device=dev)
     ws = torch.empty((int(_lib_().cgg_instance_masks_picks_workspace_bytes(Q, n)) + 3) // 4, dtype=torch.int32, device=dev)
     rc = _lib_().cgg_instance_masks_picks(dev_ptr(logits, 'logits', torch.float32), dev_ptr(qidx, 'qidx', torch.int64),
                                           dev_ptr(cls_scores, 'cls_scores', torch.float32), n, dev_ptr(masks),
                                           dev_ptr(bboxes), dev_ptr(ws), Q, H, W, int(up_size[0]), int(up_size[1]),
-                                          int(crop_size[0]), int(crop_size[1]), oh, ow, stream_ptr(dev))
+                                          int(crop_size[0]), int(crop_size[1]), oh, ow, int(bool(bitpack)), stream_ptr(dev))
     check(rc, 'cgg_instance_masks_picks')
-    return masks.view(torch.bool), bboxes
+    return (masks if bitpack else masks.view(torch.bool)), bboxes
+
+
+def instance_masks_bitpack_ok(logits_hw, up_size, crop_size, out_size):
+    """Shapes the bit-packed mask output supports: integer up-scale 2 / 4 / 8, no second resize, width % 16 == 0."""
+    h, w = logits_hw
+    s = up_size[0] // h if h else 0
+    return (s in (2, 4, 8) and s * h == up_size[0] and s * w == up_size[1] and tuple(crop_size) == tuple(out_size)
+            and out_size[1] % 16 == 0)
 
 
 def bias_relu_maxpool_nhwc(x, bias):

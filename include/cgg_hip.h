@@ -402,11 +402,13 @@ int cgg_class_topk(const float* dots, int ld, int B, int Q, int n_types, const i
 /* The rest of :349-363 for ONE image and all its picks (all evaluation types concatenated): every picked query's mask
  * is interpolated once and stored into each detection slot that picked it (as cgg_instance_masks_multi, the slot plan
  * now built on the device), then bboxes[j] = (box of query qidx[j], cls_scores[j] * mask_score[qidx[j]]).
- * masks [n_picks, out_h, out_w] u8, bboxes [n_picks, 5] f32, ws: cgg_instance_masks_picks_workspace_bytes(Q, n_picks). */
+ * masks [n_picks, out_h, out_w] u8, bboxes [n_picks, 5] f32, ws: cgg_instance_masks_picks_workspace_bytes(Q, n_picks).
+ * bitpack != 0: masks [n_picks, out_h, out_w / 8] bytes, pixel x = bit (x & 7) of byte x >> 3 -- 8x fewer bytes for a
+ * host-side consumer to copy (integer up-scale 2 / 4 / 8 without a second resize, out_w % 16 == 0; else CGG_EUNSUPPORTED). */
 int64_t cgg_instance_masks_picks_workspace_bytes(int Q, int n_picks);
 int cgg_instance_masks_picks(const float* logits, const int64_t* qidx, const float* cls_scores, int n_picks,
                              uint8_t* masks, float* bboxes, void* ws, int Q, int H, int W, int up_h, int up_w,
-                             int crop_h, int crop_w, int out_h, int out_w, cgg_stream_t stream);
+                             int crop_h, int crop_w, int out_h, int out_w, int bitpack, cgg_stream_t stream);
 int cgg_panoptic_argmax(const float* logits, const int32_t* keep, const float* score, int32_t* ids,
                         uint8_t* win_half, int32_t* counts, int Q, int H, int W, int up_h, int up_w,
                         int crop_h, int crop_w, int out_h, int out_w, int n, cgg_stream_t stream);

@@ -401,3 +401,39 @@ def test_test_driver_pipeline_equals_sequential(dev, tmp_path):
         for k in ra:
             assert sorted(ra[k][0].tolist()) == sorted(rb[k][0].tolist())
             assert int(ra[k][2].sum()) == int(rb[k][2].sum())
+
+
+def test_simple_test_bitpacked_masks_equal_bool_masks(dev):
+    """`mask_bits=True` (opt-in: 8x fewer mask bytes for consumers that work on packed bits): the unpacked masks are the
+    bool masks, and the reference-format host results (per-class mask lists) agree with the device results."""
+    import numpy as np
+    from util import randomize
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+    randomize(model, seed=23)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.fill_(1.0)
+            m.running_mean.zero_()
+    model = model.to(dev).eval()
+    model.panoptic_fusion_head.test_cfg['max_per_image'] = 20      # k <= Q * n_classes for every type: the picks path
+    B, H, W = 2, 128, 192
+    metas = synthetic.img_metas(B, H, W)
+    img = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.no_grad(), runtime.precision_scope('bf16'):
+        a = model.simple_test(img, metas, rescale=True, device_results=True)
+        b = model.simple_test(img, metas, rescale=True, device_results=True, mask_bits=True)
+        host = model.simple_test(img, [dict(m) for m in metas], rescale=True)
+    for ra, rb, rh in zip(a, b, host):
+        for k in ra:
+            assert rb[k][2].dtype == torch.uint8 and rb[k][2].shape[-1] == W // 8
+            un = np.unpackbits(rb[k][2].cpu().numpy(), axis=-1, bitorder='little').astype(bool)
+            assert np.array_equal(un, ra[k][2].cpu().numpy())
+            assert torch.equal(ra[k][0], rb[k][0])
+            bbox_results, mask_results = rh[k]
+            n_host = sum(len(c) for c in mask_results)
+            assert n_host == ra[k][2].shape[0]
+            assert sum(int(m.sum()) for c in mask_results for m in c) == int(ra[k][2].sum())

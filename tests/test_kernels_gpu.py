@@ -8,6 +8,7 @@ same seeded inputs. Tolerances are written next to each check.
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -879,3 +880,21 @@ def test_point_sample_nhwc_matches_grid_sample(dev):
     want = torch.nn.functional.grid_sample(feat, (pts * 2.0 - 1.0).unsqueeze(2), align_corners=False).squeeze(3)   # (B, C, P)
     assert torch.allclose(got, want.transpose(1, 2), atol=1e-6, rtol=1e-6)
     assert (got == want.transpose(1, 2)).float().mean() > 0.99          # same arithmetic: bitwise on (nearly) all samples
+
+
+def test_instance_masks_picks_bitpacked(dev):
+    g = torch.Generator().manual_seed(78)
+    Q, H, W = 20, 24, 32
+    logits = (torch.randn(Q, H, W, generator=g) * 3).to(dev)
+    qidx = torch.randint(0, Q, (40,), generator=g).to(dev)
+    sc = torch.rand(40, generator=g).to(dev)
+    for up, crop in (((96, 128), (96, 128)), ((96, 128), (90, 112)), ((48, 64), (48, 64))):
+        assert ops.instance_masks_bitpack_ok((H, W), up, crop, crop)
+        m, bb = ops.instance_masks_picks(logits, qidx, sc, up, crop, crop)
+        p, bb2 = ops.instance_masks_picks(logits, qidx, sc, up, crop, crop, bitpack=True)
+        assert p.dtype == torch.uint8 and tuple(p.shape) == (40, crop[0], crop[1] // 8)
+        unpacked = np.unpackbits(p.cpu().numpy(), axis=-1, bitorder='little').astype(bool)
+        assert np.array_equal(unpacked, m.cpu().numpy())
+        assert torch.equal(bb[:, :4], bb2[:, :4]) and torch.allclose(bb[:, 4], bb2[:, 4], rtol=1e-5)
+    assert not ops.instance_masks_bitpack_ok((H, W), (96, 128), (90, 112), (45, 56))       # second resize
+    assert not ops.instance_masks_bitpack_ok((H, W), (72, 96), (72, 96), (72, 96))         # scale 3
