@@ -94,6 +94,9 @@ class LazyMasks:
         b / q / r = slot inside the image, host int pm = max positives per image): full-resolution logits (n_pos, h, w),
         image-major like boolean indexing; differentiable w.r.t. mask_embed and mask_feature. The positives are packed
         into a zero-padded (B, pm, C) operand so that ONE batched product serves the whole layer."""
+        pre = getattr(self, '_pre', None)
+        if pre is not None and pre[0] is pos:
+            return pre[1]
         B, Q, C = self.mask_embed.shape
         h, w = self.mask_feature.shape[-2:]
         pm = int(pos['pm'])
@@ -103,6 +106,31 @@ class LazyMasks:
         ep = self.mask_embed.new_zeros((B, pm, C)).index_put((bi, ri), self.mask_embed[bi, qi])
         full = torch.bmm(ep, self.mask_feature.flatten(2).to(ep.dtype))         # (B, pm, h*w)
         return full[bi, ri].view(-1, h, w)
+
+    @staticmethod
+    def preselect(lazies, pos_list):
+        """`select` of ALL decoder layers as one batched product: the layers share the mask feature, so their zero-padded
+        positive embeddings are concatenated along the slot axis -- (B, sum pm_l, C) x (C, h*w) -- instead of 10 skinny
+        products with 10-20 rows each, and autograd produces ONE mask-feature gradient instead of accumulating ten 1-GB
+        ones. Each layer's `select(pos)` then returns its slice."""
+        mf = lazies[0].mask_feature
+        if not all(l.mask_feature is mf for l in lazies):
+            return
+        B, _, C = lazies[0].mask_embed.shape
+        h, w = mf.shape[-2:]
+        eps, offs, off = [], [], 0
+        for lz, pos in zip(lazies, pos_list):
+            pm = int(pos['pm'])
+            offs.append(off)
+            if pm:
+                eps.append(lz.mask_embed.new_zeros((B, pm, C)).index_put((pos['b'], pos['r']), lz.mask_embed[pos['b'], pos['q']]))
+                off += pm
+        if off == 0:
+            return
+        full = torch.bmm(torch.cat(eps, 1), mf.flatten(2).to(eps[0].dtype))              # (B, sum pm, h*w)
+        for lz, pos, o in zip(lazies, pos_list, offs):
+            if int(pos['pm']):
+                lz._pre = (pos, full[pos['b'], o + pos['r']].view(-1, h, w))
 
     def select_by_weights(self, weights):
         """same from a (B, Q) weight map (host round trip for the index set)."""
@@ -1160,6 +1188,8 @@ class Mask2FormerHeadOpen(nn.Module):
             ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)[:, 1:].flatten(0, 1)
             logits = logits.view(n, B * T1, -1)
             cap_losses = [self.loss_caption_generation(logits[li], ids) for li in range(n)]
+        if all(isinstance(m, LazyMasks) for m in all_mask_preds):
+            LazyMasks.preselect(list(all_mask_preds), [t[5] for t in targets])
         results = []
         for li in range(n):
             results.append(self.loss_single(
