@@ -29,7 +29,7 @@ class StagePipeline:
     example  -- an example input batch (shape / dtype / device are frozen into the graphs)
     """
 
-    def __init__(self, stages, example, slots=None, warmup=2, priorities=None):
+    def __init__(self, stages, example, slots=None, warmup=2, priorities=None, streams=None):
         self.stages = list(stages)
         n = len(self.stages)
         self.slots = slots if slots is not None else max(2, n)
@@ -38,7 +38,8 @@ class StagePipeline:
         import os
         if priorities is None and os.environ.get('CGG_PIPE_PRIO'):
             priorities = [int(v) for v in os.environ['CGG_PIPE_PRIO'].split(',')]
-        self.streams = [torch.cuda.Stream(dev, priority=(priorities[i] if priorities else 0)) for i in range(n)]
+        self.streams = list(streams) if streams is not None else \
+            [torch.cuda.Stream(dev, priority=(priorities[i] if priorities else 0)) for i in range(n)]
         self.inputs = [torch.empty_like(example) for _ in range(self.slots)]
         self.done = [[torch.cuda.Event() for _ in range(self.slots)] for _ in range(n)]
         self.graphs = [[None] * self.slots for _ in range(n)]
