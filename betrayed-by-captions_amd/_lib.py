@@ -71,6 +71,7 @@ PROTOTYPES = {
     'cgg_point_sample_nhwc': (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     'cgg_stream_create_cumask': (_c_int, [_c_vp, _c_int, _c_vp]),
     'cgg_stream_destroy': (_c_int, [_c_vp]),
+    'cgg_subsample_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_bias_relu_maxpool_nhwc': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_bias_act_nhwc': (_c_int, [_c_vp] * 3 + [_c_i64, _c_int, _c_int, _c_vp]),
     'cgg_group_norm_workspace_bytes': (_c_i64, [_c_int] * 5),

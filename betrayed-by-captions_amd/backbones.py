@@ -193,7 +193,7 @@ class ResNet(nn.Module):
         if w2 is not None:
             sh, sw = conv.stride
             if sh > 1 or sw > 1:
-                x = x[:, ::sh, ::sw, :].contiguous()
+                x = ops.subsample_nhwc(x, sh) if (sh == sw and x.is_cuda) else x[:, ::sh, ::sw, :].contiguous()
             x2 = x.reshape(-1, x.shape[-1])
             r2 = res.reshape(-1, res.shape[-1]) if res is not None else None
             if r2 is not None and x2.is_contiguous() and w2.is_contiguous() and r2.is_contiguous():

@@ -165,3 +165,31 @@ extern "C" int cgg_im2col3x3_nhwc(const void* x, void* y, int B, int H, int W, i
   CGG_CHECK_LAUNCH("cgg_im2col3x3_nhwc");
   return 0;
 }
+
+// x[:, ::s, ::s, :] of a channel-last bf16 map as a contiguous tensor (input of the stride-s 1x1 downsample convolution
+// of a ResNet stage, which then is a plain GEMM): 16-byte vectors, one read of the kept pixels only.
+__global__ __launch_bounds__(256) void cgg_subsample_nhwc_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int H, int W,
+                                                                int Ho, int Wo, int c8, int stride, long long nvec) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // (b, oy, ox, c8)
+  if (i >= nvec) return;
+  const int c = (int)(i % c8);
+  long long p = i / c8;
+  const int ox = (int)(p % Wo);
+  p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int b = (int)(p / Ho);
+  y[i] = x[(((size_t)b * H + (size_t)oy * stride) * W + (size_t)ox * stride) * c8 + c];
+}
+
+extern "C" int cgg_subsample_nhwc(const void* x, void* y, int B, int H, int W, int C, int stride, cgg_stream_t stream) {
+  CGG_REQUIRE(x && y, CGG_EINVAL, "cgg_subsample_nhwc: null pointer");
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && stride >= 1, CGG_EINVAL, "cgg_subsample_nhwc: bad sizes");
+  CGG_REQUIRE(C % 8 == 0, CGG_EUNSUPPORTED, "cgg_subsample_nhwc: C %% 8 != 0 (C=%d)", C);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(y), CGG_EALIGN, "cgg_subsample_nhwc: pointers must be 16-byte aligned");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long nvec = (long long)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(cgg_subsample_nhwc_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, (uint4*)y, H, W, Ho, Wo, C / 8, stride, nvec);
+  CGG_CHECK_LAUNCH("cgg_subsample_nhwc");
+  return 0;
+}

@@ -979,3 +979,14 @@ def masked_stream(device, cu_mask_bits):
     with torch.cuda.device(device):
         check(_lib_().cgg_stream_create_cumask(arr, len(words), ctypes.byref(out)), 'cgg_stream_create_cumask')
     return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def subsample_nhwc(x, stride):
+    """x (B, H, W, C) channel-last bf16 -> x[:, ::stride, ::stride, :] as a new contiguous tensor."""
+    B, H, W, C = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or C % 8:
+        return x[:, ::stride, ::stride, :].contiguous()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    check(_lib_().cgg_subsample_nhwc(dev_ptr(x), dev_ptr(y), B, H, W, C, int(stride), stream_ptr(x.device)), 'cgg_subsample_nhwc')
+    return y

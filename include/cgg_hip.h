@@ -340,6 +340,10 @@ int cgg_stream_destroy(void* stream);
 int64_t cgg_stem_conv7x7_packed_bytes(void);
 int cgg_stem_conv7x7_nchw(const float* img, const void* w_packed, void* out, int B, int H, int W, cgg_stream_t stream);
 
+/* y[B, Ho, Wo, C] = x[B, ::stride, ::stride, C] (channel-last bf16, Ho = (H - 1) / stride + 1): the input of a stride-2 1x1
+ * downsample convolution ([3P] mmdet ResNet, style='pytorch') as a contiguous GEMM operand.                           */
+int cgg_subsample_nhwc(const void* x, void* y, int B, int H, int W, int C, int stride, cgg_stream_t stream);
+
 /* Stem tail of the BN-folded [3P] mmdet ResNet (`maxpool(relu(bn1(conv1(x))))`), channel-last bf16, one pass:
  *   y[B, Ho, Wo, C] = relu(maxpool3x3/s2/p1(x[B, H, W, C]) + bias[C]),  Ho = (H - 1) / 2 + 1 (same for W).          */
 int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,

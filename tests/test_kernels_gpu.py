@@ -898,3 +898,10 @@ def test_instance_masks_picks_bitpacked(dev):
         assert torch.equal(bb[:, :4], bb2[:, :4]) and torch.allclose(bb[:, 4], bb2[:, 4], rtol=1e-5)
     assert not ops.instance_masks_bitpack_ok((H, W), (96, 128), (90, 112), (45, 56))       # second resize
     assert not ops.instance_masks_bitpack_ok((H, W), (72, 96), (72, 96), (72, 96))         # scale 3
+
+
+def test_subsample_nhwc(dev):
+    g = torch.Generator().manual_seed(79)
+    for (B, H, W, C, st) in [(2, 16, 20, 32, 2), (1, 7, 9, 8, 2), (1, 6, 6, 16, 3)]:
+        x = torch.randn(B, H, W, C, generator=g).bfloat16().to(dev)
+        assert torch.equal(ops.subsample_nhwc(x, st), x[:, ::st, ::st, :].contiguous())
