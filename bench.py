@@ -8,6 +8,11 @@ results stay on the device (BASELINE.json configs[1]: R50, 100 queries, 1024x102
 N > 1: one process per GPU (torch.distributed / RCCL only for the barrier), every rank runs its own
 replica on its own batch -> weak scaling, no data-path collective (inference: "replicas only").
 
+Launch: `python bench.py --gpus N` starts the N ranks ITSELF (child processes created before the parent touches the
+GPU; rank r binds device r, RCCL for the barrier / max-over-ranks); under an external launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) RANK / LOCAL_RANK / WORLD_SIZE come from
+the environment and `--gpus` must agree with WORLD_SIZE (it fails loudly otherwise).
+
 Prints ONE JSON line (rank 0). Extra objects:
   roofline      -- the mask-logit kernel (einsum 'bqc,bchw->bqhw', cgg_mask_logits, full resolution),
                    timed with events on the launch stream INSIDE the timed steps.
@@ -47,10 +52,13 @@ def build_model(args, dev):
 
 
 def cpu_baseline(args, cfg, model, img_cpu):
-    """oracle path on the host: the SAME weights, one batch; backbone = the same plain-torch ResNet."""
+    """oracle path on the host: the SAME weights; backbone = the same plain-torch ResNet. One un-timed warm-up pass, then
+    the median of 3 timed passes over ONE image of the benched workload, plus SURVEY 8(d)'s cfg-1 case (512 x 512,
+    batch 1) timed the same way. `cores` = host cores of the box, `threads` = torch intra-op threads actually used."""
     import copy
+    import statistics
     from oracle import head as OH
-    from cgg_amd import synthetic
+    from cgg_amd import runtime, synthetic
     hc = copy.deepcopy(cfg['panoptic_head'])
     hc.update(train_cfg=cfg['train_cfg'], test_cfg=cfg['test_cfg'])
     with warnings.catch_warnings():
@@ -59,28 +67,43 @@ def cpu_baseline(args, cfg, model, img_cpu):
     sd = {k: v.detach().cpu() for k, v in model.panoptic_head.state_dict().items()}
     orc.load_state_dict(sd)
     orc.eval()
-    import copy as _c
-    backbone = _c.deepcopy(model.backbone).cpu().eval()
+    backbone = copy.deepcopy(model.backbone).cpu().eval()
     fh = model.panoptic_fusion_head
     embs = [fh.all_class_embs.cpu(), fh.novel_class_embs.cpu(), fh.base_class_embs.cpu()]
-    img_cpu = img_cpu[:1]                      # bounded sample: ONE image of the same workload
-    B, _, H, W = img_cpu.shape
-    metas = synthetic.img_metas(B, H, W)
-    threads = min(os.cpu_count() or 1, 32)
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
     torch.set_num_threads(threads)
-    from cgg_amd import runtime
-    t0 = time.perf_counter()
-    with torch.no_grad(), runtime.precision_scope('fp32'):      # the CPU reference path is plain f32 torch
-        feats = backbone(img_cpu)
-        _, emb, up = orc.simple_test(list(feats), metas)
-        for b in range(B):
-            mp = OH.crop_rescale(up[b], metas[b], True)
-            for e in embs:
-                OH.instance_postprocess_emb(emb[b], mp, e, 100)
-    dt = time.perf_counter() - t0
-    return dict(value=B / dt, unit='images/sec', cores=threads, kind='port',
-                sample=f'1 step = {B} images {H}x{W}, full detector forward + instance post-processing '
-                       f'(torch CPU oracle, fp32, {threads} threads), {dt:.1f} s')
+
+    def one_pass(x):
+        B, _, H, W = x.shape
+        metas = synthetic.img_metas(B, H, W)
+        t0 = time.perf_counter()
+        with torch.no_grad(), runtime.precision_scope('fp32'):      # the CPU reference path is plain f32 torch
+            feats = backbone(x)
+            _, emb, up = orc.simple_test(list(feats), metas)
+            for b in range(B):
+                mp = OH.crop_rescale(up[b], metas[b], True)
+                for e in embs:
+                    OH.instance_postprocess_emb(emb[b], mp, e, 100)
+        return time.perf_counter() - t0
+
+    def timed(x, reps=3):
+        one_pass(x)                                                  # warm-up: allocator, thread pool, first-touch
+        ts = [one_pass(x) for _ in range(reps)]
+        return statistics.median(ts), ts
+
+    full = img_cpu[:1]                      # bounded sample: ONE image of the same workload
+    H, W = full.shape[-2:]
+    dt, ts = timed(full)
+    small = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(4321))
+    dt1, ts1 = timed(small)
+    return dict(value=1.0 / dt, unit='images/sec', cores=cores, threads=threads, kind='port',
+                sample=f'1 image {H}x{W} of the benched workload, full detector forward + instance post-processing '
+                       f'(torch CPU oracle, fp32, {threads} threads on {cores} host cores): 1 warm-up + median of 3 '
+                       f'timed passes ({", ".join("%.2f" % t for t in ts)} s)',
+                cfg1_512=dict(value=1.0 / dt1, unit='images/sec',
+                              sample='configs[0]: one 512x512 image, same pipeline, 1 warm-up + median of 3 '
+                                     f'({", ".join("%.2f" % t for t in ts1)} s)'))
 
 
 def pmc_traffic(kernel, B, H, W):
@@ -104,6 +127,62 @@ def pmc_traffic(kernel, B, H, W):
         tot[cnt] = sum(vals) / len(vals) * 1024.0 * mult
     return tot['FETCH_SIZE'] + tot['WRITE_SIZE'], ('profiles/r1_pmc_{fetch,write}_counter_collection.csv: separate '
                                                    'rocprofv3 --pmc passes; FETCH_SIZE x2 (gfx950 correction), KB units')
+
+
+def rocprof_launch_mean(kernel):
+    """Per-launch mean of `kernel`'s full-resolution launches in the committed rocprofv3 kernel trace of this command
+    (profiles/r2_hot_kernel_launches.json, written by scratch/publish_profiles.py) -- the cross-check for `launch_ms`."""
+    for rnd in ('r2', 'r1'):
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_hot_kernel_launches.json')
+        if os.path.exists(path):
+            try:
+                rec = json.load(open(path)).get(kernel)
+            except Exception:
+                rec = None
+            if rec:
+                return dict(rec, source=os.path.relpath(path, ROOT))
+    return None
+
+
+def parity_mode_rate(args, model, img, metas, dev):
+    """images/sec of the SAME step in parity mode (`--precision fp32`: f32 GEMMs / values, 3x-bf16-split MFMA mask
+    logits, f32 MFMA attention -- the mode the 1e-3 / bit-exact parity tests run in), timed in this process right after
+    the headline region: the step captured once into a hipGraph and replayed K times (eager if capture fails)."""
+    from cgg_amd import runtime
+    with runtime.precision_scope('fp32'):
+        def step():
+            with torch.no_grad():
+                return model.simple_test(img, metas, rescale=True, device_results=True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        graph, how = None, 'eager launches'
+        if args.graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step()
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.cuda.graph(graph):
+                    step()
+                graph.replay()
+                torch.cuda.synchronize()
+                how = 'one hipGraph per step, replayed back to back'
+            except Exception as e:
+                print(f'bench.py: parity-mode hipGraph capture failed ({type(e).__name__}: {e}); eager', file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        steps = max(args.steps // 2, 5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay() if graph is not None else step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(value=img.shape[0] * steps / dt, unit='images/sec (this rank)', ms_per_step=dt / steps * 1e3, steps=steps,
+                precision='fp32', how=how)
 
 
 def train_main(args, cfg, model, img, metas, dev, rank, world):
@@ -139,7 +218,7 @@ def train_main(args, cfg, model, img, metas, dev, rank, world):
         logs = train_step(model, optimizer, reducer, data, clip)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if args.shared_devices else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -158,6 +237,29 @@ def train_main(args, cfg, model, img, metas, dev, rank, world):
             loss=logs.get('loss'), peak_mem_gb=torch.cuda.max_memory_allocated() / 2**30)))
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the
+    torch.distributed environment (rendezvous on 127.0.0.1), BEFORE this process makes any GPU call (a process that
+    has initialised the GPU must not exec / fork GPU work on this pool; `device_count()` does not initialise it).
+    Rank 0's stdout (the JSON line) is passed through; the exit code is the first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    bad = [c for c in codes if c != 0]
+    if bad:
+        raise SystemExit(f'bench.py: rank exit codes {codes}')
+    return 0
 
 
 def main():
@@ -182,20 +284,36 @@ def main():
                          '3 = backbone | pixel decoder + K/V | query decoder + post-processing, 2 = the first two '
                          'merged, 0 = one graph per step replayed back to back')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-mode', action='store_true',
+                    help='skip the fp32 (parity-mode) timing of the same step that is reported as config.parity_mode_value')
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 2 if args.mode == 'infer' else 16
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)             # parent: starts the ranks, never touches the GPU itself
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; they must agree '
+                         '(run `python bench.py --gpus N` alone, or torch.distributed.run --nproc-per-node N ... --gpus N)')
+    ndev = torch.cuda.device_count()         # does not initialise the GPU
+    if ndev < 1:
         raise SystemExit('bench.py needs a ROCm device (the hot path has no CPU implementation)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    shared = world > ndev                    # fewer devices than ranks (1-GPU dev box): ranks share devices, dry run only
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device('cuda', local_rank % ndev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if shared:
+            # RCCL refuses two ranks on one device: the barrier / max-over-ranks go over gloo; the line says so
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=dev)
+    args.shared_devices = shared
 
     import cgg_amd
     from cgg_amd import ops, runtime, synthetic
@@ -215,6 +333,7 @@ def main():
             return model.simple_test(img, metas, rescale=True, device_results=True)
 
     def barrier():
+        torch.cuda.synchronize()             # (gloo dry run: the device work must be done before the host barrier)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -276,10 +395,26 @@ def main():
     events = ops.KERNEL_EVENTS or {}
     ops.KERNEL_EVENTS = None
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if args.shared_devices else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    # ---- per-batch latency: ONE step alone (no cross-step overlap), submit -> results complete ----
+    lat = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if pipe is not None:
+            pipe.submit(img)
+            pipe.flush()
+        elif graph is not None:
+            graph.replay()
+        else:
+            out = step()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    latency_ms = sorted(lat)[len(lat) // 2]
 
     # ---- roofline of the mask-logit kernel (full resolution) ----
     timed_how = 'HIP events around the launch inside the timed steps'
@@ -294,8 +429,9 @@ def main():
         timed_how = ('HIP events around the launch in the same %d steps re-run eagerly right after the timed hipGraph '
                      'replays (events cannot be recorded inside a replay)' % args.steps)
     torch.cuda.synchronize()
-    # an event pair with nothing between it still measures a few microseconds (event-record latency on the stream):
-    # calibrate it in situ and subtract it, so that the number is the kernel's duration as rocprofv3 reports it
+    # `frac` comes from the RAW event mean. An event pair with nothing between it still measures a few microseconds
+    # (event-record latency on the stream); that floor is calibrated in situ and reported beside it as a secondary,
+    # overhead-adjusted figure (`*_event_adjusted`), never as `frac`.
     pairs = []
     for _ in range(64):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -305,8 +441,8 @@ def main():
     torch.cuda.synchronize()
     ev_over = min(a.elapsed_time(b) for a, b in pairs)     # the floor: anything above it is queueing noise, not event cost
     ml = [s.elapsed_time(e) for s, e in events['mask_logits_full']]
-    ml_raw_ms = sum(ml) / len(ml)
-    ml_ms = max(ml_raw_ms - ev_over, 1e-6)
+    ml_ms = sum(ml) / len(ml)                              # raw event mean
+    ml_adj_ms = max(ml_ms - ev_over, 1e-6)
     HW4 = (H // 4) * (W // 4)
     Q = args.queries
     in_bytes = 2 if args.precision == 'bf16' else 4       # packed bf16 (hi) or hi+lo = 4 B / element
@@ -318,16 +454,22 @@ def main():
     roofline = dict(bound='hbm', kernel='cgg_mask_logits_kernel', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, launch_ms=ml_ms, launches_timed=len(ml),
                     algorithmic_bytes=alg_bytes, tflops=tfs, frac_mfma_bf16_peak=tfs / MFMA_BF16_PEAK_TF,
-                    timed=timed_how, event_pair_overhead_ms=ev_over, launch_ms_raw=ml_raw_ms)
+                    timed=timed_how, event_pair_overhead_ms=ev_over, launch_ms_event_adjusted=ml_adj_ms,
+                    frac_event_adjusted=alg_bytes / (ml_adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    rocprof=rocprof_launch_mean('cgg_mask_logits_kernel'))
     extra = {}
     if events.get('msda_fused'):
         ms = [s.elapsed_time(e) for s, e in events['msda_fused']]
-        ms = max(sum(ms) / len(ms) - ev_over, 1e-6)
+        ms = sum(ms) / len(ms)                              # raw event mean
         N = sum((H // s) * (W // s) for s in (8, 16, 32))
         vb = 2 if args.precision == 'bf16' else 4         # bf16 stream: value, offsets|logits and output are bf16
         mbytes = B * N * (256 * vb + 288 * vb + 256 * vb)
         extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9)
 
+    parity = None
+    if args.precision == 'bf16' and not args.no_parity_mode:
+        del pipe, graph
+        parity = parity_mode_rate(args, model, img, metas, dev)
     if rank == 0:
         res = dict(metric='images/sec (COCO-shaped 1024x1024, 100 queries, forward-only)',
                    value=B * world * args.steps / dt, unit='images/sec', n_gpus=world, steps=args.steps,
@@ -339,10 +481,12 @@ def main():
                                         'decoder + mask logits + instance post-processing, results on device)',
                                global_batch=B * world, parallelism=f'replicas x{world}',
                                precision=args.precision, hip_graph=bool(args.graph),
+                               parity_mode_value=None if parity is None else parity['value'],
+                               ranks_share_devices=bool(args.shared_devices),
                                pipeline=(f'{args.pipeline}-stage software pipeline across steps (one HIP stream + hipGraph '
                                          'per stage and buffer slot; every timed step completes inside the timed '
                                          'region)') if pipe is not None else 'none'),
-                   roofline=roofline, kernels=extra)
+                   latency_ms_per_batch=latency_ms, parity_mode=parity, roofline=roofline, kernels=extra)
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args, cfg, model, img_cpu)
         print(json.dumps(res))

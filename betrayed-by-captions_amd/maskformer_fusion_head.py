@@ -249,6 +249,9 @@ class MaskFormerFusionHeadOpen(nn.Module):
         """:369-464 -> list (one dict per image) keyed by eval type."""
         eval_types = self.test_cfg.get('eval_types', [])
         rescale = kwargs.get('rescale', False)
+        # this build's extension for index-parity checks: the (query, class) picks behind every detection, i.e. the
+        # `top_indices // n_cls` of :344-347 that the reference computes and drops
+        want_idx = bool(kwargs.get('with_query_indices', False))
         results = []
         todo = [(key, embs) for key, embs in (('all_results', getattr(self, 'all_class_embs', None)),
                                               ('novel_results', getattr(self, 'novel_class_embs', None)),
@@ -277,11 +280,17 @@ class MaskFormerFusionHeadOpen(nn.Module):
                 k = labels.shape[-1]
                 for t, (key, _) in enumerate(todo):
                     result[key] = (labels[b, t], bboxes[t * k:(t + 1) * k], masks[t * k:(t + 1) * k])
+                if want_idx:
+                    result['query_indices'] = {key: qidx[b, t].long() for t, (key, _) in enumerate(todo)}
+                    result['class_scores'] = {key: cls_scores[b, t] for t, (key, _) in enumerate(todo)}
             elif todo:
                 geom = self._geom(mp, meta, rescale)
                 picks = [self._topk(self.get_cls_emb_scores(emb, embs)[:, :-1]) for _, embs in todo]
                 for (key, _), r in zip(todo, self._instances_multi(picks, geom)):
                     result[key] = r
+                if want_idx:
+                    result['query_indices'] = {key: p[2].long() for (key, _), p in zip(todo, picks)}
+                    result['class_scores'] = {key: p[1] for (key, _), p in zip(todo, picks)}
             if 'ins_results' in eval_types:
                 result['ins_results'] = self.instance_postprocess(mask_cls_result, mp, meta, rescale)
             if 'pan_results' in eval_types:

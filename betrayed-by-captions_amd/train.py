@@ -5,9 +5,14 @@ configs/instance/coco_b48n17.py:270-286) is restated here for an xGMI node:
 
   * `GradReducer` -- gradients live as VIEWS into a few large flat buckets (default 64 MiB: a ring
     all-reduce over point-to-point xGMI links is per-link bound, so few large messages beat many small ones);
-    a post-accumulate hook per parameter launches the bucket's asynchronous all-reduce as soon as its last
-    gradient lands, so the exchange overlaps the rest of backward on RCCL's own stream. No gradient copy in,
-    no copy out, no per-parameter collectives. `broadcast_buffers=False` as in the reference (frozen BN).
+    a post-accumulate hook per parameter marks the bucket ready when its last gradient lands and launches the
+    asynchronous all-reduces STRICTLY IN BUCKET ORDER (a ready bucket k waits until buckets 0..k-1 have been
+    launched; `finish()` flushes the rest in the same order), so every rank enqueues the same sequence of
+    collectives even when the autograd graphs differ between ranks (an image without GT, a parameter unused on
+    one rank only) -- RCCL matches collectives by issue order. The exchange overlaps the rest of backward on
+    RCCL's own stream. No gradient copy in, no copy out, no per-parameter collectives.
+    `broadcast_buffers=False` as in the reference (frozen BN); `broadcast_parameters` = DDP's construction-time
+    rank-0 broadcast.
   * `build_optimizer` -- AdamW with the `paramwise_cfg` semantics of [3P] mmcv DefaultOptimizerConstructor
     for the keys the shipped configs use (`custom_keys` lr_mult / decay_mult, `norm_decay_mult`).
   * `clip_grad_norm_` over the flat buckets (`grad_clip=dict(max_norm=0.01, norm_type=2)`).
@@ -51,6 +56,8 @@ class GradReducer:
             for p, _, _ in b['params']:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self._armed = False
+        self._next = 0
+        self.launch_log = []        # bucket indices in launch order of the last step (tests)
 
     def _seal(self, plist):
         # 128-byte aligned slots so every view is vector-load friendly
@@ -64,7 +71,8 @@ class GradReducer:
             p.grad = flat[off:off + p.numel()].view_as(p)
             entries.append((p, off, p.numel()))
             self._owner[p] = len(self.buckets)
-        self.buckets.append(dict(flat=flat, params=entries, pending=len(entries), handle=None, launched=False))
+        self.buckets.append(dict(flat=flat, params=entries, pending=len(entries), handle=None, launched=False,
+                                 ready=False, index=len(self.buckets)))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -74,8 +82,15 @@ class GradReducer:
             # autograd may have replaced the view (first accumulation into a None grad): restore it
             b['pending'] -= 1
             if b['pending'] == 0:
-                self._launch(b)
+                b['ready'] = True
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Launch the longest prefix of ready buckets: collective k is only ever issued after 0..k-1."""
+        while self._next < len(self.buckets) and self.buckets[self._next]['ready']:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _check_views(self, b):
         flat = b['flat']
@@ -91,6 +106,7 @@ class GradReducer:
     def _launch(self, b):
         self._check_views(b)
         b['launched'] = True
+        self.launch_log.append(b['index'])
         if self.world > 1:
             b['flat'].div_(self.world)
             b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -102,22 +118,34 @@ class GradReducer:
             b['pending'] = len(b['params'])
             b['handle'] = None
             b['launched'] = False
+            b['ready'] = False
             for p, off, n in b['params']:
                 if p.grad is None or p.grad.data_ptr() != b['flat'][off:off + n].data_ptr():
                     p.grad = b['flat'][off:off + n].view_as(p)
+        self._next = 0
+        self.launch_log = []
         self._armed = True
 
     def finish(self):
         """After backward: reduce buckets whose parameters did not all receive a gradient this step (their
         missing gradients are zeros, identically on every rank) and wait for every exchange."""
         self._armed = False
-        for b in self.buckets:
-            if not b['launched']:
-                self._launch(b)
+        while self._next < len(self.buckets):          # same order as the hooks use: 0, 1, 2, ...
+            self._launch(self.buckets[self._next])
+            self._next += 1
         for b in self.buckets:
             if b['handle'] is not None:
                 b['handle'].wait()
                 b['handle'] = None
+
+    def broadcast_parameters(self, module, src=0):
+        """Rank `src`'s parameters AND buffers to every rank, once, before the first step ([3P] DDP does this at
+        construction; `broadcast_buffers=False` only switches off the per-step re-broadcast)."""
+        if self.world <= 1:
+            return
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=src, group=self.group)
 
     def flats(self):
         return [b['flat'] for b in self.buckets]
@@ -179,6 +207,57 @@ def build_optimizer(model, cfg):
     if typ != 'AdamW':
         raise NotImplementedError(f'optimizer type {typ!r}: the shipped configs use AdamW')
     return torch.optim.AdamW(param_groups, foreach=True, **cfg)
+
+
+class LrSchedule:
+    """`lr_config` of the shipped configs (configs/instance/coco_b48n17.py:289-297), [3P] mmcv `StepLrUpdaterHook`
+    semantics with `by_epoch=False`: before iteration `it` every param group gets
+    `initial_lr * gamma ** #{s in step : it >= s}` (not below `min_lr`), and while `it < warmup_iters` that value is
+    scaled by the warmup rule ('linear': `1 - (1 - it / warmup_iters) * (1 - warmup_ratio)`, 'constant':
+    `warmup_ratio`, 'exp': `warmup_ratio ** (1 - it / warmup_iters)`). Stateless in `it`, so resuming from
+    `meta.iter` restores the schedule."""
+
+    def __init__(self, optimizer, cfg=None):
+        cfg = dict(cfg or {})
+        self.policy = cfg.get('policy', 'fixed')
+        if self.policy not in ('step', 'fixed'):
+            raise NotImplementedError(f'lr policy {self.policy!r}: the shipped configs use "step"')
+        if cfg.get('by_epoch', False):
+            raise NotImplementedError('by_epoch=True needs the dataset length (datasets are out of scope); '
+                                      'the shipped configs set by_epoch=False')
+        step = cfg.get('step', [])
+        self.steps = [step] if isinstance(step, int) else list(step)
+        self.gamma = cfg.get('gamma', 0.1)
+        self.min_lr = cfg.get('min_lr')
+        self.warmup = cfg.get('warmup')
+        if self.warmup not in (None, 'linear', 'constant', 'exp'):
+            raise ValueError(f'warmup {self.warmup!r}')
+        self.warmup_iters = cfg.get('warmup_iters', 0)
+        self.warmup_ratio = cfg.get('warmup_ratio', 0.1)
+        self.optimizer = optimizer
+        # base rates are taken from the optimizer AS BUILT from the config (construct the schedule before loading a
+        # resumed optimizer state, whose groups carry the already-decayed rates)
+        self.initial = [g.get('initial_lr', g['lr']) for g in optimizer.param_groups]
+
+    def lr_at(self, base, it):
+        lr = base
+        if self.policy == 'step':
+            lr = base * self.gamma ** sum(1 for s in self.steps if it >= s)
+            if self.min_lr is not None:
+                lr = max(lr, self.min_lr)
+        if self.warmup is not None and it < self.warmup_iters:
+            if self.warmup == 'constant':
+                lr = lr * self.warmup_ratio
+            elif self.warmup == 'linear':
+                lr = lr * (1 - (1 - it / self.warmup_iters) * (1 - self.warmup_ratio))
+            else:
+                lr = lr * self.warmup_ratio ** (1 - it / self.warmup_iters)
+        return lr
+
+    def apply(self, it):
+        for g, base in zip(self.optimizer.param_groups, self.initial):
+            g['initial_lr'] = base
+            g['lr'] = self.lr_at(base, it)
 
 
 def train_step(model, optimizer, reducer, data, grad_clip=None):

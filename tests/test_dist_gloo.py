@@ -105,6 +105,47 @@ def _worker(rank, world, port, ret):
         after = torch.sqrt(sum((f ** 2).sum() for f in red.flats()))
         assert after <= 0.01 * (1 + 1e-4)
         red.remove()
+        # --- ranks with DIFFERENT autograd graphs: rank 1 plays the image without GT -- its loss
+        # skips the `mask` branch entirely (parameters unused on that rank only) and reaches the `early` branch's
+        # parameters in the opposite order. Collectives must still be issued 0,1,2,... on both ranks.
+        torch.manual_seed(1)
+        net2 = torch.nn.ModuleDict(dict(early=torch.nn.Linear(8, 8), mask=torch.nn.Linear(8, 8),
+                                        cls=torch.nn.Linear(8, 8), late=torch.nn.Linear(8, 8)))
+        x2 = torch.randn(4, 8, generator=torch.Generator().manual_seed(200 + rank))
+
+        def loss2(r, x):
+            h = net2['early'](x)
+            if r == 0:
+                return net2['late'](net2['cls'](h)).square().sum() + net2['mask'](h).sum()
+            return net2['cls'](net2['late'](h)).square().sum()          # no `mask`, cls/late swapped
+        want2 = []
+        for r in range(world):
+            net2.zero_grad(set_to_none=True)
+            xr = torch.randn(4, 8, generator=torch.Generator().manual_seed(200 + r))
+            loss2(r, xr).backward()
+            want2.append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net2.parameters()])
+        net2.zero_grad(set_to_none=True)
+        red2 = GradReducer(net2, bucket_bytes=64)           # one bucket per tensor
+        assert len(red2.buckets) == 8
+        for _ in range(2):
+            red2.zero_grad()
+            loss2(rank, x2).backward()
+            red2.finish()
+            assert red2.launch_log == list(range(8)), red2.launch_log      # strictly in bucket order on every rank
+            for i, p in enumerate(net2.parameters()):
+                mean = sum(w[i] for w in want2) / world
+                assert torch.allclose(p.grad, mean, atol=1e-6), i
+        red2.remove()
+        # --- broadcast_parameters: rank 0's weights everywhere (DDP construction semantics) ---
+        torch.manual_seed(1000 + rank)
+        net3 = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+        red3 = GradReducer(net3)
+        red3.broadcast_parameters(net3)
+        flat3 = torch.cat([t.reshape(-1).float() for t in list(net3.parameters()) + list(net3.buffers())])
+        both = [torch.zeros_like(flat3) for _ in range(world)]
+        dist.all_gather(both, flat3)
+        assert torch.equal(both[0], both[1])
+        red3.remove()
         dist.barrier()
         dist.destroy_process_group()
         ret[rank] = 'ok'

@@ -403,6 +403,56 @@ def test_test_driver_pipeline_equals_sequential(dev, tmp_path):
             assert int(ra[k][2].sum()) == int(rb[k][2].sum())
 
 
+def mixed_shape_stream(cfg, rank, world):
+    """`--data` hook for the driver test: 2 images at 128x128, 3 at 128x160 (a shape change in the middle of a
+    batch), 2 at 128x128 again (the first pipeline is reused) and one trailing 128x160 image (odd batch)."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(128, 128)] * 2 + [(128, 160)] * 3 + [(128, 128)] * 2 + [(128, 160)]
+    for i, (h, w) in enumerate(shapes):
+        if i % world != rank:
+            continue
+        meta = synthetic.img_metas(1, h, w)[0]
+        yield torch.randn(3, h, w, generator=g), dict(meta, filename=f'mixed_{i}.jpg')
+
+
+def test_test_driver_mixed_shapes_keep_order(dev, tmp_path):
+    """ADVICE r1 (tools/test.py): when the image shape changes, the batch in flight is drained from the pipeline that
+    produced it BEFORE a new pipeline is used, non-pipelined batches do not overtake pending ones, and the trailing
+    odd batch is kept -- results arrive in dataset order and equal the sequential loop's."""
+    import importlib.util
+    import sys
+    from util import randomize
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+    randomize(model, seed=21)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.fill_(1.0)
+            m.running_mean.zero_()
+    from cgg_amd.checkpoint import save_checkpoint
+    ck = save_checkpoint(model, str(tmp_path / 'w.pth'))
+    cfg_file = tmp_path / 'tiny.py'
+    cfg_file.write_text('model = ' + repr(cfg) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    spec = importlib.util.spec_from_file_location('cgg_tools_test2', os.path.join(root, 'tools', 'test.py'))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    a = drv.main([str(cfg_file), ck, '--data', 'test_head_gpu:mixed_shape_stream'])
+    b = drv.main([str(cfg_file), ck, '--data', 'test_head_gpu:mixed_shape_stream', '--no-pipeline'])
+    widths = [128] * 2 + [160] * 3 + [128] * 2 + [160]
+    assert len(a) == 8 and len(b) == 8
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        for k in ra:
+            assert ra[k][2].shape[-1] == widths[i] and rb[k][2].shape[-1] == widths[i], (i, k)   # dataset order
+            assert sorted(ra[k][0].tolist()) == sorted(rb[k][0].tolist()), (i, k)
+            assert int(ra[k][2].sum()) == int(rb[k][2].sum()), (i, k)
+
+
 def test_simple_test_bitpacked_masks_equal_bool_masks(dev):
     """`mask_bits=True` (opt-in: 8x fewer mask bytes for consumers that work on packed bits): the unpacked masks are the
     bool masks, and the reference-format host results (per-class mask lists) agree with the device results."""

@@ -364,3 +364,38 @@ def test_cfg_option_values():
     cfg = Config(dict(optimizer=dict(lr=1e-4, betas=(0.9, 0.999)), model=dict(layers=[dict(k=1), dict(k=2)])))
     cfg.merge_from_dict({'optimizer.lr': parse_option_value('2e-4'), 'model.layers.1.k': parse_option_value('7')})
     assert cfg.optimizer.lr == 2e-4 and cfg.model.layers[1].k == 7
+
+
+def test_test_driver_reinterleaves_rank_shards():
+    """tools/test.py --launcher pytorch: rank r serves images r, r + world, ...; rank 0 restores dataset order."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('cgg_tools_test_cpu', os.path.join(root, 'tools', 'test.py'))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    for n, world in ((7, 2), (8, 2), (10, 4), (3, 4), (0, 2)):
+        parts = [[i for i in range(n) if i % world == r] for r in range(world)]
+        assert drv.interleave_rank_results(parts) == list(range(n))
+
+
+def test_lr_schedule_step_with_linear_warmup():
+    """configs/instance/coco_b48n17.py:289-297 semantics ([3P] mmcv StepLrUpdaterHook, by_epoch=False)."""
+    from cgg_amd.train import LrSchedule
+    w = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.AdamW([dict(params=[w[0]], lr=1e-4), dict(params=[w[1]], lr=1e-5)])
+    sch = LrSchedule(opt, dict(policy='step', gamma=0.1, by_epoch=False, step=[70, 80], warmup='linear',
+                               warmup_by_epoch=False, warmup_ratio=0.5, warmup_iters=10))
+    want = {0: 0.5, 5: 0.75, 9: 0.95, 10: 1.0, 69: 1.0, 70: 0.1, 79: 0.1, 80: 0.01, 1000: 0.01}
+    for it, f in want.items():
+        sch.apply(it)
+        assert abs(opt.param_groups[0]['lr'] - 1e-4 * f) < 1e-12 and abs(opt.param_groups[1]['lr'] - 1e-5 * f) < 1e-13, it
+    # warmup_ratio = 1.0 (the shipped config: "no warmup") leaves the step policy alone
+    sch = LrSchedule(opt, dict(policy='step', gamma=0.1, step=[3], warmup='linear', warmup_ratio=1.0, warmup_iters=10))
+    sch.apply(0)
+    assert abs(opt.param_groups[0]['lr'] - 1e-4) < 1e-12
+    sch.apply(3)
+    assert abs(opt.param_groups[0]['lr'] - 1e-5) < 1e-12
+    # resumed optimizer state (decayed rates in the groups) does not change the base rates
+    opt.param_groups[0]['lr'] = 123.0
+    sch.apply(0)
+    assert abs(opt.param_groups[0]['lr'] - 1e-4) < 1e-12

@@ -75,6 +75,20 @@ def to_numpy(result):
     return out
 
 
+def interleave_rank_results(parts):
+    """Per-rank result lists (image i was served by rank i % world) -> one list in dataset order: what [3P] mmcv
+    `collect_results` does with `zip(*part_list)` (reference tools/test.py -> apis/test.py:79-130), without its
+    padding duplicates because the shards here are not padded to equal length."""
+    world = len(parts)
+    total = sum(len(p) for p in parts)
+    out = []
+    for i in range(total + world):
+        r, j = i % world, i // world
+        if j < len(parts[r]):
+            out.append(parts[r][j])
+    return out[:total]
+
+
 def main(argv=None):
     args = parse_args(argv)
     cfg = Config.fromfile(args.config)
@@ -108,11 +122,17 @@ def main(argv=None):
         stream = (s for i, s in enumerate(synthetic_images(args.num_images, args.synthetic, seed=11)) if i % world == rank)
 
     B = args.samples_per_gpu
-    results, pending = [], []
+    results, pending = [], []          # pending: (pipeline, slot) pairs -- a slot is only meaningful for ITS pipeline
     n_img, t0 = 0, None
     pipe = None
     with torch.no_grad(), runtime.precision_scope(args.precision):
         group = []
+
+        def drain():
+            """copy out every batch still in flight, in submission order, from the pipeline that produced it"""
+            while pending:
+                owner, slot = pending.pop(0)
+                results.extend(to_numpy(r) for r in owner.wait(slot))
 
         def run(group):
             nonlocal pipe, t0, n_img
@@ -121,34 +141,43 @@ def main(argv=None):
             use_pipe = (not args.no_pipeline and args.precision == 'bf16' and len(group) == B
                         and all(m['img_shape'] == metas[0]['img_shape'] and m['ori_shape'] == metas[0]['ori_shape'] for m in metas))
             if use_pipe:
-                if pipe is None or pipe.inputs[0].shape != imgs.shape or pipe.meta_key != (metas[0]['img_shape'], metas[0]['ori_shape']):
-                    from cgg_amd.pipeline import detector_pipeline
-                    pipe = detector_pipeline(model, imgs, metas, stages=2, rescale=True, device_results=True, mask_bits=args.mask_bits)
-                    pipe.meta_key = (metas[0]['img_shape'], metas[0]['ori_shape'])
-                    torch.cuda.synchronize()
-                    t0, n_img = time.perf_counter(), 0
+                key = (tuple(imgs.shape), metas[0]['img_shape'], metas[0]['ori_shape'])
+                if pipe is None or pipe.meta_key != key:
+                    drain()            # the old pipeline's results leave before its buffers are dropped
+                    pipe = pipes.get(key)
+                    if pipe is None:
+                        from cgg_amd.pipeline import detector_pipeline
+                        pipe = detector_pipeline(model, imgs, metas, stages=2, rescale=True, device_results=True, mask_bits=args.mask_bits)
+                        pipe.meta_key = key
+                        pipes[key] = pipe
+                        torch.cuda.synchronize()
+                    if t0 is None:
+                        t0, n_img = time.perf_counter(), 0
                 slot = pipe.submit(imgs)
                 # results of the PREVIOUS batch are copied out while this one runs (slot buffers are reused 2 batches later)
-                if pending:
-                    results.extend(to_numpy(r) for r in pipe.wait(pending.pop()))
-                pending.append(slot)
+                drain()
+                pending.append((pipe, slot))
             else:
+                drain()                # keep dataset order: earlier batches first
                 if t0 is None:
                     t0 = time.perf_counter()
                 results.extend(to_numpy(r) for r in model.simple_test(imgs, metas, rescale=True, device_results=True, mask_bits=args.mask_bits))
             n_img += len(group)
 
+        pipes = {}                     # one captured pipeline per (batch shape, img_shape, ori_shape)
         for sample in stream:
+            # a batch holds images of ONE padded shape (the reference pads a batch to its largest image through the
+            # dataset's collate; this driver takes pre-sized tensors and starts a new batch when the shape changes)
+            if group and tuple(sample[0].shape) != tuple(group[0][0].shape):
+                run(group)
+                group = []
             group.append(sample)
             if len(group) == B:
                 run(group)
                 group = []
-        if pending:
-            results.extend(to_numpy(r) for r in pipe.wait(pending.pop()))
         if group:
-            saved, args.no_pipeline = args.no_pipeline, True
-            run(group)
-            args.no_pipeline = saved
+            run(group)                 # trailing short batch: sequential path (len(group) != B)
+        drain()
         torch.cuda.synchronize()
     dt = time.perf_counter() - (t0 or time.perf_counter())
     if distributed:
@@ -156,7 +185,7 @@ def main(argv=None):
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(results, gathered, dst=0)
         if rank == 0:
-            results = [r for part in gathered for r in part]
+            results = interleave_rank_results(gathered)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(dict(images=len(results), images_per_sec_this_rank=round(n_img / max(dt, 1e-9), 1),

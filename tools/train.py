@@ -29,7 +29,7 @@ from cgg_amd import registry, runtime, synthetic                                
 from cgg_amd.checkpoint import load_checkpoint, save_checkpoint                         # noqa: E402
 from cgg_amd.config import Config, parse_option_value                                   # noqa: E402
 from cgg_amd.data_contract import OpenFormatBundle, collate, collect, to_forward_kwargs  # noqa: E402
-from cgg_amd.train import GradReducer, build_optimizer, train_step                       # noqa: E402
+from cgg_amd.train import GradReducer, LrSchedule, build_optimizer, train_step                    # noqa: E402
 
 
 def parse_args(argv=None):
@@ -110,9 +110,12 @@ def main(argv=None):
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
     device = torch.device('cuda', local) if torch.cuda.is_available() else torch.device('cpu')
-    seed = (args.seed if args.seed is not None else 0) + (rank if args.diff_seed else 0)
-    torch.manual_seed(seed)
-    np.random.seed(seed)
+    # the MODEL is initialised from the same seed on every rank (and rank 0's weights are broadcast below, as DDP does
+    # at construction); --diff-seed only offsets the data / sampling RNG, which is re-seeded after the model is built
+    base_seed = args.seed if args.seed is not None else 0
+    seed = base_seed + (rank if args.diff_seed else 0)
+    torch.manual_seed(base_seed)
+    np.random.seed(base_seed)
     if args.deterministic:
         torch.backends.cudnn.deterministic = True
         torch.backends.cudnn.benchmark = False
@@ -125,6 +128,7 @@ def main(argv=None):
         model.init_weights()
     model = model.to(device).train()
     optimizer = build_optimizer(model, cfg.optimizer)
+    schedule = LrSchedule(optimizer, cfg.get('lr_config'))      # stateless in the iteration -> resume restores it
     grad_clip = (cfg.get('optimizer_config') or {}).get('grad_clip')
     start_iter = 0
     resume = args.resume_from or cfg.get('resume_from')
@@ -136,6 +140,9 @@ def main(argv=None):
     elif cfg.get('load_from'):
         load_checkpoint(model, cfg.load_from, map_location='cpu')
     reducer = GradReducer(model)
+    reducer.broadcast_parameters(model)          # [3P] DDP construction: rank 0's parameters and buffers everywhere
+    torch.manual_seed(seed)
+    np.random.seed(seed)
 
     spg = args.samples_per_gpu or (cfg.get('data') or {}).get('samples_per_gpu', 2)
     head = cfg.model['panoptic_head']
@@ -146,7 +153,10 @@ def main(argv=None):
     else:
         vocab = ((head.get('caption_generator') or {}).get('nb_tokens')) or 30522      # token ids must index the table
         samples = synthetic_samples(args.synthetic, num_classes, seed=1000 * rank + seed, vocab=vocab)
-    max_iters = args.max_iters or (cfg.get('runner') or {}).get('max_iters') or 100
+    max_iters = args.max_iters or (cfg.get('runner') or {}).get('max_iters')
+    if not max_iters:
+        # EpochBasedRunner configs (max_epochs) need the dataset length, which this driver does not have
+        raise SystemExit('tools/train.py: the config has no runner.max_iters (epoch-based runner); pass --max-iters N')
 
     log = open(os.path.join(work_dir, 'train.log.json'), 'a') if rank == 0 else None
     t0 = time.perf_counter()
@@ -155,6 +165,7 @@ def main(argv=None):
         for data in batches(samples, spg, device):
             if it >= max_iters:
                 break
+            schedule.apply(it)
             logs = train_step(model, optimizer, reducer, data, grad_clip)
             it += 1
             if rank == 0 and (it % args.log_interval == 0 or it == max_iters):
