@@ -467,8 +467,9 @@ def main():
         extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9)
 
     parity = None
+    pipelined = pipe is not None
     if args.precision == 'bf16' and not args.no_parity_mode:
-        del pipe, graph
+        pipe = graph = None                  # release the captured graphs' buffers before the second mode
         parity = parity_mode_rate(args, model, img, metas, dev)
     if rank == 0:
         res = dict(metric='images/sec (COCO-shaped 1024x1024, 100 queries, forward-only)',
@@ -485,7 +486,7 @@ def main():
                                ranks_share_devices=bool(args.shared_devices),
                                pipeline=(f'{args.pipeline}-stage software pipeline across steps (one HIP stream + hipGraph '
                                          'per stage and buffer slot; every timed step completes inside the timed '
-                                         'region)') if pipe is not None else 'none'),
+                                         'region)') if pipelined else 'none'),
                    latency_ms_per_batch=latency_ms, parity_mode=parity, roofline=roofline, kernels=extra)
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args, cfg, model, img_cpu)

@@ -134,6 +134,30 @@ def backbone_feats(B, H, W, channels=(256, 512, 1024, 2048), seed=0, device='cpu
     return [torch.randn(B, c, H // s, W // s, generator=g).to(device) for c, s in zip(channels, (4, 8, 16, 32))]
 
 
+def structured_images(B, H, W, seed=0, shapes=24, noise=0.15):
+    """Normalised-image-like batch WITH spatial structure: a smooth background plus `shapes` random rectangles /
+    ellipses of random colour per image and a little noise. White-noise images average out in a stride-4 backbone and
+    give spatially constant features (every mask all-on or all-off); parity tests need masks with real boundaries."""
+    g = torch.Generator().manual_seed(seed)
+    ys = torch.linspace(-1, 1, H).view(1, H, 1)
+    xs = torch.linspace(-1, 1, W).view(1, 1, W)
+    out = torch.empty(B, 3, H, W)
+    for b in range(B):
+        a = torch.randn(3, 1, 1, generator=g)
+        img = a * ys + torch.randn(3, 1, 1, generator=g) * xs + 0.3 * torch.randn(3, 1, 1, generator=g)
+        for i in range(shapes):
+            cy, cx = (torch.rand(2, generator=g) * 2 - 1).tolist()
+            ry, rx = (torch.rand(2, generator=g) * 0.35 + 0.04).tolist()
+            col = torch.randn(3, 1, 1, generator=g) * 1.2
+            if i % 2 == 0:
+                m = ((ys - cy).abs() <= ry) & ((xs - cx).abs() <= rx)
+            else:
+                m = ((ys - cy) / ry)**2 + ((xs - cx) / rx)**2 <= 1
+            img = torch.where(m, col.expand(3, H, W), img)
+        out[b] = img + noise * torch.randn(3, H, W, generator=g)
+    return out
+
+
 def img_metas(B, H, W, ori=None):
     ori = ori or (H, W)
     return [dict(img_shape=(H, W, 3), ori_shape=(ori[0], ori[1], 3), pad_shape=(H, W, 3),

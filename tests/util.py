@@ -70,6 +70,7 @@ class MaskTeacher:
         self.orc = oracle_head
         self.margin = margin
         self.seen = []
+        self.worst = []
 
     def run_oracle(self, fn):
         self.orc.trace = dict(attn_logits=[])
@@ -88,12 +89,14 @@ class MaskTeacher:
         mine = ops.unpack_bits(bits, S).cpu()
         want = lg < 0
         clear = lg.abs() > self.margin
+        wrong = mine != want
+        self.worst.append(float(lg.abs()[wrong].max()) if bool(wrong.any()) else 0.0)   # largest |logit| with a flipped bit
         self.seen.append((bool(torch.equal(mine[clear], want[clear])), float(clear.float().mean())))
         return pack_bool_mask(want).to(bits.device).contiguous()
 
     def check(self):
         assert self.seen, 'hook never called'
-        assert all(ok for ok, _ in self.seen), self.seen
+        assert all(ok for ok, _ in self.seen), (self.seen, self.worst)
         assert min(frac for _, frac in self.seen) > 0.98, self.seen
 
 
