@@ -520,8 +520,9 @@ def instance_postprocess_emb(emb, mask_pred, gt_embs, max_per_image=100):
 
 
 def panoptic_postprocess_emb(emb, mask_pred, gt_embs, num_classes, num_things, object_mask_thr=0.8,
-                             iou_thr=0.8, filter_low_score=False, stuff_area_limit=4096):
-    """:77-159."""
+                             iou_thr=0.8, filter_low_score=False, stuff_area_limit=4096, debug=None):
+    """:77-159. `debug` (a dict, tests only) receives the decision margins: per-pixel top1 - top2 probability, the
+    winner's |sigmoid - 0.5|, per-query |score - thr|, per-segment |area ratio - iou_thr| and stuff |area - limit|."""
     scores, labels = cls_emb_scores(emb, gt_embs).max(-1)
     mask_pred = mask_pred.sigmoid()
     keep = labels.ne(num_classes) & (scores > object_mask_thr)
@@ -530,8 +531,14 @@ def panoptic_postprocess_emb(emb, mask_pred, gt_embs, num_classes, num_things, o
     h, w = mask_pred.shape[-2:]
     seg = torch.full((h, w), num_classes, dtype=torch.int32)
     stuff = []
+    if debug is not None:
+        debug.update(score_margin=(scores - object_mask_thr).abs(), kept=int(keep.sum()), ratio_margin=[], stuff_margin=[])
     if cm.shape[0] > 0:
         ids = prob.argmax(0)
+        if debug is not None:
+            top2 = prob.topk(min(2, prob.shape[0]), dim=0)[0]
+            debug['pixel_margin'] = (top2[0] - top2[1]) if prob.shape[0] > 1 else torch.full_like(top2[0], float('inf'))
+            debug['half_margin'] = (cm.gather(0, ids[None])[0] - 0.5).abs()
         inst = 1
         for k in range(cc.shape[0]):
             pc = int(cc[k].item())
@@ -541,6 +548,8 @@ def panoptic_postprocess_emb(emb, mask_pred, gt_embs, num_classes, num_things, o
             if filter_low_score:
                 mask = mask & (cm[k] >= 0.5)
             if area > 0 and orig > 0:
+                if debug is not None:
+                    debug['ratio_margin'].append(abs(area / orig - iou_thr))
                 if area / orig < iou_thr:
                     continue
                 if pc >= num_things:
@@ -550,6 +559,8 @@ def panoptic_postprocess_emb(emb, mask_pred, gt_embs, num_classes, num_things, o
                 inst += 1
         for k in stuff:
             mask = (ids == k) & (seg == num_classes)
+            if debug is not None:
+                debug['stuff_margin'].append(abs(mask.sum().item() - stuff_area_limit))
             if mask.sum().item() < stuff_area_limit:
                 continue
             seg[mask] = int(cc[k].item())

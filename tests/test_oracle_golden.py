@@ -290,3 +290,37 @@ def test_g9_open_format_bundle_matches_reference():
         assert float(res['scale_factor']) == float(z[f'c{case}_scale_factor'])
         assert np.array_equal(res['img_norm_cfg']['mean'], z[f'c{case}_norm_mean'])
         assert np.array_equal(res['img_norm_cfg']['std'], z[f'c{case}_norm_std'])
+
+
+def test_swin_product_module_equals_dense_oracle():
+    """`cgg_amd.swin.SwinTransformer` (roll + window partition + SDPA + nn.Unfold merging) against `oracle.swin.OracleSwin`
+    (dense per-pair window membership / region mask / relative-position lookup, explicit 2x2 gather, patch matmul): the
+    two formulations share only the parameter tensors. Sizes that are NOT multiples of the patch / window size exercise
+    the padding paths of both; depths (2, 2, 2, 2) put a shifted block and a merge in every stage."""
+    import torch
+    import cgg_amd  # noqa: F401
+    from cgg_amd import registry
+    from oracle.swin import OracleSwin
+    from util import randomize
+    kw = dict(embed_dims=32, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), window_size=7, mlp_ratio=4,
+              out_indices=(0, 1, 2, 3), patch_norm=True)
+    bb = registry.build_backbone(dict(type='SwinTransformer', drop_path_rate=0.1, **kw))
+    randomize(bb, seed=3)
+    with torch.no_grad():
+        for n, p in bb.named_parameters():
+            if n.endswith('relative_position_bias_table'):
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))))     # O(1) biases
+    bb.eval()
+    orc = OracleSwin(**kw)
+    missing, unexpected = orc.load_state_dict(bb.state_dict(), strict=False)
+    assert not missing and all(k.endswith('relative_position_index') for k in unexpected), (missing, unexpected)
+    orc.eval()
+    for shape in ((1, 3, 90, 128), (2, 3, 112, 84)):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(shape[2]))
+        with torch.no_grad():
+            want = orc(x)
+            got = bb(x)
+        assert len(want) == len(got) == 4
+        for a, b in zip(got, want):
+            assert a.shape == b.shape
+            assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (a - b).abs().max().item()
