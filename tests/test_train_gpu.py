@@ -50,16 +50,19 @@ def test_forward_train_losses_and_gradients(dev):
     # ---- oracle (cpu) ----
     teacher = MaskTeacher(orc)
     orc.point_hook = Bank(7)
-    with torch.no_grad():
-        oc, oe, om = teacher.run_oracle(lambda: orc.forward(feats, metas))
-        olosses = orc.loss(oc, oe, om, batch['gt_labels'], [m.long() for m in batch['gt_masks']],
-                           batch['gt_caption_ids'], batch['gt_caption_mask'], batch['gt_caption_nouns_ids'],
-                           batch['gt_caption_nouns_mask'])
+    ofeats = [f.clone().requires_grad_(True) for f in feats]
+    oc, oe, om = teacher.run_oracle(lambda: orc.forward(ofeats, metas))
+    olosses = orc.loss(oc, oe, om, batch['gt_labels'], [m.long() for m in batch['gt_masks']],
+                       batch['gt_caption_ids'], batch['gt_caption_mask'], batch['gt_caption_nouns_ids'],
+                       batch['gt_caption_nouns_mask'])
+    sum(olosses.values()).backward()            # the oracle's gradients: plain torch autograd on the CPU
+    ograds = {k: (None if p.grad is None else p.grad.clone()) for k, p in orc.named_parameters()}
     # ---- product (device), oracle masks injected (tie-aware parity, see util.MaskTeacher) ----
     prod.point_hook = Bank(7)
     prod.attn_mask_hook = teacher.hook
     to = lambda lst: [t.to(dev) for t in lst]   # noqa: E731
-    losses = prod.forward_train([f.to(dev).requires_grad_(True) for f in feats], metas, to(batch['gt_bboxes']),
+    pfeats = [f.to(dev).requires_grad_(True) for f in feats]
+    losses = prod.forward_train(pfeats, metas, to(batch['gt_bboxes']),
                                 to(batch['gt_labels']), to(batch['gt_masks']), None, to(batch['gt_caption_ids']),
                                 to(batch['gt_caption_mask']), to(batch['gt_caption_nouns_ids']),
                                 to(batch['gt_caption_nouns_mask']))
@@ -72,14 +75,43 @@ def test_forward_train_losses_and_gradients(dev):
     total = sum(v for v in losses.values())
     total.backward()
     named = dict(prod.named_parameters())
+    # GRADIENT PARITY: every hand-written backward on the path -- the tiled MSDeformAttn backward
+    # kernel (sampling_offsets / attention_weights / value_proj), the masked cross-attention backward from bit masks
+    # (in_proj / out_proj), the mask-logit contraction backward (mask_embed, mask_feature), the LazyMasks
+    # E.sample(F) rewrite, the de-duplicated grounding loss (v2l_transform) and the caption head -- against the oracle's
+    # autograd: max |dg| <= 1e-3 of the gradient's own scale, per parameter.
+    worst = {}
     for key in ['pixel_decoder.encoder.layers.0.attentions.0.sampling_offsets.weight',
+                'pixel_decoder.encoder.layers.0.attentions.0.sampling_offsets.bias',
                 'pixel_decoder.encoder.layers.1.attentions.0.attention_weights.weight',
                 'pixel_decoder.encoder.layers.0.attentions.0.value_proj.weight',
+                'pixel_decoder.encoder.layers.1.attentions.0.output_proj.weight',
+                'pixel_decoder.encoder.layers.0.ffns.0.layers.0.0.weight',
+                'pixel_decoder.input_convs.0.conv.weight', 'pixel_decoder.lateral_convs.0.conv.weight',
+                'pixel_decoder.output_convs.0.conv.weight', 'pixel_decoder.mask_feature.weight',
+                'pixel_decoder.level_encoding.weight', 'level_embed.weight',
                 'transformer_decoder.layers.0.attentions.0.attn.in_proj_weight',
-                'transformer_decoder.layers.2.ffns.0.layers.1.weight', 'mask_embed.4.weight', 'v2l_transform.weight',
-                'query_feat.weight', 'caption_generator.generator.weight', 'pixel_decoder.mask_feature.weight']:
+                'transformer_decoder.layers.1.attentions.0.attn.out_proj.weight',
+                'transformer_decoder.layers.1.attentions.1.attn.in_proj_weight',
+                'transformer_decoder.layers.2.ffns.0.layers.1.weight', 'transformer_decoder.post_norm.weight',
+                'mask_embed.0.weight', 'mask_embed.4.weight', 'v2l_transform.weight', 'query_feat.weight',
+                'query_embed.weight', 'caption_generator.generator.weight',
+                'caption_generator.transformer_decoder.decoders.0.crx_layer.to_key.weight']:
         g = named[key].grad
         assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, key
+        og = ograds[key]
+        assert og is not None, key
+        scale = og.abs().max().item()
+        err = (g.cpu() - og).abs().max().item()
+        worst[key] = err / max(scale, 1e-12)
+        assert err <= 1e-3 * scale + 1e-7, (key, err, scale)
+    for pf, of in zip(pfeats, ofeats):                        # gradients w.r.t. the backbone features
+        scale = of.grad.abs().max().item()
+        err = (pf.grad.cpu() - of.grad).abs().max().item()
+        assert err <= 1e-3 * scale + 1e-7, (tuple(pf.shape), err, scale)
+    print('gradient parity, worst relative error: %.2e (%s)' % max((v, k) for k, v in worst.items()))
+    # cls_embed: loss_cls has weight 0.0 in the open-vocabulary configs -> exactly-zero gradient
+    assert float(named['cls_embed.weight'].grad.abs().max()) == 0.0 and float(ograds['cls_embed.weight'].abs().max()) == 0.0
     assert named['bert_embeddings.word_embeddings.weight'].grad is None        # frozen text encoder
 
 
