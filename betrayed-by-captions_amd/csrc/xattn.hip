@@ -26,7 +26,7 @@ __device__ __forceinline__ int xa_kswz(int key, int slot) { return slot ^ ((key 
 __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
     const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
     float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S, int words, int KC,
-    int nchunks, float scale, float* __restrict__ out_direct) {
+    int nchunks, float scale, float* __restrict__ out_direct, float* __restrict__ lse) {
   constexpr int D = 32;
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
       f32x4 v = {o[4 * g] / l_run, o[4 * g + 1] / l_run, o[4 * g + 2] / l_run, o[4 * g + 3] / l_run};
       *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hi) = v;
     }
+    if (lse != nullptr && hi == 0) lse[((size_t)b * H + h) * Q + qi] = m_run + logf(l_run);
   } else if (wave_live && qi < Q) {
     const size_t base = (((size_t)b * H + h) * nchunks + chunk) * Q + qi;
     float* op = ws_o + base * D;
@@ -468,7 +469,7 @@ extern "C" int cgg_self_attn_rows_bf16(const float* q, int ldq, const float* kv,
 __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict__ ws_o,
                                                          const float* __restrict__ ws_ml,
                                                          float* __restrict__ out, int B, int Q, int H,
-                                                         int D, int nchunks) {
+                                                         int D, int nchunks, float* __restrict__ lse) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)B * Q * H * D;
   if (gid >= total) return;
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict
     den += f * ws_ml[r * 2 + 1];
   }
   out[((size_t)b * Q + qq) * (H * D) + h * D + d] = num / den;  // den == 0 -> NaN, as the reference
+  if (lse != nullptr && d == 0) lse[((size_t)b * H + h) * Q + qq] = M + logf(den);
 }
 
 // Same result, one wavefront per (b, h, q) row, for nchunks <= 64: lane c first owns chunk c's (max, sum) -- the
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine(const float* __restrict
 __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __restrict__ ws_o,
                                                               const float* __restrict__ ws_ml,
                                                               float* __restrict__ out, int B, int Q, int H,
-                                                              int nchunks, int log2_domain) {
+                                                              int nchunks, int log2_domain, float* __restrict__ lse) {
   constexpr int D = 32;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, h, q) flattened as ((b*H + h)*Q + q)
   const int lane = threadIdx.x & 63;
@@ -537,21 +539,22 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __res
   if (half == 0) {
     const int b = bh / H, h = bh - b * H;
     out[((size_t)b * Q + qq) * (H * D) + h * D + d] = num / den;   // den == 0 -> NaN, as the reference
+    if (lse != nullptr && d == 0) lse[(size_t)bh * Q + qq] = M + logf(den);   // natural-log domain callers only
   }
 }
 
 static int xattn_combine_launch(const float* ws_o, const float* ws_ml, float* out, int B, int Q, int H, int D, int nch,
-                                hipStream_t s, int log2_domain) {
+                                hipStream_t s, int log2_domain, float* lse = nullptr) {
   if (nch <= 64 && D == 32) {
     const int rows = B * H * Q;
     hipLaunchKernelGGL(cgg_xattn_combine_wave, dim3((rows + 3) / 4), dim3(256), 0, s, ws_o, ws_ml, out, B, Q, H, nch,
-                       log2_domain);
+                       log2_domain, lse);
   } else if (log2_domain) {
     return -1;                           // callers keep nch <= 64 for the log2-domain kernel
   } else {
     const long long total = (long long)B * Q * H * D;
     hipLaunchKernelGGL(cgg_xattn_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws_o, ws_ml, out, B,
-                       Q, H, D, nch);
+                       Q, H, D, nch, lse);
   }
   return 0;
 }
@@ -577,9 +580,8 @@ extern "C" int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, 
   return (int64_t)B * H * nch * Q * (D + 2) * (int64_t)sizeof(float);
 }
 
-extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bits,
-                                        float* out, void* ws, int B, int Q, int H, int D, int S,
-                                        float scale, int kv_dtype, cgg_stream_t stream) {
+static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse, void* ws, int B,
+                             int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream) {
   CGG_REQUIRE(q && kv && out && ws, CGG_EINVAL, "cgg_masked_xattn_forward: null pointer");
   CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_forward: bad sizes");
   CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward: head dim %d (only 32 is built)", D);
@@ -598,11 +600,24 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
   const size_t lds = (size_t)2 * XA_TK * D * sizeof(float) + (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
-                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr);
+                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
-  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 0);
+  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 0, lse);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
   return CGG_OK;
+}
+
+extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bits,
+                                        float* out, void* ws, int B, int Q, int H, int D, int S,
+                                        float scale, int kv_dtype, cgg_stream_t stream) {
+  return xattn_forward_f32(q, kv, bits, out, nullptr, ws, B, Q, H, D, S, scale, kv_dtype, stream);
+}
+
+extern "C" int cgg_masked_xattn_forward_lse(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse,
+                                            void* ws, int B, int Q, int H, int D, int S, float scale, int kv_dtype,
+                                            cgg_stream_t stream) {
+  CGG_REQUIRE(lse, CGG_EINVAL, "cgg_masked_xattn_forward_lse: null lse");
+  return xattn_forward_f32(q, kv, bits, out, lse, ws, B, Q, H, D, S, scale, kv_dtype, stream);
 }
 
 extern "C" int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt, const uint32_t* bits,

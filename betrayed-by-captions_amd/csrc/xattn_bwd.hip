@@ -1,0 +1,253 @@
+// K6 backward: gradients of the masked multi-head cross-attention core (cgg_masked_xattn_forward_lse) with respect to
+// the projected queries and the projected [K | V] rows. This is the backward of the `baddbmm + masked softmax + bmm` inside
+// nn.MultiheadAttention on the training path open_set/models/mask2former_head.py:829-840 (called from forward_train,
+// :851-921). The reference materialises (B*8, Q, S) scores / probabilities / their gradients (26 MB x 3 per layer and
+// image at S = 16 384); here nothing of size Q x S ever leaves the registers:
+//
+//   P  = exp(scale q k^T + mask - LSE)            (LSE saved by the forward: one float per (b, h, query))
+//   dV = P^T dO        dP = dO V^T        dS = P o (dP - delta),   delta = rowsum(dO o O)
+//   dQ = scale dS K    dK = scale dS^T Q
+//
+// Work split: one workgroup = (key chunk, head, image); its 4 wavefronts each own 32 KEYS of every 128-key tile and loop
+// over the <= 4 query tiles. Keys never leave their wavefront, so dK / dV accumulate in registers and are stored once
+// per key (no atomics, deterministic); dQ is accumulated per wavefront over its keys and written as one partial plane
+// per (chunk, wave) that a small second kernel sums in a fixed order.
+//
+// MFMA orientation: S[query][key] with QUERIES on the MFMA rows and KEYS on the lanes (the transpose of the forward
+// kernel): P and dS are then directly the B operands of dV^T = dO^T P and dK^T = Q^T dS (contraction over queries), K / V
+// rows are loaded straight from global memory into B-operand registers (64 contiguous bytes per lane), and only dQ
+// (contraction over keys) needs dS transposed -- through a per-wave 32 x 32 LDS tile. v_mfma_f32_32x32x2_f32 throughout:
+// exact f32 products, f32 accumulation (training / parity precision).
+#include "cgg_common.h"
+
+#define XB_LD 36   // LDS row stride in floats: 16-byte aligned rows, rows skewed by 4 banks
+
+__device__ __forceinline__ int xb_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
+    const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ gout,
+    float* __restrict__ gkv, float* __restrict__ ws_dq, int Q, int H, int S, int words, int KC, int nchunks,
+    float scale) {
+  constexpr int D = 32;
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int HD = H * D;
+  const int nmt = (Q + 31) / 32;
+  const int s_begin = chunk * KC, s_end = min(S, s_begin + KC);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Qs = reinterpret_cast<float*>(smem_raw);      // [128][XB_LD]  scale * q
+  float* Gs = Qs + 128 * XB_LD;                        // [128][XB_LD]  dO
+  float* Ls = Gs + 128 * XB_LD;                        // [128] LSE
+  float* Ds = Ls + 128;                                // [128] delta
+  float* Kt = Ds + 128 + wave * (32 * XB_LD);          // per wave [32 keys][XB_LD]
+  float* Tt = Ds + 128 + 4 * (32 * XB_LD) + wave * (32 * XB_LD);   // per wave dS tile [32 queries][XB_LD]
+
+  // ---- queries, output gradients, LSE and delta of this (image, head) ----
+  for (int i = tid; i < 128 * 8; i += 256) {
+    const int qq = i >> 3, c4 = (i & 7) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    if (qq < Q) {
+      const size_t off = ((size_t)b * Q + qq) * HD + h * D + c4;
+      a = *reinterpret_cast<const f32x4*>(q + off);
+      g = *reinterpret_cast<const f32x4*>(gout + off);
+      a = a * scale;
+    }
+    *reinterpret_cast<f32x4*>(Qs + qq * XB_LD + c4) = a;
+    *reinterpret_cast<f32x4*>(Gs + qq * XB_LD + c4) = g;
+  }
+  if (tid < 128) {
+    float l = 0.f, dl = 0.f;
+    if (tid < Q) {
+      l = lse[((size_t)b * H + h) * Q + tid];
+      const size_t off = ((size_t)b * Q + tid) * HD + h * D;
+#pragma unroll
+      for (int c = 0; c < D; c += 4) {
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(out + off + c);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gout + off + c);
+        dl += o4[0] * g4[0] + o4[1] * g4[1] + o4[2] * g4[2] + o4[3] * g4[3];
+      }
+    }
+    Ls[tid] = l;
+    Ds[tid] = dl;
+  }
+  __syncthreads();
+
+  f32x16 dq[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+
+  const float* kvb = kv + (size_t)b * S * (2 * HD) + h * D;
+  for (int s0 = s_begin; s0 < s_end; s0 += 128) {
+    const int key = s0 + 32 * wave + j;
+    if (s0 + 32 * wave >= s_end) break;                          // wave-uniform: this wave's 32 keys are past the chunk
+    const bool kvalid = key < s_end;
+    // ---- this lane's key: K / V [16 hi .. 16 hi + 15] as B operands of S = Q K^T and dP = dO V^T ----
+    float kf[16], vf[16];
+    {
+      const float* row = kvb + (size_t)(kvalid ? key : s_begin) * (2 * HD) + 16 * hi;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 kx = *reinterpret_cast<const f32x4*>(row + 4 * t);
+        const f32x4 vx = *reinterpret_cast<const f32x4*>(row + HD + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kf[4 * t + e] = kvalid ? kx[e] : 0.f;
+          vf[4 * t + e] = kvalid ? vx[e] : 0.f;
+        }
+        f32x4 kz = {kf[4 * t], kf[4 * t + 1], kf[4 * t + 2], kf[4 * t + 3]};
+        *reinterpret_cast<f32x4*>(Kt + j * XB_LD + 16 * hi + 4 * t) = kz;     // K tile for the dQ contraction
+      }
+    }
+    const int wq = key >> 5, bq = key & 31;                      // mask word / bit of this lane's key
+    f32x16 dkt, dvt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
+
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      if (qt >= nmt) break;                                       // wave-uniform
+      const float* qrow = Qs + (qt * 32 + j) * XB_LD + 16 * hi;   // A operand rows: lane i = query
+      const float* grow = Gs + (qt * 32 + j) * XB_LD + 16 * hi;
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(qrow + 4 * t);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(grow + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[4 * t + e], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[4 * t + e], dp, 0, 0, 0);
+        }
+      }
+      // ---- P and dS for (query xb_row(r, hi), this lane's key) ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = qt * 32 + xb_row(r, hi);
+        bool blocked = !kvalid || qq >= Q;
+        if (bits != nullptr && !blocked) blocked = (bits[((size_t)b * Q + qq) * words + wq] >> bq) & 1u;
+        const float p = blocked ? 0.f : __expf(sc[r] - Ls[qq]);
+        sc[r] = p;                                   // P
+        dp[r] = p * (dp[r] - Ds[qq]);                // dS
+      }
+      // ---- dV^T[d][key] += dO^T[d][query] P[query][key],  dK^T[d][key] += (scale Q)^T[d][query] dS[query][key] ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = qt * 32 + xb_row(r, hi);
+        dvt = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[qq * XB_LD + j], sc[r], dvt, 0, 0, 0);
+        dkt = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qq * XB_LD + j], dp[r], dkt, 0, 0, 0);
+      }
+      // ---- dQ[query][d] += dS[query][key] K[key][d]: dS through the per-wave LDS tile as A operand ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Tt[xb_row(r, hi) * XB_LD + j] = dp[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x16 acc = dq[qt];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(Tt + j * XB_LD + 16 * hi + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], Kt[(16 * hi + 4 * t + e) * XB_LD + j], acc, 0, 0, 0);
+      }
+      dq[qt] = acc;
+      __builtin_amdgcn_wave_barrier();               // Tt is rewritten by the next query tile
+    }
+    // ---- dK / dV of this lane's key: regs r <-> d = xb_row(r, hi) (4 consecutive d per group) ----
+    if (kvalid) {
+      float* gk = gkv + ((size_t)b * S + key) * (2 * HD) + h * D + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a = {dkt[4 * g], dkt[4 * g + 1], dkt[4 * g + 2], dkt[4 * g + 3]};
+        const f32x4 c = {dvt[4 * g], dvt[4 * g + 1], dvt[4 * g + 2], dvt[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(gk + 8 * g) = a;
+        *reinterpret_cast<f32x4*>(gk + HD + 8 * g) = c;
+      }
+    }
+  }
+  // ---- dQ partial plane of this (chunk, wave): ws_dq[b][h][chunk * 4 + wave][q][d], lane j = d ----
+  float* wp = ws_dq + ((((size_t)b * H + h) * nchunks + chunk) * 4 + wave) * (size_t)Q * D;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nmt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = t * 32 + xb_row(r, hi);
+        if (qq < Q) wp[(size_t)qq * D + j] = dq[t][r];
+      }
+    }
+  }
+}
+
+// grad_q[b][q][h*D + d] = scale * sum over the (chunk, wave) planes, fixed order
+__global__ __launch_bounds__(256) void cgg_xattn_bwd_reduce_dq(const float* __restrict__ ws_dq, float* __restrict__ gq,
+                                                               int B, int Q, int H, int planes, float scale) {
+  constexpr int D = 32;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)B * Q * H * D) return;
+  const int d = (int)(gid % D), h = (int)((gid / D) % H);
+  const int qq = (int)((gid / ((long long)D * H)) % Q), b = (int)(gid / ((long long)D * H * Q));
+  const float* p = ws_dq + ((size_t)b * H + h) * planes * (size_t)Q * D + (size_t)qq * D + d;
+  float s = 0.f;
+  for (int c = 0; c < planes; ++c) s += p[(size_t)c * Q * D];
+  gq[((size_t)b * Q + qq) * (H * D) + h * D + d] = s * scale;
+}
+
+static void xattn_bwd_plan(int B, int H, int S, int* KC, int* nchunks) {
+  // ~2 workgroups per CU; a chunk is a multiple of 128 keys (4 wavefronts x 32 keys)
+  int want = (512 + B * H - 1) / (B * H);
+  const int tiles = (S + 127) / 128;
+  if (want > tiles) want = tiles;
+  if (want < 1) want = 1;
+  const int tpc = (tiles + want - 1) / want;
+  *KC = tpc * 128;
+  *nchunks = (S + *KC - 1) / *KC;
+}
+
+extern "C" int64_t cgg_masked_xattn_backward_workspace_bytes(int B, int Q, int H, int D, int S) {
+  if (B <= 0 || Q <= 0 || H <= 0 || D <= 0 || S <= 0) return 0;
+  int KC, nch;
+  xattn_bwd_plan(B, H, S, &KC, &nch);
+  return (int64_t)B * H * nch * 4 * Q * D * (int64_t)sizeof(float);
+}
+
+extern "C" int cgg_masked_xattn_backward(const float* q, const void* kv, const uint32_t* bits, const float* out,
+                                         const float* lse, const float* grad_out, float* grad_q, void* grad_kv, void* ws,
+                                         int B, int Q, int H, int D, int S, float scale, int kv_dtype,
+                                         cgg_stream_t stream) {
+  CGG_REQUIRE(q && kv && out && lse && grad_out && grad_q && grad_kv && ws, CGG_EINVAL,
+              "cgg_masked_xattn_backward: null pointer");
+  CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_backward: bad sizes");
+  CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: head dim %d (only 32 is built)", D);
+  CGG_REQUIRE(Q <= 128, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: Q=%d > 128", Q);
+  CGG_REQUIRE(kv_dtype == CGG_F32, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: kv dtype %d (f32 only)", kv_dtype);
+  CGG_REQUIRE(cgg_aligned16(q) && cgg_aligned16(kv) && cgg_aligned16(out) && cgg_aligned16(grad_out) &&
+                  cgg_aligned16(grad_q) && cgg_aligned16(grad_kv) && cgg_aligned16(ws),
+              CGG_EALIGN, "cgg_masked_xattn_backward: all tensors must be 16-B aligned");
+  int KC, nch;
+  xattn_bwd_plan(B, H, S, &KC, &nch);
+  const int words = (S + 31) / 32;
+  const size_t lds = (size_t)(2 * 128 * XB_LD + 256 + 8 * 32 * XB_LD) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(cgg_xattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cgg_xattn_bwd_kernel, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv, bits, out, lse,
+                     grad_out, (float*)grad_kv, (float*)ws, Q, H, S, words, KC, nch, scale);
+  CGG_CHECK_LAUNCH("cgg_masked_xattn_backward(main)");
+  const long long total = (long long)B * Q * H * D;
+  hipLaunchKernelGGL(cgg_xattn_bwd_reduce_dq, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ws,
+                     grad_q, B, Q, H, nch * 4, scale);
+  CGG_CHECK_LAUNCH("cgg_masked_xattn_backward(reduce)");
+  return CGG_OK;
+}

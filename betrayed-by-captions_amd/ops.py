@@ -228,14 +228,27 @@ def unpack_bits(bits, npix):
 # ------------------------------------------------------------------------------------------------
 # K6  masked cross attention core
 # ------------------------------------------------------------------------------------------------
-def masked_xattn(q, kv, bits, num_heads, scale=None):
+def _xattn_ws(lib_fn, q, B, Q, H, D, S):
+    nbytes = lib_fn(B, Q, H, D, S)
+    key = (q.device.index, stream_ptr(q.device).value)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
     """q (B,Q,E) f32 projected queries; kv (B,S,2E) f32 [K|V] projected; bits (B,Q,ceil(S/32)) int32
-    (bit set = blocked) or None -> (B,Q,E) f32 = softmax(q k^T * scale + mask) v, per head."""
+    (bit set = blocked) or None -> (B,Q,E) f32 = softmax(q k^T * scale + mask) v, per head.
+    return_lse: also the (B,H,Q) log-sum-exp rows that `masked_xattn_backward` consumes."""
     B, Q, E = q.shape
     if Q > 128:     # the kernels hold <= 4 query tiles per workgroup: split the (independent) queries
-        return torch.cat([masked_xattn(q[:, s:s + 128].contiguous(), kv,
-                                       None if bits is None else bits[:, s:s + 128].contiguous(), num_heads, scale)
-                          for s in range(0, Q, 128)], 1)
+        parts = [masked_xattn(q[:, s:s + 128].contiguous(), kv, None if bits is None else bits[:, s:s + 128].contiguous(),
+                              num_heads, scale, return_lse) for s in range(0, Q, 128)]
+        if return_lse:
+            return torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 2)
+        return torch.cat(parts, 1)
     S = kv.shape[1]
     H = int(num_heads)
     D = E // H
@@ -246,18 +259,53 @@ def masked_xattn(q, kv, bits, num_heads, scale=None):
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _lib_()
-    nbytes = lib.cgg_masked_xattn_workspace_bytes(B, Q, H, D, S)
-    key = (q.device.index, stream_ptr(q.device).value)
-    ws = _WS_CACHE.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
-        _WS_CACHE[key] = ws
+    ws = _xattn_ws(lib.cgg_masked_xattn_workspace_bytes, q, B, Q, H, D, S)
     out = torch.empty((B, Q, E), dtype=torch.float32, device=q.device)
+    if return_lse:
+        lse = torch.empty((B, H, Q), dtype=torch.float32, device=q.device)
+        rc = lib.cgg_masked_xattn_forward_lse(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
+                                              dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(lse), dev_ptr(ws),
+                                              B, Q, H, D, S, float(scale), CGG_F32, stream_ptr(q.device))
+        check(rc, 'cgg_masked_xattn_forward_lse')
+        return out, lse
     rc = lib.cgg_masked_xattn_forward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
                                       dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(ws), B,
                                       Q, H, D, S, float(scale), CGG_F32, stream_ptr(q.device))
     check(rc, 'cgg_masked_xattn_forward')
     return out
+
+
+def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None):
+    """Gradients of `masked_xattn` w.r.t. q (B,Q,E) and kv (B,S,2E) from the saved output / log-sum-exp rows: recomputes
+    the probabilities tile by tile from the bit mask, nothing of size Q x S is stored (cgg_masked_xattn_backward)."""
+    B, Q, E = q.shape
+    S = kv.shape[1]
+    H = int(num_heads)
+    D = E // H
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    grad_out = grad_out.contiguous()
+    if Q > 128:     # independent query groups: grad_q per group, grad_kv summed over the groups
+        gq, gkv = [], None
+        for s in range(0, Q, 128):
+            a, b = masked_xattn_backward(q[:, s:s + 128].contiguous(), kv,
+                                         None if bits is None else bits[:, s:s + 128].contiguous(),
+                                         out[:, s:s + 128].contiguous(), lse[:, :, s:s + 128].contiguous(),
+                                         grad_out[:, s:s + 128].contiguous(), num_heads, scale)
+            gq.append(a)
+            gkv = b if gkv is None else gkv.add_(b)
+        return torch.cat(gq, 1), gkv
+    lib = _lib_()
+    ws = _xattn_ws(lib.cgg_masked_xattn_backward_workspace_bytes, q, B, Q, H, D, S)
+    gq = torch.empty_like(q)
+    gkv = torch.empty_like(kv)
+    rc = lib.cgg_masked_xattn_backward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
+                                       dev_ptr(bits, 'bits', torch.int32), dev_ptr(out, 'out', torch.float32),
+                                       dev_ptr(lse, 'lse', torch.float32), dev_ptr(grad_out, 'grad_out', torch.float32),
+                                       dev_ptr(gq), dev_ptr(gkv), dev_ptr(ws), B, Q, H, D, S, float(scale), CGG_F32,
+                                       stream_ptr(q.device))
+    check(rc, 'cgg_masked_xattn_backward')
+    return gq, gkv
 
 
 # ------------------------------------------------------------------------------------------------

@@ -182,35 +182,42 @@ class MultiheadAttention(nn.Module):
 
 
 class _XAttnFn(torch.autograd.Function):
-    """HIP forward; backward re-derived with torch ops on the device (round-1: the attention backward
-    kernel is not written yet -- forward is the judged inference path)."""
+    """HIP forward (saves the log-sum-exp rows) and HIP backward (`cgg_masked_xattn_backward`: probabilities recomputed
+    tile by tile from the bit mask; the reference's (B*8, Q, S) score / probability / gradient tensors never exist)."""
 
     @staticmethod
     def forward(ctx, q, kv, bits, num_heads):
-        ctx.save_for_backward(q, kv, bits if bits is not None else torch.empty(0, device=q.device))
+        out, lse = ops.masked_xattn(q, kv, bits, num_heads, return_lse=True)
+        ctx.save_for_backward(q, kv, bits if bits is not None else torch.empty(0, device=q.device), out, lse)
         ctx.num_heads = num_heads
         ctx.has_bits = bits is not None
-        return ops.masked_xattn(q, kv, bits, num_heads)
+        return out
 
     @staticmethod
     def backward(ctx, go):
-        q, kv, bits = ctx.saved_tensors
-        H = ctx.num_heads
-        B, Q, E = q.shape
-        S = kv.shape[1]
-        D = E // H
-        with torch.enable_grad():
-            q_ = q.detach().requires_grad_(True)
-            kv_ = kv.detach().requires_grad_(True)
-            qh = (q_ * D**-0.5).view(B, Q, H, D).transpose(1, 2)
-            kh = kv_[..., :E].view(B, S, H, D).transpose(1, 2)
-            vh = kv_[..., E:].view(B, S, H, D).transpose(1, 2)
-            att = qh @ kh.transpose(-1, -2)
-            if ctx.has_bits:
-                att = att.masked_fill(ops.unpack_bits(bits, S)[:, None], float('-inf'))
-            out = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Q, E)
-            gq, gkv = torch.autograd.grad(out, (q_, kv_), go)
+        q, kv, bits, out, lse = ctx.saved_tensors
+        gq, gkv = ops.masked_xattn_backward(q, kv, bits if ctx.has_bits else None, out, lse, go, ctx.num_heads)
         return gq, gkv, None, None
+
+
+def xattn_backward_torch(q, kv, bits, go, num_heads):
+    """The same gradients with torch ops (materialises the (B, H, Q, S) scores): the formulation the HIP kernel is
+    tested against, not used by the product path."""
+    H = num_heads
+    B, Q, E = q.shape
+    S = kv.shape[1]
+    D = E // H
+    with torch.enable_grad():
+        q_ = q.detach().requires_grad_(True)
+        kv_ = kv.detach().requires_grad_(True)
+        qh = (q_ * D**-0.5).view(B, Q, H, D).transpose(1, 2)
+        kh = kv_[..., :E].view(B, S, H, D).transpose(1, 2)
+        vh = kv_[..., E:].view(B, S, H, D).transpose(1, 2)
+        att = qh @ kh.transpose(-1, -2)
+        if bits is not None:
+            att = att.masked_fill(ops.unpack_bits(bits, S)[:, None], float('-inf'))
+        out = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Q, E)
+        return torch.autograd.grad(out, (q_, kv_), go)
 
 
 def _xattn(q, kv, bits, num_heads):

@@ -173,6 +173,28 @@ int cgg_masked_xattn_forward_bf16(const float* q, const void* k, const void* vt,
                                   void* ws, int B, int Q, int H, int D, int S, float scale, int ldk, int64_t vt_bstride,
                                   int auto_unmask, cgg_stream_t stream);
 
+/* Training pair of K6 ("cgg_masked_xattn_forward ... + backward"): the forward that also saves the
+ * log-sum-exp of every (image, head, query) row, and the backward of the attention core -- what autograd derives for the
+ * `baddbmm + masked softmax + bmm` inside nn.MultiheadAttention on the training path
+ * open_set/models/mask2former_head.py:829-840 (reached from forward_train, :851-921).
+ *
+ *   lse       [B, H, Q] f32   max + log(sum exp) of the masked, scaled scores (natural log)
+ *   out       [B, Q, H*D] f32 the forward's output (delta = rowsum(grad_out o out) is recomputed from it)
+ *   grad_out  [B, Q, H*D] f32
+ *   grad_q    [B, Q, H*D] f32   d loss / d q      (written, not accumulated)
+ *   grad_kv   [B, S, 2*H*D] f32 d loss / d [K | V] (written, not accumulated; every key row is written exactly once)
+ *   ws        cgg_masked_xattn_backward_workspace_bytes(...) bytes (per-(chunk, wavefront) grad_q partial planes,
+ *             summed in a fixed order: no floating-point atomics, bit-reproducible)
+ * The bit mask is consumed as in the forward (bit set = blocked, shared by the heads); nothing of size Q x S is ever
+ * stored. f32 MFMA (exact products). Requires D == 32, Q <= 128, kv_dtype == CGG_F32.                              */
+int cgg_masked_xattn_forward_lse(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse,
+                                 void* ws, int B, int Q, int H, int D, int S, float scale, int kv_dtype,
+                                 cgg_stream_t stream);
+int64_t cgg_masked_xattn_backward_workspace_bytes(int B, int Q, int H, int D, int S);
+int cgg_masked_xattn_backward(const float* q, const void* kv, const uint32_t* bits, const float* out,
+                              const float* lse, const float* grad_out, float* grad_q, void* grad_kv, void* ws,
+                              int B, int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream);
+
 /* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
  * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =
  * softmax(scale q k^T) v per head. bf16 MFMA operands, f32 accumulation and softmax; D == 32.                       */

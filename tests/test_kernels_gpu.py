@@ -301,6 +301,67 @@ def test_masked_xattn_full_row_is_nan_like_reference(dev):
     assert torch.isnan(got[0, 1]).all() and not torch.isnan(got[0, 0]).any()
 
 
+@pytest.mark.parametrize('B,Q,S,H,masked', [(2, 100, 1050, 8, True), (1, 20, 77, 4, True), (2, 100, 100, 8, False),
+                                            (3, 128, 4096, 8, True), (1, 33, 16384, 8, True)])
+def test_masked_xattn_backward_vs_float64_autograd(dev, B, Q, S, H, masked):
+    """cgg_masked_xattn_forward_lse + cgg_masked_xattn_backward against float64 autograd of the reference formulation
+    (scores -> masked_fill(-inf) -> softmax -> @ v, the arithmetic of nn.MultiheadAttention at
+    mask2former_head.py:829-840): ragged key counts (1050 = the 25 x 42 level of configs[4], 77), fewer queries than one
+    tile, the unmasked self-attention case, several key chunks per head, rows with a single visible key."""
+    from cgg_amd.query_decoder import pack_bool_mask
+    g = torch.Generator().manual_seed(23 + S)
+    D = 32
+    E = H * D
+    q = torch.randn(B, Q, E, generator=g)
+    kv = torch.randn(B, S, 2 * E, generator=g)
+    go = torch.randn(B, Q, E, generator=g)
+    mask = None
+    if masked:
+        mask = torch.rand(B, Q, S, generator=g) < 0.6
+        mask[0, 1] = False                      # un-masked row
+        mask[0, 2] = True
+        mask[0, 2, S - 1] = False               # single visible key (the last one)
+    qd = q.double().requires_grad_(True)
+    kvd = kv.double().requires_grad_(True)
+    qh = (qd * D**-0.5).view(B, Q, H, D).transpose(1, 2)
+    kh = kvd[..., :E].view(B, S, H, D).transpose(1, 2)
+    vh = kvd[..., E:].view(B, S, H, D).transpose(1, 2)
+    att = qh @ kh.transpose(-1, -2)
+    if mask is not None:
+        att = att.masked_fill(mask[:, None], float('-inf'))
+    want_lse = torch.logsumexp(att, -1)
+    want = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Q, E)
+    wgq, wgkv = torch.autograd.grad(want, (qd, kvd), go.double())
+    bits = None if mask is None else pack_bool_mask(mask).contiguous().to(dev)
+    out, lse = ops.masked_xattn(q.to(dev), kv.to(dev), bits, H, return_lse=True)
+    assert (out.cpu() - want.detach().float()).abs().max().item() <= 1e-4
+    assert (lse.cpu() - want_lse.detach().float()).abs().max().item() <= 1e-4
+    gq, gkv = ops.masked_xattn_backward(q.to(dev), kv.to(dev), bits, out, lse, go.to(dev), H)
+    for got, ref_, name in ((gq, wgq, 'grad_q'), (gkv, wgkv, 'grad_kv')):
+        scale = ref_.abs().max().item()
+        err = (got.cpu().double() - ref_).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-6, (name, err, scale)
+    # run to run bit-identical (no floating-point atomics)
+    gq2, gkv2 = ops.masked_xattn_backward(q.to(dev), kv.to(dev), bits, out, lse, go.to(dev), H)
+    assert torch.equal(gq, gq2) and torch.equal(gkv, gkv2)
+
+
+def test_xattn_autograd_function_uses_hip_backward(dev):
+    """`_XAttnFn` (what the decoder layers call in training): gradients equal the torch formulation, incl. Q > 128."""
+    from cgg_amd.query_decoder import _XAttnFn, pack_bool_mask, xattn_backward_torch
+    g = torch.Generator().manual_seed(29)
+    B, Q, S, H, E = 2, 200, 333, 8, 256
+    q = torch.randn(B, Q, E, generator=g).to(dev).requires_grad_(True)
+    kv = torch.randn(B, S, 2 * E, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, Q, E, generator=g).to(dev)
+    bits = pack_bool_mask(torch.rand(B, Q, S, generator=g) < 0.5).contiguous().to(dev)
+    out = _XAttnFn.apply(q, kv, bits, H)
+    gq, gkv = torch.autograd.grad(out, (q, kv), go)
+    wq, wkv = xattn_backward_torch(q.detach(), kv.detach(), bits, go, H)
+    assert (gq - wq).abs().max().item() <= 1e-4 * wq.abs().max().item()
+    assert (gkv - wkv).abs().max().item() <= 1e-4 * wkv.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------
 def test_upsample_bilinear(dev):
     g = torch.Generator().manual_seed(30)
