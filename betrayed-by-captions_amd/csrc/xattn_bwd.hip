@@ -238,7 +238,7 @@ extern "C" int cgg_masked_xattn_backward(const float* q, const void* kv, const u
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(cgg_xattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cgg_xattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     attr_set = true;
   }

@@ -155,15 +155,62 @@ class DiceLoss(nn.Module):
         return self.loss_weight * weight_reduce_loss(loss, weight, reduction, avg_factor)
 
 
+class _GroundingPairCostsFn(torch.autograd.Function):
+    """(caption i, image j) pair costs of grounding_loss.py:32-58 on the HIP kernel (scores, both softmaxes and the
+    reductions in one launch; the (B*B, T, Q) tensors never exist). Backward: d cost / d score recomputed by the kernel,
+    then ONE batched GEMM against the (constant) caption embeddings."""
+
+    @staticmethod
+    def forward(ctx, pred, cap, cap_mask, inv_temperature):
+        from . import ops
+        pred_c, cap_c = pred.contiguous(), cap.contiguous()
+        mask_i = cap_mask.to(torch.int32).contiguous()
+        ctx.save_for_backward(pred_c, cap_c, mask_i)
+        ctx.inv_t = float(inv_temperature)
+        return ops.grounding_pair_costs(pred_c, cap_c, mask_i, ctx.inv_t)
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        from . import ops
+        pred, cap, mask_i = ctx.saved_tensors
+        dsim = ops.grounding_pair_costs_backward(pred, cap, mask_i, grad_cost, ctx.inv_t)     # (Bp, Bc*T, Q)
+        grad_pred = torch.matmul(dsim.transpose(1, 2), cap.reshape(-1, cap.shape[-1]))       # (Bp, Q, d)
+        grad_cap = None
+        if ctx.needs_input_grad[1]:      # not on the CGG path (frozen text encoder); kept for completeness
+            Bc, T, d = cap.shape
+            grad_cap = torch.einsum('jkq,jqd->kd', dsim, pred).view(Bc, T, d)
+        return grad_pred, grad_cap, None, None
+
+
+def _grounding_tail(d_l2v, d_v2l, num_tokens):
+    """grounding_loss.py:60-77: captions without nouns are pushed away (+100, detached), then the four
+    log-softmax diagonals over the (caption, image) cost matrices."""
+    B = d_l2v.shape[0]
+    valid = (num_tokens > 0)[:, None].expand(B, d_l2v.shape[1])
+    d_l2v = torch.where(valid, d_l2v, d_l2v.max().detach() + 100.0)
+    d_v2l = torch.where(valid, d_v2l, d_v2l.max().detach() + 100.0)
+    total = 0.
+    for cost in (d_l2v, d_v2l):
+        total = total + torch.diag(-torch.log_softmax(-cost, dim=0)).mean() \
+            + torch.diag(-torch.log_softmax(-cost, dim=1)).mean()
+    return total / 4
+
+
 def grounding_loss(cls_emb_pred, gt_caption_embs, gt_caption_mask, temperature):
     """Caption grounding loss of open_set/models/losses/grounding_loss.py:9-77, evaluated for all
     (caption i, image j) pairs from ONE (B*T, d) x (d, B*Q) contraction -- the reference's three
     B^2-fold `repeat`s (:23-30) are index arithmetic here, nothing is replicated.
 
-    cls_emb_pred (B,Q,d), gt_caption_embs (B,T,d), gt_caption_mask (B,T) 0/1."""
+    cls_emb_pred (B,Q,d), gt_caption_embs (B,T,d), gt_caption_mask (B,T) 0/1.
+    On a ROCm device (f32, Q <= 128, T <= 64) the pair costs come from `cgg_grounding_pair_costs`; other shapes
+    (e.g. 200 queries) and CPU tensors (host-side unit tests) take the torch formulation below."""
     B, Q, d = cls_emb_pred.shape
     T = gt_caption_mask.shape[1]
     num_tokens = gt_caption_mask.sum(dim=1)                                  # (B,)
+    from . import ops
+    if ops.grounding_supported(cls_emb_pred, gt_caption_embs) and cls_emb_pred.shape[0] == gt_caption_embs.shape[0]:
+        cost = _GroundingPairCostsFn.apply(cls_emb_pred, gt_caption_embs, gt_caption_mask, 1.0 / float(temperature))
+        return _grounding_tail(cost[0], cost[1], num_tokens)
     sim = torch.matmul(gt_caption_embs.reshape(B * T, d), cls_emb_pred.reshape(B * Q, d).t())
     sim = sim.view(B, T, B, Q).permute(0, 2, 1, 3)                           # [i, j, t, q]
     sim_t = sim / temperature
@@ -172,14 +219,7 @@ def grounding_loss(cls_emb_pred, gt_caption_embs, gt_caption_mask, temperature):
     d_l2v = (att_l2v * dist_t).sum(3).sum(2) / torch.max(num_tokens, torch.ones_like(num_tokens))[:, None]
     att_v2l = F.softmax(sim_t, dim=2)
     d_v2l = (att_v2l * dist_t).sum(3).sum(2) / Q
-    valid = (num_tokens > 0)[:, None].expand(B, B)
-    d_l2v = torch.where(valid, d_l2v, d_l2v.max().detach() + 100.0)
-    d_v2l = torch.where(valid, d_v2l, d_v2l.max().detach() + 100.0)
-    total = 0.
-    for cost in (d_l2v, d_v2l):
-        total = total + torch.diag(-torch.log_softmax(-cost, dim=0)).mean() \
-            + torch.diag(-torch.log_softmax(-cost, dim=1)).mean()
-    return total / 4
+    return _grounding_tail(d_l2v, d_v2l, num_tokens)
 
 
 @LOSSES.register_module()

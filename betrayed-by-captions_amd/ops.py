@@ -309,6 +309,40 @@ def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None
 
 
 # ------------------------------------------------------------------------------------------------
+# K16  caption grounding pair costs
+# ------------------------------------------------------------------------------------------------
+def grounding_supported(pred, cap):
+    return (pred.is_cuda and pred.dtype == torch.float32 and cap.dtype == torch.float32 and pred.shape[1] <= 128
+            and cap.shape[1] <= 64 and pred.shape[2] % 8 == 0)
+
+
+def grounding_pair_costs(pred, cap, cap_mask, inv_temperature):
+    """pred (Bp,Q,d) f32, cap (Bc,T,d) f32, cap_mask (Bc,T) int32 -> cost (2,Bc,Bp) f32 (l2v, v2l) of
+    grounding_loss.py:32-58 for every (caption, image) pair."""
+    Bp, Q, d = pred.shape
+    Bc, T, _ = cap.shape
+    cost = torch.empty((2, Bc, Bp), dtype=torch.float32, device=pred.device)
+    rc = _lib_().cgg_grounding_pair_costs(dev_ptr(pred, 'pred', torch.float32), dev_ptr(cap, 'cap', torch.float32),
+                                          dev_ptr(cap_mask, 'cap_mask', torch.int32), dev_ptr(cost), Bp, Bc, Q, T, d,
+                                          float(inv_temperature), stream_ptr(pred.device))
+    check(rc, 'cgg_grounding_pair_costs')
+    return cost
+
+
+def grounding_pair_costs_backward(pred, cap, cap_mask, grad_cost, inv_temperature):
+    """-> dsim (Bp, Bc*T, Q): d loss / d (cap[i,t] . pred[j,q]) from grad_cost (2,Bc,Bp)."""
+    Bp, Q, d = pred.shape
+    Bc, T, _ = cap.shape
+    dsim = torch.empty((Bp, Bc * T, Q), dtype=torch.float32, device=pred.device)
+    rc = _lib_().cgg_grounding_pair_costs_backward(
+        dev_ptr(pred, 'pred', torch.float32), dev_ptr(cap, 'cap', torch.float32),
+        dev_ptr(cap_mask, 'cap_mask', torch.int32), dev_ptr(grad_cost.contiguous(), 'grad_cost', torch.float32),
+        dev_ptr(dsim), Bp, Bc, Q, T, d, float(inv_temperature), stream_ptr(pred.device))
+    check(rc, 'cgg_grounding_pair_costs_backward')
+    return dsim
+
+
+# ------------------------------------------------------------------------------------------------
 # K19  inference tail
 # ------------------------------------------------------------------------------------------------
 def upsample_bilinear(x, size):

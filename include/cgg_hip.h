@@ -195,6 +195,32 @@ int cgg_masked_xattn_backward(const float* q, const void* kv, const uint32_t* bi
                               const float* lse, const float* grad_out, float* grad_q, void* grad_kv, void* ws,
                               int B, int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * K16  Caption-grounding pair costs and their backward.
+ *
+ * Replaces the body of open_set/models/losses/grounding_loss.py:32-58 (`grounding_loss`, evaluated for each of the 10
+ * decoder outputs at open_set/models/mask2former_head.py:542-548): for every (caption i, image j) pair
+ *     s = caption_i predictions_j^T * inv_temperature                                  (T x Q)
+ *     cost[0][i][j] = sum_t mask[i][t] sum_q softmax_q(s)[t][q] * (-s[t][q]) / max(sum_t mask[i][t], 1)
+ *     cost[1][i][j] = sum_q sum_t softmax_t(s)[t][q] * (-s[t][q]) / Q         (token softmax unmasked, as :44)
+ * The reference's B-fold `repeat`s and its (B*B, T, Q) score / attention tensors are never materialised; the remaining
+ * steps of the loss (the +100 fill of captions without nouns and the four log-softmax diagonals over the (Bc, Bp)
+ * matrices, :60-77) are a few elementwise ops on B x B values and stay with the caller.
+ *
+ *   pred      [Bp, Q, d] f32   caption embeddings predicted by the head (all gathered images)
+ *   cap       [Bc, T, d] f32   text embeddings of the caption nouns
+ *   cap_mask  [Bc, T]   i32    1 = token present
+ *   cost      [2, Bc, Bp] f32  (written)
+ * backward: grad_cost [2, Bc, Bp] -> dsim [Bp, Bc*T, Q] f32 = d loss / d (caption_i[t] . pred_j[q]); the caller finishes
+ * with ONE batched GEMM grad_pred[j] = dsim[j]^T x cap.reshape(Bc*T, d) (captions are constants: frozen text encoder).
+ * f32 MFMA (exact products). Requires Q <= 128, T <= 64, d % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_grounding_pair_costs(const float* pred, const float* cap, const int32_t* cap_mask, float* cost, int Bp, int Bc,
+                             int Q, int T, int d, float inv_temperature, cgg_stream_t stream);
+int cgg_grounding_pair_costs_backward(const float* pred, const float* cap, const int32_t* cap_mask,
+                                      const float* grad_cost, float* dsim, int Bp, int Bc, int Q, int T, int d,
+                                      float inv_temperature, cgg_stream_t stream);
+
 /* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
  * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =
  * softmax(scale q k^T) v per head. bf16 MFMA operands, f32 accumulation and softmax; D == 32.                       */

@@ -362,6 +362,39 @@ def test_xattn_autograd_function_uses_hip_backward(dev):
     assert (gkv - wkv).abs().max().item() <= 1e-4 * wkv.abs().max().item()
 
 
+@pytest.mark.parametrize('B,Q,T,d', [(16, 100, 35, 768), (4, 100, 35, 768), (2, 20, 35, 768), (3, 128, 64, 64), (1, 7, 5, 8)])
+def test_grounding_loss_kernel_vs_oracle(dev, B, Q, T, d):
+    """`losses.grounding_loss` on the HIP pair-cost kernel (cgg_grounding_pair_costs + backward) against the oracle's
+    literal restatement of grounding_loss.py:9-77 (with the B^2 repeat; pinned by golden G1) in float64: loss value and
+    the gradient w.r.t. the predicted embeddings. Includes a caption without nouns (the +100 branch), ragged token counts
+    and the global-batch size of configs[2] (B_g = 16)."""
+    from cgg_amd import losses
+    from oracle import head as OH
+    g = torch.Generator().manual_seed(60 + B)
+    pred = (torch.randn(B, Q, d, generator=g) * 0.5)
+    cap = torch.randn(B, T, d, generator=g)
+    ntok = torch.randint(1, min(T, 7) + 1, (B,), generator=g)
+    if B > 1:
+        ntok[1] = 0                                          # caption without nouns
+    mask = (torch.arange(T)[None] < ntok[:, None]).long()
+    pd = pred.double().requires_grad_(True)
+    want = OH.grounding_loss(pd, cap.double(), mask, 10.0)
+    wg, = torch.autograd.grad(want, pd)
+    pg = pred.to(dev).requires_grad_(True)
+    got = losses.grounding_loss(pg, cap.to(dev), mask.to(dev), 10.0)
+    gg, = torch.autograd.grad(got, pg)
+    assert abs(float(got) - float(want)) <= 1e-5 * (1 + abs(float(want))), (float(got), float(want))
+    scale = wg.abs().max().item()
+    assert (gg.cpu().double() - wg).abs().max().item() <= 1e-4 * scale + 1e-9, ((gg.cpu().double() - wg).abs().max().item(), scale)
+    # the pair costs themselves against the torch formulation (same arithmetic, (B, B, T, Q) tensors materialised)
+    cost = ops.grounding_pair_costs(pred.to(dev), cap.to(dev), mask.to(torch.int32).to(dev), 0.1).cpu()
+    sim = torch.einsum('itd,jqd->ijtq', cap.double(), pred.double()) / 10.0
+    l2v = ((sim.softmax(3) * mask[:, None, :, None]) * -sim).sum((2, 3)) / ntok.clamp(min=1)[:, None]
+    v2l = (sim.softmax(2) * -sim).sum((2, 3)) / Q
+    assert (cost[0].double() - l2v).abs().max().item() <= 1e-5 * (1 + l2v.abs().max().item())
+    assert (cost[1].double() - v2l).abs().max().item() <= 1e-5 * (1 + v2l.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------
 def test_upsample_bilinear(dev):
     g = torch.Generator().manual_seed(30)
