@@ -169,6 +169,72 @@ def build_key_padding_mask(seq, pad_idx):
     return seq == pad_idx
 
 
+class _GeneratorCEFn(torch.autograd.Function):
+    """Per-row cross-entropy of `generator(hidden)` without ever holding the (M, 30522) logits (mask2former_head.py:551-565):
+    row chunks of logits come from a library GEMM against the padded generator weight into ONE reused buffer and are
+    consumed by `cgg_ce_rows_forward` (log-sum-exp + row loss). Backward recomputes a chunk, `cgg_ce_rows_backward` turns
+    it in place into g_row (softmax - onehot), and the two gradient GEMMs read it. bf16 logits / f32 statistics in
+    throughput mode (what bf16 autocast of the reference formulation computes), f32 in parity mode."""
+
+    CHUNK = 2048
+
+    @staticmethod
+    def _operands(weight, bias, dt):
+        from . import ops
+        N, K = weight.shape
+        pad = (-N) % 8
+
+        def make():
+            w = torch.cat([weight.detach(), weight.new_zeros((pad, K))], 0) if pad else weight.detach()
+            b = torch.cat([bias.detach(), bias.new_full((pad,), -1e30)], 0) if pad else bias.detach()
+            return w.to(dt).contiguous(), b.to(dt).contiguous()
+        return runtime.derived_cached('generator_ce_%s' % dt, (weight, bias), make)
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, target, ignore_index):
+        from . import ops
+        dt = torch.bfloat16 if runtime.is_bf16() else torch.float32
+        w, b = _GeneratorCEFn._operands(weight, bias, dt)
+        x = hidden.detach().to(dt).contiguous()
+        M = x.shape[0]
+        C = min(_GeneratorCEFn.CHUNK, M)
+        buf = torch.empty((C, w.shape[0]), dtype=dt, device=x.device)
+        loss = torch.empty(M, dtype=torch.float32, device=x.device)
+        lse = torch.empty(M, dtype=torch.float32, device=x.device)
+        for r0 in range(0, M, C):
+            r1 = min(r0 + C, M)
+            lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
+            l, s = ops.ce_rows_forward(lg, target[r0:r1], ignore_index)
+            loss[r0:r1] = l
+            lse[r0:r1] = s
+        ctx.save_for_backward(x, w, b, target, lse)
+        ctx.ignore_index = ignore_index
+        ctx.n_out = weight.shape[0]
+        ctx.in_dtype = hidden.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        from . import ops
+        x, w, b, target, lse = ctx.saved_tensors
+        M = x.shape[0]
+        C = min(_GeneratorCEFn.CHUNK, M)
+        buf = torch.empty((C, w.shape[0]), dtype=x.dtype, device=x.device)
+        gx = torch.empty_like(x)
+        gw = torch.zeros(w.shape, dtype=torch.float32, device=x.device)
+        gb = torch.zeros(w.shape[0], dtype=torch.float32, device=x.device)
+        g = grad_rows.float().contiguous()
+        for r0 in range(0, M, C):
+            r1 = min(r0 + C, M)
+            lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
+            dl = ops.ce_rows_backward_(lg, target[r0:r1], lse[r0:r1], g[r0:r1], ctx.ignore_index)
+            torch.mm(dl, w, out=gx[r0:r1])
+            gw += torch.mm(dl.t(), x[r0:r1])
+            gb += dl.sum(0, dtype=torch.float32)
+        n = ctx.n_out
+        return gx.to(ctx.in_dtype), gw[:n], gb[:n], None, None
+
+
 @HEADS.register_module()
 class CaptionTransformer(nn.Module):
     """forward(tgt (B,L,in), memory (B,Q,in), ...) -> (list of per-layer outputs, last-layer logits (B,L,V))."""
@@ -193,3 +259,20 @@ class CaptionTransformer(nn.Module):
                                               memory_key_padding_mask)
             logits = self.generator(output[-1])
         return output, logits.float()
+
+    def forward_hidden(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                       memory_key_padding_mask=None):
+        """The decoder stack WITHOUT the generator: last layer's hidden states (B, L, hidden) f32."""
+        with runtime.autocast():
+            memory = self.adapter(memory)
+            tgt = self.position_encoder(tgt)
+            if tgt_mask is None:
+                tgt_mask = build_mask(tgt).to(tgt.device)
+            output = self.transformer_decoder(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
+                                              memory_key_padding_mask)
+        return output[-1].float()
+
+    def generator_ce_rows(self, hidden, target, ignore_index=None):
+        """`F.cross_entropy(generator(hidden), target, reduction='none', ignore_index=...)` for hidden (M, hidden) and
+        target (M,) without materialising the (M, nb_tokens) logits (HIP row kernels + chunked library GEMMs)."""
+        return _GeneratorCEFn.apply(hidden, self.generator.weight, self.generator.bias, target.contiguous(), ignore_index)

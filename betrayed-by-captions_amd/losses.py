@@ -110,6 +110,25 @@ class _CEBase(nn.Module):
         return self.loss_weight * loss
 
 
+    def rows_ok(self):
+        """True when the loss is the plain softmax cross-entropy that `forward_rows` can finish from per-row losses."""
+        return not (self.use_sigmoid or self.use_mask or self.use_logsoftmax) and self.class_weight is None
+
+    def forward_rows(self, loss_rows, label, weight=None, avg_factor=None, reduction_override=None, ignore_index=None):
+        """`forward` from ALREADY-COMPUTED per-row losses (`F.cross_entropy(..., reduction='none', ignore_index)`): the
+        weighting / averaging rules of the reference's CrossEntropyLoss (cross_entropy_loss.py:63-112) applied to them.
+        Used with `CaptionTransformer.generator_ce_rows`, which never materialises the logits."""
+        assert self.rows_ok()
+        reduction = reduction_override if reduction_override else self.reduction
+        if ignore_index is None:
+            ignore_index = self.ignore_index
+        ii = -100 if ignore_index is None else ignore_index
+        if avg_factor is None and self.avg_non_ignore and reduction == 'mean':
+            avg_factor = label.numel() - (label == ii).sum().item()
+        return self.loss_weight * weight_reduce_loss(loss_rows, None if weight is None else weight.float(), reduction,
+                                                     avg_factor)
+
+
 @LOSSES.register_module()
 class CrossEntropyLoss(_CEBase):
     """[3P] mmdet CrossEntropyLoss (`type='CrossEntropyLoss'` in every shipped config)."""

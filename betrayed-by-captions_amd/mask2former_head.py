@@ -1028,11 +1028,15 @@ class Mask2FormerHeadOpen(nn.Module):
         elif self.use_caption_generation:
             gt_caption_embs = torch.stack(gt_caption_embs_list, dim=0)
             gt_caption_masks = torch.stack(gt_caption_mask_list, dim=0).bool()
-            caption_logits = self.caption_generator(
-                tgt=gt_caption_embs[:, :-1, :], memory=cls_emb_preds,
-                tgt_key_padding_mask=torch.logical_not(gt_caption_masks[:, :-1]))[1].flatten(0, 1)
-            ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)
-            loss_caption_generation = self.loss_caption_generation(caption_logits, ids[:, 1:].flatten(0, 1))
+            ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)[:, 1:].flatten(0, 1)
+            cg, lcg = self.caption_generator, self.loss_caption_generation
+            kw = dict(tgt=gt_caption_embs[:, :-1, :], memory=cls_emb_preds,
+                      tgt_key_padding_mask=torch.logical_not(gt_caption_masks[:, :-1]))
+            if gt_caption_embs.is_cuda and hasattr(cg, 'generator_ce_rows') and getattr(lcg, 'rows_ok', lambda: False)():
+                rows = cg.generator_ce_rows(cg.forward_hidden(**kw).flatten(0, 1), ids, lcg.ignore_index)
+                loss_caption_generation = lcg.forward_rows(rows, ids)
+            else:
+                loss_caption_generation = lcg(cg(**kw)[1].flatten(0, 1), ids)
 
         loss_caption_align = zero
         if self.use_caption_align:
@@ -1182,12 +1186,18 @@ class Mask2FormerHeadOpen(nn.Module):
             emb = torch.stack(gt_caption_embs_list, dim=0)
             msk = torch.stack(gt_caption_mask_list, dim=0).bool()
             T1 = emb.shape[1] - 1
-            logits = self.caption_generator(
-                tgt=emb[:, :-1, :].repeat(n, 1, 1), memory=torch.cat(list(all_cls_emb_preds), 0),
-                tgt_key_padding_mask=torch.logical_not(msk[:, :-1]).repeat(n, 1))[1]         # (n*B, T-1, V)
             ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)[:, 1:].flatten(0, 1)
-            logits = logits.view(n, B * T1, -1)
-            cap_losses = [self.loss_caption_generation(logits[li], ids) for li in range(n)]
+            cg, lcg = self.caption_generator, self.loss_caption_generation
+            kw = dict(tgt=emb[:, :-1, :].repeat(n, 1, 1), memory=torch.cat(list(all_cls_emb_preds), 0),
+                      tgt_key_padding_mask=torch.logical_not(msk[:, :-1]).repeat(n, 1))
+            if emb.is_cuda and hasattr(cg, 'generator_ce_rows') and getattr(lcg, 'rows_ok', lambda: False)():
+                # generator + cross-entropy without the (n*B*34, 30522) logits: HIP row kernels over GEMM row chunks
+                hidden = cg.forward_hidden(**kw).flatten(0, 1)                                   # (n*B*(T-1), hidden)
+                rows = cg.generator_ce_rows(hidden, ids.repeat(n), lcg.ignore_index).view(n, B * T1)
+                cap_losses = [lcg.forward_rows(rows[li], ids) for li in range(n)]
+            else:
+                logits = cg(**kw)[1].view(n, B * T1, -1)                                         # (n, B*(T-1), V)
+                cap_losses = [lcg(logits[li], ids) for li in range(n)]
         if all(isinstance(m, LazyMasks) for m in all_mask_preds):
             LazyMasks.preselect(list(all_mask_preds), [t[5] for t in targets])
         results = []

@@ -343,6 +343,42 @@ def grounding_pair_costs_backward(pred, cap, cap_mask, grad_cost, inv_temperatur
 
 
 # ------------------------------------------------------------------------------------------------
+# K18  generator + cross-entropy row kernels
+# ------------------------------------------------------------------------------------------------
+def _ce_dtype(logits):
+    if logits.dtype == torch.float32:
+        return CGG_F32
+    if logits.dtype == torch.bfloat16:
+        return CGG_BF16
+    raise CggError(f'ce_rows: logits must be f32 or bf16 (got {logits.dtype})')
+
+
+def ce_rows_forward(logits, target, ignore_index):
+    """logits (M, N) f32 / bf16 (row stride >= N), target (M,) int64 -> (loss (M,), lse (M,)) f32."""
+    M, N = logits.shape
+    if logits.stride(1) != 1:
+        raise CggError('ce_rows_forward: rows must be contiguous')
+    loss = torch.empty(M, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(M, dtype=torch.float32, device=logits.device)
+    rc = _lib_().cgg_ce_rows_forward(ctypes.c_void_p(logits.data_ptr()), dev_ptr(target, 'target', torch.int64), dev_ptr(loss),
+                                     dev_ptr(lse), M, N, int(logits.stride(0)), int(-100 if ignore_index is None else ignore_index),
+                                     _ce_dtype(logits), stream_ptr(logits.device))
+    check(rc, 'cgg_ce_rows_forward')
+    return loss, lse
+
+
+def ce_rows_backward_(logits, target, lse, grad_rows, ignore_index):
+    """logits (M, N) -> d loss / d logits IN PLACE: grad_rows[row] * (softmax - onehot); returns `logits`."""
+    M, N = logits.shape
+    rc = _lib_().cgg_ce_rows_backward(ctypes.c_void_p(logits.data_ptr()), dev_ptr(target, 'target', torch.int64),
+                                      dev_ptr(lse, 'lse', torch.float32), dev_ptr(grad_rows.contiguous(), 'grad_rows', torch.float32),
+                                      M, N, int(logits.stride(0)), int(-100 if ignore_index is None else ignore_index),
+                                      _ce_dtype(logits), stream_ptr(logits.device))
+    check(rc, 'cgg_ce_rows_backward')
+    return logits
+
+
+# ------------------------------------------------------------------------------------------------
 # K19  inference tail
 # ------------------------------------------------------------------------------------------------
 def upsample_bilinear(x, size):

@@ -221,6 +221,22 @@ int cgg_grounding_pair_costs_backward(const float* pred, const float* cap, const
                                       const float* grad_cost, float* dsim, int Bp, int Bc, int Q, int T, int d,
                                       float inv_temperature, cgg_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * K18  Row kernels of the caption generator + cross-entropy, so that the (B*34, 30522) logits of
+ * open_set/models/mask2former_head.py:551-565 (`caption_generator(...)[1]` -> `loss_caption_generation`) are never
+ * stored beyond one row chunk: the caller's library GEMM writes a chunk of logits, these kernels consume it.
+ *
+ *   logits  [M, ld] f32 or bf16 (dtype), N valid columns per row (N and ld multiples of 4 (f32) / 8 (bf16) elements:
+ *           pad the vocabulary with -1e30 bias columns, which contribute exp(.) = 0)
+ *   target  [M] i64; rows with target == ignore_index (or outside [0, N)) get loss 0 / gradient 0
+ * forward : loss[row] = lse[row] - logits[row][target],  lse[row] = log sum_n exp(logits[row][n])  (both f32, written)
+ * backward: logits[row][n] <- grad_rows[row] * (exp(logits[row][n] - lse[row]) - [n == target])   IN PLACE (same dtype)
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_ce_rows_forward(const void* logits, const int64_t* target, float* loss, float* lse, int M, int N, int64_t ld,
+                        int64_t ignore_index, int dtype, cgg_stream_t stream);
+int cgg_ce_rows_backward(void* logits, const int64_t* target, const float* lse, const float* grad_rows, int M, int N,
+                         int64_t ld, int64_t ignore_index, int dtype, cgg_stream_t stream);
+
 /* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
  * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =
  * softmax(scale q k^T) v per head. bf16 MFMA operands, f32 accumulation and softmax; D == 32.                       */

@@ -999,3 +999,47 @@ def test_subsample_nhwc(dev):
     for (B, H, W, C, st) in [(2, 16, 20, 32, 2), (1, 7, 9, 8, 2), (1, 6, 6, 16, 3)]:
         x = torch.randn(B, H, W, C, generator=g).bfloat16().to(dev)
         assert torch.equal(ops.subsample_nhwc(x, st), x[:, ::st, ::st, :].contiguous())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_generator_ce_rows_vs_materialised_logits(dev, precision):
+    """`CaptionTransformer.generator_ce_rows` (cgg_ce_rows_forward / _backward over GEMM row chunks; the logits are never
+    stored) against `F.cross_entropy(generator(hidden), target, reduction='none', ignore_index=0)` on materialised logits:
+    row losses and the gradients w.r.t. hidden / generator weight / bias. Vocabulary 30522 (not a multiple of 8: padded
+    columns), several row chunks, ignored rows, a target in the last column."""
+    from cgg_amd import registry, runtime
+    from cgg_amd.caption_transformer import _GeneratorCEFn
+    torch.manual_seed(5)
+    V, K, M = 30522, 768, 600
+    cg = registry.build_head(dict(type='CaptionTransformer', nb_layers=1, input_dim=K, hidden_dim=K, ff_dim=64, nb_heads=8,
+                                  drop_val=0.0, pre_norm=False, seq_length=35, nb_tokens=V)).to(dev)
+    with torch.no_grad():
+        cg.generator.weight.normal_(0, 0.05)
+        cg.generator.bias.normal_(0, 0.5)
+    hidden = torch.randn(M, K, device=dev, requires_grad=True)
+    target = torch.randint(1, V, (M,), device=dev)
+    target[::5] = 0                      # ignored positions (caption padding)
+    target[1] = V - 1
+    grow = torch.rand(M, device=dev)
+    old = _GeneratorCEFn.CHUNK
+    _GeneratorCEFn.CHUNK = 256           # 3 chunks, the last one ragged
+    try:
+        with runtime.precision_scope(precision):
+            rows = cg.generator_ce_rows(hidden, target, 0)
+            g = torch.autograd.grad(rows, (hidden, cg.generator.weight, cg.generator.bias), grow)
+    finally:
+        _GeneratorCEFn.CHUNK = old
+    # reference: the formulation the reference runs (in bf16 mode: what bf16 autocast of it computes)
+    h2 = hidden.detach().clone().requires_grad_(True)
+    if precision == 'bf16':
+        logits = torch.nn.functional.linear(h2.bfloat16(), cg.generator.weight.bfloat16(), cg.generator.bias.bfloat16()).float()
+    else:
+        logits = torch.nn.functional.linear(h2.double(), cg.generator.weight.double(), cg.generator.bias.double())
+    want = torch.nn.functional.cross_entropy(logits, target, reduction='none', ignore_index=0)
+    wg = torch.autograd.grad(want, (h2, cg.generator.weight, cg.generator.bias), grow.to(want.dtype))
+    tol = 2e-5 if precision == 'fp32' else 2e-2
+    assert float(rows[::5].abs().max()) == 0.0
+    assert (rows.double() - want.double()).abs().max().item() <= tol * (1 + want.abs().max().item())
+    for a, b, name in zip(g, wg, ('hidden', 'weight', 'bias')):
+        scale = b.abs().max().item()
+        assert (a.double() - b.double()).abs().max().item() <= tol * scale + 1e-9, (name, (a.double() - b.double()).abs().max().item(), scale)
