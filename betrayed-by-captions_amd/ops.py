@@ -1108,3 +1108,34 @@ def subsample_nhwc(x, stride):
     y = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
     check(_lib_().cgg_subsample_nhwc(dev_ptr(x), dev_ptr(y), B, H, W, C, int(stride), stream_ptr(x.device)), 'cgg_subsample_nhwc')
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# host side of the inference tail: COCO RLE of bit-packed masks (host function of the library, no device work)
+# ------------------------------------------------------------------------------------------------
+def rle_encode_bitmasks(bits, width, threads=8):
+    """bits: HOST uint8 tensor / numpy array (n, H, row_bytes), pixel x in bit (x & 7) of byte (x >> 3) (what
+    `instance_masks_picks(bitpack=True)` writes) -> list of n COCO RLE dicts {'size': [H, W], 'counts': bytes}."""
+    import numpy as np
+    arr = bits.numpy() if torch.is_tensor(bits) else np.asarray(bits)
+    if arr.dtype != np.uint8 or arr.ndim != 3 or not arr.flags['C_CONTIGUOUS']:
+        raise CggError('rle_encode_bitmasks: (n, H, row_bytes) contiguous uint8 host array expected')
+    n, H, rb = arr.shape
+    W = int(width)
+    if n == 0:
+        return []
+    lib = _lib_()
+    offs = np.empty(n + 1, dtype=np.int64)
+    cap = max(1 << 16, n * 256)
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        total = lib.cgg_rle_encode_bitmasks(ctypes.c_void_p(arr.ctypes.data), n, H, W, H * rb, rb, int(threads),
+                                            ctypes.c_void_p(out.ctypes.data), cap, ctypes.c_void_p(offs.ctypes.data))
+        if total < 0:
+            check(int(-total), 'cgg_rle_encode_bitmasks')
+        if total <= cap:
+            break
+        cap = int(total)
+    raw = out[:total].tobytes()
+    o = offs.tolist()
+    return [dict(size=[H, W], counts=raw[o[i]:o[i + 1]]) for i in range(n)]

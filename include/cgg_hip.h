@@ -237,6 +237,24 @@ int cgg_ce_rows_forward(const void* logits, const int64_t* target, float* loss, 
 int cgg_ce_rows_backward(void* logits, const int64_t* target, const float* lse, const float* grad_rows, int M, int N,
                          int64_t ld, int64_t ignore_index, int dtype, cgg_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * HOST function (no device work, no stream): COCO run-length encoding of bit-packed instance masks.
+ *
+ * Replaces, for the serving / evaluation path, the per-mask `.cpu().numpy()` of open_set/models/maskformer.py:205-208
+ * followed by pycocotools `mask.encode` in the dataset's results2json: the (n, H, W/8) bit planes written by
+ * cgg_instance_masks_picks(bitpack = 1) are copied to the host ONCE per batch and encoded here on `threads` host threads.
+ *
+ *   bits    host pointer, n planes of H rows x row_bytes bytes; pixel x of a row = bit (x & 7) of byte (x >> 3);
+ *           plane i starts at bits + i * mask_stride_bytes
+ *   out     host buffer of out_cap bytes receiving the n COCO "counts" strings back to back (compressed form of
+ *           pycocotools' rleToString: column-major runs, first run = zeros); offsets[i] .. offsets[i+1] = string i
+ *   offsets host int64[n + 1] (always written)
+ * Returns the total number of bytes of all strings; if that exceeds out_cap nothing is copied (call again with a larger
+ * buffer); negative = -CGG_E*.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, int W, int64_t mask_stride_bytes, int row_bytes,
+                                int threads, uint8_t* out, int64_t out_cap, int64_t* offsets);
+
 /* Throughput-mode self-attention of the query decoder ([3P] DetrTransformerDecoderLayer self_attn, no mask; S = Q <= 128):
  * q [B*Q, ldq] and kv = [k | v] [B*Q, ldkv] f32 rows (as written by the fused q|k|v projection) -> out [B*Q, H*D] f32 =
  * softmax(scale q k^T) v per head. bf16 MFMA operands, f32 accumulation and softmax; D == 32.                       */

@@ -453,6 +453,51 @@ def test_test_driver_mixed_shapes_keep_order(dev, tmp_path):
             assert int(ra[k][2].sum()) == int(rb[k][2].sum()), (i, k)
 
 
+def test_test_driver_rle_results_equal_bool_masks(dev, tmp_path):
+    """tools/test.py --rle (pinned staging + asynchronous copies + C++ COCO-RLE encoder, overlapped with the pipeline):
+    every detection's decoded RLE equals the bool mask the plain driver returns, per class, in dataset order."""
+    import importlib.util
+    import sys
+    import numpy as np
+    from cgg_amd.checkpoint import save_checkpoint
+    from cgg_amd.host_results import rle_to_mask
+    from util import randomize
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+    randomize(model, seed=21)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.fill_(1.0)
+            m.running_mean.zero_()
+    ck = save_checkpoint(model, str(tmp_path / 'w.pth'))
+    cfg_file = tmp_path / 'tiny.py'
+    cfg_file.write_text('model = ' + repr(cfg) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    spec = importlib.util.spec_from_file_location('cgg_tools_test3', os.path.join(root, 'tools', 'test.py'))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    a = drv.main([str(cfg_file), ck, '--num-images', '7', '--synthetic', '128', '--rle'])
+    b = drv.main([str(cfg_file), ck, '--num-images', '7', '--synthetic', '128', '--no-pipeline'])
+    assert len(a) == 7 and len(b) == 7
+    n_det = 0
+    for ra, rb in zip(a, b):
+        assert set(ra) == set(rb)
+        for k in ra:
+            bbox_results, segm = ra[k]
+            labels, bboxes, masks = rb[k]                       # plain driver: device-layout numpy (labels, boxes, bool masks)
+            assert sum(len(c) for c in segm) == masks.shape[0] == sum(len(c) for c in bbox_results)
+            for c in range(len(segm)):
+                want = sorted((int(m.sum()), m.tobytes()) for m in masks[labels == c])
+                got = sorted((int(x.sum()), x.tobytes()) for x in (rle_to_mask(r) for r in segm[c]))
+                assert [w[0] for w in want] == [g[0] for g in got] and all(w[1] == g[1] for w, g in zip(want, got)), (k, c)
+                n_det += len(got)
+    assert n_det > 0
+
+
 def test_simple_test_bitpacked_masks_equal_bool_masks(dev):
     """`mask_bits=True` (opt-in: 8x fewer mask bytes for consumers that work on packed bits): the unpacked masks are the
     bool masks, and the reference-format host results (per-class mask lists) agree with the device results."""

@@ -49,6 +49,10 @@ def parse_args(argv=None):
     p.add_argument('--data', default=None, help='pkg.module:function -> iterable of (img (3,H,W) float tensor, img_meta)')
     p.add_argument('--precision', default='bf16', choices=['fp32', 'bf16'])
     p.add_argument('--no-pipeline', action='store_true', help='plain sequential simple_test (no graphs / overlap)')
+    p.add_argument('--rle', action='store_true',
+                   help='results in the evaluation format: masks as COCO RLE dicts (what results2json builds with pycocotools from '
+                        'the reference\'s arrays), from bit-packed device masks through pinned staging buffers, one asynchronous '
+                        'copy per tensor and the C++ host encoder of the extension, overlapped with the next batch')
     p.add_argument('--mask-bits', action='store_true',
                    help='keep the masks bit-packed ((n, H, W / 8) uint8, pixel x = bit x & 7 of byte x >> 3) in the results: '
                         '8x less PCIe traffic and 8x smaller result files; unpacking 315 MB of bool masks per 1024^2 image on '
@@ -122,6 +126,26 @@ def main(argv=None):
         stream = (s for i, s in enumerate(synthetic_images(args.num_images, args.synthetic, seed=11)) if i % world == rank)
 
     B = args.samples_per_gpu
+    collector, in_copy = None, []
+    if args.rle:
+        from cgg_amd.host_results import RleCollector, fusion_class_counts
+        args.mask_bits = True
+        collector = RleCollector(device, fusion_class_counts(model.panoptic_fusion_head))
+
+    def emit(device_results):
+        """device results of one batch -> `results` (numpy now, or a future of the RLE collector)"""
+        if collector is None:
+            results.extend(to_numpy(r) for r in device_results)
+        else:
+            fut = collector.submit(device_results)
+            results.append(fut)
+            in_copy.append(fut)
+
+    def copies_done(keep=0):
+        """the pipeline reuses a slot's device buffers two submits later: their copies must have left by then"""
+        while len(in_copy) > keep:
+            RleCollector.wait_copied(in_copy.pop(0))
+
     results, pending = [], []          # pending: (pipeline, slot) pairs -- a slot is only meaningful for ITS pipeline
     n_img, t0 = 0, None
     pipe = None
@@ -132,7 +156,7 @@ def main(argv=None):
             """copy out every batch still in flight, in submission order, from the pipeline that produced it"""
             while pending:
                 owner, slot = pending.pop(0)
-                results.extend(to_numpy(r) for r in owner.wait(slot))
+                emit(owner.wait(slot))
 
         def run(group):
             nonlocal pipe, t0, n_img
@@ -153,6 +177,8 @@ def main(argv=None):
                         torch.cuda.synchronize()
                     if t0 is None:
                         t0, n_img = time.perf_counter(), 0
+                if collector is not None:
+                    copies_done(keep=1)
                 slot = pipe.submit(imgs)
                 # results of the PREVIOUS batch are copied out while this one runs (slot buffers are reused 2 batches later)
                 drain()
@@ -161,7 +187,9 @@ def main(argv=None):
                 drain()                # keep dataset order: earlier batches first
                 if t0 is None:
                     t0 = time.perf_counter()
-                results.extend(to_numpy(r) for r in model.simple_test(imgs, metas, rescale=True, device_results=True, mask_bits=args.mask_bits))
+                emit(model.simple_test(imgs, metas, rescale=True, device_results=True, mask_bits=args.mask_bits))
+                if collector is not None:
+                    copies_done()
             n_img += len(group)
 
         pipes = {}                     # one captured pipeline per (batch shape, img_shape, ori_shape)
@@ -179,6 +207,12 @@ def main(argv=None):
             run(group)                 # trailing short batch: sequential path (len(group) != B)
         drain()
         torch.cuda.synchronize()
+        if collector is not None:          # futures -> host results, in submission (= dataset) order
+            flat = []
+            for r in results:
+                flat.extend(r.result())
+            results = flat
+            collector.close()
     dt = time.perf_counter() - (t0 or time.perf_counter())
     if distributed:
         import torch.distributed as dist
@@ -189,7 +223,8 @@ def main(argv=None):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(dict(images=len(results), images_per_sec_this_rank=round(n_img / max(dt, 1e-9), 1),
-                              precision=args.precision, pipeline=pipe is not None)), flush=True)
+                              precision=args.precision, pipeline=pipe is not None,
+                              results='coco-rle' if args.rle else ('bit-packed' if args.mask_bits else 'bool arrays'))), flush=True)
         if args.out:
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
             with open(args.out, 'wb') as f:
