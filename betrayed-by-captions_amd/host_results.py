@@ -61,15 +61,17 @@ class RleCollector:
                     if not (isinstance(val, (tuple, list)) and len(val) == 3 and torch.is_tensor(val[2])):
                         continue
                     labels, bboxes, masks = val
-                    if masks.dtype != torch.uint8:
-                        raise ops.CggError('RleCollector needs bit-packed masks: simple_test(..., mask_bits=True)')
+                    packed = masks.dtype != torch.bool
+                    if not packed:                      # shapes outside the bit-packing kernel: packed on the host below
+                        masks = masks.view(torch.uint8)
+                    w_px = int(width) if width is not None else masks.shape[-1] * (8 if packed else 1)
                     hl = self._pinned(slot, (i, key, 'l'), labels)
                     hb = self._pinned(slot, (i, key, 'b'), bboxes)
                     hm = self._pinned(slot, (i, key, 'm'), masks)
                     hl.copy_(labels, non_blocking=True)
                     hb.copy_(bboxes, non_blocking=True)
                     hm.copy_(masks, non_blocking=True)
-                    per[key] = (hl, hb, hm, int(width) if width is not None else masks.shape[-1] * 8)
+                    per[key] = (hl, hb, hm, w_px, packed)
                 staged.append(per)
             done = torch.cuda.Event()
             done.record(self.copy_stream)
@@ -89,10 +91,11 @@ class RleCollector:
         out = []
         for per in staged:
             res = {}
-            for key, (hl, hb, hm, W) in per.items():
+            for key, (hl, hb, hm, W, packed) in per.items():
                 labels = hl.numpy().astype(np.int64)
                 bboxes = hb.numpy().copy()
-                rles = ops.rle_encode_bitmasks(hm, W, threads=self.rle_threads)
+                bits = hm if packed else np.packbits(hm.numpy(), axis=-1, bitorder='little')
+                rles = ops.rle_encode_bitmasks(bits, W, threads=self.rle_threads)
                 ncls = int(self.num_classes[key])
                 bbox_results = [bboxes[labels == c, :] for c in range(ncls)]
                 segm = [[] for _ in range(ncls)]
