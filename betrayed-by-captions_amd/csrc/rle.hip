@@ -57,6 +57,7 @@ struct RunWriter {
 
 void encode_one(const uint8_t* bits, int H, int W, int row_bytes, std::string& out) {
   RunWriter rw;
+  rw.out.reserve(4096);
   const int HB = (H + 63) / 64;
   std::vector<uint64_t> col((size_t)64 * HB);       // col[c * HB + by]: rows by*64 .. of column (block column c)
   int p = 0;               // value of the current run

@@ -24,12 +24,14 @@ from . import ops
 
 class RleCollector:
 
-    def __init__(self, device, num_classes, depth=3, rle_threads=16):
+    def __init__(self, device, num_classes, depth=3, rle_threads=None):
         """num_classes: {eval_type: number of classes} (the fusion head's all / novel / base class counts)."""
         self.device = torch.device(device)
         self.num_classes = dict(num_classes)
         self.depth = depth
-        self.rle_threads = rle_threads
+        import os
+        # the encoder's cost is per RUN; depth batches are encoded concurrently, each on this many host threads
+        self.rle_threads = rle_threads or max(4, min(64, (os.cpu_count() or 8) // 4))
         self.copy_stream = torch.cuda.Stream(self.device)
         self.pool = cf.ThreadPoolExecutor(max_workers=depth)
         self._slots = [dict(buffers={}, event=None, future=None) for _ in range(depth)]

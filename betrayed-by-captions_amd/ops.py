@@ -1086,19 +1086,6 @@ def point_sample_nhwc(feat, points):
     return out
 
 
-def masked_stream(device, cu_mask_bits):
-    """torch stream on `device` restricted to the CUs i with cu_mask_bits[i] truthy (hipExtStreamCreateWithCUMask)."""
-    words = [0] * ((len(cu_mask_bits) + 31) // 32)
-    for i, b in enumerate(cu_mask_bits):
-        if b:
-            words[i // 32] |= 1 << (i % 32)
-    arr = (ctypes.c_uint32 * len(words))(*words)
-    out = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        check(_lib_().cgg_stream_create_cumask(arr, len(words), ctypes.byref(out)), 'cgg_stream_create_cumask')
-    return torch.cuda.ExternalStream(out.value, device=device)
-
-
 def subsample_nhwc(x, stride):
     """x (B, H, W, C) channel-last bf16 -> x[:, ::stride, ::stride, :] as a new contiguous tensor."""
     B, H, W, C = x.shape

@@ -410,11 +410,6 @@ int cgg_linear_sum_assignment_f32(const float* cost, int n_problems, const int* 
 int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
                           cgg_stream_t stream);
 
-/* A HIP stream restricted to the compute units whose bits are set in mask_host (n_words x 32 bits, bit i = CU i;
- * hipExtStreamCreateWithCUMask) -- used by the serving pipeline to give the latency-bound decode stage its own CUs.  */
-int cgg_stream_create_cumask(const uint32_t* mask_host, int n_words, void** stream_out);
-int cgg_stream_destroy(void* stream);
-
 /* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
  * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),
  * Ho = (H - 1) / 2 + 1. w_packed: cgg_stem_conv7x7_packed_bytes() bytes, bf16 MFMA A fragments

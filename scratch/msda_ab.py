@@ -1,26 +1,42 @@
-import sys, os, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from cgg_amd import ops
-dev = 'cuda'
-g = torch.Generator().manual_seed(0)
-B = 2
-shapes = [(32, 32), (64, 64), (128, 128)]; starts = [0, 1024, 5120]; N = 21504
-raw = torch.randn(B, N, 288, generator=g); raw[..., :192] *= 2.0
-ref = []
-for h, w in shapes:
-    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')
-    ref.append(torch.stack([(xs.flatten() + .5) / w, (ys.flatten() + .5) / h], -1))
-ref = torch.cat(ref).to(dev); raw16 = raw.to(dev).bfloat16()
-v = torch.randn(B, N, 8, 32, generator=g).to(dev).bfloat16()
-f = lambda: ops.msda_forward_fused_bf16(v, shapes, starts, raw16, ref, 4)
-for _ in range(3): out = f()
-torch.cuda.synchronize()
-gr = torch.cuda.CUDAGraph()
-with torch.cuda.graph(gr):
-    for _ in range(20): out = f()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): gr.replay()
-e1.record(); torch.cuda.synchronize()
-print('msda bf16 stream: %.2f us  checksum %.6f' % (e0.elapsed_time(e1) * 1e3 / 100, out.float().abs().mean().item()))
+"""A/B of the encoder-stream MSDeformAttn forward at configs[1] shapes: vector-row kernel (default) vs the generic kernel
+(CGG_MSDA_GENERIC=1), each in its own process; outputs must be bit-identical.  python scratch/msda_ab.py"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1:
+    import torch
+    sys.path.insert(0, ROOT)
+    import cgg_amd
+    from cgg_amd import ops
+    dev = 'cuda'
+    B = 2
+    g = torch.Generator().manual_seed(0)
+    shapes = [(32, 32), (64, 64), (128, 128)]; starts = [0, 1024, 5120]; N = 21504
+    raw = torch.randn(B, N, 288, generator=g); raw[..., :192] *= 2.0
+    ref = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')
+        ref.append(torch.stack([(xs.flatten() + .5) / w, (ys.flatten() + .5) / h], -1))
+    ref = torch.cat(ref).to(dev)
+    raw16 = raw.to(dev).to(torch.bfloat16)
+    v = torch.randn(B, N, 8, 32, generator=g).to(dev).to(torch.bfloat16)
+    for _ in range(10):
+        out = ops.msda_forward_fused_bf16(v, shapes, starts, raw16, ref, 4)
+    torch.cuda.synchronize()
+    flush = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+    for mode in ('warm', 'flushed'):
+        ts = []
+        for _ in range(50):
+            if mode == 'flushed':
+                flush.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = ops.msda_forward_fused_bf16(v, shapes, starts, raw16, ref, 4); e1.record()
+            torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort()
+        print('%s %s: median %.1f us, min %.1f us' % (sys.argv[1], mode, ts[len(ts) // 2], ts[0]), flush=True)
+    torch.save(out.cpu(), sys.argv[2])
+else:
+    import torch
+    for name, env in (('vector-row', {}), ('generic', {'CGG_MSDA_GENERIC': '1'})):
+        subprocess.run([sys.executable, os.path.abspath(__file__), name, f'/tmp/msda_{name}.pt'], env=dict(os.environ, **env), check=True)
+    a, b = torch.load('/tmp/msda_vector-row.pt'), torch.load('/tmp/msda_generic.pt')
+    print('bit-identical:', torch.equal(a, b), ' max |diff|:', float((a.float() - b.float()).abs().max()))
