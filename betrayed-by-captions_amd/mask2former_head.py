@@ -75,8 +75,16 @@ class LazyMasks:
     the mask feature + a (Q x C) x (C x P) product, (b) an einsum over the positives only. The forward / backward of
     the 10 full einsums (2 x 53.7 GFLOP f32 and 0.7 GB of gradient traffic per layer at configs[2]) disappears."""
 
-    def __init__(self, mask_embed, mask_feature):
+    def __init__(self, mask_embed, mask_feature, packed=None):
         self.mask_embed, self.mask_feature = mask_embed, mask_feature        # (B, Q, C), (B, C, h, w)
+        self.packed = packed          # PackedFeature of mask_feature: the positives' logits then run on the MFMA kernels
+
+    @staticmethod
+    def _contract(ep, mf, packed):
+        """(B, n, C) x (B, C, h, w) -> (B, n, h*w): the einsum of mask2former_head.py:748 restricted to the matched queries."""
+        if packed is not None and ep.is_cuda and ep.shape[-1] == 256 and ep.dtype == torch.float32:
+            return _MaskLogitsFn.apply(ep, mf, packed).flatten(2)
+        return torch.bmm(ep, mf.flatten(2).to(ep.dtype))
 
     @property
     def shape(self):
@@ -104,7 +112,7 @@ class LazyMasks:
             return self.mask_embed.new_zeros((0, h, w)) + 0 * self.mask_embed.sum() + 0 * self.mask_feature.sum()
         bi, qi, ri = pos['b'], pos['q'], pos['r']
         ep = self.mask_embed.new_zeros((B, pm, C)).index_put((bi, ri), self.mask_embed[bi, qi])
-        full = torch.bmm(ep, self.mask_feature.flatten(2).to(ep.dtype))         # (B, pm, h*w)
+        full = self._contract(ep, self.mask_feature, self.packed)              # (B, pm, h*w)
         return full[bi, ri].view(-1, h, w)
 
     @staticmethod
@@ -127,7 +135,7 @@ class LazyMasks:
                 off += pm
         if off == 0:
             return
-        full = torch.bmm(torch.cat(eps, 1), mf.flatten(2).to(eps[0].dtype))              # (B, sum pm, h*w)
+        full = LazyMasks._contract(torch.cat(eps, 1), mf, lazies[0].packed)              # (B, sum pm, h*w)
         for lz, pos, o in zip(lazies, pos_list, offs):
             if int(pos['pm']):
                 lz._pre = (pos, full[pos['b'], o + pos['r']].view(-1, h, w))
@@ -142,18 +150,25 @@ class LazyMasks:
 
 
 class _MaskLogitsFn(torch.autograd.Function):
-    """einsum('bqc,bchw->bqhw') with the HIP MFMA forward; backward = the two transposed contractions
-    (library GEMMs on the device; round 1)."""
+    """einsum('bqc,bchw->bqhw') on the HIP MFMA kernels, forward (`cgg_mask_logits` on the packed feature) and backward
+    (`cgg_mask_logits_backward`: the two transposed contractions; shapes outside the kernels' limits keep torch.einsum)."""
 
     @staticmethod
     def forward(ctx, embed, feat, packed):
+        embed = embed.contiguous()
         ctx.save_for_backward(embed, feat)
-        out, _ = ops.mask_logits(embed.contiguous(), packed, want_logits=True)
+        ctx.split = packed.lo is not None
+        out = torch.cat([ops.mask_logits(embed[:, s:s + 256].contiguous(), packed, want_logits=True)[0]
+                         for s in range(0, embed.shape[1], 256)], 1) if embed.shape[1] > 256 else \
+            ops.mask_logits(embed, packed, want_logits=True)[0]
         return out
 
     @staticmethod
     def backward(ctx, go):
         embed, feat = ctx.saved_tensors
+        if ops.mask_logits_backward_ok(embed, feat):
+            g_e, g_f = ops.mask_logits_backward(embed, feat, go, ctx.split, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            return g_e, g_f, None
         g_e = torch.einsum('bqhw,bchw->bqc', go, feat)
         g_f = torch.einsum('bqc,bqhw->bchw', embed, go)
         return g_e, g_f, None
@@ -348,7 +363,7 @@ class Mask2FormerHeadOpen(nn.Module):
             if mask_feature is not None and torch.is_grad_enabled() and (mask_embed.requires_grad or
                                                                          mask_feature.requires_grad):
                 if getattr(self, '_lazy_masks', False):
-                    mask_pred = LazyMasks(mask_embed, mask_feature)
+                    mask_pred = LazyMasks(mask_embed, mask_feature, packed)
                 else:
                     mask_pred = _MaskLogitsFn.apply(mask_embed, mask_feature, packed)
             else:

@@ -197,6 +197,44 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
     return out, bits
 
 
+def mask_logits_backward_ok(embed, feat):
+    """shapes the HIP backward kernels cover (otherwise the caller keeps the torch contractions)."""
+    return (embed.is_cuda and embed.dtype == torch.float32 and feat.dtype == torch.float32 and embed.shape[-1] == 256
+            and (feat.shape[-2] * feat.shape[-1]) % 8 == 0)
+
+
+def mask_logits_backward(embed, feat, grad_out, split, need_embed=True, need_feat=True):
+    """Gradients of einsum('bqc,bchw->bqhw', embed, feat): embed (B,Q,C) f32, feat (B,C,h,w) f32, grad_out (B,Q,h,w) f32
+    -> (grad_embed (B,Q,C) | None, grad_feat (B,C,h,w) | None) on cgg_mask_logits_backward. Row groups beyond the
+    kernel's limit (128 in split mode, 256 otherwise) are separate launches; their grad_feat parts are summed."""
+    B, Q, C = embed.shape
+    h, w = feat.shape[-2:]
+    npix = h * w
+    lim = 128 if split else 256
+    feat = feat.contiguous()
+    go = grad_out.contiguous()
+    lib = _lib_()
+    ge = torch.empty((B, Q, C), dtype=torch.float32, device=embed.device) if need_embed else None
+    gf = None
+    for s0 in range(0, Q, lim):
+        s1 = min(Q, s0 + lim)
+        e_part = embed[:, s0:s1].contiguous()
+        g_part = go[:, s0:s1].contiguous() if (s0 > 0 or s1 < Q) else go
+        n = s1 - s0
+        ws = _xattn_ws(lambda *a: lib.cgg_mask_logits_backward_workspace_bytes(B, n, C, npix), embed, 0, 0, 0, 0, 0)
+        ge_part = torch.empty((B, n, C), dtype=torch.float32, device=embed.device) if need_embed else None
+        gf_part = torch.empty((B, C, h, w), dtype=torch.float32, device=embed.device) if need_feat else None
+        rc = lib.cgg_mask_logits_backward(dev_ptr(e_part, 'embed', torch.float32), dev_ptr(feat, 'feat', torch.float32),
+                                          dev_ptr(g_part, 'grad_out', torch.float32), dev_ptr(ge_part), dev_ptr(gf_part),
+                                          dev_ptr(ws), B, n, C, npix, int(bool(split)), stream_ptr(embed.device))
+        check(rc, 'cgg_mask_logits_backward')
+        if need_embed:
+            ge[:, s0:s1] = ge_part
+        if need_feat:
+            gf = gf_part if gf is None else gf.add_(gf_part)
+    return ge, gf
+
+
 def attn_mask_fix_full_rows(bits, npix):
     """In place: rows of the bit mask that block all `npix` keys are cleared."""
     rows = bits.numel() // bits.shape[-1]

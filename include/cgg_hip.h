@@ -133,6 +133,17 @@ int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int B, int C, i
 int cgg_mask_logits(const float* embed, const void* hi, const void* lo, float* out, uint32_t* bits,
                     int B, int Q, int C, int npix, cgg_stream_t stream);
 
+/* Backward of K3 (the einsum of mask2former_head.py:748 differentiated on the training path :851-921):
+ *   grad_feat [B, C, npix] f32 = sum_q embed[b][q][c] * grad_out[b][q][p]     (nullable: skipped)
+ *   grad_embed[B, Q, C]   f32 = sum_p grad_out[b][q][p] * feat[b][c][p]       (nullable: skipped)
+ * embed [B, Q, C] f32, feat [B, C, npix] f32 (the un-packed mask feature), grad_out [B, Q, npix] f32; outputs are written,
+ * not accumulated. bf16 MFMA with f32 accumulation; split != 0 = 3 MFMAs on (hi, lo) bf16 pairs (f32-class accuracy,
+ * Q <= 128), else Q <= 256. ws: cgg_mask_logits_backward_workspace_bytes(...) bytes (grad_embed partial planes, summed
+ * in a fixed order: no atomics). Requires C == 256, npix % 8 == 0.                                                  */
+int64_t cgg_mask_logits_backward_workspace_bytes(int B, int Q, int C, int npix);
+int cgg_mask_logits_backward(const float* embed, const float* feat, const float* grad_out, float* grad_embed,
+                             float* grad_feat, void* ws, int B, int Q, int C, int npix, int split, cgg_stream_t stream);
+
 /* rows of `bits` that block every key are cleared (open_set/models/mask2former_head.py:825-826).
  *   bits [rows, words] u32, npix valid bits per row.                                             */
 int cgg_attn_mask_fix_full_rows(uint32_t* bits, int rows, int npix, cgg_stream_t stream);

@@ -1043,3 +1043,36 @@ def test_generator_ce_rows_vs_materialised_logits(dev, precision):
     for a, b, name in zip(g, wg, ('hidden', 'weight', 'bias')):
         scale = b.abs().max().item()
         assert (a.double() - b.double()).abs().max().item() <= tol * scale + 1e-9, (name, (a.double() - b.double()).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('B,Q,h,w,split', [(2, 100, 64, 64, True), (1, 37, 40, 56, True), (2, 200, 64, 64, False),
+                                           (2, 160, 32, 72, True), (1, 300, 16, 24, False), (2, 100, 256, 256, False)])
+def test_mask_logits_backward_vs_float64(dev, B, Q, h, w, split):
+    """cgg_mask_logits_backward (the transposed contractions of the einsum at mask2former_head.py:748) against float64:
+    split (hi, lo) mode to 2e-5 of the gradient scale, plain bf16 mode to the bf16 bound; ragged pixel tiles
+    (40 x 56 = 70 tiles of 32), row counts that are not multiples of 16 / 32, row groups beyond one launch (160 split,
+    300 plain), full resolution; and the autograd function end to end."""
+    from cgg_amd.mask2former_head import _MaskLogitsFn
+    g = torch.Generator().manual_seed(70 + Q)
+    C = 256
+    E = torch.randn(B, Q, C, generator=g)
+    F_ = torch.randn(B, C, h, w, generator=g)
+    go = torch.randn(B, Q, h, w, generator=g)
+    want_e = torch.einsum('bqhw,bchw->bqc', go.double(), F_.double())
+    want_f = torch.einsum('bqc,bqhw->bchw', E.double(), go.double())
+    ge, gf = ops.mask_logits_backward(E.to(dev), F_.to(dev), go.to(dev), split)
+    tol = 2e-5 if split else 1e-2
+    for got, want, name in ((ge, want_e, 'grad_embed'), (gf, want_f, 'grad_feat')):
+        scale = want.abs().max().item()
+        err = (got.cpu().double() - want).abs().max().item()
+        assert err <= tol * scale, (name, err, scale)
+    ge2, gf2 = ops.mask_logits_backward(E.to(dev), F_.to(dev), go.to(dev), split)
+    assert torch.equal(ge, ge2) and torch.equal(gf, gf2)                    # deterministic
+    # autograd function (forward on the packed image + this backward)
+    Ed, Fd = E.to(dev).requires_grad_(True), F_.to(dev).requires_grad_(True)
+    packed = ops.pack_mask_feature(Fd.detach(), 1, split)
+    out = _MaskLogitsFn.apply(Ed, Fd, packed)
+    want_o = torch.einsum('bqc,bchw->bqhw', E.double(), F_.double())
+    assert (out.detach().cpu().double() - want_o).abs().max().item() <= tol * want_o.abs().max().item()
+    a, b = torch.autograd.grad(out, (Ed, Fd), go.to(dev))
+    assert torch.equal(a, ge) and torch.equal(b, gf)
