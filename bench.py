@@ -116,8 +116,9 @@ def pmc_traffic(kernel, B, H, W):
     if (B, H, W) != (2, 1024, 1024):
         return None, None
     tot = {}
+    rnd = 'r2' if os.path.exists(os.path.join(ROOT, 'profiles', 'r2_pmc_fetch_counter_collection.csv')) else 'r1'
     for name, cnt, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
-        path = os.path.join(ROOT, 'profiles', f'r1_pmc_{name}_counter_collection.csv')
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{name}_counter_collection.csv')
         if not os.path.exists(path):
             return None, None
         vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
@@ -125,7 +126,7 @@ def pmc_traffic(kernel, B, H, W):
         if not vals:
             return None, None
         tot[cnt] = sum(vals) / len(vals) * 1024.0 * mult
-    return tot['FETCH_SIZE'] + tot['WRITE_SIZE'], ('profiles/r1_pmc_{fetch,write}_counter_collection.csv: separate '
+    return tot['FETCH_SIZE'] + tot['WRITE_SIZE'], (f'profiles/{rnd}_pmc_' + '{fetch,write}_counter_collection.csv: separate '
                                                    'rocprofv3 --pmc passes; FETCH_SIZE x2 (gfx950 correction), KB units')
 
 

@@ -3,11 +3,11 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-O=$R/gpurun_out/r1
+O=$R/gpurun_out/r2
 rm -rf $O && mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 cp $(find /tmp/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
-python3 $R/scratch/hot_launches.py /tmp/stats > $O/hot_kernel_launches.txt
+python3 $R/scratch/hot_launches.py /tmp/stats $O/hot_kernel_launches.json > $O/hot_kernel_launches.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/scratch/kernel_only.py > /dev/null 2>&1
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_$c.csv
@@ -21,5 +21,14 @@ python bench.py > $O/bench_line.json 2> $O/bench_line.err
 python bench.py --pipeline 0 --no-cpu-baseline > $O/bench_line_nopipeline.json 2>> $O/bench_line.err
 python bench.py --graph 0 --no-cpu-baseline > $O/bench_line_eager.json 2>> $O/bench_line.err
 python bench.py --mode train --steps 5 --warmup 3 > $O/bench_train_line.json 2>> $O/bench_line.err
+python scratch/kernel_bench.py > $O/kernel_bench.json 2>> $O/bench_line.err
+python scratch/xattn_bwd_bench.py > $O/xattn_bwd_bench.txt 2>> $O/bench_line.err
+python scratch/ml_bwd_bench.py > $O/ml_bwd_bench.txt 2>> $O/bench_line.err
+python scratch/msda_ab.py > $O/msda_ab.txt 2>> $O/bench_line.err
+python scratch/serve_bench.py 128 2>> $O/bench_line.err | grep images > $O/serve_bench.txt
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/train_prof -- python3 $R/bench.py --mode train --steps 3 --warmup 2 > /dev/null 2>&1
+python3 $R/scratch/train_step_prof.py /tmp/train_prof > $O/train_top.txt
+cd $R
 ls -la $O
 tail -c 400 $O/bench_line.json
