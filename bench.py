@@ -509,7 +509,9 @@ def main():
         N = sum((H // s) * (W // s) for s in (8, 16, 32))
         vb = 2 if args.precision == 'bf16' else 4         # bf16 stream: value, offsets|logits and output are bf16
         mbytes = B * N * (256 * vb + 288 * vb + 256 * vb)
-        extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9)
+        extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9,
+                             frac_hbm_peak=mbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             rocprof=rocprof_launch_mean('cgg_msda_fwd_stream_kernel'))
 
     parity = None
     pipelined = pipe is not None

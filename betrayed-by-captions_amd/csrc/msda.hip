@@ -253,6 +253,121 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream_kernel(
                  cgg_pack2(cgg_f2bf(acc[4]), cgg_f2bf(acc[5])), cgg_pack2(cgg_f2bf(acc[6]), cgg_f2bf(acc[7])));
 }
 
+// Second encoder-stream specialisation. PMC (profiles/r2_pmc_sq_*): the kernel above is INSTRUCTION-ISSUE bound -- the
+// SIMDs issue ~100 % of the kernel's cycles (a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles), 20 % of the
+// wave cycles wait on memory -- so this version removes instructions instead of bytes:
+//   * the 4 lanes of a (query, head) each compute the tap geometry of ONE of the level's 4 points (corner offsets, bilinear
+//     weights already multiplied by the point's attention probability) and broadcast it to their quad with DPP quad_perm
+//     moves: 1 geometry evaluation + 32 moves per lane and level instead of 4 evaluations (~200 instructions);
+//   * the bilinear / attention weights are folded before the channel loop and the accumulation runs on v_pk_fma_f32
+//     (two channels per instruction): 16 packed FMAs per point instead of 40 scalar ones.
+// Same inputs / outputs; the summation order differs from the kernel above (w_p c_k folded first), so results agree to
+// rounding of the f32 accumulation (<= 1 bf16 ulp on the output), not bit for bit.
+typedef float msda_v2f __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float msda_quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int msda_quad_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+template <int PSEL>
+__device__ __forceinline__ void msda_point_gather(msda_v2f (&acc)[4], const uint16_t* __restrict__ vl, const int (&my_o)[4],
+                                                  const float (&my_w)[4]) {
+  constexpr int CTRL = PSEL | (PSEL << 2) | (PSEL << 4) | (PSEL << 6);      // quad_perm: every lane reads lane PSEL of its quad
+  uint4 u[4];
+  float w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = msda_quad_bcast<CTRL>(my_o[k]);
+    w[k] = msda_quad_bcast<CTRL>(my_w[k]);
+    u[k] = *reinterpret_cast<const uint4*>(vl + o);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t q[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+    const msda_v2f ww = {w[k], w[k]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const msda_v2f vv = {__uint_as_float(q[c] << 16), __uint_as_float(q[c] & 0xffff0000u)};
+      acc[c] = __builtin_elementwise_fma(vv, ww, acc[c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_kernel(
+    const uint16_t* __restrict__ value, MsdaLevels lv, const uint16_t* __restrict__ rows, const float* __restrict__ ref,
+    int ld, uint16_t* __restrict__ out, int Nv, int H, int Nq, long long total) {
+  constexpr int D = 32, CPL = 8, DQ = 4, L = 3, LP = 12;
+  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
+  const long long gid = (long long)bid * 256 + threadIdx.x;
+  if (gid >= total) return;               // total is a multiple of 4: quads are never split
+  const int cq = (int)(gid % DQ);
+  const int h = (int)((gid / DQ) % H);
+  const long long bq = gid / ((long long)DQ * H);
+  const int b = (int)(bq / Nq);
+  const int q = (int)(bq - (long long)b * Nq);
+  const int rowstride = H * D;
+  const uint16_t* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
+  const uint16_t* row = rows + (size_t)bq * ld;
+  const uint16_t* lp = row + (size_t)h * LP * 2 + 2 * cq;              // this lane's point: (x, y) of point cq, + 8 per level
+  const uint16_t* wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  float e[LP];
+  {
+    const uint2 a = *reinterpret_cast<const uint2*>(wp), c = *reinterpret_cast<const uint2*>(wp + 4),
+                d = *reinterpret_cast<const uint2*>(wp + 8);
+    const uint32_t u[6] = {a.x, a.y, c.x, c.y, d.x, d.y};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      e[2 * i] = __uint_as_float(u[i] << 16);
+      e[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+  }
+  float smax = e[0];
+#pragma unroll
+  for (int i = 1; i < LP; ++i) smax = fmaxf(smax, e[i]);
+  float ssum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    e[i] = __expf(e[i] - smax);
+    ssum += e[i];
+  }
+  const float sinv = 1.f / ssum;
+  // attention probability of THIS lane's point on each level
+  float pw[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+    pw[l] = (cq == 0 ? e[4 * l] : (cq == 1 ? e[4 * l + 1] : (cq == 2 ? e[4 * l + 2] : e[4 * l + 3]))) * sinv;
+
+  msda_v2f acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = msda_v2f{0.f, 0.f};
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.h[l], Wl = lv.w[l];
+    const uint16_t* vl = vb + (size_t)lv.start[l] * rowstride;
+    const uint32_t o = *reinterpret_cast<const uint32_t*>(lp + 8 * l);
+    const float x = rx + __uint_as_float(o << 16) / (float)Wl;
+    const float y = ry + __uint_as_float(o & 0xffff0000u) / (float)Hl;
+    const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
+    const float wl = l == 0 ? pw[0] : (l == 1 ? pw[1] : pw[2]);
+    const int my_o[4] = {t.o00 * rowstride, t.o01 * rowstride, t.o10 * rowstride, t.o11 * rowstride};
+    const float my_w[4] = {t.w00 * wl, t.w01 * wl, t.w10 * wl, t.w11 * wl};
+    msda_point_gather<0>(acc, vl, my_o, my_w);
+    msda_point_gather<1>(acc, vl, my_o, my_w);
+    msda_point_gather<2>(acc, vl, my_o, my_w);
+    msda_point_gather<3>(acc, vl, my_o, my_w);
+  }
+  uint16_t* op = out + (size_t)bq * rowstride + (size_t)h * D + cq * CPL;
+  *reinterpret_cast<uint4*>(op) =
+      make_uint4(cgg_pack2(cgg_f2bf(acc[0][0]), cgg_f2bf(acc[0][1])), cgg_pack2(cgg_f2bf(acc[1][0]), cgg_f2bf(acc[1][1])),
+                 cgg_pack2(cgg_f2bf(acc[2][0]), cgg_f2bf(acc[2][1])), cgg_pack2(cgg_f2bf(acc[3][0]), cgg_f2bf(acc[3][1])));
+}
+
 // Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
 // grad_loc / grad_attn are wave shuffles; grad_value is scattered with hardware f32 atomics.
 template <int P_>
@@ -839,8 +954,14 @@ extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* lev
   const long long total = (long long)B * Nq * H * (D / 8);
   const int nblk = (int)((total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
-  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;      // A/B switch for the vector-row kernel
-  if (L == 3 && P == 4 && D == 32 && ld % 8 == 0 && cgg_aligned16(offs_logits) && !generic_only)
+  // A/B switches: CGG_MSDA_GENERIC=1 -> generic kernel, CGG_MSDA_V1=1 -> vector-row kernel, default -> quad-shared taps
+  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
+  static const bool v1_only = getenv("CGG_MSDA_V1") != nullptr;
+  const bool fast_ok = L == 3 && P == 4 && D == 32 && ld % 8 == 0 && cgg_aligned16(offs_logits) && !generic_only;
+  if (fast_ok && !v1_only && (long long)Nv * H * D < (1ll << 31))
+    hipLaunchKernelGGL(cgg_msda_fwd_stream2_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
+                       (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, H, Nq, total);
+  else if (fast_ok)
     hipLaunchKernelGGL(cgg_msda_fwd_stream_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
                        (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, H, Nq, total);
   else if (L == 3 && P == 4)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/r2
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --host-results 0 > $O/bench_under_rocprof.log 2>&1
 cp $(find /tmp/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python3 $R/scratch/hot_launches.py /tmp/stats $O/hot_kernel_launches.json > $O/hot_kernel_launches.txt
 for c in FETCH_SIZE WRITE_SIZE; do

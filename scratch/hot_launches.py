@@ -7,9 +7,9 @@ for r in csv.DictReader(open(f)):
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if 'cgg_mask_logits_kernel' in n:
         agg[('cgg_mask_logits_kernel', r['Grid_Size_X'], r['Grid_Size_Y'])].append(d)
-    elif 'cgg_msda_fwd' in n:
-        agg[('cgg_msda_fwd_kernel(bf16 stream)', r['Grid_Size_X'], r['Grid_Size_Y'])].append(d)
-print('Per-launch durations from the rocprofv3 kernel trace of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`')
+    elif 'cgg_msda_fwd_stream' in n:
+        agg[('cgg_msda_fwd_stream_kernel', r['Grid_Size_X'], r['Grid_Size_Y'])].append(d)
+print('Per-launch durations from the rocprofv3 kernel trace of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --host-results 0`')
 print('(same run as r2_bench_kernel_stats.csv; the stats file averages the 9 bit-mask-only launches per step together')
 print(' with the ONE full-resolution launch that bench.py prices in `roofline`, so they are split here by grid size)\n')
 print('%-36s %10s %8s %8s %10s %10s %10s' % ('kernel', 'grid_x', 'grid_y', 'calls', 'avg_us', 'min_us', 'max_us'))
@@ -24,8 +24,8 @@ if len(sys.argv) > 2:
     for k, v in agg.items():
         full = k[0] == 'cgg_mask_logits_kernel' and int(k[1]) == 65536 and int(k[2]) == 2
         if full or k[0].startswith('cgg_msda_fwd'):
-            name = 'cgg_mask_logits_kernel' if full else 'cgg_msda_fwd_kernel'
+            name = 'cgg_mask_logits_kernel' if full else 'cgg_msda_fwd_stream_kernel'
             out[name] = dict(launch_ms_mean=sum(v) / len(v) / 1e3, launch_ms_min=min(v) / 1e3, launch_ms_max=max(v) / 1e3,
                              launches=len(v), grid=[int(k[1]), int(k[2])],
-                             command='rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline')
+                             command='rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --host-results 0')
     json.dump(out, open(sys.argv[2], 'w'), indent=1)

@@ -1,5 +1,6 @@
-"""A/B of the encoder-stream MSDeformAttn forward at configs[1] shapes: vector-row kernel (default) vs the generic kernel
-(CGG_MSDA_GENERIC=1), each in its own process; outputs must be bit-identical.  python scratch/msda_ab.py"""
+"""A/B of the encoder-stream MSDeformAttn forward at configs[1] shapes: quad-shared-tap kernel (default), vector-row kernel
+(CGG_MSDA_V1=1) and the generic kernel (CGG_MSDA_GENERIC=1), each in its own process; vector-row == generic bit for bit,
+quad-shared within one bf16 ulp (different f32 summation order).  python scratch/msda_ab.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
@@ -36,7 +37,11 @@ if len(sys.argv) > 1:
     torch.save(out.cpu(), sys.argv[2])
 else:
     import torch
-    for name, env in (('vector-row', {}), ('generic', {'CGG_MSDA_GENERIC': '1'})):
+    for name, env in (('quad-shared', {}), ('vector-row', {'CGG_MSDA_V1': '1'}), ('generic', {'CGG_MSDA_GENERIC': '1'})):
         subprocess.run([sys.executable, os.path.abspath(__file__), name, f'/tmp/msda_{name}.pt'], env=dict(os.environ, **env), check=True)
-    a, b = torch.load('/tmp/msda_vector-row.pt'), torch.load('/tmp/msda_generic.pt')
-    print('bit-identical:', torch.equal(a, b), ' max |diff|:', float((a.float() - b.float()).abs().max()))
+    a, b, c = torch.load('/tmp/msda_vector-row.pt'), torch.load('/tmp/msda_generic.pt'), torch.load('/tmp/msda_quad-shared.pt')
+    print('vector-row vs generic: bit-identical:', torch.equal(a, b), ' max |diff|:', float((a.float() - b.float()).abs().max()))
+    d = (c.float() - b.float()).abs()
+    ulp = b.float().abs().clamp(min=1e-3) * 2.0 ** -7          # one bf16 ulp is <= 2^-7 of the value
+    print('quad-shared vs generic: max |diff| %.3e, elements differing %.4f %%, max diff in bf16 ulps %.2f' %
+          (float(d.max()), 100.0 * float((d > 0).float().mean()), float((d / ulp).max())))

@@ -17,7 +17,7 @@ for a, b in pairs.items():
 rows = list(csv.DictReader(open(os.path.join(dst, 'r2_bench_kernel_stats.csv'))))
 rows.sort(key=lambda r: -int(r['TotalDurationNs']))
 with open(os.path.join(dst, 'r2_bench_kernel_stats_top.txt'), 'w') as f:
-    f.write('rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline   (bf16, hipGraph, 2-stage pipeline, 1x MI355X)\n')
+    f.write('rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --host-results 0   (bf16, hipGraph, 2-stage pipeline, 1x MI355X)\n')
     f.write('whole process: eager warm-up (incl. the MIOpen solver search) + graph captures + 20 timed pipelined steps + 20 eager event-timed steps\n')
     f.write('(kernel tracing serialises the two pipeline streams: ms_per_step under the profiler is ~1.3 ms above the unprofiled step)\n')
     f.write('%-100s %8s %12s %10s %7s\n' % ('kernel', 'calls', 'total_us', 'avg_us', 'pct'))
