@@ -868,6 +868,48 @@ __global__ __launch_bounds__(256) void cgg_point_sample_nhwc_kernel(const float*
   reinterpret_cast<f32x4*>(out)[i] = acc;
 }
 
+// Single-channel variant with a plane index per row: out[j][p] = bilinear sample of planes[index[j]] (H x W, f32) at
+// pts[j][p]. Training losses sample the ASSIGNED ground-truth mask of every matched query at its own 12 544 points
+// (mask2former_head.py:609-612): one launch per decoder layer for all images instead of one F.grid_sample per image
+// over ALL of the image's masks (G x the work, 160 launches per step). Same arithmetic as the kernel above.
+__global__ __launch_bounds__(256) void cgg_point_sample_planes_kernel(const float* __restrict__ planes,
+                                                                     const int32_t* __restrict__ index,
+                                                                     const float* __restrict__ pts, float* __restrict__ out,
+                                                                     int H, int W, int P, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // (row j, point p)
+  if (i >= total) return;
+  const long long j = i / P;
+  const float px = pts[i * 2], py = pts[i * 2 + 1];
+  const float gx = __fsub_rn(__fmul_rn(px, 2.0f), 1.0f), gy = __fsub_rn(__fmul_rn(py, 2.0f), 1.0f);
+  const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 2.f);
+  const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 2.f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = __fsub_rn(ix, fx), ty = __fsub_rn(iy, fy);
+  const float ux = __fsub_rn(__fadd_rn(fx, 1.f), ix), uy = __fsub_rn(__fadd_rn(fy, 1.f), iy);
+  const float wnw = __fmul_rn(ux, uy), wne = __fmul_rn(tx, uy), wsw = __fmul_rn(ux, ty), wse = __fmul_rn(tx, ty);
+  const float* pl = planes + (size_t)index[j] * H * W;
+  const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+  float acc = 0.f;
+  if (xin0 && yin0) acc = fmaf(pl[(size_t)y0 * W + x0], wnw, acc);
+  if (xin1 && yin0) acc = fmaf(pl[(size_t)y0 * W + x0 + 1], wne, acc);
+  if (xin0 && yin1) acc = fmaf(pl[(size_t)(y0 + 1) * W + x0], wsw, acc);
+  if (xin1 && yin1) acc = fmaf(pl[(size_t)(y0 + 1) * W + x0 + 1], wse, acc);
+  out[i] = acc;
+}
+
+extern "C" int cgg_point_sample_planes(const float* planes, const int32_t* index, const float* pts, float* out, int N, int H,
+                                       int W, int rows, int P, cgg_stream_t stream) {
+  CGG_REQUIRE(planes && index && pts && out, CGG_EINVAL, "cgg_point_sample_planes: null pointer");
+  CGG_REQUIRE(N > 0 && H > 0 && W > 0 && rows > 0 && P > 0, CGG_EINVAL, "cgg_point_sample_planes: bad sizes");
+  const long long total = (long long)rows * P;
+  hipLaunchKernelGGL(cgg_point_sample_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     planes, index, pts, out, H, W, P, total);
+  CGG_CHECK_LAUNCH("cgg_point_sample_planes");
+  return CGG_OK;
+}
+
 extern "C" int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
                                      cgg_stream_t stream) {
   CGG_REQUIRE(feat && pts && out, CGG_EINVAL, "cgg_point_sample_nhwc: null pointer");

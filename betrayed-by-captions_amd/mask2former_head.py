@@ -996,7 +996,7 @@ class Mask2FormerHeadOpen(nn.Module):
         num_imgs = cls_scores.size(0)
         pos_b = pos_g = gt_f = cap_loss = None
         if fast is not None:
-            (labels2, mask_weights, pos_b, pos_g, num_total_pos, pos_dev), gt_f, cls_emb_logits, cap_loss = fast
+            (labels2, mask_weights, pos_b, pos_g, num_total_pos, pos_dev), gt_f, cls_emb_logits, cap_loss = fast[:4]
             labels = labels2.flatten(0, 1)
             label_weights = torch.ones_like(labels)
             mask_targets = None
@@ -1079,19 +1079,26 @@ class Mask2FormerHeadOpen(nn.Module):
             if fast is not None:
                 # positives are ordered image-major (boolean indexing above): sample each image's float GT masks
                 # at its positives' points and pick the assigned mask -- no (npos, H, W) gather / float pass
-                Pn = points_coords.shape[1]
-                chunks, j0 = [], 0
-                while j0 < len(pos_b):
-                    b = pos_b[j0]
-                    j1 = j0
-                    while j1 < len(pos_b) and pos_b[j1] == b:
-                        j1 += 1
-                    g_idx = pos_dev['g'][j0:j1]
-                    smp = point_sample(gt_f[b][None], points_coords[j0:j1].reshape(1, (j1 - j0) * Pn, 2))[0]
-                    smp = smp.view(-1, j1 - j0, Pn)                                   # (G, npos_b, P)
-                    chunks.append(smp[g_idx, torch.arange(j1 - j0, device=smp.device)])
-                    j0 = j1
-                mask_point_targets = torch.cat(chunks, 0)
+                gt_cat = fast[4] if len(fast) > 4 else None
+                if gt_cat is not None and points_coords.is_cuda:
+                    # ONE launch for all images: every positive samples only ITS assigned ground-truth plane
+                    planes, g_off = gt_cat
+                    idx = (g_off[pos_dev['b']] + pos_dev['g']).to(torch.int32)
+                    mask_point_targets = ops.point_sample_planes(planes, idx.contiguous(), points_coords)
+                else:
+                    Pn = points_coords.shape[1]
+                    chunks, j0 = [], 0
+                    while j0 < len(pos_b):
+                        b = pos_b[j0]
+                        j1 = j0
+                        while j1 < len(pos_b) and pos_b[j1] == b:
+                            j1 += 1
+                        g_idx = pos_dev['g'][j0:j1]
+                        smp = point_sample(gt_f[b][None], points_coords[j0:j1].reshape(1, (j1 - j0) * Pn, 2))[0]
+                        smp = smp.view(-1, j1 - j0, Pn)                                   # (G, npos_b, P)
+                        chunks.append(smp[g_idx, torch.arange(j1 - j0, device=smp.device)])
+                        j0 = j1
+                    mask_point_targets = torch.cat(chunks, 0)
             else:
                 mask_point_targets = point_sample(mask_targets.unsqueeze(1).float(), points_coords).squeeze(1)
         mask_point_preds = point_sample(mask_preds.unsqueeze(1), points_coords).squeeze(1)
@@ -1186,6 +1193,10 @@ class Mask2FormerHeadOpen(nn.Module):
         n = len(all_cls_scores)
         B = all_cls_scores[0].size(0)
         gt_f = [gm.float() for gm in gt_masks_list]        # (G, H, W) once per step
+        gt_cat = None
+        if gt_f and gt_f[0].is_cuda and len({tuple(g.shape[-2:]) for g in gt_f}) == 1 and sum(g.shape[0] for g in gt_f) > 0:
+            counts = torch.tensor([0] + [g.shape[0] for g in gt_f[:-1]], device=gt_f[0].device)
+            gt_cat = (torch.cat(gt_f, 0).contiguous(), torch.cumsum(counts, 0))     # planes of all images + first plane of image b
         targets = self._targets_batched(all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f)
         pos_counts = [float(t[4]) for t in targets]
         if dist.is_available() and dist.is_initialized():
@@ -1221,7 +1232,7 @@ class Mask2FormerHeadOpen(nn.Module):
                 all_cls_scores[li], all_cls_emb_preds[li], all_mask_preds[li], gt_labels_list, gt_masks_list,
                 gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list, gt_caption_nouns_ids_list,
                 gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas, num_total_masks=ntm[li],
-                gathered=gathered[li], fast=(targets[li], gt_f, emb_logits[li], cap_losses[li])))
+                gathered=gathered[li], fast=(targets[li], gt_f, emb_logits[li], cap_losses[li], gt_cat)))
         names = ('loss_cls', 'loss_cls_emb', 'loss_grounding', 'loss_caption_generation',
                  'loss_caption_align', 'loss_mask', 'loss_dice')
         loss_dict = {k: v for k, v in zip(names, results[-1])}

@@ -1110,6 +1110,20 @@ def linear_sum_assignment_batch(costs):
     return out
 
 
+def point_sample_planes(planes, index, points):
+    """planes (N, H, W) f32, index (rows,) int32, points (rows, P, 2) f32 in [0, 1] (x, y) -> (rows, P): row j = bilinear
+    sample (grid_sample arithmetic, zeros outside) of planes[index[j]] at points[j]."""
+    N, H, W = planes.shape
+    rows, P, _ = points.shape
+    out = torch.empty((rows, P), dtype=torch.float32, device=planes.device)
+    if rows == 0:
+        return out
+    check(_lib_().cgg_point_sample_planes(dev_ptr(planes, 'planes', torch.float32), dev_ptr(index, 'index', torch.int32),
+                                          dev_ptr(points.contiguous(), 'points', torch.float32), dev_ptr(out), N, H, W, rows, P,
+                                          stream_ptr(planes.device)), 'cgg_point_sample_planes')
+    return out
+
+
 def point_sample_nhwc(feat, points):
     """feat (B, H, W, C) f32 channel-last, points (B, P, 2) in [0, 1] (x, y) -> (B, P, C): [3P] mmcv point_sample
     (grid_sample bilinear / zeros / align_corners=False) with the layout that makes a point's taps contiguous rows."""

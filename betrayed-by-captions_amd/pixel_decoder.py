@@ -241,8 +241,13 @@ class MultiScaleDeformableAttention(nn.Module):
                              runtime.cast_cached(self.value_proj.bias))      # bf16 values for the gather
         else:
             value = runtime.linear(src, self.value_proj.weight, self.value_proj.bias)
-        # offsets / logits decide WHERE to sample: keep them f32 in both precisions
-        offs_logits = F.linear(src_pos, w_cat, b_cat)
+        if runtime.is_bf16() and torch.is_grad_enabled():
+            # training in throughput mode: bf16 operands like the inference stream (whose kernel reads bf16 offset rows);
+            # the f32 GEMM and its two backward GEMMs cost 11 ms per step at configs[2]
+            offs_logits = runtime.linear(src_pos, w_cat, b_cat)
+        else:
+            # offsets / logits decide WHERE to sample: f32 in parity mode and in the f32-value inference path
+            offs_logits = F.linear(src_pos, w_cat, b_cat)
         value = value.view(B, N, H, D)
         if torch.is_grad_enabled() and (value.requires_grad or offs_logits.requires_grad):
             # training: un-fused prologue in torch so autograd reaches the linears; the sampling core

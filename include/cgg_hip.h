@@ -420,6 +420,11 @@ int cgg_linear_sum_assignment_f32(const float* cost, int n_problems, const int* 
  * Used for sample(E F) = E sample(F) at the matching points of all decoder layers (mask2former_head.py:357-366). C % 4 == 0. */
 int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
                           cgg_stream_t stream);
+/* Same sampling of single-channel f32 planes [N, H, W] with a plane index per output row: out[j, p] = sample of
+ * planes[index[j]] at pts[j, p] (pts [rows, P, 2], out [rows, P]). Used for the matched queries' ground-truth mask targets
+ * (mask2former_head.py:609-612): one launch per decoder layer for all images.                                          */
+int cgg_point_sample_planes(const float* planes, const int32_t* index, const float* pts, float* out, int N, int H, int W,
+                            int rows, int P, cgg_stream_t stream);
 
 /* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
  * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),

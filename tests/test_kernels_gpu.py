@@ -1081,3 +1081,19 @@ def test_mask_logits_backward_vs_float64(dev, B, Q, h, w, split):
     assert (out.detach().cpu().double() - want_o).abs().max().item() <= tol * want_o.abs().max().item()
     a, b = torch.autograd.grad(out, (Ed, Fd), go.to(dev))
     assert torch.equal(a, ge) and torch.equal(b, gf)
+
+
+def test_point_sample_planes_vs_grid_sample(dev):
+    """cgg_point_sample_planes == [3P] point_sample (F.grid_sample(2 p - 1, bilinear, zeros, align_corners=False)) of the
+    indexed plane, incl. points on / outside the border."""
+    g = torch.Generator().manual_seed(81)
+    N, H, W, rows, P = 7, 37, 52, 11, 300
+    planes = torch.randn(N, H, W, generator=g)
+    index = torch.randint(0, N, (rows,), generator=g).to(torch.int32)
+    pts = torch.rand(rows, P, 2, generator=g) * 1.2 - 0.1            # some outside [0, 1]
+    pts[0, 0] = torch.tensor([0.0, 0.0])
+    pts[0, 1] = torch.tensor([1.0, 1.0])
+    want = torch.nn.functional.grid_sample(planes[index.long()][:, None], (2.0 * pts - 1.0)[:, :, None, :],
+                                           align_corners=False)[:, 0, :, 0]
+    got = ops.point_sample_planes(planes.to(dev), index.to(dev), pts.to(dev)).cpu()
+    assert (got - want).abs().max().item() <= 1e-6
