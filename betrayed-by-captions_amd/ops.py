@@ -6,6 +6,7 @@ tensor raises `CggError` (see _lib.dev_ptr). References are to the reference rep
 kernel ids (K1..K19).
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -150,13 +151,19 @@ class MultiScaleDeformableAttnFunction(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # K3/K4/K5  mask logits  (open_set/models/mask2former_head.py:748-759, :825-826)
 # ------------------------------------------------------------------------------------------------
+# parity mode: contract the mask logits in exact f32 (f32 MFMA) instead of 3 x bf16 on (hi, lo) pairs; CGG_EXACT_F32_LOGITS=0
+# restores the split kernel (A/B)
+EXACT_F32_LOGITS = os.environ.get('CGG_EXACT_F32_LOGITS', '1') != '0'
+
+
 class PackedFeature:
     """mask_feature packed for the MFMA B operand (see include/cgg_hip.h)."""
 
-    def __init__(self, hi, lo, B, C, h, w):
+    def __init__(self, hi, lo, B, C, h, w, f32=None):
         self.hi, self.lo, self.B, self.C, self.h, self.w = hi, lo, B, C, h, w
         self.npix = h * w
         self.words = (self.npix + 31) // 32
+        self.f32 = f32        # parity mode: the un-packed f32 map (B, C, h, w) for the exact-f32 contraction
 
 
 def pack_mask_feature(feat, pool=1, split=True):
@@ -171,7 +178,17 @@ def pack_mask_feature(feat, pool=1, split=True):
     rc = _lib_().cgg_pack_mask_feature(dev_ptr(feat, 'mask_feature', torch.float32), dev_ptr(hi),
                                        dev_ptr(lo), B, C, H, W, pool, stream_ptr(feat.device))
     check(rc, 'cgg_pack_mask_feature')
-    return PackedFeature(hi, lo, B, C, h, w)
+    f32 = None
+    if split and C == 256 and EXACT_F32_LOGITS:
+        # parity mode: keep the f32 map for `cgg_mask_logits_f32` (pool > 1: the same 2x2 mean, same association order
+        # as the pack kernel and as torch's bilinear down-sampling with all lambdas 0.5)
+        if pool == 1:
+            f32 = feat
+        else:
+            o = pool // 2 - 1
+            f32 = (((feat[:, :, o::pool, o::pool] + feat[:, :, o::pool, o + 1::pool])
+                    + (feat[:, :, o + 1::pool, o::pool] + feat[:, :, o + 1::pool, o + 1::pool])) * 0.25).contiguous()
+    return PackedFeature(hi, lo, B, C, h, w, f32)
 
 
 def mask_logits(embed, packed, want_logits=True, want_bits=False):
@@ -179,6 +196,19 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
     B, Q, C = embed.shape
     if B != packed.B or C != packed.C:
         raise CggError(f'mask_logits: embed {tuple(embed.shape)} vs packed B={packed.B} C={packed.C}')
+    if packed.f32 is not None and Q > 128:
+        parts = [mask_logits(embed[:, s:s + 128].contiguous(), packed, want_logits, want_bits) for s in range(0, Q, 128)]
+        return (torch.cat([p[0] for p in parts], 1) if want_logits else None,
+                torch.cat([p[1] for p in parts], 1) if want_bits else None)
+    if packed.f32 is not None:
+        out = torch.empty((B, Q, packed.h, packed.w), dtype=torch.float32, device=embed.device) if want_logits else None
+        bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device) if want_bits else None
+        with _timed('mask_logits_full' if want_logits else 'mask_logits_bits'):
+            rc = _lib_().cgg_mask_logits_f32(dev_ptr(embed, 'mask_embed', torch.float32),
+                                             dev_ptr(packed.f32.contiguous(), 'mask_feature', torch.float32), dev_ptr(out),
+                                             dev_ptr(bits), B, Q, C, packed.npix, stream_ptr(embed.device))
+        check(rc, 'cgg_mask_logits_f32')
+        return out, bits
     if packed.lo is not None and Q > 128:      # 3-MFMA (hi, lo) mode keeps <= 4 query tiles in LDS: split the queries
         parts = [mask_logits(embed[:, s:s + 128].contiguous(), packed, want_logits, want_bits)
                  for s in range(0, Q, 128)]

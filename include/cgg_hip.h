@@ -132,6 +132,10 @@ int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int B, int C, i
  * Requires C == 256 (feat_channels of every shipped config), Q <= 256 (bf16) / Q <= 128 (split).  */
 int cgg_mask_logits(const float* embed, const void* hi, const void* lo, float* out, uint32_t* bits,
                     int B, int Q, int C, int npix, cgg_stream_t stream);
+/* Exact-f32 variant for parity mode (f32 MFMA, f32 products): feat = the UN-packed f32 map [B, C, npix] (full resolution,
+ * or the 2x2-mean map the pooled images are made of); same out / bits contract. Requires C == 256, Q <= 128.            */
+int cgg_mask_logits_f32(const float* embed, const float* feat, float* out, uint32_t* bits, int B, int Q, int C, int npix,
+                        cgg_stream_t stream);
 
 /* Backward of K3 (the einsum of mask2former_head.py:748 differentiated on the training path :851-921):
  *   grad_feat [B, C, npix] f32 = sum_q embed[b][q][c] * grad_out[b][q][p]     (nullable: skipped)

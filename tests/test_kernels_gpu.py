@@ -1097,3 +1097,26 @@ def test_point_sample_planes_vs_grid_sample(dev):
                                            align_corners=False)[:, 0, :, 0]
     got = ops.point_sample_planes(planes.to(dev), index.to(dev), pts.to(dev)).cpu()
     assert (got - want).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize('B,Q,h,w,pool', [(2, 100, 64, 64, 1), (1, 37, 40, 56, 1), (2, 100, 64, 64, 2), (1, 200, 32, 40, 4)])
+def test_mask_logits_exact_f32_kernel(dev, B, Q, h, w, pool):
+    """cgg_mask_logits_f32 (parity mode: f32 MFMA) vs float64: logits to f32 rounding (1e-6 of the operand scale -- the
+    3 x bf16 split kernel sits at 2e-5), attention-mask bits equal to (interpolated logit < 0) away from rounding, for the
+    full-resolution and the pooled feature, ragged pixel tiles and more than 128 queries."""
+    g = torch.Generator().manual_seed(90 + Q)
+    C = 256
+    E = torch.randn(B, Q, C, generator=g)
+    F_ = torch.randn(B, C, h, w, generator=g)
+    packed = ops.pack_mask_feature(F_.to(dev), pool, split=True)
+    assert packed.f32 is not None
+    out, bits = ops.mask_logits(E.to(dev), packed, want_logits=True, want_bits=True)
+    full = torch.einsum('bqc,bchw->bqhw', E.double(), F_.double())
+    want = full if pool == 1 else torch.nn.functional.interpolate(full, (h // pool, w // pool), mode='bilinear',
+                                                                  align_corners=False)
+    scale = (E.abs().double() @ F_.abs().double().flatten(2)).max().item()
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= 2e-6 * scale, (err, scale)
+    got_bits = ops.unpack_bits(bits, packed.npix).cpu().view(B, Q, -1)
+    clear = want.flatten(2).abs() > 1e-5 * scale
+    assert torch.equal(got_bits[clear], (want.flatten(2) < 0)[clear])
