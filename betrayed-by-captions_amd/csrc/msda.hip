@@ -300,16 +300,17 @@ __device__ __forceinline__ void msda_point_gather(msda_v2f (&acc)[4], const uint
 
 __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_kernel(
     const uint16_t* __restrict__ value, MsdaLevels lv, const uint16_t* __restrict__ rows, const float* __restrict__ ref,
-    int ld, uint16_t* __restrict__ out, int Nv, int H, int Nq, long long total) {
-  constexpr int D = 32, CPL = 8, DQ = 4, L = 3, LP = 12;
-  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
-  const long long gid = (long long)bid * 256 + threadIdx.x;
+    int ld, uint16_t* __restrict__ out, int Nv, int Nq, unsigned total) {
+  constexpr int D = 32, CPL = 8, H = 8, L = 3, LP = 12;
+  // 32-bit index arithmetic with H = 8 and 4 lanes per (query, head) as compile-time shifts: the generic kernel's
+  // 64-bit `gid / (DQ * H)` and `bq / Nq` expand to software division loops (~25 % of its instructions)
+  const unsigned gid = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (gid >= total) return;               // total is a multiple of 4: quads are never split
-  const int cq = (int)(gid % DQ);
-  const int h = (int)((gid / DQ) % H);
-  const long long bq = gid / ((long long)DQ * H);
-  const int b = (int)(bq / Nq);
-  const int q = (int)(bq - (long long)b * Nq);
+  const int cq = (int)(gid & 3u);
+  const int h = (int)((gid >> 2) & 7u);
+  const unsigned bq = gid >> 5;
+  const unsigned b = bq / (unsigned)Nq;
+  const int q = (int)(bq - b * (unsigned)Nq);
   const int rowstride = H * D;
   const uint16_t* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
   const uint16_t* row = rows + (size_t)bq * ld;
@@ -958,9 +959,9 @@ extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* lev
   static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
   static const bool v1_only = getenv("CGG_MSDA_V1") != nullptr;
   const bool fast_ok = L == 3 && P == 4 && D == 32 && ld % 8 == 0 && cgg_aligned16(offs_logits) && !generic_only;
-  if (fast_ok && !v1_only && (long long)Nv * H * D < (1ll << 31))
+  if (fast_ok && !v1_only && H == 8 && (long long)Nv * H * D < (1ll << 31) && total < (1ll << 31))
     hipLaunchKernelGGL(cgg_msda_fwd_stream2_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
-                       (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, H, Nq, total);
+                       (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, Nq, (unsigned)total);
   else if (fast_ok)
     hipLaunchKernelGGL(cgg_msda_fwd_stream_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
                        (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, H, Nq, total);

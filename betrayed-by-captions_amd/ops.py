@@ -251,7 +251,7 @@ def mask_logits_backward(embed, feat, grad_out, split, need_embed=True, need_fea
         e_part = embed[:, s0:s1].contiguous()
         g_part = go[:, s0:s1].contiguous() if (s0 > 0 or s1 < Q) else go
         n = s1 - s0
-        ws = _xattn_ws(lambda *a: lib.cgg_mask_logits_backward_workspace_bytes(B, n, C, npix), embed, 0, 0, 0, 0, 0)
+        ws = _workspace(lib.cgg_mask_logits_backward_workspace_bytes(B, n, C, npix), embed.device)
         ge_part = torch.empty((B, n, C), dtype=torch.float32, device=embed.device) if need_embed else None
         gf_part = torch.empty((B, C, h, w), dtype=torch.float32, device=embed.device) if need_feat else None
         rc = lib.cgg_mask_logits_backward(dev_ptr(e_part, 'embed', torch.float32), dev_ptr(feat, 'feat', torch.float32),
@@ -296,14 +296,18 @@ def unpack_bits(bits, npix):
 # ------------------------------------------------------------------------------------------------
 # K6  masked cross attention core
 # ------------------------------------------------------------------------------------------------
-def _xattn_ws(lib_fn, q, B, Q, H, D, S):
-    nbytes = lib_fn(B, Q, H, D, S)
-    key = (q.device.index, stream_ptr(q.device).value)
+def _workspace(nbytes, device):
+    """Per-(device, stream) scratch buffer shared by the kernels that need one (grown on demand, never shrunk)."""
+    key = (device.index, stream_ptr(device).value)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=q.device)
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS_CACHE[key] = ws
     return ws
+
+
+def _xattn_ws(lib_fn, q, B, Q, H, D, S):
+    return _workspace(lib_fn(B, Q, H, D, S), q.device)
 
 
 def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
