@@ -10,7 +10,7 @@ pairs = {'kernel_stats.csv': 'r2_bench_kernel_stats.csv', 'hot_kernel_launches.t
          'bench_train_line.json': 'r2_bench_train_line.json', 'hot_kernel_launches.json': 'r2_hot_kernel_launches.json',
          'kernel_bench.json': 'r2_kernel_bench.json', 'xattn_bwd_bench.txt': 'r2_xattn_bwd_bench.txt',
          'ml_bwd_bench.txt': 'r2_ml_bwd_bench.txt', 'msda_ab.txt': 'r2_msda_ab.txt', 'serve_bench.txt': 'r2_serve_bench.txt',
-         'train_top.txt': 'r2_train_step_top_kernels.txt'}
+         'train_top.txt': 'r2_train_step_top_kernels.txt', 'step_kernels.txt': 'r2_inference_step_kernels.txt'}
 for a, b in pairs.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
