@@ -25,13 +25,18 @@ __device__ __forceinline__ void lr_cvt8(const f32x4& a, const f32x4& b, u32x4& h
   lo = u32x4{cgg_pack2(l[0], l[1]), cgg_pack2(l[2], l[3]), cgg_pack2(l[4], l[5]), cgg_pack2(l[6], l[7])};
 }
 
-template <bool SPLIT>
+// MODE 0: bf16 operands; 1: 3 bf16 MFMAs on (hi, lo) pairs (~2e-5 of sum |x w|); 2: EXACT f32 (v_mfma_f32_32x32x2_f32 on
+// the un-rounded operands: the W tile sits in LDS as f32, same slot layout, k pairs = (8 hi + e) of each 16-block).
+template <int MODE>
 __global__ __launch_bounds__(256) void cgg_linear_rows_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy, int M, int N, int K, int relu) {
+  constexpr bool SPLIT = MODE == 1;
+  constexpr bool EXACT = MODE == 2;
   constexpr int STEPS = LR_KC / 16;
-  __shared__ __attribute__((aligned(16))) u32x4 w_hi[STEPS * 64];
+  __shared__ __attribute__((aligned(16))) u32x4 w_hi[EXACT ? 1 : STEPS * 64];
   __shared__ __attribute__((aligned(16))) u32x4 w_lo[SPLIT ? STEPS * 64 : 1];
+  __shared__ __attribute__((aligned(16))) f32x4 w_f32[EXACT ? STEPS * 64 * 2 : 1];
   const int n0 = blockIdx.x * 32;
   const int m0 = blockIdx.y * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,10 +85,15 @@ __global__ __launch_bounds__(256) void cgg_linear_rows_kernel(
     __syncthreads();  // previous chunk's fragment reads are done
 #pragma unroll
     for (int it = 0; it < STEPS / 4; ++it) {
-      u32x4 h, lo;
-      lr_cvt8(wa[it][0], wa[it][1], h, lo, SPLIT);
-      w_hi[tid + 256 * it] = h;
-      if (SPLIT) w_lo[tid + 256 * it] = lo;
+      if constexpr (EXACT) {
+        w_f32[(tid + 256 * it) * 2] = wa[it][0];
+        w_f32[(tid + 256 * it) * 2 + 1] = wa[it][1];
+      } else {
+        u32x4 h, lo;
+        lr_cvt8(wa[it][0], wa[it][1], h, lo, SPLIT);
+        w_hi[tid + 256 * it] = h;
+        if (SPLIT) w_lo[tid + 256 * it] = lo;
+      }
     }
     __syncthreads();
     if (!wave_live) continue;
@@ -91,6 +101,14 @@ __global__ __launch_bounds__(256) void cgg_linear_rows_kernel(
 #pragma unroll
     for (int ks = 0; ks < STEPS; ++ks) {
       if (ks < steps) {
+        if constexpr (EXACT) {
+          const f32x4 b0 = w_f32[(ks * 64 + lane) * 2], b1 = w_f32[(ks * 64 + lane) * 2 + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[ks][0][e], b0[e], acc, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[ks][1][e], b1[e], acc, 0, 0, 0);
+          continue;
+        }
         u32x4 ah, al;
         lr_cvt8(xa[ks][0], xa[ks][1], ah, al, SPLIT);
         const bf16x8 vah = __builtin_bit_cast(bf16x8, ah);
@@ -160,10 +178,12 @@ extern "C" int cgg_linear_rows(const float* x, int ldx, const float* w, const fl
   CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w), CGG_EALIGN, "cgg_linear_rows: x / w must be 16-B aligned");
   dim3 grid((N + 31) / 32, (M + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
-  if (split)
-    hipLaunchKernelGGL(cgg_linear_rows_kernel<true>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
+  if (split == 2)
+    hipLaunchKernelGGL(cgg_linear_rows_kernel<2>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
+  else if (split)
+    hipLaunchKernelGGL(cgg_linear_rows_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
   else
-    hipLaunchKernelGGL(cgg_linear_rows_kernel<false>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
+    hipLaunchKernelGGL(cgg_linear_rows_kernel<0>, grid, dim3(256), 0, s, x, ldx, w, bias, res, ldr, y, ldy, M, N, K, relu);
   CGG_CHECK_LAUNCH("cgg_linear_rows");
   return CGG_OK;
 }

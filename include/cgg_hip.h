@@ -281,7 +281,8 @@ int cgg_self_attn_rows_bf16(const float* q, int ldq, const float* kv, int ldkv, 
  * the q / out / self-attention projections and FFN of DetrTransformerDecoderLayer ([3P], called at
  * open_set/models/mask2former_head.py:829-840) and the cls / v2l / mask_embed MLPs of forward_head (:734-746).
  *   y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ res)      x row stride ldx, y row stride ldy, res stride ldr
- *   relu != 0 applies ReLU before the residual add; split != 0 -> f32-class accuracy (3 bf16 MFMAs).
+ *   relu != 0 applies ReLU before the residual add; split == 1 -> 3 bf16 MFMAs on (hi, lo) pairs (~2e-5 of sum |x w|),
+ *   split == 2 -> exact f32 (f32 MFMA on the un-rounded operands; what parity mode uses), split == 0 -> plain bf16.
  * Requires K % 16 == 0, ldx % 4 == 0.
  * cgg_add_layernorm: y = LayerNorm(a (+ b)) * gamma + beta over the last dim N (b nullable).
  * ---------------------------------------------------------------------------------------------- */
