@@ -14,6 +14,7 @@
 #include "cgg_common.h"
 
 #include <atomic>
+#include <exception>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -132,6 +133,7 @@ extern "C" int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, in
     cgg_set_error("cgg_rle_encode_bitmasks: bad arguments (n=%d H=%d W=%d row_bytes=%d)", n, H, W, row_bytes);
     return -(int64_t)CGG_EINVAL;
   }
+  try {                                   // no C++ exception may cross the C ABI (std::thread / allocation failures)
   std::vector<std::string> enc((size_t)n);
   if (threads < 1) threads = 1;
   if (threads > n) threads = n > 0 ? n : 1;
@@ -148,7 +150,12 @@ extern "C" int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, in
   } else {
     std::vector<std::thread> pool;
     pool.reserve((size_t)threads);
-    for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+    try {
+      for (int t = 0; t < threads - 1; ++t) pool.emplace_back(work);
+    } catch (...) {
+      // could not start (all of) the helpers: the calling thread and the ones that did start finish the job
+    }
+    work();
     for (auto& th : pool) th.join();
   }
   int64_t total = 0;
@@ -161,4 +168,11 @@ extern "C" int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, in
     for (int i = 0; i < n; ++i) std::memcpy(out + offsets[i], enc[(size_t)i].data(), enc[(size_t)i].size());
   }
   return total;     // > out_cap: nothing was copied, call again with a larger buffer
+  } catch (const std::exception& e) {
+    cgg_set_error("cgg_rle_encode_bitmasks: %s", e.what());
+    return -(int64_t)CGG_EINVAL;
+  } catch (...) {
+    cgg_set_error("cgg_rle_encode_bitmasks: unknown C++ exception");
+    return -(int64_t)CGG_EINVAL;
+  }
 }
