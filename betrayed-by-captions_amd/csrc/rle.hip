@@ -138,11 +138,16 @@ extern "C" int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, in
   if (threads < 1) threads = 1;
   if (threads > n) threads = n > 0 ? n : 1;
   std::atomic<int> next(0);
+  std::atomic<bool> failed(false);
   auto work = [&]() {
-    for (;;) {
-      const int i = next.fetch_add(1);
-      if (i >= n) break;
-      encode_one(bits + (size_t)i * mask_stride_bytes, H, W, row_bytes, enc[(size_t)i]);
+    try {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) break;
+        encode_one(bits + (size_t)i * mask_stride_bytes, H, W, row_bytes, enc[(size_t)i]);
+      }
+    } catch (...) {
+      failed.store(true);                 // an exception must not leave a std::thread either
     }
   };
   if (threads == 1) {
@@ -157,6 +162,10 @@ extern "C" int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, in
     }
     work();
     for (auto& th : pool) th.join();
+  }
+  if (failed.load()) {
+    cgg_set_error("cgg_rle_encode_bitmasks: out of memory while encoding");
+    return -(int64_t)CGG_EINVAL;
   }
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
