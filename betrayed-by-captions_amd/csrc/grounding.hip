@@ -15,22 +15,25 @@
 // side): dsim [Bp][Bc * T][Q].
 #include "cgg_common.h"
 
-#define GR_LD 132   // LDS row stride (floats) of the score tile
+// NW wavefronts per workgroup = NW x 32 query columns (4: Q <= 128, 8: Q <= 256, e.g. the 200 queries of configs[3])
 
 __device__ __forceinline__ int gr_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void cgg_grounding_kernel(const float* __restrict__ pred, const float* __restrict__ cap,
+template <bool BWD, int NW>
+__global__ __launch_bounds__(NW * 64) void cgg_grounding_kernel(const float* __restrict__ pred, const float* __restrict__ cap,
                                                             const int32_t* __restrict__ cmask, float* __restrict__ cost,
                                                             const float* __restrict__ gcost, float* __restrict__ dsim,
                                                             int Bp, int Bc, int Q, int T, int d, float inv_temp) {
   const int i = blockIdx.x, j = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x = lane & 31, hi = lane >> 5;
-  __shared__ __attribute__((aligned(16))) float S[64 * GR_LD];
-  __shared__ float cst[3][128];       // per query column: max, sum, u = sum softmax * s
-  __shared__ float rst[3][64];        // per token row
-  __shared__ float red[4];
+  constexpr int GR_LD = NW * 32 + 4;                    // LDS row stride (floats) of the score tile
+  constexpr int QP = NW * 32;
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float gr_smem[];
+  float* S = gr_smem;                                   // [64][GR_LD]
+  float (*cst)[QP] = reinterpret_cast<float (*)[QP]>(S + 64 * GR_LD);     // [3][QP] per query column: max, sum, u
+  float (*rst)[64] = reinterpret_cast<float (*)[64]>(S + 64 * GR_LD + 3 * QP);   // [3][64] per token row
 
   const int half = d >> 1;
   const int t0 = x, t1 = 32 + x, qq = 32 * wave + x;
@@ -84,13 +87,22 @@ __global__ __launch_bounds__(256) void cgg_grounding_kernel(const float* __restr
   }
   __syncthreads();
   // ---- query softmax of every token row: one wavefront per row, lanes over the queries ----
-  for (int t = wave; t < T; t += 4) {
-    const float v0 = lane < Q ? S[t * GR_LD + lane] : -INFINITY;
-    const float v1 = lane + 64 < Q ? S[t * GR_LD + lane + 64] : -INFINITY;
-    float m = fmaxf(v0, v1);
+  for (int t = wave; t < T; t += NW) {
+    float v[QP / 64];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < QP / 64; ++c) {
+      v[c] = lane + 64 * c < Q ? S[t * GR_LD + lane + 64 * c] : -INFINITY;
+      m = fmaxf(m, v[c]);
+    }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const float p0 = lane < Q ? __expf(v0 - m) : 0.f, p1 = lane + 64 < Q ? __expf(v1 - m) : 0.f;
-    float sm = p0 + p1, u = (lane < Q ? p0 * v0 : 0.f) + (lane + 64 < Q ? p1 * v1 : 0.f);
+    float sm = 0.f, u = 0.f;
+#pragma unroll
+    for (int c = 0; c < QP / 64; ++c) {
+      const float p = lane + 64 * c < Q ? __expf(v[c] - m) : 0.f;
+      sm += p;
+      u += lane + 64 * c < Q ? p * v[c] : 0.f;
+    }
     for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); u += __shfl_xor(u, o); }
     if (lane == 0) { rst[0][t] = m; rst[1][t] = sm; rst[2][t] = u / sm; }
   }
@@ -103,7 +115,9 @@ __global__ __launch_bounds__(256) void cgg_grounding_kernel(const float* __restr
   if (!BWD) {
     if (wave == 0) {
       float l2v = lane < T ? mt * rst[2][lane] : 0.f;
-      float v2l = (lane < Q ? cst[2][lane] : 0.f) + (lane + 64 < Q ? cst[2][lane + 64] : 0.f);
+      float v2l = 0.f;
+#pragma unroll
+      for (int c = 0; c < QP / 64; ++c) v2l += lane + 64 * c < Q ? cst[2][lane + 64 * c] : 0.f;
       for (int o = 32; o > 0; o >>= 1) { l2v += __shfl_xor(l2v, o); v2l += __shfl_xor(v2l, o); }
       if (lane == 0) {
         cost[(size_t)i * Bp + j] = -l2v * inv_n;
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(256) void cgg_grounding_kernel(const float* __restr
     const float g1 = -gcost[(size_t)i * Bp + j] * inv_n * inv_temp;
     const float g2 = -gcost[(size_t)Bc * Bp + (size_t)i * Bp + j] / (float)Q * inv_temp;
     float* out = dsim + ((size_t)j * Bc + i) * T * (size_t)Q;
-    for (int idx = tid; idx < T * Q; idx += 256) {
+    for (int idx = tid; idx < T * Q; idx += NT) {
       const int t = idx / Q, q2 = idx - t * Q;
       const float s = S[t * GR_LD + q2];
       const float m_t = cmask[(size_t)i * T + t] != 0 ? 1.f : 0.f;
@@ -129,9 +143,26 @@ static int grounding_check(const void* pred, const void* cap, const void* cmask,
                            const char* who) {
   CGG_REQUIRE(pred && cap && cmask, CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(Bp > 0 && Bc > 0 && Q > 0 && T > 0 && d > 0, CGG_EINVAL, "%s: bad sizes", who);
-  CGG_REQUIRE(Q <= 128 && T <= 64, CGG_EUNSUPPORTED, "%s: Q=%d (<= 128) / T=%d (<= 64)", who, Q, T);
+  CGG_REQUIRE(Q <= 256 && T <= 64, CGG_EUNSUPPORTED, "%s: Q=%d (<= 256) / T=%d (<= 64)", who, Q, T);
   CGG_REQUIRE(d % 8 == 0, CGG_EUNSUPPORTED, "%s: embedding width %d must be a multiple of 8", who, d);
   CGG_REQUIRE(cgg_aligned16(pred) && cgg_aligned16(cap), CGG_EALIGN, "%s: pred / cap must be 16-B aligned", who);
+  return CGG_OK;
+}
+
+template <bool BWD>
+static int grounding_launch(const float* pred, const float* cap, const int32_t* cap_mask, float* cost, const float* gcost,
+                            float* dsim, int Bp, int Bc, int Q, int T, int d, float inv_t, hipStream_t s) {
+  const int nw = Q <= 128 ? 4 : 8;
+  const size_t lds = (size_t)(64 * (nw * 32 + 4) + 3 * nw * 32 + 3 * 64) * sizeof(float);
+  if (nw == 4) {
+    hipLaunchKernelGGL((cgg_grounding_kernel<BWD, 4>), dim3(Bc, Bp), dim3(256), lds, s, pred, cap, cap_mask, cost, gcost, dsim,
+                       Bp, Bc, Q, T, d, inv_t);
+  } else {
+    auto kern = cgg_grounding_kernel<BWD, 8>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_grounding: cannot raise dynamic LDS to %zu", lds);
+    hipLaunchKernelGGL(kern, dim3(Bc, Bp), dim3(512), lds, s, pred, cap, cap_mask, cost, gcost, dsim, Bp, Bc, Q, T, d, inv_t);
+  }
   return CGG_OK;
 }
 
@@ -141,8 +172,9 @@ extern "C" int cgg_grounding_pair_costs(const float* pred, const float* cap, con
   int rc = grounding_check(pred, cap, cap_mask, Bp, Bc, Q, T, d, "cgg_grounding_pair_costs");
   if (rc != CGG_OK) return rc;
   CGG_REQUIRE(cost, CGG_EINVAL, "cgg_grounding_pair_costs: null cost");
-  hipLaunchKernelGGL(cgg_grounding_kernel<false>, dim3(Bc, Bp), dim3(256), 0, (hipStream_t)stream, pred, cap, cap_mask,
-                     cost, (const float*)nullptr, (float*)nullptr, Bp, Bc, Q, T, d, inv_temperature);
+  rc = grounding_launch<false>(pred, cap, cap_mask, cost, nullptr, nullptr, Bp, Bc, Q, T, d, inv_temperature,
+                               (hipStream_t)stream);
+  if (rc != CGG_OK) return rc;
   CGG_CHECK_LAUNCH("cgg_grounding_pair_costs");
   return CGG_OK;
 }
@@ -153,8 +185,9 @@ extern "C" int cgg_grounding_pair_costs_backward(const float* pred, const float*
   int rc = grounding_check(pred, cap, cap_mask, Bp, Bc, Q, T, d, "cgg_grounding_pair_costs_backward");
   if (rc != CGG_OK) return rc;
   CGG_REQUIRE(grad_cost && dsim, CGG_EINVAL, "cgg_grounding_pair_costs_backward: null pointer");
-  hipLaunchKernelGGL(cgg_grounding_kernel<true>, dim3(Bc, Bp), dim3(256), 0, (hipStream_t)stream, pred, cap, cap_mask,
-                     (float*)nullptr, grad_cost, dsim, Bp, Bc, Q, T, d, inv_temperature);
+  rc = grounding_launch<true>(pred, cap, cap_mask, nullptr, grad_cost, dsim, Bp, Bc, Q, T, d, inv_temperature,
+                              (hipStream_t)stream);
+  if (rc != CGG_OK) return rc;
   CGG_CHECK_LAUNCH("cgg_grounding_pair_costs_backward");
   return CGG_OK;
 }

@@ -221,8 +221,8 @@ def grounding_loss(cls_emb_pred, gt_caption_embs, gt_caption_mask, temperature):
     B^2-fold `repeat`s (:23-30) are index arithmetic here, nothing is replicated.
 
     cls_emb_pred (B,Q,d), gt_caption_embs (B,T,d), gt_caption_mask (B,T) 0/1.
-    On a ROCm device (f32, Q <= 128, T <= 64) the pair costs come from `cgg_grounding_pair_costs`; other shapes
-    (e.g. 200 queries) and CPU tensors (host-side unit tests) take the torch formulation below."""
+    On a ROCm device (f32, Q <= 256, T <= 64) the pair costs come from `cgg_grounding_pair_costs`; other shapes
+    and CPU tensors (host-side unit tests) take the torch formulation below."""
     B, Q, d = cls_emb_pred.shape
     T = gt_caption_mask.shape[1]
     num_tokens = gt_caption_mask.sum(dim=1)                                  # (B,)

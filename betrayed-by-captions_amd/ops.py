@@ -384,7 +384,7 @@ def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None
 # K16  caption grounding pair costs
 # ------------------------------------------------------------------------------------------------
 def grounding_supported(pred, cap):
-    return (pred.is_cuda and pred.dtype == torch.float32 and cap.dtype == torch.float32 and pred.shape[1] <= 128
+    return (pred.is_cuda and pred.dtype == torch.float32 and cap.dtype == torch.float32 and pred.shape[1] <= 256
             and cap.shape[1] <= 64 and pred.shape[2] % 8 == 0)
 
 

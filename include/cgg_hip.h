@@ -228,7 +228,7 @@ int cgg_masked_xattn_backward(const float* q, const void* kv, const uint32_t* bi
  *   cost      [2, Bc, Bp] f32  (written)
  * backward: grad_cost [2, Bc, Bp] -> dsim [Bp, Bc*T, Q] f32 = d loss / d (caption_i[t] . pred_j[q]); the caller finishes
  * with ONE batched GEMM grad_pred[j] = dsim[j]^T x cap.reshape(Bc*T, d) (captions are constants: frozen text encoder).
- * f32 MFMA (exact products). Requires Q <= 128, T <= 64, d % 8 == 0.
+ * f32 MFMA (exact products). Requires Q <= 256, T <= 64, d % 8 == 0.
  * ---------------------------------------------------------------------------------------------- */
 int cgg_grounding_pair_costs(const float* pred, const float* cap, const int32_t* cap_mask, float* cost, int Bp, int Bc,
                              int Q, int T, int d, float inv_temperature, cgg_stream_t stream);

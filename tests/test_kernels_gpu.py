@@ -362,7 +362,8 @@ def test_xattn_autograd_function_uses_hip_backward(dev):
     assert (gkv - wkv).abs().max().item() <= 1e-4 * wkv.abs().max().item()
 
 
-@pytest.mark.parametrize('B,Q,T,d', [(16, 100, 35, 768), (4, 100, 35, 768), (2, 20, 35, 768), (3, 128, 64, 64), (1, 7, 5, 8)])
+@pytest.mark.parametrize('B,Q,T,d', [(16, 100, 35, 768), (4, 100, 35, 768), (2, 20, 35, 768), (3, 128, 64, 64), (1, 7, 5, 8),
+                                     (4, 200, 35, 768), (2, 256, 64, 64), (2, 129, 33, 16)])
 def test_grounding_loss_kernel_vs_oracle(dev, B, Q, T, d):
     """`losses.grounding_loss` on the HIP pair-cost kernel (cgg_grounding_pair_costs + backward) against the oracle's
     literal restatement of grounding_loss.py:9-77 (with the B^2 repeat; pinned by golden G1) in float64: loss value and
