@@ -32,8 +32,11 @@ class Bank:
         return torch.rand(*shape, generator=g).to(device)
 
 
-def test_forward_train_losses_and_gradients(dev):
-    cfg = small_cfg(num_queries=12, num_points=512)
+@pytest.mark.parametrize('num_queries', [12, 200])
+def test_forward_train_losses_and_gradients(dev, num_queries):
+    # 200 queries (configs[3]): query groups > 128 in the attention forward / backward kernels, the 8-wavefront grounding
+    # kernel, row groups in the mask-logit kernels
+    cfg = small_cfg(num_queries=num_queries, num_points=512)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         prod, orc = build_heads(cfg)
