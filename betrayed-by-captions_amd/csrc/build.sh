@@ -11,7 +11,9 @@ pids=""
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "${f%.hip}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/cgg_common.h" -nt "$o" ] || [ "$HERE/../../include/cgg_hip.h" -nt "$o" ]; then
-    $HIPCC $FLAGS -c "$f" -o "$o" &
+    # a source may ask for extra compiler flags on a "// build-flags: ..." line (e.g. the MFMA VGPR form)
+    extra="$(grep -m1 '^// build-flags:' "$f" | sed 's|^// build-flags:||')"
+    $HIPCC $FLAGS $extra -c "$f" -o "$o" &
     pids="$pids $!"
   fi
   OBJS="$OBJS $o"

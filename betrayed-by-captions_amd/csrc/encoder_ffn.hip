@@ -1,0 +1,283 @@
+// Encoder-stream FFN block of the MSDeformAttn pixel decoder ([3P] BaseTransformerLayer ('self_attn','norm','ffn','norm'),
+// built at open_set/models/mask2former_head.py:112-117; 6 layers x 43 008 rows at configs[1]) as ONE launch:
+//
+//     y = LayerNorm( x + W2 relu(W1 x + b1) + b2 ),   y16 = bf16(y),  yp16 = bf16(y + pos)     (x: bf16 rows, 256 wide)
+//
+// replacing two library GEMMs (256 -> 1024 with a ReLU epilogue, 1024 -> 256) and the residual-LayerNorm pass: the
+// (rows x 1024) hidden activation -- 88 MB written and 88 MB read per layer at configs[1] -- never leaves the chip, the
+// second GEMM's 22-MB output and its re-read by the LayerNorm disappear as well: HBM traffic per layer 220 MB -> 66 MB.
+//
+// A workgroup (8 wavefronts, arranged 2 x 4) owns 128 complete rows, held in LDS as bf16 MFMA A-fragment images. The
+// hidden dimension runs in 4 chunks of 256. Wave (wm, wn) computes a 64-row x 64-column block of every GEMM as 2 x 2
+// MFMA tiles: one A-fragment read from LDS and one B-fragment load (packed weight image, straight from L2 into registers,
+// prefetched 4 k-steps ahead) each feed TWO MFMAs -- the first version gave every wave one 32-column tile and paid one
+// 1-KiB LDS read per MFMA, which tied the kernel to the LDS bandwidth (112 us). The chunk's relu(. + b1) block goes back
+// to LDS as A-fragments (pairs of columns exchanged by DPP so that every store is a full 32-bit word) and is consumed by
+// the second GEMM, whose 2 x 2 accumulators persist over the chunks. Epilogue: f32 tile in LDS -> row-major LayerNorm (one
+// wavefront per row, shuffle reductions), bf16 residual rows added there. v_mfma_f32_32x32x16_bf16, f32 accumulation.
+//
+// build-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+// (both accumulator blocks live in VGPRs; the default AGPR form copied the 64 persistent GEMM-2 accumulators in and out of
+//  a[0:63] around every GEMM-1 block: 384 v_accvgpr moves per chunk and wave, a third of the MFMA time.)
+#include "cgg_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t ef_u32x4;
+typedef __attribute__((ext_vector_type(2))) float ef_f2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ef_bf2;
+
+#define EF_C 256
+#define EF_STEPS 16
+#define EF_RB 64               // rows per workgroup
+#define EF_NT (4 * EF_RB)      // threads per workgroup: one wavefront per 64 output columns x 64 rows
+#define EF_TS 260              // f32 LayerNorm tile row stride
+#define EF_PF 4                // B-fragment prefetch distance (k-steps)
+
+__device__ __forceinline__ uint32_t ef_pk(float a, float b) {            // v_cvt_pk_bf16_f32
+  const ef_f2 pr = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, ef_bf2));
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float ef_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
+// One 64 x 64 block of C += A B^T over 16 k-steps. A-fragment images of the two 32-row m-tiles in LDS (a0 / a1 = lane
+// pointers for even k-steps, a0o / a1o for odd ones -- the hidden image is bank-swizzled by k-step parity); B fragments of the
+// two 32-column n-tiles come through the rotating queue q0 / q1, which on entry already holds this block's first EF_PF k-steps
+// and on exit the NEXT block's (nb0 / nb1), so the weight stream never drains at a block boundary. The scheduling barriers
+// pin the software pipeline: without them the compiler sinks every load to just before its use (vmcnt(0..3) after each issue)
+// and the L2 latency is paid at every k-step.
+__device__ __forceinline__ void ef_block(f32x16 (&acc)[2][2], const ef_u32x4* __restrict__ a0, const ef_u32x4* __restrict__ a1,
+                                         const ef_u32x4* __restrict__ a0o, const ef_u32x4* __restrict__ a1o,
+                                         ef_u32x4 (&q0)[EF_PF], ef_u32x4 (&q1)[EF_PF], const ef_u32x4* __restrict__ b0,
+                                         const ef_u32x4* __restrict__ b1, const ef_u32x4* __restrict__ nb0,
+                                         const ef_u32x4* __restrict__ nb1) {
+  ef_u32x4 ua0 = a0[0], ua1 = a1[0];
+#pragma unroll
+  for (int s = 0; s < EF_STEPS; ++s) {
+    const bf16x8 vb0 = __builtin_bit_cast(bf16x8, q0[s % EF_PF]), vb1 = __builtin_bit_cast(bf16x8, q1[s % EF_PF]);
+    const bf16x8 va0 = __builtin_bit_cast(bf16x8, ua0), va1 = __builtin_bit_cast(bf16x8, ua1);
+    if (s + 1 < EF_STEPS) {
+      ua0 = ((s + 1) & 1) ? a0o[(s + 1) * 64] : a0[(s + 1) * 64];
+      ua1 = ((s + 1) & 1) ? a1o[(s + 1) * 64] : a1[(s + 1) * 64];
+    }
+#ifndef EF_NOB
+    if (s + EF_PF < EF_STEPS) {
+      q0[s % EF_PF] = b0[(s + EF_PF) * 64];
+      q1[s % EF_PF] = b1[(s + EF_PF) * 64];
+    } else {
+      q0[s % EF_PF] = nb0[(s + EF_PF - EF_STEPS) * 64];
+      q1[s % EF_PF] = nb1[(s + EF_PF - EF_STEPS) * 64];
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);                 // loads of the later steps issue BEFORE this step's four MFMAs
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, vb0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, vb1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, vb0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, vb1, acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
+    const uint16_t* __restrict__ x16, const ef_u32x4* __restrict__ w1, const float* __restrict__ b1,
+    const ef_u32x4* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, const float* __restrict__ pos, int pos_rows, uint16_t* __restrict__ y16,
+    uint16_t* __restrict__ yp16, float* __restrict__ y32, int M, int F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ef_smem[];
+  ef_u32x4* xfrag = reinterpret_cast<ef_u32x4*>(ef_smem);                     // [4 m-tiles][16][64]   64 KiB
+  ef_u32x4* hfrag = xfrag + (EF_RB / 32) * EF_STEPS * 64;                                // [4 m-tiles][16][64]   64 KiB
+  float* tile = reinterpret_cast<float*>(ef_smem);                            // [128][EF_TS] f32, after the GEMMs (130 KiB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi5 = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;                                    // wave grid (EF_RB / 64 row blocks) x 4 (columns)                                    // wave grid 2 (rows) x 4 (columns)
+  const int m0 = blockIdx.x * EF_RB;
+  const int nchunk = F >> 8;
+  const int KS2 = F >> 4;                                                     // k-steps of W2
+
+  // weight stream: the first EF_PF k-steps of GEMM 1 / chunk 0 are in flight while the rows are staged
+  ef_u32x4 q0[EF_PF], q1[EF_PF];
+#pragma unroll
+  for (int s = 0; s < EF_PF; ++s) {
+    q0[s] = w1[((size_t)(2 * wn) * EF_STEPS + s) * 64 + lane];
+    q1[s] = w1[((size_t)(2 * wn + 1) * EF_STEPS + s) * 64 + lane];
+  }
+  // ---- rows -> A-fragment images: 16-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k8 / 2, row % 32 + 32 (k8 & 1))
+  for (int p = tid; p < EF_RB * 32; p += EF_NT) {
+    const int row = p >> 5, k8 = p & 31;
+    ef_u32x4 v = {0u, 0u, 0u, 0u};
+    if (m0 + row < M) v = *reinterpret_cast<const ef_u32x4*>(x16 + (size_t)(m0 + row) * EF_C + 8 * k8);
+    xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (row & 31) + 32 * (k8 & 1)] = v;
+  }
+  f32x16 acc2[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+  __syncthreads();
+
+  const ef_u32x4* xa0 = xfrag + (2 * wm) * (EF_STEPS * 64) + lane;
+  const ef_u32x4* xa1 = xfrag + (2 * wm + 1) * (EF_STEPS * 64) + lane;
+  // hidden image, bank-swizzled: slot (k-step, half, row) sits at k-step * 64 + half * 32 + (row ^ 2 (k-step & 1) ^ 8 half), so the
+  // 32 stores of one instruction (2 k-steps x 2 halves x 8 (row, word) positions) fall into distinct banks
+  const int hoff_e = hi5 * 32 + (j ^ (8 * hi5)), hoff_o = hi5 * 32 + (j ^ 2 ^ (8 * hi5));
+  const ef_u32x4* ha0 = hfrag + (2 * wm) * (EF_STEPS * 64) + hoff_e;
+  const ef_u32x4* ha1 = hfrag + (2 * wm + 1) * (EF_STEPS * 64) + hoff_e;
+  const ef_u32x4* ha0o = hfrag + (2 * wm) * (EF_STEPS * 64) + hoff_o;
+  const ef_u32x4* ha1o = hfrag + (2 * wm + 1) * (EF_STEPS * 64) + hoff_o;
+  uint32_t* h32 = reinterpret_cast<uint32_t*>(hfrag);
+  const int odd = j & 1, k1 = (j >> 4) & 1, half = (j >> 3) & 1;
+  int hb[2][2];                                        // word index of this lane's store for (bit 1, bit 3) of the register row
+#pragma unroll
+  for (int X = 0; X < 2; ++X)
+#pragma unroll
+    for (int Y = 0; Y < 2; ++Y)
+      hb[X][Y] = ((((2 * wm) * EF_STEPS + 4 * wn + k1) * 64 + half * 32 + 2 * (X ^ k1) + 8 * (Y ^ half) + 4 * hi5 + odd) << 2) +
+                 ((j & 7) >> 1);
+  const uint32_t rot = 16u * (uint32_t)odd;
+  for (int c = 0; c < nchunk; ++c) {
+    // ---- GEMM 1: rows 64 wm .., hidden columns 256 c + 64 wn .. (n-tiles 8 c + 2 wn, + 1 of W1) ----
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const ef_u32x4* g2b0 = w2 + ((size_t)(2 * wn) * KS2 + 16 * c) * 64 + lane;
+    const ef_u32x4* g2b1 = w2 + ((size_t)(2 * wn + 1) * KS2 + 16 * c) * 64 + lane;
+    ef_block(acc, xa0, xa1, xa0, xa1, q0, q1, w1 + ((size_t)(8 * c + 2 * wn) * EF_STEPS) * 64 + lane,
+             w1 + ((size_t)(8 * c + 2 * wn + 1) * EF_STEPS) * 64 + lane, g2b0, g2b1);
+    // relu(. + b1) -> A-fragment image of the chunk; column (64 wn + 32 nt + j) of the chunk = k index of GEMM 2. Lanes j, j ^ 1 hold
+    // neighbouring columns: per register pair (2 rp, 2 rp + 1) they swap one value, the even lane then owns row(2 rp), the odd
+    // lane row(2 rp + 1), and each stores one full 32-bit word (v_cvt_pk_bf16_f32 + one DPP move per two values).
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float bias1 = b1[256 * c + 64 * wn + 32 * nt + j];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const float v0 = fmaxf(acc[mt][nt][2 * rp] + bias1, 0.f), v1 = fmaxf(acc[mt][nt][2 * rp + 1] + bias1, 0.f);
+          const float kept = odd ? v1 : v0, sent = odd ? v0 : v1;
+          const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sent), 0xB1, 0xf, 0xf, true));  // lane ^ 1
+          const uint32_t pk = ef_pk(kept, recv);
+          h32[hb[rp & 1][(rp >> 1) & 1] + (((mt * EF_STEPS + 2 * nt) * 64 + 16 * (rp >> 2)) << 2)] =
+              __builtin_amdgcn_alignbit(pk, pk, rot);              // odd lanes: (recv, kept)
+        }
+      }
+    }
+    __syncthreads();                                   // the chunk's hidden block is complete
+    // ---- GEMM 2: rows 64 wm .., output columns 64 wn .. over the chunk's 256 hidden units (k-steps 16 c .. of W2) ----
+    const int cn = c + 1 < nchunk ? c + 1 : 0;         // last chunk: the queue refills with chunk 0 again (unused)
+    ef_block(acc2, ha0, ha1, ha0o, ha1o, q0, q1, g2b0, g2b1, w1 + ((size_t)(8 * cn + 2 * wn) * EF_STEPS) * 64 + lane,
+             w1 + ((size_t)(8 * cn + 2 * wn + 1) * EF_STEPS) * 64 + lane);
+    __syncthreads();                                   // hfrag is rewritten by the next chunk (and by the tile below)
+  }
+
+  // ---- f32 block (+ b2) -> LDS tile; the fragment images are dead ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = 64 * wn + 32 * nt + j;
+    const float bias2 = b2[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+        tile[row * EF_TS + col] = acc2[mt][nt][r] + bias2;
+      }
+  }
+  __syncthreads();
+  // ---- row-major LayerNorm of x + ffn(x): wave w owns rows 16 w .. 16 w + 15, four at a time; 16 lanes share a row (lane
+  //      sub = lane & 15 holds columns 4 sub + 64 k .. + 3, k = 0..3), so the two row reductions are 4 DPP adds each and
+  //      the four rows' dependency chains run side by side (one row per wavefront with six ds_bpermute steps per reduction was
+  //      a 1.5-us serial chain per row) ----
+#ifdef EF_NOLN
+  if (M > 0) return;
+#endif
+  const int sub = lane & 15, rsub = lane >> 4;
+  f32x4 g4[4], be4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    g4[k] = *reinterpret_cast<const f32x4*>(gamma + 4 * sub + 64 * k);
+    be4[k] = *reinterpret_cast<const f32x4*>(beta + 4 * sub + 64 * k);
+  }
+  constexpr float inv_n = 1.f / (float)EF_C;
+#pragma unroll 2
+  for (int it = 0; it < 4; ++it) {
+    const int row = 16 * wave + 4 * it + rsub, m = m0 + row;
+    const bool live = m < M;
+    const int mc = live ? m : M - 1;                                          // clamped: reductions stay convergent
+    f32x4 v[4];
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = *reinterpret_cast<const f32x4*>(&tile[row * EF_TS + 4 * sub + 64 * k]);
+      const uint2 xr = *reinterpret_cast<const uint2*>(x16 + (size_t)mc * EF_C + 4 * sub + 64 * k);
+      v[k][0] += __uint_as_float(xr.x << 16);
+      v[k][1] += __uint_as_float(xr.x & 0xffff0000u);
+      v[k][2] += __uint_as_float(xr.y << 16);
+      v[k][3] += __uint_as_float(xr.y & 0xffff0000u);
+      sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    sm = ef_row16_sum(sm);
+    const float mean = sm * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = v[k] - mean;
+      q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+    }
+    q = ef_row16_sum(q);
+    const float rstd = rsqrtf(q * inv_n + eps);
+    if (!live) continue;
+    const float* prow = yp16 ? pos + (size_t)(m % pos_rows) * EF_C : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+      const size_t o = (size_t)m * EF_C + 4 * sub + 64 * k;
+      if (y32) *reinterpret_cast<f32x4*>(y32 + o) = y;
+      if (y16) *reinterpret_cast<uint2*>(y16 + o) = make_uint2(ef_pk(y[0], y[1]), ef_pk(y[2], y[3]));
+      if (yp16) {
+        const f32x4 yp = y + *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
+        *reinterpret_cast<uint2*>(yp16 + o) = make_uint2(ef_pk(yp[0], yp[1]), ef_pk(yp[2], yp[3]));
+      }
+    }
+  }
+}
+
+extern "C" int cgg_encoder_ffn_ln_bf16(const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
+                                       const float* b2, const float* gamma, const float* beta, float eps, const float* pos,
+                                       int pos_rows, void* y16, void* yp16, float* y32, int M, int C, int F,
+                                       cgg_stream_t stream) {
+  CGG_REQUIRE(x16 && w1_packed && b1 && w2_packed && b2 && gamma && beta && (y16 || y32), CGG_EINVAL,
+              "cgg_encoder_ffn_ln_bf16: null pointer");
+  CGG_REQUIRE(C == EF_C, CGG_EUNSUPPORTED, "cgg_encoder_ffn_ln_bf16: C=%d (only 256 is built)", C);
+  CGG_REQUIRE(M > 0 && F > 0 && F % 256 == 0, CGG_EUNSUPPORTED, "cgg_encoder_ffn_ln_bf16: F=%d must be a multiple of 256", F);
+  CGG_REQUIRE(!yp16 || (pos && pos_rows > 0), CGG_EINVAL, "cgg_encoder_ffn_ln_bf16: yp16 needs pos");
+  CGG_REQUIRE(cgg_aligned16(x16) && cgg_aligned16(w1_packed) && cgg_aligned16(w2_packed) && cgg_aligned16(gamma) &&
+                  cgg_aligned16(beta) && (!pos || cgg_aligned16(pos)) && (!y16 || cgg_aligned16(y16)) &&
+                  (!yp16 || cgg_aligned16(yp16)) && (!y32 || cgg_aligned16(y32)),
+              CGG_EALIGN, "cgg_encoder_ffn_ln_bf16: 16-B alignment");
+  const size_t lds = (size_t)EF_RB * EF_TS * sizeof(float);          // >= the two fragment images (128 KiB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_ffn_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_encoder_ffn_ln_bf16: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cgg_encoder_ffn_ln_kernel, dim3((M + EF_RB - 1) / EF_RB), dim3(EF_NT), lds, (hipStream_t)stream,
+                     (const uint16_t*)x16, (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos,
+                     pos_rows, (uint16_t*)y16, (uint16_t*)yp16, y32, M, F);
+  CGG_CHECK_LAUNCH("cgg_encoder_ffn_ln_bf16");
+  return CGG_OK;
+}

@@ -630,6 +630,24 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
     return y32, y16, yp16
 
 
+def encoder_ffn_ln(x16, w1p, b1, w2p, b2, gamma, beta, eps=1e-5, pos=None, want_f32=False, want_bf16=True, want_pos=False):
+    """LN(x + W2 relu(W1 x + b1) + b2) on (..., 256) bf16 rows in ONE launch (hidden activation stays on chip); w1p / w2p
+    from `pack_linear_weight`. Returns (y f32 | None, bf16(y) | None, bf16(y + pos[row % len(pos)]) | None)."""
+    C = x16.shape[-1]
+    M = x16.numel() // C
+    F_ = b1.numel()
+    y32 = torch.empty(x16.shape, dtype=torch.float32, device=x16.device) if want_f32 else None
+    y16 = torch.empty(x16.shape, dtype=torch.bfloat16, device=x16.device) if want_bf16 else None
+    yp16 = torch.empty(x16.shape, dtype=torch.bfloat16, device=x16.device) if want_pos else None
+    rc = _lib_().cgg_encoder_ffn_ln_bf16(
+        dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(w1p), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2p),
+        dev_ptr(b2, 'b2', torch.float32), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
+        float(eps), dev_ptr(pos, 'pos', torch.float32), pos.shape[0] if pos is not None else 0, dev_ptr(y16), dev_ptr(yp16),
+        dev_ptr(y32), M, C, F_, stream_ptr(x16.device))
+    check(rc, 'cgg_encoder_ffn_ln_bf16')
+    return y32, y16, yp16
+
+
 def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=True):
     """Last encoder LayerNorm of the inference stream: y = LN(a + b) (a (B, S, 256) f32, b f32|bf16|None) plus the
     query decoder's K / V operands m16 = bf16(y + shift[s]), mp16 = bf16(y + shift[s] + pos[s]) (shift, pos (S, 256)

@@ -13,6 +13,7 @@ reference checkpoint's `state_dict` loads unchanged. The execution is MI355X-fir
   * sine positional encodings and reference points depend only on the level shapes -> cached.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -23,6 +24,10 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
                        TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
                        build_feedforward_network, build_positional_encoding,
                        build_transformer_layer, build_transformer_layer_sequence)
+
+# throughput mode: encoder FFN + residual LayerNorm as one HIP launch (ops.encoder_ffn_ln); CGG_FUSED_FFN=0 restores the
+# two library GEMMs + LayerNorm pass for A/B measurements
+FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
 
 
 # ------------------------------------------------------------------------------------------------
@@ -559,11 +564,20 @@ class MSDeformAttnPixelDecoder(nn.Module):
             else:
                 src, x16, _ = ops.add_layernorm_stream(src, o16, n0.weight, n0.bias, n0.eps)
             ffn = layer.ffns[0]
+            last = li == n_layers - 1
+            if self.stream_residual_bf16 and not last and FUSED_FFN and ffn.layers[0][0].out_features % 256 == 0:
+                # FFN + residual LayerNorm as one launch: the (B, N, 1024) hidden activation stays on chip
+                fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+                w1p = runtime.derived_cached('ffn_w1p', (fc1.weight,), lambda: ops.pack_linear_weight(fc1.weight))
+                w2p = runtime.derived_cached('ffn_w2p', (fc2.weight,), lambda: ops.pack_linear_weight(fc2.weight))
+                _, x16, xp16 = ops.encoder_ffn_ln(x16, w1p, fc1.bias, w2p, fc2.bias, n1.weight, n1.bias, n1.eps, pos=pos,
+                                                  want_bf16=True, want_pos=True)
+                src = x16
+                continue
             # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a separate pass over the (B, N, 1024) hidden
             h16 = torch._addmm_activation(cc(ffn.layers[0][0].bias), x16.view(B * N, C),
                                           cc(ffn.layers[0][0].weight).t()).view(B, N, -1)
             f16 = F.linear(h16, cc(ffn.layers[1].weight), cc(ffn.layers[1].bias))
-            last = li == n_layers - 1
             if last and kv_tables is not None:
                 # the memory's last LayerNorm also emits the query decoder's bf16 K / V operands (level-major)
                 src, m16, mp16 = ops.add_layernorm_kv(src, f16, n1.weight, n1.bias, n1.eps, kv_tables[0], kv_tables[1],

@@ -356,6 +356,15 @@ int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype,
                          const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
                          float eps, cgg_stream_t stream);
 
+/* Encoder-stream FFN block of the pixel decoder as ONE launch ([3P] BaseTransformerLayer 'ffn' + 'norm' of the
+ * MSDeformAttn encoder layers built at open_set/models/mask2former_head.py:112-117):
+ *   y = LayerNorm(x + W2 relu(W1 x + b1) + b2);  x16 (M, 256) bf16 rows, w1 (F x 256) / w2 (256 x F) packed by
+ *   cgg_linear_rows_pack, F % 256 == 0. Outputs (each nullable except one of y16 / y32): y16 = bf16(y),
+ *   yp16 = bf16(y + pos[row % pos_rows]), y32 = y. The (M x F) hidden activation never reaches HBM. */
+int cgg_encoder_ffn_ln_bf16(const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
+                            const float* b2, const float* gamma, const float* beta, float eps, const float* pos,
+                            int pos_rows, void* y16, void* yp16, float* y32, int M, int C, int F, cgg_stream_t stream);
+
 /* Last encoder layer of the stream: y = LN(a + b) as above (y32 nullable) plus the two bf16 operands of the query
  * decoder's K / V projections (mask2former_head.py:795-812), written LEVEL-MAJOR -- [level][batch][hw_l][256], level l =
  * rows level_start[l] .. level_start[l+1] of each batch's S rows -- so that every level is one contiguous GEMM operand:

@@ -1121,3 +1121,39 @@ def test_mask_logits_exact_f32_kernel(dev, B, Q, h, w, pool):
     got_bits = ops.unpack_bits(bits, packed.npix).cpu().view(B, Q, -1)
     clear = want.flatten(2).abs() > 1e-5 * scale
     assert torch.equal(got_bits[clear], (want.flatten(2) < 0)[clear])
+
+
+@pytest.mark.parametrize('M,N,FF', [(43008, 21504, 1024), (4071, 1357, 1024), (100, 50, 512), (64, 64, 256)])
+def test_encoder_ffn_ln_fused_vs_float64(dev, M, N, FF):
+    """Fused encoder FFN + residual LayerNorm (one launch, hidden activation on chip) against float64 on the SAME
+    bf16-rounded operands (x, W1, W2; hidden rounded to bf16 as the kernel does): outputs are bf16, so the bound is one
+    bf16 ulp of |y| <= ~4 (2^-6 = 0.0157) for both y and y + pos; ragged M (not a multiple of the 64-row block) and
+    pos rows wrapping per image (row % N); three runs bit-identical."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(M + FF)
+    C = 256
+    x16 = torch.randn(M, C, generator=g).to(dev).bfloat16()
+    w1 = (torch.randn(FF, C, generator=g) * 0.05).to(dev)
+    b1 = (torch.randn(FF, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(C, FF, generator=g) * 0.03).to(dev)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    pos = torch.randn(N, C, generator=g).to(dev)
+    w1p, w2p = ops.pack_linear_weight(w1), ops.pack_linear_weight(w2)
+    runs = []
+    for _ in range(3):
+        y32, y16, yp16 = ops.encoder_ffn_ln(x16, w1p, b1, w2p, b2, gamma, beta, 1e-5, pos=pos, want_f32=True,
+                                            want_bf16=True, want_pos=True)
+        torch.cuda.synchronize()
+        runs.append((y32.clone(), y16.clone(), yp16.clone()))
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+    xd = x16.double()
+    h = torch.relu(xd @ w1.bfloat16().double().t() + b1.double()).bfloat16().double()
+    ref64 = F.layer_norm(xd + h @ w2.bfloat16().double().t() + b2.double(), (C,), gamma.double(), beta.double(), 1e-5)
+    refp = ref64 + pos.double().repeat((M + N - 1) // N, 1)[:M]
+    y32, y16, yp16 = runs[0]
+    assert (y32.double() - ref64).abs().max().item() <= 2e-3          # f32 output: accumulation-order error only
+    assert (y16.double() - ref64).abs().max().item() <= 2 ** -6 + 2e-3
+    assert (yp16.double() - refp).abs().max().item() <= 2 ** -5 + 2e-3  # |y + pos| < 8: one ulp = 2^-5 at most
