@@ -30,7 +30,8 @@ typedef __attribute__((ext_vector_type(2))) __bf16 ef_bf2;
 #define EF_RB 64               // rows per workgroup
 #define EF_NT (4 * EF_RB)      // threads per workgroup: one wavefront per 64 output columns x 64 rows
 #define EF_TS 260              // f32 LayerNorm tile row stride
-#define EF_PF 4                // B-fragment prefetch distance (k-steps)
+#define EF_PF 4                // B-fragment prefetch distance (k-steps); must divide EF_STEPS (the queue rotates across blocks)
+static_assert(EF_STEPS % EF_PF == 0, "the B queue index s % EF_PF must line up across blocks");
 
 __device__ __forceinline__ uint32_t ef_pk(float a, float b) {            // v_cvt_pk_bf16_f32
   const ef_f2 pr = {a, b};
@@ -84,11 +85,17 @@ __device__ __forceinline__ void ef_block(f32x16 (&acc)[2][2], const ef_u32x4* __
   }
 }
 
+// KV = false: y16 = bf16(y), yp16 = bf16(y + pos[m % pos_rows]) at row m.
+// KV = true (last encoder layer, see cgg_add_layernorm_kv): pos_rows = S rows per image, y16 = bf16(y + shift[s]) and
+// yp16 = bf16(y + shift[s] + pos[s]) written LEVEL-MAJOR (row B * start_l + b * hw_l + (s - start_l)); y32 stays row m.
+struct EfLevels { int n; int start[9]; };
+
+template <bool KV>
 __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     const uint16_t* __restrict__ x16, const ef_u32x4* __restrict__ w1, const float* __restrict__ b1,
     const ef_u32x4* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ pos, int pos_rows, uint16_t* __restrict__ y16,
-    uint16_t* __restrict__ yp16, float* __restrict__ y32, int M, int F) {
+    uint16_t* __restrict__ yp16, float* __restrict__ y32, int M, int F, const float* __restrict__ shift, EfLevels lv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ef_smem[];
   ef_u32x4* xfrag = reinterpret_cast<ef_u32x4*>(ef_smem);                     // [4 m-tiles][16][64]   64 KiB
   ef_u32x4* hfrag = xfrag + (EF_RB / 32) * EF_STEPS * 64;                                // [4 m-tiles][16][64]   64 KiB
@@ -239,45 +246,106 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     q = ef_row16_sum(q);
     const float rstd = rsqrtf(q * inv_n + eps);
     if (!live) continue;
-    const float* prow = yp16 ? pos + (size_t)(m % pos_rows) * EF_C : nullptr;
+    if constexpr (KV) {
+      const int S = pos_rows, nimg = M / S;
+      const int bi = m / S, si = m - bi * S;
+      int l = 0;
+      while (l + 1 < lv.n && si >= lv.start[l + 1]) ++l;
+      const size_t orow = (size_t)nimg * lv.start[l] + (size_t)bi * (lv.start[l + 1] - lv.start[l]) + (si - lv.start[l]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 y = v[k] * rstd * g4[k] + be4[k];
-      const size_t o = (size_t)m * EF_C + 4 * sub + 64 * k;
-      if (y32) *reinterpret_cast<f32x4*>(y32 + o) = y;
-      if (y16) *reinterpret_cast<uint2*>(y16 + o) = make_uint2(ef_pk(y[0], y[1]), ef_pk(y[2], y[3]));
-      if (yp16) {
-        const f32x4 yp = y + *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
-        *reinterpret_cast<uint2*>(yp16 + o) = make_uint2(ef_pk(yp[0], yp[1]), ef_pk(yp[2], yp[3]));
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+        const int cofs = 4 * sub + 64 * k;
+        if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)m * EF_C + cofs) = y;
+        const f32x4 mm = y + *reinterpret_cast<const f32x4*>(shift + (size_t)si * EF_C + cofs);
+        *reinterpret_cast<uint2*>(y16 + orow * EF_C + cofs) = make_uint2(ef_pk(mm[0], mm[1]), ef_pk(mm[2], mm[3]));
+        const f32x4 z = mm + *reinterpret_cast<const f32x4*>(pos + (size_t)si * EF_C + cofs);
+        *reinterpret_cast<uint2*>(yp16 + orow * EF_C + cofs) = make_uint2(ef_pk(z[0], z[1]), ef_pk(z[2], z[3]));
+      }
+    } else {
+      const float* prow = yp16 ? pos + (size_t)(m % pos_rows) * EF_C : nullptr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+        const size_t o = (size_t)m * EF_C + 4 * sub + 64 * k;
+        if (y32) *reinterpret_cast<f32x4*>(y32 + o) = y;
+        if (y16) *reinterpret_cast<uint2*>(y16 + o) = make_uint2(ef_pk(y[0], y[1]), ef_pk(y[2], y[3]));
+        if (yp16) {
+          const f32x4 yp = y + *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
+          *reinterpret_cast<uint2*>(yp16 + o) = make_uint2(ef_pk(yp[0], yp[1]), ef_pk(yp[2], yp[3]));
+        }
       }
     }
   }
+}
+
+static int ef_launch(bool kv, const void* x16, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
+                     const float* gamma, const float* beta, float eps, const float* pos, int pos_rows, void* y16, void* yp16,
+                     float* y32, int M, int C, int F, const float* shift, const EfLevels& lv, cgg_stream_t stream,
+                     const char* who) {
+  CGG_REQUIRE(x16 && w1_packed && b1 && w2_packed && b2 && gamma && beta && (y16 || y32), CGG_EINVAL, "%s: null pointer", who);
+  CGG_REQUIRE(C == EF_C, CGG_EUNSUPPORTED, "%s: C=%d (only 256 is built)", who, C);
+  CGG_REQUIRE(M > 0 && F > 0 && F % 256 == 0, CGG_EUNSUPPORTED, "%s: F=%d must be a multiple of 256", who, F);
+  CGG_REQUIRE(!yp16 || (pos && pos_rows > 0), CGG_EINVAL, "%s: yp16 needs pos", who);
+  CGG_REQUIRE(cgg_aligned16(x16) && cgg_aligned16(w1_packed) && cgg_aligned16(w2_packed) && cgg_aligned16(gamma) &&
+                  cgg_aligned16(beta) && (!pos || cgg_aligned16(pos)) && (!y16 || cgg_aligned16(y16)) &&
+                  (!yp16 || cgg_aligned16(yp16)) && (!y32 || cgg_aligned16(y32)) && (!shift || cgg_aligned16(shift)),
+              CGG_EALIGN, "%s: 16-B alignment", who);
+  const size_t lds = (size_t)EF_RB * EF_TS * sizeof(float);          // >= the two fragment images (64 KiB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_ffn_ln_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)cgg_encoder_ffn_ln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    CGG_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise dynamic LDS to %zu", who, lds);
+    attr_set = true;
+  }
+  const dim3 grid((M + EF_RB - 1) / EF_RB), block(EF_NT);
+  if (kv)
+    hipLaunchKernelGGL(cgg_encoder_ffn_ln_kernel<true>, grid, block, lds, (hipStream_t)stream, (const uint16_t*)x16,
+                       (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos, pos_rows,
+                       (uint16_t*)y16, (uint16_t*)yp16, y32, M, F, shift, lv);
+  else
+    hipLaunchKernelGGL(cgg_encoder_ffn_ln_kernel<false>, grid, block, lds, (hipStream_t)stream, (const uint16_t*)x16,
+                       (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos, pos_rows,
+                       (uint16_t*)y16, (uint16_t*)yp16, y32, M, F, shift, lv);
+  return CGG_OK;
 }
 
 extern "C" int cgg_encoder_ffn_ln_bf16(const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
                                        const float* b2, const float* gamma, const float* beta, float eps, const float* pos,
                                        int pos_rows, void* y16, void* yp16, float* y32, int M, int C, int F,
                                        cgg_stream_t stream) {
-  CGG_REQUIRE(x16 && w1_packed && b1 && w2_packed && b2 && gamma && beta && (y16 || y32), CGG_EINVAL,
-              "cgg_encoder_ffn_ln_bf16: null pointer");
-  CGG_REQUIRE(C == EF_C, CGG_EUNSUPPORTED, "cgg_encoder_ffn_ln_bf16: C=%d (only 256 is built)", C);
-  CGG_REQUIRE(M > 0 && F > 0 && F % 256 == 0, CGG_EUNSUPPORTED, "cgg_encoder_ffn_ln_bf16: F=%d must be a multiple of 256", F);
-  CGG_REQUIRE(!yp16 || (pos && pos_rows > 0), CGG_EINVAL, "cgg_encoder_ffn_ln_bf16: yp16 needs pos");
-  CGG_REQUIRE(cgg_aligned16(x16) && cgg_aligned16(w1_packed) && cgg_aligned16(w2_packed) && cgg_aligned16(gamma) &&
-                  cgg_aligned16(beta) && (!pos || cgg_aligned16(pos)) && (!y16 || cgg_aligned16(y16)) &&
-                  (!yp16 || cgg_aligned16(yp16)) && (!y32 || cgg_aligned16(y32)),
-              CGG_EALIGN, "cgg_encoder_ffn_ln_bf16: 16-B alignment");
-  const size_t lds = (size_t)EF_RB * EF_TS * sizeof(float);          // >= the two fragment images (128 KiB)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_ffn_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_encoder_ffn_ln_bf16: cannot raise dynamic LDS to %zu", lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(cgg_encoder_ffn_ln_kernel, dim3((M + EF_RB - 1) / EF_RB), dim3(EF_NT), lds, (hipStream_t)stream,
-                     (const uint16_t*)x16, (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos,
-                     pos_rows, (uint16_t*)y16, (uint16_t*)yp16, y32, M, F);
+  EfLevels lv;
+  lv.n = 0;
+  int rc = ef_launch(false, x16, w1_packed, b1, w2_packed, b2, gamma, beta, eps, pos, pos_rows, y16, yp16, y32, M, C, F, nullptr,
+                     lv, stream, "cgg_encoder_ffn_ln_bf16");
+  if (rc != CGG_OK) return rc;
   CGG_CHECK_LAUNCH("cgg_encoder_ffn_ln_bf16");
+  return CGG_OK;
+}
+
+extern "C" int cgg_encoder_ffn_ln_kv_bf16(const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
+                                          const float* b2, const float* gamma, const float* beta, float eps,
+                                          const float* shift, const float* pos, int S, const int* level_start_host,
+                                          int n_levels, float* y32, void* m16, void* mp16, int M, int C, int F,
+                                          cgg_stream_t stream) {
+  CGG_REQUIRE(shift && pos && m16 && mp16 && level_start_host, CGG_EINVAL, "cgg_encoder_ffn_ln_kv_bf16: null pointer");
+  CGG_REQUIRE(M > 0 && S > 0 && M % S == 0, CGG_EINVAL, "cgg_encoder_ffn_ln_kv_bf16: M=%d not a multiple of S=%d", M, S);
+  CGG_REQUIRE(n_levels >= 1 && n_levels <= 8, CGG_EUNSUPPORTED, "cgg_encoder_ffn_ln_kv_bf16: n_levels=%d (1..8)", n_levels);
+  EfLevels lv;
+  lv.n = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    lv.start[l] = level_start_host[l];
+    CGG_REQUIRE(lv.start[l] >= 0 && lv.start[l] < S && (l == 0 ? lv.start[l] == 0 : lv.start[l] > lv.start[l - 1]), CGG_EINVAL,
+                "cgg_encoder_ffn_ln_kv_bf16: level_start must start at 0 and increase (level %d: %d)", l, lv.start[l]);
+  }
+  lv.start[n_levels] = S;
+  int rc = ef_launch(true, x16, w1_packed, b1, w2_packed, b2, gamma, beta, eps, pos, S, m16, mp16, y32, M, C, F, shift, lv, stream,
+                     "cgg_encoder_ffn_ln_kv_bf16");
+  if (rc != CGG_OK) return rc;
+  CGG_CHECK_LAUNCH("cgg_encoder_ffn_ln_kv_bf16");
   return CGG_OK;
 }

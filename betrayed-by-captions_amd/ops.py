@@ -648,6 +648,22 @@ def encoder_ffn_ln(x16, w1p, b1, w2p, b2, gamma, beta, eps=1e-5, pos=None, want_
     return y32, y16, yp16
 
 
+def encoder_ffn_ln_kv(x16, w1p, b1, w2p, b2, gamma, beta, eps, shift, pos, level_start, want_f32=True):
+    """Last encoder layer: `encoder_ffn_ln` whose LayerNorm also emits the query decoder's K / V operands like
+    `add_layernorm_kv` (x16 (B, S, 256) bf16). Returns (y f32 | None, m16, mp16), the bf16 pair level-major."""
+    B, S, C = x16.shape
+    y32 = torch.empty(x16.shape, dtype=torch.float32, device=x16.device) if want_f32 else None
+    m16 = torch.empty((B * S, C), dtype=torch.bfloat16, device=x16.device)
+    mp16 = torch.empty((B * S, C), dtype=torch.bfloat16, device=x16.device)
+    rc = _lib_().cgg_encoder_ffn_ln_kv_bf16(
+        dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(w1p), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2p),
+        dev_ptr(b2, 'b2', torch.float32), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
+        float(eps), dev_ptr(shift, 'shift', torch.float32), dev_ptr(pos, 'pos', torch.float32), S, _int_array(level_start),
+        len(level_start), dev_ptr(y32), dev_ptr(m16), dev_ptr(mp16), B * S, C, b1.numel(), stream_ptr(x16.device))
+    check(rc, 'cgg_encoder_ffn_ln_kv_bf16')
+    return y32, m16, mp16
+
+
 def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=True):
     """Last encoder LayerNorm of the inference stream: y = LN(a + b) (a (B, S, 256) f32, b f32|bf16|None) plus the
     query decoder's K / V operands m16 = bf16(y + shift[s]), mp16 = bf16(y + shift[s] + pos[s]) (shift, pos (S, 256)

@@ -565,11 +565,17 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 src, x16, _ = ops.add_layernorm_stream(src, o16, n0.weight, n0.bias, n0.eps)
             ffn = layer.ffns[0]
             last = li == n_layers - 1
-            if self.stream_residual_bf16 and not last and FUSED_FFN and ffn.layers[0][0].out_features % 256 == 0:
+            if (self.stream_residual_bf16 and FUSED_FFN and ffn.layers[0][0].out_features % 256 == 0
+                    and (not last or kv_tables is not None)):
                 # FFN + residual LayerNorm as one launch: the (B, N, 1024) hidden activation stays on chip
                 fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
                 w1p = runtime.derived_cached('ffn_w1p', (fc1.weight,), lambda: ops.pack_linear_weight(fc1.weight))
                 w2p = runtime.derived_cached('ffn_w2p', (fc2.weight,), lambda: ops.pack_linear_weight(fc2.weight))
+                if last:
+                    # ... whose LayerNorm also emits the query decoder's bf16 K / V operands (level-major)
+                    src, m16, mp16 = ops.encoder_ffn_ln_kv(x16, w1p, fc1.bias, w2p, fc2.bias, n1.weight, n1.bias, n1.eps,
+                                                           kv_tables[0], kv_tables[1], level_start)
+                    return src, (m16, mp16)
                 _, x16, xp16 = ops.encoder_ffn_ln(x16, w1p, fc1.bias, w2p, fc2.bias, n1.weight, n1.bias, n1.eps, pos=pos,
                                                   want_bf16=True, want_pos=True)
                 src = x16

@@ -364,6 +364,13 @@ int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype,
 int cgg_encoder_ffn_ln_bf16(const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
                             const float* b2, const float* gamma, const float* beta, float eps, const float* pos,
                             int pos_rows, void* y16, void* yp16, float* y32, int M, int C, int F, cgg_stream_t stream);
+/* Same block for the LAST encoder layer: the LayerNorm also emits the query decoder's K / V operands exactly as
+ * cgg_add_layernorm_kv does (m16 = bf16(y + shift[s]), mp16 = bf16(y + shift[s] + pos[s]), level-major rows); y32 (nullable)
+ * is the f32 memory at its natural rows. M = B * S rows, level_start_host[n_levels] ascending from 0. */
+int cgg_encoder_ffn_ln_kv_bf16(const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
+                               const float* b2, const float* gamma, const float* beta, float eps, const float* shift,
+                               const float* pos, int S, const int* level_start_host, int n_levels, float* y32, void* m16,
+                               void* mp16, int M, int C, int F, cgg_stream_t stream);
 
 /* Last encoder layer of the stream: y = LN(a + b) as above (y32 nullable) plus the two bf16 operands of the query
  * decoder's K / V projections (mask2former_head.py:795-812), written LEVEL-MAJOR -- [level][batch][hw_l][256], level l =

@@ -1157,3 +1157,31 @@ def test_encoder_ffn_ln_fused_vs_float64(dev, M, N, FF):
     assert (y32.double() - ref64).abs().max().item() <= 2e-3          # f32 output: accumulation-order error only
     assert (y16.double() - ref64).abs().max().item() <= 2 ** -6 + 2e-3
     assert (yp16.double() - refp).abs().max().item() <= 2 ** -5 + 2e-3  # |y + pos| < 8: one ulp = 2^-5 at most
+
+
+def test_encoder_ffn_ln_kv_variant_matches_two_pass_path(dev):
+    """Last-layer variant: fused FFN + LayerNorm + level-major K / V operands == `encoder_ffn_ln` (f32 output) followed by the
+    existing `add_layernorm_kv` row remap, bit for bit on m16 / mp16 / y32 (same arithmetic order in both epilogues)."""
+    g = torch.Generator().manual_seed(5)
+    B, C, FF = 2, 256, 1024
+    shapes = [(8, 12), (16, 24), (32, 48)]
+    starts, S = _levels(shapes)
+    x16 = torch.randn(B, S, C, generator=g).to(dev).bfloat16()
+    w1 = (torch.randn(FF, C, generator=g) * 0.05).to(dev)
+    b1 = (torch.randn(FF, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(C, FF, generator=g) * 0.03).to(dev)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    shift = torch.randn(S, C, generator=g).to(dev)
+    pos = torch.randn(S, C, generator=g).to(dev)
+    w1p, w2p = ops.pack_linear_weight(w1), ops.pack_linear_weight(w2)
+    y32, m16, mp16 = ops.encoder_ffn_ln_kv(x16, w1p, b1, w2p, b2, gamma, beta, 1e-5, shift, pos, starts)
+    y_ref, _, _ = ops.encoder_ffn_ln(x16, w1p, b1, w2p, b2, gamma, beta, 1e-5, want_f32=True, want_bf16=False)
+    assert torch.equal(y32, y_ref)
+    # level-major remap of bf16(y + shift) and bf16(y + shift + pos), row by row
+    m = y_ref + shift[None]
+    z = m + pos[None]
+    want_m = torch.cat([m[:, s:s + h * w].reshape(-1, C) for s, (h, w) in zip(starts, shapes)], 0).bfloat16()
+    want_z = torch.cat([z[:, s:s + h * w].reshape(-1, C) for s, (h, w) in zip(starts, shapes)], 0).bfloat16()
+    assert torch.equal(m16, want_m) and torch.equal(mp16, want_z)
