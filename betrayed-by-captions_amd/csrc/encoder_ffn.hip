@@ -53,19 +53,28 @@ __device__ __forceinline__ float ef_row16_sum(float v) {
 // and on exit the NEXT block's (nb0 / nb1), so the weight stream never drains at a block boundary. The scheduling barriers
 // pin the software pipeline: without them the compiler sinks every load to just before its use (vmcnt(0..3) after each issue)
 // and the L2 latency is paid at every k-step.
+// XS = true: the image is the row image, swizzled by the whole k-step (slot ^ s): a0 / a1 are the m-tile bases and xl the lane.
+template <bool XS>
 __device__ __forceinline__ void ef_block(f32x16 (&acc)[2][2], const ef_u32x4* __restrict__ a0, const ef_u32x4* __restrict__ a1,
-                                         const ef_u32x4* __restrict__ a0o, const ef_u32x4* __restrict__ a1o,
+                                         const ef_u32x4* __restrict__ a0o, const ef_u32x4* __restrict__ a1o, int xl,
                                          ef_u32x4 (&q0)[EF_PF], ef_u32x4 (&q1)[EF_PF], const ef_u32x4* __restrict__ b0,
                                          const ef_u32x4* __restrict__ b1, const ef_u32x4* __restrict__ nb0,
                                          const ef_u32x4* __restrict__ nb1) {
-  ef_u32x4 ua0 = a0[0], ua1 = a1[0];
+  if constexpr (XS) asm volatile("" : "+v"(xl));       // keep the 15 swizzled lane offsets out of the chunk loop's live set
+  ef_u32x4 ua0 = XS ? a0[xl] : a0[0], ua1 = XS ? a0[EF_STEPS * 64 + xl] : a1[0];
 #pragma unroll
   for (int s = 0; s < EF_STEPS; ++s) {
     const bf16x8 vb0 = __builtin_bit_cast(bf16x8, q0[s % EF_PF]), vb1 = __builtin_bit_cast(bf16x8, q1[s % EF_PF]);
     const bf16x8 va0 = __builtin_bit_cast(bf16x8, ua0), va1 = __builtin_bit_cast(bf16x8, ua1);
     if (s + 1 < EF_STEPS) {
-      ua0 = ((s + 1) & 1) ? a0o[(s + 1) * 64] : a0[(s + 1) * 64];
-      ua1 = ((s + 1) & 1) ? a1o[(s + 1) * 64] : a1[(s + 1) * 64];
+      if constexpr (XS) {
+        const int xo = xl ^ (s + 1);                     // one v_xor per k-step; the m-tile / k-step parts are immediates
+        ua0 = a0[(s + 1) * 64 + xo];
+        ua1 = a0[(EF_STEPS + s + 1) * 64 + xo];
+      } else {
+        ua0 = ((s + 1) & 1) ? a0o[(s + 1) * 64] : a0[(s + 1) * 64];
+        ua1 = ((s + 1) & 1) ? a1o[(s + 1) * 64] : a1[(s + 1) * 64];
+      }
     }
 #ifndef EF_NOB
     if (s + EF_PF < EF_STEPS) {
@@ -114,12 +123,15 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     q0[s] = w1[((size_t)(2 * wn) * EF_STEPS + s) * 64 + lane];
     q1[s] = w1[((size_t)(2 * wn + 1) * EF_STEPS + s) * 64 + lane];
   }
-  // ---- rows -> A-fragment images: 16-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k8 / 2, row % 32 + 32 (k8 & 1))
+  // ---- rows -> A-fragment images: 16-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k-step = k8 / 2, (row % 32 +
+  //      32 (k8 & 1)) ^ k-step). The XOR spreads the 32 pieces of a row (one coalesced 512-byte read) over all 16 four-bank
+  //      groups -- unswizzled, every 128-bit store was a 32-way bank conflict.
+#pragma unroll 4
   for (int p = tid; p < EF_RB * 32; p += EF_NT) {
     const int row = p >> 5, k8 = p & 31;
     ef_u32x4 v = {0u, 0u, 0u, 0u};
     if (m0 + row < M) v = *reinterpret_cast<const ef_u32x4*>(x16 + (size_t)(m0 + row) * EF_C + 8 * k8);
-    xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (row & 31) + 32 * (k8 & 1)] = v;
+    xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v;
   }
   f32x16 acc2[2][2];
 #pragma unroll
@@ -130,8 +142,28 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
       for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
   __syncthreads();
 
-  const ef_u32x4* xa0 = xfrag + (2 * wm) * (EF_STEPS * 64) + lane;
-  const ef_u32x4* xa1 = xfrag + (2 * wm + 1) * (EF_STEPS * 64) + lane;
+  // residual: the GEMM-2 accumulators start as x itself -- x (bf16, exact in f32) times the identity, 8 MFMAs per wave on the
+  // row image that is already in LDS (wave wn's columns 64 wn .. 64 wn + 63 are k-steps 4 wn .. 4 wn + 3), instead of a second
+  // read of the rows from memory in the LayerNorm pass
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ks = 4 * wn + 2 * nt + kk;
+      const int es = j - 16 * kk - 8 * hi5;                       // B[k][n] = 1 iff 16 kk + 8 hi5 + e == j
+      const uint32_t one = (es >= 0 && es < 8) ? ((es & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
+      const int ed = es >> 1;
+      const ef_u32x4 idv = {ed == 0 ? one : 0u, ed == 1 ? one : 0u, ed == 2 ? one : 0u, ed == 3 ? one : 0u};
+      const bf16x8 vid = __builtin_bit_cast(bf16x8, idv);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const ef_u32x4 ua = xfrag[((2 * wm + mt) * EF_STEPS + ks) * 64 + (lane ^ ks)];
+        acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), vid, acc2[mt][nt], 0, 0, 0);
+      }
+    }
+
+  const ef_u32x4* xa0 = xfrag + (2 * wm) * (EF_STEPS * 64);
+  const ef_u32x4* xa1 = xfrag + (2 * wm + 1) * (EF_STEPS * 64);
   // hidden image, bank-swizzled: slot (k-step, half, row) sits at k-step * 64 + half * 32 + (row ^ 2 (k-step & 1) ^ 8 half), so the
   // 32 stores of one instruction (2 k-steps x 2 halves x 8 (row, word) positions) fall into distinct banks
   const int hoff_e = hi5 * 32 + (j ^ (8 * hi5)), hoff_o = hi5 * 32 + (j ^ 2 ^ (8 * hi5));
@@ -160,7 +192,7 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const ef_u32x4* g2b0 = w2 + ((size_t)(2 * wn) * KS2 + 16 * c) * 64 + lane;
     const ef_u32x4* g2b1 = w2 + ((size_t)(2 * wn + 1) * KS2 + 16 * c) * 64 + lane;
-    ef_block(acc, xa0, xa1, xa0, xa1, q0, q1, w1 + ((size_t)(8 * c + 2 * wn) * EF_STEPS) * 64 + lane,
+    ef_block<true>(acc, xa0, xa1, xa0, xa1, lane, q0, q1, w1 + ((size_t)(8 * c + 2 * wn) * EF_STEPS) * 64 + lane,
              w1 + ((size_t)(8 * c + 2 * wn + 1) * EF_STEPS) * 64 + lane, g2b0, g2b1);
     // relu(. + b1) -> A-fragment image of the chunk; column (64 wn + 32 nt + j) of the chunk = k index of GEMM 2. Lanes j, j ^ 1 hold
     // neighbouring columns: per register pair (2 rp, 2 rp + 1) they swap one value, the even lane then owns row(2 rp), the odd
@@ -184,7 +216,7 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     __syncthreads();                                   // the chunk's hidden block is complete
     // ---- GEMM 2: rows 64 wm .., output columns 64 wn .. over the chunk's 256 hidden units (k-steps 16 c .. of W2) ----
     const int cn = c + 1 < nchunk ? c + 1 : 0;         // last chunk: the queue refills with chunk 0 again (unused)
-    ef_block(acc2, ha0, ha1, ha0o, ha1o, q0, q1, g2b0, g2b1, w1 + ((size_t)(8 * cn + 2 * wn) * EF_STEPS) * 64 + lane,
+    ef_block<false>(acc2, ha0, ha1, ha0o, ha1o, 0, q0, q1, g2b0, g2b1, w1 + ((size_t)(8 * cn + 2 * wn) * EF_STEPS) * 64 + lane,
              w1 + ((size_t)(8 * cn + 2 * wn + 1) * EF_STEPS) * 64 + lane);
     __syncthreads();                                   // hfrag is rewritten by the next chunk (and by the tile below)
   }
@@ -222,17 +254,11 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
   for (int it = 0; it < 4; ++it) {
     const int row = 16 * wave + 4 * it + rsub, m = m0 + row;
     const bool live = m < M;
-    const int mc = live ? m : M - 1;                                          // clamped: reductions stay convergent
     f32x4 v[4];
     float sm = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       v[k] = *reinterpret_cast<const f32x4*>(&tile[row * EF_TS + 4 * sub + 64 * k]);
-      const uint2 xr = *reinterpret_cast<const uint2*>(x16 + (size_t)mc * EF_C + 4 * sub + 64 * k);
-      v[k][0] += __uint_as_float(xr.x << 16);
-      v[k][1] += __uint_as_float(xr.x & 0xffff0000u);
-      v[k][2] += __uint_as_float(xr.y << 16);
-      v[k][3] += __uint_as_float(xr.y & 0xffff0000u);
       sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
     }
     sm = ef_row16_sum(sm);

@@ -1,0 +1,200 @@
+// Input projections of one MSDeformAttn encoder layer ([3P] MultiScaleDeformableAttention.forward: `value_proj(value)`,
+// `sampling_offsets(query)`, `attention_weights(query)`; the layers are built at open_set/models/mask2former_head.py:112-117)
+// as ONE launch over the (B * N) x 256 bf16 stream:
+//
+//     value = x  Wv^T + bv            (M x 256, bf16)         x  = the layer input rows
+//     offs  = xp Wc^T + bc            (M x 384, bf16)         xp = x + pos rows,  Wc = [W_offsets; W_attention_weights]
+//
+// Both are K = 256 GEMMs whose cost is reading and writing the rows (99 MB per layer at configs[1]); the two library
+// GEMMs ran at ~2 TB/s (22 + 28 us). Here a workgroup (4 wavefronts) owns 64 rows: x and xp are staged once as MFMA
+// A-fragment images in LDS, every wave computes a 64-row x 64-column block of `value` and a 64 x 96 block of `offs` as
+// 2 x 2 / 2 x 3 MFMA tiles with the packed weights streamed L2 -> registers (4 k-steps ahead, pinned by scheduling
+// barriers as in encoder_ffn.hip), and writes bf16 straight from the accumulators. The weights are packed by
+// cgg_encoder_proj_pack with the output columns of a wave's NT n-tiles interleaved in pairs (tile t, lane column j <-> output
+// column 2 NT (j / 2) + 2 t + (j & 1) of the wave's block): lanes j, j ^ 1 swap one value per register pair, after which a lane
+// holds 2 NT ADJACENT output columns of one row and stores them as one 8- / 12-byte word -- the 16 lanes of a row write one
+// contiguous 128- / 192-byte run. (Plain column order gave 4-byte stores in 64-byte runs and cost 10 of 34 us.)
+// v_mfma_f32_32x32x16_bf16, f32 accumulation, bias added in f32.
+//
+// build-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+#include "cgg_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t ep_u32x4;
+typedef __attribute__((ext_vector_type(2))) float ep_f2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ep_bf2;
+
+#define EP_C 256
+#define EP_STEPS 16
+#define EP_RB 64
+#define EP_PF 4
+
+__device__ __forceinline__ uint32_t ep_pk(float a, float b) {            // v_cvt_pk_bf16_f32
+  const ep_f2 pr = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, ep_bf2));
+}
+
+// acc[2][NT] += A (two 32-row m-tiles, fragment images in LDS at a0 / a1) x B (NT consecutive n-tiles of the packed weight,
+// b = lane pointer to k-step 0 of the first; n-tiles are EP_STEPS * 64 fragments apart)
+template <int NT>
+__device__ __forceinline__ void ep_block(f32x16 (&acc)[2][NT], const ep_u32x4* __restrict__ a0, const ep_u32x4* __restrict__ a1,
+                                         int lane, const ep_u32x4* __restrict__ b) {
+  ep_u32x4 q[NT][EP_PF];
+#pragma unroll
+  for (int s = 0; s < EP_PF; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) q[t][s] = b[(t * EP_STEPS + s) * 64];
+  ep_u32x4 ua0 = a0[lane], ua1 = a1[lane];                      // k-step 0: lane ^ 0
+#pragma unroll
+  for (int s = 0; s < EP_STEPS; ++s) {
+    bf16x8 vb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) vb[t] = __builtin_bit_cast(bf16x8, q[t][s % EP_PF]);
+    const bf16x8 va0 = __builtin_bit_cast(bf16x8, ua0), va1 = __builtin_bit_cast(bf16x8, ua1);
+    if (s + 1 < EP_STEPS) {
+      ua0 = a0[(s + 1) * 64 + (lane ^ (s + 1))];               // bank swizzle of the image, see the staging loop
+      ua1 = a1[(s + 1) * 64 + (lane ^ (s + 1))];
+    }
+    if (s + EP_PF < EP_STEPS) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) q[t][s % EP_PF] = b[(t * EP_STEPS + s + EP_PF) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, vb[t], acc[0][t], 0, 0, 0);
+      acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, vb[t], acc[1][t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+struct ep_u32x3 { uint32_t a, b, c; };
+
+// output column (within the wave's 32 NT-column block) that tile t, lane column j computes
+__host__ __device__ __forceinline__ int ep_col(int NT, int t, int j) { return 2 * NT * (j >> 1) + 2 * t + (j & 1); }
+
+// bf16(acc + bias) -> out rows m0 .. m0 + 63, the wave's columns col0 .. col0 + 32 NT - 1 (ldo = row stride in elements)
+template <int NT>
+__device__ __forceinline__ void ep_store(const f32x16 (&acc)[2][NT], const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                         int ldo, int col0, int m0, int M, int lane) {
+  const int j = lane & 31, hi5 = lane >> 5, odd = j & 1;
+  const uint32_t rot = 16u * (uint32_t)odd;
+  float bs[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bs[t] = bias[col0 + ep_col(NT, t, j)];
+  uint16_t* ocol = out + col0 + 2 * NT * (j >> 1);                 // both lanes of a pair: the same 2 NT columns, rows r / r + 1
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+      uint32_t pk[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float v0 = acc[mt][t][2 * rp] + bs[t], v1 = acc[mt][t][2 * rp + 1] + bs[t];
+        const float kept = odd ? v1 : v0, sent = odd ? v0 : v1;
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sent), 0xB1, 0xf, 0xf, true));  // lane ^ 1
+        // even lane: row(2 rp), columns (even, odd) = (kept, recv); odd lane: row(2 rp + 1), (recv, kept)
+        const uint32_t w = ep_pk(kept, recv);
+        pk[t] = __builtin_amdgcn_alignbit(w, w, rot);
+      }
+      const int row = 32 * mt + 2 * (rp & 1) + 8 * (rp >> 1) + 4 * hi5 + odd;
+      if (m0 + row < M) {
+        uint16_t* o = ocol + (size_t)(m0 + row) * ldo;
+        if constexpr (NT == 2) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+        else *reinterpret_cast<ep_u32x3*>(o) = ep_u32x3{pk[0], pk[1], pk[2]};
+      }
+    }
+  }
+}
+
+// weight (N x 256) f32 -> bf16 MFMA-B fragments with the column interleave above: N = 4 waves x NT tiles x 32
+__global__ __launch_bounds__(256) void cgg_encoder_proj_pack_kernel(const float* __restrict__ w, ep_u32x4* __restrict__ out, int NT,
+                                                                   int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int lane = i & 63, t_all = i >> 6;
+  const int ks = t_all % EP_STEPS, tile = t_all / EP_STEPS;
+  const int wave = tile / NT, t = tile % NT;
+  const int n = wave * 32 * NT + ep_col(NT, t, lane & 31);
+  const float* s = w + (size_t)n * EP_C + ks * 16 + 8 * (lane >> 5);
+  out[i] = ep_u32x4{ep_pk(s[0], s[1]), ep_pk(s[2], s[3]), ep_pk(s[4], s[5]), ep_pk(s[6], s[7])};
+}
+
+__global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
+    const uint16_t* __restrict__ x16, const uint16_t* __restrict__ xp16, const ep_u32x4* __restrict__ wv,
+    const float* __restrict__ bv, const ep_u32x4* __restrict__ wc, const float* __restrict__ bc, uint16_t* __restrict__ value,
+    uint16_t* __restrict__ offs, int M) {
+  __shared__ __attribute__((aligned(16))) ep_u32x4 frag[2][2 * EP_STEPS * 64];      // x and xp images: 2 x 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * EP_RB;
+  // rows -> A-fragment images: 16-byte piece (row, k8) = 8 channels -> slot (row / 32, k-step = k8 / 2, (row % 32 + 32 (k8 & 1)) ^
+  // k-step). The XOR spreads the 32 pieces of a row (one coalesced 512-byte read) over all 16 four-bank groups; unswizzled
+  // they share one group and every 128-bit LDS store is a 32-way bank conflict. All 16 loads of a thread are in flight at once.
+  // (Requesting the xp rows late, to overlap them with the value block, does not help: vmcnt retires in order, so the first
+  // wait on a weight fragment also waits for the older row loads.)
+  {
+    ep_u32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = tid + 256 * i, which = p >> 11, row = (p >> 5) & 63, k8 = p & 31;
+      v[i] = ep_u32x4{0u, 0u, 0u, 0u};
+      if (m0 + row < M) v[i] = *reinterpret_cast<const ep_u32x4*>((which ? xp16 : x16) + (size_t)(m0 + row) * EP_C + 8 * k8);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = tid + 256 * i, which = p >> 11, row = (p >> 5) & 63, k8 = p & 31;
+      frag[which][((row >> 5) * EP_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v[i];
+    }
+  }
+  __syncthreads();
+  {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    ep_block<2>(acc, frag[0], frag[0] + EP_STEPS * 64, lane, wv + (size_t)(2 * wave) * EP_STEPS * 64 + lane);
+    ep_store<2>(acc, bv, value, 256, 64 * wave, m0, M, lane);
+  }
+  {
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    ep_block<3>(acc, frag[1], frag[1] + EP_STEPS * 64, lane, wc + (size_t)(3 * wave) * EP_STEPS * 64 + lane);
+    ep_store<3>(acc, bc, offs, 384, 96 * wave, m0, M, lane);
+  }
+}
+
+extern "C" int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream) {
+  CGG_REQUIRE(w && packed, CGG_EINVAL, "cgg_encoder_proj_pack: null pointer");
+  CGG_REQUIRE(K == EP_C && (N == 256 || N == 384), CGG_EUNSUPPORTED, "cgg_encoder_proj_pack: N=%d K=%d (256 or 384 x 256)", N, K);
+  const int total = (N / 32) * EP_STEPS * 64;
+  hipLaunchKernelGGL(cgg_encoder_proj_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                     (ep_u32x4*)packed, N / 128, total);
+  CGG_CHECK_LAUNCH("cgg_encoder_proj_pack");
+  return CGG_OK;
+}
+
+extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* wv_packed, const float* bv,
+                                     const void* wc_packed, const float* bc, void* value, void* offs, int M, int C, int NV,
+                                     int NC, cgg_stream_t stream) {
+  CGG_REQUIRE(x16 && xp16 && wv_packed && bv && wc_packed && bc && value && offs, CGG_EINVAL,
+              "cgg_encoder_proj_bf16: null pointer");
+  CGG_REQUIRE(C == EP_C && NV == 256 && NC == 384, CGG_EUNSUPPORTED,
+              "cgg_encoder_proj_bf16: C=%d NV=%d NC=%d (built for 256 -> 256 + 384: 8 heads x 4 levels x 4 points)", C, NV, NC);
+  CGG_REQUIRE(M > 0, CGG_EINVAL, "cgg_encoder_proj_bf16: M=%d", M);
+  CGG_REQUIRE(cgg_aligned16(x16) && cgg_aligned16(xp16) && cgg_aligned16(wv_packed) && cgg_aligned16(wc_packed) &&
+                  cgg_aligned16(value) && cgg_aligned16(offs),
+              CGG_EALIGN, "cgg_encoder_proj_bf16: 16-B alignment");
+  hipLaunchKernelGGL(cgg_encoder_proj_kernel, dim3((M + EP_RB - 1) / EP_RB), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x16, (const uint16_t*)xp16, (const ep_u32x4*)wv_packed, bv, (const ep_u32x4*)wc_packed, bc,
+                     (uint16_t*)value, (uint16_t*)offs, M);
+  CGG_CHECK_LAUNCH("cgg_encoder_proj_bf16");
+  return CGG_OK;
+}

@@ -630,6 +630,31 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
     return y32, y16, yp16
 
 
+def pack_encoder_proj_weight(weight):
+    """weight (256 | 384, 256) f32 -> packed bf16 operand of `encoder_proj` (uint8 tensor)."""
+    N, K = weight.shape
+    out = torch.empty((_lib_().cgg_linear_rows_packed_bytes(N, K),), dtype=torch.uint8, device=weight.device)
+    w = weight.detach().float().contiguous()
+    check(_lib_().cgg_encoder_proj_pack(dev_ptr(w, 'weight', torch.float32), dev_ptr(out), N, K, stream_ptr(weight.device)),
+          'cgg_encoder_proj_pack')
+    return out
+
+
+def encoder_proj(x16, xp16, wvp, bv, wcp, bc):
+    """value = x16 Wv^T + bv (..., 256) and offs = xp16 Wc^T + bc (..., 384), both bf16, in ONE launch over the bf16 rows
+    (weights from `pack_encoder_proj_weight`, biases f32)."""
+    C = x16.shape[-1]
+    M = x16.numel() // C
+    value = torch.empty(x16.shape[:-1] + (bv.numel(),), dtype=torch.bfloat16, device=x16.device)
+    offs = torch.empty(x16.shape[:-1] + (bc.numel(),), dtype=torch.bfloat16, device=x16.device)
+    rc = _lib_().cgg_encoder_proj_bf16(
+        dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(xp16, 'xp16', torch.bfloat16), dev_ptr(wvp),
+        dev_ptr(bv, 'bv', torch.float32), dev_ptr(wcp), dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M, C,
+        bv.numel(), bc.numel(), stream_ptr(x16.device))
+    check(rc, 'cgg_encoder_proj_bf16')
+    return value, offs
+
+
 def encoder_ffn_ln(x16, w1p, b1, w2p, b2, gamma, beta, eps=1e-5, pos=None, want_f32=False, want_bf16=True, want_pos=False):
     """LN(x + W2 relu(W1 x + b1) + b2) on (..., 256) bf16 rows in ONE launch (hidden activation stays on chip); w1p / w2p
     from `pack_linear_weight`. Returns (y f32 | None, bf16(y) | None, bf16(y + pos[row % len(pos)]) | None)."""

@@ -28,6 +28,7 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
 # throughput mode: encoder FFN + residual LayerNorm as one HIP launch (ops.encoder_ffn_ln); CGG_FUSED_FFN=0 restores the
 # two library GEMMs + LayerNorm pass for A/B measurements
 FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
+FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'   # value_proj + offsets/weights GEMMs as one HIP launch
 
 
 # ------------------------------------------------------------------------------------------------
@@ -552,8 +553,19 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                            lambda: torch.cat([so.weight, aw.weight], 0).to(bf).contiguous())
             b_cat = runtime.derived_cached('msda_bcat', (so.bias, aw.bias),
                                            lambda: torch.cat([so.bias, aw.bias], 0).to(bf).contiguous())
-            value = F.linear(x16, cc(attn.value_proj.weight), cc(attn.value_proj.bias)).view(B, N, H, D)
-            offs = F.linear(xp16, w_cat, b_cat)
+            if FUSED_PROJ and C == 256 and w_cat.shape[0] == 384:
+                # value_proj + [sampling_offsets; attention_weights] as one launch over the bf16 rows
+                vp = attn.value_proj
+                wvp = runtime.derived_cached('msda_wvp', (vp.weight,), lambda: ops.pack_encoder_proj_weight(vp.weight))
+                wcp = runtime.derived_cached('msda_wcp', (so.weight, aw.weight),
+                                             lambda: ops.pack_encoder_proj_weight(torch.cat([so.weight, aw.weight], 0)))
+                bcf = runtime.derived_cached('msda_bcf', (so.bias, aw.bias),
+                                             lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
+                value, offs = ops.encoder_proj(x16, xp16, wvp, vp.bias, wcp, bcf)
+                value = value.view(B, N, H, D)
+            else:
+                value = F.linear(x16, cc(attn.value_proj.weight), cc(attn.value_proj.bias)).view(B, N, H, D)
+                offs = F.linear(xp16, w_cat, b_cat)
             a16 = ops.msda_forward_fused_bf16(value, level_hw, level_start, offs, ref, attn.num_points)
             o16 = F.linear(a16, cc(attn.output_proj.weight), cc(attn.output_proj.bias))
             n0, n1 = layer.norms

@@ -356,6 +356,15 @@ int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype,
                          const float* pos, int pos_rows, float* y32, void* y16, void* yp16, int rows, int N,
                          float eps, cgg_stream_t stream);
 
+/* Input projections of one MSDeformAttn encoder layer as ONE launch ([3P] MultiScaleDeformableAttention.forward:
+ * value_proj / sampling_offsets / attention_weights; layers built at open_set/models/mask2former_head.py:112-117):
+ *   value (M, 256) bf16 = x16 Wv^T + bv,   offs (M, 384) bf16 = xp16 Wc^T + bc   (Wc = [W_offsets; W_attention_weights]),
+ * x16 / xp16 (M, 256) bf16 rows, biases f32; weights (N x 256 f32, N = 256 / 384) packed once by cgg_encoder_proj_pack
+ * (bf16 MFMA-B fragments, cgg_linear_rows_packed_bytes(N, 256) bytes, output columns interleaved for wide stores). */
+int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream);
+int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* wv_packed, const float* bv, const void* wc_packed,
+                          const float* bc, void* value, void* offs, int M, int C, int NV, int NC, cgg_stream_t stream);
+
 /* Encoder-stream FFN block of the pixel decoder as ONE launch ([3P] BaseTransformerLayer 'ffn' + 'norm' of the
  * MSDeformAttn encoder layers built at open_set/models/mask2former_head.py:112-117):
  *   y = LayerNorm(x + W2 relu(W1 x + b1) + b2);  x16 (M, 256) bf16 rows, w1 (F x 256) / w2 (256 x F) packed by

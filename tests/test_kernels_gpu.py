@@ -1185,3 +1185,29 @@ def test_encoder_ffn_ln_kv_variant_matches_two_pass_path(dev):
     want_m = torch.cat([m[:, s:s + h * w].reshape(-1, C) for s, (h, w) in zip(starts, shapes)], 0).bfloat16()
     want_z = torch.cat([z[:, s:s + h * w].reshape(-1, C) for s, (h, w) in zip(starts, shapes)], 0).bfloat16()
     assert torch.equal(m16, want_m) and torch.equal(mp16, want_z)
+
+
+@pytest.mark.parametrize('M', [43008, 4071, 37])
+def test_encoder_proj_fused_vs_float64(dev, M):
+    """value_proj + [sampling_offsets; attention_weights] projections as one launch against float64 on the same bf16-rounded
+    operands: bf16 outputs, so the bound is half a bf16 ulp of the value (|v| < 4 -> 2^-7; offsets reach |o| < 8 -> 2^-6)
+    plus f32 accumulation noise; the column-interleaved weight packing is transparent (outputs in natural column order);
+    ragged M; two runs bit-identical."""
+    g = torch.Generator().manual_seed(M)
+    C = 256
+    x16 = torch.randn(M, C, generator=g).to(dev).bfloat16()
+    xp16 = torch.randn(M, C, generator=g).to(dev).bfloat16()
+    wv = (torch.randn(256, C, generator=g) * 0.05).to(dev)
+    bv = (torch.randn(256, generator=g) * 0.1).to(dev)
+    wc = (torch.randn(384, C, generator=g) * 0.05).to(dev)
+    bc = torch.randn(384, generator=g).to(dev)
+    wvp, wcp = ops.pack_encoder_proj_weight(wv), ops.pack_encoder_proj_weight(wc)
+    v, o = ops.encoder_proj(x16, xp16, wvp, bv, wcp, bc)
+    v2, o2 = ops.encoder_proj(x16, xp16, wvp, bv, wcp, bc)
+    torch.cuda.synchronize()
+    assert torch.equal(v, v2) and torch.equal(o, o2)
+    assert v.shape == (M, 256) and o.shape == (M, 384)
+    rv = x16.double() @ wv.bfloat16().double().t() + bv.double()
+    ro = xp16.double() @ wc.bfloat16().double().t() + bc.double()
+    assert ((v.double() - rv).abs() / rv.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4    # relative half ulp
+    assert ((o.double() - ro).abs() / ro.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4
