@@ -99,12 +99,18 @@ __device__ __forceinline__ void ef_block(f32x16 (&acc)[2][2], const ef_u32x4* __
 // yp16 = bf16(y + shift[s] + pos[s]) written LEVEL-MAJOR (row B * start_l + b * hw_l + (s - start_l)); y32 stays row m.
 struct EfLevels { int n; int start[9]; };
 
-template <bool KV>
+// PRO = true: the block starts one step earlier, at the attention output projection and its residual LayerNorm
+// ('self_attn' tail + first 'norm' of the layer): x1 = LN0(x + a Wo^T + bo) is computed in the workgroup from the attention
+// rows a16 (GEMM K = N = 256 on the same row image / weight-stream machinery, f32 tile, row LayerNorm with the layer-input rows
+// x16 as residual) and written straight into the row image as bf16 -- x1 never exists in memory.
+struct EfPro { const uint16_t* a16; const ef_u32x4* wo; const float* bo; const float* gamma0; const float* beta0; float eps0; };
+
+template <bool KV, bool PRO>
 __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     const uint16_t* __restrict__ x16, const ef_u32x4* __restrict__ w1, const float* __restrict__ b1,
     const ef_u32x4* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ pos, int pos_rows, uint16_t* __restrict__ y16,
-    uint16_t* __restrict__ yp16, float* __restrict__ y32, int M, int F, const float* __restrict__ shift, EfLevels lv) {
+    uint16_t* __restrict__ yp16, float* __restrict__ y32, int M, int F, const float* __restrict__ shift, EfLevels lv, EfPro pro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ef_smem[];
   ef_u32x4* xfrag = reinterpret_cast<ef_u32x4*>(ef_smem);                     // [4 m-tiles][16][64]   64 KiB
   ef_u32x4* hfrag = xfrag + (EF_RB / 32) * EF_STEPS * 64;                                // [4 m-tiles][16][64]   64 KiB
@@ -116,22 +122,101 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
   const int nchunk = F >> 8;
   const int KS2 = F >> 4;                                                     // k-steps of W2
 
-  // weight stream: the first EF_PF k-steps of GEMM 1 / chunk 0 are in flight while the rows are staged
+  // weight stream: the first EF_PF k-steps of the first GEMM block are in flight while the rows are staged
+  const ef_u32x4* wfirst = PRO ? pro.wo : w1;
   ef_u32x4 q0[EF_PF], q1[EF_PF];
 #pragma unroll
   for (int s = 0; s < EF_PF; ++s) {
-    q0[s] = w1[((size_t)(2 * wn) * EF_STEPS + s) * 64 + lane];
-    q1[s] = w1[((size_t)(2 * wn + 1) * EF_STEPS + s) * 64 + lane];
+    q0[s] = wfirst[((size_t)(2 * wn) * EF_STEPS + s) * 64 + lane];
+    q1[s] = wfirst[((size_t)(2 * wn + 1) * EF_STEPS + s) * 64 + lane];
   }
   // ---- rows -> A-fragment images: 16-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k-step = k8 / 2, (row % 32 +
   //      32 (k8 & 1)) ^ k-step). The XOR spreads the 32 pieces of a row (one coalesced 512-byte read) over all 16 four-bank
   //      groups -- unswizzled, every 128-bit store was a 32-way bank conflict.
+  const uint16_t* rows_in = PRO ? pro.a16 : x16;
 #pragma unroll 4
   for (int p = tid; p < EF_RB * 32; p += EF_NT) {
     const int row = p >> 5, k8 = p & 31;
     ef_u32x4 v = {0u, 0u, 0u, 0u};
-    if (m0 + row < M) v = *reinterpret_cast<const ef_u32x4*>(x16 + (size_t)(m0 + row) * EF_C + 8 * k8);
+    if (m0 + row < M) v = *reinterpret_cast<const ef_u32x4*>(rows_in + (size_t)(m0 + row) * EF_C + 8 * k8);
     xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v;
+  }
+  if constexpr (PRO) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    __syncthreads();
+    const ef_u32x4* xb = xfrag + (2 * wm) * (EF_STEPS * 64);
+    ef_block<true>(acc, xb, xb, xb, xb, lane, q0, q1, pro.wo + ((size_t)(2 * wn) * EF_STEPS) * 64 + lane,
+                   pro.wo + ((size_t)(2 * wn + 1) * EF_STEPS) * 64 + lane, w1 + ((size_t)(2 * wn) * EF_STEPS) * 64 + lane,
+                   w1 + ((size_t)(2 * wn + 1) * EF_STEPS) * 64 + lane);
+    __syncthreads();                                   // every wave is done with the attention-row image
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = 64 * wn + 32 * nt + j;
+      const float bias = pro.bo[col];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tile[(64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi5) * EF_TS + col] = acc[mt][nt][r] + bias;
+    }
+    __syncthreads();
+    // LayerNorm 0 over x + attn_out, 16 lanes per row as in the final pass; the bf16 result waits in registers until the tile
+    // (which overlaps the row image) has been read by everyone
+    const int sub = lane & 15, rsub = lane >> 4;
+    uint2 xs[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = 16 * wave + 4 * it + rsub;
+      const int mc = m0 + row < M ? m0 + row : M - 1;
+      f32x4 v[4];
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = *reinterpret_cast<const f32x4*>(&tile[row * EF_TS + 4 * sub + 64 * k]);
+        const uint2 xr = *reinterpret_cast<const uint2*>(x16 + (size_t)mc * EF_C + 4 * sub + 64 * k);
+        v[k][0] += __uint_as_float(xr.x << 16);
+        v[k][1] += __uint_as_float(xr.x & 0xffff0000u);
+        v[k][2] += __uint_as_float(xr.y << 16);
+        v[k][3] += __uint_as_float(xr.y & 0xffff0000u);
+        sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+      }
+      sm = ef_row16_sum(sm);
+      const float mean = sm * (1.f / (float)EF_C);
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = v[k] - mean;
+        q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+      }
+      q = ef_row16_sum(q);
+      const float rstd = rsqrtf(q * (1.f / (float)EF_C) + pro.eps0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(pro.gamma0 + 4 * sub + 64 * k);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(pro.beta0 + 4 * sub + 64 * k);
+        const f32x4 y = v[k] * rstd * g + be;
+        xs[it][k] = make_uint2(ef_pk(y[0], y[1]), ef_pk(y[2], y[3]));
+      }
+    }
+    __syncthreads();
+    // x1 -> row image: columns c0 = 4 sub + 64 k .. + 3 of a row are half of the 16-byte slot (k-step c0 / 16, half (c0 / 8) & 1)
+    uint2* xf2 = reinterpret_cast<uint2*>(xfrag);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = 16 * wave + 4 * it + rsub;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ks = (sub >> 2) + 4 * k;
+        const int slot = ((row >> 5) * EF_STEPS + ks) * 64 + (((row & 31) + 32 * ((sub >> 1) & 1)) ^ ks);
+        xf2[2 * slot + (sub & 1)] = xs[it][k];
+      }
+    }
   }
   f32x16 acc2[2][2];
 #pragma unroll
@@ -305,9 +390,9 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
   }
 }
 
-static int ef_launch(bool kv, const void* x16, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
-                     const float* gamma, const float* beta, float eps, const float* pos, int pos_rows, void* y16, void* yp16,
-                     float* y32, int M, int C, int F, const float* shift, const EfLevels& lv, cgg_stream_t stream,
+static int ef_launch(bool kv, const EfPro* prop, const void* x16, const void* w1_packed, const float* b1, const void* w2_packed,
+                     const float* b2, const float* gamma, const float* beta, float eps, const float* pos, int pos_rows, void* y16,
+                     void* yp16, float* y32, int M, int C, int F, const float* shift, const EfLevels& lv, cgg_stream_t stream,
                      const char* who) {
   CGG_REQUIRE(x16 && w1_packed && b1 && w2_packed && b2 && gamma && beta && (y16 || y32), CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(C == EF_C, CGG_EUNSUPPORTED, "%s: C=%d (only 256 is built)", who, C);
@@ -317,26 +402,48 @@ static int ef_launch(bool kv, const void* x16, const void* w1_packed, const floa
                   cgg_aligned16(beta) && (!pos || cgg_aligned16(pos)) && (!y16 || cgg_aligned16(y16)) &&
                   (!yp16 || cgg_aligned16(yp16)) && (!y32 || cgg_aligned16(y32)) && (!shift || cgg_aligned16(shift)),
               CGG_EALIGN, "%s: 16-B alignment", who);
+  EfPro pro = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
+  if (prop) {
+    pro = *prop;
+    CGG_REQUIRE(pro.a16 && pro.wo && pro.bo && pro.gamma0 && pro.beta0, CGG_EINVAL, "%s: null pointer (attention tail)", who);
+    CGG_REQUIRE(cgg_aligned16(pro.a16) && cgg_aligned16(pro.wo) && cgg_aligned16(pro.gamma0) && cgg_aligned16(pro.beta0),
+                CGG_EALIGN, "%s: 16-B alignment (attention tail)", who);
+  }
   const size_t lds = (size_t)EF_RB * EF_TS * sizeof(float);          // >= the two fragment images (64 KiB)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_ffn_ln_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)cgg_encoder_ffn_ln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    CGG_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise dynamic LDS to %zu", who, lds);
+    const void* fns[4] = {(const void*)cgg_encoder_ffn_ln_kernel<false, false>, (const void*)cgg_encoder_ffn_ln_kernel<true, false>,
+                          (const void*)cgg_encoder_ffn_ln_kernel<false, true>, (const void*)cgg_encoder_ffn_ln_kernel<true, true>};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      CGG_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise dynamic LDS to %zu", who, lds);
+    }
     attr_set = true;
   }
   const dim3 grid((M + EF_RB - 1) / EF_RB), block(EF_NT);
-  if (kv)
-    hipLaunchKernelGGL(cgg_encoder_ffn_ln_kernel<true>, grid, block, lds, (hipStream_t)stream, (const uint16_t*)x16,
-                       (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos, pos_rows,
-                       (uint16_t*)y16, (uint16_t*)yp16, y32, M, F, shift, lv);
-  else
-    hipLaunchKernelGGL(cgg_encoder_ffn_ln_kernel<false>, grid, block, lds, (hipStream_t)stream, (const uint16_t*)x16,
-                       (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos, pos_rows,
-                       (uint16_t*)y16, (uint16_t*)yp16, y32, M, F, shift, lv);
+#define EF_LAUNCH(KV, PRO)                                                                                                    \
+  hipLaunchKernelGGL((cgg_encoder_ffn_ln_kernel<KV, PRO>), grid, block, lds, (hipStream_t)stream, (const uint16_t*)x16,       \
+                     (const ef_u32x4*)w1_packed, b1, (const ef_u32x4*)w2_packed, b2, gamma, beta, eps, pos, pos_rows,          \
+                     (uint16_t*)y16, (uint16_t*)yp16, y32, M, F, shift, lv, pro)
+  if (kv && prop) EF_LAUNCH(true, true);
+  else if (kv) EF_LAUNCH(true, false);
+  else if (prop) EF_LAUNCH(false, true);
+  else EF_LAUNCH(false, false);
+#undef EF_LAUNCH
+  return CGG_OK;
+}
+
+static int ef_levels(EfLevels& lv, const int* level_start_host, int n_levels, int M, int S, const char* who) {
+  CGG_REQUIRE(level_start_host, CGG_EINVAL, "%s: null pointer", who);
+  CGG_REQUIRE(M > 0 && S > 0 && M % S == 0, CGG_EINVAL, "%s: M=%d not a multiple of S=%d", who, M, S);
+  CGG_REQUIRE(n_levels >= 1 && n_levels <= 8, CGG_EUNSUPPORTED, "%s: n_levels=%d (1..8)", who, n_levels);
+  lv.n = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    lv.start[l] = level_start_host[l];
+    CGG_REQUIRE(lv.start[l] >= 0 && lv.start[l] < S && (l == 0 ? lv.start[l] == 0 : lv.start[l] > lv.start[l - 1]), CGG_EINVAL,
+                "%s: level_start must start at 0 and increase (level %d: %d)", who, l, lv.start[l]);
+  }
+  lv.start[n_levels] = S;
   return CGG_OK;
 }
 
@@ -346,8 +453,8 @@ extern "C" int cgg_encoder_ffn_ln_bf16(const void* x16, const void* w1_packed, c
                                        cgg_stream_t stream) {
   EfLevels lv;
   lv.n = 0;
-  int rc = ef_launch(false, x16, w1_packed, b1, w2_packed, b2, gamma, beta, eps, pos, pos_rows, y16, yp16, y32, M, C, F, nullptr,
-                     lv, stream, "cgg_encoder_ffn_ln_bf16");
+  int rc = ef_launch(false, nullptr, x16, w1_packed, b1, w2_packed, b2, gamma, beta, eps, pos, pos_rows, y16, yp16, y32, M, C, F,
+                     nullptr, lv, stream, "cgg_encoder_ffn_ln_bf16");
   if (rc != CGG_OK) return rc;
   CGG_CHECK_LAUNCH("cgg_encoder_ffn_ln_bf16");
   return CGG_OK;
@@ -358,20 +465,34 @@ extern "C" int cgg_encoder_ffn_ln_kv_bf16(const void* x16, const void* w1_packed
                                           const float* shift, const float* pos, int S, const int* level_start_host,
                                           int n_levels, float* y32, void* m16, void* mp16, int M, int C, int F,
                                           cgg_stream_t stream) {
-  CGG_REQUIRE(shift && pos && m16 && mp16 && level_start_host, CGG_EINVAL, "cgg_encoder_ffn_ln_kv_bf16: null pointer");
-  CGG_REQUIRE(M > 0 && S > 0 && M % S == 0, CGG_EINVAL, "cgg_encoder_ffn_ln_kv_bf16: M=%d not a multiple of S=%d", M, S);
-  CGG_REQUIRE(n_levels >= 1 && n_levels <= 8, CGG_EUNSUPPORTED, "cgg_encoder_ffn_ln_kv_bf16: n_levels=%d (1..8)", n_levels);
+  CGG_REQUIRE(shift && pos && m16 && mp16, CGG_EINVAL, "cgg_encoder_ffn_ln_kv_bf16: null pointer");
   EfLevels lv;
-  lv.n = n_levels;
-  for (int l = 0; l < n_levels; ++l) {
-    lv.start[l] = level_start_host[l];
-    CGG_REQUIRE(lv.start[l] >= 0 && lv.start[l] < S && (l == 0 ? lv.start[l] == 0 : lv.start[l] > lv.start[l - 1]), CGG_EINVAL,
-                "cgg_encoder_ffn_ln_kv_bf16: level_start must start at 0 and increase (level %d: %d)", l, lv.start[l]);
-  }
-  lv.start[n_levels] = S;
-  int rc = ef_launch(true, x16, w1_packed, b1, w2_packed, b2, gamma, beta, eps, pos, S, m16, mp16, y32, M, C, F, shift, lv, stream,
-                     "cgg_encoder_ffn_ln_kv_bf16");
+  int rc = ef_levels(lv, level_start_host, n_levels, M, S, "cgg_encoder_ffn_ln_kv_bf16");
+  if (rc != CGG_OK) return rc;
+  rc = ef_launch(true, nullptr, x16, w1_packed, b1, w2_packed, b2, gamma, beta, eps, pos, S, m16, mp16, y32, M, C, F, shift, lv,
+                 stream, "cgg_encoder_ffn_ln_kv_bf16");
   if (rc != CGG_OK) return rc;
   CGG_CHECK_LAUNCH("cgg_encoder_ffn_ln_kv_bf16");
+  return CGG_OK;
+}
+
+extern "C" int cgg_encoder_layer_tail_bf16(const void* a16, const void* x16, const void* wo_packed, const float* bo,
+                                           const float* gamma0, const float* beta0, float eps0, const void* w1_packed,
+                                           const float* b1, const void* w2_packed, const float* b2, const float* gamma1,
+                                           const float* beta1, float eps1, const float* pos, int pos_rows, const float* shift,
+                                           const int* level_start_host, int n_levels, void* y16, void* yp16, float* y32, int M,
+                                           int C, int F, cgg_stream_t stream) {
+  EfLevels lv;
+  lv.n = 0;
+  if (shift) {
+    CGG_REQUIRE(pos && y16 && yp16, CGG_EINVAL, "cgg_encoder_layer_tail_bf16: null pointer (K / V mode)");
+    int rc = ef_levels(lv, level_start_host, n_levels, M, pos_rows, "cgg_encoder_layer_tail_bf16");
+    if (rc != CGG_OK) return rc;
+  }
+  const EfPro pro = {(const uint16_t*)a16, (const ef_u32x4*)wo_packed, bo, gamma0, beta0, eps0};
+  int rc = ef_launch(shift != nullptr, &pro, x16, w1_packed, b1, w2_packed, b2, gamma1, beta1, eps1, pos, pos_rows, y16, yp16, y32,
+                     M, C, F, shift, lv, stream, "cgg_encoder_layer_tail_bf16");
+  if (rc != CGG_OK) return rc;
+  CGG_CHECK_LAUNCH("cgg_encoder_layer_tail_bf16");
   return CGG_OK;
 }

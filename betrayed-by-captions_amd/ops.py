@@ -689,6 +689,38 @@ def encoder_ffn_ln_kv(x16, w1p, b1, w2p, b2, gamma, beta, eps, shift, pos, level
     return y32, m16, mp16
 
 
+def encoder_layer_tail(a16, x16, wop, bo, norm0, w1p, b1, w2p, b2, norm1, pos=None, kv=None, want_f32=False, want_bf16=True,
+                       want_pos=False):
+    """Post-attention half of an encoder layer in ONE launch: x1 = LN0(x16 + a16 Wo^T + bo), y = LN1(x1 + FFN(x1)).
+    norm0 / norm1 = (gamma, beta, eps); weights from `pack_linear_weight`. kv=None: returns (y f32 | None, bf16(y) | None,
+    bf16(y + pos[row % len(pos)]) | None) like `encoder_ffn_ln`; kv=(shift, pos, level_start) (x16 (B, S, 256)): returns
+    (y f32 | None, m16, mp16) like `encoder_ffn_ln_kv`."""
+    C = x16.shape[-1]
+    M = x16.numel() // C
+    dev = x16.device
+    y32 = torch.empty(x16.shape, dtype=torch.float32, device=dev) if want_f32 else None
+    if kv is not None:
+        shift, pos, level_start = kv
+        S = x16.shape[-2]
+        y16 = torch.empty((M, C), dtype=torch.bfloat16, device=dev)
+        yp16 = torch.empty((M, C), dtype=torch.bfloat16, device=dev)
+        pos_rows, ls, nl = S, _int_array(level_start), len(level_start)
+    else:
+        shift, ls, nl = None, None, 0
+        y16 = torch.empty(x16.shape, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+        yp16 = torch.empty(x16.shape, dtype=torch.bfloat16, device=dev) if want_pos else None
+        pos_rows = pos.shape[0] if pos is not None else 0
+    rc = _lib_().cgg_encoder_layer_tail_bf16(
+        dev_ptr(a16, 'a16', torch.bfloat16), dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(wop),
+        dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32), dev_ptr(norm0[1], 'beta0', torch.float32),
+        float(norm0[2]), dev_ptr(w1p), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2p), dev_ptr(b2, 'b2', torch.float32),
+        dev_ptr(norm1[0], 'gamma1', torch.float32), dev_ptr(norm1[1], 'beta1', torch.float32), float(norm1[2]),
+        dev_ptr(pos, 'pos', torch.float32), pos_rows, dev_ptr(shift, 'shift', torch.float32), ls, nl, dev_ptr(y16), dev_ptr(yp16),
+        dev_ptr(y32), M, C, b1.numel(), stream_ptr(dev))
+    check(rc, 'cgg_encoder_layer_tail_bf16')
+    return y32, y16, yp16
+
+
 def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=True):
     """Last encoder LayerNorm of the inference stream: y = LN(a + b) (a (B, S, 256) f32, b f32|bf16|None) plus the
     query decoder's K / V operands m16 = bf16(y + shift[s]), mp16 = bf16(y + shift[s] + pos[s]) (shift, pos (S, 256)

@@ -28,6 +28,7 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
 # throughput mode: encoder FFN + residual LayerNorm as one HIP launch (ops.encoder_ffn_ln); CGG_FUSED_FFN=0 restores the
 # two library GEMMs + LayerNorm pass for A/B measurements
 FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
+FUSED_TAIL = os.environ.get('CGG_FUSED_TAIL', '1') != '0'   # ... preceded by output_proj + its residual LayerNorm
 FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'   # value_proj + offsets/weights GEMMs as one HIP launch
 
 
@@ -567,18 +568,35 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 value = F.linear(x16, cc(attn.value_proj.weight), cc(attn.value_proj.bias)).view(B, N, H, D)
                 offs = F.linear(xp16, w_cat, b_cat)
             a16 = ops.msda_forward_fused_bf16(value, level_hw, level_start, offs, ref, attn.num_points)
-            o16 = F.linear(a16, cc(attn.output_proj.weight), cc(attn.output_proj.bias))
             n0, n1 = layer.norms
+            ffn = layer.ffns[0]
+            last = li == n_layers - 1
+            fused_ffn = (self.stream_residual_bf16 and FUSED_FFN and ffn.layers[0][0].out_features % 256 == 0
+                         and (not last or kv_tables is not None))
+            if fused_ffn and FUSED_TAIL and C == 256:
+                # output_proj + residual LayerNorm + FFN + residual LayerNorm as ONE launch: neither the projection output, nor
+                # the first LayerNorm's rows, nor the (B, N, 1024) hidden activation reach memory
+                op, fc1, fc2 = attn.output_proj, ffn.layers[0][0], ffn.layers[1]
+                wop = runtime.derived_cached('msda_wop', (op.weight,), lambda: ops.pack_linear_weight(op.weight))
+                w1p = runtime.derived_cached('ffn_w1p', (fc1.weight,), lambda: ops.pack_linear_weight(fc1.weight))
+                w2p = runtime.derived_cached('ffn_w2p', (fc2.weight,), lambda: ops.pack_linear_weight(fc2.weight))
+                norm0, norm1 = (n0.weight, n0.bias, n0.eps), (n1.weight, n1.bias, n1.eps)
+                if last:
+                    src, m16, mp16 = ops.encoder_layer_tail(a16, x16, wop, op.bias, norm0, w1p, fc1.bias, w2p, fc2.bias, norm1,
+                                                            kv=(kv_tables[0], kv_tables[1], level_start), want_f32=True)
+                    return src, (m16, mp16)
+                _, x16, xp16 = ops.encoder_layer_tail(a16, x16, wop, op.bias, norm0, w1p, fc1.bias, w2p, fc2.bias, norm1,
+                                                      pos=pos, want_bf16=True, want_pos=True)
+                src = x16
+                continue
+            o16 = F.linear(a16, cc(attn.output_proj.weight), cc(attn.output_proj.bias))
             if self.stream_residual_bf16:
                 # residual stream in bf16: the LayerNorm reads the same bf16 rows the GEMMs read (66 instead of 132 MB)
                 _, x16, _ = ops.add_layernorm_stream(x16, o16, n0.weight, n0.bias, n0.eps, want_f32=False)
                 src = x16
             else:
                 src, x16, _ = ops.add_layernorm_stream(src, o16, n0.weight, n0.bias, n0.eps)
-            ffn = layer.ffns[0]
-            last = li == n_layers - 1
-            if (self.stream_residual_bf16 and FUSED_FFN and ffn.layers[0][0].out_features % 256 == 0
-                    and (not last or kv_tables is not None)):
+            if fused_ffn:
                 # FFN + residual LayerNorm as one launch: the (B, N, 1024) hidden activation stays on chip
                 fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
                 w1p = runtime.derived_cached('ffn_w1p', (fc1.weight,), lambda: ops.pack_linear_weight(fc1.weight))

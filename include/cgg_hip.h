@@ -380,6 +380,18 @@ int cgg_encoder_ffn_ln_kv_bf16(const void* x16, const void* w1_packed, const flo
                                const float* b2, const float* gamma, const float* beta, float eps, const float* shift,
                                const float* pos, int S, const int* level_start_host, int n_levels, float* y32, void* m16,
                                void* mp16, int M, int C, int F, cgg_stream_t stream);
+/* The whole post-attention half of an encoder layer as ONE launch ('self_attn' output projection + 'norm' + 'ffn' + 'norm' of
+ * the [3P] BaseTransformerLayer, open_set/models/mask2former_head.py:112-117):
+ *   x1 = LayerNorm0(x + a Wo^T + bo);   y = LayerNorm1(x1 + W2 relu(W1 x1 + b1) + b2)
+ * a16 = attention rows (MSDeformAttn output before output_proj), x16 = layer input rows, both (M, 256) bf16; wo / w1 / w2 packed by
+ * cgg_linear_rows_pack. x1 and the hidden activation never reach memory. Outputs as cgg_encoder_ffn_ln_bf16 (shift == NULL:
+ * y16 / yp16 / y32, pos nullable) or as cgg_encoder_ffn_ln_kv_bf16 (shift != NULL: pos_rows = S, y16 = m16, yp16 = mp16,
+ * level-major, level_start_host[n_levels]). */
+int cgg_encoder_layer_tail_bf16(const void* a16, const void* x16, const void* wo_packed, const float* bo, const float* gamma0,
+                                const float* beta0, float eps0, const void* w1_packed, const float* b1, const void* w2_packed,
+                                const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                                int pos_rows, const float* shift, const int* level_start_host, int n_levels, void* y16,
+                                void* yp16, float* y32, int M, int C, int F, cgg_stream_t stream);
 
 /* Last encoder layer of the stream: y = LN(a + b) as above (y32 nullable) plus the two bf16 operands of the query
  * decoder's K / V projections (mask2former_head.py:795-812), written LEVEL-MAJOR -- [level][batch][hw_l][256], level l =
