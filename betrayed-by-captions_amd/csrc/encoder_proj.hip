@@ -3,12 +3,13 @@
 // as ONE launch over the (B * N) x 256 bf16 stream:
 //
 //     value = x  Wv^T + bv            (M x 256, bf16)         x  = the layer input rows
-//     offs  = xp Wc^T + bc            (M x 384, bf16)         xp = x + pos rows,  Wc = [W_offsets; W_attention_weights]
+//     offs  = xp Wc^T + bc            (M x NC, bf16)          xp = x + pos rows,  Wc = [W_offsets; W_attention_weights],
+//                                                             NC = 3 * heads * levels * points: 288 (3 levels) or 384 (4)
 //
 // Both are K = 256 GEMMs whose cost is reading and writing the rows (99 MB per layer at configs[1]); the two library
 // GEMMs ran at ~2 TB/s (22 + 28 us). Here a workgroup (4 wavefronts) owns 64 rows: x and xp are staged once as MFMA
-// A-fragment images in LDS, every wave computes a 64-row x 64-column block of `value` and a 64 x 96 block of `offs` as
-// 2 x 2 / 2 x 3 MFMA tiles with the packed weights streamed L2 -> registers (4 k-steps ahead, pinned by scheduling
+// A-fragment images in LDS, every wave computes a 64-row x 64-column block of `value` and a 64 x 64 or 64 x 96 block of `offs`
+// (NC / 32 = 9 .. 12 n-tiles dealt 2 or 3 per wave, the larger blocks last) as 2 x 2 / 2 x 3 MFMA tiles with the packed weights streamed L2 -> registers (4 k-steps ahead, pinned by scheduling
 // barriers as in encoder_ffn.hip), and writes bf16 straight from the accumulators. The weights are packed by
 // cgg_encoder_proj_pack with the output columns of a wave's NT n-tiles interleaved in pairs (tile t, lane column j <-> output
 // column 2 NT (j / 2) + 2 t + (j & 1) of the wave's block): lanes j, j ^ 1 swap one value per register pair, after which a lane
@@ -107,15 +108,24 @@ __device__ __forceinline__ void ep_store(const f32x16 (&acc)[2][NT], const float
   }
 }
 
-// weight (N x 256) f32 -> bf16 MFMA-B fragments with the column interleave above: N = 4 waves x NT tiles x 32
-__global__ __launch_bounds__(256) void cgg_encoder_proj_pack_kernel(const float* __restrict__ w, ep_u32x4* __restrict__ out, int NT,
+// N / 32 n-tiles dealt to the 4 waves: `base` each, the last `extra` waves one more (N = 256: 2 2 2 2; 288: 2 2 2 3; 384: 3 3 3 3)
+__host__ __device__ __forceinline__ int ep_wave_nt(int ntiles, int w) { return ntiles / 4 + (w >= 4 - ntiles % 4 ? 1 : 0); }
+__host__ __device__ __forceinline__ int ep_wave_tile0(int ntiles, int w) {
+  const int first_big = 4 - ntiles % 4;
+  return w * (ntiles / 4) + (w > first_big ? w - first_big : 0);
+}
+
+// weight (N x 256) f32 -> bf16 MFMA-B fragments with the column interleave above inside every wave's block
+__global__ __launch_bounds__(256) void cgg_encoder_proj_pack_kernel(const float* __restrict__ w, ep_u32x4* __restrict__ out, int ntiles,
                                                                    int total) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int lane = i & 63, t_all = i >> 6;
   const int ks = t_all % EP_STEPS, tile = t_all / EP_STEPS;
-  const int wave = tile / NT, t = tile % NT;
-  const int n = wave * 32 * NT + ep_col(NT, t, lane & 31);
+  int wave = 3;
+  while (wave > 0 && ep_wave_tile0(ntiles, wave) > tile) --wave;
+  const int NT = ep_wave_nt(ntiles, wave), tile0 = ep_wave_tile0(ntiles, wave);
+  const int n = 32 * tile0 + ep_col(NT, tile - tile0, lane & 31);
   const float* s = w + (size_t)n * EP_C + ks * 16 + 8 * (lane >> 5);
   out[i] = ep_u32x4{ep_pk(s[0], s[1]), ep_pk(s[2], s[3]), ep_pk(s[4], s[5]), ep_pk(s[6], s[7])};
 }
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_pack_kernel(const float*
 __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
     const uint16_t* __restrict__ x16, const uint16_t* __restrict__ xp16, const ep_u32x4* __restrict__ wv,
     const float* __restrict__ bv, const ep_u32x4* __restrict__ wc, const float* __restrict__ bc, uint16_t* __restrict__ value,
-    uint16_t* __restrict__ offs, int M) {
+    uint16_t* __restrict__ offs, int M, int NC) {
   __shared__ __attribute__((aligned(16))) ep_u32x4 frag[2][2 * EP_STEPS * 64];      // x and xp images: 2 x 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * EP_RB;
@@ -158,7 +168,8 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
     ep_block<2>(acc, frag[0], frag[0] + EP_STEPS * 64, lane, wv + (size_t)(2 * wave) * EP_STEPS * 64 + lane);
     ep_store<2>(acc, bv, value, 256, 64 * wave, m0, M, lane);
   }
-  {
+  const int ntiles = NC >> 5, tile0 = ep_wave_tile0(ntiles, wave);
+  if (ep_wave_nt(ntiles, wave) == 3) {                 // wave-uniform
     f32x16 acc[2][3];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -166,17 +177,28 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
       for (int b = 0; b < 3; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    ep_block<3>(acc, frag[1], frag[1] + EP_STEPS * 64, lane, wc + (size_t)(3 * wave) * EP_STEPS * 64 + lane);
-    ep_store<3>(acc, bc, offs, 384, 96 * wave, m0, M, lane);
+    ep_block<3>(acc, frag[1], frag[1] + EP_STEPS * 64, lane, wc + (size_t)tile0 * EP_STEPS * 64 + lane);
+    ep_store<3>(acc, bc, offs, NC, 32 * tile0, m0, M, lane);
+  } else {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    ep_block<2>(acc, frag[1], frag[1] + EP_STEPS * 64, lane, wc + (size_t)tile0 * EP_STEPS * 64 + lane);
+    ep_store<2>(acc, bc, offs, NC, 32 * tile0, m0, M, lane);
   }
 }
 
 extern "C" int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream) {
   CGG_REQUIRE(w && packed, CGG_EINVAL, "cgg_encoder_proj_pack: null pointer");
-  CGG_REQUIRE(K == EP_C && (N == 256 || N == 384), CGG_EUNSUPPORTED, "cgg_encoder_proj_pack: N=%d K=%d (256 or 384 x 256)", N, K);
+  CGG_REQUIRE(K == EP_C && N % 32 == 0 && N >= 256 && N <= 384, CGG_EUNSUPPORTED,
+              "cgg_encoder_proj_pack: N=%d K=%d (N = 256 .. 384 in steps of 32, K = 256)", N, K);
   const int total = (N / 32) * EP_STEPS * 64;
   hipLaunchKernelGGL(cgg_encoder_proj_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
-                     (ep_u32x4*)packed, N / 128, total);
+                     (ep_u32x4*)packed, N / 32, total);
   CGG_CHECK_LAUNCH("cgg_encoder_proj_pack");
   return CGG_OK;
 }
@@ -186,15 +208,15 @@ extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const vo
                                      int NC, cgg_stream_t stream) {
   CGG_REQUIRE(x16 && xp16 && wv_packed && bv && wc_packed && bc && value && offs, CGG_EINVAL,
               "cgg_encoder_proj_bf16: null pointer");
-  CGG_REQUIRE(C == EP_C && NV == 256 && NC == 384, CGG_EUNSUPPORTED,
-              "cgg_encoder_proj_bf16: C=%d NV=%d NC=%d (built for 256 -> 256 + 384: 8 heads x 4 levels x 4 points)", C, NV, NC);
+  CGG_REQUIRE(C == EP_C && NV == 256 && NC % 32 == 0 && NC >= 256 && NC <= 384, CGG_EUNSUPPORTED,
+              "cgg_encoder_proj_bf16: C=%d NV=%d NC=%d (built for 256 -> 256 + 256 .. 384 in steps of 32)", C, NV, NC);
   CGG_REQUIRE(M > 0, CGG_EINVAL, "cgg_encoder_proj_bf16: M=%d", M);
   CGG_REQUIRE(cgg_aligned16(x16) && cgg_aligned16(xp16) && cgg_aligned16(wv_packed) && cgg_aligned16(wc_packed) &&
                   cgg_aligned16(value) && cgg_aligned16(offs),
               CGG_EALIGN, "cgg_encoder_proj_bf16: 16-B alignment");
   hipLaunchKernelGGL(cgg_encoder_proj_kernel, dim3((M + EP_RB - 1) / EP_RB), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)x16, (const uint16_t*)xp16, (const ep_u32x4*)wv_packed, bv, (const ep_u32x4*)wc_packed, bc,
-                     (uint16_t*)value, (uint16_t*)offs, M);
+                     (uint16_t*)value, (uint16_t*)offs, M, NC);
   CGG_CHECK_LAUNCH("cgg_encoder_proj_bf16");
   return CGG_OK;
 }

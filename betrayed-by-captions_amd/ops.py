@@ -631,7 +631,7 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
 
 
 def pack_encoder_proj_weight(weight):
-    """weight (256 | 384, 256) f32 -> packed bf16 operand of `encoder_proj` (uint8 tensor)."""
+    """weight (256 .. 384 in steps of 32, 256) f32 -> packed bf16 operand of `encoder_proj` (uint8 tensor)."""
     N, K = weight.shape
     out = torch.empty((_lib_().cgg_linear_rows_packed_bytes(N, K),), dtype=torch.uint8, device=weight.device)
     w = weight.detach().float().contiguous()
@@ -641,7 +641,7 @@ def pack_encoder_proj_weight(weight):
 
 
 def encoder_proj(x16, xp16, wvp, bv, wcp, bc):
-    """value = x16 Wv^T + bv (..., 256) and offs = xp16 Wc^T + bc (..., 384), both bf16, in ONE launch over the bf16 rows
+    """value = x16 Wv^T + bv (..., 256) and offs = xp16 Wc^T + bc (..., NC), both bf16, in ONE launch over the bf16 rows
     (weights from `pack_encoder_proj_weight`, biases f32)."""
     C = x16.shape[-1]
     M = x16.numel() // C

@@ -554,7 +554,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                            lambda: torch.cat([so.weight, aw.weight], 0).to(bf).contiguous())
             b_cat = runtime.derived_cached('msda_bcat', (so.bias, aw.bias),
                                            lambda: torch.cat([so.bias, aw.bias], 0).to(bf).contiguous())
-            if FUSED_PROJ and C == 256 and w_cat.shape[0] == 384:
+            if FUSED_PROJ and C == 256 and w_cat.shape[0] % 32 == 0 and 256 <= w_cat.shape[0] <= 384:
                 # value_proj + [sampling_offsets; attention_weights] as one launch over the bf16 rows
                 vp = attn.value_proj
                 wvp = runtime.derived_cached('msda_wvp', (vp.weight,), lambda: ops.pack_encoder_proj_weight(vp.weight))

@@ -9,7 +9,7 @@ for M in (43008, 1000):
     C = 256
     x16 = torch.randn(M, C, device=dev).bfloat16(); xp16 = torch.randn(M, C, device=dev).bfloat16()
     wv = torch.randn(256, C, device=dev) * 0.06; bv = torch.randn(256, device=dev) * 0.1
-    wc = torch.randn(384, C, device=dev) * 0.06; bc = torch.randn(384, device=dev)
+    wc = torch.randn(288, C, device=dev) * 0.06; bc = torch.randn(288, device=dev)
     wvp, wcp = ops.pack_encoder_proj_weight(wv), ops.pack_encoder_proj_weight(wc)
     wvb, wcb, bvb, bcb = wv.bfloat16(), wc.bfloat16(), bv.bfloat16(), bc.bfloat16()
     lib = lambda: (F.linear(x16, wvb, bvb), F.linear(xp16, wcb, bcb))

@@ -1187,8 +1187,8 @@ def test_encoder_ffn_ln_kv_variant_matches_two_pass_path(dev):
     assert torch.equal(m16, want_m) and torch.equal(mp16, want_z)
 
 
-@pytest.mark.parametrize('M', [43008, 4071, 37])
-def test_encoder_proj_fused_vs_float64(dev, M):
+@pytest.mark.parametrize('M,NC', [(43008, 288), (4071, 384), (37, 288), (300, 320), (129, 256)])
+def test_encoder_proj_fused_vs_float64(dev, M, NC):
     """value_proj + [sampling_offsets; attention_weights] projections as one launch against float64 on the same bf16-rounded
     operands: bf16 outputs, so the bound is half a bf16 ulp of the value (|v| < 4 -> 2^-7; offsets reach |o| < 8 -> 2^-6)
     plus f32 accumulation noise; the column-interleaved weight packing is transparent (outputs in natural column order);
@@ -1199,14 +1199,14 @@ def test_encoder_proj_fused_vs_float64(dev, M):
     xp16 = torch.randn(M, C, generator=g).to(dev).bfloat16()
     wv = (torch.randn(256, C, generator=g) * 0.05).to(dev)
     bv = (torch.randn(256, generator=g) * 0.1).to(dev)
-    wc = (torch.randn(384, C, generator=g) * 0.05).to(dev)
-    bc = torch.randn(384, generator=g).to(dev)
+    wc = (torch.randn(NC, C, generator=g) * 0.05).to(dev)
+    bc = torch.randn(NC, generator=g).to(dev)
     wvp, wcp = ops.pack_encoder_proj_weight(wv), ops.pack_encoder_proj_weight(wc)
     v, o = ops.encoder_proj(x16, xp16, wvp, bv, wcp, bc)
     v2, o2 = ops.encoder_proj(x16, xp16, wvp, bv, wcp, bc)
     torch.cuda.synchronize()
     assert torch.equal(v, v2) and torch.equal(o, o2)
-    assert v.shape == (M, 256) and o.shape == (M, 384)
+    assert v.shape == (M, 256) and o.shape == (M, NC)
     rv = x16.double() @ wv.bfloat16().double().t() + bv.double()
     ro = xp16.double() @ wc.bfloat16().double().t() + bc.double()
     assert ((v.double() - rv).abs() / rv.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4    # relative half ulp
