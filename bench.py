@@ -147,14 +147,15 @@ def rocprof_launch_mean(kernel):
 
 def host_results_rate(args, model, img, metas, dev):
     """images/sec of the same step when the results must reach the HOST in the evaluation format: the
-    two-stage pipeline with bit-packed masks, ONE asynchronous device->host copy per result tensor into pinned staging
+    staged pipeline (same stage split as the headline run) with bit-packed masks, ONE asynchronous device->host copy per result tensor into pinned staging
     buffers, COCO RLE on the extension's host threads overlapped with the next batch (host_results.RleCollector).
     PCIe-inclusive; never `value`. Also reports the mean number of runs per mask (encoder cost is per run: the
     random-weight masks of this benchmark are far noisier than a trained model's)."""
     from cgg_amd.host_results import RleCollector, fusion_class_counts
     from cgg_amd.pipeline import detector_pipeline
-    pipe = detector_pipeline(model, img, metas, stages=2, defer_tail=args.defer_tail, rescale=True, device_results=True,
-                             mask_bits=True)
+    nstage = min(max(args.pipeline, 2), 3)
+    pipe = detector_pipeline(model, img, metas, stages=nstage, defer_tail=args.defer_tail, rescale=True,
+                             device_results=True, mask_bits=True)
     col = RleCollector(dev, fusion_class_counts(model.panoptic_fusion_head))
     steps = max(args.steps, 8)
 
@@ -183,7 +184,7 @@ def host_results_rate(args, model, img, metas, dev):
     nbytes = sum(len(r['counts']) for r in rles)
     return dict(value=len(res) / dt, unit='images/sec (this rank, results on the host as COCO RLE)', steps=steps,
                 masks_per_image=len(rles) / max(len(res), 1), rle_bytes_per_mask=nbytes / max(len(rles), 1),
-                how='2-stage pipeline, bit-packed masks, pinned async D2H, C++ RLE on host threads overlapped with the next batch')
+                how=f'{nstage}-stage pipeline, bit-packed masks, pinned async D2H, C++ RLE on host threads overlapped with the next batch')
 
 
 def parity_mode_rate(args, model, img, metas, dev):
@@ -319,9 +320,9 @@ def main():
     ap.add_argument('--graph', type=int, default=1,
                     help='1: capture the step once and replay it from a hipGraph (default; the eager step is '
                          'host-bound at ~530 launches); 0: eager launches')
-    ap.add_argument('--defer-tail', type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument('--defer-tail', type=int, default=0, choices=[0, 1, 2],
                     help='pipeline stage balancing: K/V projections + mask-feature packing run in the decode stage')
-    ap.add_argument('--pipeline', type=int, default=2, choices=[0, 2, 3, 4],
+    ap.add_argument('--pipeline', type=int, default=3, choices=[0, 2, 3, 4, 5],
                     help='(with --graph 1) software pipeline across steps, one HIP stream + hipGraph per stage: '
                          '3 = backbone | pixel decoder + K/V | query decoder + post-processing, 2 = the first two '
                          'merged, 0 = one graph per step replayed back to back')
@@ -399,7 +400,7 @@ def main():
             pipe.flush()
             torch.cuda.synchronize()
         except Exception as e:
-            print(f'bench.py: two-stage pipeline setup failed ({type(e).__name__}: {e}); falling back to one graph '
+            print(f'bench.py: stage pipeline setup failed ({type(e).__name__}: {e}); falling back to one graph '
                   'per step', file=sys.stderr)
             pipe = None
             args.pipeline = 0
@@ -512,6 +513,33 @@ def main():
         extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9,
                              frac_hbm_peak=mbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              rocprof=rocprof_launch_mean('cgg_msda_fwd_stream_kernel'))
+
+    if events.get('encoder_tail'):
+        # post-attention half of an encoder layer (output_proj + LN + FFN + LN) as one launch: MFMA-bound.
+        # flops = 2 M (256*256 + 2 * 256*1024); algorithmic bytes = attention rows + layer input rows in, y and y + pos rows
+        # out (bf16) + the f32 pos table once per image set.
+        ms = [s.elapsed_time(e) for s, e in events['encoder_tail']]
+        ms = sum(ms) / len(ms)
+        N = sum((H // s) * (W // s) for s in (8, 16, 32))
+        M = B * N
+        fl = 2.0 * M * (256 * 256 + 2 * 256 * 1024)
+        tb = M * 256 * 2 * 4 + N * 256 * 4
+        extra['encoder_tail'] = dict(kernel='cgg_encoder_ffn_ln_kernel<false, true>', bound='mfma', launch_ms=ms,
+                                     launches_timed=len(events['encoder_tail']), flops=fl,
+                                     achieved_TFs=fl / (ms * 1e-3) / 1e12, peak_TFs=MFMA_BF16_PEAK_TF,
+                                     frac_mfma_bf16_peak=fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, algorithmic_bytes=tb,
+                                     achieved_GBs=tb / (ms * 1e-3) / 1e9,
+                                     replaces='2 library GEMM pairs + 2 LayerNorm passes: 396 MB of HBM traffic per layer -> 110 MB',
+                                     rocprof=rocprof_launch_mean('cgg_encoder_ffn_ln_kernel<false, true>'))
+    if events.get('encoder_proj'):
+        ms = [s.elapsed_time(e) for s, e in events['encoder_proj']]
+        ms = sum(ms) / len(ms)
+        N = sum((H // s) * (W // s) for s in (8, 16, 32))
+        pb = B * N * (256 + 256 + 256 + 288) * 2
+        extra['encoder_proj'] = dict(kernel='cgg_encoder_proj_kernel', bound='hbm', launch_ms=ms,
+                                     launches_timed=len(events['encoder_proj']), algorithmic_bytes=pb,
+                                     achieved_GBs=pb / (ms * 1e-3) / 1e9, frac_hbm_peak=pb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     rocprof=rocprof_launch_mean('cgg_encoder_proj_kernel'))
 
     parity = None
     pipelined = pipe is not None

@@ -647,10 +647,11 @@ def encoder_proj(x16, xp16, wvp, bv, wcp, bc):
     M = x16.numel() // C
     value = torch.empty(x16.shape[:-1] + (bv.numel(),), dtype=torch.bfloat16, device=x16.device)
     offs = torch.empty(x16.shape[:-1] + (bc.numel(),), dtype=torch.bfloat16, device=x16.device)
-    rc = _lib_().cgg_encoder_proj_bf16(
-        dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(xp16, 'xp16', torch.bfloat16), dev_ptr(wvp),
-        dev_ptr(bv, 'bv', torch.float32), dev_ptr(wcp), dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M, C,
-        bv.numel(), bc.numel(), stream_ptr(x16.device))
+    with _timed('encoder_proj'):
+        rc = _lib_().cgg_encoder_proj_bf16(
+            dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(xp16, 'xp16', torch.bfloat16), dev_ptr(wvp),
+            dev_ptr(bv, 'bv', torch.float32), dev_ptr(wcp), dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M,
+            C, bv.numel(), bc.numel(), stream_ptr(x16.device))
     check(rc, 'cgg_encoder_proj_bf16')
     return value, offs
 
@@ -710,13 +711,15 @@ def encoder_layer_tail(a16, x16, wop, bo, norm0, w1p, b1, w2p, b2, norm1, pos=No
         y16 = torch.empty(x16.shape, dtype=torch.bfloat16, device=dev) if want_bf16 else None
         yp16 = torch.empty(x16.shape, dtype=torch.bfloat16, device=dev) if want_pos else None
         pos_rows = pos.shape[0] if pos is not None else 0
-    rc = _lib_().cgg_encoder_layer_tail_bf16(
-        dev_ptr(a16, 'a16', torch.bfloat16), dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(wop),
-        dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32), dev_ptr(norm0[1], 'beta0', torch.float32),
-        float(norm0[2]), dev_ptr(w1p), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2p), dev_ptr(b2, 'b2', torch.float32),
-        dev_ptr(norm1[0], 'gamma1', torch.float32), dev_ptr(norm1[1], 'beta1', torch.float32), float(norm1[2]),
-        dev_ptr(pos, 'pos', torch.float32), pos_rows, dev_ptr(shift, 'shift', torch.float32), ls, nl, dev_ptr(y16), dev_ptr(yp16),
-        dev_ptr(y32), M, C, b1.numel(), stream_ptr(dev))
+    with _timed('encoder_tail_kv' if kv is not None else 'encoder_tail'):
+        rc = _lib_().cgg_encoder_layer_tail_bf16(
+            dev_ptr(a16, 'a16', torch.bfloat16), dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(wop),
+            dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32),
+            dev_ptr(norm0[1], 'beta0', torch.float32), float(norm0[2]), dev_ptr(w1p), dev_ptr(b1, 'b1', torch.float32),
+            dev_ptr(w2p), dev_ptr(b2, 'b2', torch.float32), dev_ptr(norm1[0], 'gamma1', torch.float32),
+            dev_ptr(norm1[1], 'beta1', torch.float32), float(norm1[2]), dev_ptr(pos, 'pos', torch.float32), pos_rows,
+            dev_ptr(shift, 'shift', torch.float32), ls, nl, dev_ptr(y16), dev_ptr(yp16), dev_ptr(y32), M, C, b1.numel(),
+            stream_ptr(dev))
     check(rc, 'cgg_encoder_layer_tail_bf16')
     return y32, y16, yp16
 

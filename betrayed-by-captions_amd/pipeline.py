@@ -119,8 +119,12 @@ def detector_pipeline(model, example, metas, stages=3, defer_tail=True, **decode
         fns = [lambda x: model.stage_encode(x, defer_tail=defer_tail),
                lambda enc: model.stage_head(enc, metas, **decode_kwargs),
                lambda out: model.stage_post(out, metas, **decode_kwargs)]
+    elif stages == 5:      # backbone | pixel decoder | query decoder | post-processing (device results only)
+        fns = [model.extract_feat, lambda f: head._encode(f, defer_tail=defer_tail),
+               lambda enc: model.stage_head(enc, metas, **decode_kwargs),
+               lambda out: model.stage_post(out, metas, **decode_kwargs)]
     else:
-        raise ValueError('stages must be 2, 3 or 4')
+        raise ValueError('stages must be 2, 3, 4 or 5')
     return StagePipeline(fns, example)
 
 

@@ -25,10 +25,14 @@ python scratch/kernel_bench.py > $O/kernel_bench.json 2>> $O/bench_line.err
 python scratch/xattn_bwd_bench.py > $O/xattn_bwd_bench.txt 2>> $O/bench_line.err
 python scratch/ml_bwd_bench.py > $O/ml_bwd_bench.txt 2>> $O/bench_line.err
 python scratch/msda_ab.py > $O/msda_ab.txt 2>> $O/bench_line.err
+python scratch/ffn_bench.py > $O/encoder_ffn_bench.txt 2>> $O/bench_line.err
+python scratch/proj_bench.py > $O/encoder_proj_bench.txt 2>> $O/bench_line.err
 python scratch/serve_bench.py 128 2>> $O/bench_line.err | grep images > $O/serve_bench.txt
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/train_prof -- python3 $R/bench.py --mode train --steps 3 --warmup 2 > /dev/null 2>&1
 python3 $R/scratch/train_step_prof.py /tmp/train_prof > $O/train_top.txt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/stepprof -- python3 $R/bench.py --graph 0 --pipeline 0 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --host-results 0 > /dev/null 2>&1
+python3 $R/scratch/step_kernels.py /tmp/stepprof > $O/step_kernels.txt
 cd $R
 ls -la $O
 tail -c 400 $O/bench_line.json

@@ -35,3 +35,26 @@ for name, fn in (('lib', lib), ('fused', fused)):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(50): fn()
     torch.cuda.synchronize(); print(name, (time.perf_counter() - t) / 50 * 1e6, 'us')
+
+# ---- the whole layer tail: output_proj + LayerNorm + FFN + LayerNorm ----
+a16 = torch.randn(M, C, device=dev).bfloat16()
+wo = torch.randn(C, C, device=dev) * 0.06; bo = torch.randn(C, device=dev) * 0.1
+wop, wob, bob = ops.pack_linear_weight(wo), wo.bfloat16(), bo.bfloat16()
+
+def lib_tail():
+    o = F.linear(a16, wob, bob)
+    _, x1, _ = ops.add_layernorm_stream(x16, o, g, be, 1e-5, want_f32=False)
+    h = torch._addmm_activation(b1b, x1, w1b.t())
+    f = F.linear(h, w2b, b2b)
+    return ops.add_layernorm_stream(x1, f, g, be, 1e-5, pos=pos, want_f32=False, want_bf16=True, want_pos=True)
+
+def fused_tail():
+    return ops.encoder_layer_tail(a16, x16, wop, bo, (g, be, 1e-5), w1p, b1, w2p, b2, (g, be, 1e-5), pos=pos, want_pos=True)
+
+_, yl, _ = lib_tail(); _, yf, _ = fused_tail(); torch.cuda.synchronize()
+print('layer tail: |fused - library path| max', (yl.float() - yf.float()).abs().max().item())
+for name, fn in (('lib_tail (3 GEMMs + 2 LayerNorm passes)', lib_tail), ('fused_tail (one launch)', fused_tail)):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(50): fn()
+    torch.cuda.synchronize(); print(name, (time.perf_counter() - t) / 50 * 1e6, 'us')

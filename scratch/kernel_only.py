@@ -29,4 +29,19 @@ raw16 = raw.to(torch.bfloat16)
 for _ in range(20):      # the encoder-stream variant the bench runs: bf16 value / offsets / output
     ops.msda_forward_fused_bf16(v, shapes, starts, raw16, ref, 4)
 torch.cuda.synchronize()
+# encoder layer tail (output_proj + LN + FFN + LN) and input projections at the same shapes
+M = B * N
+mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dev)
+a16, x16, xp16 = mk(M, 256).bfloat16(), mk(M, 256).bfloat16(), mk(M, 256).bfloat16()
+wo, w1, w2 = ops.pack_linear_weight(mk(256, 256, sc=0.05)), ops.pack_linear_weight(mk(1024, 256, sc=0.05)), \
+    ops.pack_linear_weight(mk(256, 1024, sc=0.03))
+bo, b1, b2, g0, g1, be = mk(256, sc=0.1), mk(1024, sc=0.1), mk(256, sc=0.1), mk(256, sc=0.1) + 1, mk(256, sc=0.1) + 1, mk(256, sc=0.1)
+pos = mk(N, 256)
+for _ in range(20):
+    ops.encoder_layer_tail(a16, x16, wo, bo, (g0, be, 1e-5), w1, b1, w2, b2, (g1, be, 1e-5), pos=pos, want_pos=True)
+torch.cuda.synchronize()
+wv, wc = ops.pack_encoder_proj_weight(mk(256, 256, sc=0.05)), ops.pack_encoder_proj_weight(mk(288, 256, sc=0.05))
+for _ in range(20):
+    ops.encoder_proj(x16, xp16, wv, bo, wc, mk(288))
+torch.cuda.synchronize()
 print('done')
