@@ -3,7 +3,8 @@
 // as ONE launch over the (B * N) x 256 bf16 stream:
 //
 //     value = x  Wv^T + bv            (M x 256, bf16)         x  = the layer input rows
-//     offs  = xp Wc^T + bc            (M x NC, bf16)          xp = x + pos rows,  Wc = [W_offsets; W_attention_weights],
+//     offs  = xp Wc^T + bc            (M x NC, bf16)          xp = x + pos rows (given, or formed here from a bf16 pos
+//                                                             table: xp16 == NULL),  Wc = [W_offsets; W_attention_weights],
 //                                                             NC = 3 * heads * levels * points: 288 (3 levels) or 384 (4)
 //
 // Both are K = 256 GEMMs whose cost is reading and writing the rows (99 MB per layer at configs[1]); the two library
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_pack_kernel(const float*
 __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
     const uint16_t* __restrict__ x16, const uint16_t* __restrict__ xp16, const ep_u32x4* __restrict__ wv,
     const float* __restrict__ bv, const ep_u32x4* __restrict__ wc, const float* __restrict__ bc, uint16_t* __restrict__ value,
-    uint16_t* __restrict__ offs, int M, int NC) {
+    uint16_t* __restrict__ offs, int M, int NC, const uint16_t* __restrict__ pos16, int pos_rows) {
   __shared__ __attribute__((aligned(16))) ep_u32x4 frag[2][2 * EP_STEPS * 64];      // x and xp images: 2 x 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * EP_RB;
@@ -148,7 +149,19 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
     for (int i = 0; i < 16; ++i) {
       const int p = tid + 256 * i, which = p >> 11, row = (p >> 5) & 63, k8 = p & 31;
       v[i] = ep_u32x4{0u, 0u, 0u, 0u};
-      if (m0 + row < M) v[i] = *reinterpret_cast<const ep_u32x4*>((which ? xp16 : x16) + (size_t)(m0 + row) * EP_C + 8 * k8);
+      if (m0 + row < M) {
+        if (which && xp16 == nullptr) {
+          // xp = bf16(x + pos) from the bf16 rows and the bf16 pos table: the (M, 256) `x + pos` rows are never stored
+          const ep_u32x4 a = *reinterpret_cast<const ep_u32x4*>(x16 + (size_t)(m0 + row) * EP_C + 8 * k8);
+          const ep_u32x4 b = *reinterpret_cast<const ep_u32x4*>(pos16 + (size_t)((m0 + row) % pos_rows) * EP_C + 8 * k8);
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            v[i][d] = ep_pk(__uint_as_float(a[d] << 16) + __uint_as_float(b[d] << 16),
+                            __uint_as_float(a[d] & 0xffff0000u) + __uint_as_float(b[d] & 0xffff0000u));
+        } else {
+          v[i] = *reinterpret_cast<const ep_u32x4*>((which ? xp16 : x16) + (size_t)(m0 + row) * EP_C + 8 * k8);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -203,20 +216,20 @@ extern "C" int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K,
   return CGG_OK;
 }
 
-extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* wv_packed, const float* bv,
-                                     const void* wc_packed, const float* bc, void* value, void* offs, int M, int C, int NV,
-                                     int NC, cgg_stream_t stream) {
-  CGG_REQUIRE(x16 && xp16 && wv_packed && bv && wc_packed && bc && value && offs, CGG_EINVAL,
-              "cgg_encoder_proj_bf16: null pointer");
+extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* pos16, int pos_rows, const void* wv_packed,
+                                     const float* bv, const void* wc_packed, const float* bc, void* value, void* offs, int M,
+                                     int C, int NV, int NC, cgg_stream_t stream) {
+  CGG_REQUIRE(x16 && wv_packed && bv && wc_packed && bc && value && offs, CGG_EINVAL, "cgg_encoder_proj_bf16: null pointer");
+  CGG_REQUIRE(xp16 || (pos16 && pos_rows > 0), CGG_EINVAL, "cgg_encoder_proj_bf16: either xp16 or a pos16 table is required");
   CGG_REQUIRE(C == EP_C && NV == 256 && NC % 32 == 0 && NC >= 256 && NC <= 384, CGG_EUNSUPPORTED,
               "cgg_encoder_proj_bf16: C=%d NV=%d NC=%d (built for 256 -> 256 + 256 .. 384 in steps of 32)", C, NV, NC);
   CGG_REQUIRE(M > 0, CGG_EINVAL, "cgg_encoder_proj_bf16: M=%d", M);
-  CGG_REQUIRE(cgg_aligned16(x16) && cgg_aligned16(xp16) && cgg_aligned16(wv_packed) && cgg_aligned16(wc_packed) &&
+  CGG_REQUIRE(cgg_aligned16(x16) && (!xp16 || cgg_aligned16(xp16)) && (!pos16 || cgg_aligned16(pos16)) && cgg_aligned16(wv_packed) && cgg_aligned16(wc_packed) &&
                   cgg_aligned16(value) && cgg_aligned16(offs),
               CGG_EALIGN, "cgg_encoder_proj_bf16: 16-B alignment");
   hipLaunchKernelGGL(cgg_encoder_proj_kernel, dim3((M + EP_RB - 1) / EP_RB), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)x16, (const uint16_t*)xp16, (const ep_u32x4*)wv_packed, bv, (const ep_u32x4*)wc_packed, bc,
-                     (uint16_t*)value, (uint16_t*)offs, M, NC);
+                     (uint16_t*)value, (uint16_t*)offs, M, NC, (const uint16_t*)pos16, pos_rows);
   CGG_CHECK_LAUNCH("cgg_encoder_proj_bf16");
   return CGG_OK;
 }

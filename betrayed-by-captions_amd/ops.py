@@ -640,18 +640,20 @@ def pack_encoder_proj_weight(weight):
     return out
 
 
-def encoder_proj(x16, xp16, wvp, bv, wcp, bc):
+def encoder_proj(x16, xp16, wvp, bv, wcp, bc, pos16=None):
     """value = x16 Wv^T + bv (..., 256) and offs = xp16 Wc^T + bc (..., NC), both bf16, in ONE launch over the bf16 rows
-    (weights from `pack_encoder_proj_weight`, biases f32)."""
+    (weights from `pack_encoder_proj_weight`, biases f32). xp16=None: xp = bf16(x16 + pos16[row % len(pos16)]) is formed
+    inside the kernel from the bf16 table pos16."""
     C = x16.shape[-1]
     M = x16.numel() // C
     value = torch.empty(x16.shape[:-1] + (bv.numel(),), dtype=torch.bfloat16, device=x16.device)
     offs = torch.empty(x16.shape[:-1] + (bc.numel(),), dtype=torch.bfloat16, device=x16.device)
     with _timed('encoder_proj'):
         rc = _lib_().cgg_encoder_proj_bf16(
-            dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(xp16, 'xp16', torch.bfloat16), dev_ptr(wvp),
-            dev_ptr(bv, 'bv', torch.float32), dev_ptr(wcp), dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M,
-            C, bv.numel(), bc.numel(), stream_ptr(x16.device))
+            dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(xp16, 'xp16', torch.bfloat16), dev_ptr(pos16, 'pos16', torch.bfloat16),
+            pos16.shape[0] if pos16 is not None else 0, dev_ptr(wvp), dev_ptr(bv, 'bv', torch.float32), dev_ptr(wcp),
+            dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M, C, bv.numel(), bc.numel(),
+            stream_ptr(x16.device))
     check(rc, 'cgg_encoder_proj_bf16')
     return value, offs
 

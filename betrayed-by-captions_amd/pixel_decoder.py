@@ -29,7 +29,8 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
 # two library GEMMs + LayerNorm pass for A/B measurements
 FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
 FUSED_TAIL = os.environ.get('CGG_FUSED_TAIL', '1') != '0'   # ... preceded by output_proj + its residual LayerNorm
-FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'   # value_proj + offsets/weights GEMMs as one HIP launch
+FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
+POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
 
 
 # ------------------------------------------------------------------------------------------------
@@ -546,6 +547,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
             xp16 = (src + pos[None]).to(bf)
         B, N, C = src.shape
         n_layers = len(self.encoder.layers)
+
+        def _nc(layer):
+            a = layer.attentions[0]
+            return a.sampling_offsets.out_features + a.attention_weights.out_features
+        proj_ok = FUSED_PROJ and C == 256 and all(_nc(l) % 32 == 0 and 256 <= _nc(l) <= 384 for l in self.encoder.layers)
+        # with the projection kernel forming `x + pos` itself (bf16 pos table), the layer tails stop writing those rows
+        pos16 = runtime.derived_cached('enc_pos16', (pos,), lambda: pos.to(bf).contiguous()) if proj_ok and POS_IN_PROJ else None
         for li, layer in enumerate(self.encoder.layers):
             attn = layer.attentions[0]
             H, D = attn.num_heads, C // attn.num_heads
@@ -554,7 +562,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                            lambda: torch.cat([so.weight, aw.weight], 0).to(bf).contiguous())
             b_cat = runtime.derived_cached('msda_bcat', (so.bias, aw.bias),
                                            lambda: torch.cat([so.bias, aw.bias], 0).to(bf).contiguous())
-            if FUSED_PROJ and C == 256 and w_cat.shape[0] % 32 == 0 and 256 <= w_cat.shape[0] <= 384:
+            if proj_ok:
                 # value_proj + [sampling_offsets; attention_weights] as one launch over the bf16 rows
                 vp = attn.value_proj
                 wvp = runtime.derived_cached('msda_wvp', (vp.weight,), lambda: ops.pack_encoder_proj_weight(vp.weight))
@@ -562,7 +570,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                              lambda: ops.pack_encoder_proj_weight(torch.cat([so.weight, aw.weight], 0)))
                 bcf = runtime.derived_cached('msda_bcf', (so.bias, aw.bias),
                                              lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
-                value, offs = ops.encoder_proj(x16, xp16, wvp, vp.bias, wcp, bcf)
+                value, offs = ops.encoder_proj(x16, xp16, wvp, vp.bias, wcp, bcf, pos16=pos16 if xp16 is None else None)
                 value = value.view(B, N, H, D)
             else:
                 value = F.linear(x16, cc(attn.value_proj.weight), cc(attn.value_proj.bias)).view(B, N, H, D)
@@ -586,7 +594,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                                             kv=(kv_tables[0], kv_tables[1], level_start), want_f32=True)
                     return src, (m16, mp16)
                 _, x16, xp16 = ops.encoder_layer_tail(a16, x16, wop, op.bias, norm0, w1p, fc1.bias, w2p, fc2.bias, norm1,
-                                                      pos=pos, want_bf16=True, want_pos=True)
+                                                      pos=pos, want_bf16=True, want_pos=pos16 is None)
                 src = x16
                 continue
             o16 = F.linear(a16, cc(attn.output_proj.weight), cc(attn.output_proj.bias))

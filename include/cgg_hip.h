@@ -360,11 +360,13 @@ int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype,
  * value_proj / sampling_offsets / attention_weights; layers built at open_set/models/mask2former_head.py:112-117):
  *   value (M, 256) bf16 = x16 Wv^T + bv,   offs (M, NC) bf16 = xp16 Wc^T + bc   (Wc = [W_offsets; W_attention_weights],
  *   NC = 3 * heads * levels * points, 256 .. 384 in steps of 32: 288 for the 3-level encoder, 384 for 4 levels),
- * x16 / xp16 (M, 256) bf16 rows, biases f32; weights (N x 256 f32, N = 256 / NC) packed once by cgg_encoder_proj_pack
+ * x16 / xp16 (M, 256) bf16 rows; xp16 == NULL: xp = bf16(x16 + pos16[row % pos_rows]) is formed in the kernel from the bf16
+ * table pos16 (pos_rows, 256) and the `x + pos` rows are never stored. Biases f32; weights (N x 256 f32, N = 256 / NC) packed once by cgg_encoder_proj_pack
  * (bf16 MFMA-B fragments, cgg_linear_rows_packed_bytes(N, 256) bytes, output columns interleaved for wide stores). */
 int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream);
-int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* wv_packed, const float* bv, const void* wc_packed,
-                          const float* bc, void* value, void* offs, int M, int C, int NV, int NC, cgg_stream_t stream);
+int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* pos16, int pos_rows, const void* wv_packed,
+                          const float* bv, const void* wc_packed, const float* bc, void* value, void* offs, int M, int C, int NV,
+                          int NC, cgg_stream_t stream);
 
 /* Encoder-stream FFN block of the pixel decoder as ONE launch ([3P] BaseTransformerLayer 'ffn' + 'norm' of the
  * MSDeformAttn encoder layers built at open_set/models/mask2former_head.py:112-117):

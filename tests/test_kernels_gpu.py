@@ -1278,3 +1278,20 @@ def test_encoder_layer_tail_kv_mode_matches_plain_mode(dev):
     want_m = torch.cat([m[:, s:s + h * w].reshape(-1, C) for s, (h, w) in zip(starts, shapes)], 0).bfloat16()
     want_z = torch.cat([z[:, s:s + h * w].reshape(-1, C) for s, (h, w) in zip(starts, shapes)], 0).bfloat16()
     assert torch.equal(m16, want_m) and torch.equal(mp16, want_z)
+
+
+def test_encoder_proj_forms_x_plus_pos_in_kernel(dev):
+    """xp16=None: the projection kernel forms bf16(x16 + pos16[row % N]) itself -- identical (bit for bit) to handing it the
+    rows computed the same way by torch (bf16 + bf16 -> f32 add -> one bf16 rounding)."""
+    g = torch.Generator().manual_seed(11)
+    M, N, C, NC = 4071, 1357, 256, 288
+    x16 = torch.randn(M, C, generator=g).to(dev).bfloat16()
+    pos16 = torch.randn(N, C, generator=g).to(dev).bfloat16()
+    wv = (torch.randn(256, C, generator=g) * 0.05).to(dev)
+    wc = (torch.randn(NC, C, generator=g) * 0.05).to(dev)
+    bv, bc = torch.randn(256, generator=g).to(dev), torch.randn(NC, generator=g).to(dev)
+    wvp, wcp = ops.pack_encoder_proj_weight(wv), ops.pack_encoder_proj_weight(wc)
+    xp16 = (x16.float() + pos16.repeat((M + N - 1) // N, 1)[:M].float()).bfloat16()
+    v_a, o_a = ops.encoder_proj(x16, xp16, wvp, bv, wcp, bc)
+    v_b, o_b = ops.encoder_proj(x16, None, wvp, bv, wcp, bc, pos16=pos16)
+    assert torch.equal(v_a, v_b) and torch.equal(o_a, o_b)
