@@ -535,23 +535,29 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 and isinstance(layer.attentions[0], MultiScaleDeformableAttention)
                 and layer.attentions[0].dropout.p == 0)
 
+    def _proj_fused(self, C):
+        """True when every encoder layer's input projections fit `ops.encoder_proj` (256 -> 256 + 256..384 columns)."""
+        def nc(layer):
+            a = layer.attentions[0]
+            return a.sampling_offsets.out_features + a.attention_weights.out_features
+        return FUSED_PROJ and C == 256 and all(nc(l) % 32 == 0 and 256 <= nc(l) <= 384 for l in self.encoder.layers)
+
     def _encoder_stream_bf16(self, src, pos, ref, level_hw, level_start, x16=None, xp16=None, kv_tables=None):
-        """Throughput-mode encoder: per layer 4 library GEMMs (bf16 in / bf16 out), the MSDeformAttn kernel
-        (bf16 values, offsets, output), one in-place ReLU and TWO fused residual-LayerNorm passes that also emit the
-        bf16 copies (`y`, `y + pos`) the next GEMMs read -- 9 launches per layer instead of ~25, and no separate
-        cast / add / `query + pos` passes over the (B, 21504, 256) stream. The residual stream itself stays f32."""
+        """Throughput-mode encoder over the (B, 21504, 256) bf16 stream, THREE launches per layer (round 2):
+        `ops.encoder_proj` (value_proj + offsets / attention-weight projections; forms `x + pos` from a bf16 pos table),
+        `ops.msda_forward_fused_bf16` (softmax / sampling locations in the prologue) and `ops.encoder_layer_tail`
+        (output_proj + residual LayerNorm + FFN + residual LayerNorm; the last layer also emits the query decoder's
+        K / V operands). Each stage falls back to its library-GEMM form (4 GEMMs + 2 fused residual-LayerNorm passes, the
+        round-1 path) when its shape is not built or its CGG_FUSED_* switch is off. `src` (f32 stream) is only read
+        with the f32 residual option (CGG_STREAM_RES_F32)."""
         bf = torch.bfloat16
         cc = runtime.cast_cached
         if x16 is None:
             x16 = src.to(bf)
             xp16 = (src + pos[None]).to(bf)
-        B, N, C = src.shape
+        B, N, C = (src if src is not None else x16).shape
         n_layers = len(self.encoder.layers)
-
-        def _nc(layer):
-            a = layer.attentions[0]
-            return a.sampling_offsets.out_features + a.attention_weights.out_features
-        proj_ok = FUSED_PROJ and C == 256 and all(_nc(l) % 32 == 0 and 256 <= _nc(l) <= 384 for l in self.encoder.layers)
+        proj_ok = self._proj_fused(C)
         # with the projection kernel forming `x + pos` itself (bf16 pos table), the layer tails stop writing those rows
         pos16 = runtime.derived_cached('enc_pos16', (pos,), lambda: pos.to(bf).contiguous()) if proj_ok and POS_IN_PROJ else None
         for li, layer in enumerate(self.encoder.layers):
@@ -693,9 +699,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
             N += h * w
         pos = self._pos_cached(level_hw, dev)
         ref = self._reference_points(level_hw, dev)
-        src = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        # bf16 residual stream: the f32 copy of the encoder input is never read; projection kernel with the bf16 pos table:
+        # neither are the `x + pos` rows
+        need32 = not self.stream_residual_bf16
+        needp = not (self._proj_fused(C) and POS_IN_PROJ)
+        src = torch.empty((B, N, C), dtype=torch.float32, device=dev) if need32 else None
         x16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
-        xp16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
+        xp16 = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev) if needp else None
         ws = ops.group_norm_nhwc_workspace(B, int(feats[0].shape[2]) * int(feats[0].shape[3]), 32, dev)   # largest map
         for i in range(self.num_encoder_levels):
             f = feats[self.num_input_levels - i - 1]
@@ -704,8 +714,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             y = self._gemm1x1(f.permute(0, 2, 3, 1).reshape(B * h * w, f.shape[1]), cm.conv).view(B, h * w, C)
             gn = getattr(cm, cm.norm_name)
             off = level_start[i] * C
-            ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, out32=(src, off, N * C),
-                                out16=(x16, off, N * C), pos=(pos, off), outp16=(xp16, off, N * C))
+            ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, out32=(src, off, N * C) if need32 else None,
+                                out16=(x16, off, N * C), pos=(pos, off) if needp else None,
+                                outp16=(xp16, off, N * C) if needp else None)
         kv16 = None
         if kv_tables is not None:
             src, kv = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start, x16, xp16,
