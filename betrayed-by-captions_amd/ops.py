@@ -156,6 +156,12 @@ class MultiScaleDeformableAttnFunction(torch.autograd.Function):
 EXACT_F32_LOGITS = os.environ.get('CGG_EXACT_F32_LOGITS', '1') != '0'
 
 
+def _throughput_mode():
+    """bf16 (throughput) mode keeps the 3 x bf16 split GEMM for f32 rows: the exact-f32 MFMA form is parity mode's."""
+    from . import runtime
+    return runtime.is_bf16()
+
+
 class PackedFeature:
     """mask_feature packed for the MFMA B operand (see include/cgg_hip.h)."""
 
@@ -558,7 +564,8 @@ def linear_rows(x, weight, bias=None, relu=False, res=None, split=True, out=None
                                  ctypes.c_void_p(r2.data_ptr()) if r2 is not None else None,
                                  r2.stride(0) if r2 is not None else 0, ctypes.c_void_p(y.data_ptr()),
                                  y.stride(0), M, N, K,
-                                 1 if relu else 0, (2 if EXACT_F32_LOGITS else 1) if split else 0, stream_ptr(x.device))
+                                 1 if relu else 0, (2 if EXACT_F32_LOGITS and not _throughput_mode() else 1) if split else 0,
+                                 stream_ptr(x.device))
     check(rc, 'cgg_linear_rows')
     return y.view(*x.shape[:-1], N) if out is None else out
 

@@ -29,7 +29,8 @@ if len(sys.argv) > 2:
     out = {}
     for k, v in agg.items():
         full = k[0] == 'cgg_mask_logits_kernel' and int(k[1]) == 65536 and int(k[2]) == 2
-XX
+        if full or k[0].startswith('cgg_msda_fwd') or k[0].startswith('cgg_encoder_'):
+            name = 'cgg_msda_fwd_stream_kernel' if k[0].startswith('cgg_msda_fwd') else k[0]
             out[name] = dict(launch_ms_mean=sum(v) / len(v) / 1e3, launch_ms_min=min(v) / 1e3, launch_ms_max=max(v) / 1e3,
                              launches=len(v), grid=[int(k[1]), int(k[2])],
                              command='rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --host-results 0')

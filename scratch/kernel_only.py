@@ -38,10 +38,11 @@ wo, w1, w2 = ops.pack_linear_weight(mk(256, 256, sc=0.05)), ops.pack_linear_weig
 bo, b1, b2, g0, g1, be = mk(256, sc=0.1), mk(1024, sc=0.1), mk(256, sc=0.1), mk(256, sc=0.1) + 1, mk(256, sc=0.1) + 1, mk(256, sc=0.1)
 pos = mk(N, 256)
 for _ in range(20):
-    ops.encoder_layer_tail(a16, x16, wo, bo, (g0, be, 1e-5), w1, b1, w2, b2, (g1, be, 1e-5), pos=pos, want_pos=True)
+    ops.encoder_layer_tail(a16, x16, wo, bo, (g0, be, 1e-5), w1, b1, w2, b2, (g1, be, 1e-5))     # as in the step: y rows only
 torch.cuda.synchronize()
 wv, wc = ops.pack_encoder_proj_weight(mk(256, 256, sc=0.05)), ops.pack_encoder_proj_weight(mk(288, 256, sc=0.05))
+bc288, pos16 = mk(288), pos.bfloat16()
 for _ in range(20):
-    ops.encoder_proj(x16, xp16, wv, bo, wc, mk(288))
+    ops.encoder_proj(x16, None, wv, bo, wc, bc288, pos16=pos16)                                  # x + pos formed in the kernel
 torch.cuda.synchronize()
 print('done')
