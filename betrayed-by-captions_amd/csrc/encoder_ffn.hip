@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 ef_bf2;
 #define EF_NT (4 * EF_RB)      // threads per workgroup: one wavefront per 64 output columns x 64 rows
 #define EF_TS 260              // f32 LayerNorm tile row stride
 #define EF_PF 4                // B-fragment prefetch distance (k-steps); must divide EF_STEPS (the queue rotates across blocks)
+#define EF_PA 1                // A-fragment (LDS) prefetch distance (k-steps); 2 measured no better (78 vs 76 us)
 static_assert(EF_STEPS % EF_PF == 0, "the B queue index s % EF_PF must line up across blocks");
 
 __device__ __forceinline__ uint32_t ef_pk(float a, float b) {            // v_cvt_pk_bf16_f32
@@ -61,21 +62,25 @@ __device__ __forceinline__ void ef_block(f32x16 (&acc)[2][2], const ef_u32x4* __
                                          const ef_u32x4* __restrict__ b1, const ef_u32x4* __restrict__ nb0,
                                          const ef_u32x4* __restrict__ nb1) {
   if constexpr (XS) asm volatile("" : "+v"(xl));       // keep the 15 swizzled lane offsets out of the chunk loop's live set
-  ef_u32x4 ua0 = XS ? a0[xl] : a0[0], ua1 = XS ? a0[EF_STEPS * 64 + xl] : a1[0];
+  // A fragments run EF_PA k-steps ahead of their MFMAs (LDS serves 8 waves: a read issued one step ahead was late under load)
+  auto load_a = [&](int s, ef_u32x4& u0, ef_u32x4& u1) {
+    if constexpr (XS) {
+      const int xo = xl ^ s;                            // one v_xor per k-step; the m-tile / k-step parts are immediates
+      u0 = a0[s * 64 + xo];
+      u1 = a0[(EF_STEPS + s) * 64 + xo];
+    } else {
+      u0 = (s & 1) ? a0o[s * 64] : a0[s * 64];
+      u1 = (s & 1) ? a1o[s * 64] : a1[s * 64];
+    }
+  };
+  ef_u32x4 ua0[EF_PA], ua1[EF_PA];
+#pragma unroll
+  for (int s = 0; s < EF_PA; ++s) load_a(s, ua0[s], ua1[s]);
 #pragma unroll
   for (int s = 0; s < EF_STEPS; ++s) {
     const bf16x8 vb0 = __builtin_bit_cast(bf16x8, q0[s % EF_PF]), vb1 = __builtin_bit_cast(bf16x8, q1[s % EF_PF]);
-    const bf16x8 va0 = __builtin_bit_cast(bf16x8, ua0), va1 = __builtin_bit_cast(bf16x8, ua1);
-    if (s + 1 < EF_STEPS) {
-      if constexpr (XS) {
-        const int xo = xl ^ (s + 1);                     // one v_xor per k-step; the m-tile / k-step parts are immediates
-        ua0 = a0[(s + 1) * 64 + xo];
-        ua1 = a0[(EF_STEPS + s + 1) * 64 + xo];
-      } else {
-        ua0 = ((s + 1) & 1) ? a0o[(s + 1) * 64] : a0[(s + 1) * 64];
-        ua1 = ((s + 1) & 1) ? a1o[(s + 1) * 64] : a1[(s + 1) * 64];
-      }
-    }
+    const bf16x8 va0 = __builtin_bit_cast(bf16x8, ua0[s % EF_PA]), va1 = __builtin_bit_cast(bf16x8, ua1[s % EF_PA]);
+    if (s + EF_PA < EF_STEPS) load_a(s + EF_PA, ua0[s % EF_PA], ua1[s % EF_PA]);
 #ifndef EF_NOB
     if (s + EF_PF < EF_STEPS) {
       q0[s % EF_PF] = b0[(s + EF_PF) * 64];
@@ -142,6 +147,18 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v;
   }
   if constexpr (PRO) {
+    // the layer-input rows LayerNorm 0 adds (its residual) are requested now: they arrive behind the output projection's MFMAs
+    uint2 xres[4][4];
+    {
+      const int sub = lane & 15, rsub = lane >> 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = 16 * wave + 4 * it + rsub;
+        const int mc = m0 + row < M ? m0 + row : M - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xres[it][k] = *reinterpret_cast<const uint2*>(x16 + (size_t)mc * EF_C + 4 * sub + 64 * k);
+      }
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -173,13 +190,12 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = 16 * wave + 4 * it + rsub;
-      const int mc = m0 + row < M ? m0 + row : M - 1;
       f32x4 v[4];
       float sm = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[k] = *reinterpret_cast<const f32x4*>(&tile[row * EF_TS + 4 * sub + 64 * k]);
-        const uint2 xr = *reinterpret_cast<const uint2*>(x16 + (size_t)mc * EF_C + 4 * sub + 64 * k);
+        const uint2 xr = xres[it][k];
         v[k][0] += __uint_as_float(xr.x << 16);
         v[k][1] += __uint_as_float(xr.x & 0xffff0000u);
         v[k][2] += __uint_as_float(xr.y << 16);
