@@ -37,7 +37,9 @@ __device__ __forceinline__ uint32_t ep_pk(float a, float b) {            // v_cv
 
 // acc[2][NT] += A (two 32-row m-tiles, fragment images in LDS at a0 / a1) x B (NT consecutive n-tiles of the packed weight,
 // b = lane pointer to k-step 0 of the first; n-tiles are EP_STEPS * 64 fragments apart)
-template <int NT>
+// TR = true: the operand roles are swapped (weight fragment as A, row image as B): acc[mt][t] is the TRANSPOSED block, rows =
+// the 32 output channels of n-tile t, columns = the 32 rows of m-tile mt (fragment layouts of A and B are the same).
+template <int NT, bool TR = false>
 __device__ __forceinline__ void ep_block(f32x16 (&acc)[2][NT], const ep_u32x4* __restrict__ a0, const ep_u32x4* __restrict__ a1,
                                          int lane, const ep_u32x4* __restrict__ b) {
   ep_u32x4 q[NT][EP_PF];
@@ -63,8 +65,13 @@ __device__ __forceinline__ void ep_block(f32x16 (&acc)[2][NT], const ep_u32x4* _
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, vb[t], acc[0][t], 0, 0, 0);
-      acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, vb[t], acc[1][t], 0, 0, 0);
+      if constexpr (TR) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[t], va0, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[t], va1, acc[1][t], 0, 0, 0);
+      } else {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, vb[t], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, vb[t], acc[1][t], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -231,5 +238,132 @@ extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const vo
                      (const uint16_t*)x16, (const uint16_t*)xp16, (const ep_u32x4*)wv_packed, bv, (const ep_u32x4*)wc_packed, bc,
                      (uint16_t*)value, (uint16_t*)offs, M, NC, (const uint16_t*)pos16, pos_rows);
   CGG_CHECK_LAUNCH("cgg_encoder_proj_bf16");
+  return CGG_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// K / V projections of the query decoder for ONE memory level (open_set/models/mask2former_head.py:795-812 + the
+// [3P] nn.MultiheadAttention in_proj of the cross-attention): the decoder layers that read this level (l, l + 3, l + 6) share
+// their input, so their projections are stacked into NK = NVT = n * 256 outputs:
+//     k  (M, NK)           = mp16 Wk^T + bk            rows = (batch, pixel), what the attention kernel reads key-major
+//     vt (B, NVT, hw)      = Wv m16^T                  the value projection TRANSPOSED (channel-major), no bias (added after P V)
+// One launch instead of a library GEMM pair per level (6 per forward, ~2 TB/s on these K = 256 shapes). Same structure as the
+// kernel above: 64-row blocks, both operand images in LDS, weights streamed L2 -> registers, 2 x 2 MFMA tiles. The k block
+// uses the column-interleaved packing (8-byte stores, 128-byte runs). The vt block swaps the MFMA operand roles, which yields
+// the transposed tile directly; the m16 image is staged with its ROWS interleaved between the two m-tiles (image row (mt, j)
+// = block row 4 (j / 2) + 2 mt + (j & 1)), so that after the same lane-pair swap a lane holds 4 consecutive pixels of one
+// channel: 8-byte stores, 128-byte runs along the pixel axis.
+template <int NT>
+__device__ __forceinline__ void ep_store_tr(const f32x16 (&acc)[2][NT], uint16_t* __restrict__ vt, int tile0, long long ldc,
+                                            int pix0, int lane) {
+  const int j = lane & 31, hi5 = lane >> 5, odd = j & 1;
+  const uint32_t rot = 16u * (uint32_t)odd;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+      uint32_t pk[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float v0 = acc[mt][t][2 * rp], v1 = acc[mt][t][2 * rp + 1];
+        const float kept = odd ? v1 : v0, sent = odd ? v0 : v1;
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sent), 0xB1, 0xf, 0xf, true));  // lane ^ 1
+        const uint32_t w = ep_pk(kept, recv);          // even lane: channel row(2 rp), pixels (j, j + 1) of m-tile mt; odd: row + 1
+        pk[mt] = __builtin_amdgcn_alignbit(w, w, rot);
+      }
+      const int ch = 32 * (tile0 + t) + 2 * (rp & 1) + 8 * (rp >> 1) + 4 * hi5 + odd;
+      *reinterpret_cast<uint2*>(vt + (size_t)ch * ldc + pix0 + 4 * (j >> 1)) = make_uint2(pk[0], pk[1]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cgg_decoder_kv_proj_kernel(
+    const uint16_t* __restrict__ m16, const uint16_t* __restrict__ mp16, const ep_u32x4* __restrict__ wk,
+    const float* __restrict__ bk, const ep_u32x4* __restrict__ wv, uint16_t* __restrict__ k, uint16_t* __restrict__ vt, int hw,
+    int NK) {
+  __shared__ __attribute__((aligned(16))) ep_u32x4 frag[2][2 * EP_STEPS * 64];      // m16 (row-interleaved) and mp16 images
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * EP_RB;                     // hw % 64 == 0: a block never straddles two images
+  {
+    ep_u32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = tid + 256 * i, which = p >> 11, row = (p >> 5) & 63, k8 = p & 31;
+      v[i] = *reinterpret_cast<const ep_u32x4*>((which ? mp16 : m16) + (size_t)(m0 + row) * EP_C + 8 * k8);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = tid + 256 * i, which = p >> 11, row = (p >> 5) & 63, k8 = p & 31;
+      // image row of block row `row`: the m16 image interleaves the two m-tiles in pixel pairs, the mp16 image is in order
+      const int ir = which ? row : (((row >> 1) & 1) * 32 + 2 * (row >> 2) + (row & 1));
+      frag[which][((ir >> 5) * EP_STEPS + (k8 >> 1)) * 64 + (((ir & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v[i];
+    }
+  }
+  __syncthreads();
+  const int npass = NK >> 8;                             // 64 columns / channels per wave and pass
+  for (int ps = 0; ps < npass; ++ps) {
+    const int tile0 = 2 * (4 * ps + wave);
+    {
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      ep_block<2>(acc, frag[1], frag[1] + EP_STEPS * 64, lane, wk + (size_t)tile0 * EP_STEPS * 64 + lane);
+      ep_store<2>(acc, bk, k, NK, 32 * tile0, m0, 0x7fffffff, lane);
+    }
+    {
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      ep_block<2, true>(acc, frag[0], frag[0] + EP_STEPS * 64, lane, wv + (size_t)tile0 * EP_STEPS * 64 + lane);
+      const int b = m0 / hw, pix0 = m0 - b * hw;
+      ep_store_tr<2>(acc, vt + (size_t)b * NK * hw, tile0, hw, pix0, lane);
+    }
+  }
+}
+
+// weight (N x 256) f32, N % 64 == 0 -> bf16 B fragments for the k block: 64-column groups, the two n-tiles of a group interleaved
+__global__ __launch_bounds__(256) void cgg_decoder_kv_pack_k_kernel(const float* __restrict__ w, ep_u32x4* __restrict__ out, int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int lane = i & 63, t_all = i >> 6;
+  const int ks = t_all % EP_STEPS, tile = t_all / EP_STEPS;
+  const int n = 64 * (tile >> 1) + ep_col(2, tile & 1, lane & 31);
+  const float* s = w + (size_t)n * EP_C + ks * 16 + 8 * (lane >> 5);
+  out[i] = ep_u32x4{ep_pk(s[0], s[1]), ep_pk(s[2], s[3]), ep_pk(s[4], s[5]), ep_pk(s[6], s[7])};
+}
+
+extern "C" int cgg_decoder_kv_pack_k(const float* w, void* packed, int N, int K, cgg_stream_t stream) {
+  CGG_REQUIRE(w && packed, CGG_EINVAL, "cgg_decoder_kv_pack_k: null pointer");
+  CGG_REQUIRE(K == EP_C && N > 0 && N % 256 == 0, CGG_EUNSUPPORTED, "cgg_decoder_kv_pack_k: N=%d K=%d (N %% 256, K = 256)", N, K);
+  const int total = (N / 32) * EP_STEPS * 64;
+  hipLaunchKernelGGL(cgg_decoder_kv_pack_k_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                     (ep_u32x4*)packed, total);
+  CGG_CHECK_LAUNCH("cgg_decoder_kv_pack_k");
+  return CGG_OK;
+}
+
+extern "C" int cgg_decoder_kv_proj_bf16(const void* m16, const void* mp16, const void* wk_packed, const float* bk,
+                                        const void* wv_packed, void* k, void* vt, int B, int hw, int C, int NK,
+                                        cgg_stream_t stream) {
+  CGG_REQUIRE(m16 && mp16 && wk_packed && bk && wv_packed && k && vt, CGG_EINVAL, "cgg_decoder_kv_proj_bf16: null pointer");
+  CGG_REQUIRE(C == EP_C && NK > 0 && NK % 256 == 0, CGG_EUNSUPPORTED, "cgg_decoder_kv_proj_bf16: C=%d NK=%d (C = 256, NK %% 256)", C,
+              NK);
+  CGG_REQUIRE(B > 0 && hw > 0 && hw % 64 == 0, CGG_EUNSUPPORTED, "cgg_decoder_kv_proj_bf16: hw=%d must be a multiple of 64", hw);
+  CGG_REQUIRE((long long)B * hw * NK < (1ll << 31), CGG_EUNSUPPORTED, "cgg_decoder_kv_proj_bf16: output too large for 32-bit offsets");
+  CGG_REQUIRE(cgg_aligned16(m16) && cgg_aligned16(mp16) && cgg_aligned16(wk_packed) && cgg_aligned16(wv_packed) && cgg_aligned16(k) &&
+                  cgg_aligned16(vt),
+              CGG_EALIGN, "cgg_decoder_kv_proj_bf16: 16-B alignment");
+  hipLaunchKernelGGL(cgg_decoder_kv_proj_kernel, dim3(B * hw / EP_RB), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)m16,
+                     (const uint16_t*)mp16, (const ep_u32x4*)wk_packed, bk, (const ep_u32x4*)wv_packed, (uint16_t*)k, (uint16_t*)vt,
+                     hw, NK);
+  CGG_CHECK_LAUNCH("cgg_decoder_kv_proj_bf16");
   return CGG_OK;
 }

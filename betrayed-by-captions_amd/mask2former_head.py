@@ -30,6 +30,8 @@ from .config import ConfigDict, to_config_dict
 from .registry import (HEADS, build_assigner, build_head, build_loss, build_plugin_layer,
                        build_positional_encoding, build_sampler, build_transformer_layer_sequence)
 
+# throughput mode: the decoder's per-level K / V projections as one HIP launch (ops.decoder_kv_proj); CGG_FUSED_KV=0 = library GEMMs
+FUSED_KV = os.environ.get('CGG_FUSED_KV', '1') != '0'
 BOS_TOKEN = 101
 EOS_TOKEN = 102
 
@@ -584,8 +586,15 @@ class Mask2FormerHeadOpen(nn.Module):
             bk = runtime.derived_cached('kv_levels_bk', bs, lambda: torch.cat([b[E:2 * E] for b in bs], 0).to(torch.bfloat16).contiguous())
             wv = runtime.derived_cached('kv_levels_wv', ws, lambda: torch.cat([w[2 * E:] for w in ws], 0).to(torch.bfloat16).contiguous())
             m16, mp16 = kv16[l]
-            k_all = F.linear(mp16, wk, bk)                               # (B, hw, n E)
-            vt_all = torch.matmul(wv, m16.transpose(1, 2))               # (B, n E, hw)
+            if FUSED_KV and E == 256 and m16.shape[1] % 64 == 0 and m16.is_contiguous() and mp16.is_contiguous():
+                # both projections of the level in ONE launch (k row-major, v transposed straight from the MFMA tiles)
+                wkp = runtime.derived_cached('kv_levels_wkp', ws, lambda: ops.pack_decoder_k_weight(torch.cat([w[E:2 * E] for w in ws], 0)))
+                wvp = runtime.derived_cached('kv_levels_wvp', ws, lambda: ops.pack_linear_weight(torch.cat([w[2 * E:] for w in ws], 0)))
+                bkf = runtime.derived_cached('kv_levels_bkf', bs, lambda: torch.cat([b[E:2 * E] for b in bs], 0).float().contiguous())
+                k_all, vt_all = ops.decoder_kv_proj(m16, mp16, wkp, bkf, wvp)
+            else:
+                k_all = F.linear(mp16, wk, bk)                               # (B, hw, n E)
+                vt_all = torch.matmul(wv, m16.transpose(1, 2))               # (B, n E, hw)
             for j, i in enumerate(idx):
                 kvs[i] = (k_all[:, :, j * E:(j + 1) * E], vt_all[:, j * E:(j + 1) * E, :])
         return kvs

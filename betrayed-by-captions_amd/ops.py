@@ -637,6 +637,31 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
     return y32, y16, yp16
 
 
+def pack_decoder_k_weight(weight):
+    """weight (n * 256, 256) f32 (stacked key projections) -> packed bf16 operand of `decoder_kv_proj` (uint8 tensor)."""
+    N, K = weight.shape
+    out = torch.empty((_lib_().cgg_linear_rows_packed_bytes(N, K),), dtype=torch.uint8, device=weight.device)
+    w = weight.detach().float().contiguous()
+    check(_lib_().cgg_decoder_kv_pack_k(dev_ptr(w, 'weight', torch.float32), dev_ptr(out), N, K, stream_ptr(weight.device)),
+          'cgg_decoder_kv_pack_k')
+    return out
+
+
+def decoder_kv_proj(m16, mp16, wkp, bk, wvp):
+    """k (B, hw, NK) = mp16 Wk^T + bk and vt (B, NK, hw) = Wv m16^T (bf16) for one memory level in ONE launch; m16 / mp16
+    (B, hw, 256) bf16, wkp from `pack_decoder_k_weight`, wvp from `pack_linear_weight`, bk (NK,) f32."""
+    B, hw, C = m16.shape
+    NK = bk.numel()
+    k = torch.empty((B, hw, NK), dtype=torch.bfloat16, device=m16.device)
+    vt = torch.empty((B, NK, hw), dtype=torch.bfloat16, device=m16.device)
+    with _timed('decoder_kv_proj'):
+        rc = _lib_().cgg_decoder_kv_proj_bf16(dev_ptr(m16, 'm16', torch.bfloat16), dev_ptr(mp16, 'mp16', torch.bfloat16),
+                                              dev_ptr(wkp), dev_ptr(bk, 'bk', torch.float32), dev_ptr(wvp), dev_ptr(k),
+                                              dev_ptr(vt), B, hw, C, NK, stream_ptr(m16.device))
+    check(rc, 'cgg_decoder_kv_proj_bf16')
+    return k, vt
+
+
 def pack_encoder_proj_weight(weight):
     """weight (256 .. 384 in steps of 32, 256) f32 -> packed bf16 operand of `encoder_proj` (uint8 tensor)."""
     N, K = weight.shape

@@ -368,6 +368,15 @@ int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* pos16, 
                           const float* bv, const void* wc_packed, const float* bc, void* value, void* offs, int M, int C, int NV,
                           int NC, cgg_stream_t stream);
 
+/* K / V projections of the query decoder for one memory level, all decoder layers that read the level stacked (NK = n * 256
+ * outputs; open_set/models/mask2former_head.py:795-812 feeding the cross-attention in_proj of [3P] nn.MultiheadAttention):
+ *   k  (B * hw, NK) bf16 = mp16 Wk^T + bk;     vt (B, NK, hw) bf16 = Wv m16^T   (value projection transposed, no bias)
+ * m16 / mp16 (B * hw, 256) bf16 rows, hw % 64 == 0; wk packed by cgg_decoder_kv_pack_k, wv by cgg_linear_rows_pack (both
+ * cgg_linear_rows_packed_bytes(NK, 256) bytes); bk f32. */
+int cgg_decoder_kv_pack_k(const float* w, void* packed, int N, int K, cgg_stream_t stream);
+int cgg_decoder_kv_proj_bf16(const void* m16, const void* mp16, const void* wk_packed, const float* bk, const void* wv_packed,
+                             void* k, void* vt, int B, int hw, int C, int NK, cgg_stream_t stream);
+
 /* Encoder-stream FFN block of the pixel decoder as ONE launch ([3P] BaseTransformerLayer 'ffn' + 'norm' of the
  * MSDeformAttn encoder layers built at open_set/models/mask2former_head.py:112-117):
  *   y = LayerNorm(x + W2 relu(W1 x + b1) + b2);  x16 (M, 256) bf16 rows, w1 (F x 256) / w2 (256 x F) packed by

@@ -1295,3 +1295,26 @@ def test_encoder_proj_forms_x_plus_pos_in_kernel(dev):
     v_a, o_a = ops.encoder_proj(x16, xp16, wvp, bv, wcp, bc)
     v_b, o_b = ops.encoder_proj(x16, None, wvp, bv, wcp, bc, pos16=pos16)
     assert torch.equal(v_a, v_b) and torch.equal(o_a, o_b)
+
+
+@pytest.mark.parametrize('B,hw,n', [(2, 16384, 3), (2, 1024, 3), (1, 64, 1), (3, 4096, 2)])
+def test_decoder_kv_proj_fused_vs_float64(dev, B, hw, n):
+    """Decoder K / V projections of one memory level in one launch: k = mp16 Wk^T + bk (row-major) and vt = Wv m16^T
+    (transposed, straight from the swapped-operand MFMA tiles) against float64 on the same bf16-rounded operands: half a bf16
+    ulp relative (2^-8 of max(|v|, 1)) + f32 accumulation noise; layouts exactly those of F.linear / torch.matmul."""
+    g = torch.Generator().manual_seed(B * hw + n)
+    C, NK = 256, 256 * n
+    m16 = torch.randn(B, hw, C, generator=g).to(dev).bfloat16()
+    mp16 = torch.randn(B, hw, C, generator=g).to(dev).bfloat16()
+    wk = (torch.randn(NK, C, generator=g) * 0.05).to(dev)
+    wv = (torch.randn(NK, C, generator=g) * 0.05).to(dev)
+    bk = torch.randn(NK, generator=g).to(dev)
+    k, vt = ops.decoder_kv_proj(m16, mp16, ops.pack_decoder_k_weight(wk), bk, ops.pack_linear_weight(wv))
+    k2, vt2 = ops.decoder_kv_proj(m16, mp16, ops.pack_decoder_k_weight(wk), bk, ops.pack_linear_weight(wv))
+    torch.cuda.synchronize()
+    assert torch.equal(k, k2) and torch.equal(vt, vt2)
+    assert k.shape == (B, hw, NK) and vt.shape == (B, NK, hw)
+    rk = mp16.double() @ wk.bfloat16().double().t() + bk.double()
+    rv = wv.bfloat16().double() @ m16.double().transpose(1, 2)
+    assert ((k.double() - rk).abs() / rk.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4
+    assert ((vt.double() - rv).abs() / rv.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4
