@@ -116,6 +116,39 @@ __device__ __forceinline__ void ep_store(const f32x16 (&acc)[2][NT], const float
   }
 }
 
+// `value` block (NT = 2, the wave's 64 columns = heads 2 w, 2 w + 1) stored HEAD-MAJOR: value[(b * 8 + head) * N + n][32]
+// for row m = b * N + n -- the layout cgg_msda_forward_fused_bf16_hm gathers from (see msda.hip)
+__device__ __forceinline__ void ep_store_value_hm(const f32x16 (&acc)[2][2], const float* __restrict__ bias,
+                                                  uint16_t* __restrict__ out, int col0, int m0, int M, int N, int lane) {
+  const int j = lane & 31, hi5 = lane >> 5, odd = j & 1;
+  const uint32_t rot = 16u * (uint32_t)odd;
+  float bs[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bs[t] = bias[col0 + ep_col(2, t, j)];
+  const int col = col0 + 4 * (j >> 1);                              // first of this lane's 4 consecutive columns
+  const int head = col >> 5, ch = col & 31;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+      uint32_t pk[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float v0 = acc[mt][t][2 * rp] + bs[t], v1 = acc[mt][t][2 * rp + 1] + bs[t];
+        const float kept = odd ? v1 : v0, sent = odd ? v0 : v1;
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sent), 0xB1, 0xf, 0xf, true));  // lane ^ 1
+        const uint32_t w = ep_pk(kept, recv);
+        pk[t] = __builtin_amdgcn_alignbit(w, w, rot);
+      }
+      const int m = m0 + 32 * mt + 2 * (rp & 1) + 8 * (rp >> 1) + 4 * hi5 + odd;
+      if (m < M) {
+        const int b = m / N, n = m - b * N;
+        *reinterpret_cast<uint2*>(out + (((size_t)b * 8 + head) * N + n) * 32 + ch) = make_uint2(pk[0], pk[1]);
+      }
+    }
+  }
+}
+
 // N / 32 n-tiles dealt to the 4 waves: `base` each, the last `extra` waves one more (N = 256: 2 2 2 2; 288: 2 2 2 3; 384: 3 3 3 3)
 __host__ __device__ __forceinline__ int ep_wave_nt(int ntiles, int w) { return ntiles / 4 + (w >= 4 - ntiles % 4 ? 1 : 0); }
 __host__ __device__ __forceinline__ int ep_wave_tile0(int ntiles, int w) {
@@ -141,7 +174,7 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_pack_kernel(const float*
 __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
     const uint16_t* __restrict__ x16, const uint16_t* __restrict__ xp16, const ep_u32x4* __restrict__ wv,
     const float* __restrict__ bv, const ep_u32x4* __restrict__ wc, const float* __restrict__ bc, uint16_t* __restrict__ value,
-    uint16_t* __restrict__ offs, int M, int NC, const uint16_t* __restrict__ pos16, int pos_rows) {
+    uint16_t* __restrict__ offs, int M, int NC, const uint16_t* __restrict__ pos16, int pos_rows, int hm_rows) {
   __shared__ __attribute__((aligned(16))) ep_u32x4 frag[2][2 * EP_STEPS * 64];      // x and xp images: 2 x 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * EP_RB;
@@ -186,7 +219,8 @@ __global__ __launch_bounds__(256) void cgg_encoder_proj_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     ep_block<2>(acc, frag[0], frag[0] + EP_STEPS * 64, lane, wv + (size_t)(2 * wave) * EP_STEPS * 64 + lane);
-    ep_store<2>(acc, bv, value, 256, 64 * wave, m0, M, lane);
+    if (hm_rows > 0) ep_store_value_hm(acc, bv, value, 64 * wave, m0, M, hm_rows, lane);     // block-uniform
+    else ep_store<2>(acc, bv, value, 256, 64 * wave, m0, M, lane);
   }
   const int ntiles = NC >> 5, tile0 = ep_wave_tile0(ntiles, wave);
   if (ep_wave_nt(ntiles, wave) == 3) {                 // wave-uniform
@@ -225,7 +259,9 @@ extern "C" int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K,
 
 extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* pos16, int pos_rows, const void* wv_packed,
                                      const float* bv, const void* wc_packed, const float* bc, void* value, void* offs, int M,
-                                     int C, int NV, int NC, cgg_stream_t stream) {
+                                     int C, int NV, int NC, int value_head_major_rows, cgg_stream_t stream) {
+  CGG_REQUIRE(value_head_major_rows >= 0 && (value_head_major_rows == 0 || M % value_head_major_rows == 0), CGG_EINVAL,
+              "cgg_encoder_proj_bf16: value_head_major_rows=%d must divide M=%d", value_head_major_rows, M);
   CGG_REQUIRE(x16 && wv_packed && bv && wc_packed && bc && value && offs, CGG_EINVAL, "cgg_encoder_proj_bf16: null pointer");
   CGG_REQUIRE(xp16 || (pos16 && pos_rows > 0), CGG_EINVAL, "cgg_encoder_proj_bf16: either xp16 or a pos16 table is required");
   CGG_REQUIRE(C == EP_C && NV == 256 && NC % 32 == 0 && NC >= 256 && NC <= 384, CGG_EUNSUPPORTED,
@@ -236,7 +272,7 @@ extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const vo
               CGG_EALIGN, "cgg_encoder_proj_bf16: 16-B alignment");
   hipLaunchKernelGGL(cgg_encoder_proj_kernel, dim3((M + EP_RB - 1) / EP_RB), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)x16, (const uint16_t*)xp16, (const ep_u32x4*)wv_packed, bv, (const ep_u32x4*)wc_packed, bc,
-                     (uint16_t*)value, (uint16_t*)offs, M, NC, (const uint16_t*)pos16, pos_rows);
+                     (uint16_t*)value, (uint16_t*)offs, M, NC, (const uint16_t*)pos16, pos_rows, value_head_major_rows);
   CGG_CHECK_LAUNCH("cgg_encoder_proj_bf16");
   return CGG_OK;
 }

@@ -298,21 +298,38 @@ __device__ __forceinline__ void msda_point_gather(msda_v2f (&acc)[4], const uint
   }
 }
 
+// HM = true: `value` is HEAD-MAJOR, (B, H, Nv, 32): the two x-neighbours of a bilinear tap are then adjacent 64-byte pieces (one
+// 128-byte line when x0 is even) and a line holds only this head's pixels -- in the row layout (B, Nv, H, 32) every 64-byte tap
+// drags the other half of its line (another head's channels, which that head samples elsewhere) through L2 and L1.
+template <bool HM>
 __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_kernel(
     const uint16_t* __restrict__ value, MsdaLevels lv, const uint16_t* __restrict__ rows, const float* __restrict__ ref,
     int ld, uint16_t* __restrict__ out, int Nv, int Nq, unsigned total) {
   constexpr int D = 32, CPL = 8, H = 8, L = 3, LP = 12;
   // 32-bit index arithmetic with H = 8 and 4 lanes per (query, head) as compile-time shifts: the generic kernel's
   // 64-bit `gid / (DQ * H)` and `bq / Nq` expand to software division loops (~25 % of its instructions)
-  const unsigned gid = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
-  if (gid >= total) return;               // total is a multiple of 4: quads are never split
-  const int cq = (int)(gid & 3u);
-  const int h = (int)((gid >> 2) & 7u);
-  const unsigned bq = gid >> 5;
+  unsigned gid = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  int cq, h;
+  unsigned bq;
+  if constexpr (HM) {
+    // a wavefront = 16 consecutive queries of ONE head (wave-uniform plane): the 16 tap pieces of a load instruction lie in the
+    // same plane, near each other, instead of in 8 planes; a block = 4 heads of a 16-query group, two blocks per group
+    const unsigned blk = gid >> 8, t = threadIdx.x;
+    cq = (int)(t & 3u);
+    h = (int)((blk & 1u) * 4u + (t >> 6));
+    bq = (blk >> 1) * 16u + ((t >> 2) & 15u);
+    if (bq >= total / 32u) return;        // whole quads
+  } else {
+    if (gid >= total) return;             // total is a multiple of 4: quads are never split
+    cq = (int)(gid & 3u);
+    h = (int)((gid >> 2) & 7u);
+    bq = gid >> 5;
+  }
   const unsigned b = bq / (unsigned)Nq;
   const int q = (int)(bq - b * (unsigned)Nq);
-  const int rowstride = H * D;
-  const uint16_t* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
+  constexpr int rowstride = HM ? D : H * D;              // elements between two pixels of this head
+  const uint16_t* vb = HM ? value + ((size_t)b * H + h) * Nv * D + cq * CPL
+                          : value + (size_t)b * Nv * (H * D) + (size_t)h * D + cq * CPL;
   const uint16_t* row = rows + (size_t)bq * ld;
   const uint16_t* lp = row + (size_t)h * LP * 2 + 2 * cq;              // this lane's point: (x, y) of point cq, + 8 per level
   const uint16_t* wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_kernel(
     msda_point_gather<2>(acc, vl, my_o, my_w);
     msda_point_gather<3>(acc, vl, my_o, my_w);
   }
-  uint16_t* op = out + (size_t)bq * rowstride + (size_t)h * D + cq * CPL;
+  uint16_t* op = out + (size_t)bq * (H * D) + (size_t)h * D + cq * CPL;
   *reinterpret_cast<uint4*>(op) =
       make_uint4(cgg_pack2(cgg_f2bf(acc[0][0]), cgg_f2bf(acc[0][1])), cgg_pack2(cgg_f2bf(acc[1][0]), cgg_f2bf(acc[1][1])),
                  cgg_pack2(cgg_f2bf(acc[2][0]), cgg_f2bf(acc[2][1])), cgg_pack2(cgg_f2bf(acc[3][0]), cgg_f2bf(acc[3][1])));
@@ -934,10 +951,9 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
 
 // Throughput-mode encoder stream: bf16 value, bf16 raw [offsets | logits] rows (a bf16 GEMM's output), bf16 output
 // (the next GEMM's input). Level table from the host (graph-capturable). L == 3, P == 4 fast path or generic.
-extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* level_hw, const int32_t* level_start,
-                                           const void* offs_logits, int ld, const float* ref_points, void* out,
-                                           int B, int Nv, int H, int D, int L, int Nq, int P,
-                                           cgg_stream_t stream) {
+static int msda_fused_bf16_impl(bool head_major, const void* value, const int32_t* level_hw, const int32_t* level_start,
+                                const void* offs_logits, int ld, const float* ref_points, void* out, int B, int Nv, int H,
+                                int D, int L, int Nq, int P, cgg_stream_t stream) {
   int rc = msda_check("cgg_msda_forward_fused_bf16", value, offs_logits, ref_points, out, B, Nv, H, D, L, Nq, P,
                       CGG_BF16);
   if (rc) return rc;
@@ -959,8 +975,14 @@ extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* lev
   static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
   static const bool v1_only = getenv("CGG_MSDA_V1") != nullptr;
   const bool fast_ok = L == 3 && P == 4 && D == 32 && ld % 8 == 0 && cgg_aligned16(offs_logits) && !generic_only;
-  if (fast_ok && !v1_only && H == 8 && (long long)Nv * H * D < (1ll << 31) && total < (1ll << 31))
-    hipLaunchKernelGGL(cgg_msda_fwd_stream2_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
+  const bool quad_ok = fast_ok && !v1_only && H == 8 && (long long)Nv * H * D < (1ll << 31) && total < (1ll << 31);
+  CGG_REQUIRE(!head_major || quad_ok, CGG_EUNSUPPORTED,
+              "cgg_msda_forward_fused_bf16_hm: head-major values need H=8, D=32, L=3, P=4 (H=%d D=%d L=%d P=%d)", H, D, L, P);
+  if (quad_ok && head_major)
+    hipLaunchKernelGGL(cgg_msda_fwd_stream2_kernel<true>, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s, (const uint16_t*)value, lv,
+                       (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, Nq, (unsigned)total);
+  else if (quad_ok)
+    hipLaunchKernelGGL(cgg_msda_fwd_stream2_kernel<false>, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
                        (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, Nq, (unsigned)total);
   else if (fast_ok)
     hipLaunchKernelGGL(cgg_msda_fwd_stream_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
@@ -975,4 +997,18 @@ extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* lev
                        ld, (uint16_t*)out, Nv, H, D, L, Nq, P, total);
   CGG_CHECK_LAUNCH("cgg_msda_forward_fused_bf16");
   return CGG_OK;
+}
+
+extern "C" int cgg_msda_forward_fused_bf16(const void* value, const int32_t* level_hw, const int32_t* level_start,
+                                           const void* offs_logits, int ld, const float* ref_points, void* out,
+                                           int B, int Nv, int H, int D, int L, int Nq, int P,
+                                           cgg_stream_t stream) {
+  return msda_fused_bf16_impl(false, value, level_hw, level_start, offs_logits, ld, ref_points, out, B, Nv, H, D, L, Nq, P, stream);
+}
+
+// value HEAD-MAJOR (B, H, Nv, D) -- what cgg_encoder_proj_bf16 writes with value_head_major != 0
+extern "C" int cgg_msda_forward_fused_bf16_hm(const void* value, const int32_t* level_hw, const int32_t* level_start,
+                                              const void* offs_logits, int ld, const float* ref_points, void* out,
+                                              int B, int Nv, int H, int D, int L, int Nq, int P, cgg_stream_t stream) {
+  return msda_fused_bf16_impl(true, value, level_hw, level_start, offs_logits, ld, ref_points, out, B, Nv, H, D, L, Nq, P, stream);
 }

@@ -601,19 +601,22 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
 # ------------------------------------------------------------------------------------------------
 # throughput-mode encoder stream (bf16 activations between the library GEMMs, f32 residual stream)
 # ------------------------------------------------------------------------------------------------
-def msda_forward_fused_bf16(value, level_hw, level_start, offs_logits, ref_points, num_points):
-    """value (B,Nv,H,D) bf16, offs_logits (B,Nq,ld) bf16 raw [offsets | logits], ref_points (Nq,2) f32
-    -> (B,Nq,H*D) bf16."""
-    B, Nv, H, D = value.shape
+def msda_forward_fused_bf16(value, level_hw, level_start, offs_logits, ref_points, num_points, head_major=False):
+    """value (B,Nv,H,D) bf16 -- or, head_major=True, (B,H,Nv,D) as `encoder_proj(..., value_head_major=True)` writes it --,
+    offs_logits (B,Nq,ld) bf16 raw [offsets | logits], ref_points (Nq,2) f32 -> (B,Nq,H*D) bf16."""
+    if head_major:
+        B, H, Nv, D = value.shape
+    else:
+        B, Nv, H, D = value.shape
     _, Nq, ld = offs_logits.shape
     out = torch.empty((B, Nq, H * D), dtype=torch.bfloat16, device=value.device)
     hw = _int_array([v for pair in level_hw for v in pair])
     st = _int_array(level_start)
+    fn = _lib_().cgg_msda_forward_fused_bf16_hm if head_major else _lib_().cgg_msda_forward_fused_bf16
     with _timed('msda_fused'):
-        rc = _lib_().cgg_msda_forward_fused_bf16(
-            dev_ptr(value, 'value', torch.bfloat16), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.bfloat16),
-            ld, dev_ptr(ref_points, 'ref_points', torch.float32), dev_ptr(out), B, Nv, H, D, len(level_start), Nq,
-            int(num_points), stream_ptr(value.device))
+        rc = fn(dev_ptr(value, 'value', torch.bfloat16), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.bfloat16),
+                ld, dev_ptr(ref_points, 'ref_points', torch.float32), dev_ptr(out), B, Nv, H, D, len(level_start), Nq,
+                int(num_points), stream_ptr(value.device))
     check(rc, 'cgg_msda_forward_fused_bf16')
     return out
 
@@ -672,19 +675,26 @@ def pack_encoder_proj_weight(weight):
     return out
 
 
-def encoder_proj(x16, xp16, wvp, bv, wcp, bc, pos16=None):
+def encoder_proj(x16, xp16, wvp, bv, wcp, bc, pos16=None, value_head_major=False):
     """value = x16 Wv^T + bv (..., 256) and offs = xp16 Wc^T + bc (..., NC), both bf16, in ONE launch over the bf16 rows
     (weights from `pack_encoder_proj_weight`, biases f32). xp16=None: xp = bf16(x16 + pos16[row % len(pos16)]) is formed
-    inside the kernel from the bf16 table pos16."""
+    inside the kernel from the bf16 table pos16. value_head_major (x16 (B, N, 256)): value comes back (B, 8, N, 32)."""
     C = x16.shape[-1]
     M = x16.numel() // C
-    value = torch.empty(x16.shape[:-1] + (bv.numel(),), dtype=torch.bfloat16, device=x16.device)
+    hm_rows = 0
+    if value_head_major:
+        if x16.dim() != 3 or bv.numel() != 256:
+            raise CggError('encoder_proj: value_head_major needs x16 (B, N, 256) and 256 value columns')
+        hm_rows = x16.shape[1]
+        value = torch.empty((x16.shape[0], 8, hm_rows, 32), dtype=torch.bfloat16, device=x16.device)
+    else:
+        value = torch.empty(x16.shape[:-1] + (bv.numel(),), dtype=torch.bfloat16, device=x16.device)
     offs = torch.empty(x16.shape[:-1] + (bc.numel(),), dtype=torch.bfloat16, device=x16.device)
     with _timed('encoder_proj'):
         rc = _lib_().cgg_encoder_proj_bf16(
             dev_ptr(x16, 'x16', torch.bfloat16), dev_ptr(xp16, 'xp16', torch.bfloat16), dev_ptr(pos16, 'pos16', torch.bfloat16),
             pos16.shape[0] if pos16 is not None else 0, dev_ptr(wvp), dev_ptr(bv, 'bv', torch.float32), dev_ptr(wcp),
-            dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M, C, bv.numel(), bc.numel(),
+            dev_ptr(bc, 'bc', torch.float32), dev_ptr(value), dev_ptr(offs), M, C, bv.numel(), bc.numel(), hm_rows,
             stream_ptr(x16.device))
     check(rc, 'cgg_encoder_proj_bf16')
     return value, offs

@@ -30,6 +30,7 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
 FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
 FUSED_TAIL = os.environ.get('CGG_FUSED_TAIL', '1') != '0'   # ... preceded by output_proj + its residual LayerNorm
 FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
+VALUE_HEAD_MAJOR = os.environ.get('CGG_VALUE_HEAD_MAJOR', '1') != '0'   # value written (B, 8, N, 32) for the MSDeformAttn gather
 POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
 
 
@@ -576,12 +577,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                              lambda: ops.pack_encoder_proj_weight(torch.cat([so.weight, aw.weight], 0)))
                 bcf = runtime.derived_cached('msda_bcf', (so.bias, aw.bias),
                                              lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
-                value, offs = ops.encoder_proj(x16, xp16, wvp, vp.bias, wcp, bcf, pos16=pos16 if xp16 is None else None)
-                value = value.view(B, N, H, D)
+                hm = VALUE_HEAD_MAJOR and H == 8 and D == 32 and len(level_hw) == 3 and attn.num_points == 4
+                value, offs = ops.encoder_proj(x16, xp16, wvp, vp.bias, wcp, bcf, pos16=pos16 if xp16 is None else None,
+                                               value_head_major=hm)
+                if not hm:
+                    value = value.view(B, N, H, D)
             else:
+                hm = False
                 value = F.linear(x16, cc(attn.value_proj.weight), cc(attn.value_proj.bias)).view(B, N, H, D)
                 offs = F.linear(xp16, w_cat, b_cat)
-            a16 = ops.msda_forward_fused_bf16(value, level_hw, level_start, offs, ref, attn.num_points)
+            a16 = ops.msda_forward_fused_bf16(value, level_hw, level_start, offs, ref, attn.num_points, head_major=hm)
             n0, n1 = layer.norms
             ffn = layer.ffns[0]
             last = li == n_layers - 1

@@ -92,6 +92,11 @@ int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
 int cgg_msda_forward_fused_bf16(const void* value, const int32_t* level_hw, const int32_t* level_start,
                                 const void* offs_logits, int ld, const float* ref_points, void* out, int B,
                                 int Nv, int H, int D, int L, int Nq, int P, cgg_stream_t stream);
+/* Same with `value` HEAD-MAJOR, (B, H, Nv, D): a 128-byte line then holds two x-neighbouring pixels of ONE head instead of
+ * half-lines of two heads (H = 8, D = 32, L = 3, P = 4 only). */
+int cgg_msda_forward_fused_bf16_hm(const void* value, const int32_t* level_hw, const int32_t* level_start,
+                                const void* offs_logits, int ld, const float* ref_points, void* out, int B,
+                                int Nv, int H, int D, int L, int Nq, int P, cgg_stream_t stream);
 
 /* Backward of cgg_msda_forward (f32 value). grad_value / grad_loc / grad_attn must be ZEROED by the
  * caller and are accumulated in place (same contract as mmcv's ms_deform_attn_backward).           */
@@ -361,12 +366,13 @@ int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype,
  *   value (M, 256) bf16 = x16 Wv^T + bv,   offs (M, NC) bf16 = xp16 Wc^T + bc   (Wc = [W_offsets; W_attention_weights],
  *   NC = 3 * heads * levels * points, 256 .. 384 in steps of 32: 288 for the 3-level encoder, 384 for 4 levels),
  * x16 / xp16 (M, 256) bf16 rows; xp16 == NULL: xp = bf16(x16 + pos16[row % pos_rows]) is formed in the kernel from the bf16
- * table pos16 (pos_rows, 256) and the `x + pos` rows are never stored. Biases f32; weights (N x 256 f32, N = 256 / NC) packed once by cgg_encoder_proj_pack
+ * table pos16 (pos_rows, 256) and the `x + pos` rows are never stored. value_head_major_rows = N > 0: `value` is written
+ * head-major, (M / N, 8, N, 32), for cgg_msda_forward_fused_bf16_hm; 0: (M, 256) rows. Biases f32; weights (N x 256 f32, N = 256 / NC) packed once by cgg_encoder_proj_pack
  * (bf16 MFMA-B fragments, cgg_linear_rows_packed_bytes(N, 256) bytes, output columns interleaved for wide stores). */
 int cgg_encoder_proj_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream);
 int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* pos16, int pos_rows, const void* wv_packed,
                           const float* bv, const void* wc_packed, const float* bc, void* value, void* offs, int M, int C, int NV,
-                          int NC, cgg_stream_t stream);
+                          int NC, int value_head_major_rows, cgg_stream_t stream);
 
 /* K / V projections of the query decoder for one memory level, all decoder layers that read the level stacked (NK = n * 256
  * outputs; open_set/models/mask2former_head.py:795-812 feeding the cross-attention in_proj of [3P] nn.MultiheadAttention):

@@ -1318,3 +1318,30 @@ def test_decoder_kv_proj_fused_vs_float64(dev, B, hw, n):
     rv = wv.bfloat16().double() @ m16.double().transpose(1, 2)
     assert ((k.double() - rk).abs() / rk.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4
     assert ((vt.double() - rv).abs() / rv.abs().clamp_min(1.0)).max().item() <= 2 ** -8 + 1e-4
+
+
+def test_msda_head_major_value_path_is_bit_identical(dev):
+    """Head-major value layout, (B, 8, N, 32), written by `encoder_proj(value_head_major=True)` and gathered by
+    `msda_forward_fused_bf16(head_major=True)`: same arithmetic, different addresses -- both the projection output (after
+    the permute) and the attention output are bit-identical to the row-layout path."""
+    g = torch.Generator().manual_seed(3)
+    B, C = 2, 256
+    shapes = [(16, 24), (32, 48), (64, 96)]
+    starts, N = _levels(shapes)
+    x16 = torch.randn(B, N, C, generator=g).to(dev).bfloat16()
+    pos16 = torch.randn(N, C, generator=g).to(dev).bfloat16()
+    wv = (torch.randn(256, C, generator=g) * 0.05).to(dev)
+    wc = torch.randn(288, C, generator=g).to(dev) * 0.05
+    bv, bc = torch.randn(256, generator=g).to(dev) * 0.1, torch.randn(288, generator=g).to(dev) * 0.5
+    wvp, wcp = ops.pack_encoder_proj_weight(wv), ops.pack_encoder_proj_weight(wc)
+    ref_pts = torch.cat([torch.stack([(xs.flatten() + .5) / w, (ys.flatten() + .5) / h], -1)
+                         for h, w in shapes
+                         for ys, xs in [torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')]]).to(dev)
+    v_rows, offs = ops.encoder_proj(x16, None, wvp, bv, wcp, bc, pos16=pos16)
+    v_hm, offs2 = ops.encoder_proj(x16, None, wvp, bv, wcp, bc, pos16=pos16, value_head_major=True)
+    assert torch.equal(offs, offs2)
+    assert v_hm.shape == (B, 8, N, 32)
+    assert torch.equal(v_hm.permute(0, 2, 1, 3).reshape(B, N, 256), v_rows)
+    a = ops.msda_forward_fused_bf16(v_rows.view(B, N, 8, 32), shapes, starts, offs, ref_pts, 4)
+    b = ops.msda_forward_fused_bf16(v_hm, shapes, starts, offs, ref_pts, 4, head_major=True)
+    assert torch.equal(a, b)
