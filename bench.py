@@ -199,8 +199,24 @@ def parity_mode_rate(args, model, img, metas, dev):
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        graph, how = None, 'eager launches'
-        if args.graph:
+        graph, how, pipe = None, 'eager launches', None
+        if args.graph and args.pipeline:
+            # the same staged pipeline as the headline run (stages captured under the fp32 scope)
+            try:
+                from cgg_amd.pipeline import detector_pipeline
+                nst = min(max(args.pipeline, 2), 3)
+                pipe = detector_pipeline(model, img, metas, stages=nst, defer_tail=args.defer_tail, rescale=True,
+                                         device_results=True)
+                for _ in range(nst):
+                    pipe.submit(img)
+                pipe.flush()
+                torch.cuda.synchronize()
+                how = f'{nst}-stage software pipeline across steps, as the headline run'
+            except Exception as e:
+                print(f'bench.py: parity-mode pipeline setup failed ({type(e).__name__}: {e}); one graph per step', file=sys.stderr)
+                pipe = None
+                torch.cuda.synchronize()
+        if args.graph and pipe is None:
             try:
                 graph = torch.cuda.CUDAGraph()
                 side = torch.cuda.Stream()
@@ -220,10 +236,16 @@ def parity_mode_rate(args, model, img, metas, dev):
         steps = max(args.steps // 2, 5)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            graph.replay() if graph is not None else step()
+        if pipe is not None:
+            for _ in range(steps):
+                pipe.submit(img)
+            pipe.flush()
+        else:
+            for _ in range(steps):
+                graph.replay() if graph is not None else step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        pipe = None
     return dict(value=img.shape[0] * steps / dt, unit='images/sec (this rank)', ms_per_step=dt / steps * 1e3, steps=steps,
                 precision='fp32', how=how)
 
