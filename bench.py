@@ -160,18 +160,25 @@ def host_results_rate(args, model, img, metas, dev):
     steps = max(args.steps, 8)
 
     def run(n):
-        futs, in_copy, prev = [], [], None
+        # `depth` batches stay in flight behind the one being submitted; a slot's result buffers are overwritten by the LAST
+        # stage of the batch that reuses it, which waits (on the GPU) for the slot's previous device->host copies
+        depth = nstage - 1
+        futs, in_copy, pending, copied = [], [], [], {}
         for _ in range(n):
-            while len(in_copy) > 1:
+            while len(in_copy) > depth + 1:
                 RleCollector.wait_copied(in_copy.pop(0))
-            slot = pipe.submit(img)
-            if prev is not None:
-                f = col.submit(pipe.wait(prev))
+            ev = copied.pop(pipe._n % pipe.slots, None)
+            if ev is not None:
+                pipe.streams[-1].wait_event(ev)
+            pending.append(pipe.submit(img))
+            while len(pending) > depth:
+                old = pending.pop(0)
+                f = col.submit(pipe.wait(old))
                 futs.append(f)
                 in_copy.append(f)
-            prev = slot
-        f = col.submit(pipe.wait(prev))
-        futs.append(f)
+                copied[old] = f.copied
+        for old in pending:
+            futs.append(col.submit(pipe.wait(old)))
         return [r for f in futs for r in f.result()]
     run(3)
     torch.cuda.synchronize()

@@ -1,20 +1,22 @@
-// Encoder-stream FFN block of the MSDeformAttn pixel decoder ([3P] BaseTransformerLayer ('self_attn','norm','ffn','norm'),
-// built at open_set/models/mask2former_head.py:112-117; 6 layers x 43 008 rows at configs[1]) as ONE launch:
+// Post-attention half of an MSDeformAttn encoder layer ([3P] BaseTransformerLayer ('self_attn','norm','ffn','norm'), built at
+// open_set/models/mask2former_head.py:112-117; 6 layers x 43 008 rows at configs[1]) as ONE launch:
 //
-//     y = LayerNorm( x + W2 relu(W1 x + b1) + b2 ),   y16 = bf16(y),  yp16 = bf16(y + pos)     (x: bf16 rows, 256 wide)
+//     x1 = LayerNorm0( x + a Wo^T + bo )                      (PRO: a = attention rows, x = layer input rows; else x1 = x given)
+//     y  = LayerNorm1( x1 + W2 relu(W1 x1 + b1) + b2 )        y16 = bf16(y), yp16 = bf16(y + pos), y32 = y   (each optional)
 //
-// replacing two library GEMMs (256 -> 1024 with a ReLU epilogue, 1024 -> 256) and the residual-LayerNorm pass: the
-// (rows x 1024) hidden activation -- 88 MB written and 88 MB read per layer at configs[1] -- never leaves the chip, the
-// second GEMM's 22-MB output and its re-read by the LayerNorm disappear as well: HBM traffic per layer 220 MB -> 66 MB.
+// replacing three library GEMMs (256 -> 256, 256 -> 1024 with a ReLU epilogue, 1024 -> 256) and two residual-LayerNorm passes:
+// neither the projection output, nor x1, nor the (rows x 1024) hidden activation -- 88 MB written and 88 MB read per layer at
+// configs[1] -- leave the chip: HBM traffic per layer 396 MB -> 66 MB.
 //
-// A workgroup (8 wavefronts, arranged 2 x 4) owns 128 complete rows, held in LDS as bf16 MFMA A-fragment images. The
-// hidden dimension runs in 4 chunks of 256. Wave (wm, wn) computes a 64-row x 64-column block of every GEMM as 2 x 2
-// MFMA tiles: one A-fragment read from LDS and one B-fragment load (packed weight image, straight from L2 into registers,
-// prefetched 4 k-steps ahead) each feed TWO MFMAs -- the first version gave every wave one 32-column tile and paid one
-// 1-KiB LDS read per MFMA, which tied the kernel to the LDS bandwidth (112 us). The chunk's relu(. + b1) block goes back
-// to LDS as A-fragments (pairs of columns exchanged by DPP so that every store is a full 32-bit word) and is consumed by
-// the second GEMM, whose 2 x 2 accumulators persist over the chunks. Epilogue: f32 tile in LDS -> row-major LayerNorm (one
-// wavefront per row, shuffle reductions), bf16 residual rows added there. v_mfma_f32_32x32x16_bf16, f32 accumulation.
+// A workgroup (4 wavefronts) owns 64 complete rows, held in LDS as a bf16 MFMA A-fragment image (bank-swizzled by k-step); two
+// workgroups share a CU. The hidden dimension runs in 4 chunks of 256. Wave wn computes the 64-row x 64-column block of every
+// GEMM as 2 x 2 MFMA tiles: one A-fragment read from LDS and one B-fragment load (packed weights, straight from L2 into registers,
+// 4 k-steps ahead, the queue carried across blocks) each feed TWO MFMAs. The chunk's relu(. + b1) block goes back to LDS as
+// A-fragments (pairs of columns exchanged by DPP so that every store is a full 32-bit word, slots swizzled so that a store
+// instruction hits 64 banks) and is consumed by the second GEMM, whose accumulators persist over the chunks and START as x1 itself
+// (x1 times the identity: 8 MFMAs on the image already in LDS) -- the residual costs no memory access. Epilogue: f32 tile in LDS
+// (it overlays the images) -> row-major LayerNorm, 16 lanes per row, DPP row reductions. v_mfma_f32_32x32x16_bf16, f32 accumulation.
+// What each step bought is listed in DESIGN.md section 4.
 //
 // build-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 // (both accumulator blocks live in VGPRs; the default AGPR form copied the 64 persistent GEMM-2 accumulators in and out of
@@ -117,12 +119,12 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
     const float* __restrict__ beta, float eps, const float* __restrict__ pos, int pos_rows, uint16_t* __restrict__ y16,
     uint16_t* __restrict__ yp16, float* __restrict__ y32, int M, int F, const float* __restrict__ shift, EfLevels lv, EfPro pro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ef_smem[];
-  ef_u32x4* xfrag = reinterpret_cast<ef_u32x4*>(ef_smem);                     // [4 m-tiles][16][64]   64 KiB
-  ef_u32x4* hfrag = xfrag + (EF_RB / 32) * EF_STEPS * 64;                                // [4 m-tiles][16][64]   64 KiB
-  float* tile = reinterpret_cast<float*>(ef_smem);                            // [128][EF_TS] f32, after the GEMMs (130 KiB)
+  ef_u32x4* xfrag = reinterpret_cast<ef_u32x4*>(ef_smem);                     // row image      [2 m-tiles][16][64]   32 KiB
+  ef_u32x4* hfrag = xfrag + (EF_RB / 32) * EF_STEPS * 64;                     // hidden chunk   [2 m-tiles][16][64]   32 KiB
+  float* tile = reinterpret_cast<float*>(ef_smem);                            // [64][EF_TS] f32 LayerNorm tile, overlays both (65 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi5 = lane >> 5;
-  const int wm = wave >> 2, wn = wave & 3;                                    // wave grid (EF_RB / 64 row blocks) x 4 (columns)                                    // wave grid 2 (rows) x 4 (columns)
+  const int wm = wave >> 2, wn = wave & 3;                                    // wave grid (EF_RB / 64 row blocks) x 4 (columns)
   const int m0 = blockIdx.x * EF_RB;
   const int nchunk = F >> 8;
   const int KS2 = F >> 4;                                                     // k-steps of W2

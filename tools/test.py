@@ -147,11 +147,12 @@ def main(argv=None):
             in_copy.append(fut)
 
     def copies_done(keep=0):
-        """the pipeline reuses a slot's device buffers two submits later: their copies must have left by then"""
+        """host-side wait until all but the `keep` newest batches have been copied out of their device buffers"""
         while len(in_copy) > keep:
             RleCollector.wait_copied(in_copy.pop(0))
 
     results, pending = [], []          # pending: (pipeline, slot) pairs -- a slot is only meaningful for ITS pipeline
+    slot_copied = {}                   # (pipeline, slot) -> event: that slot's last results have been copied to the host
     n_img, t0 = 0, None
     pipe = None
     with torch.no_grad(), runtime.precision_scope(args.precision):
@@ -185,12 +186,22 @@ def main(argv=None):
                         torch.cuda.synchronize()
                     if t0 is None:
                         t0, n_img = time.perf_counter(), 0
+                depth = len(pipe.stages) - 1       # batches that may stay in flight behind the one being submitted
                 if collector is not None:
-                    copies_done(keep=1)
+                    copies_done(keep=depth + 1)    # bounds the pinned staging in use; ordering is enforced on the GPU below
+                    # the slot this submit reuses: its previous batch's device->host copies must have left before the LAST stage
+                    # overwrites the result buffers -- a GPU-side wait on that stage's stream, not a host wait
+                    ev = slot_copied.pop((id(pipe), pipe._n % pipe.slots), None)
+                    if ev is not None:
+                        pipe.streams[-1].wait_event(ev)
                 slot = pipe.submit(imgs)
-                # results of the PREVIOUS batch are copied out while this one runs (slot buffers are reused 2 batches later)
-                drain()
                 pending.append((pipe, slot))
+                # results of the batch `depth` submits back are copied out while the newer ones run
+                while len(pending) > depth:
+                    owner, old_slot = pending.pop(0)
+                    emit(owner.wait(old_slot))
+                    if collector is not None:
+                        slot_copied[(id(owner), old_slot)] = in_copy[-1].copied
             else:
                 drain()                # keep dataset order: earlier batches first
                 if t0 is None:
