@@ -181,10 +181,8 @@ class FFN(nn.Module):
                 # training in throughput mode: ONE autocast region for both projections, so the hidden activation
                 # (B x N x 1024: 1.4 GB in f32 at configs[2]) stays bf16 between them -- `runtime.linear` would widen it
                 # to f32, apply the ReLU there and narrow it again: ~5.6 GB of extra traffic per layer and direction
-                with runtime.autocast():
-                    h = F.relu(F.linear(x, self.layers[0][0].weight, self.layers[0][0].bias))
-                    out = F.linear(h, self.layers[1].weight, self.layers[1].bias)
-                out = out.float()
+                h = F.relu(runtime.linear_bf16_train(x, self.layers[0][0].weight, self.layers[0][0].bias))
+                out = runtime.linear_bf16_train(h, self.layers[1].weight, self.layers[1].bias).float()
             else:
                 h = torch.relu_(runtime.linear(x, self.layers[0][0].weight, self.layers[0][0].bias))
                 out = runtime.linear(h, self.layers[1].weight, self.layers[1].bias)

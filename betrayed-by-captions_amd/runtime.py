@@ -85,6 +85,56 @@ def cast_cache_replace(p, t, dtype=torch.bfloat16):
     _WCACHE[_wkey(p, dtype)] = (weakref.ref(base), base._version, t)
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+    """Training-time `F.linear` in bf16 for operands with VERY many rows (the encoder stream: B * 21 504 rows). Forward and
+    grad-input are the library GEMMs autocast would run; the weight gradient dW = dY^T X has a tiny output (<= 1024 x 256) and a
+    reduction over all rows -- the library picks a 64 x 64 tile without split-K and leaves 240 of 256 CUs idle (0.66 ms for
+    45 GFLOP at configs[2]). Here the rows are cut into S slabs, ONE batched GEMM produces S partial gradients (S x 16+ tiles)
+    and their f32 sum is the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        import torch.nn.functional as F
+        x16 = x.to(torch.bfloat16)
+        w16 = weight.to(torch.bfloat16)
+        y = F.linear(x16, w16, bias.to(torch.bfloat16) if bias is not None else None)
+        ctx.save_for_backward(x16, w16)
+        ctx.x_dtype = x.dtype
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x16, w16 = ctx.saved_tensors
+        N, K = w16.shape
+        g2 = gy.reshape(-1, N).to(torch.bfloat16)
+        x2 = x16.reshape(-1, K)
+        M = x2.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ w16).view(x16.shape).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            S = next((s for s in (32, 16, 8, 4, 2) if M % s == 0 and M // s >= 4096), 1)
+            gw = torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)).sum(0, dtype=torch.float32)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0, dtype=torch.float32)
+        return gx, gw, gb
+
+
+SPLITK_WGRAD_ROWS = 32768          # rows from which the training linears use `_SplitKLinearFn` (CGG_SPLITK_WGRAD=0 disables)
+
+
+def linear_bf16_train(x, weight, bias=None):
+    """bf16 `F.linear` for the training step (returns bf16): split-K weight gradient for huge row counts, autocast otherwise."""
+    import os
+    import torch.nn.functional as F
+    rows = x.numel() // x.shape[-1]
+    if rows >= SPLITK_WGRAD_ROWS and weight.requires_grad and os.environ.get('CGG_SPLITK_WGRAD', '1') != '0':
+        return _SplitKLinearFn.apply(x, weight, bias)
+    with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+        return F.linear(x, weight, bias)
+
+
 def linear(x, weight, bias=None):
     """Large-M library GEMM (hipBLASLt): f32 in parity mode, bf16 operands (f32 accumulate) in throughput
     mode with the bf16 weight copy cached. Returns f32."""
@@ -93,8 +143,7 @@ def linear(x, weight, bias=None):
         y = F.linear(x.to(torch.bfloat16), cast_cached(weight), cast_cached(bias) if bias is not None else None)
         return y.float()
     if is_bf16():
-        with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
-            return F.linear(x, weight, bias).float()
+        return linear_bf16_train(x, weight, bias).float()
     return F.linear(x, weight, bias)
 
 
