@@ -180,7 +180,7 @@ def main(argv=None):
                     pipe = pipes.get(key)
                     if pipe is None:
                         from cgg_amd.pipeline import detector_pipeline
-                        pipe = detector_pipeline(model, imgs, metas, stages=3, defer_tail=False, rescale=True, device_results=True, mask_bits=args.mask_bits)
+                        pipe = detector_pipeline(model, imgs, metas, stages=int(os.environ.get('CGG_TEST_STAGES', '3')), defer_tail=False, rescale=True, device_results=True, mask_bits=args.mask_bits)
                         pipe.meta_key = key
                         pipes[key] = pipe
                         torch.cuda.synchronize()
