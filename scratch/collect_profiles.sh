@@ -27,7 +27,7 @@ python scratch/ml_bwd_bench.py > $O/ml_bwd_bench.txt 2>> $O/bench_line.err
 python scratch/msda_ab.py > $O/msda_ab.txt 2>> $O/bench_line.err
 python scratch/ffn_bench.py > $O/encoder_ffn_bench.txt 2>> $O/bench_line.err
 python scratch/proj_bench.py > $O/encoder_proj_bench.txt 2>> $O/bench_line.err
-python scratch/serve_bench.py 128 2>> $O/bench_line.err | grep images > $O/serve_bench.txt
+python scratch/serve_bench.py 128 2>> $O/bench_line.err | grep images > $O/serve_bench.txt   # one process per result format
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/train_prof -- python3 $R/bench.py --mode train --steps 3 --warmup 2 > /dev/null 2>&1
 python3 $R/scratch/train_step_prof.py /tmp/train_prof > $O/train_top.txt
