@@ -768,6 +768,57 @@ def encoder_layer_tail(a16, x16, wop, bo, norm0, w1p, b1, w2p, b2, norm1, pos=No
     return y32, y16, yp16
 
 
+def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False):
+    """Backward of LN(a + b) over the last dim (256): returns (dx f32, bf16(dx) | None, dgamma, dbeta); d/da = d/db = dx."""
+    N = a.shape[-1]
+    rows = a.numel() // N
+    dx = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    dx16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
+    nb = _lib_().cgg_add_layernorm_backward_partials(rows)
+    partial = torch.empty((nb, 2 * N), dtype=torch.float32, device=a.device)
+    bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
+    rc = _lib_().cgg_add_layernorm_backward(dev_ptr(dy, 'dy', torch.float32), dev_ptr(a, 'a', torch.float32), dev_ptr(b, 'b'), bdt,
+                                            dev_ptr(gamma, 'gamma', torch.float32), float(eps), dev_ptr(dx), dev_ptr(dx16),
+                                            dev_ptr(partial), rows, N, stream_ptr(a.device))
+    check(rc, 'cgg_add_layernorm_backward')
+    sums = partial.sum(0)
+    return dx, dx16, sums[:N], sums[N:]
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(a + b) (a f32, b f32 | bf16, 256 channels) with the one-pass HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        a = a.contiguous()
+        b = b.contiguous()
+        y, _, _ = add_layernorm_stream(a, b, gamma, beta, eps, want_f32=True, want_bf16=False)
+        ctx.save_for_backward(a, b, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, b, gamma = ctx.saved_tensors
+        dx, dx16, dgamma, dbeta = add_layernorm_backward(gy.contiguous().float(), a, b, gamma, ctx.eps,
+                                                         want_bf16=b.dtype == torch.bfloat16 and ctx.needs_input_grad[1])
+        gb = None
+        if ctx.needs_input_grad[1]:
+            gb = dx16 if b.dtype == torch.bfloat16 else dx
+        return (dx if ctx.needs_input_grad[0] else None), gb, dgamma, dbeta, None
+
+
+def add_layernorm_train_ok(a, b, norm):
+    return (a.is_cuda and a.dtype == torch.float32 and a.shape[-1] == 256 and b.shape == a.shape
+            and b.dtype in (torch.float32, torch.bfloat16) and tuple(norm.normalized_shape) == (256,) and norm.elementwise_affine
+            and norm.bias is not None)
+
+
+def add_layernorm_train(a, b, norm):
+    """LayerNorm(a + b) of an `nn.LayerNorm(256)` for the training step (autograd-aware)."""
+    return _AddLayerNormFn.apply(a, b, norm.weight, norm.bias, norm.eps)
+
+
 def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=True):
     """Last encoder LayerNorm of the inference stream: y = LN(a + b) (a (B, S, 256) f32, b f32|bf16|None) plus the
     query decoder's K / V operands m16 = bf16(y + shift[s]), mp16 = bf16(y + shift[s] + pos[s]) (shift, pos (S, 256)

@@ -30,6 +30,7 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
 FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
 FUSED_TAIL = os.environ.get('CGG_FUSED_TAIL', '1') != '0'   # ... preceded by output_proj + its residual LayerNorm
 FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
+FUSED_TRAIN_LN = os.environ.get('CGG_FUSED_TRAIN_LN', '1') != '0'   # training: residual + LayerNorm as one-pass HIP fwd / bwd
 VALUE_HEAD_MAJOR = os.environ.get('CGG_VALUE_HEAD_MAJOR', '1') != '0'   # value written (B, 8, N, 32) for the MSDeformAttn gather
 POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
 
@@ -174,6 +175,16 @@ class FFN(nn.Module):
         self.dropout_layer = nn.Dropout(dropout_layer['drop_prob']) if dropout_layer else nn.Identity()
         self.add_identity = add_identity
 
+    def forward_bf16_noidentity(self, x):
+        """Training, bf16 mode: W2 relu(W1 x + b1) + b2 in bf16 WITHOUT the residual (it is added inside the fused LayerNorm)."""
+        h = F.relu(runtime.linear_bf16_train(x, self.layers[0][0].weight, self.layers[0][0].bias))
+        return runtime.linear_bf16_train(h, self.layers[1].weight, self.layers[1].bias)
+
+    def plain_relu_ffn(self):
+        return (len(self.layers) == 3 and isinstance(self.layers[0][1], nn.ReLU) and self.layers[0][2].p == 0
+                and self.layers[2].p == 0 and self.add_identity
+                and (isinstance(self.dropout_layer, nn.Identity) or getattr(self.dropout_layer, 'p', 1) == 0))
+
     def forward(self, x, identity=None):
         if len(self.layers) == 3 and isinstance(self.layers[0][1], nn.ReLU) and self.layers[0][2].p == 0 \
                 and self.layers[2].p == 0:
@@ -236,9 +247,10 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.constant_(self.output_proj.bias, 0.)
 
     # -- fast path used by MSDeformAttnPixelDecoder (batch-first, fused prologue, forward-only) ----
-    def forward_fused(self, src, src_pos, ref_points, level_hw, level_start):
+    def forward_fused(self, src, src_pos, ref_points, level_hw, level_start, add_identity=True):
         """src (B,N,C) f32 (value input and identity), src_pos = src + pos (query input),
-        ref_points (N,2). Returns identity + dropout(output_proj(msda))."""
+        ref_points (N,2). Returns identity + dropout(output_proj(msda)); add_identity=False (training, bf16 mode, no dropout):
+        the bf16 output projection alone, for the fused residual + LayerNorm (`ops.add_layernorm_train`)."""
         B, N, C = src.shape
         H, D = self.num_heads, C // self.num_heads
         w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
@@ -273,6 +285,8 @@ class MultiScaleDeformableAttention(nn.Module):
         else:
             out = ops.msda_forward_fused(value.contiguous(), level_hw, level_start,
                                          offs_logits.contiguous(), ref_points, self.num_points)
+        if not add_identity:
+            return runtime.linear_bf16_train(out, self.output_proj.weight, self.output_proj.bias)
         out = runtime.linear(out, self.output_proj.weight, self.output_proj.bias)
         return src + self.dropout(out)
 
@@ -791,7 +805,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
             src = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start)
         else:
             for layer in self.encoder.layers:
-                attn = layer.attentions[0]
+                attn, ffn = layer.attentions[0], layer.ffns[0]
+                if (FUSED_TRAIN_LN and runtime.is_bf16() and torch.is_grad_enabled() and src.is_cuda and src.shape[-1] == 256
+                        and attn.dropout.p == 0 and ffn.plain_relu_ffn() and isinstance(layer.norms[0], nn.LayerNorm)
+                        and isinstance(layer.norms[1], nn.LayerNorm)):
+                    # training: the branch outputs stay bf16 and the residual add happens INSIDE one-pass LayerNorm kernels
+                    # (forward and backward) instead of cast + add + layer_norm (+ their three backward kernels) per norm
+                    out16 = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start, add_identity=False)
+                    src = ops.add_layernorm_train(src, out16, layer.norms[0])
+                    src = ops.add_layernorm_train(src, ffn.forward_bf16_noidentity(src), layer.norms[1])
+                    continue
                 src = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start)
                 src = layer.norms[0](src)
                 src = layer.ffns[0](src)

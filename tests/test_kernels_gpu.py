@@ -1345,3 +1345,35 @@ def test_msda_head_major_value_path_is_bit_identical(dev):
     a = ops.msda_forward_fused_bf16(v_rows.view(B, N, 8, 32), shapes, starts, offs, ref_pts, 4)
     b = ops.msda_forward_fused_bf16(v_hm, shapes, starts, offs, ref_pts, 4, head_major=True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('rows,bdt', [(344064, torch.bfloat16), (4071, torch.float32), (37, torch.bfloat16)])
+def test_add_layernorm_train_forward_backward_vs_autograd(dev, rows, bdt):
+    """One-pass LayerNorm(a + b) forward + backward (training encoder stream) against torch autograd of the same expression in
+    float64: y and d/da within 2e-5 (f32 arithmetic), d/db the bf16 rounding of d/da for a bf16 b, dgamma / dbeta (sums over
+    all rows) within 1e-4 relative to their scale; ragged row counts."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows)
+    a = torch.randn(rows, 256, generator=g).to(dev).requires_grad_(True)
+    b = (torch.randn(rows, 256, generator=g) * 0.5).to(dev).to(bdt).requires_grad_(True)
+    norm = torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(256, generator=g).to(dev) + 0.5)
+        norm.bias.copy_(torch.randn(256, generator=g).to(dev) * 0.1)
+    gy = torch.randn(rows, 256, generator=g).to(dev)
+    assert ops.add_layernorm_train_ok(a, b, norm)
+    y = ops.add_layernorm_train(a, b, norm)
+    y.backward(gy)
+    got = (y.detach(), a.grad.clone(), b.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone())
+    a64 = a.detach().double().requires_grad_(True)
+    b64 = b.detach().double().requires_grad_(True)
+    w64 = norm.weight.detach().double().requires_grad_(True)
+    c64 = norm.bias.detach().double().requires_grad_(True)
+    y64 = F.layer_norm(a64 + b64, (256,), w64, c64, norm.eps)
+    y64.backward(gy.double())
+    assert (got[0].double() - y64.detach()).abs().max().item() <= 2e-5
+    assert (got[1].double() - a64.grad).abs().max().item() <= 2e-5 * max(1.0, a64.grad.abs().max().item())
+    tol_b = 2 ** -8 if bdt == torch.bfloat16 else 2e-5
+    assert ((got[2].double() - b64.grad).abs() / b64.grad.abs().clamp_min(1.0)).max().item() <= tol_b
+    assert (got[3].double() - w64.grad).abs().max().item() <= 1e-4 * max(1.0, w64.grad.abs().max().item())
+    assert (got[4].double() - c64.grad).abs().max().item() <= 1e-4 * max(1.0, c64.grad.abs().max().item())
