@@ -4,6 +4,7 @@
 // grad input) at ~1.9 TB/s; here the forward is cgg_add_layernorm_ex (one pass) and the backward ONE pass:
 //
 //     s = a + b,  xhat = (s - mean(s)) * rstd(s)                                   (statistics recomputed from the row: nothing saved)
+//     dy = dy32 + dy16a + dy16b   (any subset: the forward can also emit bf16(y) and bf16(y + pos), whose gradients arrive in bf16)
 //     g = dy * gamma,   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))           d/da = d/db = dx   (dx16 = bf16(dx), optional)
 //     dgamma = sum_rows dy * xhat,   dbeta = sum_rows dy                            as per-workgroup partials (summed by the caller)
 //
@@ -29,7 +30,8 @@ __device__ __forceinline__ f32x4 lnb_load4(const uint16_t* p) {
 }
 
 template <typename BT>
-__global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float* __restrict__ dy, const uint16_t* __restrict__ dy16a,
+                                                                   const uint16_t* __restrict__ dy16b, const float* __restrict__ a,
                                                                    const BT* __restrict__ b, const float* __restrict__ gamma,
                                                                    float eps, float* __restrict__ dx, uint16_t* __restrict__ dx16,
                                                                    float* __restrict__ partial, int rows) {
@@ -56,7 +58,9 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
     for (int k = 0; k < 4; ++k) {
       s[k] = lnb_load4(a + off + 64 * k);
       if (b != nullptr) s[k] += lnb_load4(b + off + 64 * k);
-      y[k] = lnb_load4(dy + off + 64 * k);
+      y[k] = dy != nullptr ? lnb_load4(dy + off + 64 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dy16a != nullptr) y[k] += lnb_load4(dy16a + off + 64 * k);
+      if (dy16b != nullptr) y[k] += lnb_load4(dy16b + off + 64 * k);
       sm += (s[k][0] + s[k][1]) + (s[k][2] + s[k][3]);
     }
     const float mean = lnb_row16_sum(sm) * inv_n;
@@ -113,21 +117,22 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
 
 extern "C" int64_t cgg_add_layernorm_backward_partials(int rows) { return rows > 0 ? (int64_t)((rows + LNB_ROWS - 1) / LNB_ROWS) : 0; }
 
-extern "C" int cgg_add_layernorm_backward(const float* dy, const float* a, const void* b, int b_dtype, const float* gamma, float eps,
-                                          float* dx, void* dx16, float* partial, int rows, int N, cgg_stream_t stream) {
-  CGG_REQUIRE(dy && a && gamma && dx && partial, CGG_EINVAL, "cgg_add_layernorm_backward: null pointer");
+extern "C" int cgg_add_layernorm_backward(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b,
+                                          int b_dtype, const float* gamma, float eps, float* dx, void* dx16, float* partial,
+                                          int rows, int N, cgg_stream_t stream) {
+  CGG_REQUIRE((dy || dy16a || dy16b) && a && gamma && dx && partial, CGG_EINVAL, "cgg_add_layernorm_backward: null pointer");
   CGG_REQUIRE(rows > 0 && N == 256, CGG_EUNSUPPORTED, "cgg_add_layernorm_backward: rows=%d N=%d (only N = 256 is built)", rows, N);
   CGG_REQUIRE(b_dtype == CGG_F32 || b_dtype == CGG_BF16, CGG_EUNSUPPORTED, "cgg_add_layernorm_backward: b dtype %d", b_dtype);
-  CGG_REQUIRE(cgg_aligned16(dy) && cgg_aligned16(a) && (!b || cgg_aligned16(b)) && cgg_aligned16(gamma) && cgg_aligned16(dx) &&
+  CGG_REQUIRE((!dy || cgg_aligned16(dy)) && (!dy16a || cgg_aligned16(dy16a)) && (!dy16b || cgg_aligned16(dy16b)) && cgg_aligned16(a) && (!b || cgg_aligned16(b)) && cgg_aligned16(gamma) && cgg_aligned16(dx) &&
                   (!dx16 || cgg_aligned16(dx16)),
               CGG_EALIGN, "cgg_add_layernorm_backward: 16-B alignment");
   const dim3 grid((rows + LNB_ROWS - 1) / LNB_ROWS), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (b_dtype == CGG_BF16)
-    hipLaunchKernelGGL(cgg_add_layernorm_bwd_kernel<uint16_t>, grid, block, 0, s, dy, a, (const uint16_t*)b, gamma, eps, dx,
+    hipLaunchKernelGGL(cgg_add_layernorm_bwd_kernel<uint16_t>, grid, block, 0, s, dy, (const uint16_t*)dy16a, (const uint16_t*)dy16b, a, (const uint16_t*)b, gamma, eps, dx,
                        (uint16_t*)dx16, partial, rows);
   else
-    hipLaunchKernelGGL(cgg_add_layernorm_bwd_kernel<float>, grid, block, 0, s, dy, a, (const float*)b, gamma, eps, dx,
+    hipLaunchKernelGGL(cgg_add_layernorm_bwd_kernel<float>, grid, block, 0, s, dy, (const uint16_t*)dy16a, (const uint16_t*)dy16b, a, (const float*)b, gamma, eps, dx,
                        (uint16_t*)dx16, partial, rows);
   CGG_CHECK_LAUNCH("cgg_add_layernorm_backward");
   return CGG_OK;

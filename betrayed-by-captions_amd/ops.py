@@ -768,8 +768,9 @@ def encoder_layer_tail(a16, x16, wop, bo, norm0, w1p, b1, w2p, b2, norm1, pos=No
     return y32, y16, yp16
 
 
-def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False):
-    """Backward of LN(a + b) over the last dim (256): returns (dx f32, bf16(dx) | None, dgamma, dbeta); d/da = d/db = dx."""
+def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False, dy16a=None, dy16b=None):
+    """Backward of LN(a + b) over the last dim (256) for the upstream gradient dy (f32) + dy16a + dy16b (bf16; any subset):
+    returns (dx f32, bf16(dx) | None, dgamma, dbeta); d/da = d/db = dx."""
     N = a.shape[-1]
     rows = a.numel() // N
     dx = torch.empty(a.shape, dtype=torch.float32, device=a.device)
@@ -777,35 +778,46 @@ def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False):
     nb = _lib_().cgg_add_layernorm_backward_partials(rows)
     partial = torch.empty((nb, 2 * N), dtype=torch.float32, device=a.device)
     bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
-    rc = _lib_().cgg_add_layernorm_backward(dev_ptr(dy, 'dy', torch.float32), dev_ptr(a, 'a', torch.float32), dev_ptr(b, 'b'), bdt,
-                                            dev_ptr(gamma, 'gamma', torch.float32), float(eps), dev_ptr(dx), dev_ptr(dx16),
-                                            dev_ptr(partial), rows, N, stream_ptr(a.device))
+    rc = _lib_().cgg_add_layernorm_backward(dev_ptr(dy, 'dy', torch.float32), dev_ptr(dy16a, 'dy16a', torch.bfloat16),
+                                            dev_ptr(dy16b, 'dy16b', torch.bfloat16), dev_ptr(a, 'a', torch.float32),
+                                            dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32), float(eps),
+                                            dev_ptr(dx), dev_ptr(dx16), dev_ptr(partial), rows, N, stream_ptr(a.device))
     check(rc, 'cgg_add_layernorm_backward')
     sums = partial.sum(0)
     return dx, dx16, sums[:N], sums[N:]
 
 
 class _AddLayerNormFn(torch.autograd.Function):
-    """y = LayerNorm(a + b) (a f32, b f32 | bf16, 256 channels) with the one-pass HIP forward and backward."""
+    """(y, bf16(y) | None, bf16(y + pos) | None) = LayerNorm(a + b) (a f32, b f32 | bf16, 256 channels) with the one-pass HIP
+    forward and backward; the bf16 outputs feed the next bf16 GEMMs directly (no cast pass) and their bf16 gradients are summed
+    with dy inside the backward kernel (no accumulation pass)."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, eps):
+    def forward(ctx, a, b, gamma, beta, eps, pos, want16, wantp):
         a = a.contiguous()
         b = b.contiguous()
-        y, _, _ = add_layernorm_stream(a, b, gamma, beta, eps, want_f32=True, want_bf16=False)
+        y, y16, yp16 = add_layernorm_stream(a, b, gamma, beta, eps, pos=pos if wantp else None, want_f32=True,
+                                            want_bf16=bool(want16), want_pos=bool(wantp))
         ctx.save_for_backward(a, b, gamma)
         ctx.eps = eps
-        return y
+        ctx.pos_shape = tuple(pos.shape) if (pos is not None and wantp) else None
+        return y, y16, yp16
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gy16, gyp16):
         a, b, gamma = ctx.saved_tensors
-        dx, dx16, dgamma, dbeta = add_layernorm_backward(gy.contiguous().float(), a, b, gamma, ctx.eps,
-                                                         want_bf16=b.dtype == torch.bfloat16 and ctx.needs_input_grad[1])
+        c = lambda t, dt: None if t is None else t.contiguous().to(dt)
+        dx, dx16, dgamma, dbeta = add_layernorm_backward(c(gy, torch.float32), a, b, gamma, ctx.eps,
+                                                         want_bf16=b.dtype == torch.bfloat16 and ctx.needs_input_grad[1],
+                                                         dy16a=c(gy16, torch.bfloat16), dy16b=c(gyp16, torch.bfloat16))
         gb = None
         if ctx.needs_input_grad[1]:
             gb = dx16 if b.dtype == torch.bfloat16 else dx
-        return (dx if ctx.needs_input_grad[0] else None), gb, dgamma, dbeta, None
+        gpos = None
+        if ctx.pos_shape is not None and gyp16 is not None and ctx.needs_input_grad[5]:
+            # yp = y + pos[row % len(pos)]: the table's gradient is the sum of the bf16 gradient over the repeats (the batch)
+            gpos = gyp16.reshape((-1,) + ctx.pos_shape).sum(0, dtype=torch.float32)
+        return (dx if ctx.needs_input_grad[0] else None), gb, dgamma, dbeta, None, gpos, None, None
 
 
 def add_layernorm_train_ok(a, b, norm):
@@ -814,9 +826,13 @@ def add_layernorm_train_ok(a, b, norm):
             and norm.bias is not None)
 
 
-def add_layernorm_train(a, b, norm):
-    """LayerNorm(a + b) of an `nn.LayerNorm(256)` for the training step (autograd-aware)."""
-    return _AddLayerNormFn.apply(a, b, norm.weight, norm.bias, norm.eps)
+def add_layernorm_train(a, b, norm, pos=None, want_bf16=False, want_pos=False):
+    """LayerNorm(a + b) of an `nn.LayerNorm(256)` for the training step (autograd-aware). Returns y, or with want_bf16 / want_pos
+    the triple (y, bf16(y) | None, bf16(y + pos[row % len(pos)]) | None)."""
+    y, y16, yp16 = _AddLayerNormFn.apply(a, b, norm.weight, norm.bias, norm.eps, pos, want_bf16, want_pos)
+    if want_bf16 or want_pos:
+        return y, y16, yp16
+    return y
 
 
 def add_layernorm_kv(a, b, gamma, beta, eps, shift, pos, level_start, want_f32=True):

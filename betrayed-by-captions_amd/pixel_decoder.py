@@ -247,7 +247,7 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.constant_(self.output_proj.bias, 0.)
 
     # -- fast path used by MSDeformAttnPixelDecoder (batch-first, fused prologue, forward-only) ----
-    def forward_fused(self, src, src_pos, ref_points, level_hw, level_start, add_identity=True):
+    def forward_fused(self, src, src_pos, ref_points, level_hw, level_start, add_identity=True, src16=None, src_pos16=None):
         """src (B,N,C) f32 (value input and identity), src_pos = src + pos (query input),
         ref_points (N,2). Returns identity + dropout(output_proj(msda)); add_identity=False (training, bf16 mode, no dropout):
         the bf16 output projection alone, for the fused residual + LayerNorm (`ops.add_layernorm_train`)."""
@@ -255,12 +255,18 @@ class MultiScaleDeformableAttention(nn.Module):
         H, D = self.num_heads, C // self.num_heads
         w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        if runtime.is_bf16() and not torch.is_grad_enabled():
+        if src16 is not None:
+            # training, bf16 mode: the bf16 copies of src / src + pos come from the previous LayerNorm kernel (no cast passes)
+            value = runtime.linear_bf16_train(src16, self.value_proj.weight, self.value_proj.bias).float()
+            offs_logits = runtime.linear_bf16_train(src_pos16, w_cat, b_cat).float()
+        elif runtime.is_bf16() and not torch.is_grad_enabled():
             value = F.linear(src.to(torch.bfloat16), runtime.cast_cached(self.value_proj.weight),
                              runtime.cast_cached(self.value_proj.bias))      # bf16 values for the gather
         else:
             value = runtime.linear(src, self.value_proj.weight, self.value_proj.bias)
-        if runtime.is_bf16() and torch.is_grad_enabled():
+        if src16 is not None:
+            pass
+        elif runtime.is_bf16() and torch.is_grad_enabled():
             # training in throughput mode: bf16 operands like the inference stream (whose kernel reads bf16 offset rows);
             # the f32 GEMM and its two backward GEMMs cost 11 ms per step at configs[2]
             offs_logits = runtime.linear(src_pos, w_cat, b_cat)
@@ -804,17 +810,28 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 all(self._stream_ok(l) for l in self.encoder.layers):
             src = self._encoder_stream_bf16(src, pos, ref, level_hw, level_start)
         else:
-            for layer in self.encoder.layers:
-                attn, ffn = layer.attentions[0], layer.ffns[0]
-                if (FUSED_TRAIN_LN and runtime.is_bf16() and torch.is_grad_enabled() and src.is_cuda and src.shape[-1] == 256
-                        and attn.dropout.p == 0 and ffn.plain_relu_ffn() and isinstance(layer.norms[0], nn.LayerNorm)
-                        and isinstance(layer.norms[1], nn.LayerNorm)):
-                    # training: the branch outputs stay bf16 and the residual add happens INSIDE one-pass LayerNorm kernels
-                    # (forward and backward) instead of cast + add + layer_norm (+ their three backward kernels) per norm
-                    out16 = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start, add_identity=False)
-                    src = ops.add_layernorm_train(src, out16, layer.norms[0])
-                    src = ops.add_layernorm_train(src, ffn.forward_bf16_noidentity(src), layer.norms[1])
-                    continue
+            fused_ln = (FUSED_TRAIN_LN and runtime.is_bf16() and torch.is_grad_enabled() and src.is_cuda and src.shape[-1] == 256
+                        and all(l.attentions[0].dropout.p == 0 and l.ffns[0].plain_relu_ffn()
+                                and isinstance(l.norms[0], nn.LayerNorm) and isinstance(l.norms[1], nn.LayerNorm)
+                                for l in self.encoder.layers))
+            if fused_ln:
+                # training: the branch outputs stay bf16, the residual add happens INSIDE one-pass LayerNorm kernels (forward and
+                # backward) instead of cast + add + layer_norm (+ their three backward kernels) per norm, and the same kernels
+                # emit the bf16 copies (x, x + pos) the next GEMMs read -- whose bf16 gradients they sum again on the way back
+                pos_c = pos.contiguous()                      # differentiable: the level embedding is part of it
+                src16, srcp16 = src.to(torch.bfloat16), (src + pos[None]).to(torch.bfloat16)
+                n_layers = len(self.encoder.layers)
+                for li, layer in enumerate(self.encoder.layers):
+                    attn, ffn = layer.attentions[0], layer.ffns[0]
+                    out16 = attn.forward_fused(src, None, ref, level_hw, level_start, add_identity=False, src16=src16,
+                                               src_pos16=srcp16)
+                    mid, mid16, _ = ops.add_layernorm_train(src, out16, layer.norms[0], want_bf16=True)
+                    last = li == n_layers - 1
+                    nxt = ops.add_layernorm_train(mid, ffn.forward_bf16_noidentity(mid16), layer.norms[1], pos=pos_c,
+                                                  want_bf16=not last, want_pos=not last)
+                    src, src16, srcp16 = nxt if not last else (nxt, None, None)
+            for layer in ([] if fused_ln else self.encoder.layers):
+                attn = layer.attentions[0]
                 src = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start)
                 src = layer.norms[0](src)
                 src = layer.ffns[0](src)

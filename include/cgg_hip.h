@@ -362,12 +362,14 @@ int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype,
                          float eps, cgg_stream_t stream);
 
 /* Backward of y = LayerNorm(a + b) over N = 256 channels (training; forward = cgg_add_layernorm_ex): one pass over the rows,
- * statistics recomputed, d/da = d/db = dx (f32; dx16 = optional bf16 copy for a bf16 `b`), per-workgroup partial sums of
+ * statistics recomputed, upstream gradient = dy (f32) + dy16a + dy16b (bf16 gradients of the forward's bf16(y) / bf16(y + pos)
+ * outputs; each nullable, at least one given), d/da = d/db = dx (f32; dx16 = optional bf16 copy for a bf16 `b`), per-workgroup partial sums of
  * (dgamma | dbeta): partial (cgg_add_layernorm_backward_partials(rows), 512) f32, to be summed over dim 0 by the caller.
  * Replaces autograd's add / layer_norm backward kernels on the encoder stream of [3P] BaseTransformerLayer. */
 int64_t cgg_add_layernorm_backward_partials(int rows);
-int cgg_add_layernorm_backward(const float* dy, const float* a, const void* b, int b_dtype, const float* gamma, float eps, float* dx,
-                               void* dx16, float* partial, int rows, int N, cgg_stream_t stream);
+int cgg_add_layernorm_backward(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b, int b_dtype,
+                               const float* gamma, float eps, float* dx, void* dx16, float* partial, int rows, int N,
+                               cgg_stream_t stream);
 
 /* Input projections of one MSDeformAttn encoder layer as ONE launch ([3P] MultiScaleDeformableAttention.forward:
  * value_proj / sampling_offsets / attention_weights; layers built at open_set/models/mask2former_head.py:112-117):

@@ -1377,3 +1377,31 @@ def test_add_layernorm_train_forward_backward_vs_autograd(dev, rows, bdt):
     assert ((got[2].double() - b64.grad).abs() / b64.grad.abs().clamp_min(1.0)).max().item() <= tol_b
     assert (got[3].double() - w64.grad).abs().max().item() <= 1e-4 * max(1.0, w64.grad.abs().max().item())
     assert (got[4].double() - c64.grad).abs().max().item() <= 1e-4 * max(1.0, c64.grad.abs().max().item())
+
+
+def test_add_layernorm_train_bf16_outputs_and_their_gradients(dev):
+    """The three-output form: (y, bf16(y), bf16(y + pos)) with gradients arriving on all three (f32, bf16, bf16) and flowing to
+    a, b, gamma, beta AND the pos table (sum over the batch repeats) == torch autograd of the same graph in float64 up to the
+    bf16 rounding of the two bf16 gradients' sum path (they are added in f32 inside the kernel: 2e-5) ."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 1357
+    a = torch.randn(B, N, 256, generator=g).to(dev).requires_grad_(True)
+    b = (torch.randn(B, N, 256, generator=g) * 0.5).to(dev).bfloat16().requires_grad_(True)
+    pos = torch.randn(N, 256, generator=g).to(dev).requires_grad_(True)
+    norm = torch.nn.LayerNorm(256).to(dev)
+    gy = torch.randn(B, N, 256, generator=g).to(dev)
+    g16 = torch.randn(B, N, 256, generator=g).to(dev).bfloat16()
+    gp16 = torch.randn(B, N, 256, generator=g).to(dev).bfloat16()
+    y, y16, yp16 = ops.add_layernorm_train(a, b, norm, pos=pos, want_bf16=True, want_pos=True)
+    torch.autograd.backward([y, y16, yp16], [gy, g16, gp16])
+    a64, b64, p64 = (t.detach().double().requires_grad_(True) for t in (a, b, pos))
+    w64, c64 = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    y64 = F.layer_norm(a64 + b64, (256,), w64, c64, norm.eps)
+    torch.autograd.backward([y64, y64, y64 + p64[None]], [gy.double(), g16.double(), gp16.double()])
+    assert (y.double() - y64).abs().max().item() <= 2e-5
+    assert (y16.double() - y64).abs().max().item() <= 2 ** -6 and (yp16.double() - (y64 + p64[None])).abs().max().item() <= 2 ** -5
+    assert (a.grad.double() - a64.grad).abs().max().item() <= 1e-4
+    assert ((b.grad.double() - b64.grad).abs() / b64.grad.abs().clamp_min(1.0)).max().item() <= 2 ** -8
+    assert (pos.grad.double() - p64.grad).abs().max().item() <= 1e-4
+    assert (norm.weight.grad.double() - w64.grad).abs().max().item() <= 1e-3 and (norm.bias.grad.double() - c64.grad).abs().max().item() <= 1e-3
