@@ -61,6 +61,8 @@ PROTOTYPES = {
     'cgg_decoder_ffn_bf16': (_c_int, [_c_vp, _c_int] + [_c_vp] * 5 + [_c_int] * 3 + [_c_vp]),
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
+    'cgg_msda_prologue': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
+    'cgg_msda_prologue_backward': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_msda_forward_fused_bf16': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 7 + [_c_vp]),
     'cgg_msda_forward_fused_bf16_hm': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 7 + [_c_vp]),
     'cgg_decoder_kv_pack_k': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp]),

@@ -1012,3 +1012,236 @@ extern "C" int cgg_msda_forward_fused_bf16_hm(const void* value, const int32_t* 
                                               int B, int Nv, int H, int D, int L, int Nq, int P, cgg_stream_t stream) {
   return msda_fused_bf16_impl(true, value, level_hw, level_start, offs_logits, ld, ref_points, out, B, Nv, H, D, L, Nq, P, stream);
 }
+
+// -------------------------------------------------------------------------------------------------
+// Training: the prologue of MSDeformAttn ([3P] MultiScaleDeformableAttention.forward: `sampling_offsets(query)` ->
+// `reference_points + offsets / (W_l, H_l)`, `attention_weights(query).softmax(-1)`) and its backward as TWO elementwise kernels
+// around the gather's backward, instead of ~10 autograd-recorded torch passes over (B, Nq, H, L, P[, 2]) tensors per layer:
+//   prologue:  rows (B*Nq, ld) f32 = [offsets H*L*P*2 | logits H*L*P]  ->  loc (B*Nq, H, L, P, 2), aw (B*Nq, H, L, P)
+//   backward:  (grad_loc, grad_aw, rows)  ->  grad_rows (B*Nq, ld) f32:  d offs = d loc / (W_l, H_l);
+//              d logit = aw * (d aw - sum_j aw_j d aw_j), aw recomputed from the logits
+// One thread per (row, head); L * P <= 16.
+__global__ __launch_bounds__(256) void cgg_msda_prologue_kernel(const float* __restrict__ rows, int ld, const float* __restrict__ ref,
+                                                               MsdaLevels lv, float* __restrict__ loc, float* __restrict__ aw,
+                                                               long long total, int Nq, int H, int L, int P) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int h = (int)(gid % H);
+  const long long bq = gid / H;
+  const int q = (int)(bq % Nq);
+  const int LP = L * P;
+  const float* ro = rows + (size_t)bq * ld + (size_t)h * LP * 2;
+  const float* rl = rows + (size_t)bq * ld + (size_t)H * LP * 2 + (size_t)h * LP;
+  float* lo = loc + ((size_t)bq * H + h) * LP * 2;
+  float* ao = aw + ((size_t)bq * H + h) * LP;
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  float e[16];
+  float m = -3.4e38f;
+  for (int i = 0; i < LP; ++i) {
+    e[i] = rl[i];
+    m = fmaxf(m, e[i]);
+  }
+  float sum = 0.f;
+  for (int i = 0; i < LP; ++i) {
+    e[i] = __expf(e[i] - m);
+    sum += e[i];
+  }
+  const float inv = 1.f / sum;
+  for (int l = 0; l < L; ++l) {
+    const float iw = 1.f / (float)lv.w[l], ih = 1.f / (float)lv.h[l];
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      lo[2 * i] = rx + ro[2 * i] * iw;
+      lo[2 * i + 1] = ry + ro[2 * i + 1] * ih;
+      ao[i] = e[i] * inv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cgg_msda_prologue_bwd_kernel(const float* __restrict__ gloc, const float* __restrict__ gaw,
+                                                                   const float* __restrict__ rows, int ld, MsdaLevels lv,
+                                                                   float* __restrict__ grows, long long total, int H, int L, int P) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int h = (int)(gid % H);
+  const long long bq = gid / H;
+  const int LP = L * P;
+  const float* rl = rows + (size_t)bq * ld + (size_t)H * LP * 2 + (size_t)h * LP;
+  const float* gl = gloc + ((size_t)bq * H + h) * LP * 2;
+  const float* ga = gaw + ((size_t)bq * H + h) * LP;
+  float* go = grows + (size_t)bq * ld + (size_t)h * LP * 2;
+  float* gg = grows + (size_t)bq * ld + (size_t)H * LP * 2 + (size_t)h * LP;
+  float e[16];
+  float m = -3.4e38f;
+  for (int i = 0; i < LP; ++i) {
+    e[i] = rl[i];
+    m = fmaxf(m, e[i]);
+  }
+  float sum = 0.f;
+  for (int i = 0; i < LP; ++i) {
+    e[i] = __expf(e[i] - m);
+    sum += e[i];
+  }
+  const float inv = 1.f / sum;
+  float dot = 0.f;
+  for (int i = 0; i < LP; ++i) {
+    e[i] *= inv;
+    dot += e[i] * ga[i];
+  }
+  for (int l = 0; l < L; ++l) {
+    const float iw = 1.f / (float)lv.w[l], ih = 1.f / (float)lv.h[l];
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      go[2 * i] = gl[2 * i] * iw;
+      go[2 * i + 1] = gl[2 * i + 1] * ih;
+      gg[i] = e[i] * (ga[i] - dot);
+    }
+  }
+}
+
+// L = 3, P = 4 (12 points per head): the same two kernels with 16-byte accesses -- a thread's 24 offsets and 12 logits are 6 + 3
+// aligned float4 (the scalar versions issue 36 four-byte loads at a 96-byte lane stride and run at a quarter of the bandwidth)
+__global__ __launch_bounds__(256) void cgg_msda_prologue12_kernel(const float* __restrict__ rows, int ld, const float* __restrict__ ref,
+                                                                 MsdaLevels lv, float* __restrict__ loc, float* __restrict__ aw,
+                                                                 long long total, int Nq, int H) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int h = (int)(gid % H);
+  const long long bq = gid / H;
+  const int q = (int)(bq % Nq);
+  const f32x4* ro = reinterpret_cast<const f32x4*>(rows + (size_t)bq * ld + (size_t)h * 24);
+  const f32x4* rl = reinterpret_cast<const f32x4*>(rows + (size_t)bq * ld + (size_t)H * 24 + (size_t)h * 12);
+  f32x4* lo = reinterpret_cast<f32x4*>(loc + ((size_t)bq * H + h) * 24);
+  f32x4* ao = reinterpret_cast<f32x4*>(aw + ((size_t)bq * H + h) * 12);
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  f32x4 e[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e[i] = rl[i];
+  float m = e[0][0];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m = fmaxf(m, e[i][c]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      e[i][c] = __expf(e[i][c] - m);
+      sum += e[i][c];
+    }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float iw = 1.f / (float)lv.w[l], ih = 1.f / (float)lv.h[l];
+    ao[l] = e[l] * inv;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                        // two float4 = 4 points' (x, y) ... of level l: (x0 y0 x1 y1), (x2 y2 x3 y3)
+      const f32x4 o = ro[2 * l + k];
+      lo[2 * l + k] = f32x4{rx + o[0] * iw, ry + o[1] * ih, rx + o[2] * iw, ry + o[3] * ih};
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cgg_msda_prologue12_bwd_kernel(const float* __restrict__ gloc, const float* __restrict__ gaw,
+                                                                     const float* __restrict__ rows, int ld, MsdaLevels lv,
+                                                                     float* __restrict__ grows, long long total, int H) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int h = (int)(gid % H);
+  const long long bq = gid / H;
+  const f32x4* rl = reinterpret_cast<const f32x4*>(rows + (size_t)bq * ld + (size_t)H * 24 + (size_t)h * 12);
+  const f32x4* gl = reinterpret_cast<const f32x4*>(gloc + ((size_t)bq * H + h) * 24);
+  const f32x4* ga = reinterpret_cast<const f32x4*>(gaw + ((size_t)bq * H + h) * 12);
+  f32x4* go = reinterpret_cast<f32x4*>(grows + (size_t)bq * ld + (size_t)h * 24);
+  f32x4* gg = reinterpret_cast<f32x4*>(grows + (size_t)bq * ld + (size_t)H * 24 + (size_t)h * 12);
+  f32x4 e[3], g[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    e[i] = rl[i];
+    g[i] = ga[i];
+  }
+  float m = e[0][0];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m = fmaxf(m, e[i][c]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      e[i][c] = __expf(e[i][c] - m);
+      sum += e[i][c];
+    }
+  const float inv = 1.f / sum;
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      e[i][c] *= inv;
+      dot += e[i][c] * g[i][c];
+    }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float iw = 1.f / (float)lv.w[l], ih = 1.f / (float)lv.h[l];
+    gg[l] = e[l] * (g[l] - dot);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const f32x4 o = gl[2 * l + k];
+      go[2 * l + k] = f32x4{o[0] * iw, o[1] * ih, o[2] * iw, o[3] * ih};
+    }
+  }
+}
+
+static int msda_prologue_levels(MsdaLevels& lv, const int32_t* level_hw, int L, const char* who) {
+  CGG_REQUIRE(level_hw && L >= 1 && L <= 8, CGG_EINVAL, "%s: bad level table (L=%d)", who, L);
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = 0;
+    CGG_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0, CGG_EINVAL, "%s: level %d is empty", who, l);
+  }
+  return CGG_OK;
+}
+
+extern "C" int cgg_msda_prologue(const float* rows, int ld, const float* ref_points, const int32_t* level_hw, float* loc,
+                                 float* attn, int B, int Nq, int H, int L, int P, cgg_stream_t stream) {
+  CGG_REQUIRE(rows && ref_points && loc && attn, CGG_EINVAL, "cgg_msda_prologue: null pointer");
+  CGG_REQUIRE(B > 0 && Nq > 0 && H > 0 && P > 0 && L * P <= 16 && ld >= H * L * P * 3, CGG_EUNSUPPORTED,
+              "cgg_msda_prologue: H=%d L=%d P=%d ld=%d (L * P <= 16, ld >= 3 H L P)", H, L, P, ld);
+  MsdaLevels lv;
+  int rc = msda_prologue_levels(lv, level_hw, L, "cgg_msda_prologue");
+  if (rc) return rc;
+  const long long total = (long long)B * Nq * H;
+  if (L == 3 && P == 4 && ld % 4 == 0 && cgg_aligned16(rows) && cgg_aligned16(loc) && cgg_aligned16(attn))
+    hipLaunchKernelGGL(cgg_msda_prologue12_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, ld,
+                       ref_points, lv, loc, attn, total, Nq, H);
+  else
+    hipLaunchKernelGGL(cgg_msda_prologue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, ld,
+                       ref_points, lv, loc, attn, total, Nq, H, L, P);
+  CGG_CHECK_LAUNCH("cgg_msda_prologue");
+  return CGG_OK;
+}
+
+extern "C" int cgg_msda_prologue_backward(const float* grad_loc, const float* grad_attn, const float* rows, int ld,
+                                          const int32_t* level_hw, float* grad_rows, int B, int Nq, int H, int L, int P,
+                                          cgg_stream_t stream) {
+  CGG_REQUIRE(grad_loc && grad_attn && rows && grad_rows, CGG_EINVAL, "cgg_msda_prologue_backward: null pointer");
+  CGG_REQUIRE(B > 0 && Nq > 0 && H > 0 && P > 0 && L * P <= 16 && ld == H * L * P * 3, CGG_EUNSUPPORTED,
+              "cgg_msda_prologue_backward: H=%d L=%d P=%d ld=%d (L * P <= 16, ld == 3 H L P: every column gets a gradient)", H, L,
+              P, ld);
+  MsdaLevels lv;
+  int rc = msda_prologue_levels(lv, level_hw, L, "cgg_msda_prologue_backward");
+  if (rc) return rc;
+  const long long total = (long long)B * Nq * H;
+  if (L == 3 && P == 4 && cgg_aligned16(rows) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn) && cgg_aligned16(grad_rows))
+    hipLaunchKernelGGL(cgg_msda_prologue12_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_loc, grad_attn, rows, ld, lv, grad_rows, total, H);
+  else
+    hipLaunchKernelGGL(cgg_msda_prologue_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_loc,
+                       grad_attn, rows, ld, lv, grad_rows, total, H, L, P);
+  CGG_CHECK_LAUNCH("cgg_msda_prologue_backward");
+  return CGG_OK;
+}

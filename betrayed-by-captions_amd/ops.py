@@ -148,6 +148,41 @@ class MultiScaleDeformableAttnFunction(torch.autograd.Function):
         return gv.to(value.dtype), None, None, gl, gw, None
 
 
+class MSDeformAttnRowsFunction(torch.autograd.Function):
+    """Training form of the encoder's MSDeformAttn core on the RAW projection rows: out = msda(value, loc(rows), softmax(rows))
+    with loc / softmax computed inside the forward kernel (`msda_forward_fused`) and, for the backward, by one prologue kernel,
+    the gather's backward kernel and one kernel mapping (grad_loc, grad_attn) back to the rows -- the ~10 autograd-recorded
+    elementwise passes over (B, Nq, H, L, P[, 2]) tensors of the un-fused formulation are gone.
+    value (B, Nv, H, D) f32, rows (B, Nq, 3 H L P) f32 = [offsets | logits], ref_points (Nq, 2) f32."""
+
+    @staticmethod
+    def forward(ctx, value, rows, ref_points, level_hw, level_start, num_points):
+        value, rows = value.contiguous(), rows.contiguous()
+        ctx.save_for_backward(value, rows, ref_points)
+        ctx.geom = (tuple(tuple(int(v) for v in hw) for hw in level_hw), tuple(int(s) for s in level_start), int(num_points))
+        return msda_forward_fused(value, ctx.geom[0], ctx.geom[1], rows, ref_points, ctx.geom[2])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, rows, ref_points = ctx.saved_tensors
+        level_hw, level_start, P = ctx.geom
+        B, Nv, H, D = value.shape
+        _, Nq, ld = rows.shape
+        L = len(level_hw)
+        hw = _int_array([v for pair in level_hw for v in pair])
+        loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=value.device)
+        aw = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=value.device)
+        check(_lib_().cgg_msda_prologue(dev_ptr(rows, 'rows', torch.float32), ld, dev_ptr(ref_points, 'ref', torch.float32), hw,
+                                        dev_ptr(loc), dev_ptr(aw), B, Nq, H, L, P, stream_ptr(value.device)), 'cgg_msda_prologue')
+        shapes = torch.tensor(level_hw, dtype=torch.int64, device=value.device)
+        starts = torch.tensor(level_start, dtype=torch.int64, device=value.device)
+        gv, gl, gw = msda_backward(value, shapes, starts, loc, aw, grad_out.contiguous())
+        grows = torch.empty_like(rows)
+        check(_lib_().cgg_msda_prologue_backward(dev_ptr(gl), dev_ptr(gw), dev_ptr(rows), ld, hw, dev_ptr(grows), B, Nq, H, L, P,
+                                                 stream_ptr(value.device)), 'cgg_msda_prologue_backward')
+        return gv, grows, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------
 # K3/K4/K5  mask logits  (open_set/models/mask2former_head.py:748-759, :825-826)
 # ------------------------------------------------------------------------------------------------

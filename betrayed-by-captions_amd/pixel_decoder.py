@@ -30,6 +30,7 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL
 FUSED_FFN = os.environ.get('CGG_FUSED_FFN', '1') != '0'
 FUSED_TAIL = os.environ.get('CGG_FUSED_TAIL', '1') != '0'   # ... preceded by output_proj + its residual LayerNorm
 FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
+FUSED_TRAIN_MSDA = os.environ.get('CGG_FUSED_TRAIN_MSDA', '1') != '0'   # training: MSDeformAttn prologue inside the kernels (fwd + bwd)
 FUSED_TRAIN_LN = os.environ.get('CGG_FUSED_TRAIN_LN', '1') != '0'   # training: residual + LayerNorm as one-pass HIP fwd / bwd
 VALUE_HEAD_MAJOR = os.environ.get('CGG_VALUE_HEAD_MAJOR', '1') != '0'   # value written (B, 8, N, 32) for the MSDeformAttn gather
 POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
@@ -274,7 +275,13 @@ class MultiScaleDeformableAttention(nn.Module):
             # offsets / logits decide WHERE to sample: f32 in parity mode and in the f32-value inference path
             offs_logits = F.linear(src_pos, w_cat, b_cat)
         value = value.view(B, N, H, D)
-        if torch.is_grad_enabled() and (value.requires_grad or offs_logits.requires_grad):
+        if (torch.is_grad_enabled() and (value.requires_grad or offs_logits.requires_grad) and FUSED_TRAIN_MSDA
+                and value.is_cuda and self.num_levels * self.num_points <= 16
+                and offs_logits.shape[-1] == 3 * H * self.num_levels * self.num_points):
+            # training: the prologue (loc = ref + off / (W, H), softmax) stays inside the kernels, forward and backward
+            out = ops.MSDeformAttnRowsFunction.apply(value.float(), offs_logits.float(), ref_points, level_hw, level_start,
+                                                     self.num_points)
+        elif torch.is_grad_enabled() and (value.requires_grad or offs_logits.requires_grad):
             # training: un-fused prologue in torch so autograd reaches the linears; the sampling core
             # and its backward are still the HIP kernels (MultiScaleDeformableAttnFunction)
             L, P = self.num_levels, self.num_points

@@ -87,6 +87,15 @@ int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
                                 float* out, int B, int Nv, int H, int D, int L, int Nq, int P,
                                 int value_dtype, int fused, cgg_stream_t stream);
 
+/* Training: the MSDeformAttn prologue ([3P] MultiScaleDeformableAttention.forward: reference_points + offsets / (W_l, H_l),
+ * softmax of the attention logits) and its backward as elementwise kernels on the raw rows [offsets H*L*P*2 | logits H*L*P]
+ * (f32, row stride ld): loc (B, Nq, H, L, P, 2) / attn (B, Nq, H, L, P) out; backward: grad_rows (ld == 3 H L P) from the
+ * gather's grad_loc / grad_attn, the softmax recomputed from the logits. level_hw host [L, 2] = (H_l, W_l); L * P <= 16. */
+int cgg_msda_prologue(const float* rows, int ld, const float* ref_points, const int32_t* level_hw, float* loc, float* attn, int B,
+                      int Nq, int H, int L, int P, cgg_stream_t stream);
+int cgg_msda_prologue_backward(const float* grad_loc, const float* grad_attn, const float* rows, int ld, const int32_t* level_hw,
+                               float* grad_rows, int B, int Nq, int H, int L, int P, cgg_stream_t stream);
+
 /* Throughput-mode encoder stream: value bf16, offs_logits bf16 (the raw output of ONE bf16 GEMM over
  * [sampling_offsets; attention_weights]), out bf16 (input of the output_proj GEMM); host level table.    */
 int cgg_msda_forward_fused_bf16(const void* value, const int32_t* level_hw, const int32_t* level_start,
