@@ -28,6 +28,11 @@ def point_sample(input, points, align_corners=False, **kwargs):
     if points.dim() == 3:
         add_dim = True
         points = points.unsqueeze(2)
+    if (input.is_cuda and input.shape[1] == 1 and add_dim and not align_corners and not kwargs and input.dtype == torch.float32
+            and points.dtype == torch.float32 and not (torch.is_grad_enabled() and points.requires_grad)):
+        # single-channel maps sampled at per-row point lists (uncertainty sampling, mask losses): the HIP gather (+ scatter backward)
+        from . import ops
+        return ops.point_sample_rows(input[:, 0], points[:, :, 0]).unsqueeze(1)
     out = F.grid_sample(input, points * 2.0 - 1.0, align_corners=align_corners, **kwargs)
     if add_dim:
         out = out.squeeze(3)

@@ -910,6 +910,46 @@ extern "C" int cgg_point_sample_planes(const float* planes, const int32_t* index
   return CGG_OK;
 }
 
+// Backward of cgg_point_sample_planes wrt the planes (the points are constants of the loss: `get_uncertain_point_coords...` runs
+// under no_grad at mask2former_head.py:600-606, so no gradient wrt the grid is needed -- F.grid_sample's backward computes it
+// anyway): grad_planes[index[j]] += the four tap weights x grad_out[j][p]; f32 hardware atomics into the caller's zeroed buffer.
+__global__ __launch_bounds__(256) void cgg_point_sample_planes_bwd_kernel(const float* __restrict__ gout,
+                                                                         const int32_t* __restrict__ index,
+                                                                         const float* __restrict__ pts, float* __restrict__ gplanes,
+                                                                         int H, int W, int P, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // (row j, point p)
+  if (i >= total) return;
+  const long long j = i / P;
+  const float px = pts[i * 2], py = pts[i * 2 + 1];
+  const float gx = __fsub_rn(__fmul_rn(px, 2.0f), 1.0f), gy = __fsub_rn(__fmul_rn(py, 2.0f), 1.0f);
+  const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 2.f);
+  const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 2.f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = __fsub_rn(ix, fx), ty = __fsub_rn(iy, fy);
+  const float ux = __fsub_rn(__fadd_rn(fx, 1.f), ix), uy = __fsub_rn(__fadd_rn(fy, 1.f), iy);
+  const float g = gout[i];
+  float* pl = gplanes + (size_t)(index ? index[j] : (int)j) * H * W;
+  const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+  if (xin0 && yin0) atomicAdd(pl + (size_t)y0 * W + x0, __fmul_rn(__fmul_rn(ux, uy), g));
+  if (xin1 && yin0) atomicAdd(pl + (size_t)y0 * W + x0 + 1, __fmul_rn(__fmul_rn(tx, uy), g));
+  if (xin0 && yin1) atomicAdd(pl + (size_t)(y0 + 1) * W + x0, __fmul_rn(__fmul_rn(ux, ty), g));
+  if (xin1 && yin1) atomicAdd(pl + (size_t)(y0 + 1) * W + x0 + 1, __fmul_rn(__fmul_rn(tx, ty), g));
+}
+
+extern "C" int cgg_point_sample_planes_backward(const float* grad_out, const int32_t* index, const float* pts, float* grad_planes,
+                                                int N, int H, int W, int rows, int P, cgg_stream_t stream) {
+  CGG_REQUIRE(grad_out && pts && grad_planes, CGG_EINVAL, "cgg_point_sample_planes_backward: null pointer");
+  CGG_REQUIRE(N > 0 && H > 0 && W > 0 && rows > 0 && P > 0 && (index || rows <= N), CGG_EINVAL,
+              "cgg_point_sample_planes_backward: bad sizes");
+  const long long total = (long long)rows * P;
+  hipLaunchKernelGGL(cgg_point_sample_planes_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_out, index, pts, grad_planes, H, W, P, total);
+  CGG_CHECK_LAUNCH("cgg_point_sample_planes_backward");
+  return CGG_OK;
+}
+
 extern "C" int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
                                      cgg_stream_t stream) {
   CGG_REQUIRE(feat && pts && out, CGG_EINVAL, "cgg_point_sample_nhwc: null pointer");

@@ -1110,7 +1110,11 @@ class Mask2FormerHeadOpen(nn.Module):
                     mask_point_targets = torch.cat(chunks, 0)
             else:
                 mask_point_targets = point_sample(mask_targets.unsqueeze(1).float(), points_coords).squeeze(1)
-        mask_point_preds = point_sample(mask_preds.unsqueeze(1), points_coords).squeeze(1)
+        if ops.point_sample_rows_ok(mask_preds, points_coords):
+            # one gather kernel forward, one scatter kernel backward (no gradient wrt the constant points)
+            mask_point_preds = ops.point_sample_rows(mask_preds, points_coords)
+        else:
+            mask_point_preds = point_sample(mask_preds.unsqueeze(1), points_coords).squeeze(1)
         loss_dice = self.loss_dice(mask_point_preds, mask_point_targets, avg_factor=num_total_masks)
         loss_mask = self.loss_mask(mask_point_preds.reshape(-1), mask_point_targets.reshape(-1),
                                    avg_factor=num_total_masks * self.num_points)

@@ -1398,6 +1398,44 @@ def point_sample_planes(planes, index, points):
     return out
 
 
+class _PointSampleRowsFn(torch.autograd.Function):
+    """out (rows, P) = bilinear samples of planes[j] (rows, H, W) f32 at points[j] (rows, P, 2) (grid_sample arithmetic, zeros
+    outside, align_corners=False); differentiable wrt the planes only (the points are constants of the loss)."""
+
+    @staticmethod
+    def forward(ctx, planes, points):
+        planes = planes.contiguous()
+        points = points.contiguous()
+        rows, H, W = planes.shape
+        idx = torch.arange(rows, dtype=torch.int32, device=planes.device)
+        ctx.save_for_backward(points)
+        ctx.shape = (rows, H, W)
+        return point_sample_planes(planes, idx, points)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (points,) = ctx.saved_tensors
+        rows, H, W = ctx.shape
+        gp = torch.zeros((rows, H, W), dtype=torch.float32, device=gout.device)
+        if rows:
+            check(_lib_().cgg_point_sample_planes_backward(dev_ptr(gout.contiguous().float(), 'grad', torch.float32), None,
+                                                           dev_ptr(points, 'points', torch.float32), dev_ptr(gp), rows, H, W, rows,
+                                                           points.shape[1], stream_ptr(gout.device)),
+                  'cgg_point_sample_planes_backward')
+        return gp, None
+
+
+def point_sample_rows(planes, points):
+    """planes (rows, H, W) f32 (may require grad), points (rows, P, 2) f32 in [0, 1] -> (rows, P); == [3P] mmcv point_sample of
+    planes.unsqueeze(1) at the same points (F.grid_sample bilinear / zeros / align_corners=False)."""
+    return _PointSampleRowsFn.apply(planes, points)
+
+
+def point_sample_rows_ok(planes, points):
+    return (planes.is_cuda and planes.dtype == torch.float32 and planes.dim() == 3 and points.dim() == 3
+            and points.dtype == torch.float32 and points.shape[0] == planes.shape[0] and points.shape[2] == 2)
+
+
 def point_sample_nhwc(feat, points):
     """feat (B, H, W, C) f32 channel-last, points (B, P, 2) in [0, 1] (x, y) -> (B, P, C): [3P] mmcv point_sample
     (grid_sample bilinear / zeros / align_corners=False) with the layout that makes a point's taps contiguous rows."""

@@ -504,6 +504,11 @@ int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B
  * (mask2former_head.py:609-612): one launch per decoder layer for all images.                                          */
 int cgg_point_sample_planes(const float* planes, const int32_t* index, const float* pts, float* out, int N, int H, int W,
                             int rows, int P, cgg_stream_t stream);
+/* Backward of cgg_point_sample_planes wrt the planes (points are constants): grad_planes (N, H, W), ZEROED by the caller,
+ * accumulates the tap weights x grad_out (rows, P) with f32 atomics; index nullable = row j samples plane j. Replaces
+ * F.grid_sample's backward (which also computes the unused grid gradient) at open_set/models/mask2former_head.py:609-620. */
+int cgg_point_sample_planes_backward(const float* grad_out, const int32_t* index, const float* pts, float* grad_planes, int N,
+                                     int H, int W, int rows, int P, cgg_stream_t stream);
 
 /* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
  * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),
