@@ -13,6 +13,9 @@ import torch.nn as nn
 from . import ops, runtime
 from .registry import BACKBONES
 
+# throughput mode: ResNet layer1 identity Bottlenecks as one HIP launch (ops.bottleneck64); CGG_FUSED_BOTTLENECK=0 = three library calls
+FUSED_BOTTLENECK = os.environ.get('CGG_FUSED_BOTTLENECK', '1') != '0'
+
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -256,6 +259,15 @@ class ResNet(nn.Module):
                 identity = x
                 if blk.downsample is not None:
                     identity = self._conv_nhwc(x, blk.downsample[0], next(seq), False)
+                if (FUSED_BOTTLENECK and isinstance(blk, Bottleneck) and blk.downsample is None and blk.conv1.in_channels == 256
+                        and blk.conv1.out_channels == 64 and tuple(blk.conv2.stride) == (1, 1) and blk.conv2.groups == 1
+                        and tuple(blk.conv2.dilation) == (1, 1) and tuple(blk.conv2.padding) == (1, 1) and ops.bottleneck64_ok(x)):
+                    # layer1 identity block: conv1 -> conv2 -> conv3 + residual in ONE launch (the 64-channel intermediates stay in LDS)
+                    f1, f2, f3 = next(seq), next(seq), next(seq)
+                    packed = runtime.derived_cached('bottleneck64', (f1[2], f2[0], f3[2], f1[1], f2[1], f3[1]),
+                                                    lambda: ops.pack_bottleneck64(f1[2], f1[1], f2[0], f2[1], f3[2], f3[1]))
+                    x = ops.bottleneck64(x, packed)
+                    continue
                 y = self._conv_nhwc(x, blk.conv1, next(seq), True)
                 if isinstance(blk, Bottleneck):
                     y = self._conv_nhwc(y, blk.conv2, next(seq), True)

@@ -675,6 +675,38 @@ def add_layernorm_stream(a, b, gamma, beta, eps=1e-5, pos=None, want_f32=True, w
     return y32, y16, yp16
 
 
+def pack_bottleneck64(w1, b1, w2, b2, w3, b3):
+    """BN-folded weights of a ResNet layer1 identity Bottleneck -> the packed operands of `bottleneck64`:
+    w1 (64, 256), w2 (64, 64, 3, 3), w3 (256, 64) (any float dtype), biases (64,), (64,), (256,)."""
+    dev = w1.device
+    w1p = pack_linear_weight(w1.reshape(64, 256).float())
+    w2p = pack_linear_weight(w2.float().permute(0, 2, 3, 1).reshape(64, 576).contiguous())
+    T = torch.arange(8, device=dev).view(8, 1)
+    jj = torch.arange(32, device=dev).view(1, 32)
+    perm = (64 * (T // 2) + 4 * (jj // 2) + 2 * (T % 2) + (jj % 2)).reshape(-1)          # packed row 32 T + j <- output channel
+    w3p = pack_linear_weight(w3.reshape(256, 64).float()[perm].contiguous())
+    return (w1p, b1.float().contiguous(), w2p, b2.float().contiguous(), w3p, b3.float().contiguous())
+
+
+def bottleneck64_ok(x):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 256 and x.is_contiguous()
+            and x.shape[1] % 8 == 0 and x.shape[2] % 16 == 0 and x.numel() < (1 << 31))
+
+
+def bottleneck64(x, packed):
+    """x (B, H, W, 256) bf16 channel-last -> relu(conv3(relu(conv2(relu(conv1 x)))) + x) of a BN-folded ResNet layer1 identity
+    Bottleneck in ONE launch; `packed` from `pack_bottleneck64`."""
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    w1p, b1, w2p, b2, w3p, b3 = packed
+    with _timed('bottleneck64'):
+        rc = _lib_().cgg_bottleneck64_bf16(dev_ptr(x, 'x', torch.bfloat16), dev_ptr(w1p), dev_ptr(b1, 'b1', torch.float32),
+                                           dev_ptr(w2p), dev_ptr(b2, 'b2', torch.float32), dev_ptr(w3p),
+                                           dev_ptr(b3, 'b3', torch.float32), dev_ptr(y), B, H, W, C, 64, stream_ptr(x.device))
+    check(rc, 'cgg_bottleneck64_bf16')
+    return y
+
+
 def pack_decoder_k_weight(weight):
     """weight (n * 256, 256) f32 (stacked key projections) -> packed bf16 operand of `decoder_kv_proj` (uint8 tensor)."""
     N, K = weight.shape

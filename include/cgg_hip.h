@@ -402,6 +402,14 @@ int cgg_decoder_kv_pack_k(const float* w, void* packed, int N, int K, cgg_stream
 int cgg_decoder_kv_proj_bf16(const void* m16, const void* mp16, const void* wk_packed, const float* bk, const void* wv_packed,
                              void* k, void* vt, int B, int hw, int C, int NK, cgg_stream_t stream);
 
+/* ResNet-50 layer1 identity Bottleneck (mmdet ResNet `Bottleneck.forward`, configs/instance/coco_b48n17.py:17-26), BN folded,
+ * channel-last bf16, as ONE launch: y = relu(conv1x1(relu(conv3x3(relu(conv1x1(x, W1) + b1), W2) + b2), W3) + b3 + x).
+ * x / y (B, H, W, 256) bf16, H % 8 == 0, W % 16 == 0; all weights packed by cgg_linear_rows_pack: W1 (64 x 256), W2 as the
+ * (64 x 576) matrix with K = (ky * 3 + kx) * 64 + c_in, W3 (256 x 64) with its ROWS permuted so that packed row 32 T + j is output
+ * channel 64 (T / 2) + 4 (j / 2) + 2 (T & 1) + (j & 1) (see ops.pack_bottleneck64); biases f32. */
+int cgg_bottleneck64_bf16(const void* x, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
+                          const void* w3_packed, const float* b3, void* y, int B, int H, int W, int C, int CMID, cgg_stream_t stream);
+
 /* Encoder-stream FFN block of the pixel decoder as ONE launch ([3P] BaseTransformerLayer 'ffn' + 'norm' of the
  * MSDeformAttn encoder layers built at open_set/models/mask2former_head.py:112-117):
  *   y = LayerNorm(x + W2 relu(W1 x + b1) + b2);  x16 (M, 256) bf16 rows, w1 (F x 256) / w2 (256 x F) packed by

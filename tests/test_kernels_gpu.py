@@ -1464,3 +1464,31 @@ def test_point_sample_rows_forward_backward_vs_grid_sample(dev):
     from cgg_amd.assigner import point_sample
     o2 = point_sample(planes.detach().unsqueeze(1), pts)
     assert o2.shape == (rows, 1, P) and torch.equal(o2[:, 0], out.detach())
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 256, 256), (1, 8, 16), (1, 24, 48)])
+def test_bottleneck64_fused_vs_float64(dev, B, H, W):
+    """ResNet layer1 identity Bottleneck in one launch against float64 convolutions on the same bf16 operands with the same bf16
+    rounding points (t1, t2 rounded to bf16 like the three-call path): the output is bf16, so half an ulp of max(|y|, 1) (2^-8
+    relative) plus the effect of a t1 / t2 element landing on the other side of a bf16 rounding boundary (bounded by 0.03 absolute
+    for these operand scales); borders (zero padding of t1, not of x) included; two runs bit-identical."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * H + W)
+    x = (torch.randn(B, H, W, 256, generator=g) * 0.7).to(dev).bfloat16()
+    w1 = (torch.randn(64, 256, generator=g) * 0.06).to(dev).bfloat16()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev).bfloat16()
+    w3 = (torch.randn(256, 64, generator=g) * 0.1).to(dev).bfloat16()
+    b1, b2, b3 = (torch.randn(n, generator=g).to(dev).bfloat16() * 0.2 for n in (64, 64, 256))
+    packed = ops.pack_bottleneck64(w1, b1, w2, b2, w3, b3)
+    assert ops.bottleneck64_ok(x)
+    y = ops.bottleneck64(x, packed)
+    y2 = ops.bottleneck64(x, packed)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    xd = x.double().permute(0, 3, 1, 2)
+    t1 = F.relu(F.conv2d(xd, w1.double().view(64, 256, 1, 1), b1.double())).bfloat16().double()
+    t2 = F.relu(F.conv2d(t1, w2.double(), b2.double(), padding=1)).bfloat16().double()
+    ref64 = F.relu(F.conv2d(t2, w3.double().view(256, 64, 1, 1), b3.double()) + xd).permute(0, 2, 3, 1)
+    err = (y.double() - ref64).abs()
+    assert (err / ref64.abs().clamp_min(1.0)).max().item() <= 0.03
+    assert (err / ref64.abs().clamp_min(1.0)).mean().item() <= 2e-3
