@@ -462,3 +462,31 @@ def test_rle_decoder_round_trip():
     bits = np.packbits(m, axis=-1, bitorder='little')
     for g, mk in zip(ops.rle_encode_bitmasks(bits, 48, threads=1), m):
         assert np.array_equal(rle_to_mask(g), mk)
+
+
+def test_splitk_linear_function_matches_autograd_on_cpu():
+    """runtime._SplitKLinearFn (training linears of the encoder stream: dW as ONE batched GEMM over row slabs + an f32 sum) against
+    plain autograd of the same bf16 linear on the CPU: forward identical, grad_input identical (same GEMM), grad_weight / grad_bias
+    equal up to the bf16 rounding of the per-slab partial products (2^-8 relative to the gradient's scale)."""
+    import torch
+    import torch.nn.functional as F
+    from cgg_amd import runtime
+    g = torch.Generator().manual_seed(0)
+    M, K, N = 32768, 64, 48                      # 32 768 rows -> 8 slabs of 4 096
+    x = torch.randn(M, K, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    gy = torch.randn(M, N, generator=g).bfloat16()
+    y = runtime._SplitKLinearFn.apply(x, w, b)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    x16, w16, b16 = x.detach().bfloat16().requires_grad_(True), w.detach().bfloat16().requires_grad_(True), b.detach().bfloat16().requires_grad_(True)
+    yr = F.linear(x16, w16, b16)
+    yr.backward(gy)
+    assert torch.equal(got[0], yr.detach())
+    assert got[1].dtype == torch.float32 and torch.allclose(got[1], x16.grad.float(), atol=2e-2, rtol=2e-2)
+    gw64 = gy.double().t() @ x.detach().bfloat16().double()
+    assert (got[2].double() - gw64).abs().max().item() <= 2 ** -8 * gw64.abs().max().item() + 1e-3
+    assert (got[3].double() - gy.double().sum(0)).abs().max().item() <= 1e-2
+    assert got[2].dtype == torch.float32 and got[3].dtype == torch.float32
