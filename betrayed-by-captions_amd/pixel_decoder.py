@@ -852,7 +852,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
             with runtime.autocast():
                 y = self.output_convs[i](y)
-            outs.append(y.float())
+            # an FPN level that is not among the returned outputs only feeds the next convolution: it stays in the autocast
+            # dtype (bf16 -> f32 -> bf16 is exact, but two 1-GB passes forward and two backward at configs[2])
+            outs.append(y.float() if len(outs) < self.num_outs or i > 0 else y)
         with runtime.autocast():
             mask_feature = self.mask_feature(outs[-1].contiguous())
         return mask_feature.float(), outs[:self.num_outs]
