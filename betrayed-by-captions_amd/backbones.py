@@ -15,6 +15,8 @@ from .registry import BACKBONES
 
 # throughput mode: ResNet layer1 identity Bottlenecks as one HIP launch (ops.bottleneck64); CGG_FUSED_BOTTLENECK=0 = three library calls
 FUSED_BOTTLENECK = os.environ.get('CGG_FUSED_BOTTLENECK', '1') != '0'
+# training: frozen stem + stages on the BN-folded inference path under no_grad (CGG_FROZEN_FOLDED=0 = autograd-recorded torch path)
+FROZEN_FOLDED = os.environ.get('CGG_FROZEN_FOLDED', '1') != '0'
 
 
 class Bottleneck(nn.Module):
@@ -227,7 +229,7 @@ class ResNet(nn.Module):
         y = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         return ops.bias_act_nhwc_(y, b, res, relu)
 
-    def _forward_folded(self, x):
+    def _forward_folded(self, x, upto=None):
         import torch.nn.functional as F
         seq = iter(self._folded())
         mp = self.maxpool
@@ -239,7 +241,7 @@ class ResNet(nn.Module):
             w4, b, _ = next(seq)
             packed = runtime.derived_cached('stem_packed', (w4,), lambda: ops.pack_stem_weight(w4))
             x = ops.bias_relu_maxpool_nhwc(ops.stem_conv7x7(x, packed), b)
-            return self._forward_folded_layers(x, seq)
+            return self._forward_folded_layers(x, seq, upto)
         x = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last).permute(0, 2, 3, 1)
         if pool_ok:
             # conv -> (+bias, ReLU, 3x3/s2 max-pool) in one HIP pass over the raw convolution output
@@ -250,11 +252,14 @@ class ResNet(nn.Module):
         else:
             x = self._conv_nhwc(x, self.conv1, next(seq), True)
             x = mp(x.permute(0, 3, 1, 2)).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-        return self._forward_folded_layers(x, seq)
+        return self._forward_folded_layers(x, seq, upto)
 
-    def _forward_folded_layers(self, x, seq):
+    def _forward_folded_layers(self, x, seq, upto=None):
+        """`upto` = number of leading res layers to run (training: the frozen stages): returns (outs so far, x) instead."""
         outs = []
         for i, name in enumerate(self.res_layers):
+            if upto is not None and i >= upto:
+                return outs, x
             for blk in getattr(self, name):
                 identity = x
                 if blk.downsample is not None:
@@ -276,6 +281,8 @@ class ResNet(nn.Module):
                     x = self._conv_nhwc(y, blk.conv2, next(seq), True, identity)
             if i in self.out_indices:
                 outs.append(x)
+        if upto is not None:
+            return outs, x
         # (B, C, H, W)-shaped views of the channel-last bf16 activations: no copy, no cast. The pixel decoder's
         # inference stream consumes them as they are; anything else can `.float().contiguous()` them.
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
@@ -285,6 +292,18 @@ class ResNet(nn.Module):
         if runtime.is_bf16() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda:
             return self._forward_folded(x)
         outs = []
+        first = 0
+        if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1
+                and not any(p.requires_grad for n in self.res_layers[:self.frozen_stages] for p in getattr(self, n).parameters())
+                and not any(p.requires_grad for p in list(self.conv1.parameters()) + list(self.bn1.parameters()))):
+            # training with frozen stages (configs: frozen_stages=3, norm_eval=True): nothing before the first trainable layer is
+            # recorded by autograd anyway, so the stem and the frozen layers run on the BN-folded bf16 channel-last inference
+            # path (GEMM / fused kernels instead of conv + BN + ReLU launches); only the trainable tail goes through autograd
+            with torch.no_grad():
+                fouts, xf = self._forward_folded(x, upto=self.frozen_stages)
+            outs = [o.permute(0, 3, 1, 2) for o in fouts]
+            x = xf.permute(0, 3, 1, 2)                       # channels-last strided (B, C, H, W) bf16 view
+            first = self.frozen_stages
         with runtime.autocast():
             if runtime.is_bf16():
                 # MIOpen's bf16 solvers want NHWC activations AND NHWC filters (a mixed pair falls back
@@ -293,8 +312,11 @@ class ResNet(nn.Module):
                     self.to(memory_format=torch.channels_last)
                     self._channels_last = True
                 x = x.contiguous(memory_format=torch.channels_last)
-            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            if first == 0:
+                x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
             for i, name in enumerate(self.res_layers):
+                if i < first:
+                    continue
                 x = getattr(self, name)(x)
                 if i in self.out_indices:
                     outs.append(x)
