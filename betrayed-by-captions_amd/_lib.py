@@ -59,6 +59,18 @@ PROTOTYPES = {
     'cgg_decoder_mid_bf16': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int] +
                              [_c_vp] * 5 + [_c_int, _c_int, _c_vp]),
     'cgg_decoder_ffn_bf16': (_c_int, [_c_vp, _c_int] + [_c_vp] * 5 + [_c_int] * 3 + [_c_vp]),
+    'cgg_x3_packed_bytes': (_c_i64, [_c_int, _c_int]),
+    'cgg_x3_pack': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp]),
+    'cgg_linear_rows_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_f,
+                                    _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 5 +
+                           [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp]),
+    'cgg_decoder_tail_x3': (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f] +
+                            [_c_vp] * 12 + [_c_int, _c_int, _c_vp]),
+    'cgg_decoder_mid_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int] +
+                           [_c_vp] * 5 + [_c_int, _c_int, _c_vp]),
+    'cgg_decoder_ffn_x3': (_c_int, [_c_vp, _c_int] + [_c_vp] * 5 + [_c_int] * 3 + [_c_vp]),
+    'cgg_gemm_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 4 + [_c_vp]),
+    'cgg_conv_x3_nhwc': (_c_int, [_c_vp] * 5 + [_c_int] * 10 + [_c_vp]),
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
     'cgg_msda_prologue': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
@@ -84,6 +96,9 @@ PROTOTYPES = {
     'cgg_group_norm_nhwc_workspace_bytes': (_c_i64, [_c_int] * 3),
     'cgg_group_norm_nhwc': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,
                                        _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
+    'cgg_group_norm_nhwc_f32': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,
+                                           _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
+    'cgg_pack_mask_feature_nhwc_f32_x3': (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
     'cgg_pack_mask_feature_nhwc_multi': (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_pack_mask_feature_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_blaslt_init': (_c_int, [ctypes.c_char_p]),

@@ -151,6 +151,7 @@ class ResNet(nn.Module):
         # .to() / .cuda() / .float() replace buffer objects: drop the folded-weight caches that reference them
         self.__dict__.pop('_fold_tensors', None)
         self.__dict__.pop('_fold_cache', None)
+        self.__dict__.pop('_fold_cache_x3', None)
         return super()._apply(fn, *args, **kwargs)
 
     # ---- throughput-mode inference: BN folded into the convolutions, bf16 NHWC filters kept resident ----
@@ -287,10 +288,88 @@ class ResNet(nn.Module):
         # inference stream consumes them as they are; anything else can `.float().contiguous()` them.
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
 
+    # ---- parity-mode inference: BN folded in f32, channel-last f32 activations, every convolution after the stem on the
+    #      f32-class implicit-GEMM kernel (ops.conv_x3_nhwc: f16 x 3 MFMA, csrc/x3_gemm.hip) with bias / residual / ReLU fused ----
+    def _folded_x3(self):
+        """[(x3 image | folded f32 filter for the stem, bias f32)] per conv in execution order; rebuilt when a parameter or
+        buffer version changes."""
+        tensors = self.__dict__.get('_fold_tensors')
+        if tensors is None:
+            tensors = list(self.parameters()) + list(self.buffers())
+            self.__dict__['_fold_tensors'] = tensors
+        key = sum(t._version for t in tensors)
+        hit = self.__dict__.get('_fold_cache_x3')
+        if hit is not None and hit[0] == key and hit[1][0][1].device == self.conv1.weight.device:
+            return hit[1]
+
+        def fold(conv, bn, stem=False):
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            w = conv.weight.detach().float() * s.view(-1, 1, 1, 1)
+            b = (bn.bias.detach().float() - bn.running_mean.detach().float() * s).contiguous()
+            return (w.contiguous() if stem else ops.pack_conv_weight_x3(w)), b
+
+        with torch.no_grad():
+            seq = [fold(self.conv1, self.bn1, stem=True)]
+            for name in self.res_layers:
+                for blk in getattr(self, name):
+                    if blk.downsample is not None:
+                        seq.append(fold(blk.downsample[0], blk.downsample[1]))
+                    seq.append(fold(blk.conv1, blk.bn1))
+                    seq.append(fold(blk.conv2, blk.bn2))
+                    if isinstance(blk, Bottleneck):
+                        seq.append(fold(blk.conv3, blk.bn3))
+        self.__dict__['_fold_cache_x3'] = (key, seq)
+        return seq
+
+    def _x3_ok(self):
+        def conv_ok(c):
+            return (c.groups == 1 and tuple(c.dilation) == (1, 1) and c.kernel_size[0] == c.kernel_size[1]
+                    and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.in_channels % 32 == 0 and c.bias is None)
+        for name in self.res_layers:
+            for blk in getattr(self, name):
+                convs = [blk.conv1, blk.conv2] + ([blk.conv3] if isinstance(blk, Bottleneck) else [])
+                if blk.downsample is not None:
+                    if not (isinstance(blk.downsample[0], nn.Conv2d) and isinstance(blk.downsample[1], nn.BatchNorm2d)):
+                        return False
+                    convs.append(blk.downsample[0])
+                if not all(conv_ok(c) for c in convs):
+                    return False
+        return self.conv1.bias is None
+
+    def _forward_x3(self, x):
+        import torch.nn.functional as F
+        seq = iter(self._folded_x3())
+        w, b = next(seq)
+        # stem (3 input channels: not an implicit-GEMM shape): MIOpen f32 with the folded filter, then channel-last
+        x = F.conv2d(x.float(), w, b, stride=self.conv1.stride, padding=self.conv1.padding)
+        x = self.maxpool(torch.relu_(x)).permute(0, 2, 3, 1).contiguous()
+
+        def conv(x, c, relu, res=None):
+            wk, bias = next(seq)
+            return ops.conv_x3_nhwc(x, wk, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], bias, res=res, relu=relu)
+
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk in getattr(self, name):
+                identity = x if blk.downsample is None else conv(x, blk.downsample[0], False)
+                y = conv(x, blk.conv1, True)
+                if isinstance(blk, Bottleneck):
+                    y = conv(y, blk.conv2, True)
+                    x = conv(y, blk.conv3, True, identity)
+                else:
+                    x = conv(y, blk.conv2, True, identity)
+            if i in self.out_indices:
+                outs.append(x)
+        # (B, C, H, W)-shaped views of the channel-last f32 activations (no copy): the pixel decoder's parity-mode stream reads
+        # them as they are; anything else can `.contiguous()` them
+        return tuple(o.permute(0, 3, 1, 2) for o in outs)
+
     def forward(self, x):
         frozen_bn = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         if runtime.is_bf16() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda:
             return self._forward_folded(x)
+        if runtime.x3_enabled() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda and self._x3_ok():
+            return self._forward_x3(x)
         outs = []
         first = 0
         if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1

@@ -13,15 +13,20 @@
 //     LayerNorm-chain kernel: deterministic, no atomics) so the K = 2048 projection uses 56 workgroups instead of 7;
 //   * ReLU can be limited to the first `relu_cols` columns, which lets cls_embed / v2l_transform / mask_embed[0]
 //     (open_set/models/mask2former_head.py:734-746) run as ONE GEMM over concatenated weights.
-#include "cgg_common.h"
+//   * X3 = true (parity mode, runtime precision 'fp32'): the same kernel on the f32-class f16 x 3 contraction of x3.h -- the
+//     weight is an x3 image (hi / lo fragments + per-column scale), the activation block is split into (hi, lo) f16 fragment
+//     images, three MFMAs per k-step into the one accumulator; it replaces the f32-MFMA cgg_linear_rows_kernel<2> of round 2
+//     (17 us per call: 128 dependent v_mfma_f32_32x32x2_f32 per tile) at the bf16 kernel's launch time.
+#include "x3.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define LR2_KC 256  // K chunk per LDS fill (16 MFMA k-steps)
 
-template <bool LN>
+template <bool LN, bool X3>
 __global__ __launch_bounds__(512) void cgg_lr2_kernel(
-    const float* __restrict__ x, int ldx, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ x, int ldx, const u32x4* __restrict__ wp, const u32x4* __restrict__ wlo,
+    const float* __restrict__ wscale, const float* __restrict__ bias,
     const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ pos, int pos_rows,
     float* __restrict__ yp, int ldyp, int M, int N, int K, int relu_cols, const float* __restrict__ x2, int ldx2,
@@ -33,6 +38,7 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
   int ncol0 = 0;
   if (y2 != nullptr && (int)blockIdx.x * 256 >= y2_col) { y = y2; ldy = ldy2; ncol0 = y2_col; }
   __shared__ __attribute__((aligned(16))) u32x4 a_frag[STEPS * 64];
+  __shared__ __attribute__((aligned(16))) u32x4 a_lo[X3 ? STEPS * 64 : 1];
   __shared__ float red[8][32];
   __shared__ float stat[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
   const bool col_ok = tile_live && n < N;
   const bool first = blockIdx.z == 0;
   const float bv = (col_ok && bias && first) ? bias[n] : 0.f;
+  const float cs = (X3 && col_ok) ? wscale[n] : 1.f;
   float resv[16], posv[16];
   float lg = 0.f, lb = 0.f;
   if (LN && col_ok) {
@@ -76,6 +83,12 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
       bf[s] = (tile_live && s < steps) ? wp[((size_t)nt * KS + kc + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    u32x4 bl[X3 ? STEPS : 1];
+    if constexpr (X3) {
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+        bl[s] = (tile_live && s < steps) ? wlo[((size_t)nt * KS + kc + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    }
     // A: rows m0..m0+31, k = 16*kc .. : thread -> (row, 8-float group), coalesced along k
     __syncthreads();   // previous chunk's fragment reads are done
     const int groups = steps * 2;               // 8-float groups per row in this chunk
@@ -88,18 +101,29 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
         v0 = *reinterpret_cast<const f32x4*>(src);
         v1 = *reinterpret_cast<const f32x4*>(src + 4);
       }
-      const u32x4 p = {cgg_pack2(cgg_f2bf(v0[0]), cgg_f2bf(v0[1])), cgg_pack2(cgg_f2bf(v0[2]), cgg_f2bf(v0[3])),
-                       cgg_pack2(cgg_f2bf(v1[0]), cgg_f2bf(v1[1])), cgg_pack2(cgg_f2bf(v1[2]), cgg_f2bf(v1[3]))};
-      a_frag[(kg >> 1) * 64 + (kg & 1) * 32 + row] = p;
+      if constexpr (X3) {
+        u32x4 ph, pl;
+        cgg_x3_split8(v0, v1, ph, pl);
+        a_frag[(kg >> 1) * 64 + (kg & 1) * 32 + row] = ph;
+        a_lo[(kg >> 1) * 64 + (kg & 1) * 32 + row] = pl;
+      } else {
+        const u32x4 p = {cgg_pack2(cgg_f2bf(v0[0]), cgg_f2bf(v0[1])), cgg_pack2(cgg_f2bf(v0[2]), cgg_f2bf(v0[3])),
+                         cgg_pack2(cgg_f2bf(v1[0]), cgg_f2bf(v1[1])), cgg_pack2(cgg_f2bf(v1[2]), cgg_f2bf(v1[3]))};
+        a_frag[(kg >> 1) * 64 + (kg & 1) * 32 + row] = p;
+      }
     }
     __syncthreads();
     if (tile_live) {
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         if (s < steps) {
-          const bf16x8 va = __builtin_bit_cast(bf16x8, a_frag[s * 64 + lane]);
-          const bf16x8 vb = __builtin_bit_cast(bf16x8, bf[s]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+          if constexpr (X3) {
+            cgg_x3_mfma(acc, a_frag[s * 64 + lane], a_lo[s * 64 + lane], bf[s], bl[s]);
+          } else {
+            const bf16x8 va = __builtin_bit_cast(bf16x8, a_frag[s * 64 + lane]);
+            const bf16x8 vb = __builtin_bit_cast(bf16x8, bf[s]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+          }
         }
       }
     }
@@ -111,7 +135,7 @@ __global__ __launch_bounds__(512) void cgg_lr2_kernel(
     const bool do_relu = n < relu_cols;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float t = acc[r] + bv;
+      float t = (X3 ? acc[r] * cs : acc[r]) + bv;
       if (do_relu) t = fmaxf(t, 0.f);
       t += resv[r];
       v[r] = col_ok ? t : 0.f;
@@ -298,33 +322,122 @@ extern "C" int cgg_linear_rows_pack(const float* w, void* packed, int N, int K, 
   return CGG_OK;
 }
 
+static int lr2_launch(bool x3, const char* who, const float* x, int ldx, const void* w_packed, const float* bias,
+                      const float* res, int ldr, float* y, int ldy, const float* ln_gamma,
+                      const float* ln_beta, float ln_eps, const float* pos, int pos_rows, float* yp,
+                      int ldyp, int M, int N, int K, int relu_cols, int ksplit, const float* x2, int ldx2,
+                      int x2_col, float* y2, int ldy2, int y2_col, cgg_stream_t stream) {
+  CGG_REQUIRE(x && w_packed && y, CGG_EINVAL, "%s: null pointer", who);
+  CGG_REQUIRE(!x2 || (x2_col > 0 && x2_col % 256 == 0 && ldx2 % 4 == 0 && cgg_aligned16(x2)), CGG_EUNSUPPORTED,
+              "%s: x2_col=%d must be a positive multiple of 256 (ldx2=%d)", who, x2_col, ldx2);
+  CGG_REQUIRE(!y2 || (y2_col > 0 && y2_col % 256 == 0), CGG_EUNSUPPORTED,
+              "%s: y2_col=%d must be a positive multiple of 256", who, y2_col);
+  CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "%s: bad sizes", who);
+  CGG_REQUIRE(K % 16 == 0 && ldx % 4 == 0, CGG_EUNSUPPORTED, "%s: K=%d ldx=%d", who, K, ldx);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w_packed), CGG_EALIGN, "%s: alignment", who);
+  if (ksplit < 1) ksplit = 1;
+  const bool ln = ln_gamma != nullptr;
+  CGG_REQUIRE(!ln || (ln_beta && N <= 256 && ksplit == 1), CGG_EUNSUPPORTED,
+              "%s: the LayerNorm epilogue needs N <= 256 and no K split", who);
+  CGG_REQUIRE(!yp || (pos && pos_rows > 0 && ksplit == 1), CGG_EINVAL, "%s: yp needs pos, no split", who);
+  CGG_REQUIRE(ksplit == 1 || relu_cols == 0, CGG_EUNSUPPORTED, "%s: no ReLU with a K split", who);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + 255) / 256, (M + 31) / 32, ksplit);
+  const CggX3W w = x3 ? cgg_x3_view(w_packed, N, K) : CggX3W{(const cgg_u32x4*)w_packed, nullptr, nullptr};
+#define LR2_LAUNCH(LN, X3)                                                                                                  \
+  hipLaunchKernelGGL((cgg_lr2_kernel<LN, X3>), grid, dim3(512), 0, s, x, ldx, (const u32x4*)w.hi, (const u32x4*)w.lo, w.scale, \
+                     bias, res, ldr, y, ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols, x2, ldx2,  \
+                     x2_col, y2, ldy2, y2_col)
+  if (ln && x3) LR2_LAUNCH(true, true);
+  else if (ln) LR2_LAUNCH(true, false);
+  else if (x3) LR2_LAUNCH(false, true);
+  else LR2_LAUNCH(false, false);
+#undef LR2_LAUNCH
+  CGG_CHECK_LAUNCH(who);
+  return CGG_OK;
+}
+
 extern "C" int cgg_linear_rows_bf16(const float* x, int ldx, const void* w_packed, const float* bias,
                                     const float* res, int ldr, float* y, int ldy, const float* ln_gamma,
                                     const float* ln_beta, float ln_eps, const float* pos, int pos_rows, float* yp,
                                     int ldyp, int M, int N, int K, int relu_cols, int ksplit, const float* x2, int ldx2,
                                     int x2_col, float* y2, int ldy2, int y2_col, cgg_stream_t stream) {
-  CGG_REQUIRE(x && w_packed && y, CGG_EINVAL, "cgg_linear_rows_bf16: null pointer");
-  CGG_REQUIRE(!x2 || (x2_col > 0 && x2_col % 256 == 0 && ldx2 % 4 == 0 && cgg_aligned16(x2)), CGG_EUNSUPPORTED,
-              "cgg_linear_rows_bf16: x2_col=%d must be a positive multiple of 256 (ldx2=%d)", x2_col, ldx2);
-  CGG_REQUIRE(!y2 || (y2_col > 0 && y2_col % 256 == 0), CGG_EUNSUPPORTED,
-              "cgg_linear_rows_bf16: y2_col=%d must be a positive multiple of 256", y2_col);
-  CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "cgg_linear_rows_bf16: bad sizes");
-  CGG_REQUIRE(K % 16 == 0 && ldx % 4 == 0, CGG_EUNSUPPORTED, "cgg_linear_rows_bf16: K=%d ldx=%d", K, ldx);
-  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(w_packed), CGG_EALIGN, "cgg_linear_rows_bf16: alignment");
-  if (ksplit < 1) ksplit = 1;
-  const bool ln = ln_gamma != nullptr;
-  CGG_REQUIRE(!ln || (ln_beta && N <= 256 && ksplit == 1), CGG_EUNSUPPORTED,
-              "cgg_linear_rows_bf16: the LayerNorm epilogue needs N <= 256 and no K split");
-  CGG_REQUIRE(!yp || (pos && pos_rows > 0 && ksplit == 1), CGG_EINVAL, "cgg_linear_rows_bf16: yp needs pos, no split");
-  CGG_REQUIRE(ksplit == 1 || relu_cols == 0, CGG_EUNSUPPORTED, "cgg_linear_rows_bf16: no ReLU with a K split");
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid((N + 255) / 256, (M + 31) / 32, ksplit);
-  if (ln)
-    hipLaunchKernelGGL(cgg_lr2_kernel<true>, grid, dim3(512), 0, s, x, ldx, (const u32x4*)w_packed, bias, res, ldr, y,
-                       ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols, x2, ldx2, x2_col, y2, ldy2, y2_col);
-  else
-    hipLaunchKernelGGL(cgg_lr2_kernel<false>, grid, dim3(512), 0, s, x, ldx, (const u32x4*)w_packed, bias, res, ldr, y,
-                       ldy, ln_gamma, ln_beta, ln_eps, pos, pos_rows, yp, ldyp, M, N, K, relu_cols, x2, ldx2, x2_col, y2, ldy2, y2_col);
-  CGG_CHECK_LAUNCH("cgg_linear_rows_bf16");
+  return lr2_launch(false, "cgg_linear_rows_bf16", x, ldx, w_packed, bias, res, ldr, y, ldy, ln_gamma, ln_beta, ln_eps, pos,
+                    pos_rows, yp, ldyp, M, N, K, relu_cols, ksplit, x2, ldx2, x2_col, y2, ldy2, y2_col, stream);
+}
+
+extern "C" int cgg_linear_rows_x3(const float* x, int ldx, const void* w_x3, const float* bias,
+                                  const float* res, int ldr, float* y, int ldy, const float* ln_gamma,
+                                  const float* ln_beta, float ln_eps, const float* pos, int pos_rows, float* yp,
+                                  int ldyp, int M, int N, int K, int relu_cols, int ksplit, const float* x2, int ldx2,
+                                  int x2_col, float* y2, int ldy2, int y2_col, cgg_stream_t stream) {
+  return lr2_launch(true, "cgg_linear_rows_x3", x, ldx, w_x3, bias, res, ldr, y, ldy, ln_gamma, ln_beta, ln_eps, pos,
+                    pos_rows, yp, ldyp, M, N, K, relu_cols, ksplit, x2, ldx2, x2_col, y2, ldy2, y2_col, stream);
+}
+
+// ---- x3 image of a weight (x3.h): per-row power-of-two scale, then hi / lo f16 B fragments ----
+__global__ __launch_bounds__(256) void cgg_x3_rowscale_kernel(const float* __restrict__ w, float* __restrict__ colscale, int N,
+                                                             int K, int NP) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= NP) return;
+  float m = 0.f;
+  if (n < N)
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(w[(size_t)n * K + k]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) {
+    float cs = 0.f;
+    if (n < N) {
+      int e = 0;
+      if (m > 0.f && m < 3.0e38f) frexpf(m, &e);          // m = f 2^e, f in [0.5, 1): w' = w 2^(11 - e) has max in [2^10, 2^11)
+      cs = ldexpf(CGG_X3_INV_ASCALE, e - 11);              // un-scales the accumulator: 2^(e - 11) / ASCALE
+    }
+    colscale[n] = cs;
+  }
+}
+
+__global__ __launch_bounds__(256) void cgg_x3_pack_kernel(const float* __restrict__ w, const float* __restrict__ colscale,
+                                                         u32x4* __restrict__ hi, u32x4* __restrict__ lo, int N, int K,
+                                                         long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const long long t = i >> 6;
+  const int KS = K >> 4;
+  const int ks = (int)(t % KS), nt = (int)(t / KS);
+  const int n = nt * 32 + (lane & 31);
+  const int k = ks * 16 + 8 * (lane >> 5);
+  u32x4 ph = {0u, 0u, 0u, 0u}, pl = ph;
+  if (n < N) {
+    const float ws = CGG_X3_INV_ASCALE / colscale[n];      // = 2^(11 - e), exact
+    const float* s = w + (size_t)n * K + k;
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cgg_x3_split2(s[2 * e] * ws, s[2 * e + 1] * ws, h[e], l[e]);
+    ph = u32x4{h[0], h[1], h[2], h[3]};
+    pl = u32x4{l[0], l[1], l[2], l[3]};
+  }
+  hi[i] = ph;
+  lo[i] = pl;
+}
+
+extern "C" int64_t cgg_x3_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 16) return 0;
+  const int64_t nt = (N + 31) / 32;
+  return 2 * nt * (K / 16) * 64 * 16 + nt * 32 * 4;
+}
+
+extern "C" int cgg_x3_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream) {
+  CGG_REQUIRE(w && packed, CGG_EINVAL, "cgg_x3_pack: null pointer");
+  CGG_REQUIRE(N > 0 && K > 0 && K % 16 == 0, CGG_EUNSUPPORTED, "cgg_x3_pack: N=%d K=%d (K %% 16)", N, K);
+  CGG_REQUIRE(cgg_aligned16(packed), CGG_EALIGN, "cgg_x3_pack: alignment");
+  const int NP = (N + 31) / 32 * 32;
+  const long long total = (long long)(NP / 32) * (K / 16) * 64;
+  u32x4* hi = (u32x4*)packed;
+  u32x4* lo = hi + total;
+  float* cs = (float*)(hi + 2 * total);
+  hipLaunchKernelGGL(cgg_x3_rowscale_kernel, dim3((NP + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, cs, N, K, NP);
+  hipLaunchKernelGGL(cgg_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (const float*)cs, hi, lo, N, K, total);
+  CGG_CHECK_LAUNCH("cgg_x3_pack");
   return CGG_OK;
 }

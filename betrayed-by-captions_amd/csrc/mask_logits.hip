@@ -8,7 +8,11 @@
 // goes straight into MFMA registers (no LDS round trip for the streamed operand); the small,
 // 100%-reused A operand (mask_embed, <= 128x256) sits in LDS in fragment order (conflict-free
 // ds_read_b128); outputs leave as full 128-B lines.
-#include "cgg_common.h"
+//
+// SPLIT = true is parity mode's f32-class form (x3.h): both operands are split into two f16 pieces (pre-scaled by 2^4 each,
+// un-scaled by 2^-8 in the epilogue), three v_mfma_f32_32x32x16_f16 per k-step into the one accumulator -- as accurate as
+// an f32 GEMM (rounds 1-2 used a 3 x bf16 split, 8-10 x less accurate, and an exact-f32 MFMA kernel at 172 us).
+#include "x3.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void cgg_pack_kernel(const float* __restrict__
   uint16_t h[8], l[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    if (SPLIT) cgg_split_bf(v[e], h[e], l[e]);
+    if (SPLIT) cgg_x3_split1(v[e], h[e], l[e]);
     else h[e] = cgg_f2bf(v[e]);
   }
   const size_t slot = (((size_t)b * T + (p >> 5)) * KC + kc) * 32 + (p & 31);
@@ -118,6 +122,58 @@ __global__ __launch_bounds__(256) void cgg_pack_nhwc_kernel(const uint4* __restr
   __syncthreads();
   u32x4* dst = hi + ((size_t)b * T + t) * n;
   for (int idx = threadIdx.x; idx < n; idx += 256) dst[idx] = tile[idx];
+}
+
+// parity mode's pack: channel-last F32 map [B, H, W, C] -> the x3 images (hi, lo: [B, T, C/8, 32, 8] f16 pieces, x3.h) of up to 4
+// jobs (full resolution + the 2x2-mean images of the decoder levels) from one launch. One block = one 32-pixel tile: 32-byte
+// channel octets are read pixel-major (1 KiB contiguous per pixel), split, and written octet-major through LDS.
+struct PackJobsX3 { int n; int pool[4]; int Wp[4]; int npix[4]; int T[4]; int t0[4]; u32x4* hi[4]; u32x4* lo[4]; };
+
+__global__ __launch_bounds__(256) void cgg_pack_nhwc_f32_x3_kernel(const float* __restrict__ feat, PackJobsX3 jobs, int KC, int H,
+                                                                   int W) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 tile[];   // hi [KC][32] | lo [KC][32]
+  int job = 0;
+  while (job + 1 < jobs.n && (int)blockIdx.x >= jobs.t0[job + 1]) ++job;
+  const int t = blockIdx.x - jobs.t0[job], b = blockIdx.y;
+  const int pool = jobs.pool[job], Wp = jobs.Wp[job], npix = jobs.npix[job], T = jobs.T[job];
+  const int n = KC * 32;
+  const size_t C = (size_t)KC * 8;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    const int pl = idx / KC, kc = idx - pl * KC;
+    const int p = t * 32 + pl;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (p < npix) {
+      if (pool == 1) {
+        const float* s0 = feat + ((size_t)b * H * W + p) * C + kc * 8;
+        v0 = *reinterpret_cast<const f32x4*>(s0);
+        v1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+      } else {
+        const int i = p / Wp, j = p - i * Wp;
+        const int r0 = pool * i + (pool >> 1) - 1, c0 = pool * j + (pool >> 1) - 1;
+        const float* s00 = feat + ((size_t)b * H * W + (size_t)r0 * W + c0) * C + kc * 8;
+        const float* s10 = s00 + (size_t)W * C;
+        // same association order as the NCHW pack kernel / torch's bilinear with all lambdas == 0.5
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(s00 + 4 * h), c = *reinterpret_cast<const f32x4*>(s00 + C + 4 * h);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(s10 + 4 * h), e = *reinterpret_cast<const f32x4*>(s10 + C + 4 * h);
+          const f32x4 m = ((a + c) + (d + e)) * 0.25f;
+          if (h == 0) v0 = m; else v1 = m;
+        }
+      }
+    }
+    u32x4 ph, plo;
+    cgg_x3_split8(v0, v1, ph, plo);
+    tile[kc * 32 + pl] = ph;
+    tile[n + kc * 32 + pl] = plo;
+  }
+  __syncthreads();
+  u32x4* dh = jobs.hi[job] + ((size_t)b * T + t) * n;
+  u32x4* dl = jobs.lo[job] + ((size_t)b * T + t) * n;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    dh[idx] = tile[idx];
+    dl[idx] = tile[n + idx];
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -194,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
           uint16_t h[4], lw[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (SPLIT) cgg_split_bf(ev[u][e], h[e], lw[e]);
+            if (SPLIT) cgg_x3_split1(ev[u][e], h[e], lw[e]);
             else h[e] = cgg_f2bf(ev[u][e]);
           }
           a_hi2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(h[0], h[1]), cgg_pack2(h[2], h[3]));
@@ -220,16 +276,15 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
       const u32x4* __restrict__ al = a_lo + mt * (KS * 64) + lane;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 vbh = __builtin_bit_cast(bf16x8, cur[ks]);
-        const bf16x8 vah = __builtin_bit_cast(bf16x8, ah[ks * 64]);
         if constexpr (SPLIT) {
-          const bf16x8 val = __builtin_bit_cast(bf16x8, al[ks * 64]);
-          const bf16x8 vbl = __builtin_bit_cast(bf16x8, bl[ks]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbl, acc, 0, 0, 0);
+          cgg_x3_mfma(acc, ah[ks * 64], al[ks * 64], cur[ks], bl[ks]);
+        } else {
+          const bf16x8 vbh = __builtin_bit_cast(bf16x8, cur[ks]);
+          const bf16x8 vah = __builtin_bit_cast(bf16x8, ah[ks * 64]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbh, acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vbh, acc, 0, 0, 0);
       }
+      if constexpr (SPLIT) acc = acc * (CGG_X3_INV_ASCALE * CGG_X3_INV_ASCALE);      // both operands carry the 2^4 pre-scale
       const int rows_left = Q - mt * 32;                                     // uniform; >= 32 for full m-tiles
       if (ob != nullptr) {
         float* __restrict__ tile_row = ob + (size_t)(mt * 32) * npix;        // uniform
@@ -398,6 +453,38 @@ extern "C" int cgg_pack_mask_feature_nhwc_multi(const void* feat, void* const* h
   hipLaunchKernelGGL(cgg_pack_nhwc_kernel, dim3(total, B), dim3(256), (size_t)KC * 32 * 16, (hipStream_t)stream,
                      (const uint4*)feat, jobs, KC, H, W);
   CGG_CHECK_LAUNCH("cgg_pack_mask_feature_nhwc");
+  return CGG_OK;
+}
+
+extern "C" int cgg_pack_mask_feature_nhwc_f32_x3(const float* feat, void* const* hi_host, void* const* lo_host,
+                                                  const int* pools_host, int n, int B, int C, int H, int W, cgg_stream_t stream) {
+  CGG_REQUIRE(feat && hi_host && lo_host && pools_host, CGG_EINVAL, "cgg_pack_mask_feature_nhwc_f32_x3: null pointer");
+  CGG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && n >= 1 && n <= 4, CGG_EINVAL, "cgg_pack_mask_feature_nhwc_f32_x3: bad sizes");
+  CGG_REQUIRE(C % 8 == 0 && C <= 1024, CGG_EUNSUPPORTED, "cgg_pack_mask_feature_nhwc_f32_x3: C=%d", C);
+  CGG_REQUIRE(cgg_aligned16(feat), CGG_EALIGN, "cgg_pack_mask_feature_nhwc_f32_x3: alignment");
+  PackJobsX3 jobs;
+  jobs.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int pool = pools_host[i];
+    CGG_REQUIRE(pool == 1 || (pool >= 2 && pool % 2 == 0 && H % pool == 0 && W % pool == 0), CGG_EUNSUPPORTED,
+                "cgg_pack_mask_feature_nhwc_f32_x3: pool=%d must be 1 or an even divisor of %dx%d", pool, H, W);
+    CGG_REQUIRE(hi_host[i] && lo_host[i] && cgg_aligned16(hi_host[i]) && cgg_aligned16(lo_host[i]), CGG_EALIGN,
+                "cgg_pack_mask_feature_nhwc_f32_x3: output %d", i);
+    const int Hp = H / pool, Wp = W / pool;
+    jobs.pool[i] = pool;
+    jobs.Wp[i] = Wp;
+    jobs.npix[i] = Hp * Wp;
+    jobs.T[i] = (Hp * Wp + 31) / 32;
+    jobs.t0[i] = total;
+    jobs.hi[i] = (u32x4*)hi_host[i];
+    jobs.lo[i] = (u32x4*)lo_host[i];
+    total += jobs.T[i];
+  }
+  const int KC = C / 8;
+  hipLaunchKernelGGL(cgg_pack_nhwc_f32_x3_kernel, dim3(total, B), dim3(256), (size_t)KC * 32 * 16 * 2, (hipStream_t)stream, feat,
+                     jobs, KC, H, W);
+  CGG_CHECK_LAUNCH("cgg_pack_mask_feature_nhwc_f32_x3");
   return CGG_OK;
 }
 

@@ -131,6 +131,28 @@ extern "C" int cgg_group_norm(const float* x, const float* gamma, const float* b
 // -------------------------------------------------------------------------------------------------
 #define GNH_PIX 64   // pixels per stats block (1024 blocks per 256x256 image; partials are reduced by a second kernel)
 
+// the 8 channels of (pixel-group) vector i: one 16-byte bf16 vector, or two of f32 (XF32: parity mode's f32 channel-last maps)
+template <bool XF32>
+__device__ __forceinline__ void gnh_load(const uint4* __restrict__ x, size_t i, float* f) {
+  if constexpr (XF32) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] = a[k];
+      f[k + 4] = b[k];
+    }
+  } else {
+    const uint4 v = x[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = __uint_as_float(w[k] << 16);
+      f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+  }
+}
+
+template <bool XF32>
 __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __restrict__ x, float* __restrict__ ws,
                                                                int HW, int G, int ppb, int B_G2_floats) {
   // thread t: group g = t % G (G <= 256 and 256 % G == 0), pixel lane = t / G
@@ -142,11 +164,11 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __r
   const int p1 = min(p0 + ppb, HW);
   float s = 0.f, q = 0.f;
   for (int p = p0 + pl; p < p1; p += PL) {
-    const uint4 v = x[((size_t)b * HW + p) * G + g];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+    gnh_load<XF32>(x, ((size_t)b * HW + p) * G + g, f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+      const float lo = f[2 * k], hi = f[2 * k + 1];
       s += lo + hi;
       q += lo * lo + hi * hi;
     }
@@ -201,7 +223,7 @@ __device__ __forceinline__ uint4 gnh_pack(const float* f) {
                     cgg_pack2(cgg_f2bf(f[4]), cgg_f2bf(f[5])), cgg_pack2(cgg_f2bf(f[6]), cgg_f2bf(f[7])));
 }
 
-template <bool UPADD>
+template <bool UPADD, bool XF32>
 __global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
     const uint4* __restrict__ x, const float* __restrict__ ws, const float* __restrict__ gamma,
     const float* __restrict__ beta, int HW, int G, float inv_n, float eps, int relu,
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
   const float mean = s * inv_n;
   const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
   float f[8];
-  gnh_unpack(x[(size_t)b * HW * G + i], f);
+  gnh_load<XF32>(x, (size_t)b * HW * G + i, f);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 8), gb = *reinterpret_cast<const f32x4*>(gamma + g * 8 + 4);
   const f32x4 ba = *reinterpret_cast<const f32x4*>(beta + g * 8), bb = *reinterpret_cast<const f32x4*>(beta + g * 8 + 4);
 #pragma unroll
@@ -275,10 +297,10 @@ extern "C" int64_t cgg_group_norm_nhwc_workspace_bytes(int B, int HW, int groups
   return ((int64_t)B * groups * 2 + (int64_t)B * nblk * groups * 2) * (int64_t)sizeof(float);
 }
 
-extern "C" int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, void* ws, int B, int HW,
-                                   int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
-                                   int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
-                                   const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
+static int gnh_launch(bool xf32, const void* x, const float* gamma, const float* beta, void* ws, int B, int HW,
+                      int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
+                      int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
+                      const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
   CGG_REQUIRE(x && gamma && beta && ws, CGG_EINVAL, "cgg_group_norm_nhwc: null pointer");
   CGG_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0, CGG_EINVAL, "cgg_group_norm_nhwc: bad sizes");
   CGG_REQUIRE(C == groups * 8 && groups <= 256 && 256 % groups == 0, CGG_EUNSUPPORTED,
@@ -294,20 +316,41 @@ extern "C" int cgg_group_norm_nhwc(const void* x, const float* gamma, const floa
   hipStream_t s = (hipStream_t)stream;
   const int nblk = (HW + GNH_PIX - 1) / GNH_PIX;
   const int head = B * groups * 2;        // ws = [B][G][2] totals, then [B][nblk][G][2] per-block partials
-  hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel, dim3(nblk, B), dim3(256), 0, s, (const uint4*)x, (float*)ws, HW, groups,
-                     GNH_PIX, head);
+  if (xf32)
+    hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel<true>, dim3(nblk, B), dim3(256), 0, s, (const uint4*)x, (float*)ws, HW, groups,
+                       GNH_PIX, head);
+  else
+    hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel<false>, dim3(nblk, B), dim3(256), 0, s, (const uint4*)x, (float*)ws, HW, groups,
+                       GNH_PIX, head);
   hipLaunchKernelGGL(cgg_gn_nhwc_reduce_kernel, dim3(B * groups), dim3(64), 0, s, (float*)ws, head, nblk, groups, B);
   const long long nvec = (long long)HW * groups;
   const dim3 grid((unsigned)((nvec + 255) / 256), B);
   const float inv_n = 1.f / ((float)HW * 8.f);
-  if (up_src)
-    hipLaunchKernelGGL(cgg_gn_nhwc_apply_kernel<true>, grid, dim3(256), 0, s, (const uint4*)x, (const float*)ws,
-                       gamma, beta, HW, groups, inv_n, eps, relu, up_src, up_h, up_w, (long long)up_bstride, W, y32,
-                       (long long)y32_bstride, (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8));
-  else
-    hipLaunchKernelGGL(cgg_gn_nhwc_apply_kernel<false>, grid, dim3(256), 0, s, (const uint4*)x, (const float*)ws,
-                       gamma, beta, HW, groups, inv_n, eps, relu, (const float*)nullptr, 0, 0, 0ll, W, y32,
-                       (long long)y32_bstride, (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8));
+#define GNH_APPLY(UP, XF)                                                                                                   \
+  hipLaunchKernelGGL((cgg_gn_nhwc_apply_kernel<UP, XF>), grid, dim3(256), 0, s, (const uint4*)x, (const float*)ws, gamma, beta,  \
+                     HW, groups, inv_n, eps, relu, up_src, up_h, up_w, (long long)up_bstride, W, y32, (long long)y32_bstride,  \
+                     (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8))
+  if (up_src && xf32) GNH_APPLY(true, true);
+  else if (up_src) GNH_APPLY(true, false);
+  else if (xf32) GNH_APPLY(false, true);
+  else GNH_APPLY(false, false);
+#undef GNH_APPLY
   CGG_CHECK_LAUNCH("cgg_group_norm_nhwc");
   return CGG_OK;
+}
+
+extern "C" int cgg_group_norm_nhwc(const void* x, const float* gamma, const float* beta, void* ws, int B, int HW,
+                                   int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
+                                   int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
+                                   const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
+  return gnh_launch(false, x, gamma, beta, ws, B, HW, C, groups, eps, relu, up_src, up_h, up_w, up_bstride, W, y32, y32_bstride,
+                    y16, pos, yp16, y16_bstride, stream);
+}
+
+extern "C" int cgg_group_norm_nhwc_f32(const float* x, const float* gamma, const float* beta, void* ws, int B, int HW,
+                                       int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
+                                       int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
+                                       const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
+  return gnh_launch(true, x, gamma, beta, ws, B, HW, C, groups, eps, relu, up_src, up_h, up_w, up_bstride, W, y32, y32_bstride,
+                    y16, pos, yp16, y16_bstride, stream);
 }

@@ -1,0 +1,92 @@
+// "f32-class" contractions on the f16 matrix cores (parity mode of the path; runtime precision 'fp32').
+//
+// The reference computes every contraction of open_set/models/mask2former_head.py:763-849 in f32. gfx950's f32-input
+// MFMA runs at 1/16 of the 16-bit rate, so parity mode splits each f32 operand into two f16 pieces and issues THREE
+// v_mfma_f32_32x32x16_f16 per product into ONE f32 accumulator:
+//
+//     a' = s_a a = ah + al,   ah = f16(a'),  al = f16(a' - ah)          (residual computed exactly in f32)
+//     sum_k a'b' ~= sum_k (al bh + ah bl + ah bh)                        (the dropped al bl term is <= 2^-22 |a'b'|)
+//
+// f16 carries 11 significand bits, so the pair (ah, al) holds a' to 22 bits (f32: 24); the 22-bit products are exact in the
+// MFMA's f32 accumulation. Operands are pre-scaled by powers of two so that the low pieces stay well inside f16's range:
+// activations by CGG_X3_ASCALE = 2^4 (|a| < 4094 required -- larger values overflow to inf / NaN, loudly), every weight row n
+// by 2^e_n with max_k |w'_nk| in [2^10, 2^11). Low pieces that still fall below 2^-14 become f16 subnormals (absolute
+// error <= 2^-25 of the pre-scaled value); v_cvt_pk_f16_f32 produces them and the f16 MFMA consumes them without flushing
+// (checked on MI355X, scratch/x3/denorm_test.hip). The accumulator is un-scaled in the epilogue by colscale[n] =
+// 2^-e_n / CGG_X3_ASCALE (exact). Measured against float64 the result is as accurate as an f32 GEMM (tests/test_x3_gpu.py);
+// a 3 x bf16 split (8 + 8 bits, round 1-2) was 8-10 x worse than f32.
+//
+// Packed weight ("x3 image") of W [N, K] f32, K % 16 == 0, NT = ceil(N / 32), KS = K / 16:
+//     hi  [NT][KS][64 lanes] x 16 B   B fragments of v_mfma_f32_32x32x16_f16: lane l holds W'[32 nt + (l & 31)][16 ks + 8 (l >> 5) .. + 7]
+//     lo  [NT][KS][64 lanes] x 16 B   the residual pieces, same order
+//     colscale [NT * 32] f32
+// = cgg_x3_packed_bytes(N, K) bytes; rows >= N are zero with colscale 0.
+#pragma once
+#include "cgg_common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float cgg_f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t cgg_u32x4;
+
+#define CGG_X3_ASCALE 16.0f
+#define CGG_X3_INV_ASCALE 0.0625f
+
+// (a, b) -> packed f16 pair hi and residual pair lo of the values AS GIVEN (caller applies the pre-scale)
+__device__ __forceinline__ void cgg_x3_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const cgg_f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);                       // v_cvt_pk_f16_f32 (RNE)
+  const cgg_f32x2 r = v - __builtin_convertvector(h, cgg_f32x2);           // exact
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// 4 activations (un-scaled) -> 8-byte halves of an A-fragment slot
+__device__ __forceinline__ void cgg_x3_split4(const f32x4 v, uint2& hi, uint2& lo) {
+  const f32x4 s = v * CGG_X3_ASCALE;
+  cgg_x3_split2(s[0], s[1], hi.x, lo.x);
+  cgg_x3_split2(s[2], s[3], hi.y, lo.y);
+}
+
+// 8 activations -> one 16-byte A-fragment slot each
+__device__ __forceinline__ void cgg_x3_split8(const f32x4 v0, const f32x4 v1, cgg_u32x4& hi, cgg_u32x4& lo) {
+  uint2 h0, l0, h1, l1;
+  cgg_x3_split4(v0, h0, l0);
+  cgg_x3_split4(v1, h1, l1);
+  hi = cgg_u32x4{h0.x, h0.y, h1.x, h1.y};
+  lo = cgg_u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+
+// one activation -> its two f16 pieces (element-wise fragment stores)
+__device__ __forceinline__ void cgg_x3_split1(float a, uint16_t& hi, uint16_t& lo) {
+  const float s = a * CGG_X3_ASCALE;
+  const _Float16 h = (_Float16)s;
+  const _Float16 l = (_Float16)(s - (float)h);
+  hi = __builtin_bit_cast(uint16_t, h);
+  lo = __builtin_bit_cast(uint16_t, l);
+}
+
+// acc += A B^T for one k-step, A = (ah, al), B = (bh, bl): small terms first
+__device__ __forceinline__ void cgg_x3_mfma(f32x16& acc, const cgg_u32x4 ah, const cgg_u32x4 al, const cgg_u32x4 bh,
+                                            const cgg_u32x4 bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+}
+
+// views of an x3 image
+struct CggX3W {
+  const cgg_u32x4* hi;
+  const cgg_u32x4* lo;
+  const float* scale;
+};
+
+static inline CggX3W cgg_x3_view(const void* packed, int N, int K) {
+  const size_t frags = (size_t)((N + 31) / 32) * (K / 16) * 64;
+  CggX3W w;
+  w.hi = (const cgg_u32x4*)packed;
+  w.lo = packed ? w.hi + frags : nullptr;
+  w.scale = packed ? (const float*)(w.hi + 2 * frags) : nullptr;
+  return w;
+}

@@ -656,6 +656,26 @@ class Mask2FormerHeadOpen(nn.Module):
                     mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
                     poss.append(self.decoder_positional_encoding.flat_unpadded(level_hw[i][0], level_hw[i][1], mf.device))
             packed_full, pooled = self._pack_stream(mf, sizes)
+        elif (hasattr(pd, 'stream_ready_x3') and pd.stream_ready_x3(feats) and pd.num_outs >= L
+              and all(isinstance(p, nn.Identity) for p in self.decoder_input_projs)
+              and self.transformer_decoder.post_norm is not None and self.query_embed.weight.shape[1] % 32 == 0
+              and all(l.stream_ready() for l in self.transformer_decoder.layers)):
+            # parity-mode inference: channel-last f32 all the way on the f32-class x3 kernels; the mask feature only ever
+            # exists as its packed x3 images (full + pooled, one launch)
+            mf, memorys, level_hw = pd.forward_stream_x3(feats)
+            mask_features = None
+            H4, W4 = int(mf.shape[1]), int(mf.shape[2])
+            pools = []
+            for i in range(L):
+                h, w = level_hw[i]
+                sizes.append((h, w))
+                mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
+                poss.append(self.decoder_positional_encoding.flat_unpadded(h, w, mf.device))
+                s = H4 // h
+                pools.append(s if (h * s == H4 and w * s == W4 and s in (2, 4, 8)) else None)
+            uniq = [1] + sorted({p for p in pools if p is not None})
+            packed = dict(zip(uniq, ops.pack_mask_feature_nhwc_x3(mf, uniq)))
+            packed_full, pooled = packed[1], [packed[p] if p is not None else None for p in pools]
         else:
             feats = [f.float().contiguous() if f.dtype != torch.float32 else f for f in feats]
             mask_features, memorys = pd(feats)
@@ -691,7 +711,12 @@ class Mask2FormerHeadOpen(nn.Module):
         # K/V of every decoder layer (layer i reads level i % L) -- independent of the queries
         kvs = [layers[i].attentions[0].project_kv(mems[i % L], poss[i % L])
                for i in range(self.num_transformer_decoder_layers)]
-        return dict(stream=False, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled,
+        # parity mode: the query side runs the same row-stream kernels as throughput mode on f32-class (x3) contractions,
+        # with the f32 [K | V] tensors and the f32-MFMA attention kernels
+        x3_stream = (runtime.x3_enabled() and not torch.is_grad_enabled() and packed_full.hi.is_cuda
+                     and self.transformer_decoder.post_norm is not None and all(l.stream_ready() for l in layers)
+                     and self.query_embed.weight.shape[1] % 32 == 0)
+        return dict(stream=x3_stream, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled,
                     mask_features=mask_features)
 
     def _decode(self, enc, B, all_masks=True):

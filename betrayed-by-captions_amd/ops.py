@@ -220,7 +220,8 @@ def pack_mask_feature(feat, pool=1, split=True):
                                        dev_ptr(lo), B, C, H, W, pool, stream_ptr(feat.device))
     check(rc, 'cgg_pack_mask_feature')
     f32 = None
-    if split and C == 256 and EXACT_F32_LOGITS:
+    from . import runtime
+    if split and C == 256 and EXACT_F32_LOGITS and not runtime.x3_enabled():
         # parity mode: keep the f32 map for `cgg_mask_logits_f32` (pool > 1: the same 2x2 mean, same association order
         # as the pack kernel and as torch's bilinear down-sampling with all lambdas 0.5)
         if pool == 1:
@@ -957,14 +958,17 @@ def group_norm_nhwc(x, gamma, beta, groups, eps, ws, relu=False, up=None, W=0, o
     Destinations are raw (tensor, offset, stride) triples so the three encoder levels can land directly inside the
     (B, N, C) stream tensors."""
     B, HW, C = x.shape
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise CggError(f'group_norm_nhwc: x dtype {x.dtype}')
+    fn = _lib_().cgg_group_norm_nhwc if x.dtype == torch.bfloat16 else _lib_().cgg_group_norm_nhwc_f32
     need = _lib_().cgg_group_norm_nhwc_workspace_bytes(B, HW, int(groups))
     if ws is None or ws.numel() * ws.element_size() < need:
         raise CggError(f'group_norm_nhwc: workspace too small ({need} bytes needed; see group_norm_nhwc_workspace)')
     b16 = out16[2] if out16 is not None else (outp16[2] if outp16 is not None else 0)
     if out16 is not None and outp16 is not None and out16[2] != outp16[2]:
         raise CggError('group_norm_nhwc: out16 and outp16 must share the batch stride')
-    rc = _lib_().cgg_group_norm_nhwc(
-        dev_ptr(x, 'x', torch.bfloat16), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
+    rc = fn(
+        dev_ptr(x, 'x', x.dtype), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
         dev_ptr(ws, 'ws', torch.float32), B, HW, C, int(groups), float(eps), int(bool(relu)),
         _ptr_at(up[0], up[1]) if up is not None else None, up[3] if up is not None else 0,
         up[4] if up is not None else 0, up[2] if up is not None else 0, int(W),
@@ -989,6 +993,30 @@ def pack_mask_feature_nhwc(feat, pool=1):
     return PackedFeature(hi, None, B, C, h, w)
 
 
+def pack_mask_feature_nhwc_x3(feat, pools):
+    """feat (B, H, W, C) F32 channel-last -> [PackedFeature with hi / lo x3 images for each pool in `pools`] (<= 4) from ONE
+    launch: parity mode's packed mask feature (split mode of `mask_logits`)."""
+    B, H, W, C = feat.shape
+    if feat.dtype != torch.float32 or not feat.is_contiguous():
+        raise CggError('pack_mask_feature_nhwc_x3: feat must be a contiguous (B, H, W, C) float32 tensor')
+    outs, hp, lp = [], [], []
+    for pool in pools:
+        if H % pool or W % pool:
+            raise CggError(f'pack_mask_feature_nhwc_x3: {H}x{W} not divisible by pool={pool}')
+        h, w = H // pool, W // pool
+        hi = torch.empty((B, (h * w + 31) // 32, C // 8, 32, 8), dtype=torch.bfloat16, device=feat.device)
+        lo = torch.empty_like(hi)
+        outs.append(PackedFeature(hi, lo, B, C, h, w))
+        hp.append(hi.data_ptr())
+        lp.append(lo.data_ptr())
+    n = len(pools)
+    rc = _lib_().cgg_pack_mask_feature_nhwc_f32_x3(dev_ptr(feat, 'mask_feature', torch.float32), (ctypes.c_void_p * n)(*hp),
+                                                   (ctypes.c_void_p * n)(*lp), _int_array([int(p) for p in pools]), n,
+                                                   B, C, H, W, stream_ptr(feat.device))
+    check(rc, 'cgg_pack_mask_feature_nhwc_f32_x3')
+    return outs
+
+
 def pack_mask_feature_nhwc_multi(feat, pools):
     """feat (B, H, W, C) bf16 channel-last -> [PackedFeature for each pool in `pools`] (<= 4) from ONE launch."""
     B, H, W, C = feat.shape
@@ -1011,6 +1039,83 @@ def pack_mask_feature_nhwc_multi(feat, pools):
 # ------------------------------------------------------------------------------------------------
 # throughput-mode query-side linear (packed bf16 weights, fused LayerNorm / `+ pos` / split-K)
 # ------------------------------------------------------------------------------------------------
+class X3Image(torch.Tensor):
+    """uint8 buffer holding the x3 image of a weight (csrc/x3.h): the query-side wrappers route to the *_x3 kernels when they
+    are handed one instead of a bf16 packed buffer."""
+
+    def __deepcopy__(self, memo):       # cached images sit in module __dict__s that get deep-copied with the module
+        return self.as_subclass(torch.Tensor).clone().as_subclass(X3Image)
+
+
+def is_x3(packed):
+    return isinstance(packed, X3Image)
+
+
+def _x3_fn(name, *packed):
+    """C entry point `cgg_<name>_bf16` or its f32-class twin `cgg_<name>_x3`; all packed operands must be of one kind."""
+    kinds = {is_x3(p) for p in packed if p is not None}
+    if len(kinds) > 1:
+        raise CggError(f'{name}: bf16 and x3 packed weights mixed in one call')
+    return getattr(_lib_(), f'cgg_{name}_x3' if True in kinds else f'cgg_{name}_bf16'), ('x3' if True in kinds else 'bf16')
+
+
+def pack_linear_weight_x3(weight):
+    """weight (N, K) f32 -> x3 image (hi / lo f16 MFMA-B fragments + per-column scales) for the parity-mode kernels."""
+    N, K = weight.shape
+    nbytes = _lib_().cgg_x3_packed_bytes(N, K)
+    if nbytes <= 0:
+        raise CggError(f'pack_linear_weight_x3: unsupported shape {tuple(weight.shape)} (K % 16)')
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+    w = weight.detach().float().contiguous()
+    rc = _lib_().cgg_x3_pack(dev_ptr(w, 'weight', torch.float32), dev_ptr(out), N, K, stream_ptr(weight.device))
+    check(rc, 'cgg_x3_pack')
+    return out.as_subclass(X3Image)
+
+
+def pack_conv_weight_x3(weight):
+    """conv filter (N, C, KH, KW) -> x3 image with k = (ky, kx, c), the order `conv_x3_nhwc` walks a channel-last map in."""
+    N = weight.shape[0]
+    return pack_linear_weight_x3(weight.detach().float().permute(0, 2, 3, 1).reshape(N, -1))
+
+
+def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
+    """a (M, K) f32 rows (row stride free, last dim contiguous) x x3 image -> act(a W^T + bias (+ res)) (M, N) f32:
+    parity mode's large linear (csrc/x3_gemm.hip)."""
+    if a.dim() != 2 or a.stride(1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
+        raise CggError('gemm_x3: a must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
+    M, K = a.shape
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
+        raise CggError('gemm_x3: bad `out` view')
+    if res is not None and (res.dim() != 2 or res.stride(1) != 1 or res.shape != (M, N) or res.dtype != torch.float32):
+        raise CggError('gemm_x3: bad `res` view')
+    with _timed('gemm_x3'):
+        rc = _lib_().cgg_gemm_x3(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                 ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                 res.stride(0) if res is not None else 0, ctypes.c_void_p(y.data_ptr()), y.stride(0), M, N, K,
+                                 int(bool(relu)), stream_ptr(a.device))
+    check(rc, 'cgg_gemm_x3')
+    return y
+
+
+def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, relu=False):
+    """x (B, H, W, C) f32 channel-last (contiguous) -> act(conv + bias (+ res)) (B, OH, OW, N) f32 as an implicit GEMM on the
+    x3 image made by `pack_conv_weight_x3` (C % 32 == 0)."""
+    if x.dim() != 4 or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda or not is_x3(packed):
+        raise CggError('conv_x3_nhwc: x must be a contiguous (B, H, W, C) float32 ROCm tensor, packed an x3 image')
+    B, H, W, C = x.shape
+    KH, KW = (kernel, kernel) if isinstance(kernel, int) else kernel
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = torch.empty((B, OH, OW, N), dtype=torch.float32, device=x.device)
+    if res is not None and (tuple(res.shape) != (B, OH, OW, N) or not res.is_contiguous() or res.dtype != torch.float32):
+        raise CggError('conv_x3_nhwc: res must be a contiguous (B, OH, OW, N) float32 tensor')
+    with _timed('conv_x3'):
+        rc = _lib_().cgg_conv_x3_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res), dev_ptr(y),
+                                      B, H, W, C, N, KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
+    check(rc, 'cgg_conv_x3_nhwc')
+    return y
+
+
 def pack_linear_weight(weight):
     """weight (N, K) f32 -> opaque packed bf16 buffer for `linear_rows_bf16` (uint8 tensor)."""
     N, K = weight.shape
@@ -1034,11 +1139,12 @@ def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, po
     if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda:
         raise CggError('linear_rows_bf16: x must be a 2-D float32 ROCm tensor with a contiguous last dim')
     M, K = x.shape
+    fn, _ = _x3_fn('linear_rows', packed)
     if ksplit > 1:
         if out is not None or want_pos or ln is not None or relu_cols:
             raise CggError('linear_rows_bf16: split-K returns (ksplit, M, N) partial planes; no out / ln / pos / relu')
         y = torch.empty((int(ksplit), M, N), dtype=torch.float32, device=x.device)
-        rc = _lib_().cgg_linear_rows_bf16(
+        rc = fn(
             ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
             ctypes.c_void_p(res.data_ptr()) if res is not None else None, res.stride(0) if res is not None else 0,
             dev_ptr(y), N, None, None, 0.0, None, 0, None, 0, M, N, K, 0, int(ksplit), None, 0, 0, None, 0, 0,
@@ -1052,7 +1158,7 @@ def linear_rows_bf16(x, packed, N, bias=None, res=None, relu_cols=0, ln=None, po
         raise CggError('linear_rows_bf16: bad `res` view')
     yp = torch.empty((M, N), dtype=torch.float32, device=x.device) if want_pos else None
     g, b, eps = ln if ln is not None else (None, None, 0.0)
-    rc = _lib_().cgg_linear_rows_bf16(
+    rc = fn(
         ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
         ctypes.c_void_p(res.data_ptr()) if res is not None else None, res.stride(0) if res is not None else 0,
         ctypes.c_void_p(y.data_ptr()), y.stride(0), dev_ptr(g, 'gamma', torch.float32),
@@ -1074,7 +1180,7 @@ def linear_rows_bf16_qkv(xqk, xv, packed, bias, E):
         raise CggError('linear_rows_bf16_qkv: E must be a multiple of 256')
     q = torch.empty((M, E), dtype=torch.float32, device=xqk.device)
     kv = torch.empty((M, 2 * E), dtype=torch.float32, device=xqk.device)
-    rc = _lib_().cgg_linear_rows_bf16(
+    rc = _x3_fn('linear_rows', packed)[0](
         ctypes.c_void_p(xqk.data_ptr()), xqk.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), None, 0,
         dev_ptr(q), E, None, None, 0.0, None, 0, None, 0, M, 3 * E, K, 0, 1,
         ctypes.c_void_p(xv.data_ptr()), xv.stride(0), 2 * E, dev_ptr(kv), 2 * E, E, stream_ptr(xqk.device))
@@ -1123,7 +1229,7 @@ def decoder_mid(core, wo, bo, res, norm, pos=None, qkv=None):
         wqkv, bqkv = qkv
         q = torch.empty((M, C), dtype=torch.float32, device=dev)
         kv = torch.empty((M, 2 * C), dtype=torch.float32, device=dev)
-    rc = _lib_().cgg_decoder_mid_bf16(
+    rc = _x3_fn('decoder_mid', wo, wqkv)[0](
         ctypes.c_void_p(core.data_ptr()), core.stride(0), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32),
         ctypes.c_void_p(res.data_ptr()), res.stride(0), dev_ptr(norm[0], 'gamma', torch.float32),
         dev_ptr(norm[1], 'beta', torch.float32), float(norm[2]), dev_ptr(pos, 'pos', torch.float32),
@@ -1140,7 +1246,7 @@ def decoder_ffn(x, w1, b1, w2, b2, F):
     if x.stride(1) != 1 or x.dtype != torch.float32 or F % 256:
         raise CggError('decoder_ffn: x must be (M, C) float32 rows and F a multiple of 256')
     planes = torch.empty((F // 256, M, C), dtype=torch.float32, device=x.device)
-    rc = _lib_().cgg_decoder_ffn_bf16(ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(w1),
+    rc = _x3_fn('decoder_ffn', w1, w2)[0](ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(w1),
                                       dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2), dev_ptr(b2, 'b2', torch.float32),
                                       dev_ptr(planes), M, C, int(F), stream_ptr(x.device))
     check(rc, 'cgg_decoder_ffn_bf16')
@@ -1174,7 +1280,7 @@ def decoder_tail(planes, norm_a, pos, norm_b, mlp, qproj=None, want_pos=False):
     me = torch.empty_like(y)
     qn = torch.empty_like(y) if qproj is not None else None
     wq, bq = qproj if qproj is not None else (None, None)
-    rc = _lib_().cgg_decoder_tail_bf16(
+    rc = _x3_fn('decoder_tail', mlp[0], mlp[2], mlp[4], wq)[0](
         dev_ptr(planes), nsum, M * C, C, dev_ptr(norm_a[0], 'gamma_a', torch.float32),
         dev_ptr(norm_a[1], 'beta_a', torch.float32), float(norm_a[2]), dev_ptr(pos, 'pos', torch.float32), pos.shape[0],
         dev_ptr(norm_b[0], 'gamma_b', torch.float32), dev_ptr(norm_b[1], 'beta_b', torch.float32), float(norm_b[2]),

@@ -790,6 +790,102 @@ class MSDeformAttnPixelDecoder(nn.Module):
         ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, relu=True, out16=(z, 0, H4 * W4 * C))
         return self._gemm1x1(z.view(B * H4 * W4, C), self.mask_feature).view(B, H4, W4, -1)
 
+    # ---- parity-mode inference stream: channel-last F32 from the backbone to the mask feature, every contraction on the
+    #      f32-class x3 kernels (ops.gemm_x3 / conv_x3_nhwc: f16 x 3 MFMA, f32 accumulate), norms / sampling in f32 ----
+    def stream_ready_x3(self, feats):
+        """True when `forward_stream_x3` applies: parity mode on the x3 kernels, no autograd, channel-last f32 features (what the
+        ResNet's parity-mode path hands over), GN-32 over 256 channels, post-norm ReLU encoder layers, one FPN level."""
+        if not runtime.x3_enabled() or torch.is_grad_enabled():
+            return False
+        if self.num_input_levels - self.num_encoder_levels != 1 or self.mask_feature.out_channels != 256:
+            return False
+        for f in feats:
+            if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 4 and f.permute(0, 2, 3, 1).is_contiguous()
+                    and f.shape[1] % 32 == 0):
+                return False
+        for cm in list(self.input_convs) + list(self.lateral_convs) + list(self.output_convs):
+            gn = getattr(cm, cm.norm_name, None) if cm.norm_name else None
+            if not isinstance(gn, nn.GroupNorm) or gn.num_channels != 256 or gn.num_groups != 32:
+                return False
+        if not isinstance(self.output_convs[0].activate, nn.ReLU) or self.input_convs[0].activate is not None:
+            return False
+        oc = self.output_convs[0].conv
+        if tuple(oc.kernel_size) != (3, 3) or tuple(oc.stride) != (1, 1) or tuple(oc.padding) != (1, 1):
+            return False
+        return all(tuple(l.operation_order) == ('self_attn', 'norm', 'ffn', 'norm') and self._stream_ok(l)
+                   and isinstance(l.norms[0], nn.LayerNorm) and l.attentions[0].embed_dims == 256 for l in self.encoder.layers)
+
+    def _encoder_stream_x3(self, src, pos, ref, level_hw, level_start):
+        """The 6 encoder layers on the (B, N, 256) f32 stream: value / offsets+weights / output / FFN projections on the x3 GEMM
+        (residuals and the ReLU in its epilogue), the f32 MSDeformAttn kernel with the softmax / location prologue inside."""
+        B, N, C = src.shape
+        lx = runtime.linear_x3
+        for layer in self.encoder.layers:
+            attn = layer.attentions[0]
+            H = attn.num_heads
+            so, aw = attn.sampling_offsets, attn.attention_weights
+            w_cat = runtime.derived_cached('msda_wcat32', (so.weight, aw.weight),
+                                           lambda: torch.cat([so.weight, aw.weight], 0).float().contiguous())
+            b_cat = runtime.derived_cached('msda_bcat32', (so.bias, aw.bias),
+                                           lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
+            value = lx(src, attn.value_proj.weight, attn.value_proj.bias).view(B, N, H, C // H)
+            offs = lx(src + pos[None], w_cat, b_cat)
+            a = ops.msda_forward_fused(value, level_hw, level_start, offs, ref, attn.num_points)
+            y = lx(a, attn.output_proj.weight, attn.output_proj.bias, res=src)
+            n0, n1 = layer.norms
+            x1 = ops.add_layernorm_stream(y, None, n0.weight, n0.bias, n0.eps, want_bf16=False)[0]
+            fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
+            h = lx(x1, fc1.weight, fc1.bias, relu=True)
+            y = lx(h, fc2.weight, fc2.bias, res=x1)
+            src = ops.add_layernorm_stream(y, None, n1.weight, n1.bias, n1.eps, want_bf16=False)[0]
+        return src
+
+    def forward_stream_x3(self, feats):
+        """-> (mask_feature (B, H4, W4, C) f32 channel-last, [memories (B, hw_l, C) f32 low->high res], level sizes). 1x1
+        convolutions are x3 GEMMs on the (B*H*W, C) views, the 3x3 output convolution the x3 implicit GEMM, every GroupNorm the
+        channel-last kernel on f32 input (the three encoder inputs normalised straight into the (B, N, C) stream, the FPN's
+        `cur + up-sample(out)` in the GroupNorm's epilogue)."""
+        B = feats[0].shape[0]
+        dev = feats[0].device
+        C = 256
+        level_hw = []
+        for i in range(self.num_encoder_levels):
+            f = feats[self.num_input_levels - i - 1]
+            level_hw.append((int(f.shape[2]), int(f.shape[3])))
+        level_start, N = [], 0
+        for h, w in level_hw:
+            level_start.append(N)
+            N += h * w
+        pos = self._pos_cached(level_hw, dev)
+        ref = self._reference_points(level_hw, dev)
+        src = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        ws = ops.group_norm_nhwc_workspace(B, int(feats[0].shape[2]) * int(feats[0].shape[3]), 32, dev)   # largest map
+        for i in range(self.num_encoder_levels):
+            f = feats[self.num_input_levels - i - 1]
+            h, w = level_hw[i]
+            cm = self.input_convs[i]
+            y = runtime.linear_x3(f.permute(0, 2, 3, 1).reshape(B * h * w, f.shape[1]), cm.conv.weight.flatten(1), cm.conv.bias)
+            gn = getattr(cm, cm.norm_name)
+            ops.group_norm_nhwc(y.view(B, h * w, C), gn.weight, gn.bias, 32, gn.eps, ws, out32=(src, level_start[i] * C, N * C))
+        src = self._encoder_stream_x3(src, pos, ref, level_hw, level_start)
+        mems = [src[:, s0:s0 + h * w, :] for s0, (h, w) in zip(level_start, level_hw)]
+        # FPN: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN + ReLU, mask_feature
+        f = feats[0]
+        H4, W4 = int(f.shape[2]), int(f.shape[3])
+        lat, outc = self.lateral_convs[0], self.output_convs[0]
+        y = runtime.linear_x3(f.permute(0, 2, 3, 1).reshape(B * H4 * W4, f.shape[1]), lat.conv.weight.flatten(1), lat.conv.bias)
+        gn = getattr(lat, lat.norm_name)
+        hl, wl = level_hw[-1]
+        y = y.view(B, H4 * W4, C)
+        ops.group_norm_nhwc(y, gn.weight, gn.bias, 32, gn.eps, ws, up=(src, level_start[-1] * C, N * C, hl, wl), W=W4,
+                            out32=(y, 0, H4 * W4 * C))
+        w3 = runtime.derived_cached('x3_conv_image', (outc.conv.weight,), lambda: ops.pack_conv_weight_x3(outc.conv.weight))
+        z = ops.conv_x3_nhwc(y.view(B, H4, W4, C), w3, C, 3, 1, 1, outc.conv.bias).view(B, H4 * W4, C)
+        gn = getattr(outc, outc.norm_name)
+        ops.group_norm_nhwc(z, gn.weight, gn.bias, 32, gn.eps, ws, relu=True, out32=(z, 0, H4 * W4 * C))
+        mf = runtime.linear_x3(z.view(B * H4 * W4, C), self.mask_feature.weight.flatten(1), self.mask_feature.bias)
+        return mf.view(B, H4, W4, -1), mems, level_hw
+
     def forward(self, feats):
         B = feats[0].shape[0]
         dev = feats[0].device

@@ -93,10 +93,21 @@ class MultiheadAttention(nn.Module):
         E = self.embed_dims
         w_kv, b_kv = self.kv_weight()
         if key_pos is not None:
-            kbias = F.linear(key_pos, w_kv[:E])                       # (S,C): pos @ Wk^T
-            bias = torch.cat([kbias + b_kv[:E], b_kv[E:].expand(kbias.shape[0], E)], 1)  # (S,2C)
+            def make_bias():
+                kbias = F.linear(key_pos, w_kv[:E])                   # (S,C): pos @ Wk^T
+                return torch.cat([kbias + b_kv[:E], b_kv[E:].expand(kbias.shape[0], E)], 1).contiguous()  # (S,2C)
+            if _needs_grad(key_pos, w_kv, b_kv):
+                bias = make_bias()
+            else:   # inference: depends on the weights and the level's (cached) encoding alone
+                bias = runtime.derived_cached('kv_pos_bias', (key_pos, self.attn.in_proj_weight, self.attn.in_proj_bias), make_bias)
         else:
             bias = b_kv
+        if bias.dim() == 2 and runtime.x3_linear_ok(mem, w_kv) and mem.dim() == 3:
+            # parity mode: the batch-independent (S, 2C) bias rides in the x3 GEMM's residual input, one image at a time
+            kv = torch.empty((mem.shape[0], mem.shape[1], 2 * E), dtype=torch.float32, device=mem.device)
+            for b in range(mem.shape[0]):
+                runtime.linear_x3(mem[b], w_kv, None, res=bias, out=kv[b])
+            return kv
         kv = runtime.linear(mem, w_kv)
         return (kv + bias).contiguous()
 
@@ -298,7 +309,7 @@ class DetrTransformerDecoderLayer(BaseTransformerLayer):
             kv2 = torch.empty((M, 2 * E), dtype=torch.float32, device=x.device)
             lr(x1p, wk, E, bk, out=kv2[:, :E])
             lr(x1, wv, E, bv, out=kv2[:, E:])
-        if Q <= 128 and E // sa.num_heads == 32:
+        if Q <= 128 and E // sa.num_heads == 32 and runtime.is_bf16():
             core2 = ops.self_attn_rows_bf16(q2, kv2, B, sa.num_heads)
         else:
             core2 = ops.masked_xattn(q2.view(B, Q, E), kv2.view(B, Q, 2 * E), None, sa.num_heads).view(M, E)

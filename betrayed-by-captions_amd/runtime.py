@@ -38,6 +38,13 @@ def is_bf16():
     return _STATE['precision'] == 'bf16'
 
 
+def x3_enabled():
+    """Parity mode on the f32-class f16 x 3 kernels (csrc/x3.h); CGG_X3=0 restores the round-2 parity path (f32 library
+    GEMMs, f32-MFMA skinny linears) for A/B measurements."""
+    import os
+    return _STATE['precision'] == 'fp32' and os.environ.get('CGG_X3', '1') != '0'
+
+
 @contextlib.contextmanager
 def precision_scope(p):
     old = _STATE['precision']
@@ -144,7 +151,29 @@ def linear(x, weight, bias=None):
         return y.float()
     if is_bf16():
         return linear_bf16_train(x, weight, bias).float()
+    if x3_linear_ok(x, weight):
+        return linear_x3(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def x3_linear_ok(x, weight):
+    """parity mode, no autograd, ROCm f32 rows whose K the x3 GEMM tiles (K % 32 == 0), enough rows to be worth a tile grid."""
+    return (x3_enabled() and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and weight.shape[1] % 32 == 0 and x.shape[-1] == weight.shape[1] and x.numel() // x.shape[-1] >= 512)
+
+
+def linear_x3(x, weight, bias=None, res=None, relu=False, out=None):
+    """act(x W^T + b (+ res)) on the f32-class x3 GEMM (`ops.gemm_x3`), the weight's x3 image cached like `packed_cached`."""
+    from . import ops
+    N, K = weight.shape
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    wk = derived_cached('x3_image', (weight,), lambda: ops.pack_linear_weight_x3(weight))
+    r2 = res.reshape(-1, N) if res is not None else None
+    y = ops.gemm_x3(x2, wk, N, bias.detach() if bias is not None else None, res=r2, relu=relu,
+                    out=out.view(-1, N) if out is not None else None)
+    return out if out is not None else y.view(*x.shape[:-1], N)
 
 
 _CONST = {}
@@ -165,13 +194,16 @@ _PCACHE = {}
 
 
 def packed_cached(weights, biases=None):
-    """(packed bf16 MFMA-fragment image of cat(weights, 0), cat(biases) | None, N) for `ops.linear_rows_bf16`, cached
+    """(packed MFMA-fragment image of cat(weights, 0), cat(biases) | None, N) for `ops.linear_rows_bf16`, cached
     like `cast_cached` (slice address + geometry, validated by weak references / versions of the owning
-    parameters). `weights` is a tuple of (N_i, K) tensors (parameters or views of parameters)."""
+    parameters). `weights` is a tuple of (N_i, K) tensors (parameters or views of parameters). The image is bf16 in
+    throughput mode and an x3 image (f32-class f16 x 3 contraction, `ops.pack_linear_weight_x3`) in parity mode; the
+    kernels pick their variant from the image type."""
     from . import ops
     allp = tuple(weights) + tuple(b for b in (biases or ()) if b is not None)
     bases = [t._base if t._base is not None else t for t in allp]
-    key = tuple(_wkey(t, 'packed') for t in allp)
+    kind = 'packed' if is_bf16() else 'x3'
+    key = tuple(_wkey(t, kind) for t in allp)
     hit = _PCACHE.get(key)
     if hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and \
             hit[1] == tuple(b._version for b in bases) and hit[2].device == weights[0].device:
@@ -180,7 +212,7 @@ def packed_cached(weights, biases=None):
         for k in [k for k, v in _PCACHE.items() if any(r() is None for r in v[0])]:
             del _PCACHE[k]
     w = torch.cat([t.detach().float() for t in weights], 0) if len(weights) > 1 else weights[0].detach().float()
-    packed = ops.pack_linear_weight(w.contiguous())
+    packed = ops.pack_linear_weight(w.contiguous()) if kind == 'packed' else ops.pack_linear_weight_x3(w.contiguous())
     bias = None
     if biases is not None:
         bias = torch.cat([b.detach().float() for b in biases], 0).contiguous() if len(biases) > 1 \

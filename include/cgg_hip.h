@@ -364,6 +364,57 @@ int cgg_decoder_mid_bf16(const float* core, int ldc, const void* wo, const float
 int cgg_decoder_ffn_bf16(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
                          float* planes, int M, int C, int F, cgg_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Parity mode ("x3"): the same query-side kernels on f32-class contractions. The reference runs every linear of
+ * open_set/models/mask2former_head.py:711-761 and of the [3P] DetrTransformerDecoderLayer in f32; here each f32 operand is
+ * split into two f16 pieces and every product is three v_mfma_f32_32x32x16_f16 into one f32 accumulator (csrc/x3.h:
+ * 22-bit operands, pre-scaled by powers of two, f32-GEMM accuracy; activations must satisfy |x| < 4094). The weight is
+ * packed once by cgg_x3_pack into an "x3 image" of cgg_x3_packed_bytes(N, K) bytes (hi fragments, lo fragments, per-column
+ * un-scaling factors; K % 16 == 0). The *_x3 entry points take the argument lists of their *_bf16 twins with x3 images in
+ * place of the bf16 packed weights.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t cgg_x3_packed_bytes(int N, int K);
+int cgg_x3_pack(const float* w, void* packed, int N, int K, cgg_stream_t stream);
+int cgg_linear_rows_x3(const float* x, int ldx, const void* w_x3, const float* bias, const float* res,
+                       int ldr, float* y, int ldy, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                       const float* pos, int pos_rows, float* yp, int ldyp, int M, int N, int K, int relu_cols,
+                       int ksplit, const float* x2, int ldx2, int x2_col, float* y2, int ldy2, int y2_col,
+                       cgg_stream_t stream);
+int cgg_decoder_tail_x3(const float* planes, int nsum, int64_t plane_stride, int ld, const float* gamma_a,
+                        const float* beta_a, float eps_a, const float* pos, int pos_rows, const float* gamma_b,
+                        const float* beta_b, float eps_b, const void* w1, const float* b1, const void* w2,
+                        const float* b2, const void* w3, const float* b3, const void* wq, const float* bq, float* y,
+                        float* yp, float* mask_embed, float* qn, int M, int C, cgg_stream_t stream);
+int cgg_decoder_mid_x3(const float* core, int ldc, const void* wo, const float* bo, const float* res, int ldr,
+                       const float* gamma, const float* beta, float eps, const float* pos, int pos_rows,
+                       const void* wqkv, const float* bqkv, float* x1, float* q, float* kv, int M, int C,
+                       cgg_stream_t stream);
+int cgg_decoder_ffn_x3(const float* x, int ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                       float* planes, int M, int C, int F, cgg_stream_t stream);
+
+/* Parity mode's large contractions (csrc/x3_gemm.hip), f32 in / f32 out, f32-class arithmetic, w_x3 = cgg_x3_pack image:
+ *   cgg_gemm_x3:      out[M, N] (row stride ldc) = act(a[M, K] (row stride lda) W^T * colscale + bias (+ res[M, N], stride ldr));
+ *                     relu != 0 applies max(., 0) last. K % 32 == 0, lda % 4 == 0, a 16-byte aligned. bias / res nullable.
+ *   cgg_conv_x3_nhwc: the same contraction as an implicit GEMM over a channel-last map x [B, H, W, C] f32 (C % 32 == 0):
+ *                     out [B, OH, OW, N] = act(conv(x, W, stride, pad) + bias (+ res [B, OH, OW, N])); W's x3 image is packed
+ *                     from the filter re-laid-out as [N][KH][KW][C] (k = (ky, kx, c)). No im2col matrix is written.
+ * Replace the f32 library GEMMs / convolutions under [3P] MSDeformAttnPixelDecoder, nn.MultiheadAttention's key / value
+ * projections (mask2former_head.py:787, :829-840) and the ResNet backbone in parity mode.                          */
+/* Channel-last pieces of parity mode's pixel decoder: cgg_group_norm_nhwc with an F32 input map x [B, HW, C] (same outputs
+ * and options; y32 may alias x), and the x3 images of the channel-last f32 mask feature for cgg_mask_logits' split mode: up to
+ * 4 pools (1 = full resolution, 2 / 4 / 8 = the 2x2-mean images of the decoder levels) from one launch; hi_host / lo_host /
+ * pools_host are HOST arrays of n device pointers / ints, each image [B, ceil(npix / 32), C / 8, 32, 8] 16-bit pieces. */
+int cgg_group_norm_nhwc_f32(const float* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C, int groups,
+                            float eps, int relu, const float* up_src, int up_h, int up_w, int64_t up_bstride, int W,
+                            float* y32, int64_t y32_bstride, void* y16, const float* pos, void* yp16, int64_t y16_bstride,
+                            cgg_stream_t stream);
+int cgg_pack_mask_feature_nhwc_f32_x3(const float* feat, void* const* hi_host, void* const* lo_host, const int* pools_host,
+                                      int n, int B, int C, int H, int W, cgg_stream_t stream);
+int cgg_gemm_x3(const float* a, int lda, const void* w_x3, const float* bias, const float* res, int ldr, float* out, int ldc,
+                int M, int N, int K, int relu, cgg_stream_t stream);
+int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* bias, const float* res, float* out, int B, int H, int W,
+                     int C, int N, int KH, int KW, int stride, int pad, int relu, cgg_stream_t stream);
+
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
 int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma, const float* beta,

@@ -85,8 +85,8 @@ def build_detector_pair(cfg, seed, img, dev):
             m.training = False
     model = model.eval().to(dev)
     with torch.no_grad(), runtime.precision_scope('fp32'):
-        enc = head._encode(model.extract_feat(img.to(dev)))
-        head.pixel_decoder.mask_feature.bias -= enc['mask_features'].mean((0, 2, 3))
+        mf = head.pixel_decoder([f.float().contiguous() for f in model.extract_feat(img.to(dev))])[0]
+        head.pixel_decoder.mask_feature.bias -= mf.mean((0, 2, 3))
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         orc = OH.OracleHead(**head_cfg(cfg))

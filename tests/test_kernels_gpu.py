@@ -1101,10 +1101,12 @@ def test_point_sample_planes_vs_grid_sample(dev):
 
 
 @pytest.mark.parametrize('B,Q,h,w,pool', [(2, 100, 64, 64, 1), (1, 37, 40, 56, 1), (2, 100, 64, 64, 2), (1, 200, 32, 40, 4)])
-def test_mask_logits_exact_f32_kernel(dev, B, Q, h, w, pool):
-    """cgg_mask_logits_f32 (parity mode: f32 MFMA) vs float64: logits to f32 rounding (1e-6 of the operand scale -- the
-    3 x bf16 split kernel sits at 2e-5), attention-mask bits equal to (interpolated logit < 0) away from rounding, for the
-    full-resolution and the pooled feature, ragged pixel tiles and more than 128 queries."""
+def test_mask_logits_exact_f32_kernel(dev, B, Q, h, w, pool, monkeypatch):
+    """cgg_mask_logits_f32 (round 2's parity-mode kernel: f32 MFMA; since round 3 only behind CGG_X3=0, parity mode runs the
+    f16 x 3 split kernel -- tests/test_x3_gpu.py) vs float64: logits to f32 rounding (1e-6 of the operand scale),
+    attention-mask bits equal to (interpolated logit < 0) away from rounding, for the full-resolution and the pooled feature,
+    ragged pixel tiles and more than 128 queries."""
+    monkeypatch.setenv('CGG_X3', '0')
     g = torch.Generator().manual_seed(90 + Q)
     C = 256
     E = torch.randn(B, Q, C, generator=g)
