@@ -1,0 +1,372 @@
+// Parity mode's post-attention half of an MSDeformAttn encoder layer ([3P] BaseTransformerLayer ('self_attn','norm','ffn','norm'),
+// built at open_set/models/mask2former_head.py:112-117; 6 layers x 43 008 rows at configs[1]) as ONE launch on the f32-class
+// f16 x 3 contraction of x3.h -- the f32 twin of cgg_encoder_layer_tail_bf16 (encoder_ffn.hip):
+//
+//     x1 = LayerNorm0( x + a Wo^T + bo )                      a = attention rows (f32), x = layer input rows (f32)
+//     y  = LayerNorm1( x1 + W2 relu(W1 x1 + b1) + b2 )        y32 = y, yp32 = y + pos[row % pos_rows] (optional)
+//
+// replacing three x3 GEMM launches (256 -> 256, 256 -> 1024 + ReLU, 1024 -> 256) and two residual-LayerNorm passes whose
+// f32 intermediates (projection output, x1 twice, the rows x 1024 hidden activation twice: 0.6 GB per layer at configs[1])
+// never leave the chip here: HBM traffic per layer 88 MB in, 44-88 MB out.
+//
+// A workgroup (4 wavefronts, ONE per CU: 130 KiB of LDS) owns 64 complete rows, held in LDS as hi / lo f16 MFMA A-fragment
+// images (bank-swizzled by k-step). The hidden dimension runs in chunks of 256. Wave wn computes the 64-row x 64-column block of
+// every GEMM as 2 x 2 MFMA tiles: per k-step four A-fragment reads (hi, lo of two m-tiles) from LDS and four B-fragment loads
+// (hi, lo of two n-tiles of the x3 image, straight from L2 into registers, EF3_PF k-steps ahead, the queue carried across
+// blocks) feed TWELVE MFMAs (a bf16 kernel gets four out of the same operand traffic). The chunk's relu(. + b1) block goes back
+// to LDS as split A fragments and is consumed by the second GEMM, whose accumulators persist over the chunks. x1 stays in
+// registers (f32) as LayerNorm 1's residual. Epilogues: f32 tile in LDS (it overlays the hidden images) -> row-major LayerNorm,
+// 16 lanes per row, DPP row reductions. v_mfma_f32_32x32x16_f16, f32 accumulation; accuracy of an f32 GEMM chain
+// (tests/test_x3_gpu.py).
+//
+// build-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+#include "x3.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t e3_u32x4;
+
+#define E3_C 256
+#define E3_STEPS 16
+#define E3_RB 64               // rows per workgroup
+#define E3_NT 256              // threads per workgroup: one wavefront per 64 output columns x 64 rows
+#define E3_TS 260              // f32 LayerNorm tile row stride
+#define E3_PF 4                // B-fragment prefetch distance (k-steps); divides E3_STEPS (the queue rotates across blocks)
+#define E3_IMG (2 * E3_STEPS * 64)          // u32x4 slots of one 64 x 256 image piece (32 KiB)
+
+// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float e3_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
+struct E3Q {                   // rotating B-fragment queue of one n-tile: hi and lo pieces
+  e3_u32x4 h[E3_PF], l[E3_PF];
+};
+
+// One 64 x 64 block of C += A B^T over 16 k-steps, x3 arithmetic. A-fragment images (hi at a, lo at a + lo_off) of the two
+// 32-row m-tiles in LDS; B fragments of the two 32-column n-tiles come through the rotating queues q0 / q1, which on entry hold
+// this block's first E3_PF k-steps and on exit the NEXT block's (nb*), so the weight stream never drains at a block boundary.
+// XS = true: row image, swizzled by the whole k-step (slot ^ s); XS = false: hidden image, swizzled by k-step parity (see
+// the store below): a0 / a1 = even k-step lane pointers, a0o / a1o odd ones.
+template <bool XS>
+__device__ __forceinline__ void e3_block(f32x16 (&acc)[2][2], const e3_u32x4* __restrict__ a0, const e3_u32x4* __restrict__ a1,
+                                         const e3_u32x4* __restrict__ a0o, const e3_u32x4* __restrict__ a1o, int lo_off, int xl,
+                                         E3Q& q0, E3Q& q1, const e3_u32x4* __restrict__ b0h, const e3_u32x4* __restrict__ b0l,
+                                         const e3_u32x4* __restrict__ b1h, const e3_u32x4* __restrict__ b1l,
+                                         const e3_u32x4* __restrict__ n0h, const e3_u32x4* __restrict__ n0l,
+                                         const e3_u32x4* __restrict__ n1h, const e3_u32x4* __restrict__ n1l) {
+  if constexpr (XS) asm volatile("" : "+v"(xl));
+  auto load_a = [&](int s, e3_u32x4& h0, e3_u32x4& l0, e3_u32x4& h1, e3_u32x4& l1) {
+    if constexpr (XS) {
+      const int xo = xl ^ s;
+      h0 = a0[s * 64 + xo];
+      l0 = a0[lo_off + s * 64 + xo];
+      h1 = a0[(E3_STEPS + s) * 64 + xo];
+      l1 = a0[lo_off + (E3_STEPS + s) * 64 + xo];
+    } else {
+      const e3_u32x4* p0 = (s & 1) ? a0o : a0;
+      const e3_u32x4* p1 = (s & 1) ? a1o : a1;
+      h0 = p0[s * 64];
+      l0 = p0[lo_off + s * 64];
+      h1 = p1[s * 64];
+      l1 = p1[lo_off + s * 64];
+    }
+  };
+  e3_u32x4 ah0, al0, ah1, al1;
+  load_a(0, ah0, al0, ah1, al1);
+#pragma unroll
+  for (int s = 0; s < E3_STEPS; ++s) {
+    const e3_u32x4 b0hv = q0.h[s % E3_PF], b0lv = q0.l[s % E3_PF], b1hv = q1.h[s % E3_PF], b1lv = q1.l[s % E3_PF];
+    const e3_u32x4 vah0 = ah0, val0 = al0, vah1 = ah1, val1 = al1;
+    if (s + 1 < E3_STEPS) load_a(s + 1, ah0, al0, ah1, al1);
+    if (s + E3_PF < E3_STEPS) {
+      q0.h[s % E3_PF] = b0h[(s + E3_PF) * 64];
+      q0.l[s % E3_PF] = b0l[(s + E3_PF) * 64];
+      q1.h[s % E3_PF] = b1h[(s + E3_PF) * 64];
+      q1.l[s % E3_PF] = b1l[(s + E3_PF) * 64];
+    } else {
+      q0.h[s % E3_PF] = n0h[(s + E3_PF - E3_STEPS) * 64];
+      q0.l[s % E3_PF] = n0l[(s + E3_PF - E3_STEPS) * 64];
+      q1.h[s % E3_PF] = n1h[(s + E3_PF - E3_STEPS) * 64];
+      q1.l[s % E3_PF] = n1l[(s + E3_PF - E3_STEPS) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // loads of the later steps issue BEFORE this step's twelve MFMAs
+#define E3_MF(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+    E3_MF(val0, b0hv, acc[0][0]);
+    E3_MF(val0, b1hv, acc[0][1]);
+    E3_MF(val1, b0hv, acc[1][0]);
+    E3_MF(val1, b1hv, acc[1][1]);
+    E3_MF(vah0, b0lv, acc[0][0]);
+    E3_MF(vah0, b1lv, acc[0][1]);
+    E3_MF(vah1, b0lv, acc[1][0]);
+    E3_MF(vah1, b1lv, acc[1][1]);
+    E3_MF(vah0, b0hv, acc[0][0]);
+    E3_MF(vah0, b1hv, acc[0][1]);
+    E3_MF(vah1, b0hv, acc[1][0]);
+    E3_MF(vah1, b1hv, acc[1][1]);
+#undef E3_MF
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
+    const float* __restrict__ a32, const float* __restrict__ x32, const CggX3W wo, const float* __restrict__ bo,
+    const float* __restrict__ gamma0, const float* __restrict__ beta0, float eps0, const CggX3W w1, const float* __restrict__ b1,
+    const CggX3W w2, const float* __restrict__ b2, const float* __restrict__ gamma1, const float* __restrict__ beta1, float eps1,
+    const float* __restrict__ pos, int pos_rows, float* __restrict__ y32, float* __restrict__ yp32, int M, int F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char e3_smem[];
+  e3_u32x4* xfrag = reinterpret_cast<e3_u32x4*>(e3_smem);                   // row image: hi [2 m-tiles][16][64] | lo    64 KiB
+  e3_u32x4* hfrag = xfrag + 2 * E3_IMG;                                      // hidden chunk: hi | lo                     64 KiB
+  float* tile = reinterpret_cast<float*>(hfrag);                             // [64][E3_TS] f32 LayerNorm tile, overlays the hidden images (65 KiB)
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int j = lane & 31, hi5 = lane >> 5;
+  const int m0 = blockIdx.x * E3_RB;
+  const int nchunk = F >> 8;
+  const int KS2 = F >> 4;                                                    // k-steps of W2
+
+  // weight stream: the first E3_PF k-steps of the output projection are in flight while the rows are staged
+  E3Q q0, q1;
+#pragma unroll
+  for (int s = 0; s < E3_PF; ++s) {
+    q0.h[s] = wo.hi[((size_t)(2 * wn) * E3_STEPS + s) * 64 + lane];
+    q0.l[s] = wo.lo[((size_t)(2 * wn) * E3_STEPS + s) * 64 + lane];
+    q1.h[s] = wo.hi[((size_t)(2 * wn + 1) * E3_STEPS + s) * 64 + lane];
+    q1.l[s] = wo.lo[((size_t)(2 * wn + 1) * E3_STEPS + s) * 64 + lane];
+  }
+  // ---- attention rows -> split A-fragment images: 32-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k-step = k8 / 2,
+  //      (row % 32 + 32 (k8 & 1)) ^ k-step): the XOR spreads a row's pieces over all bank groups ----
+#pragma unroll 4
+  for (int p = tid; p < E3_RB * 32; p += E3_NT) {
+    const int row = p >> 5, k8 = p & 31;
+    const int mc = m0 + row < M ? m0 + row : M - 1;
+    const float* src = a32 + (size_t)mc * E3_C + 8 * k8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    e3_u32x4 h, l;
+    cgg_x3_split8(v0, v1, h, l);
+    const int slot = ((row >> 5) * E3_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1));
+    xfrag[slot] = h;
+    xfrag[E3_IMG + slot] = l;
+  }
+  // the layer-input rows LayerNorm 0 adds (its residual) are requested now: they arrive behind the output projection's MFMAs
+  const int sub = lane & 15, rsub = lane >> 4;
+  f32x4 xr[4][4];                                       // residual rows (later: x1, LayerNorm 1's residual), f32
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = 16 * wn + 4 * it + rsub;
+    const int mc = m0 + row < M ? m0 + row : M - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xr[it][k] = *reinterpret_cast<const f32x4*>(x32 + (size_t)mc * E3_C + 4 * sub + 64 * k);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  __syncthreads();
+  // ---- output projection: a Wo^T (next block in the weight stream: W1's first chunk) ----
+  {
+    const size_t o0 = ((size_t)(2 * wn) * E3_STEPS) * 64 + lane, o1 = ((size_t)(2 * wn + 1) * E3_STEPS) * 64 + lane;
+    e3_block<true>(acc, xfrag, xfrag, xfrag, xfrag, E3_IMG, lane, q0, q1, wo.hi + o0, wo.lo + o0, wo.hi + o1, wo.lo + o1,
+                   w1.hi + o0, w1.lo + o0, w1.hi + o1, w1.lo + o1);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = 64 * wn + 32 * nt + j;
+    const float cs = wo.scale[col], bias = bo[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi5) * E3_TS + col] = acc[mt][nt][r] * cs + bias;
+  }
+  __syncthreads();                                     // the tile is complete, every wave is done with the attention-row image
+  // ---- LayerNorm 0 over x + attn_out, 16 lanes per row; x1 stays in registers (f32) and goes to the row image as split pieces ----
+  {
+    uint2* xh2 = reinterpret_cast<uint2*>(xfrag);
+    uint2* xl2 = reinterpret_cast<uint2*>(xfrag + E3_IMG);
+    constexpr float inv_n = 1.f / (float)E3_C;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = 16 * wn + 4 * it + rsub;
+      f32x4 v[4];
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = *reinterpret_cast<const f32x4*>(&tile[row * E3_TS + 4 * sub + 64 * k]) + xr[it][k];
+        sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+      }
+      sm = e3_row16_sum(sm);
+      const float mean = sm * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = v[k] - mean;
+        q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+      }
+      q = e3_row16_sum(q);
+      const float rstd = rsqrtf(q * inv_n + eps0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma0 + 4 * sub + 64 * k);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta0 + 4 * sub + 64 * k);
+        const f32x4 y = v[k] * rstd * g + be;
+        xr[it][k] = y;
+        // columns c0 = 4 sub + 64 k .. + 3 of the row are half of the 16-byte slot (k-step c0 / 16, half (c0 / 8) & 1)
+        const int ks = (sub >> 2) + 4 * k;
+        const int slot = ((row >> 5) * E3_STEPS + ks) * 64 + (((row & 31) + 32 * ((sub >> 1) & 1)) ^ ks);
+        uint2 h, l;
+        cgg_x3_split4(y, h, l);
+        xh2[2 * slot + (sub & 1)] = h;
+        xl2[2 * slot + (sub & 1)] = l;
+      }
+    }
+  }
+  f32x16 acc2[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+  __syncthreads();                                     // x1 image complete; the tile (hidden region) is free again
+
+  // hidden image, bank-swizzled: slot (k-step, half, row) sits at k-step * 64 + half * 32 + (row ^ 2 (k-step & 1) ^ 8 half), so the
+  // stores of one instruction fall into distinct banks (layout of encoder_ffn.hip); hi and lo images share the addressing
+  const int hoff_e = hi5 * 32 + (j ^ (8 * hi5)), hoff_o = hi5 * 32 + (j ^ 2 ^ (8 * hi5));
+  const e3_u32x4* ha0 = hfrag + hoff_e;
+  const e3_u32x4* ha1 = hfrag + E3_STEPS * 64 + hoff_e;
+  const e3_u32x4* ha0o = hfrag + hoff_o;
+  const e3_u32x4* ha1o = hfrag + E3_STEPS * 64 + hoff_o;
+  uint32_t* h32 = reinterpret_cast<uint32_t*>(hfrag);
+  const int odd = j & 1, k1 = (j >> 4) & 1, half = (j >> 3) & 1;
+  int hb[2][2];                                        // word index of this lane's store for (bit 1, bit 3) of the register row
+#pragma unroll
+  for (int X = 0; X < 2; ++X)
+#pragma unroll
+    for (int Y = 0; Y < 2; ++Y)
+      hb[X][Y] = (((4 * wn + k1) * 64 + half * 32 + 2 * (X ^ k1) + 8 * (Y ^ half) + 4 * hi5 + odd) << 2) + ((j & 7) >> 1);
+  const uint32_t rot = 16u * (uint32_t)odd;
+  for (int c = 0; c < nchunk; ++c) {
+    // ---- GEMM 1: hidden columns 256 c + 64 wn .. (n-tiles 8 c + 2 wn, + 1 of W1); next in the stream: this chunk's W2 slice ----
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const size_t g20 = ((size_t)(2 * wn) * KS2 + 16 * c) * 64 + lane, g21 = ((size_t)(2 * wn + 1) * KS2 + 16 * c) * 64 + lane;
+    const size_t g10 = ((size_t)(8 * c + 2 * wn) * E3_STEPS) * 64 + lane, g11 = ((size_t)(8 * c + 2 * wn + 1) * E3_STEPS) * 64 + lane;
+    e3_block<true>(acc, xfrag, xfrag, xfrag, xfrag, E3_IMG, lane, q0, q1, w1.hi + g10, w1.lo + g10, w1.hi + g11, w1.lo + g11,
+                   w2.hi + g20, w2.lo + g20, w2.hi + g21, w2.lo + g21);
+    // relu(. + b1) -> split A-fragment images of the chunk; column (64 wn + 32 nt + j) of the chunk = k index of GEMM 2. Lanes j,
+    // j ^ 1 hold neighbouring columns: per register pair they swap one value, the even lane then owns row(2 rp), the odd lane
+    // row(2 rp + 1), and each stores one 32-bit word per image
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int hc = 256 * c + 64 * wn + 32 * nt + j;
+      const float cs1 = w1.scale[hc], bias1 = b1[hc];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const float v0 = fmaxf(acc[mt][nt][2 * rp] * cs1 + bias1, 0.f), v1 = fmaxf(acc[mt][nt][2 * rp + 1] * cs1 + bias1, 0.f);
+          const float kept = odd ? v1 : v0, sent = odd ? v0 : v1;
+          const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sent), 0xB1, 0xf, 0xf, true));  // lane ^ 1
+          uint32_t ph, pl;
+          cgg_x3_split2(kept * CGG_X3_ASCALE, recv * CGG_X3_ASCALE, ph, pl);
+          const int o = hb[rp & 1][(rp >> 1) & 1] + (((mt * E3_STEPS + 2 * nt) * 64 + 16 * (rp >> 2)) << 2);
+          h32[o] = __builtin_amdgcn_alignbit(ph, ph, rot);              // odd lanes: (recv, kept)
+          h32[4 * E3_IMG + o] = __builtin_amdgcn_alignbit(pl, pl, rot);
+        }
+      }
+    }
+    __syncthreads();                                   // the chunk's hidden block is complete
+    // ---- GEMM 2: output columns 64 wn .. over the chunk's 256 hidden units (k-steps 16 c .. of W2); next: W1's next chunk ----
+    const int cn = c + 1 < nchunk ? c + 1 : 0;         // last chunk: the queue refills with chunk 0 again (unused)
+    const size_t n10 = ((size_t)(8 * cn + 2 * wn) * E3_STEPS) * 64 + lane, n11 = ((size_t)(8 * cn + 2 * wn + 1) * E3_STEPS) * 64 + lane;
+    e3_block<false>(acc2, ha0, ha1, ha0o, ha1o, E3_IMG, 0, q0, q1, w2.hi + g20, w2.lo + g20, w2.hi + g21, w2.lo + g21,
+                    w1.hi + n10, w1.lo + n10, w1.hi + n11, w1.lo + n11);
+    __syncthreads();                                   // hfrag is rewritten by the next chunk (and by the tile below)
+  }
+
+  // ---- f32 block (* colscale + b2) -> LDS tile; the hidden images are dead ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = 64 * wn + 32 * nt + j;
+    const float cs2 = w2.scale[col], bias2 = b2[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi5) * E3_TS + col] = acc2[mt][nt][r] * cs2 + bias2;
+  }
+  __syncthreads();
+  // ---- row-major LayerNorm of x1 + ffn(x1): wave w owns rows 16 w .. 16 w + 15, four at a time; 16 lanes share a row ----
+  f32x4 g4[4], be4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    g4[k] = *reinterpret_cast<const f32x4*>(gamma1 + 4 * sub + 64 * k);
+    be4[k] = *reinterpret_cast<const f32x4*>(beta1 + 4 * sub + 64 * k);
+  }
+  constexpr float inv_n = 1.f / (float)E3_C;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = 16 * wn + 4 * it + rsub, m = m0 + row;
+    f32x4 v[4];
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = *reinterpret_cast<const f32x4*>(&tile[row * E3_TS + 4 * sub + 64 * k]) + xr[it][k];
+      sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    sm = e3_row16_sum(sm);
+    const float mean = sm * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = v[k] - mean;
+      q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+    }
+    q = e3_row16_sum(q);
+    const float rstd = rsqrtf(q * inv_n + eps1);
+    if (m >= M) continue;
+    const float* prow = yp32 ? pos + (size_t)(m % pos_rows) * E3_C : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+      const size_t o = (size_t)m * E3_C + 4 * sub + 64 * k;
+      *reinterpret_cast<f32x4*>(y32 + o) = y;
+      if (yp32) *reinterpret_cast<f32x4*>(yp32 + o) = y + *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
+    }
+  }
+}
+
+extern "C" int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, const void* wo_x3, const float* bo, const float* gamma0,
+                                         const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
+                                         const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                                         int pos_rows, float* y32, float* yp32, int M, int C, int F, cgg_stream_t stream) {
+  const char* who = "cgg_encoder_layer_tail_x3";
+  CGG_REQUIRE(a32 && x32 && wo_x3 && bo && gamma0 && beta0 && w1_x3 && b1 && w2_x3 && b2 && gamma1 && beta1 && y32, CGG_EINVAL,
+              "%s: null pointer", who);
+  CGG_REQUIRE(C == E3_C, CGG_EUNSUPPORTED, "%s: C=%d (only 256 is built)", who, C);
+  CGG_REQUIRE(M > 0 && F > 0 && F % 256 == 0, CGG_EUNSUPPORTED, "%s: F=%d must be a multiple of 256", who, F);
+  CGG_REQUIRE(!yp32 || (pos && pos_rows > 0), CGG_EINVAL, "%s: yp32 needs pos", who);
+  CGG_REQUIRE(cgg_aligned16(a32) && cgg_aligned16(x32) && cgg_aligned16(wo_x3) && cgg_aligned16(w1_x3) && cgg_aligned16(w2_x3) &&
+                  cgg_aligned16(gamma0) && cgg_aligned16(beta0) && cgg_aligned16(gamma1) && cgg_aligned16(beta1) &&
+                  (!pos || cgg_aligned16(pos)) && cgg_aligned16(y32) && (!yp32 || cgg_aligned16(yp32)),
+              CGG_EALIGN, "%s: 16-B alignment", who);
+  const size_t lds = (size_t)2 * E3_IMG * 16 + (size_t)E3_RB * E3_TS * sizeof(float);      // row images + tile (>= hidden images)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_tail_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    CGG_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise dynamic LDS to %zu", who, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cgg_encoder_tail_x3_kernel, dim3((M + E3_RB - 1) / E3_RB), dim3(E3_NT), lds, (hipStream_t)stream, a32, x32,
+                     cgg_x3_view(wo_x3, E3_C, E3_C), bo, gamma0, beta0, eps0, cgg_x3_view(w1_x3, F, E3_C), b1,
+                     cgg_x3_view(w2_x3, E3_C, F), b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M, F);
+  CGG_CHECK_LAUNCH(who);
+  return CGG_OK;
+}

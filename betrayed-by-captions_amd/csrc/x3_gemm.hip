@@ -8,7 +8,8 @@
 //     its base address per chunk and zero-fills taps that fall outside the map -- no im2col matrix is ever written.
 // Replaces hipBLASLt f32 GEMMs (~100 TF/s) and MIOpen's f32 Winograd / GEMM convolutions of round 2's parity mode.
 //
-// Tiling (MI355X): workgroup = 128 x 128 outputs, 4 wavefronts in a 2 x 2 grid, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32;
+// Tiling (MI355X): workgroup = 128 x 128 outputs (64 x 128 / 128 x 64 / 64 x 64 when the problem has few tiles), 4 wavefronts
+// in a 2 x 2 grid, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32;
 // K in chunks of 32 (two k-steps). A chunk is read as f32 (two 16-byte loads per thread and row: one 128-byte line per row),
 // split ONCE per workgroup into hi / lo f16 A-fragment images in LDS (slot XOR-swizzle: the 8 lanes of a ds_write_b128 group
 // hit 8 different 16-byte bank groups, a fragment read stays a permutation inside its 1-KiB block); the weight is the x3
@@ -21,13 +22,8 @@
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-#define XG_BM 128
-#define XG_BN 128
 #define XG_BK 32
 #define XG_NT 256
-// one LDS stage: A hi [4 m-tiles][2 k-steps][64] | A lo | B hi [4 n-tiles][2][64] | B lo, u32x4 slots
-#define XG_A_SLOTS (4 * 2 * 64)
-#define XG_STAGE_SLOTS (4 * XG_A_SLOTS)
 
 struct XgConv {
   int H, W, C, OH, OW, KW, stride, pad;      // channel-last input [B][H][W][C]; K = KH * KW * C
@@ -38,35 +34,43 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t xg_rsrc(const void* p, uint32_
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-template <bool CONV>
-__global__ __launch_bounds__(XG_NT, 2) void cgg_gemm_x3_kernel(const float* __restrict__ A, int lda, const CggX3W w,
-                                                              const float* __restrict__ bias, const float* __restrict__ res,
-                                                              int ldr, float* __restrict__ out, int ldc, int M, int N, int K,
-                                                              int relu, int tiles_n, int n_tiles32, XgConv cv, uint32_t a_bytes, uint32_t w_bytes) {
-  __shared__ __attribute__((aligned(16))) u32x4 lds[2 * XG_STAGE_SLOTS];      // 64 KiB: two stages
+// Workgroup tile = (64 TM) x (64 TN): 2 x 2 wavefronts, each TM x TN MFMA tiles of 32 x 32. (2, 2) is the throughput shape;
+// the smaller ones keep every CU busy when the problem has few tiles (deep ResNet stages: 2048 rows) or N = 64.
+template <bool CONV, int TM, int TN>
+__global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4) void cgg_gemm_x3_kernel(
+    const float* __restrict__ A, int lda, const CggX3W w, const float* __restrict__ bias, const float* __restrict__ res, int ldr,
+    float* __restrict__ out, int ldc, int M, int N, int K, int relu, int tiles_n, int n_tiles32, XgConv cv, uint32_t a_bytes,
+    uint32_t w_bytes) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_SLOTS = 2 * TM * 2 * 64;                 // one piece of the A stage: [2 TM m-tiles][2 k-steps][64 lanes] x 16 B
+  constexpr int B_SLOTS = 2 * TN * 2 * 64;
+  constexpr int STAGE = 2 * (A_SLOTS + B_SLOTS);           // A hi | A lo | B hi | B lo
+  constexpr int NB = 2 * TN;                               // 16-byte B units per thread and chunk
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi5 = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int m0 = tile_m * XG_BM, nt0 = tile_n * (XG_BN / 32);
+  const int m0 = tile_m * BM, nt0 = tile_n * (BN / 32);
   const int KS = K >> 4, nchunk = K / XG_BK;
 
-  // ---- A loader: thread -> rows ar + 64 i (i = 0, 1), 8 floats k8 of the chunk. Every load is branch-free: rows past M
-  //      read row M - 1 (their results are never stored); the conv form goes through a buffer descriptor and sends taps
-  //      outside the map to an out-of-range offset, which the hardware answers with zeros ----
+  // ---- A loader: thread -> rows ar + 64 i (i < TM), 8 floats k8 of the chunk. Every load is branch-free: rows past M
+  //      read row M - 1 (their results are never stored); the conv form sends taps outside the map to an out-of-range
+  //      offset of the buffer descriptor, which the hardware answers with zeros ----
   const int ar = tid >> 2, k8 = tid & 3;
   const __amdgpu_buffer_rsrc_t arsrc = xg_rsrc(A, a_bytes);
-  uint32_t aoff[2];                                        // byte offset of the row (GEMM) / of the image (CONV) + 32 k8
-  int aiy[2], aix[2];                                      // CONV: top-left input coordinate of the row's receptive field
+  uint32_t aoff[TM];                                       // byte offset of the row (GEMM) / of the image (CONV) + 32 k8
+  int aiy[TM], aix[TM];                                    // CONV: top-left input coordinate of the row's receptive field
+  int aslot[TM];                                           // LDS slot: m-tile (row >> 5), k-step k8 >> 1, half k8 & 1, swizzled row
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + ar + 64 * i;
+  for (int i = 0; i < TM; ++i) {
+    const int r = ar + 64 * i, m = m0 + r;
     const int mc = m < M ? m : M - 1;
     if constexpr (CONV) {
       const int ohw = cv.OH * cv.OW;
-      const int b = mc / ohw, r = mc - b * ohw;
-      const int oy = r / cv.OW, ox = r - oy * cv.OW;
+      const int b = mc / ohw, rr = mc - b * ohw;
+      const int oy = rr / cv.OW, ox = rr - oy * cv.OW;
       aiy[i] = oy * cv.stride - cv.pad;
       aix[i] = ox * cv.stride - cv.pad;
       aoff[i] = (uint32_t)b * (uint32_t)(cv.H * cv.W * cv.C) * 4u + 32u * k8;
@@ -74,65 +78,90 @@ __global__ __launch_bounds__(XG_NT, 2) void cgg_gemm_x3_kernel(const float* __re
       aoff[i] = (uint32_t)mc * (uint32_t)lda * 4u + 32u * k8;
       aiy[i] = aix[i] = 0;
     }
-  }
-  // LDS slot of this thread's 8 floats: m-tile (row >> 5), k-step k8 >> 1, half k8 & 1, swizzled row slot
-  int aslot[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = ar + 64 * i;
     aslot[i] = ((r >> 5) * 2 + (k8 >> 1)) * 64 + (((r & 31) ^ ((k8 << 1) & 7)) + 32 * (k8 & 1));
   }
-  // ---- B loader: 16 KiB per chunk = 4 x 16 B per thread; unit u = q 256 + tid -> (piece, n-tile, k-step, lane);
-  //      n-tiles past the weight read its last tile (columns >= N are never stored) ----
+  // ---- B loader: unit u = q 256 + tid -> (piece, n-tile, k-step, lane) of the x3 image; n-tiles past the weight read its last
+  //      tile (columns >= N are never stored) ----
   const __amdgpu_buffer_rsrc_t brsrc = xg_rsrc(w.hi, w_bytes);
-  uint32_t boff[4];                                        // byte offset inside the x3 image at chunk 0; + 2 KiB per chunk
+  uint32_t boff[NB];                                       // byte offset inside the x3 image at chunk 0; + 2 KiB per chunk
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NB; ++q) {
     const int u = q * 256 + tid;
-    const int piece = u >> 9, nt = (u >> 7) & 3, ks = (u >> 6) & 1;
+    const int piece = u / B_SLOTS, within = u - piece * B_SLOTS;
+    const int nt = within >> 7, ks = (within >> 6) & 1;
     const int ntc = nt0 + nt < n_tiles32 ? nt0 + nt : n_tiles32 - 1;
     boff[q] = (uint32_t)(((piece * n_tiles32 + ntc) * KS + ks) * 64 + lane) * 16u;
   }
 
-  auto load_chunk = [&](int c, u32x4 (&av)[2][2], u32x4 (&bv)[4]) {
-    c = c < nchunk ? c : nchunk - 1;                       // the pipeline's run-ahead past the end re-reads the last chunk
-    const int k0 = c * XG_BK;
+  // the loader walks the chunks in order (two ahead of the MFMAs); its position is scalar state: channel offset and filter tap
+  int ld_c = 0, ld_c0 = 0, ld_ky = 0, ld_kx = 0;
+  auto load_chunk = [&](u32x4 (&av)[TM][2], u32x4 (&bv)[NB]) {
+#if defined(XG_EXP) && XG_EXP == 1
+    if (ld_c > 1) { if (ld_c + 1 < nchunk) ++ld_c; return; }
+#endif
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
       if constexpr (CONV) {
-        const int tap = k0 / cv.C, c0 = k0 - tap * cv.C;
-        const int ky = tap / cv.KW, kx = tap - ky * cv.KW;
-        const int iy = aiy[i] + ky, ix = aix[i] + kx;
+        const int iy = aiy[i] + ld_ky, ix = aix[i] + ld_kx;
         const bool ok = iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
         const uint32_t off = ok ? aoff[i] + (uint32_t)((iy * cv.W + ix) * cv.C) * 4u : 0xFFFFFF00u;
-        av[i][0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, c0 * 4, 0);
-        av[i][1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, off + 16u, c0 * 4, 0);
+        av[i][0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, ld_c0 * 4, 0);
+        av[i][1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, off + 16u, ld_c0 * 4, 0);
       } else {
-        av[i][0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], k0 * 4, 0);
-        av[i][1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i] + 16u, k0 * 4, 0);
+        av[i][0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], ld_c * (XG_BK * 4), 0);
+        av[i][1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i] + 16u, ld_c * (XG_BK * 4), 0);
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[q], c * 2048, 0);
+    for (int q = 0; q < NB; ++q) bv[q] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[q], ld_c * 2048, 0);
+    // advance; the run-ahead past the last chunk re-reads it (nothing consumes those registers)
+    if (ld_c + 1 < nchunk) {
+      ++ld_c;
+      if constexpr (CONV) {
+        ld_c0 += XG_BK;
+        if (ld_c0 >= cv.C) {
+          ld_c0 = 0;
+          if (++ld_kx >= cv.KW) {
+            ld_kx = 0;
+            ++ld_ky;
+          }
+        }
+      }
+    }
   };
-  auto store_chunk = [&](int stage, const u32x4 (&av)[2][2], const u32x4 (&bv)[4]) {
-    u32x4* s = lds + stage * XG_STAGE_SLOTS;
+  auto store_chunk = [&](int stage, const u32x4 (&av)[TM][2], const u32x4 (&bv)[NB]) {
+    u32x4* s = lds + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
       u32x4 h, l;
+#if defined(XG_EXP) && XG_EXP == 2
+      h = av[i][0]; l = av[i][1];
+#else
       cgg_x3_split8(__builtin_bit_cast(f32x4, av[i][0]), __builtin_bit_cast(f32x4, av[i][1]), h, l);
+#endif
+#if !(defined(XG_EXP) && XG_EXP == 3)
       s[aslot[i]] = h;
-      s[XG_A_SLOTS + aslot[i]] = l;
+      s[A_SLOTS + aslot[i]] = l;
+#else
+      if (h[0] == 0x12345678u && l[1] == 0x9abcdef0u) s[aslot[i]] = h;
+#endif
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s[2 * XG_A_SLOTS + q * 256 + tid] = bv[q];
+    for (int q = 0; q < NB; ++q) {
+      const int u = q * 256 + tid;
+      const int piece = u / B_SLOTS, within = u - piece * B_SLOTS;
+#if defined(XG_EXP) && XG_EXP == 3
+      if (bv[q][0] == 0x12345678u && bv[q][1] == 0x9abcdef0u)
+#endif
+      s[2 * A_SLOTS + piece * B_SLOTS + within] = bv[q];
+    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -141,59 +170,59 @@ __global__ __launch_bounds__(XG_NT, 2) void cgg_gemm_x3_kernel(const float* __re
   const int aread1 = ((j ^ (((2 + hi5) << 1) & 7)) + 32 * hi5);      // k-step 1: k8 = 2 + hi5
 
   auto compute = [&](int stage) {
-    const u32x4* s = lds + stage * XG_STAGE_SLOTS;
+    const u32x4* s = lds + stage * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 ah[2], al[2], bh[2], bl[2];
+      u32x4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int o = ((2 * wm + mt) * 2 + ks) * 64 + (ks ? aread1 : aread0);
+      for (int mt = 0; mt < TM; ++mt) {
+        const int o = ((TM * wm + mt) * 2 + ks) * 64 + (ks ? aread1 : aread0);
         ah[mt] = s[o];
-        al[mt] = s[XG_A_SLOTS + o];
+        al[mt] = s[A_SLOTS + o];
       }
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int o = 2 * XG_A_SLOTS + ((2 * wn + nt) * 2 + ks) * 64 + lane;
+      for (int nt = 0; nt < TN; ++nt) {
+        const int o = 2 * A_SLOTS + ((TN * wn + nt) * 2 + ks) * 64 + lane;
         bh[nt] = s[o];
-        bl[nt] = s[XG_A_SLOTS + o];
+        bl[nt] = s[B_SLOTS + o];
       }
-      // the three products of a tile go to its accumulator in three rounds over the 4 tiles: neighbouring MFMAs are independent
+      // the three products of a tile go to its accumulator in three rounds over the tiles: neighbouring MFMAs are independent
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < TN; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[mt]), __builtin_bit_cast(f16x8, bh[nt]),
                                                                acc[mt][nt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < TN; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bl[nt]),
                                                                acc[mt][nt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < TN; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bh[nt]),
                                                                acc[mt][nt], 0, 0, 0);
     }
   };
 
   // ---- pipeline: the global loads run TWO chunks ahead of the MFMAs (register sets R0 / R1), the LDS stage one chunk ----
-  u32x4 a0[2][2], b0[4], a1[2][2], b1[4];
-  load_chunk(0, a0, b0);
-  load_chunk(1, a1, b1);
+  u32x4 a0[TM][2], b0[NB], a1[TM][2], b1[NB];
+  load_chunk(a0, b0);
+  load_chunk(a1, b1);
   store_chunk(0, a0, b0);
   __syncthreads();
   for (int c = 0; c + 1 < nchunk; c += 2) {
     // even chunk c: compute from stage 0; chunk c + 1 (in R1) -> stage 1; chunk c + 2 -> R0
-    load_chunk(c + 2, a0, b0);
+    load_chunk(a0, b0);
     __builtin_amdgcn_sched_barrier(0);                     // the loads go out BEFORE the MFMAs (the scheduler sinks them otherwise)
     compute(0);
     store_chunk(1, a1, b1);
     __syncthreads();
     // odd chunk c + 1: compute from stage 1; chunk c + 2 (in R0) -> stage 0; chunk c + 3 -> R1
-    load_chunk(c + 3, a1, b1);
+    load_chunk(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
     compute(1);
     store_chunk(0, a0, b0);
@@ -201,23 +230,27 @@ __global__ __launch_bounds__(XG_NT, 2) void cgg_gemm_x3_kernel(const float* __re
   }
   if (nchunk & 1) compute(0);                              // odd chunk count: the last chunk sits in stage 0
 
-  // ---- epilogue: acc[mt][nt][r] = C[m0 + 64 wm + 32 mt + (r & 3) + 8 (r >> 2) + 4 hi5][32 (nt0 + 2 wn + nt) + j] ----
+  // ---- epilogue: acc[mt][nt][r] = C[m0 + 32 (TM wm + mt) + (r & 3) + 8 (r >> 2) + 4 hi5][32 (nt0 + TN wn + nt) + j] ----
+  const bool full = m0 + BM <= M && (nt0 + 2 * TN) * 32 <= N;        // workgroup-uniform: interior tiles skip the bounds checks
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = (nt0 + 2 * wn + nt) * 32 + j;
-    if (n >= N) continue;
-    const float cs = w.scale[n];
-    const float bs = bias ? bias[n] : 0.f;
+  for (int nt = 0; nt < TN; ++nt) {
+    const int n = (nt0 + TN * wn + nt) * 32 + j;
+    const bool nok = full || n < N;
+    const float cs = nok ? w.scale[n] : 0.f;
+    const float bs = (nok && bias) ? bias[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < TM; ++mt) {
+      const int mrow = m0 + 32 * (TM * wm + mt) + 4 * hi5;
+      float* orow = out + (size_t)mrow * ldc + n;
+      const float* rrow = res ? res + (size_t)mrow * ldr + n : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-        if (m < M) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (full || (nok && mrow + dr < M)) {
           float v = acc[mt][nt][r] * cs + bs;
-          if (res) v += res[(size_t)m * ldr + n];
+          if (rrow) v += rrow[(size_t)dr * ldr];
           if (relu) v = fmaxf(v, 0.f);
-          out[(size_t)m * ldc + n] = v;
+          orow[(size_t)dr * ldc] = v;
         }
       }
     }
@@ -232,20 +265,37 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   CGG_REQUIRE(cgg_aligned16(a) && cgg_aligned16(w_x3) && (conv || lda % 4 == 0), CGG_EALIGN, "%s: alignment (lda=%d)", who, lda);
   CGG_REQUIRE(!res || ldr >= N, CGG_EINVAL, "%s: ldr=%d < N", who, ldr);
   CGG_REQUIRE(ldc >= N, CGG_EINVAL, "%s: ldc=%d < N", who, ldc);
-  const int tiles_m = (M + XG_BM - 1) / XG_BM, tiles_n = (N + XG_BN - 1) / XG_BN;
+  // tile shape: the largest whose grid still covers the chip about 1.5 times (256 CUs)
+  auto tiles = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)); };
+  int tm = 2, tn = N <= 64 ? 1 : 2;
+  if (tiles(tm, tn) < 384) tm = 1;
+  if (tiles(tm, tn) < 384 && tn == 2) tn = 1;
+#ifdef CGG_XG_HARNESS
+  if (getenv("CGG_XG_TM")) tm = atoi(getenv("CGG_XG_TM"));
+  if (getenv("CGG_XG_TN")) tn = atoi(getenv("CGG_XG_TN"));
+#endif
+  const int tiles_n = (N + 64 * tn - 1) / (64 * tn);
   const CggX3W w = cgg_x3_view(w_x3, N, K);
-  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(XG_NT);
+  const dim3 grid((unsigned)tiles(tm, tn)), block(XG_NT);
   // the A operand is addressed through a 32-bit buffer descriptor
   const uint64_t a_bytes = conv ? (uint64_t)(M / (cv.OH * cv.OW)) * cv.H * cv.W * cv.C * 4 : ((uint64_t)(M - 1) * lda + K) * 4;
   CGG_REQUIRE(a_bytes < 0xFFFFFF00ull, CGG_EUNSUPPORTED, "%s: the A operand spans %llu bytes (limit 4 GiB)", who,
               (unsigned long long)a_bytes);
   const uint32_t w_bytes = (uint32_t)(2ull * ((N + 31) / 32) * (K / 16) * 64 * 16);
-  if (conv)
-    hipLaunchKernelGGL(cgg_gemm_x3_kernel<true>, grid, block, 0, (hipStream_t)stream, a, lda, w, bias, res, ldr, out, ldc, M, N, K,
-                       relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes);
-  else
-    hipLaunchKernelGGL(cgg_gemm_x3_kernel<false>, grid, block, 0, (hipStream_t)stream, a, lda, w, bias, res, ldr, out, ldc, M, N, K,
-                       relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes);
+#define XG_GO(CONV, TM, TN)                                                                                                   \
+  hipLaunchKernelGGL((cgg_gemm_x3_kernel<CONV, TM, TN>), grid, block, 0, (hipStream_t)stream, a, lda, w, bias, res, ldr, out, ldc, \
+                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes)
+#define XG_PICK(CONV)                    \
+  do {                                   \
+    if (tm == 2 && tn == 2) XG_GO(CONV, 2, 2); \
+    else if (tm == 2) XG_GO(CONV, 2, 1); \
+    else if (tn == 2) XG_GO(CONV, 1, 2); \
+    else XG_GO(CONV, 1, 1);              \
+  } while (0)
+  if (conv) XG_PICK(true);
+  else XG_PICK(false);
+#undef XG_PICK
+#undef XG_GO
   CGG_CHECK_LAUNCH(who);
   return CGG_OK;
 }

@@ -1098,6 +1098,31 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
     return y
 
 
+def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False):
+    """Parity mode's encoder layer tail in ONE launch: a (attention rows), x (layer input) (..., 256) f32 ->
+    y = LN1(x1 + FFN(x1)), x1 = LN0(x + a Wo^T + bo) (and y + pos[row % len(pos)] when want_pos); wo / w1 / w2 x3 images,
+    norm_* = (gamma, beta, eps)."""
+    C = a.shape[-1]
+    M = a.numel() // C
+    for t in (a, x):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != a.shape or not t.is_cuda:
+            raise CggError('encoder_layer_tail_x3: a / x must be matching contiguous float32 ROCm tensors')
+    if not (is_x3(wo) and is_x3(w1) and is_x3(w2)):
+        raise CggError('encoder_layer_tail_x3: weights must be x3 images')
+    F = b1.numel()
+    y = torch.empty_like(a)
+    yp = torch.empty_like(a) if want_pos else None
+    with _timed('encoder_tail_x3'):
+        rc = _lib_().cgg_encoder_layer_tail_x3(
+            dev_ptr(a), dev_ptr(x), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32),
+            dev_ptr(norm0[1], 'beta0', torch.float32), float(norm0[2]), dev_ptr(w1), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2),
+            dev_ptr(b2, 'b2', torch.float32), dev_ptr(norm1[0], 'gamma1', torch.float32), dev_ptr(norm1[1], 'beta1', torch.float32),
+            float(norm1[2]), dev_ptr(pos, 'pos', torch.float32) if want_pos else None, pos.shape[0] if want_pos else 0, dev_ptr(y),
+            dev_ptr(yp), M, C, int(F), stream_ptr(a.device))
+    check(rc, 'cgg_encoder_layer_tail_x3')
+    return y, yp
+
+
 def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, relu=False):
     """x (B, H, W, C) f32 channel-last (contiguous) -> act(conv + bias (+ res)) (B, OH, OW, N) f32 as an implicit GEMM on the
     x3 image made by `pack_conv_weight_x3` (C % 32 == 0)."""

@@ -820,6 +820,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
         (residuals and the ReLU in its epilogue), the f32 MSDeformAttn kernel with the softmax / location prologue inside."""
         B, N, C = src.shape
         lx = runtime.linear_x3
+        x3w = lambda lin: runtime.derived_cached('x3_image', (lin.weight,), lambda: ops.pack_linear_weight_x3(lin.weight))
+        srcp = None
         for layer in self.encoder.layers:
             attn = layer.attentions[0]
             H = attn.num_heads
@@ -829,12 +831,21 @@ class MSDeformAttnPixelDecoder(nn.Module):
             b_cat = runtime.derived_cached('msda_bcat32', (so.bias, aw.bias),
                                            lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
             value = lx(src, attn.value_proj.weight, attn.value_proj.bias).view(B, N, H, C // H)
-            offs = lx(src + pos[None], w_cat, b_cat)
+            offs = lx(srcp if srcp is not None else src + pos[None], w_cat, b_cat)
             a = ops.msda_forward_fused(value, level_hw, level_start, offs, ref, attn.num_points)
-            y = lx(a, attn.output_proj.weight, attn.output_proj.bias, res=src)
             n0, n1 = layer.norms
-            x1 = ops.add_layernorm_stream(y, None, n0.weight, n0.bias, n0.eps, want_bf16=False)[0]
             fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
+            if FUSED_TAIL and fc1.out_features % 256 == 0:
+                # output_proj + LayerNorm + FFN + LayerNorm as ONE launch (x1 and the hidden activation stay on chip); it also
+                # writes the next layer's `x + pos` rows
+                last = layer is self.encoder.layers[-1]
+                src, srcp = ops.encoder_layer_tail_x3(a, src.contiguous(), x3w(attn.output_proj), attn.output_proj.bias,
+                                                      (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
+                                                      (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last)
+                continue
+            srcp = None
+            y = lx(a, attn.output_proj.weight, attn.output_proj.bias, res=src)
+            x1 = ops.add_layernorm_stream(y, None, n0.weight, n0.bias, n0.eps, want_bf16=False)[0]
             h = lx(x1, fc1.weight, fc1.bias, relu=True)
             y = lx(h, fc2.weight, fc2.bias, res=x1)
             src = ops.add_layernorm_stream(y, None, n1.weight, n1.bias, n1.eps, want_bf16=False)[0]

@@ -410,6 +410,16 @@ int cgg_group_norm_nhwc_f32(const float* x, const float* gamma, const float* bet
                             cgg_stream_t stream);
 int cgg_pack_mask_feature_nhwc_f32_x3(const float* feat, void* const* hi_host, void* const* lo_host, const int* pools_host,
                                       int n, int B, int C, int H, int W, cgg_stream_t stream);
+/* Parity mode's twin of cgg_encoder_layer_tail_bf16: the whole post-attention half of an encoder layer as ONE launch on the
+ * f32-class contraction (csrc/encoder_tail_x3.hip):
+ *   x1 = LayerNorm0(x + a Wo^T + bo);   y = LayerNorm1(x1 + W2 relu(W1 x1 + b1) + b2)
+ * a32 = attention rows (MSDeformAttn output before output_proj), x32 = layer input rows, both (M, 256) f32; wo / w1 / w2 = x3
+ * images (cgg_x3_pack) of the (256 x 256), (F x 256), (256 x F) weights, F % 256 == 0. Outputs y32 = y and (nullable) yp32 =
+ * y + pos[row % pos_rows], (M, 256) f32. x1 and the (M x F) hidden activation never reach memory. */
+int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, const void* wo_x3, const float* bo, const float* gamma0,
+                              const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
+                              const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                              int pos_rows, float* y32, float* yp32, int M, int C, int F, cgg_stream_t stream);
 int cgg_gemm_x3(const float* a, int lda, const void* w_x3, const float* bias, const float* res, int ldr, float* out, int ldc,
                 int M, int N, int K, int relu, cgg_stream_t stream);
 int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* bias, const float* res, float* out, int B, int H, int W,

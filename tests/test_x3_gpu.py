@@ -214,3 +214,31 @@ def test_conv_x3_nhwc_vs_float64(dev, B, H, W, C, N, k, stride):
     y2 = ops.conv_x3_nhwc(xl, pk, N, k, stride, pad, b.to(dev), res=res.to(dev), relu=True)
     w2 = (want + res.permute(0, 3, 1, 2).double()).relu()
     assert _err(y2.permute(0, 3, 1, 2), w2) <= 4 * f32_err + 2e-7 * (want.abs().max().item() + 4)
+
+
+@pytest.mark.parametrize('M,N,FF', [(43008, 21504, 1024), (4071, 1357, 1024), (100, 50, 512), (64, 64, 256)])
+def test_encoder_layer_tail_x3_vs_float64(dev, M, N, FF):
+    """cgg_encoder_layer_tail_x3 (output_proj + LN + FFN + LN in one launch, f32-class arithmetic) vs float64 on the same f32
+    inputs: 2e-5 of the unit-scale outputs (the bf16 twin: one bf16 ulp = 4e-3); ragged row counts; y + pos; reproducible."""
+    g = torch.Generator().manual_seed(500 + FF)
+    C = 256
+    r = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k)
+    a, x, pos = r(M, C), r(M, C), r(N, C)
+    wo, bo = r(C, C, k=1 / 16), r(C, k=0.1)
+    w1, b1 = r(FF, C, k=1 / 16), r(FF, k=0.1)
+    w2, b2 = r(C, FF, k=1 / 32), r(C, k=0.1)
+    n0 = (1 + 0.1 * r(C), 0.1 * r(C), 1e-5)
+    n1 = (1 + 0.1 * r(C), 0.1 * r(C), 1e-5)
+    d = lambda t: t.double()
+    F = torch.nn.functional
+    x1 = F.layer_norm(d(x) + d(a) @ d(wo).t() + d(bo), (C,), d(n0[0]), d(n0[1]), 1e-5)
+    want = F.layer_norm(x1 + torch.relu(x1 @ d(w1).t() + d(b1)) @ d(w2).t() + d(b2), (C,), d(n1[0]), d(n1[1]), 1e-5)
+    t = lambda v: v.to(dev)
+    pk = [ops.pack_linear_weight_x3(t(w)) for w in (wo, w1, w2)]
+    y, yp = ops.encoder_layer_tail_x3(t(a), t(x), pk[0], t(bo), (t(n0[0]), t(n0[1]), 1e-5), pk[1], t(b1), pk[2], t(b2),
+                                      (t(n1[0]), t(n1[1]), 1e-5), pos=t(pos), want_pos=True)
+    assert _err(y, want) <= 2e-5, _err(y, want)
+    assert _err(yp, want + d(pos)[torch.arange(M) % N]) <= 2e-5
+    y2, none = ops.encoder_layer_tail_x3(t(a), t(x), pk[0], t(bo), (t(n0[0]), t(n0[1]), 1e-5), pk[1], t(b1), pk[2], t(b2),
+                                         (t(n1[0]), t(n1[1]), 1e-5))
+    assert none is None and torch.equal(y, y2)
