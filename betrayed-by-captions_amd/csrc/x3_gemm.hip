@@ -40,7 +40,7 @@ template <bool CONV, int TM, int TN>
 __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4) void cgg_gemm_x3_kernel(
     const float* __restrict__ A, int lda, const CggX3W w, const float* __restrict__ bias, const float* __restrict__ res, int ldr,
     float* __restrict__ out, int ldc, int M, int N, int K, int relu, int tiles_n, int n_tiles32, XgConv cv, uint32_t a_bytes,
-    uint32_t w_bytes) {
+    uint32_t w_bytes, int res_mod, float* __restrict__ out2, int ldc2, int col2) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int A_SLOTS = 2 * TM * 2 * 64;                 // one piece of the A stage: [2 TM m-tiles][2 k-steps][64 lanes] x 16 B
   constexpr int B_SLOTS = 2 * TN * 2 * 64;
@@ -238,19 +238,25 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
     const bool nok = full || n < N;
     const float cs = nok ? w.scale[n] : 0.f;
     const float bs = (nok && bias) ? bias[n] : 0.f;
+    // columns from col2 on (a multiple of 32: uniform per n-tile) go to the second output
+    const bool second = out2 != nullptr && n >= col2;
+    float* const obase = second ? out2 + (n - col2) : out + n;
+    const int ldo = second ? ldc2 : ldc;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
       const int mrow = m0 + 32 * (TM * wm + mt) + 4 * hi5;
-      float* orow = out + (size_t)mrow * ldc + n;
-      const float* rrow = res ? res + (size_t)mrow * ldr + n : nullptr;
+      float* orow = obase + (size_t)mrow * ldo;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);
         if (full || (nok && mrow + dr < M)) {
           float v = acc[mt][nt][r] * cs + bs;
-          if (rrow) v += rrow[(size_t)dr * ldr];
+          if (res) {
+            const int mr = res_mod > 0 ? (mrow + dr) % res_mod : mrow + dr;      // res_mod: residual rows repeat (per-token table)
+            v += res[(size_t)mr * ldr + n];
+          }
           if (relu) v = fmaxf(v, 0.f);
-          orow[(size_t)dr * ldc] = v;
+          orow[(size_t)dr * ldo] = v;
         }
       }
     }
@@ -258,13 +264,17 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
 }
 
 static int xg_launch(bool conv, const char* who, const float* a, int lda, const void* w_x3, const float* bias, const float* res,
-                     int ldr, float* out, int ldc, int M, int N, int K, int relu, const XgConv& cv, cgg_stream_t stream) {
+                     int ldr, float* out, int ldc, int M, int N, int K, int relu, const XgConv& cv, cgg_stream_t stream,
+                     int res_mod = 0, float* out2 = nullptr, int ldc2 = 0, int col2 = 0) {
   CGG_REQUIRE(a && w_x3 && out, CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "%s: bad sizes", who);
   CGG_REQUIRE(K % XG_BK == 0, CGG_EUNSUPPORTED, "%s: K=%d must be a multiple of %d", who, K, XG_BK);
   CGG_REQUIRE(cgg_aligned16(a) && cgg_aligned16(w_x3) && (conv || lda % 4 == 0), CGG_EALIGN, "%s: alignment (lda=%d)", who, lda);
   CGG_REQUIRE(!res || ldr >= N, CGG_EINVAL, "%s: ldr=%d < N", who, ldr);
-  CGG_REQUIRE(ldc >= N, CGG_EINVAL, "%s: ldc=%d < N", who, ldc);
+  CGG_REQUIRE(ldc >= (out2 ? col2 : N), CGG_EINVAL, "%s: ldc=%d too small", who, ldc);
+  CGG_REQUIRE(!out2 || (col2 > 0 && col2 % 32 == 0 && col2 < N && ldc2 >= N - col2), CGG_EINVAL,
+              "%s: second output needs 0 < col2 < N, col2 %% 32 == 0, ldc2 >= N - col2 (col2=%d ldc2=%d)", who, col2, ldc2);
+  CGG_REQUIRE(res_mod >= 0 && (!res_mod || res), CGG_EINVAL, "%s: res_mod without res", who);
   // tile shape: the largest whose grid still covers the chip about 1.5 times (256 CUs)
   auto tiles = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)); };
   int tm = 2, tn = N <= 64 ? 1 : 2;
@@ -284,7 +294,7 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   const uint32_t w_bytes = (uint32_t)(2ull * ((N + 31) / 32) * (K / 16) * 64 * 16);
 #define XG_GO(CONV, TM, TN)                                                                                                   \
   hipLaunchKernelGGL((cgg_gemm_x3_kernel<CONV, TM, TN>), grid, block, 0, (hipStream_t)stream, a, lda, w, bias, res, ldr, out, ldc, \
-                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes)
+                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes, res_mod, out2, ldc2, col2)
 #define XG_PICK(CONV)                    \
   do {                                   \
     if (tm == 2 && tn == 2) XG_GO(CONV, 2, 2); \
@@ -305,6 +315,15 @@ extern "C" int cgg_gemm_x3(const float* a, int lda, const void* w_x3, const floa
   const XgConv cv = {0, 0, 0, 0, 0, 0, 0, 0};
   CGG_REQUIRE(lda >= K, CGG_EINVAL, "cgg_gemm_x3: lda=%d < K", lda);
   return xg_launch(false, "cgg_gemm_x3", a, lda, w_x3, bias, res, ldr, out, ldc, M, N, K, relu, cv, stream);
+}
+
+extern "C" int cgg_gemm_x3_ex(const float* a, int lda, const void* w_x3, const float* bias, const float* res, int ldr, int res_mod,
+                              float* out, int ldc, float* out2, int ldc2, int col2, int M, int N, int K, int relu,
+                              cgg_stream_t stream) {
+  const XgConv cv = {0, 0, 0, 0, 0, 0, 0, 0};
+  CGG_REQUIRE(lda >= K, CGG_EINVAL, "cgg_gemm_x3_ex: lda=%d < K", lda);
+  return xg_launch(false, "cgg_gemm_x3_ex", a, lda, w_x3, bias, res, ldr, out, ldc, M, N, K, relu, cv, stream, res_mod, out2, ldc2,
+                   col2);
 }
 
 extern "C" int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* bias, const float* res, float* out, int B, int H,

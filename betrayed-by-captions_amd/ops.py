@@ -1123,6 +1123,26 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     return y, yp
 
 
+def gemm_x3_split(a, packed, N, col2, bias=None, res_table=None):
+    """a (M, K) f32 rows x x3 image of an (N, K) weight -> (y1 (M, col2), y2 (M, N - col2)) = column blocks of
+    a W^T + bias + res_table[row % len(res_table)] (res_table (R, N) f32 | None), one launch (`cgg_gemm_x3_ex`)."""
+    if a.dim() != 2 or a.stride(1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
+        raise CggError('gemm_x3_split: a must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
+    M, K = a.shape
+    y1 = torch.empty((M, col2), dtype=torch.float32, device=a.device)
+    y2 = torch.empty((M, N - col2), dtype=torch.float32, device=a.device)
+    if res_table is not None and (res_table.dim() != 2 or res_table.shape[1] != N or not res_table.is_contiguous()
+                                  or res_table.dtype != torch.float32):
+        raise CggError('gemm_x3_split: res_table must be a contiguous (R, N) float32 tensor')
+    with _timed('gemm_x3'):
+        rc = _lib_().cgg_gemm_x3_ex(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                    dev_ptr(res_table), N if res_table is not None else 0,
+                                    res_table.shape[0] if res_table is not None else 0, dev_ptr(y1), col2, dev_ptr(y2), N - col2,
+                                    int(col2), M, N, K, 0, stream_ptr(a.device))
+    check(rc, 'cgg_gemm_x3_ex')
+    return y1, y2
+
+
 def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, relu=False):
     """x (B, H, W, C) f32 channel-last (contiguous) -> act(conv + bias (+ res)) (B, OH, OW, N) f32 as an implicit GEMM on the
     x3 image made by `pack_conv_weight_x3` (C % 32 == 0)."""

@@ -422,6 +422,12 @@ int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, const void* wo
                               int pos_rows, float* y32, float* yp32, int M, int C, int F, cgg_stream_t stream);
 int cgg_gemm_x3(const float* a, int lda, const void* w_x3, const float* bias, const float* res, int ldr, float* out, int ldc,
                 int M, int N, int K, int relu, cgg_stream_t stream);
+/* cgg_gemm_x3 with a row-periodic residual (res_mod > 0: row m adds res[m % res_mod], e.g. a per-token table shared by the
+ * images of a batch) and a column split (out2 != NULL: columns >= col2, a multiple of 32, are stored to out2[m * ldc2 + n - col2]):
+ * the MSDeformAttn layer's value_proj and sampling_offsets | attention_weights projections as ONE launch over the rows x --
+ * (x + pos) Wc^T + bc = x Wc^T + (pos Wc^T + bc), the bracket being a per-token table (mmcv MultiScaleDeformableAttention.forward). */
+int cgg_gemm_x3_ex(const float* a, int lda, const void* w_x3, const float* bias, const float* res, int ldr, int res_mod, float* out,
+                   int ldc, float* out2, int ldc2, int col2, int M, int N, int K, int relu, cgg_stream_t stream);
 int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* bias, const float* res, float* out, int B, int H, int W,
                      int C, int N, int KH, int KW, int stride, int pad, int relu, cgg_stream_t stream);
 

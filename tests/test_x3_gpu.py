@@ -242,3 +242,17 @@ def test_encoder_layer_tail_x3_vs_float64(dev, M, N, FF):
     y2, none = ops.encoder_layer_tail_x3(t(a), t(x), pk[0], t(bo), (t(n0[0]), t(n0[1]), 1e-5), pk[1], t(b1), pk[2], t(b2),
                                          (t(n1[0]), t(n1[1]), 1e-5))
     assert none is None and torch.equal(y, y2)
+
+
+def test_gemm_x3_split_outputs_and_periodic_residual(dev):
+    """cgg_gemm_x3_ex: one launch = two column blocks with a per-token residual table (the MSDeformAttn value / offsets
+    projections): == float64 of x W^T + table[row % R]."""
+    g = torch.Generator().manual_seed(321)
+    M, K, N, col2, R = 3 * 1357, 256, 544, 256, 1357
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 16
+    table = torch.randn(R, N, generator=g)
+    want = x.double() @ w.double().t() + table.double()[torch.arange(M) % R]
+    y1, y2 = ops.gemm_x3_split(x.to(dev), ops.pack_linear_weight_x3(w.to(dev)), N, col2, res_table=table.to(dev))
+    assert y1.shape == (M, col2) and y2.shape == (M, N - col2)
+    assert _err(y1, want[:, :col2]) <= 2e-5 and _err(y2, want[:, col2:]) <= 2e-5
