@@ -13,10 +13,16 @@ GPU; rank r binds device r, RCCL for the barrier / max-over-ranks); under an ext
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) RANK / LOCAL_RANK / WORLD_SIZE come from
 the environment and `--gpus` must agree with WORLD_SIZE (it fails loudly otherwise).
 
-Prints ONE JSON line (rank 0). Extra objects:
-  roofline      -- the mask-logit kernel (einsum 'bqc,bchw->bqhw', cgg_mask_logits, full resolution),
-                   timed with events on the launch stream INSIDE the timed steps.
-  cpu_baseline  -- the oracle (torch CPU restatement of the reference path, kind "port") on one batch of the
+Prints ONE JSON line (rank 0). `value` is PARITY mode (`--precision fp32`, the default): every contraction of the path in
+f32-class arithmetic on the f16 matrix cores (csrc/x3.h), the mode the 1e-3 / bit-exact parity tests run in. Extra objects:
+  roofline      -- the dominant kernel of that step, the x3 GEMM / implicit-GEMM convolution family (cgg_gemm_x3_kernel), from HIP
+                   events on the launch stream around every launch of the K steps re-run eagerly after the timed region;
+                   kernels.* hold the encoder layer tail, the mask-logit einsum and MSDeformAttn the same way;
+                   `traffic` / `rocprof` fields come from the committed rocprofv3 runs of this command (labelled as such).
+  einsum_mfma_target -- BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200, % of MFMA peak.
+  bf16_mode     -- the same step in throughput mode (bf16 MFMA): secondary, never `value`.
+  train_step    -- configs[2]'s training step, run in a child process.
+  cpu_baseline  -- the oracle (torch CPU restatement of the reference path, kind "port") on one image of the
                    same workload on this box's host cores.
 """
 import argparse
@@ -36,7 +42,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_BF16_PEAK_TF = 2500.0
+MFMA_BF16_PEAK_TF = 2500.0          # dense bf16 / f16 MFMA peak
+F32_MFMA_PEAK_TF = 157.3            # f32-input MFMA = f32 vector peak
+X3_PEAK_TF = MFMA_BF16_PEAK_TF / 3  # f32-class f16 x 3 arithmetic: three f16 MFMAs per product
 
 
 def build_model(args, dev):
@@ -71,8 +79,6 @@ def cpu_baseline(args, cfg, model, img_cpu):
     fh = model.panoptic_fusion_head
     embs = [fh.all_class_embs.cpu(), fh.novel_class_embs.cpu(), fh.base_class_embs.cpu()]
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)
-    torch.set_num_threads(threads)
 
     def one_pass(x):
         B, _, H, W = x.shape
@@ -94,55 +100,38 @@ def cpu_baseline(args, cfg, model, img_cpu):
 
     full = img_cpu[:1]                      # bounded sample: ONE image of the same workload
     H, W = full.shape[-2:]
-    dt, ts = timed(full)
     small = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(4321))
+    # intra-op thread count: torch's CPU kernels stop scaling long before 256 cores (more threads = more fork/join and NUMA
+    # traffic per op); a short sweep on the 512 x 512 case picks the count that is then used for both timed cases
+    sweep = {}
+    for t in sorted({min(cores, c) for c in (16, 32, 64, 128)}):
+        torch.set_num_threads(t)
+        one_pass(small)
+        sweep[t] = one_pass(small)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    dt, ts = timed(full)
     dt1, ts1 = timed(small)
     return dict(value=1.0 / dt, unit='images/sec', cores=cores, threads=threads, kind='port',
+                thread_sweep_512_s={str(k): round(v, 3) for k, v in sweep.items()},
                 sample=f'1 image {H}x{W} of the benched workload, full detector forward + instance post-processing '
-                       f'(torch CPU oracle, fp32, {threads} threads on {cores} host cores): 1 warm-up + median of 3 '
-                       f'timed passes ({", ".join("%.2f" % t for t in ts)} s)',
+                       f'(torch CPU oracle, fp32, {threads} threads on {cores} host cores -- the fastest of the swept counts): '
+                       f'1 warm-up + median of 3 timed passes ({", ".join("%.2f" % t for t in ts)} s)',
                 cfg1_512=dict(value=1.0 / dt1, unit='images/sec',
                               sample='configs[0]: one 512x512 image, same pipeline, 1 warm-up + median of 3 '
                                      f'({", ".join("%.2f" % t for t in ts1)} s)'))
 
 
-def pmc_traffic(kernel, B, H, W):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_pmc_{fetch,write}_*.csv:
-    separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of scratch/kernel_only.py at configs[1] shapes). Units are KB;
-    FETCH_SIZE is doubled (gfx950 tallies 128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md "HBM").
-    Counters cannot be collected from inside this process, so the value is only reported for the shapes they were
-    collected at; otherwise null."""
-    import csv
-    if (B, H, W) != (2, 1024, 1024):
-        return None, None
-    tot = {}
-    rnd = 'r2' if os.path.exists(os.path.join(ROOT, 'profiles', 'r2_pmc_fetch_counter_collection.csv')) else 'r1'
-    for name, cnt, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
-        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{name}_counter_collection.csv')
-        if not os.path.exists(path):
-            return None, None
-        vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
-                if kernel in r['Kernel_Name'] and r['Counter_Name'] == cnt]
-        if not vals:
-            return None, None
-        tot[cnt] = sum(vals) / len(vals) * 1024.0 * mult
-    return tot['FETCH_SIZE'] + tot['WRITE_SIZE'], (f'profiles/{rnd}_pmc_' + '{fetch,write}_counter_collection.csv: separate '
-                                                   'rocprofv3 --pmc passes; FETCH_SIZE x2 (gfx950 correction), KB units')
-
-
-def rocprof_launch_mean(kernel):
-    """Per-launch mean of `kernel`'s full-resolution launches in the committed rocprofv3 kernel trace of this command
-    (profiles/r2_hot_kernel_launches.json, written by scratch/publish_profiles.py) -- the cross-check for `launch_ms`."""
-    for rnd in ('r2', 'r1'):
-        path = os.path.join(ROOT, 'profiles', f'{rnd}_hot_kernel_launches.json')
-        if os.path.exists(path):
-            try:
-                rec = json.load(open(path)).get(kernel)
-            except Exception:
-                rec = None
-            if rec:
-                return dict(rec, source=os.path.relpath(path, ROOT))
-    return None
+def committed_profile(name):
+    """A summary committed under profiles/ by scratch/collect_profiles_r3.sh (rocprofv3 runs of THIS command on an MI355X;
+    counters cannot be collected from inside the process). Every field taken from it is labelled `source: committed profile`."""
+    path = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
 
 
 def host_results_rate(args, model, img, metas, dev):
@@ -194,33 +183,38 @@ def host_results_rate(args, model, img, metas, dev):
                 how=f'{nstage}-stage pipeline, bit-packed masks, pinned async D2H, C++ RLE on host threads overlapped with the next batch')
 
 
-def parity_mode_rate(args, model, img, metas, dev):
-    """images/sec of the SAME step in parity mode (`--precision fp32`: f32 GEMMs / values, 3x-bf16-split MFMA mask
-    logits, f32 MFMA attention -- the mode the 1e-3 / bit-exact parity tests run in), timed in this process right after
-    the headline region: the step captured once into a hipGraph and replayed K times (eager if capture fails)."""
-    from cgg_amd import runtime
-    with runtime.precision_scope('fp32'):
+def time_mode(args, model, img, metas, dev, precision, barrier, collect_events):
+    """images/sec of the step in one precision mode: the staged pipeline (one HIP stream + hipGraph per stage) or one graph
+    per step / eager launches; the K-step region is repeated `args.repeats` times back to back (each bracketed by the barrier)
+    and the MEDIAN region is reported, so that the timed span is >= 0.5 s while `steps` stays what the driver passed.
+    Then: per-batch latency (one step alone) and, if `collect_events`, the same K steps once more eagerly with HIP events
+    around the hot launches on the launch stream (events cannot be recorded inside a graph replay)."""
+    import statistics
+    from cgg_amd import ops, runtime
+    out = {}
+    with runtime.precision_scope(precision):
         def step():
             with torch.no_grad():
                 return model.simple_test(img, metas, rescale=True, device_results=True)
-        for _ in range(2):
+        for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
-        graph, how, pipe = None, 'eager launches', None
+        graph = pipe = None
+        how = 'eager launches'
         if args.graph and args.pipeline:
-            # the same staged pipeline as the headline run (stages captured under the fp32 scope)
             try:
                 from cgg_amd.pipeline import detector_pipeline
-                nst = min(max(args.pipeline, 2), 3)
-                pipe = detector_pipeline(model, img, metas, stages=nst, defer_tail=args.defer_tail, rescale=True,
+                pipe = detector_pipeline(model, img, metas, stages=args.pipeline, defer_tail=args.defer_tail, rescale=True,
                                          device_results=True)
-                for _ in range(nst):
+                for _ in range(len(pipe.stages)):
                     pipe.submit(img)
                 pipe.flush()
                 torch.cuda.synchronize()
-                how = f'{nst}-stage software pipeline across steps, as the headline run'
+                how = (f'{len(pipe.stages)}-stage software pipeline across steps (one HIP stream + hipGraph per stage and buffer '
+                       'slot; every timed step completes inside the timed region)')
             except Exception as e:
-                print(f'bench.py: parity-mode pipeline setup failed ({type(e).__name__}: {e}); one graph per step', file=sys.stderr)
+                print(f'bench.py: stage pipeline setup failed in {precision} mode ({type(e).__name__}: {e}); one graph per step',
+                      file=sys.stderr)
                 pipe = None
                 torch.cuda.synchronize()
         if args.graph and pipe is None:
@@ -236,25 +230,55 @@ def parity_mode_rate(args, model, img, metas, dev):
                 graph.replay()
                 torch.cuda.synchronize()
                 how = 'one hipGraph per step, replayed back to back'
-            except Exception as e:
-                print(f'bench.py: parity-mode hipGraph capture failed ({type(e).__name__}: {e}); eager', file=sys.stderr)
+            except Exception as e:      # loud, not silent: the JSON line says so
+                print(f'bench.py: hipGraph capture failed in {precision} mode ({type(e).__name__}: {e}); eager', file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
-        steps = max(args.steps // 2, 5)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if pipe is not None:
-            for _ in range(steps):
+
+        def region():
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if pipe is not None:
+                    pipe.submit(img)
+                elif graph is not None:
+                    graph.replay()
+                else:
+                    step()
+            if pipe is not None:
+                pipe.flush()          # every submitted step is complete before the closing barrier + synchronize
+            barrier()
+            return time.perf_counter() - t0
+        regions = [region() for _ in range(max(args.repeats, 1))]
+        out['regions_s'] = regions
+        out['dt'] = statistics.median(regions)
+        out['how'] = how
+        out['hip_graph'] = graph is not None or pipe is not None
+        out['pipelined'] = pipe is not None
+        # ---- per-batch latency: ONE step alone (no cross-step overlap), submit -> results complete ----
+        lat = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if pipe is not None:
                 pipe.submit(img)
-            pipe.flush()
-        else:
-            for _ in range(steps):
-                graph.replay() if graph is not None else step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        pipe = None
-    return dict(value=img.shape[0] * steps / dt, unit='images/sec (this rank)', ms_per_step=dt / steps * 1e3, steps=steps,
-                precision='fp32', how=how)
+                pipe.flush()
+            elif graph is not None:
+                graph.replay()
+            else:
+                step()
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        out['latency_ms'] = sorted(lat)[len(lat) // 2]
+        pipe = graph = None
+        if collect_events:
+            ops.KERNEL_EVENTS, ops.KERNEL_META = {}, {}
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            out['events'], out['meta'] = ops.KERNEL_EVENTS, ops.KERNEL_META
+            ops.KERNEL_EVENTS = ops.KERNEL_META = None
+    return out
 
 
 def train_main(args, cfg, model, img, metas, dev, rank, world):
@@ -334,21 +358,163 @@ def spawn_ranks(args):
     return 0
 
 
+def kernel_summaries(args, events, meta, B, H, W, Q):
+    """Roofline objects of the parity-mode step's kernels from the raw HIP-event means of the launches inside the K re-run steps
+    (`frac` is never adjusted for the event-pair floor; it is reported beside it)."""
+    pairs = []
+    for _ in range(64):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    ev_over = min(a.elapsed_time(b) for a, b in pairs)     # the floor of an empty event pair on this stream
+    timed = ('HIP events around the launches in the same %d steps re-run eagerly right after the timed region (events cannot be '
+             'recorded inside a hipGraph replay); raw means' % args.steps)
+    out = {}
+    prof = committed_profile('r3_fp32_kernels.json') or {}
+
+    def ms_list(name):
+        return [s.elapsed_time(e) for s, e in events.get(name, [])]
+
+    # ---- the x3 GEMM / implicit-GEMM convolution family: the dominant kernel of the step ----
+    g = ms_list('gemm_x3')
+    gm = meta.get('gemm_x3', [])
+    if g and len(gm) == len(g):
+        per_step = len(g) // args.steps
+        ms_step = sum(g) / args.steps
+        fl_step = sum(m['flops'] for m in gm) / args.steps
+        by_step = sum(m['bytes'] for m in gm) / args.steps
+        tf = fl_step / (ms_step * 1e-3) / 1e12
+        worst = {}
+        for t, m in zip(g, gm):
+            worst.setdefault(m['shape'], []).append(t)
+        shapes = sorted(((sum(v) / len(v), len(v) // args.steps, k) for k, v in worst.items()), reverse=True)[:6]
+        pr = prof.get('cgg_gemm_x3_kernel', {})
+        out['gemm_x3'] = dict(
+            bound='mfma', kernel='cgg_gemm_x3_kernel<CONV, TM, TN> (all instantiations: %d launches per step -- the BN-folded '
+                                 'ResNet convolutions, the pixel decoder\'s 1x1 / 3x3 convolutions, value / offset / K-V '
+                                 'projections)' % per_step,
+            achieved=tf, peak=X3_PEAK_TF, unit='TFLOP/s', frac=tf / X3_PEAK_TF,
+            peak_note='f32-class f16 x 3 arithmetic issues 3 v_mfma_f32_32x32x16_f16 per product: peak = dense f16 MFMA peak '
+                      '2500 TF / 3; achieved = ALGORITHMIC flops (2 M N K) / time',
+            frac_of_f32_mfma_peak=tf / F32_MFMA_PEAK_TF, mfma_issue_frac_of_f16_peak=3 * tf / MFMA_BF16_PEAK_TF,
+            traffic=pr.get('traffic_bytes_per_step'), traffic_source=pr.get('source'),
+            launch_ms=ms_step / per_step, launches_timed=len(g), launches_per_step=per_step, ms_per_step=ms_step,
+            flops_per_step=fl_step, algorithmic_bytes_per_step=by_step, achieved_GBs=by_step / (ms_step * 1e-3) / 1e9,
+            slowest_shapes=[dict(M_N_K=list(k), launches_per_step=n, launch_ms=t) for t, n, k in shapes],
+            timed=timed, event_pair_overhead_ms=ev_over, rocprof=pr.get('rocprof'))
+    t = ms_list('encoder_tail_x3')
+    tm = meta.get('encoder_tail_x3', [])
+    if t and tm:
+        ms = sum(t) / len(t)
+        fl, by = tm[0]['flops'], tm[0]['bytes']
+        tf = fl / (ms * 1e-3) / 1e12
+        pr = prof.get('cgg_encoder_tail_x3_kernel', {})
+        out['encoder_tail_x3'] = dict(
+            bound='mfma', kernel='cgg_encoder_tail_x3_kernel', achieved=tf, peak=X3_PEAK_TF, unit='TFLOP/s', frac=tf / X3_PEAK_TF,
+            frac_of_f32_mfma_peak=tf / F32_MFMA_PEAK_TF, traffic=pr.get('traffic_bytes'), traffic_source=pr.get('source'),
+            launch_ms=ms, launches_timed=len(t), flops=fl, algorithmic_bytes=by, achieved_GBs=by / (ms * 1e-3) / 1e9,
+            launch_ms_event_adjusted=max(ms - ev_over, 1e-6), timed=timed, rocprof=pr.get('rocprof'),
+            replaces='3 x3 GEMM launches + 2 residual-LayerNorm passes per encoder layer (0.6 GB of f32 intermediates per layer)')
+    ml = ms_list('mask_logits_full')
+    if ml:
+        ms = sum(ml) / len(ml)
+        HW4 = (H // 4) * (W // 4)
+        fl = 2.0 * B * Q * 256 * HW4
+        by = B * (256 * HW4 * 4 + Q * 256 * 4 + Q * HW4 * 4)          # hi + lo pieces = 4 B / element
+        pr = prof.get('cgg_mask_logits_kernel', {})
+        out['mask_logits'] = dict(
+            bound='hbm', kernel='cgg_mask_logits_kernel<true> (einsum bqc,bchw->bqhw, f16 x 3 split operands, f32 logits out)',
+            achieved=by / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            traffic=pr.get('traffic_bytes'), traffic_source=pr.get('source'), launch_ms=ms, launches_timed=len(ml),
+            algorithmic_bytes=by, flops=fl, tflops=fl / (ms * 1e-3) / 1e12, queries=Q,
+            frac_x3_mfma_peak=fl / (ms * 1e-3) / 1e12 / X3_PEAK_TF, timed=timed, rocprof=pr.get('rocprof'))
+    if events.get('msda_fused'):
+        ms = ms_list('msda_fused')
+        ms = sum(ms) / len(ms)
+        N = sum((H // s) * (W // s) for s in (8, 16, 32))
+        mbytes = B * N * (256 + 288 + 256) * 4
+        out['msda'] = dict(kernel='cgg_msda_fwd_kernel<float> (f32 values / offsets / output)', bound='hbm', launch_ms=ms,
+                           algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9,
+                           frac_hbm_peak=mbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    return out
+
+
+def einsum_q_sweep(dev, B, H, W):
+    """BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200 (1024 x 1024 -> 256 x 256 mask feature), both
+    arithmetic modes, launches timed back to back with HIP events (cache-warm: the 10-call sequence of a forward is)."""
+    from cgg_amd import ops, runtime
+    HW4 = (H // 4) * (W // 4)
+    g = torch.Generator().manual_seed(7)
+    feat = torch.randn(B, 256, H // 4, W // 4, generator=g).to(dev)
+    res = []
+    for Q in (100, 200):
+        emb = torch.randn(B, Q, 256, generator=g).to(dev)
+        for mode, split in (('bf16 MFMA, f32 logits out', False), ('f32-class f16 x 3 MFMA, f32 logits out', True)):
+            with runtime.precision_scope('fp32' if split else 'bf16'):
+                packed = ops.pack_mask_feature(feat, 1, split)
+                for _ in range(5):
+                    ops.mask_logits(emb, packed)
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(20):
+                    ops.mask_logits(emb, packed)
+                e.record()
+                torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / 20
+            fl = 2.0 * B * Q * 256 * HW4
+            by = B * (256 * HW4 * (4 if split else 2) + Q * 256 * 4 + Q * HW4 * 4)
+            peak = X3_PEAK_TF if split else MFMA_BF16_PEAK_TF
+            tf = fl / (ms * 1e-3) / 1e12
+            ai = fl / by
+            res.append(dict(queries=Q, mode=mode, launch_ms=ms, tflops=tf, frac_mfma_peak=tf / peak, mfma_peak_tf=peak,
+                            frac_hbm_roofline_attainable=tf / min(peak, ai * HBM_PEAK_GBS / 1e3), GBs=by / (ms * 1e-3) / 1e9,
+                            frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, launches_q_split=2 if (split and Q > 128) else 1))
+    return res
+
+
+def train_step_child(args):
+    """configs[2]'s training step (`--mode train`) in a CHILD process started after this process has finished its GPU work
+    (never an exec from a GPU-initialised process); its JSON line is embedded as `train_step`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'train', '--steps', str(args.train_steps), '--warmup', '3',
+           '--precision', 'bf16']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode != 0 or not line:
+            return dict(error=f'child exited {r.returncode}', stderr_tail=r.stderr[-400:])
+        d = json.loads(line[-1])
+        return dict(value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], warmup=d['warmup'],
+                    dtype=d['dtype'], workload=d['config']['workload'], loss=d.get('loss'), peak_mem_gb=d.get('peak_mem_gb'),
+                    launches_per_step=d.get('launches_per_step'), dominant_kernel=d.get('dominant_kernel'),
+                    how='python bench.py --mode train in a child process of this run')
+    except Exception as e:
+        return dict(error=f'{type(e).__name__}: {e}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=10,
+                    help='the K-step timed region is repeated this many times back to back; the median region is reported')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="infer = configs[1] (the metric's config); train = configs[2] training step")
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (2 infer / 16 train)')
     ap.add_argument('--bucket-mb', type=int, default=64, help='gradient all-reduce bucket size (train)')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--queries', type=int, default=100)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help="fp32 (default, the headline): parity mode -- every contraction in f32-class arithmetic (f16 x 3 split MFMA, "
+                         "f32 accumulate; the mode the 1e-3 / bit-exact parity tests run in); bf16: throughput mode, narrower "
+                         "than the reference's arithmetic, reported as the secondary `bf16_mode` object")
     ap.add_argument('--graph', type=int, default=1,
                     help='1: capture the step once and replay it from a hipGraph (default; the eager step is '
-                         'host-bound at ~530 launches); 0: eager launches')
+                         'host-bound at ~250-500 launches); 0: eager launches')
     ap.add_argument('--defer-tail', type=int, default=0, choices=[0, 1, 2],
                     help='pipeline stage balancing: K/V projections + mask-feature packing run in the decode stage')
     ap.add_argument('--pipeline', type=int, default=3, choices=[0, 2, 3, 4, 5],
@@ -359,8 +525,11 @@ def main():
     ap.add_argument('--host-results', type=int, default=1,
                     help='1 (default): also time the step with results delivered to the host as COCO RLE (reported as '
                          '`host_results`, never `value`)')
-    ap.add_argument('--no-parity-mode', action='store_true',
-                    help='skip the fp32 (parity-mode) timing of the same step that is reported as config.parity_mode_value')
+    ap.add_argument('--no-bf16-mode', action='store_true', help='skip the secondary bf16 (throughput-mode) timing')
+    ap.add_argument('--train-step', type=int, default=1,
+                    help="1 (default, rank 0 of a 1-GPU run): also run configs[2]'s training step in a child process -> `train_step`")
+    ap.add_argument('--train-steps', type=int, default=5)
+    ap.add_argument('--no-einsum-sweep', action='store_true', help='skip the Q = 100 / 200 mask-logit einsum launches (profile runs)')
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 2 if args.mode == 'infer' else 16
@@ -392,6 +561,8 @@ def main():
 
     import cgg_amd
     from cgg_amd import ops, runtime, synthetic
+    if args.mode == 'train' and '--precision' not in sys.argv:
+        args.precision = 'bf16'              # the training step's measured mode (round 2); fp32 with --precision fp32
     runtime.set_precision(args.precision)
     cfg, model = build_model(args, dev)
     B, H, W = args.batch, args.size, args.size
@@ -403,213 +574,70 @@ def main():
     if args.mode == 'train':
         return train_main(args, cfg, model, img, metas, dev, rank, world)
 
-    def step():
-        with torch.no_grad():
-            return model.simple_test(img, metas, rescale=True, device_results=True)
-
     def barrier():
         torch.cuda.synchronize()             # (gloo dry run: the device work must be done before the host barrier)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        out = step()
-    torch.cuda.synchronize()
-
-    graph = None
-    pipe = None
-    if args.graph and args.pipeline:
-        try:
-            from cgg_amd.pipeline import detector_pipeline
-            pipe = detector_pipeline(model, img, metas, stages=args.pipeline, defer_tail=args.defer_tail,
-                                     rescale=True, device_results=True)
-            for _ in range(args.pipeline):
-                pipe.submit(img)
-            pipe.flush()
-            torch.cuda.synchronize()
-        except Exception as e:
-            print(f'bench.py: stage pipeline setup failed ({type(e).__name__}: {e}); falling back to one graph '
-                  'per step', file=sys.stderr)
-            pipe = None
-            args.pipeline = 0
-            torch.cuda.synchronize()
-    if args.graph and pipe is None:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph):
-                out = step()
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:      # loud, not silent: the JSON line says hip_graph false and why
-            print(f'bench.py: hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches',
-                  file=sys.stderr)
-            graph = None
-            args.graph = 0
-            torch.cuda.synchronize()
-
-    ops.KERNEL_EVENTS = {} if (graph is None and pipe is None) else None
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if pipe is not None:
-            pipe.submit(img)
-        elif graph is not None:
-            graph.replay()
-        else:
-            out = step()
-    if pipe is not None:
-        pipe.flush()          # every submitted step is complete before the closing barrier + synchronize
-    barrier()
-    dt = time.perf_counter() - t0
-    events = ops.KERNEL_EVENTS or {}
-    ops.KERNEL_EVENTS = None
-
+    Q = args.queries
+    main_mode = time_mode(args, model, img, metas, dev, args.precision, barrier, collect_events=(args.precision == 'fp32'))
+    dt = main_mode['dt']
     tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if args.shared_devices else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # ---- per-batch latency: ONE step alone (no cross-step overlap), submit -> results complete ----
-    lat = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        if pipe is not None:
-            pipe.submit(img)
-            pipe.flush()
-        elif graph is not None:
-            graph.replay()
-        else:
-            out = step()
-        torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    latency_ms = sorted(lat)[len(lat) // 2]
+    kernels = {}
+    if args.precision == 'fp32' and rank == 0:
+        kernels = kernel_summaries(args, main_mode.get('events', {}), main_mode.get('meta', {}), B, H, W, Q)
+    roofline = kernels.pop('gemm_x3', None)
 
-    # ---- roofline of the mask-logit kernel (full resolution) ----
-    timed_how = 'HIP events around the launch inside the timed steps'
-    if not events.get('mask_logits_full'):
-        # graph mode: events cannot be recorded inside a replay -> the SAME K steps are run once more eagerly right
-        # after the timed replays (same process, weights, inputs, shapes) with events around the launches; the
-        # rocprofv3 kernel trace of the replays (profiles/) is the cross-check
-        ops.KERNEL_EVENTS = events
-        for _ in range(args.steps):
-            out = step()
-        ops.KERNEL_EVENTS = None
-        timed_how = ('HIP events around the launch in the same %d steps re-run eagerly right after the timed hipGraph '
-                     'replays (events cannot be recorded inside a replay)' % args.steps)
-    torch.cuda.synchronize()
-    # `frac` comes from the RAW event mean. An event pair with nothing between it still measures a few microseconds
-    # (event-record latency on the stream); that floor is calibrated in situ and reported beside it as a secondary,
-    # overhead-adjusted figure (`*_event_adjusted`), never as `frac`.
-    pairs = []
-    for _ in range(64):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        b.record()
-        pairs.append((a, b))
-    torch.cuda.synchronize()
-    ev_over = min(a.elapsed_time(b) for a, b in pairs)     # the floor: anything above it is queueing noise, not event cost
-    ml = [s.elapsed_time(e) for s, e in events['mask_logits_full']]
-    ml_ms = sum(ml) / len(ml)                              # raw event mean
-    ml_adj_ms = max(ml_ms - ev_over, 1e-6)
-    HW4 = (H // 4) * (W // 4)
-    Q = args.queries
-    in_bytes = 2 if args.precision == 'bf16' else 4       # packed bf16 (hi) or hi+lo = 4 B / element
-    alg_bytes = B * (256 * HW4 * in_bytes + Q * 256 * 4 + Q * HW4 * 4)
-    flops = 2.0 * B * Q * 256 * HW4
-    gbs = alg_bytes / (ml_ms * 1e-3) / 1e9
-    tfs = flops / (ml_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic('cgg_mask_logits_kernel', B, H, W)
-    roofline = dict(bound='hbm', kernel='cgg_mask_logits_kernel', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, launch_ms=ml_ms, launches_timed=len(ml),
-                    algorithmic_bytes=alg_bytes, tflops=tfs, frac_mfma_bf16_peak=tfs / MFMA_BF16_PEAK_TF,
-                    timed=timed_how, event_pair_overhead_ms=ev_over, launch_ms_event_adjusted=ml_adj_ms,
-                    frac_event_adjusted=alg_bytes / (ml_adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    rocprof=rocprof_launch_mean('cgg_mask_logits_kernel'))
-    extra = {}
-    if events.get('msda_fused'):
-        ms = [s.elapsed_time(e) for s, e in events['msda_fused']]
-        ms = sum(ms) / len(ms)                              # raw event mean
-        N = sum((H // s) * (W // s) for s in (8, 16, 32))
-        vb = 2 if args.precision == 'bf16' else 4         # bf16 stream: value, offsets|logits and output are bf16
-        mbytes = B * N * (256 * vb + 288 * vb + 256 * vb)
-        extra['msda'] = dict(launch_ms=ms, algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9,
-                             frac_hbm_peak=mbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             rocprof=rocprof_launch_mean('cgg_msda_fwd_stream_kernel'))
-
-    if events.get('encoder_tail'):
-        # post-attention half of an encoder layer (output_proj + LN + FFN + LN) as one launch: MFMA-bound, and since round 2 the
-        # kernel with the largest share of the step (5 launches of ~78 us + the K/V variant) -> it is the `roofline` kernel; the
-        # mask-logit launch that held that place in round 1 moves to `kernels.mask_logits` unchanged.
-        # flops = 2 M (256*256 + 2 * 256*1024); algorithmic bytes = attention rows + layer input rows in, y rows out (bf16)
-        # (+ f32 pos rows in and `y + pos` rows out when the projection kernel does not form x + pos itself).
-        ms_l = [s.elapsed_time(e) for s, e in events['encoder_tail']]
-        ms = sum(ms_l) / len(ms_l)
-        ms_adj = max(ms - ev_over, 1e-6)
-        N = sum((H // s) * (W // s) for s in (8, 16, 32))
-        M = B * N
-        fl = 2.0 * M * (256 * 256 + 2 * 256 * 1024)
-        from cgg_amd import pixel_decoder as _pd
-        pos_in_proj = _pd.FUSED_PROJ and _pd.POS_IN_PROJ
-        tb = M * 256 * 2 * 3 + (0 if pos_in_proj else M * 256 * 2 + N * 256 * 4)
-        tname = 'cgg_encoder_ffn_ln_kernel<false, true>'
-        ttraffic, ttraffic_src = pmc_traffic(tname, B, H, W)
-        tail = dict(bound='mfma', kernel=tname, achieved=fl / (ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s',
-                    frac=fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, traffic=ttraffic,
-                    traffic_source=ttraffic_src,
-                    launch_ms=ms, launches_timed=len(ms_l), flops=fl, algorithmic_bytes=tb, achieved_GBs=tb / (ms * 1e-3) / 1e9,
-                    timed=timed_how, event_pair_overhead_ms=ev_over, launch_ms_event_adjusted=ms_adj,
-                    frac_event_adjusted=fl / (ms_adj * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
-                    share_of_step='5 launches per step + 1 K/V-emitting variant: ~12 % of the kernel time of a step',
-                    replaces='3 library GEMMs + 2 residual-LayerNorm passes per layer: 396 MB of HBM traffic -> 66 MB',
-                    rocprof=rocprof_launch_mean(tname))
-        extra['mask_logits'] = roofline
-        roofline = tail
-    if events.get('encoder_proj'):
-        ms = [s.elapsed_time(e) for s, e in events['encoder_proj']]
-        ms = sum(ms) / len(ms)
-        N = sum((H // s) * (W // s) for s in (8, 16, 32))
-        pb = B * N * (256 + 256 + 256 + 288) * 2
-        extra['encoder_proj'] = dict(kernel='cgg_encoder_proj_kernel', bound='hbm', launch_ms=ms,
-                                     launches_timed=len(events['encoder_proj']), algorithmic_bytes=pb,
-                                     achieved_GBs=pb / (ms * 1e-3) / 1e9, frac_hbm_peak=pb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     rocprof=rocprof_launch_mean('cgg_encoder_proj_kernel'))
-
-    parity = None
-    pipelined = pipe is not None
-    if args.precision == 'bf16' and not args.no_parity_mode:
-        pipe = graph = None                  # release the captured graphs' buffers before the second mode
-        parity = parity_mode_rate(args, model, img, metas, dev)
+    other = None
+    if not args.no_bf16_mode and args.precision == 'fp32':
+        o = time_mode(args, model, img, metas, dev, 'bf16', barrier, collect_events=False)
+        agree = committed_profile('r3_bf16_agreement.json')
+        other = dict(value=B * world * args.steps / o['dt'], unit='images/sec', ms_per_step=o['dt'] / args.steps * 1e3, dtype='bf16',
+                     latency_ms_per_batch=o['latency_ms'], how=o['how'],
+                     note='throughput mode: bf16 MFMA contractions (narrower than the reference\'s f32 arithmetic; outside the '
+                          '1e-3 / bit-exact parity clause -- never `value`)',
+                     agreement_with_f32_oracle=agree)
     host = None
     if args.host_results and rank == 0:
         with runtime.precision_scope(args.precision):
             host = host_results_rate(args, model, img, metas, dev)
+    sweep = None
+    if rank == 0 and (H, W) == (1024, 1024) and not args.no_einsum_sweep:
+        sweep = einsum_q_sweep(dev, B, H, W)
     if rank == 0:
+        f32 = args.precision == 'fp32'
         res = dict(metric='images/sec (COCO-shaped 1024x1024, 100 queries, forward-only)',
                    value=B * world * args.steps / dt, unit='images/sec', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling='weak', vs_baseline=None,
-                   dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
+                   dtype='f32 (f16x3 split MFMA, f32 accumulate)' if f32 else 'bf16', data='synthetic',
                    config=dict(workload=f'configs[1]: R50 + {Q} queries, {H}x{W}, batch {B}/GPU, forward-only '
                                         '(backbone + MSDeformAttn pixel decoder + 9-layer masked-attention '
                                         'decoder + mask logits + instance post-processing, results on device)',
                                global_batch=B * world, parallelism=f'replicas x{world}',
-                               precision=args.precision, hip_graph=bool(args.graph),
-                               parity_mode_value=None if parity is None else parity['value'],
-                               ranks_share_devices=bool(args.shared_devices),
-                               pipeline=(f'{args.pipeline}-stage software pipeline across steps (one HIP stream + hipGraph '
-                                         'per stage and buffer slot; every timed step completes inside the timed '
-                                         'region)') if pipelined else 'none'),
-                   latency_ms_per_batch=latency_ms, parity_mode=parity, host_results=host, roofline=roofline,
-                   kernels=extra)
+                               precision=args.precision + (' = parity mode: every contraction of the path in f32-class arithmetic '
+                                                           '(two f16 pieces per f32 operand, three f16 MFMAs per product, f32 '
+                                                           'accumulation: as accurate as an f32 GEMM, tests/test_x3_gpu.py); '
+                                                           'softmax / norms / sampling f32' if f32 else ''),
+                               hip_graph=main_mode['hip_graph'], ranks_share_devices=bool(args.shared_devices),
+                               pipeline=main_mode['how'],
+                               timed_region=f'{args.steps} steps, repeated {args.repeats}x back to back; median region '
+                                            f'{dt * 1e3:.1f} ms (min {min(main_mode["regions_s"]) * 1e3:.1f}, max '
+                                            f'{max(main_mode["regions_s"]) * 1e3:.1f})'),
+                   latency_ms_per_batch=main_mode['latency_ms'], bf16_mode=other, host_results=host, roofline=roofline,
+                   kernels=kernels, einsum_mfma_target=sweep)
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args, cfg, model, img_cpu)
+        if args.train_step and world == 1:
+            torch.cuda.synchronize()
+            del main_mode
+            torch.cuda.empty_cache()
+            res['train_step'] = train_step_child(args)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -925,6 +925,8 @@ class Mask2FormerHeadOpen(nn.Module):
                     else:
                         den = xx.pow(2).sum(-1)[:, :, None] + t.pow(2).sum(-1)[:, None, :]
                     cost = cost + (1 - (num + dc.eps) / (den + dc.eps)) * dc.weight
+                if getattr(self, 'cost_trace', None) is not None:      # test hook: the (n, Q, G) cost matrices of image b
+                    self.cost_trace.append((b, cost.detach().float().clone()))
                 costs.append(cost.float().reshape(-1))                                        # (n*Q*G,)
             flat = torch.cat(costs).cpu() if costs else None                                  # the ONE sync
         import numpy as np

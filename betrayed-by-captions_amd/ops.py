@@ -21,9 +21,13 @@ _WS_CACHE = {}
 KERNEL_EVENTS = None
 
 
+KERNEL_META = None          # with KERNEL_EVENTS: name -> list of per-launch dicts (flops, bytes, shape) in launch order
+
+
 class _timed:
-    def __init__(self, name):
+    def __init__(self, name, **meta):
         self.name = name
+        self.meta = meta
         self.on = KERNEL_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
 
     def __enter__(self):
@@ -36,6 +40,8 @@ class _timed:
         if self.on:
             self.e.record()
             KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+            if KERNEL_META is not None and self.meta:
+                KERNEL_META.setdefault(self.name, []).append(self.meta)
 
 
 def _lib_():
@@ -1089,7 +1095,8 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
         raise CggError('gemm_x3: bad `out` view')
     if res is not None and (res.dim() != 2 or res.stride(1) != 1 or res.shape != (M, N) or res.dtype != torch.float32):
         raise CggError('gemm_x3: bad `res` view')
-    with _timed('gemm_x3'):
+    with _timed('gemm_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * K + M * N * (2 if res is not None else 1)) + 4.0 * N * K,
+                shape=(M, N, K)):
         rc = _lib_().cgg_gemm_x3(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
                                  ctypes.c_void_p(res.data_ptr()) if res is not None else None,
                                  res.stride(0) if res is not None else 0, ctypes.c_void_p(y.data_ptr()), y.stride(0), M, N, K,
@@ -1112,7 +1119,8 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     F = b1.numel()
     y = torch.empty_like(a)
     yp = torch.empty_like(a) if want_pos else None
-    with _timed('encoder_tail_x3'):
+    with _timed('encoder_tail_x3', flops=2.0 * M * (C * C + 2 * C * F), bytes=4.0 * M * C * (3 + (1 if want_pos else 0)),
+                shape=(M, C, F)):
         rc = _lib_().cgg_encoder_layer_tail_x3(
             dev_ptr(a), dev_ptr(x), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32),
             dev_ptr(norm0[1], 'beta0', torch.float32), float(norm0[2]), dev_ptr(w1), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2),
@@ -1134,7 +1142,7 @@ def gemm_x3_split(a, packed, N, col2, bias=None, res_table=None):
     if res_table is not None and (res_table.dim() != 2 or res_table.shape[1] != N or not res_table.is_contiguous()
                                   or res_table.dtype != torch.float32):
         raise CggError('gemm_x3_split: res_table must be a contiguous (R, N) float32 tensor')
-    with _timed('gemm_x3'):
+    with _timed('gemm_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * K + M * N + N * K), shape=(M, N, K)):
         rc = _lib_().cgg_gemm_x3_ex(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
                                     dev_ptr(res_table), N if res_table is not None else 0,
                                     res_table.shape[0] if res_table is not None else 0, dev_ptr(y1), col2, dev_ptr(y2), N - col2,
@@ -1154,7 +1162,9 @@ def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, rel
     y = torch.empty((B, OH, OW, N), dtype=torch.float32, device=x.device)
     if res is not None and (tuple(res.shape) != (B, OH, OW, N) or not res.is_contiguous() or res.dtype != torch.float32):
         raise CggError('conv_x3_nhwc: res must be a contiguous (B, OH, OW, N) float32 tensor')
-    with _timed('conv_x3'):
+    with _timed('gemm_x3', flops=2.0 * B * OH * OW * N * C * KH * KW,
+                bytes=4.0 * (B * H * W * C + B * OH * OW * N * (2 if res is not None else 1) + N * C * KH * KW),
+                shape=(B * OH * OW, N, C * KH * KW)):
         rc = _lib_().cgg_conv_x3_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res), dev_ptr(y),
                                       B, H, W, C, N, KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
     check(rc, 'cgg_conv_x3_nhwc')

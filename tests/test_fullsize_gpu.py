@@ -223,6 +223,62 @@ def test_configs1_fp32_mode_vs_oracle(dev, cfg1):
     check_fp32_mode(dev, cfg1)
 
 
+def test_configs1_fp32_mode_end_to_end_without_injection(dev, cfg1):
+    """Parity mode END TO END with the product's OWN attention masks (no oracle masks injected, lean serving path): what a user of
+    `simple_test` actually gets. A logit within rounding distance of 0 may put a key on the other side of the mask than on the
+    CPU, and that flip then moves everything downstream by more than rounding -- the reference's own f32-vs-f64 difference does
+    the same (scratch/fullsize_diag.py: 1e-3..4e-3 on the logits at these weights). Stated bounds, measured on MI355X with the
+    x3 kernels: per layer >= 99.99 % of the attention-mask bits equal the oracle's and every differing bit has |oracle logit|
+    <= 2e-3; final mask logits within 2e-2 (scale ~20); the (query, class) top-k sets differ by at most 1 pair per image
+    and class set; detection masks IoU >= 0.999 on the common detections; detection scores within 5e-3."""
+    c = cfg1
+    model, metas, head = c['model'], c['metas'], c['model'].panoptic_head
+    img = c['img'].to(dev)
+    logits = c['teacher'].logits
+    agree, worst = [], []
+
+    def record(layer_idx, bits):
+        lg = logits[layer_idx]
+        mine = ops.unpack_bits(bits, lg.shape[-1]).cpu()
+        wrong = mine != (lg < 0)
+        agree.append(1.0 - float(wrong.float().mean()))
+        worst.append(float(lg.abs()[wrong].max()) if bool(wrong.any()) else 0.0)
+        return bits
+    with torch.no_grad(), runtime.precision_scope('fp32'):
+        head.attn_mask_hook = record
+        try:
+            pc, pe, pm = head.forward(model.extract_feat(img), metas)
+        finally:
+            head.attn_mask_hook = None
+        res = model.simple_test(img, metas, rescale=True, device_results=True, with_query_indices=True)   # lean path, no hook
+        torch.cuda.synchronize()
+    err = (pm[-1].cpu() - c['omask'][-1]).abs().max().item()
+    jac, ious, dscore = [], [], []
+    for b in range(c['B']):
+        omp = OH.crop_rescale(c['oup'][b], metas[b], True)
+        for key in TYPES:
+            flat, n, otop, kth = _oracle_instances(c, b, key)
+            labels, bboxes, masks = res[b][key]
+            qidx = res[b]['query_indices'][key].cpu()
+            pidx = qidx * n + labels.cpu().long()
+            oset, pset = set(otop.tolist()), set(pidx.tolist())
+            jac.append(len(oset ^ pset) // 2)
+            common = torch.tensor([i for i, v in enumerate(pidx.tolist()) if v in oset])
+            want = omp[qidx[common]] > 0
+            ious.append(_iou(masks.cpu()[common], want))
+            binary = want.float()
+            ms = (omp[qidx[common]].sigmoid() * binary).flatten(1).sum(1) / (binary.flatten(1).sum(1) + 1e-6)
+            dscore.append((bboxes.cpu()[common, 4] - flat[pidx[common]] * ms).abs())
+    ious, dscore = torch.cat(ious), torch.cat(dscore)
+    rec = dict(attn_mask_bit_agreement_min=min(agree), largest_logit_under_a_flipped_bit=max(worst), final_mask_logit_err=err,
+               topk_pairs_swapped_max=max(jac), mask_iou_min=float(ious.min()), det_score_abs_err_max=float(dscore.max()))
+    print('configs[1] fp32 mode, no injection:', json.dumps(rec))
+    _write_report('configs1_fp32_no_injection', rec)
+    assert min(agree) >= 0.9999 and max(worst) <= 2e-3, rec
+    assert err <= 2e-2, rec
+    assert max(jac) <= 1 and float(ious.min()) >= 0.999 and float(dscore.max()) <= 5e-3, rec
+
+
 def _iou(a, b):
     inter = (a & b).flatten(1).sum(1).float()
     union = (a | b).flatten(1).sum(1).float()
@@ -299,7 +355,13 @@ def test_configs1_bf16_mode_agreement_without_injection(dev, cfg1):
     rec = check_bf16_agreement(dev, cfg1, 'configs1_bf16')
     assert min(rec['attn_mask_bit_agreement_per_layer']) >= 0.96, rec
     assert rec['topk_pair_jaccard_mean'] >= 0.93, rec      # (query, class) sets
+    assert rec['topk_pair_jaccard_min'] >= 0.85, rec       # worst image x class set (measured 0.92)
     assert rec['mask_iou_mean'] >= 0.94 and rec['mask_iou_p05'] >= 0.90, rec
+    # detection score = softmax(emb . E^T)[class] x mean on-pixel sigmoid. The class dots of this model are UN-normalised 768-dim
+    # products (|logit| up to ~1e2 with the synthetic table): a bf16-sized relative error of the embedding moves a logit by
+    # O(0.1-1) and a near-tied class probability by up to p (1 - p) x that -- measured 0.25 on the worst of ~600 detections
+    # (median 3e-3). It is a property of bf16 mode (which is why `value` is parity mode), bounded here so that it cannot grow.
+    assert rec['det_score_abs_err_max'] <= 0.35, rec
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -476,3 +538,8 @@ def test_configs4_panoptic_detector_bf16_runs(dev, cfg4):
     print('configs[4] bf16 agreement:', json.dumps(rec))
     _write_report('configs4_bf16', rec)
     assert len(agree) == 9 and min(agree) >= 0.95, rec
+    # the panoptic map is a chain of THRESHOLD decisions per query (class score > 0.8, mask area ratio > 0.8, stuff area >= 4096):
+    # one query whose score sits at a threshold keeps or drops a whole segment, i.e. up to a third of an image's pixels at once
+    # (measured: 0.67 / 0.99 on the two images -- one large stuff segment differs on the first). bf16 mode cannot promise more
+    # than "most segments survive"; parity mode's map is EXACT (test above). Bounded so that it cannot silently get worse.
+    assert min(same) >= 0.55 and max(same) >= 0.9, rec

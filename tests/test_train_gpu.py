@@ -191,3 +191,80 @@ def test_train_driver_runs_resumes_and_checkpoints(dev, tmp_path):
     it = drv.main([str(cfg_file), '--work-dir', work, '--max-iters', '5', '--synthetic', '128', '--seed', '5',
                    '--log-interval', '1', '--resume-from', os.path.join(work, 'latest.pth')])
     assert it == 5
+
+
+def test_hungarian_indices_on_the_gpu_path_at_configs2_shapes(dev):
+    """north_star: "bit-exact class/mask assignment indices". The production target path (`_targets_batched`: device cost
+    matrices for all layers x images, one D2H, cgg_linear_sum_assignment_f32) against the oracle's per-(layer, image)
+    `get_target_single` (reference: open_set/assigners/mask_hungarian_assigner.py:100-143, mask2former_head.py:320-390) at
+    configs[2] shapes -- batch 16, 100 queries, 12 544 points, 1..20 ground-truth instances, all 10 decoder outputs, the same
+    pinned random points: cost matrices within 1e-5, labels / positive queries / matched GT ids / negatives EQUAL. A differing
+    assignment is accepted only as a reported TIE (both assignments cost the same to 1e-6 under the oracle's own float64 cost)."""
+    from scipy.optimize import linear_sum_assignment
+    cfg = small_cfg(num_queries=100, num_points=12544)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prod, orc = build_heads(cfg)
+    prod = prod.to(dev).train()
+    n, B, Q, h, w, H, W = 10, 16, 100, 128, 128, 512, 512
+    K1 = prod.class_embs.shape[0]
+    g = torch.Generator().manual_seed(2024)
+    batch = synthetic.train_batch(B, H, W, num_classes=cfg['panoptic_head']['num_things_classes'], max_inst=20, vocab=500, seed=77)
+    gt_labels, gt_masks = batch['gt_labels'], [m.long() for m in batch['gt_masks']]
+    gt_labels[3], gt_masks[3] = gt_labels[3][:0], gt_masks[3][:0]                # one image without ground truth
+    # predictions: every GT instance has a few queries that follow it (noisy), the rest is noise -> real competition
+    cls = [torch.randn(B, Q, K1, generator=g) for _ in range(n)]
+    emb = [torch.randn(B, Q, K1, generator=g) * 2 for _ in range(n)]
+    masks = []
+    for li in range(n):
+        m = torch.randn(B, Q, h, w, generator=g) * 2
+        for b in range(B):
+            G = gt_masks[b].shape[0]
+            if G:
+                small = torch.nn.functional.interpolate(gt_masks[b][None].float(), (h, w), mode='bilinear', align_corners=False)[0]
+                own = torch.randint(0, G, (Q // 2,), generator=g)
+                m[b, :Q // 2] += (small[own] * 2 - 1) * (1.5 + li * 0.2)
+        masks.append(m)
+    # ---- oracle, reference order of the random draws: layer-major, then image ----
+    orc.point_hook = Bank(11)
+    ref = [[orc.get_target_single(cls[li][b], emb[li][b], masks[li][b], gt_labels[b], gt_masks[b]) for b in range(B)]
+           for li in range(n)]
+    # ---- product ----
+    prod.point_hook = Bank(11)
+    prod.cost_trace = []
+    to = lambda t: t.to(dev)     # noqa: E731
+    out = prod._targets_batched([to(c) for c in cls], [to(e) for e in emb], [to(m) for m in masks], [to(l) for l in gt_labels],
+                                [to(m).float() for m in gt_masks])
+    costs = dict(prod.cost_trace)
+    prod.cost_trace = None
+    ties, worst_cost = 0, 0.0
+    for li in range(n):
+        labels, weights, pos_b, pos_g, k, devi = out[li]
+        labels, weights = labels.cpu(), weights.cpu()
+        qb, gb, bb = devi['q'].cpu(), devi['g'].cpu(), devi['b'].cpu()
+        for b in range(B):
+            r_labels, _, _, r_w, r_pos, r_neg, r_cost = ref[li][b]
+            if gt_labels[b].numel() == 0:
+                assert (labels[b] == prod.num_classes).all() and float(weights[b].sum()) == 0 and not (bb == b).any()
+                continue
+            c = costs[b][li].cpu()
+            worst_cost = max(worst_cost, float((c - r_cost).abs().max()))
+            assert torch.allclose(c, r_cost, atol=1e-5, rtol=1e-5), (li, b, float((c - r_cost).abs().max()))
+            sel = bb == b
+            p_pos, p_gt = qb[sel], gb[sel]
+            r_gt = torch.full((Q,), -1, dtype=torch.long)
+            rr, cc = linear_sum_assignment(r_cost.numpy())
+            r_gt[torch.from_numpy(rr)] = torch.from_numpy(cc)
+            same = torch.equal(p_pos, r_pos) and torch.equal(p_gt, r_gt[r_pos]) and torch.equal(labels[b], r_labels)
+            if not same:
+                c64 = r_cost.double()
+                a = float(c64[p_pos, p_gt].sum())
+                o = float(c64[r_pos, r_gt[r_pos]].sum())
+                assert abs(a - o) <= 1e-6 * (1 + abs(o)), ('different assignment with a different cost', li, b, a, o)
+                ties += 1
+                continue
+            assert torch.equal(weights[b].nonzero().squeeze(-1), r_pos)
+            neg = (weights[b] == 0).nonzero().squeeze(-1)
+            assert torch.equal(neg, r_neg)
+    print(f'Hungarian parity: {n * (B - 1)} problems, max |cost - oracle| = {worst_cost:.2e}, {ties} exact-cost ties')
+    assert ties <= 2
