@@ -507,7 +507,7 @@ class Mask2FormerHeadOpen(nn.Module):
 
         a0 = layers[0].attentions[0].attn
         x, m0, q = runtime.derived_cached(
-            'lean_decode_consts_%d' % B,
+            'lean_decode_consts_%d_%s' % (B, runtime.precision()),     # computed by the mode's own kernels
             (qf, self.query_embed.weight, pn.weight, pn.bias, me[0].weight, me[0].bias, me[2].weight, me[2].bias,
              me[4].weight, me[4].bias, a0.in_proj_weight, a0.in_proj_bias), consts)
         outs = ([None], [None], [None])
