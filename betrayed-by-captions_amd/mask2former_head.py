@@ -986,9 +986,9 @@ class Mask2FormerHeadOpen(nn.Module):
         emb_l = [torch.zeros_like(embs) for _ in range(world_size)]
         mask_l = [torch.zeros_like(mask) for _ in range(world_size)]
         pred_l = [torch.zeros_like(cls_emb_preds) for _ in range(world_size)]
-        dist.all_gather(emb_l, embs.contiguous())
-        dist.all_gather(mask_l, mask.contiguous())
-        dist.all_gather(pred_l, cls_emb_preds.detach().contiguous())
+        _all_gather(emb_l, embs.contiguous())
+        _all_gather(mask_l, mask.contiguous())
+        _all_gather(pred_l, cls_emb_preds.detach().contiguous())
         all_preds = torch.cat(pred_l, dim=0)
         all_preds[rank * batch_size:(rank + 1) * batch_size] = cls_emb_preds
         return torch.cat(emb_l, dim=0), torch.cat(mask_l, dim=0), all_preds
@@ -1005,9 +1005,9 @@ class Mask2FormerHeadOpen(nn.Module):
         mask_l = [torch.zeros_like(mask) for _ in range(world_size)]
         stacked = torch.stack([p.detach() for p in all_preds], dim=0).contiguous()   # (n,B,Q,d)
         pred_l = [torch.zeros_like(stacked) for _ in range(world_size)]
-        dist.all_gather(emb_l, embs.contiguous())
-        dist.all_gather(mask_l, mask.contiguous())
-        dist.all_gather(pred_l, stacked)
+        _all_gather(emb_l, embs.contiguous())
+        _all_gather(mask_l, mask.contiguous())
+        _all_gather(pred_l, stacked)
         all_embs, all_mask = torch.cat(emb_l, dim=0), torch.cat(mask_l, dim=0)
         out = []
         for li, p in enumerate(all_preds):
@@ -1345,6 +1345,18 @@ class Mask2FormerHeadOpen(nn.Module):
             nouns_embs = self.bert_embeddings(kwargs['nouns_ids']).squeeze(0)
             att = torch.matmul(mask_cls_emb_results[0], nouns_embs.t())
         return assigned_labels, mask_cls_emb_results, masks, caption_generation_results, att
+
+
+def _all_gather(out_list, tensor):
+    """dist.all_gather; over gloo (debug / single-device multi-rank runs: RCCL refuses two ranks on one GPU) device tensors are
+    staged through the host, because gloo implements only broadcast and all_reduce for them."""
+    if tensor.is_cuda and dist.get_backend() == 'gloo':
+        host = [torch.empty(o.shape, dtype=o.dtype) for o in out_list]
+        dist.all_gather(host, tensor.cpu())
+        for o, h in zip(out_list, host):
+            o.copy_(h)
+        return
+    dist.all_gather(out_list, tensor)
 
 
 def reduce_mean(tensor):

@@ -1,0 +1,99 @@
+"""One rank of tests/test_dist_gpu.py: started as a FRESH child process (never a re-exec of pytest), both ranks on device 0,
+torch.distributed over gloo on 127.0.0.1 (RCCL refuses two ranks on one GPU; on an 8-GPU node the same code runs over RCCL).
+A tiny Mask2FormerOpen detector runs the real training step twice: forward_train with the head's caption / prediction gathers
+(open_set/models/mask2former_head.py:650-684), reduce_mean (:591), `_parse_losses`, the bucketed gradient reducer standing in
+for the DDP wrap of open_set/apis/train.py:152-161, clip, AdamW. Checks (assert = non-zero exit):
+  * reduced gradients == mean over ranks of the gradients each rank computes on its own (same collectives in the forward);
+  * `launch_log` is 0, 1, 2, ... on both ranks although rank 1 has an image WITHOUT ground truth;
+  * parameters identical on both ranks after every step; losses finite; the loss log is the mean over ranks."""
+import copy
+import os
+import sys
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch                        # noqa: E402
+import torch.distributed as dist    # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    import cgg_amd  # noqa: F401
+    from cgg_amd import registry, runtime, synthetic
+    from cgg_amd.train import GradReducer, build_optimizer, train_step
+    runtime.set_precision('fp32')
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=12, depth=50, enc_layers=1, dec_layers=2,
+                                 vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.manual_seed(100 + rank)            # DIFFERENT initial weights per rank: the broadcast must fix that
+        model = registry.build_detector(cfg)
+        model.init_weights()
+    model = model.to(dev).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B, H, W = 2, 128, 128
+    nc = cfg['panoptic_head']['num_things_classes']
+    reducer = GradReducer(model, bucket_bytes=4 << 20)           # several buckets
+    assert len(reducer.buckets) >= 3
+    reducer.broadcast_parameters(model)
+    optimizer = build_optimizer(model, dict(type='AdamW', lr=1e-3, weight_decay=0.05))
+    ref = copy.deepcopy(model)                                   # the same weights, no reducer attached: "local" gradients
+    for step in range(2):
+        batch = synthetic.train_batch(B, H, W, num_classes=nc, max_inst=4, vocab=500, seed=50 + 10 * step + rank, device=dev)
+        if rank == 1 and step == 0:                              # rank 1: one image without any ground truth
+            for k in ('gt_labels', 'gt_masks', 'gt_bboxes'):
+                batch[k][0] = batch[k][0][:0]
+        g = torch.Generator().manual_seed(7 + rank + 2 * step)
+        img = torch.randn(B, 3, H, W, generator=g).to(dev)
+        data = dict(img=img, img_metas=synthetic.img_metas(B, H, W), **batch)
+        # ---- local gradients: same forward (same collectives, same device RNG), plain backward ----
+        ref.load_state_dict(model.state_dict())
+        for p in ref.parameters():
+            p.grad = None
+        torch.manual_seed(1000 + rank + step)
+        out = ref.train_step(data)
+        out['loss'].backward()
+        local = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in ref.named_parameters()
+                 if p.requires_grad}
+        # ---- the real step ----
+        torch.manual_seed(1000 + rank + step)
+        logs = train_step(model, optimizer, reducer, data, None)
+        assert reducer.launch_log == list(range(len(reducer.buckets))), reducer.launch_log
+        assert all(v == v and abs(v) < 1e6 for v in logs.values()), logs
+        named = dict(model.named_parameters())
+        worst = 0.0
+        for n, gl in local.items():
+            both = [torch.zeros_like(gl) for _ in range(world)]
+            from cgg_amd.mask2former_head import _all_gather
+            _all_gather(both, gl.contiguous())
+            mean = sum(both) / world
+            got = named[n].grad
+            scale = float(mean.abs().max()) + 1e-12
+            err = float((got - mean).abs().max())
+            if scale > 1e-6:                      # (parameters with an all-zero gradient, e.g. cls_embed: loss weight 0)
+                worst = max(worst, err / scale)
+            assert err <= 1e-4 * scale + 1e-9, (n, err, scale)
+        # ---- identical parameters on both ranks after the optimiser step ----
+        for n, p in model.named_parameters():
+            t = p.detach().clone()
+            dist.broadcast(t, src=0)
+            assert torch.equal(t, p.detach()), ('parameters diverged', n, step)
+        # the loss log is the mean over ranks
+        mine = torch.tensor([float(out['log_vars']['loss'])])
+        both = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert abs(float(sum(both) / world) - float(out['log_vars']['loss'])) < 1e-4 * (1 + abs(float(mine)))
+        print(f'rank {rank} step {step}: loss {logs["loss"]:.4f}, {len(reducer.buckets)} buckets in order, '
+              f'reduced == mean(local) to {worst:.1e}', flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
