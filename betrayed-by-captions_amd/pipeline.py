@@ -115,11 +115,12 @@ def detector_pipeline(model, example, metas, stages=3, defer_tail=True, **decode
     elif stages == 3:
         fns = [model.extract_feat, lambda f: head._encode(f, defer_tail=defer_tail),
                lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
-    elif stages == 4:      # encode | query decoder | post-processing (device results only)
+    elif stages == 4:      # THREE functions: encode | query decoder | post-processing (device results only); `len(pipe.stages)` is
+                           # what callers report -- the argument names the 2-stage split "+ a post-processing stage"
         fns = [lambda x: model.stage_encode(x, defer_tail=defer_tail),
                lambda enc: model.stage_head(enc, metas, **decode_kwargs),
                lambda out: model.stage_post(out, metas, **decode_kwargs)]
-    elif stages == 5:      # backbone | pixel decoder | query decoder | post-processing (device results only)
+    elif stages == 5:      # FOUR functions: backbone | pixel decoder | query decoder | post-processing (device results only)
         fns = [model.extract_feat, lambda f: head._encode(f, defer_tail=defer_tail),
                lambda enc: model.stage_head(enc, metas, **decode_kwargs),
                lambda out: model.stage_post(out, metas, **decode_kwargs)]

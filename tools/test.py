@@ -4,8 +4,9 @@ the registry -> `simple_test` over a stream of images -> results pickle (`--out`
 `--launcher pytorch` (images are sharded by rank, results gathered on rank 0). COCO evaluation (`--eval`) needs the
 dataset classes, which are out of this build's scope: the option is accepted and reported as unavailable.
 
-Throughput mode (`--precision bf16`, default) serves through `pipeline.StagePipeline` (hipGraph per stage, encode of batch
-k+1 overlapped with decode of batch k); `--precision fp32` is the parity path of the reference semantics.
+Both precision modes serve through `pipeline.StagePipeline` (hipGraph per stage, encode of batch k+1 overlapped with decode of
+batch k): `--precision fp32` (default) is parity mode -- the reference's f32 semantics on the f32-class x3 kernels --,
+`--precision bf16` the faster throughput mode (narrower than the reference's arithmetic).
 
     python tools/test.py CONFIG CHECKPOINT --out results.pkl --num-images 64 --synthetic 1024
 """
@@ -47,7 +48,7 @@ def parse_args(argv=None):
     p.add_argument('--samples-per-gpu', type=int, default=2)
     p.add_argument('--synthetic', type=int, default=1024, help='synthetic image size (H = W) when --data is not given')
     p.add_argument('--data', default=None, help='pkg.module:function -> iterable of (img (3,H,W) float tensor, img_meta)')
-    p.add_argument('--precision', default='bf16', choices=['fp32', 'bf16'])
+    p.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'])
     p.add_argument('--no-pipeline', action='store_true', help='plain sequential simple_test (no graphs / overlap)')
     p.add_argument('--rle', action='store_true',
                    help='results in the evaluation format: masks as COCO RLE dicts (what results2json builds with pycocotools from '
@@ -96,6 +97,15 @@ def interleave_rank_results(parts):
         if j < len(parts[r]):
             out.append(parts[r][j])
     return out[:total]
+
+
+def _test_stages():
+    """CGG_TEST_STAGES (pipeline stage split of the serving loop): validated up front, 2..5 as `pipeline.detector_pipeline` names them
+    (4 and 5 add a separate post-processing stage to the 2- / 3-stage split)."""
+    v = os.environ.get('CGG_TEST_STAGES', '3')
+    if v not in ('2', '3', '4', '5'):
+        raise SystemExit(f'CGG_TEST_STAGES={v!r}: expected 2, 3, 4 or 5')
+    return int(v)
 
 
 def main(argv=None):
@@ -171,7 +181,7 @@ def main(argv=None):
             for k, g in enumerate(group):
                 imgs[k].copy_(g[0], non_blocking=True)
             metas = [dict(g[1], batch_input_shape=tuple(imgs.shape[-2:])) for g in group]
-            use_pipe = (not args.no_pipeline and args.precision == 'bf16' and len(group) == B
+            use_pipe = (not args.no_pipeline and len(group) == B
                         and all(m['img_shape'] == metas[0]['img_shape'] and m['ori_shape'] == metas[0]['ori_shape'] for m in metas))
             if use_pipe:
                 key = (tuple(imgs.shape), metas[0]['img_shape'], metas[0]['ori_shape'])
@@ -180,7 +190,7 @@ def main(argv=None):
                     pipe = pipes.get(key)
                     if pipe is None:
                         from cgg_amd.pipeline import detector_pipeline
-                        pipe = detector_pipeline(model, imgs, metas, stages=int(os.environ.get('CGG_TEST_STAGES', '3')), defer_tail=False, rescale=True, device_results=True, mask_bits=args.mask_bits)
+                        pipe = detector_pipeline(model, imgs, metas, stages=_test_stages(), defer_tail=False, rescale=True, device_results=True, mask_bits=args.mask_bits)
                         pipe.meta_key = key
                         pipes[key] = pipe
                         torch.cuda.synchronize()
@@ -195,6 +205,10 @@ def main(argv=None):
                     if ev is not None:
                         pipe.streams[-1].wait_event(ev)
                 slot = pipe.submit(imgs)
+                # `imgs` was filled on this stream but is READ by stage 0 on the pipeline's first stream, after `run` has dropped
+                # its reference: without this the caching allocator may hand the block to the next batch's host->device copy
+                # while stage 0 has not copied the previous batch yet (batch k served with batch k + 1's pixels)
+                imgs.record_stream(pipe.streams[0])
                 pending.append((pipe, slot))
                 # results of the batch `depth` submits back are copied out while the newer ones run
                 while len(pending) > depth:
