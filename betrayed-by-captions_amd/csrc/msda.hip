@@ -386,6 +386,102 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_kernel(
                  cgg_pack2(cgg_f2bf(acc[2][0]), cgg_f2bf(acc[2][1])), cgg_pack2(cgg_f2bf(acc[3][0]), cgg_f2bf(acc[3][1])));
 }
 
+// Parity mode's twin of the kernel above: F32 values (B, Nv, 8, 32) -- in f32 a head's 32 channels of a pixel ARE one 128-byte
+// line, so the row layout already has the property the head-major bf16 layout was introduced for --, f32 offset / logit rows,
+// f32 output. Same lane geometry (4 lanes per (query, head), each evaluates one point's taps and broadcasts them with DPP,
+// 8 channels per lane = two 16-byte loads per tap), same arithmetic order as the bf16 kernel with exact f32 operands; replaces
+// the generic cgg_msda_fwd_kernel<float> (one lane per 4 channels, software 64-bit divisions) in the x3 encoder stream.
+template <int PSEL>
+__device__ __forceinline__ void msda_point_gather_f32(msda_v2f (&acc)[4], const float* __restrict__ vl, const int (&my_o)[4],
+                                                      const float (&my_w)[4]) {
+  constexpr int CTRL = PSEL | (PSEL << 2) | (PSEL << 4) | (PSEL << 6);      // quad_perm: every lane reads lane PSEL of its quad
+  f32x4 u[4][2];
+  float w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = msda_quad_bcast<CTRL>(my_o[k]);
+    w[k] = msda_quad_bcast<CTRL>(my_w[k]);
+    u[k][0] = *reinterpret_cast<const f32x4*>(vl + o);
+    u[k][1] = *reinterpret_cast<const f32x4*>(vl + o + 4);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const msda_v2f ww = {w[k], w[k]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const msda_v2f vv = {u[k][c >> 1][2 * (c & 1)], u[k][c >> 1][2 * (c & 1) + 1]};
+      acc[c] = __builtin_elementwise_fma(vv, ww, acc[c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
+    const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ rows, const float* __restrict__ ref,
+    int ld, float* __restrict__ out, int Nv, int Nq, unsigned total) {
+  constexpr int D = 32, CPL = 8, H = 8, L = 3, LP = 12;
+  const unsigned gid = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  if (gid >= total) return;               // total is a multiple of 4: quads are never split
+  const int cq = (int)(gid & 3u);
+  const int h = (int)((gid >> 2) & 7u);
+  const unsigned bq = gid >> 5;
+  const unsigned b = bq / (unsigned)Nq;
+  const int q = (int)(bq - b * (unsigned)Nq);
+  constexpr int rowstride = H * D;
+  const float* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
+  const float* row = rows + (size_t)bq * ld;
+  const float* lp = row + (size_t)h * LP * 2 + 2 * cq;                 // this lane's point: (x, y) of point cq, + 8 per level
+  const float* wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  float e[LP];
+  {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(wp), c = *reinterpret_cast<const f32x4*>(wp + 4),
+                d = *reinterpret_cast<const f32x4*>(wp + 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      e[i] = a[i];
+      e[4 + i] = c[i];
+      e[8 + i] = d[i];
+    }
+  }
+  float smax = e[0];
+#pragma unroll
+  for (int i = 1; i < LP; ++i) smax = fmaxf(smax, e[i]);
+  float ssum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    e[i] = __expf(e[i] - smax);
+    ssum += e[i];
+  }
+  const float sinv = 1.f / ssum;
+  float pw[L];                              // attention probability of THIS lane's point on each level
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+    pw[l] = (cq == 0 ? e[4 * l] : (cq == 1 ? e[4 * l + 1] : (cq == 2 ? e[4 * l + 2] : e[4 * l + 3]))) * sinv;
+
+  msda_v2f acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = msda_v2f{0.f, 0.f};
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.h[l], Wl = lv.w[l];
+    const float* vl = vb + (size_t)lv.start[l] * rowstride;
+    const float2 o = *reinterpret_cast<const float2*>(lp + 8 * l);
+    const float x = rx + o.x / (float)Wl;
+    const float y = ry + o.y / (float)Hl;
+    const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
+    const float wl = l == 0 ? pw[0] : (l == 1 ? pw[1] : pw[2]);
+    const int my_o[4] = {t.o00 * rowstride, t.o01 * rowstride, t.o10 * rowstride, t.o11 * rowstride};
+    const float my_w[4] = {t.w00 * wl, t.w01 * wl, t.w10 * wl, t.w11 * wl};
+    msda_point_gather_f32<0>(acc, vl, my_o, my_w);
+    msda_point_gather_f32<1>(acc, vl, my_o, my_w);
+    msda_point_gather_f32<2>(acc, vl, my_o, my_w);
+    msda_point_gather_f32<3>(acc, vl, my_o, my_w);
+  }
+  float* op = out + (size_t)bq * (H * D) + (size_t)h * D + cq * CPL;
+  *reinterpret_cast<f32x4*>(op) = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+  *reinterpret_cast<f32x4*>(op + 4) = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+}
+
 // Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
 // grad_loc / grad_attn are wave shuffles; grad_value is scattered with hardware f32 atomics.
 template <int P_>
@@ -822,6 +918,16 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
   hipLaunchKernelGGL((cgg_msda_fwd_kernel<VT, LT, PT, FU>), dim3(nblk), dim3(256), 0, s,         \
                      (const VT*)value, lv, loc, attw, ref, ld, out, Nv, H, D, L, Nq, P, total)
   const bool st = (L == 3 && P == 4);  // the shipped configs: num_levels=3, num_points=4
+  // the encoder stream's shape (8 heads x 32 channels, 3 levels x 4 points, rows = [offsets | logits]): quad-shared taps
+  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
+  const long long total8 = (long long)B * Nq * H * (D / 8);
+  if (dtype == CGG_F32 && fused && st && H == 8 && D == 32 && ld % 4 == 0 && cgg_aligned16(loc) && !generic_only &&
+      (long long)Nv * H * D < (1ll << 31) && total8 < (1ll << 31)) {
+    hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const float*)value,
+                       lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
+    CGG_CHECK_LAUNCH("cgg_msda_forward");
+    return CGG_OK;
+  }
   if (dtype == CGG_F32) {
     if (fused) { if (st) CGG_MSDA_LAUNCH(float, 3, 4, true); else CGG_MSDA_LAUNCH(float, 0, 0, true); }
     else       { if (st) CGG_MSDA_LAUNCH(float, 3, 4, false); else CGG_MSDA_LAUNCH(float, 0, 0, false); }
