@@ -72,6 +72,8 @@ PROTOTYPES = {
     'cgg_encoder_layer_tail_x3': (_c_int, [_c_vp] * 6 + [_c_f] + [_c_vp] * 6 + [_c_f, _c_vp, _c_int, _c_vp, _c_vp] +
                                   [_c_int] * 3 + [_c_vp]),
     'cgg_gemm_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 4 + [_c_vp]),
+    'cgg_stem_conv7x7_x3_nchw': (_c_int, [_c_vp] * 4 + [_c_int] * 3 + [_c_vp]),
+    'cgg_bias_relu_maxpool_nhwc_f32': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_gemm_x3_ex': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_int] +
                        [_c_int] * 4 + [_c_vp]),
     'cgg_conv_x3_nhwc': (_c_int, [_c_vp] * 5 + [_c_int] * 10 + [_c_vp]),

@@ -340,9 +340,17 @@ class ResNet(nn.Module):
         import torch.nn.functional as F
         seq = iter(self._folded_x3())
         w, b = next(seq)
-        # stem (3 input channels: not an implicit-GEMM shape): MIOpen f32 with the folded filter, then channel-last
-        x = F.conv2d(x.float(), w, b, stride=self.conv1.stride, padding=self.conv1.padding)
-        x = self.maxpool(torch.relu_(x)).permute(0, 2, 3, 1).contiguous()
+        mp, c1 = self.maxpool, self.conv1
+        if ((mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) and x.dtype == torch.float32
+                and x.is_contiguous() and tuple(c1.weight.shape) == (64, 3, 7, 7) and tuple(c1.stride) == (2, 2)
+                and tuple(c1.padding) == (3, 3) and tuple(c1.dilation) == (1, 1) and os.environ.get('CGG_X3_STEM', '1') != '0'):
+            # stem: the MFMA convolution straight from the f32 NCHW image on the f32-class contraction + (bias, ReLU, max-pool) pass
+            pk, sc = runtime.derived_cached('stem_packed_x3', (w,), lambda: ops.pack_stem_weight_x3(w))
+            x = ops.bias_relu_maxpool_nhwc_f32(ops.stem_conv7x7_x3(x, pk, sc), b)
+        else:
+            # (other stems: 3 input channels are not an implicit-GEMM shape) MIOpen f32 with the folded filter, then channel-last
+            x = F.conv2d(x.float(), w, b, stride=c1.stride, padding=c1.padding)
+            x = mp(torch.relu_(x)).permute(0, 2, 3, 1).contiguous()
 
         def conv(x, c, relu, res=None):
             wk, bias = next(seq)

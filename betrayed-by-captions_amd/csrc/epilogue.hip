@@ -116,6 +116,56 @@ __global__ __launch_bounds__(256) void cgg_bias_relu_maxpool_kernel(const uint4*
   y[i] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// parity mode's twin on f32 maps (the x3 stem's raw f32 output): 4 channels per thread
+__global__ __launch_bounds__(256) void cgg_bias_relu_maxpool_f32_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ bias,
+                                                                       f32x4* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                                       int c4, long long nvec) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // output vector: (b, oy, ox, c4)
+  if (i >= nvec) return;
+  const int c = (int)(i % c4);
+  long long p = i / c4;
+  const int ox = (int)(p % Wo);
+  p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int b = (int)(p / Ho);
+  const float ninf = -__builtin_inff();
+  f32x4 m = {ninf, ninf, ninf, ninf};
+  const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = y0 + dy;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = x0 + dx;
+      if (ix < 0 || ix >= W) continue;
+      const f32x4 v = x[(((size_t)b * H + iy) * W + ix) * c4 + c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+    }
+  }
+  const f32x4 bv = bias[c];
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = fmaxf(m[k] + bv[k], 0.f);
+  y[i] = o;
+}
+
+extern "C" int cgg_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y, int B, int H, int W, int C,
+                                              cgg_stream_t stream) {
+  CGG_REQUIRE(x && bias && y, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc_f32: null pointer");
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc_f32: bad sizes");
+  CGG_REQUIRE(C % 4 == 0, CGG_EUNSUPPORTED, "cgg_bias_relu_maxpool_nhwc_f32: C %% 4 != 0 (C=%d)", C);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(bias) && cgg_aligned16(y), CGG_EALIGN,
+              "cgg_bias_relu_maxpool_nhwc_f32: pointers must be 16-byte aligned");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long nvec = (long long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(cgg_bias_relu_maxpool_f32_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)x, (const f32x4*)bias, (f32x4*)y, H, W, Ho, Wo, C / 4, nvec);
+  CGG_CHECK_LAUNCH("cgg_bias_relu_maxpool_nhwc_f32");
+  return 0;
+}
+
 extern "C" int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,
                                           cgg_stream_t stream) {
   CGG_REQUIRE(x && bias && y, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc: null pointer");

@@ -1553,6 +1553,49 @@ def stem_conv7x7(img, packed):
     return y
 
 
+def pack_stem_weight_x3(w):
+    """w (64, 3, 7, 7) f32 (BN folded) -> (hi | lo f16 MFMA A fragments (uint8), un-scaling factors (64,) f32) for
+    `stem_conv7x7_x3`: rows scaled by a power of two so that max |w'| is in [2^10, 2^11) (csrc/x3.h)."""
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise CggError(f'pack_stem_weight_x3: expected (64, 3, 7, 7), got {tuple(w.shape)}')
+    wk = torch.zeros((64, 7, 8, 3), dtype=torch.float32, device=w.device)      # (cout, ky, kx padded to 8, c)
+    wk[:, :, :7, :] = w.detach().float().permute(0, 2, 3, 1)
+    wk = torch.cat([wk.reshape(64, 168), torch.zeros((64, 8), dtype=torch.float32, device=w.device)], 1)   # K = 176
+    amax = wk.abs().amax(1).clamp_min(1e-30)
+    e = torch.floor(torch.log2(amax)) + 1                                      # amax = f 2^e, f in [0.5, 1)
+    s = torch.pow(2.0, 11 - e)
+    ws = wk * s[:, None]
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    frag = lambda t: t.view(2, 32, 11, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(torch.uint8).reshape(-1)   # (mt, ks, hi, j, e)
+    packed = torch.cat([frag(hi), frag(lo)])
+    assert packed.numel() == 2 * _lib_().cgg_stem_conv7x7_packed_bytes()
+    return packed, (1.0 / (s * 16.0)).float().contiguous()
+
+
+def stem_conv7x7_x3(img, packed, wscale):
+    """img (B, 3, H, W) f32 NCHW -> raw 7x7 / stride-2 / padding-3 convolution (B, Ho, Wo, 64) F32 channel-last, f32-class."""
+    B, C, H, W = img.shape
+    if C != 3 or img.dtype != torch.float32 or not img.is_contiguous():
+        raise CggError('stem_conv7x7_x3: img must be a contiguous (B, 3, H, W) float32 tensor')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, 64), dtype=torch.float32, device=img.device)
+    check(_lib_().cgg_stem_conv7x7_x3_nchw(dev_ptr(img), dev_ptr(packed), dev_ptr(wscale, 'wscale', torch.float32), dev_ptr(y), B, H, W,
+                                           stream_ptr(img.device)), 'cgg_stem_conv7x7_x3_nchw')
+    return y
+
+
+def bias_relu_maxpool_nhwc_f32(x, bias):
+    """x (B, H, W, C) channel-last F32 raw convolution output -> relu(maxpool3x3/s2/p1(x) + bias) (B, Ho, Wo, C) f32."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    rc = _lib_().cgg_bias_relu_maxpool_nhwc_f32(dev_ptr(x, 'x', torch.float32), dev_ptr(bias, 'bias', torch.float32), dev_ptr(y),
+                                                B, H, W, C, stream_ptr(x.device))
+    check(rc, 'cgg_bias_relu_maxpool_nhwc_f32')
+    return y
+
+
 def linear_sum_assignment_batch(costs):
     """costs: list of 2-D float32 CPU tensors -> list of (rows, cols) int64 CPU tensors; every problem of a step in ONE
     call into the C++ solver (same indices as scipy.optimize.linear_sum_assignment, incl. ties)."""

@@ -422,6 +422,13 @@ int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, const void* wo
                               int pos_rows, float* y32, float* yp32, int M, int C, int F, cgg_stream_t stream);
 int cgg_gemm_x3(const float* a, int lda, const void* w_x3, const float* bias, const float* res, int ldr, float* out, int ldc,
                 int M, int N, int K, int relu, cgg_stream_t stream);
+/* Parity mode's ResNet stem: cgg_stem_conv7x7_nchw on the f32-class contraction -- w_packed = hi | lo f16 A fragments of the
+ * per-output-channel pre-scaled, BN-folded filter (2 x cgg_stem_conv7x7_packed_bytes() bytes), wscale[64] un-scales the
+ * accumulators; out = RAW convolution (B, Ho, Wo, 64) f32 channel-last -- and the f32 (bias, ReLU, 3x3 / s2 / p1 max-pool) pass
+ * over it (x (B, H, W, C) f32 -> y (B, Ho, Wo, C) f32, C % 4 == 0). Replace MIOpen's f32 stem + relu + max_pool + layout copy. */
+int cgg_stem_conv7x7_x3_nchw(const float* img, const void* w_packed, const float* wscale, float* out, int B, int H, int W,
+                             cgg_stream_t stream);
+int cgg_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y, int B, int H, int W, int C, cgg_stream_t stream);
 /* cgg_gemm_x3 with a row-periodic residual (res_mod > 0: row m adds res[m % res_mod], e.g. a per-token table shared by the
  * images of a batch) and a column split (out2 != NULL: columns >= col2, a multiple of 32, are stored to out2[m * ldc2 + n - col2]):
  * the MSDeformAttn layer's value_proj and sampling_offsets | attention_weights projections as ONE launch over the rows x --

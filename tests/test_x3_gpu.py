@@ -256,3 +256,24 @@ def test_gemm_x3_split_outputs_and_periodic_residual(dev):
     y1, y2 = ops.gemm_x3_split(x.to(dev), ops.pack_linear_weight_x3(w.to(dev)), N, col2, res_table=table.to(dev))
     assert y1.shape == (M, col2) and y2.shape == (M, N - col2)
     assert _err(y1, want[:, :col2]) <= 2e-5 and _err(y2, want[:, col2:]) <= 2e-5
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 128, 160), (1, 70, 91)])
+def test_stem_conv7x7_x3_and_f32_maxpool_vs_float64(dev, B, H, W):
+    """parity mode's ResNet stem (mmdet ResNet.conv1 + bn1 folded + relu + maxpool): the x3 MFMA convolution straight from the
+    f32 NCHW image + the f32 (bias, ReLU, max-pool) pass == float64 conv2d / relu / max_pool2d, incl. odd sizes (ragged tiles)."""
+    g = torch.Generator().manual_seed(77)
+    img = torch.randn(B, 3, H, W, generator=g) * 2
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    w[::5] *= 1e-2
+    b = torch.randn(64, generator=g)
+    F = torch.nn.functional
+    raw = F.conv2d(img.double(), w.double(), None, stride=2, padding=3)
+    want = F.max_pool2d(torch.relu(raw + b.double().view(1, -1, 1, 1)), 3, 2, 1)
+    f32_err = (F.conv2d(img, w, None, stride=2, padding=3).double() - raw).abs().max().item()
+    pk, sc = ops.pack_stem_weight_x3(w.to(dev))
+    y = ops.stem_conv7x7_x3(img.to(dev), pk, sc)
+    assert _err(y.permute(0, 3, 1, 2), raw) <= 4 * f32_err + 1e-6
+    z = ops.bias_relu_maxpool_nhwc_f32(y, b.to(dev))
+    assert tuple(z.shape) == (B, want.shape[2], want.shape[3], 64)
+    assert _err(z.permute(0, 3, 1, 2), want) <= 4 * f32_err + 1e-6
