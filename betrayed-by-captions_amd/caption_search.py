@@ -9,9 +9,13 @@ Same search as the reference, including its scoring quirks (they decide which se
   * finished sequences are scored weight / len**alpha; the running maximum is reset at every step (:123-124), so the
     winner is the best sequence finished in the last step (else the first finished one); the search stops after
     `beam_width` finished sequences or when no live sequence is shorter than max_len - 1.
-What differs is where it runs: embeddings, transformer, generator, log-softmax and top-k stay on the device and ONE
-small device->host copy per step (2 * beam_width numbers) drives the host bookkeeping; the reference moves the
-full (beams, vocab) log-probabilities to the host every step.
+What differs is where it runs and how much of it: embeddings, transformer, generator, log-softmax and top-k stay on the
+device and ONE small device->host copy per step (2 * beam_width numbers) drives the host bookkeeping (the reference moves
+the full (beams, vocab) log-probabilities to the host every step); and the decoder runs INCREMENTALLY -- only the newest
+position of every beam, against per-block key / value prefixes re-gathered by parent beam and cross-attention keys / values
+computed once per image (`CaptionTransformer.begin_decode / decode_step`) -- where the reference re-runs every whole
+sequence, the (beams, len, vocab) generator output included, at every step (:108-113). `kv_cache=False` keeps that
+full re-run (the tests hold the two against each other).
 """
 import torch
 
@@ -22,7 +26,7 @@ def _embed(head, ids):
 
 
 def beam_search(head, memory, BOS, EOS, max_len, beam_width=7, alpha=0.7, logging=False, tokenizer=None,
-                return_ids=False):
+                return_ids=False, kv_cache=True):
     """memory (1, Q, d) = the image's query embeddings. Returns the decoded sentence (reference behaviour) or, with
     `return_ids` / when no tokenizer is available offline, the best token-id sequence (BOS ... EOS)."""
     if memory.shape[0] != 1:
@@ -31,12 +35,17 @@ def beam_search(head, memory, BOS, EOS, max_len, beam_width=7, alpha=0.7, loggin
     gen = head.caption_generator
     with torch.no_grad():
         tgt = _embed(head, torch.tensor([[BOS]], device=dev))                   # (1, 1, d)
-        outs = gen(tgt=tgt, memory=memory)[0]
-        logits = torch.stack([gen.generator(o[0, 0, :]) for o in outs], 0).mean(0)
+        if kv_cache:
+            state = gen.begin_decode(memory)
+            outs = [o[0] for o in gen.decode_step(tgt, state)]
+        else:
+            outs = [o[0, 0, :] for o in gen(tgt=tgt, memory=memory)[0]]
+        logits = torch.stack([gen.generator(o) for o in outs], 0).mean(0)
         logp = torch.log_softmax(logits[None, :].float(), dim=1)[0]
         w, cand = torch.topk(logp, k=beam_width, largest=True)
         weights, cand = w.cpu(), cand.cpu().tolist()
         seqs = [[BOS, c] for c in cand]
+        parents = [0] * len(seqs)
         finished = []
         best_idx = 0
         keep = True
@@ -46,15 +55,18 @@ def beam_search(head, memory, BOS, EOS, max_len, beam_width=7, alpha=0.7, loggin
             best_score, best_idx = -100.0, 0
             ids = torch.tensor(seqs, dtype=torch.long, device=dev)             # (nb, len)
             nb, length = ids.shape
-            outs = gen(_embed(head, ids), memory.expand(nb, -1, -1).contiguous())[0]
-            logits = torch.stack([gen.generator(o[:, -1, :]) for o in outs], 0).mean(0)
+            if kv_cache:
+                outs = gen.decode_step(_embed(head, ids[:, -1:]), state, torch.tensor(parents, dtype=torch.long, device=dev))
+            else:
+                outs = [o[:, -1, :] for o in gen(_embed(head, ids), memory.expand(nb, -1, -1).contiguous())[0]]
+            logits = torch.stack([gen.generator(o) for o in outs], 0).mean(0)
             logp = torch.log_softmax(logits.float(), dim=1)                     # (nb, V)
             V = logp.shape[1]
             weighted = (logp + weights.to(dev)[:, None]) / length ** alpha
             w, pos = torch.topk(weighted.flatten(), k=min(beam_width, weighted.numel()), largest=True)
             w = (w * length ** alpha).cpu()                                     # de-normalised
             pos = pos.cpu().tolist()
-            new_w, new_seqs = [], []
+            new_w, new_seqs, parents = [], [], []
             for idx, p in enumerate(pos):
                 row, col = p // V, p % V
                 seq = seqs[row] + [col]
@@ -69,6 +81,7 @@ def beam_search(head, memory, BOS, EOS, max_len, beam_width=7, alpha=0.7, loggin
                 elif len(seq) < max_len - 1:
                     new_w.append(w[row])          # (sic) reference :141 indexes the new weights by the parent row
                     new_seqs.append(seq)
+                    parents.append(row)
             if not new_seqs:
                 keep = False
             else:

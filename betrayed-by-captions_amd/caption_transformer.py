@@ -272,6 +272,54 @@ class CaptionTransformer(nn.Module):
                                               memory_key_padding_mask)
         return output[-1].float()
 
+    # ---- incremental decoding (caption_search.beam_search): each step runs ONE new position per beam ----
+    def begin_decode(self, memory):
+        """State of an incremental decode over `memory` (1, Q, in): the cross-attention keys / values of every block
+        (computed once -- the reference recomputes them for every beam at every step, inference.py:108-113) and empty
+        per-block self-attention key / value prefixes."""
+        with runtime.autocast():
+            mem = self.adapter(memory)
+            cross = []
+            for blk in self.transformer_decoder.decoders:
+                c = blk.crx_layer
+                Q = mem.shape[1]
+                cross.append((c.to_key(mem).view(1, Q, c.nbr_heads, c.heads_dim),
+                              c.to_val(mem).view(1, Q, c.nbr_heads, c.heads_dim)))
+        n = len(self.transformer_decoder.decoders)
+        return dict(cross=cross, k=[None] * n, v=[None] * n, length=0)
+
+    def decode_step(self, tok, state, parents=None):
+        """One position for every live sequence: `tok` (nb, 1, in) = the embedded newest token of each, `parents` (nb,)
+        long = the row of the previous step each sequence continues (None: same rows). Causal attention makes position
+        t of every block a function of positions <= t only, so the cached prefix keys / values are exactly the ones a
+        full re-run of the sequence would compute. Returns the per-block outputs at the new position, each (nb, hidden)
+        -- `TransformerDecoder.forward(...)[i][:, -1]` of the whole sequences."""
+        nb = tok.shape[0]
+        with runtime.autocast():
+            x = tok + self.position_encoder.psne_layer[state['length']][None, None]
+            outs = []
+            for i, blk in enumerate(self.transformer_decoder.decoders):
+                n, m, c = blk.layer_normalz, blk.mha_layer, blk.crx_layer
+                H, d = m.nbr_heads, m.heads_dim
+                h = n['mha'][0](x)
+                qkv = m.qkv_layer(h).view(nb, 1, H, 3, d)
+                k, v = qkv[..., 1, :], qkv[..., 2, :]
+                if state['k'][i] is not None:
+                    pk, pv = state['k'][i], state['v'][i]
+                    if parents is not None:
+                        pk, pv = pk.index_select(0, parents), pv.index_select(0, parents)
+                    k, v = torch.cat([pk, k], 1), torch.cat([pv, v], 1)
+                state['k'][i], state['v'][i] = k, v
+                h = n['mha'][1](h + m.out_layer(_attend(qkv[..., 0, :], k, v, H)))
+                y = n['crx'][0](h)
+                ck, cv = state['cross'][i]
+                att = _attend(c.to_qry(y).view(nb, 1, H, d), ck.expand(nb, -1, -1, -1), cv.expand(nb, -1, -1, -1), H)
+                y = n['crx'][1](y + c.to_out(att))
+                x = n['ffn'][1](n['ffn'][0](y) + blk.ffn_layer(y))
+                outs.append(x[:, 0])
+            state['length'] += 1
+        return outs
+
     def generator_ce_rows(self, hidden, target, ignore_index=None):
         """`F.cross_entropy(generator(hidden), target, reduction='none', ignore_index=...)` for hidden (M, hidden) and
         target (M,) without materialising the (M, nb_tokens) logits (HIP row kernels + chunked library GEMMs)."""

@@ -289,9 +289,11 @@ extern "C" int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const vo
 // the transposed tile directly; the m16 image is staged with its ROWS interleaved between the two m-tiles (image row (mt, j)
 // = block row 4 (j / 2) + 2 mt + (j & 1)), so that after the same lane-pair swap a lane holds 4 consecutive pixels of one
 // channel: 8-byte stores, 128-byte runs along the pixel axis.
-template <int NT>
+// RAGGED: only pixels < `valid` of the block exist and a channel row (ldc = hw elements) is 4-byte aligned at best (hw even: 4-byte
+// stores of pixel pairs; hw odd: 2-byte stores)
+template <int NT, bool RAGGED = false>
 __device__ __forceinline__ void ep_store_tr(const f32x16 (&acc)[2][NT], uint16_t* __restrict__ vt, int tile0, long long ldc,
-                                            int pix0, int lane) {
+                                            int pix0, int lane, int valid = 64) {
   const int j = lane & 31, hi5 = lane >> 5, odd = j & 1;
   const uint32_t rot = 16u * (uint32_t)odd;
 #pragma unroll
@@ -308,24 +310,43 @@ __device__ __forceinline__ void ep_store_tr(const f32x16 (&acc)[2][NT], uint16_t
         pk[mt] = __builtin_amdgcn_alignbit(w, w, rot);
       }
       const int ch = 32 * (tile0 + t) + 2 * (rp & 1) + 8 * (rp >> 1) + 4 * hi5 + odd;
-      *reinterpret_cast<uint2*>(vt + (size_t)ch * ldc + pix0 + 4 * (j >> 1)) = make_uint2(pk[0], pk[1]);
+      uint16_t* o = vt + (size_t)ch * ldc + pix0 + 4 * (j >> 1);
+      if constexpr (!RAGGED) {
+        *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+      } else {
+        const int p = 4 * (j >> 1);
+        if (!(ldc & 1)) {                              // uniform: valid is even too (hw and the block origin are)
+          if (p < valid) *reinterpret_cast<uint32_t*>(o) = pk[0];
+          if (p + 2 < valid) *reinterpret_cast<uint32_t*>(o + 2) = pk[1];
+        } else {
+          if (p < valid) o[0] = (uint16_t)pk[0];
+          if (p + 1 < valid) o[1] = (uint16_t)(pk[0] >> 16);
+          if (p + 2 < valid) o[2] = (uint16_t)pk[1];
+          if (p + 3 < valid) o[3] = (uint16_t)(pk[1] >> 16);
+        }
+      }
     }
   }
 }
 
+// RAGGED (hw % 64 != 0: 1050 / 4200 / 16800 keys of the 800 x 1333 geometry): blocks are cut PER IMAGE (ceil(hw / 64) each), the last
+// block of an image re-reads its last row for the missing ones (finite operands) and masks their stores
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void cgg_decoder_kv_proj_kernel(
     const uint16_t* __restrict__ m16, const uint16_t* __restrict__ mp16, const ep_u32x4* __restrict__ wk,
     const float* __restrict__ bk, const ep_u32x4* __restrict__ wv, uint16_t* __restrict__ k, uint16_t* __restrict__ vt, int hw,
-    int NK) {
+    int NK, int blocks_per_image) {
   __shared__ __attribute__((aligned(16))) ep_u32x4 frag[2][2 * EP_STEPS * 64];      // m16 (row-interleaved) and mp16 images
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * EP_RB;                     // hw % 64 == 0: a block never straddles two images
+  const int img = blockIdx.x / blocks_per_image, pix0 = (blockIdx.x - img * blocks_per_image) * EP_RB;
+  const int m0 = img * hw + pix0;                        // a block never straddles two images
+  const int valid = RAGGED ? min(EP_RB, hw - pix0) : EP_RB;
   {
     ep_u32x4 v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int p = tid + 256 * i, which = p >> 11, row = (p >> 5) & 63, k8 = p & 31;
-      v[i] = *reinterpret_cast<const ep_u32x4*>((which ? mp16 : m16) + (size_t)(m0 + row) * EP_C + 8 * k8);
+      v[i] = *reinterpret_cast<const ep_u32x4*>((which ? mp16 : m16) + (size_t)(m0 + (RAGGED ? min(row, valid - 1) : row)) * EP_C + 8 * k8);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(256) void cgg_decoder_kv_proj_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
       ep_block<2>(acc, frag[1], frag[1] + EP_STEPS * 64, lane, wk + (size_t)tile0 * EP_STEPS * 64 + lane);
-      ep_store<2>(acc, bk, k, NK, 32 * tile0, m0, 0x7fffffff, lane);
+      ep_store<2>(acc, bk, k, NK, 32 * tile0, m0, m0 + valid, lane);
     }
     {
       f32x16 acc[2][2];
@@ -359,8 +380,7 @@ __global__ __launch_bounds__(256) void cgg_decoder_kv_proj_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
       ep_block<2, true>(acc, frag[0], frag[0] + EP_STEPS * 64, lane, wv + (size_t)tile0 * EP_STEPS * 64 + lane);
-      const int b = m0 / hw, pix0 = m0 - b * hw;
-      ep_store_tr<2>(acc, vt + (size_t)b * NK * hw, tile0, hw, pix0, lane);
+      ep_store_tr<2, RAGGED>(acc, vt + (size_t)img * NK * hw, tile0, hw, pix0, lane, valid);
     }
   }
 }
@@ -392,14 +412,20 @@ extern "C" int cgg_decoder_kv_proj_bf16(const void* m16, const void* mp16, const
   CGG_REQUIRE(m16 && mp16 && wk_packed && bk && wv_packed && k && vt, CGG_EINVAL, "cgg_decoder_kv_proj_bf16: null pointer");
   CGG_REQUIRE(C == EP_C && NK > 0 && NK % 256 == 0, CGG_EUNSUPPORTED, "cgg_decoder_kv_proj_bf16: C=%d NK=%d (C = 256, NK %% 256)", C,
               NK);
-  CGG_REQUIRE(B > 0 && hw > 0 && hw % 64 == 0, CGG_EUNSUPPORTED, "cgg_decoder_kv_proj_bf16: hw=%d must be a multiple of 64", hw);
+  CGG_REQUIRE(B > 0 && hw > 0, CGG_EINVAL, "cgg_decoder_kv_proj_bf16: B=%d hw=%d", B, hw);
   CGG_REQUIRE((long long)B * hw * NK < (1ll << 31), CGG_EUNSUPPORTED, "cgg_decoder_kv_proj_bf16: output too large for 32-bit offsets");
   CGG_REQUIRE(cgg_aligned16(m16) && cgg_aligned16(mp16) && cgg_aligned16(wk_packed) && cgg_aligned16(wv_packed) && cgg_aligned16(k) &&
                   cgg_aligned16(vt),
               CGG_EALIGN, "cgg_decoder_kv_proj_bf16: 16-B alignment");
-  hipLaunchKernelGGL(cgg_decoder_kv_proj_kernel, dim3(B * hw / EP_RB), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)m16,
-                     (const uint16_t*)mp16, (const ep_u32x4*)wk_packed, bk, (const ep_u32x4*)wv_packed, (uint16_t*)k, (uint16_t*)vt,
-                     hw, NK);
+  const int bpi = (hw + EP_RB - 1) / EP_RB;
+  if (hw % EP_RB == 0)
+    hipLaunchKernelGGL(cgg_decoder_kv_proj_kernel<false>, dim3(B * bpi), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)m16,
+                       (const uint16_t*)mp16, (const ep_u32x4*)wk_packed, bk, (const ep_u32x4*)wv_packed, (uint16_t*)k, (uint16_t*)vt,
+                       hw, NK, bpi);
+  else
+    hipLaunchKernelGGL(cgg_decoder_kv_proj_kernel<true>, dim3(B * bpi), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)m16,
+                       (const uint16_t*)mp16, (const ep_u32x4*)wk_packed, bk, (const ep_u32x4*)wv_packed, (uint16_t*)k, (uint16_t*)vt,
+                       hw, NK, bpi);
   CGG_CHECK_LAUNCH("cgg_decoder_kv_proj_bf16");
   return CGG_OK;
 }

@@ -586,7 +586,7 @@ class Mask2FormerHeadOpen(nn.Module):
             bk = runtime.derived_cached('kv_levels_bk', bs, lambda: torch.cat([b[E:2 * E] for b in bs], 0).to(torch.bfloat16).contiguous())
             wv = runtime.derived_cached('kv_levels_wv', ws, lambda: torch.cat([w[2 * E:] for w in ws], 0).to(torch.bfloat16).contiguous())
             m16, mp16 = kv16[l]
-            if FUSED_KV and E == 256 and m16.shape[1] % 64 == 0 and m16.is_contiguous() and mp16.is_contiguous():
+            if FUSED_KV and E == 256 and m16.is_contiguous() and mp16.is_contiguous():
                 # both projections of the level in ONE launch (k row-major, v transposed straight from the MFMA tiles)
                 wkp = runtime.derived_cached('kv_levels_wkp', ws, lambda: ops.pack_decoder_k_weight(torch.cat([w[E:2 * E] for w in ws], 0)))
                 wvp = runtime.derived_cached('kv_levels_wvp', ws, lambda: ops.pack_linear_weight(torch.cat([w[2 * E:] for w in ws], 0)))

@@ -470,7 +470,8 @@ int cgg_encoder_proj_bf16(const void* x16, const void* xp16, const void* pos16, 
 /* K / V projections of the query decoder for one memory level, all decoder layers that read the level stacked (NK = n * 256
  * outputs; open_set/models/mask2former_head.py:795-812 feeding the cross-attention in_proj of [3P] nn.MultiheadAttention):
  *   k  (B * hw, NK) bf16 = mp16 Wk^T + bk;     vt (B, NK, hw) bf16 = Wv m16^T   (value projection transposed, no bias)
- * m16 / mp16 (B * hw, 256) bf16 rows, hw % 64 == 0; wk packed by cgg_decoder_kv_pack_k, wv by cgg_linear_rows_pack (both
+ * m16 / mp16 (B * hw, 256) bf16 rows, any hw (hw % 64 != 0 -- the 1050 / 4200 / 16800 keys of an 800 x 1333 input -- cuts the blocks
+ * per image and masks the last one's stores: 4-byte vt stores for even hw, 2-byte for odd); wk packed by cgg_decoder_kv_pack_k, wv by cgg_linear_rows_pack (both
  * cgg_linear_rows_packed_bytes(NK, 256) bytes); bk f32. */
 int cgg_decoder_kv_pack_k(const float* w, void* packed, int N, int K, cgg_stream_t stream);
 int cgg_decoder_kv_proj_bf16(const void* m16, const void* mp16, const void* wk_packed, const float* bk, const void* wv_packed,

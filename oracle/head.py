@@ -519,6 +519,51 @@ def instance_postprocess_emb(emb, mask_pred, gt_embs, max_per_image=100):
     return lab, torch.cat([mask2bbox(binary), det[:, None]], dim=-1), binary, qi, sc
 
 
+def instance_postprocess(mask_cls, mask_pred, num_classes, num_things, max_per_image=100):
+    """maskformer_fusion_head.py:245-295 (closed-set variant on the classification logits, `use_class_emb=False`)."""
+    Q = mask_cls.shape[0]
+    scores = F.softmax(mask_cls, dim=-1)[:, :-1]
+    labels = torch.arange(num_classes).unsqueeze(0).repeat(Q, 1).flatten(0, 1)
+    sc, top = scores.flatten(0, 1).topk(max_per_image, sorted=False)
+    lab = labels[top]
+    mp = mask_pred[top // num_classes]
+    thing = lab < num_things
+    sc, lab, mp = sc[thing], lab[thing], mp[thing]
+    binary = (mp > 0).float()
+    ms = (mp.sigmoid() * binary).flatten(1).sum(1) / (binary.flatten(1).sum(1) + 1e-6)
+    binary = binary.bool()
+    return lab, torch.cat([mask2bbox(binary), (sc * ms)[:, None]], dim=-1), binary
+
+
+def panoptic_postprocess(mask_cls, mask_pred, num_classes, num_things, object_mask_thr=0.8, iou_thr=0.8, filter_low_score=False):
+    """maskformer_fusion_head.py:161-225 (stuff painted in query order, no area limit -- unlike the `_emb` variant)."""
+    scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
+    mask_pred = mask_pred.sigmoid()
+    keep = labels.ne(num_classes) & (scores > object_mask_thr)
+    cs, cc, cm = scores[keep], labels[keep], mask_pred[keep]
+    h, w = mask_pred.shape[-2:]
+    seg = torch.full((h, w), num_classes, dtype=torch.int32)
+    if cm.shape[0] > 0:
+        ids = (cs.view(-1, 1, 1) * cm).argmax(0)
+        inst = 1
+        for k in range(cc.shape[0]):
+            pc = int(cc[k].item())
+            mask = ids == k
+            area = mask.sum().item()
+            orig = (cm[k] >= 0.5).sum().item()
+            if filter_low_score:
+                mask = mask & (cm[k] >= 0.5)
+            if area > 0 and orig > 0:
+                if area / orig < iou_thr:
+                    continue
+                if pc >= num_things:
+                    seg[mask] = pc
+                else:
+                    seg[mask] = pc + inst * INSTANCE_OFFSET
+                    inst += 1
+    return seg
+
+
 def panoptic_postprocess_emb(emb, mask_pred, gt_embs, num_classes, num_things, object_mask_thr=0.8,
                              iou_thr=0.8, filter_low_score=False, stuff_area_limit=4096, debug=None):
     """:77-159. `debug` (a dict, tests only) receives the decision margins: per-pixel top1 - top2 probability, the

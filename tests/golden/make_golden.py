@@ -395,6 +395,41 @@ def main():
     npz('g7_postprocess.npz', labels=lab, bboxes=box, masks=msk, labels_novel=labn, bboxes_novel=boxn, masks_novel=mskn,
         pan_seg=pan)
 
+    # ---- G10: the no-class-embedding family (configs/instance/coco_ag_pretrain_3x.py:97-133): the head with
+    #      use_class_emb=False / pred_emb_norm=True (forward, targets with cls_cost 2.0, loss_cls with weight 2.0 and
+    #      class_weight) and the closed-set post-processing of the fusion head (maskformer_fusion_head.py:161-295) ----
+    from util import ag_cfg, g10_inputs
+    cfgA = ag_cfg(num_queries=8, vocab=120)
+    hcA = OM.attrify(head_cfg(cfgA))
+    ref_ag = m2f.Mask2FormerHeadOpen(**hcA).eval()
+    randomize(ref_ag, seed=3)
+    with torch.no_grad():
+        cls_a, emb_a, mask_a = ref_ag.forward(feats, metas)
+    ref_ag.train()
+    torch.manual_seed(4321)
+    with RandCapture() as rca:
+        li = 1
+        losses_a = ref_ag.loss_single(cls_a[li], emb_a[li], mask_a[li], gt_labels, gt_masks, None, None, None, None, None, None,
+                                      metas)
+    with RandCapture() as rca2:
+        torch.manual_seed(98)
+        tgt_a = ref_ag._get_target_single(cls_a[li][1], None, mask_a[li][1], gt_labels[1], gt_masks[1], metas)
+    fa = dict(cfgA['panoptic_fusion_head'])
+    fa.pop('type')
+    fha = fus.MaskFormerFusionHeadOpen(test_cfg=dict(cfgA['test_cfg'], max_per_image=15), **fa)
+    mcls, mpred = g10_inputs()
+    with torch.no_grad():
+        labc, boxc, mskc = fha.instance_postprocess(mcls[:, :fha.num_classes + 1], mpred)
+    pha = fus.MaskFormerFusionHeadOpen(num_things_classes=8, num_stuff_classes=4, panoptic_mode=True,
+                                       test_cfg=dict(object_mask_thr=0.3, iou_thr=0.5, filter_low_score=True))
+    with torch.no_grad():
+        panc = pha.panoptic_postprocess(mcls, mpred)
+    npz('g10_no_class_emb.npz', seed=3, layer=li, cls=torch.stack(cls_a), emb=torch.stack(emb_a), mask=torch.stack(mask_a),
+        losses=torch.stack([x.detach().reshape(()) for x in losses_a]), n_draws=len(rca.draws),
+        **{f'draw{i}': d for i, d in enumerate(rca.draws)}, t_points=rca2.draws[0], t_labels=tgt_a[0], t_mask_weights=tgt_a[3],
+        t_pos=tgt_a[4], t_neg=tgt_a[5], ins_labels=labc, ins_bboxes=boxc, ins_masks=mskc, pan_seg=panc,
+        ins_num_classes=fha.num_classes)
+
     g8_beam_search()
 
 

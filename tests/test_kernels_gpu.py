@@ -1299,7 +1299,8 @@ def test_encoder_proj_forms_x_plus_pos_in_kernel(dev):
     assert torch.equal(v_a, v_b) and torch.equal(o_a, o_b)
 
 
-@pytest.mark.parametrize('B,hw,n', [(2, 16384, 3), (2, 1024, 3), (1, 64, 1), (3, 4096, 2)])
+@pytest.mark.parametrize('B,hw,n', [(2, 16384, 3), (2, 1024, 3), (1, 64, 1), (3, 4096, 2),
+                                    (2, 1050, 3), (1, 4200, 3), (1, 16800, 3), (3, 1085, 2), (2, 37, 1)])   # ragged: configs[4] levels, odd hw
 def test_decoder_kv_proj_fused_vs_float64(dev, B, hw, n):
     """Decoder K / V projections of one memory level in one launch: k = mp16 Wk^T + bk (row-major) and vt = Wv m16^T
     (transposed, straight from the swapped-operand MFMA tiles) against float64 on the same bf16-rounded operands: half a bf16

@@ -232,6 +232,89 @@ def test_g7_postprocess_oracle_matches_reference(oracle_head):
     assert len(torch.unique(pan)) > 2
 
 
+def test_caption_decode_step_equals_full_forward():
+    """`CaptionTransformer.decode_step` (one new position against cached key / value prefixes, beams re-gathered by parent)
+    == the last position of the full causal forward of the same sequences (transformers.py:187-267)."""
+    from cgg_amd import registry
+    torch.manual_seed(5)
+    gen = registry.build_head(dict(type='CaptionTransformer', nb_layers=3, input_dim=48, hidden_dim=48, ff_dim=96, nb_heads=4,
+                                   drop_val=0.1, pre_norm=False, seq_length=12, nb_tokens=50)).eval()
+    mem = torch.randn(1, 9, 48)
+    toks = torch.randn(5, 6, 48)                       # 5 beams, 6 embedded positions
+    parents = [None, torch.tensor([0, 0, 0, 0, 0]), torch.tensor([0, 1, 2, 3, 4]), torch.tensor([4, 3, 3, 0, 1]),
+               torch.tensor([2, 2, 1, 0, 4]), torch.tensor([1, 0, 4, 4, 3])]
+    with torch.no_grad():
+        state = gen.begin_decode(mem)
+        seqs = toks[:1, :1]                              # the sequences as a full re-run would see them
+        for t in range(6):
+            if t == 0:
+                new = toks[:1, :1]
+            else:
+                new = toks[:, t:t + 1]
+                seqs = torch.cat([seqs.index_select(0, parents[t]) if seqs.shape[0] > 1 else seqs.expand(5, -1, -1), new], 1)
+            outs = gen.decode_step(new, state, parents[t])
+            full = gen(seqs, mem.expand(seqs.shape[0], -1, -1))[0]
+            for a, b in zip(outs, full):
+                assert (a - b[:, -1]).abs().max().item() <= 2e-5, t
+    assert state['length'] == 6 and state['k'][0].shape[:2] == (5, 6)
+
+
+# ---- G10: the no-class-embedding family (coco_ag_pretrain_3x.py:97-133) ------------------------------------------------
+def test_g10_no_class_emb_head_targets_losses_and_closed_set_postprocess():
+    """`use_class_emb=False, pred_emb_norm=True`, `loss_cls` weight 2.0, assigner `cls_cost` 2.0: oracle AND product host logic
+    against the reference's own head / fusion head run by path (forward of all layers, loss_single with the captured points,
+    one image's target indices bit exact, `instance_postprocess` / `panoptic_postprocess` of maskformer_fusion_head.py:161-295)."""
+    from util import ag_cfg, g10_inputs
+    z = gold('g10_no_class_emb.npz')
+    cfg = ag_cfg(num_queries=8, vocab=120)
+    _, B, H, W, feats, metas, _, _ = g4_inputs()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        orc = OH.OracleHead(**head_cfg(cfg)).eval()
+        ph = registry.build_head(head_cfg(cfg))
+    randomize(orc, seed=3)
+    randomize(ph, seed=3)
+    with torch.no_grad():
+        c, e, m = orc.forward(feats, metas)
+    assert (torch.stack(c) - z['cls']).abs().max().item() <= 1e-5 and (torch.stack(m) - z['mask']).abs().max().item() <= 1e-4
+    assert (torch.stack(e) - z['emb']).abs().max().item() <= 1e-5
+    li = int(z['layer'])
+    cls, emb, mask = z['cls'][li], z['emb'][li], z['mask'][li]
+    gt_labels, gt_masks = g6_inputs(H, W)[:2]
+    draws = [z[f'draw{i}'] for i in range(int(z['n_draws']))]
+    want = z['losses']
+    assert float(want[0]) > 0 and float(want[1]) == 0          # loss_cls is live, loss_cls_emb off
+    orc.train()
+    orc.point_hook = Replay(draws)
+    with torch.no_grad():
+        got = orc.loss_single(cls, emb, mask, gt_labels, gt_masks, None, None, None, None, None)
+    got = torch.stack([g.reshape(()) for g in got])
+    assert (got - want).abs().max().item() <= 1e-5 * (1 + want.abs().max().item()), (got, want)
+    orc.point_hook = Replay([z['t_points']])
+    t = orc.get_target_single(cls[1], None, mask[1], gt_labels[1], gt_masks[1])
+    assert torch.equal(t[0], z['t_labels']) and torch.equal(t[4], z['t_pos']) and torch.equal(t[5], z['t_neg'])
+    # product host logic
+    ph.train()
+    ph.point_hook = Replay(draws)
+    with torch.no_grad():
+        pl = ph.loss_single(cls, emb, mask, gt_labels, gt_masks, None, None, None, None, None, None, metas)
+    pl = torch.stack([g.reshape(()) for g in pl])
+    assert (pl - want).abs().max().item() <= 2e-5 * (1 + want.abs().max().item()), (pl, want)
+    ph.point_hook = Replay([z['t_points']])
+    pt = ph._get_target_single(cls[1], None, mask[1], gt_labels[1], gt_masks[1], metas)
+    assert torch.equal(pt[0], z['t_labels']) and torch.equal(pt[4], z['t_pos']) and torch.equal(pt[5], z['t_neg'])
+    # closed-set post-processing (oracle restatement vs the reference)
+    mcls, mpred = g10_inputs()
+    nc = int(z['ins_num_classes'])
+    lab, box, msk = OH.instance_postprocess(mcls[:, :nc + 1], mpred, nc, nc, 15)
+    o1 = torch.argsort(box[:, 4] * 1e3 + lab, stable=True)
+    o2 = torch.argsort(z['ins_bboxes'][:, 4] * 1e3 + z['ins_labels'], stable=True)
+    assert torch.equal(lab[o1], z['ins_labels'][o2]) and torch.allclose(box[o1], z['ins_bboxes'][o2], atol=1e-6)
+    assert torch.equal(msk[o1], z['ins_masks'][o2].bool())
+    pan = OH.panoptic_postprocess(mcls, mpred, 12, 8, 0.3, 0.5, True)
+    assert torch.equal(pan, z['pan_seg'].to(torch.int32)) and len(torch.unique(pan)) > 2
+
+
 # ---- G8 -------------------------------------------------------------------------------------------------
 class _StubTokenizer:
     def decode(self, ids):
@@ -258,6 +341,8 @@ def test_g8_beam_search_matches_reference():
         got = beam_search(head, z[f'mem{case}'], 1, 2, max_len=max_len, beam_width=beam, tokenizer=_StubTokenizer())
         assert got == str(z[f'sentence{case}']), (case, got, str(z[f'sentence{case}']))
         ids = beam_search(head, z[f'mem{case}'], 1, 2, max_len=max_len, beam_width=beam, return_ids=True)
+        # the incremental (key / value prefix) decode is the default; the full re-run of every sequence is the reference's shape
+        assert ids == beam_search(head, z[f'mem{case}'], 1, 2, max_len=max_len, beam_width=beam, return_ids=True, kv_cache=False)
         assert ids[0] == 1 and ids[-1] == 2 and ' '.join(map(str, ids))[1:-1] == got
 
 

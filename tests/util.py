@@ -17,6 +17,37 @@ def small_cfg(**kw):
     return synthetic.model_config(**d)
 
 
+def ag_cfg(**kw):
+    """The no-class-embedding / class-agnostic family the reference ships (configs/instance/coco_ag_pretrain_3x.py:97-133, 144-161):
+    `use_class_emb=False, pred_emb_norm=True, class_agnostic=True`, no caption heads, `loss_cls` weight 2.0 (class_weight on), the
+    assigner's `cls_cost` 2.0 / `cls_emb_cost` 0.0, closed-set fusion head (`ins_results`)."""
+    cfg = small_cfg(use_caption=False, use_caption_generation=False, num_unknown=0, **kw)   # :5-9: one known class list, nothing held out
+    h = cfg['panoptic_head']
+    h.update(use_class_emb=False, class_agnostic=True, pred_emb_norm=True, text_emb_norm=False)
+    h['loss_cls']['loss_weight'] = 2.0
+    h['loss_cls_emb']['loss_weight'] = 0.0
+    cfg['train_cfg']['assigner']['cls_cost']['weight'] = 2.0
+    cfg['train_cfg']['assigner']['cls_emb_cost']['weight'] = 0.0
+    cfg['panoptic_fusion_head']['use_class_emb'] = False
+    cfg['test_cfg'].update(eval_types=['ins_results'], use_class_emb=False)
+    return cfg
+
+
+def g10_inputs():
+    """classification logits / blob-shaped mask logits of the G10 closed-set post-processing fixtures."""
+    g = torch.Generator().manual_seed(110)
+    Q, hh, ww, K = 10, 32, 48, 12
+    cls = torch.randn(Q, K + 1, generator=g) * 3
+    ys = torch.arange(hh).view(hh, 1).float()
+    xs = torch.arange(ww).view(1, ww).float()
+    mp = torch.empty(Q, hh, ww)
+    for q in range(Q):
+        cy, cx = float(torch.rand(1, generator=g)) * hh, float(torch.rand(1, generator=g)) * ww
+        r = 4 + float(torch.rand(1, generator=g)) * 10
+        mp[q] = (r * r - ((ys - cy)**2 + (xs - cx)**2)) / 8 + 0.3 * torch.randn(hh, ww, generator=g)
+    return cls, mp
+
+
 def head_cfg(cfg):
     hc = copy.deepcopy(cfg['panoptic_head'])
     hc.update(train_cfg=cfg['train_cfg'], test_cfg=cfg['test_cfg'])
