@@ -435,9 +435,11 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
         ms = sum(ms) / len(ms)
         N = sum((H // s) * (W // s) for s in (8, 16, 32))
         mbytes = B * N * (256 + 288 + 256) * 4
-        out['msda'] = dict(kernel='cgg_msda_fwd_kernel<float> (f32 values / offsets / output)', bound='hbm', launch_ms=ms,
+        pr = prof.get('cgg_msda_fwd_stream2_f32_kernel', {})
+        out['msda'] = dict(kernel='cgg_msda_fwd_stream2_f32_kernel (f32 values / offsets / output)', bound='hbm', launch_ms=ms,
                            algorithmic_bytes=mbytes, achieved_GBs=mbytes / (ms * 1e-3) / 1e9,
-                           frac_hbm_peak=mbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                           frac_hbm_peak=mbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=pr.get('traffic_bytes'),
+                           traffic_source=pr.get('source'), rocprof=pr.get('rocprof'))
     return out
 
 

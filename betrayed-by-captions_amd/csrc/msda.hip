@@ -419,11 +419,14 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ rows, const float* __restrict__ ref,
     int ld, float* __restrict__ out, int Nv, int Nq, unsigned total) {
   constexpr int D = 32, CPL = 8, H = 8, L = 3, LP = 12;
-  const unsigned gid = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
-  if (gid >= total) return;               // total is a multiple of 4: quads are never split
-  const int cq = (int)(gid & 3u);
-  const int h = (int)((gid >> 2) & 7u);
-  const unsigned bq = gid >> 5;
+  // a wavefront = 16 consecutive queries of ONE head: in f32 a head's slice of a pixel is one 128-byte line, so the x-neighbour
+  // taps of neighbouring queries are the SAME lines (the (x + 1) corner of query i is the x corner of query i + 1) and meet in
+  // L1; a block = 4 heads of a 16-query group, two blocks per group (the geometry of the head-major bf16 kernel): 127 -> 121 us
+  const unsigned blk = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x), t = threadIdx.x;
+  const int cq = (int)(t & 3u);
+  const int h = (int)((blk & 1u) * 4u + (t >> 6));
+  const unsigned bq = (blk >> 1) * 16u + ((t >> 2) & 15u);
+  if (bq >= total / 32u) return;          // whole quads
   const unsigned b = bq / (unsigned)Nq;
   const int q = (int)(bq - b * (unsigned)Nq);
   constexpr int rowstride = H * D;
@@ -923,7 +926,7 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
   const long long total8 = (long long)B * Nq * H * (D / 8);
   if (dtype == CGG_F32 && fused && st && H == 8 && D == 32 && ld % 4 == 0 && cgg_aligned16(loc) && !generic_only &&
       (long long)Nv * H * D < (1ll << 31) && total8 < (1ll << 31)) {
-    hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const float*)value,
+    hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s, (const float*)value,
                        lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
     CGG_CHECK_LAUNCH("cgg_msda_forward");
     return CGG_OK;

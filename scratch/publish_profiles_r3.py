@@ -12,7 +12,7 @@ pairs = {'kernel_stats.csv': 'r3_fp32_bench_kernel_stats.csv', 'hot_kernel_launc
 for a, b in pairs.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
-FAM = ('cgg_gemm_x3_kernel', 'cgg_encoder_tail_x3_kernel', 'cgg_mask_logits_kernel', 'cgg_msda_fwd_kernel')
+FAM = ('cgg_gemm_x3_kernel', 'cgg_encoder_tail_x3_kernel', 'cgg_mask_logits_kernel', 'cgg_msda_fwd_stream2_f32_kernel')
 
 
 def per_kernel(path, counter):

@@ -6,7 +6,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    for key in ('cgg_gemm_x3_kernel', 'cgg_encoder_tail_x3_kernel', 'cgg_mask_logits_kernel', 'cgg_msda_fwd_kernel', 'cgg_decoder_mid_kernel',
+    for key in ('cgg_gemm_x3_kernel', 'cgg_encoder_tail_x3_kernel', 'cgg_mask_logits_kernel', 'cgg_msda_fwd_stream2_f32_kernel', 'cgg_decoder_mid_kernel',
                 'cgg_decoder_tail_kernel', 'cgg_decoder_ffn_kernel', 'cgg_xattn_partial_f32'):
         if key in n:
             inst = n[n.index(key):].split('(')[0]
