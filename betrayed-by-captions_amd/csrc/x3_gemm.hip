@@ -246,6 +246,31 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
     for (int mt = 0; mt < TM; ++mt) {
       const int mrow = m0 + 32 * (TM * wm + mt) + 4 * hi5;
       float* orow = obase + (size_t)mrow * ldo;
+      if (full && (res_mod == 0 || res_mod >= 32)) {
+        // interior tile (workgroup-uniform): no per-element predicate, so the 16 residual loads of the tile are all in flight
+        // before the first use -- under the predicate below the compiler emits load / s_waitcnt vmcnt(0) / store per element,
+        // 16 serial memory latencies per tile (the ResNet output convolutions ran at 2.3 TB/s because of it)
+        float rv[16];
+        if (res) {
+          // res_mod: the residual rows repeat (per-token table); one modulo per tile, the 28 rows after it wrap by subtraction
+          const int mr0 = res_mod > 0 ? mrow % res_mod : mrow;
+          const int wrap = res_mod > 0 ? res_mod : 0x7fffffff;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int mr = mr0 + (r & 3) + 8 * (r >> 2);
+            mr = mr >= wrap ? mr - wrap : mr;
+            rv[r] = res[(size_t)mr * ldr + n];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[mt][nt][r] * cs + bs;
+          if (res) v += rv[r];
+          if (relu) v = fmaxf(v, 0.f);
+          orow[(size_t)((r & 3) + 8 * (r >> 2)) * ldo] = v;
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);
