@@ -157,9 +157,11 @@ __global__ __launch_bounds__(512) void cgg_decoder_tail_kernel(
       const int m = m0 + 4 * wave + rr;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        ld4[rr][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < M && p < nsum)
-          ld4[rr][p] = *reinterpret_cast<const f32x4*>(planes + (size_t)p * plane_stride + (size_t)m * ld + 4 * lane);
+        // clamped (row M - 1 / plane nsum - 1: lines this wave reads anyway), zeroed after: predicated loads compile to
+        // branch / load / s_waitcnt vmcnt(0) chains, one memory latency per row at the head of the kernel
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(planes + (size_t)(p < nsum ? p : nsum - 1) * plane_stride +
+                                                         (size_t)(m < M ? m : M - 1) * ld + 4 * lane);
+        ld4[rr][p] = (m < M && p < nsum) ? pv : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(512) void cgg_decoder_mid_kernel(
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int m = m0 + 4 * wave + rr;
-    cr[rr] = m < M ? *reinterpret_cast<const f32x4*>(core + (size_t)m * ldc + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // clamped, not predicated: a predicated load compiles to branch / load / s_waitcnt vmcnt(0) per row (four serial latencies)
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(core + (size_t)(m < M ? m : M - 1) * ldc + 4 * lane);
+    cr[rr] = m < M ? cv : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   u32x4 bf[DT_STEPS], bl[X3 ? DT_STEPS : 1];
   dt_load_b<X3>(bf, bl, wo, wave, lane);
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(512) void cgg_decoder_mid_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-    rv[r] = m < M ? res[(size_t)m * ldr + n] : 0.f;
+    const float rvv = res[(size_t)(m < M ? m : M - 1) * ldr + n];
+    rv[r] = m < M ? rvv : 0.f;
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) dt_store4<X3>(F0, fslot + (4 * wave + rr) * 8, cr[rr]);
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(512) void cgg_decoder_ffn_kernel(const float* __res
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int m = m0 + 4 * wave + rr;
-    xr[rr] = m < M ? *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)(m < M ? m : M - 1) * ldx + 4 * lane);   // clamped, see the mid kernel
+    xr[rr] = m < M ? xv : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   u32x4 bf[DT_STEPS], bl[X3 ? DT_STEPS : 1];
   dt_load_b<X3>(bf, bl, w1, cb * 8 + wave, lane);             // W1 rows 256 cb + 32 wave .. (K = 256: 16 k-steps)

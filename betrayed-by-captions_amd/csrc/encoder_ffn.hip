@@ -141,12 +141,22 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
   //      32 (k8 & 1)) ^ k-step). The XOR spreads the 32 pieces of a row (one coalesced 512-byte read) over all 16 four-bank
   //      groups -- unswizzled, every 128-bit store was a 32-way bank conflict.
   const uint16_t* rows_in = PRO ? pro.a16 : x16;
-#pragma unroll 4
-  for (int p = tid; p < EF_RB * 32; p += EF_NT) {
-    const int row = p >> 5, k8 = p & 31;
-    ef_u32x4 v = {0u, 0u, 0u, 0u};
-    if (m0 + row < M) v = *reinterpret_cast<const ef_u32x4*>(rows_in + (size_t)(m0 + row) * EF_C + 8 * k8);
-    xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v;
+  // branch-free (rows past M re-read row M - 1; nothing of theirs is ever stored): under an `if (row < M)` the compiler emits
+  // load / s_waitcnt vmcnt(0) / ds_write per piece -- one serial memory latency per iteration at the head of every workgroup
+  {
+    constexpr int NP = EF_RB * 32 / EF_NT;
+    ef_u32x4 v[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * EF_NT, row = p >> 5, k8 = p & 31;
+      const int mr = m0 + row < M ? m0 + row : M - 1;
+      v[i] = *reinterpret_cast<const ef_u32x4*>(rows_in + (size_t)mr * EF_C + 8 * k8);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * EF_NT, row = p >> 5, k8 = p & 31;
+      xfrag[((row >> 5) * EF_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1))] = v[i];
+    }
   }
   if constexpr (PRO) {
     // the layer-input rows LayerNorm 0 adds (its residual) are requested now: they arrive behind the output projection's MFMAs

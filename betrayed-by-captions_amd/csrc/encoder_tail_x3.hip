@@ -137,17 +137,29 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   }
   // ---- attention rows -> split A-fragment images: 32-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k-step = k8 / 2,
   //      (row % 32 + 32 (k8 & 1)) ^ k-step): the XOR spreads a row's pieces over all bank groups ----
-#pragma unroll 4
-  for (int p = tid; p < E3_RB * 32; p += E3_NT) {
-    const int row = p >> 5, k8 = p & 31;
-    const int mc = m0 + row < M ? m0 + row : M - 1;
-    const float* src = a32 + (size_t)mc * E3_C + 8 * k8;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-    e3_u32x4 h, l;
-    cgg_x3_split8(v0, v1, h, l);
-    const int slot = ((row >> 5) * E3_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1));
-    xfrag[slot] = h;
-    xfrag[E3_IMG + slot] = l;
+  //      All 16 loads of a thread are issued before the first split: the rolled loop the compiler made of the one-piece-at-a-time
+  //      form waited for every pair of loads (8 serial memory latencies at the head of every workgroup).
+  {
+    constexpr int NP = E3_RB * 32 / E3_NT;
+    f32x4 v0[NP], v1[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * E3_NT, row = p >> 5, k8 = p & 31;
+      const int mc = m0 + row < M ? m0 + row : M - 1;
+      const float* src = a32 + (size_t)mc * E3_C + 8 * k8;
+      v0[i] = *reinterpret_cast<const f32x4*>(src);
+      v1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * E3_NT, row = p >> 5, k8 = p & 31;
+      e3_u32x4 h, l;
+      cgg_x3_split8(v0[i], v1[i], h, l);
+      const int slot = ((row >> 5) * E3_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1));
+      xfrag[slot] = h;
+      xfrag[E3_IMG + slot] = l;
+    }
   }
   // the layer-input rows LayerNorm 0 adds (its residual) are requested now: they arrive behind the output projection's MFMAs
   const int sub = lane & 15, rsub = lane >> 4;

@@ -73,24 +73,35 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
 
   const float* kvb = kv + (size_t)b * S * (2 * HD) + h * D;
-  for (int s0 = s_begin; s0 < s_end; s0 += XA_TK) {
-    __syncthreads();  // previous tile fully consumed (also orders the Ms fill on first trip)
-    // ---- stage K, V tile: 64 keys x 128 B each; thread = 16-B chunk (2 per operand) ----
+  // K / V tile: 64 keys x 128 B each; thread = 16-B chunk (2 per operand). The loads of tile t + 1 are issued BEFORE the MFMAs of
+  // tile t and held in registers (branch-free: keys past the chunk re-read its last key and are zeroed): the memory latency of a
+  // tile -- paid in full, twice, by the predicated load -> LDS loop this replaces -- hides under ~4 000 cycles of f32 MFMAs
+  f32x4 kx[2], vx[2];
+  auto load_tile = [&](int s0) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int c = tid + 256 * it;
       const int key = c >> 3, slot = c & 7;
-      const int s = s0 + key;
-      f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-      if (s < s_end) {
-        const float* row = kvb + (size_t)s * (2 * HD) + slot * 4;
-        kx = *reinterpret_cast<const f32x4*>(row);
-        vx = *reinterpret_cast<const f32x4*>(row + HD);
-      }
-      *reinterpret_cast<f32x4*>(Ks + key * D + xa_kswz(key, slot) * 4) = kx;
-      *reinterpret_cast<f32x4*>(Vs + key * D + slot * 4) = vx;
+      const int s = min(s0 + key, s_end - 1);
+      const float* row = kvb + (size_t)s * (2 * HD) + slot * 4;
+      kx[it] = *reinterpret_cast<const f32x4*>(row);
+      vx[it] = *reinterpret_cast<const f32x4*>(row + HD);
+    }
+  };
+  load_tile(s_begin);
+  for (int s0 = s_begin; s0 < s_end; s0 += XA_TK) {
+    __syncthreads();  // previous tile fully consumed (also orders the Ms fill on first trip)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + 256 * it;
+      const int key = c >> 3, slot = c & 7;
+      const bool live = s0 + key < s_end;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Ks + key * D + xa_kswz(key, slot) * 4) = live ? kx[it] : z;
+      *reinterpret_cast<f32x4*>(Vs + key * D + slot * 4) = live ? vx[it] : z;
     }
     __syncthreads();
+    if (s0 + XA_TK < s_end) load_tile(s0 + XA_TK);       // workgroup-uniform
     if (!wave_live) continue;
 
 #pragma unroll
