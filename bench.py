@@ -474,6 +474,22 @@ def einsum_q_sweep(dev, B, H, W):
             res.append(dict(queries=Q, mode=mode, launch_ms=ms, tflops=tf, frac_mfma_peak=tf / peak, mfma_peak_tf=peak,
                             frac_hbm_roofline_attainable=tf / min(peak, ai * HBM_PEAK_GBS / 1e3), GBs=by / (ms * 1e-3) / 1e9,
                             frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, launches_q_split=2 if (split and Q > 128) else 1))
+    # what this device's memory system delivers to a pure read + write stream of the same size class (torch device copy, 128 MiB
+    # in + 128 MiB out): the practical ceiling the `GBs` figures above sit under (the 8 TB/s of `frac_hbm_peak` is the pin rate)
+    src = torch.empty(32 << 20, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        dst.copy_(src)
+    e.record()
+    torch.cuda.synchronize()
+    cms = s.elapsed_time(e) / 20
+    res.append(dict(reference='device-to-device copy, 128 MiB read + 128 MiB written per launch', launch_ms=cms,
+                    GBs=2 * src.numel() * 4 / (cms * 1e-3) / 1e9, frac_hbm_peak=2 * src.numel() * 4 / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS))
     return res
 
 

@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void cgg_pack_nhwc_f32_x3_kernel(const float* 
 template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
     const float* __restrict__ embed, const u32x4* __restrict__ fhi, const u32x4* __restrict__ flo,
-    float* __restrict__ out, uint32_t* __restrict__ bits, int Q, int npix, int T, int MT) {
+    float* __restrict__ out, uint32_t* __restrict__ bits, int Q, int npix, int T, int MT, int q_total, int q0) {
+  // Q rows q0 .. q0 + Q - 1 of tensors with q_total rows per image (a row group of a larger query set: split mode keeps <= 4
+  // query tiles in LDS, the C entry walks the groups -- the outputs land in place, nothing is concatenated afterwards)
   constexpr int KS = 16;  // C = 256
   constexpr int C = KS * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
   const int hi5 = lane >> 5;
   const int col = lane & 31;
   const int tstride = gridDim.x * 8;
-  float* __restrict__ ob = out ? out + (size_t)b * Q * npix : nullptr;       // uniform
-  uint32_t* __restrict__ bb = bits ? bits + (size_t)b * Q * T : nullptr;     // uniform
+  float* __restrict__ ob = out ? out + ((size_t)b * q_total + q0) * npix : nullptr;       // uniform
+  uint32_t* __restrict__ bb = bits ? bits + ((size_t)b * q_total + q0) * T : nullptr;     // uniform
   const u32x4* __restrict__ fhb = fhi + (size_t)b * T * (KS * 64) + lane;
   const u32x4* __restrict__ flb = SPLIT ? flo + (size_t)b * T * (KS * 64) + lane : nullptr;
   int t = blockIdx.x * 8 + wave;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
   // thread owns float4 number tid, tid+512, ... of the contiguous [Q, 256] block (coalesced); float4 (q, c4)
   // lands in slot (mt = q/32, ks = c4/4, lane = q%32 + 32*((c4/2)&1)), half (c4 & 1). Rows >= Q are zero.
   {
-    const f32x4* __restrict__ eb4 = reinterpret_cast<const f32x4*>(embed + (size_t)b * Q * C);
+    const f32x4* __restrict__ eb4 = reinterpret_cast<const f32x4*>(embed + ((size_t)b * q_total + q0) * C);
     uint2* a_hi2 = reinterpret_cast<uint2*>(a_hi);
     uint2* a_lo2 = reinterpret_cast<uint2*>(a_lo);
     const int nf = MT * 32 * (C / 4);
@@ -497,7 +499,7 @@ extern "C" int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int
 
 template <bool SPLIT>
 static int launch_mask_logits(const float* embed, const void* hi, const void* lo, float* out,
-                              uint32_t* bits, int B, int Q, int npix, hipStream_t s) {
+                              uint32_t* bits, int B, int Q, int npix, hipStream_t s, int q_total, int q0) {
   const int MT = (Q + 31) / 32;
   const int T = (npix + 31) / 32;
   const size_t lds = (size_t)MT * 16 * 64 * 16 * (SPLIT ? 2 : 1);
@@ -520,7 +522,7 @@ static int launch_mask_logits(const float* embed, const void* hi, const void* lo
     }
   }
   hipLaunchKernelGGL(kern, dim3(gx, B), dim3(512), lds, s, embed, (const u32x4*)hi,
-                     (const u32x4*)lo, out, bits, Q, npix, T, MT);
+                     (const u32x4*)lo, out, bits, Q, npix, T, MT, q_total, q0);
   CGG_CHECK_LAUNCH("cgg_mask_logits");
   return CGG_OK;
 }
@@ -536,11 +538,16 @@ extern "C" int cgg_mask_logits(const float* embed, const void* hi, const void* l
   hipStream_t s = (hipStream_t)stream;
   const int mt = (Q + 31) / 32;
   if (lo) {
-    CGG_REQUIRE(mt <= 4, CGG_EUNSUPPORTED, "cgg_mask_logits: split mode supports Q <= 128 (Q=%d)", Q);
-    return launch_mask_logits<true>(embed, hi, lo, out, bits, B, Q, npix, s);
+    // split mode keeps <= 4 query tiles (hi + lo fragment images, 128 KiB) in LDS: larger query sets run as row groups of 128,
+    // every group writing its rows of the outputs in place
+    for (int q0 = 0; q0 < Q; q0 += 128) {
+      const int rc = launch_mask_logits<true>(embed, hi, lo, out, bits, B, Q - q0 < 128 ? Q - q0 : 128, npix, s, Q, q0);
+      if (rc != CGG_OK) return rc;
+    }
+    return CGG_OK;
   }
   CGG_REQUIRE(mt <= 8, CGG_EUNSUPPORTED, "cgg_mask_logits: Q <= 256 (Q=%d)", Q);
-  return launch_mask_logits<false>(embed, hi, lo, out, bits, B, Q, npix, s);
+  return launch_mask_logits<false>(embed, hi, lo, out, bits, B, Q, npix, s, Q, 0);
 }
 
 extern "C" int cgg_attn_mask_fix_full_rows(uint32_t* bits, int rows, int npix, cgg_stream_t stream) {

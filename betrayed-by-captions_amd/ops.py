@@ -257,11 +257,6 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
                                              dev_ptr(bits), B, Q, C, packed.npix, stream_ptr(embed.device))
         check(rc, 'cgg_mask_logits_f32')
         return out, bits
-    if packed.lo is not None and Q > 128:      # 3-MFMA (hi, lo) mode keeps <= 4 query tiles in LDS: split the queries
-        parts = [mask_logits(embed[:, s:s + 128].contiguous(), packed, want_logits, want_bits)
-                 for s in range(0, Q, 128)]
-        return (torch.cat([p[0] for p in parts], 1) if want_logits else None,
-                torch.cat([p[1] for p in parts], 1) if want_bits else None)
     out = torch.empty((B, Q, packed.h, packed.w), dtype=torch.float32, device=embed.device) \
         if want_logits else None
     bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device) \

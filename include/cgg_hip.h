@@ -143,7 +143,7 @@ int cgg_pack_mask_feature(const float* feat, void* hi, void* lo, int B, int C, i
  *   out     [B, Q, npix] f32, nullable (logits not stored)
  *   bits    [B, Q, ceil(npix/32)] u32, nullable: bit (p%32) of word p/32 = (logit < 0), i.e. the
  *           boolean attention mask (True = blocked) shared by all heads -- never repeated x8.
- * Requires C == 256 (feat_channels of every shipped config), Q <= 256 (bf16) / Q <= 128 (split).  */
+ * Requires C == 256 (feat_channels of every shipped config), Q <= 256 (bf16); split mode: any Q (row groups of 128, in place).  */
 int cgg_mask_logits(const float* embed, const void* hi, const void* lo, float* out, uint32_t* bits,
                     int B, int Q, int C, int npix, cgg_stream_t stream);
 /* Exact-f32 variant for parity mode (f32 MFMA, f32 products): feat = the UN-packed f32 map [B, C, npix] (full resolution,
