@@ -402,7 +402,7 @@ __device__ __forceinline__ void msda_point_gather_f32(msda_v2f (&acc)[4], const 
     const int o = msda_quad_bcast<CTRL>(my_o[k]);
     w[k] = msda_quad_bcast<CTRL>(my_w[k]);
     u[k][0] = *reinterpret_cast<const f32x4*>(vl + o);
-    u[k][1] = *reinterpret_cast<const f32x4*>(vl + o + 4);
+    u[k][1] = *reinterpret_cast<const f32x4*>(vl + o + 16);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
   const unsigned b = bq / (unsigned)Nq;
   const int q = (int)(bq - b * (unsigned)Nq);
   constexpr int rowstride = H * D;
-  const float* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
+  // lane cq owns channels 4 cq .. + 3 and 16 + 4 cq .. + 3: each of a tap's two loads covers a CONTIGUOUS 64-byte half line per quad
+  const float* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * 4;
   const float* row = rows + (size_t)bq * ld;
   const float* lp = row + (size_t)h * LP * 2 + 2 * cq;                 // this lane's point: (x, y) of point cq, + 8 per level
   const float* wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
@@ -480,9 +481,9 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     msda_point_gather_f32<2>(acc, vl, my_o, my_w);
     msda_point_gather_f32<3>(acc, vl, my_o, my_w);
   }
-  float* op = out + (size_t)bq * (H * D) + (size_t)h * D + cq * CPL;
+  float* op = out + (size_t)bq * (H * D) + (size_t)h * D + cq * 4;
   *reinterpret_cast<f32x4*>(op) = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
-  *reinterpret_cast<f32x4*>(op + 4) = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+  *reinterpret_cast<f32x4*>(op + 16) = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
 }
 
 // Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
