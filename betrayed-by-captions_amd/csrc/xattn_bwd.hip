@@ -90,10 +90,16 @@ __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
     float kf[16], vf[16];
     {
       const float* row = kvb + (size_t)(kvalid ? key : s_begin) * (2 * HD) + 16 * hi;
+      // all eight loads first: interleaved with the LDS stores below the compiler waited for every load separately
+      f32x4 kxa[4], vxa[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 kx = *reinterpret_cast<const f32x4*>(row + 4 * t);
-        const f32x4 vx = *reinterpret_cast<const f32x4*>(row + HD + 4 * t);
+        kxa[t] = *reinterpret_cast<const f32x4*>(row + 4 * t);
+        vxa[t] = *reinterpret_cast<const f32x4*>(row + HD + 4 * t);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 kx = kxa[t], vx = vxa[t];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           kf[4 * t + e] = kvalid ? kx[e] : 0.f;
@@ -116,6 +122,18 @@ __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
       f32x16 sc, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+      // the 16 mask words this lane tests (one per query row of the tile; the 32 keys of a wave share a word) are requested
+      // here, unpredicated (rows past Q re-read row Q - 1), and arrive under the 64 MFMAs below -- as `if (!blocked) blocked =
+      // bits[...]` they compiled to 16 x (branch, load, s_waitcnt vmcnt(0)): 64 serial memory latencies per 128-key tile
+      uint32_t mw[16];
+      if (bits != nullptr) {
+        const uint32_t* mrow = bits + (size_t)b * Q * words + wq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qt * 32 + xb_row(r, hi);
+          mw[r] = mrow[(size_t)(qq < Q ? qq : Q - 1) * words];
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const f32x4 qa = *reinterpret_cast<const f32x4*>(qrow + 4 * t);
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
       for (int r = 0; r < 16; ++r) {
         const int qq = qt * 32 + xb_row(r, hi);
         bool blocked = !kvalid || qq >= Q;
-        if (bits != nullptr && !blocked) blocked = (bits[((size_t)b * Q + qq) * words + wq] >> bq) & 1u;
+        if (bits != nullptr) blocked = blocked || ((mw[r] >> bq) & 1u);
         const float p = blocked ? 0.f : __expf(sc[r] - Ls[qq]);
         sc[r] = p;                                   // P
         dp[r] = p * (dp[r] - Ds[qq]);                // dS
