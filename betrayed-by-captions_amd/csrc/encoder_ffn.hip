@@ -365,8 +365,28 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
   constexpr float inv_n = 1.f / (float)EF_C;
 #pragma unroll 2
   for (int it = 0; it < 4; ++it) {
+    // no implicit mul + add contraction in the row statistics: which products the compiler fuses depends on the code around them,
+    // and the KV and plain instantiations are held bit-equal by the tests (the affine step below is an explicit fma)
+#pragma clang fp contract(off)
     const int row = 16 * wave + 4 * it + rsub, m = m0 + row;
     const bool live = m < M;
+    // the table rows the epilogue adds (pos / shift) are requested HERE, unpredicated (rows past M use row M - 1), and arrive
+    // under the two row reductions: loaded where they are used -- behind `if (!live) continue` and the stores -- every one of
+    // them cost a full s_waitcnt vmcnt(0) (4-8 serial L2 latencies at the tail of every workgroup)
+    const int mcl = live ? m : M - 1;
+    f32x4 tp[4], ts[4];
+    if constexpr (KV) {
+      const int si0 = mcl - (mcl / pos_rows) * pos_rows;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ts[k] = *reinterpret_cast<const f32x4*>(shift + (size_t)si0 * EF_C + 4 * sub + 64 * k);
+        tp[k] = *reinterpret_cast<const f32x4*>(pos + (size_t)si0 * EF_C + 4 * sub + 64 * k);
+      }
+    } else if (yp16) {
+      const float* prow0 = pos + (size_t)(mcl % pos_rows) * EF_C;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tp[k] = *reinterpret_cast<const f32x4*>(prow0 + 4 * sub + 64 * k);
+    }
     f32x4 v[4];
     float sm = 0.f;
 #pragma unroll
@@ -393,24 +413,23 @@ __global__ __launch_bounds__(EF_NT) void cgg_encoder_ffn_ln_kernel(
       const size_t orow = (size_t)nimg * lv.start[l] + (size_t)bi * (lv.start[l + 1] - lv.start[l]) + (si - lv.start[l]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+        const f32x4 y = __builtin_elementwise_fma(v[k] * rstd, g4[k], be4[k]);   // explicit: both variants must round alike
         const int cofs = 4 * sub + 64 * k;
         if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)m * EF_C + cofs) = y;
-        const f32x4 mm = y + *reinterpret_cast<const f32x4*>(shift + (size_t)si * EF_C + cofs);
+        const f32x4 mm = y + ts[k];
         *reinterpret_cast<uint2*>(y16 + orow * EF_C + cofs) = make_uint2(ef_pk(mm[0], mm[1]), ef_pk(mm[2], mm[3]));
-        const f32x4 z = mm + *reinterpret_cast<const f32x4*>(pos + (size_t)si * EF_C + cofs);
+        const f32x4 z = mm + tp[k];
         *reinterpret_cast<uint2*>(yp16 + orow * EF_C + cofs) = make_uint2(ef_pk(z[0], z[1]), ef_pk(z[2], z[3]));
       }
     } else {
-      const float* prow = yp16 ? pos + (size_t)(m % pos_rows) * EF_C : nullptr;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+        const f32x4 y = __builtin_elementwise_fma(v[k] * rstd, g4[k], be4[k]);   // explicit: both variants must round alike
         const size_t o = (size_t)m * EF_C + 4 * sub + 64 * k;
         if (y32) *reinterpret_cast<f32x4*>(y32 + o) = y;
         if (y16) *reinterpret_cast<uint2*>(y16 + o) = make_uint2(ef_pk(y[0], y[1]), ef_pk(y[2], y[3]));
         if (yp16) {
-          const f32x4 yp = y + *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
+          const f32x4 yp = y + tp[k];
           *reinterpret_cast<uint2*>(yp16 + o) = make_uint2(ef_pk(yp[0], yp[1]), ef_pk(yp[2], yp[3]));
         }
       }

@@ -314,6 +314,18 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) tile[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi5) * E3_TS + col] = acc2[mt][nt][r] * cs2 + bias2;
   }
+  // the pos rows of this wave's 16 output rows are requested before the barrier (unpredicated: rows past M use row M - 1) and arrive
+  // under the LayerNorm reductions; loaded inside the store loop they were two loads + s_waitcnt vmcnt(0) per 4 stores
+  f32x4 pp[4][4];
+  if (yp32) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = m0 + 16 * wn + 4 * it + rsub;
+      const float* prow = pos + (size_t)((m < M ? m : M - 1) % pos_rows) * E3_C;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pp[it][k] = *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
+    }
+  }
   __syncthreads();
   // ---- row-major LayerNorm of x1 + ffn(x1): wave w owns rows 16 w .. 16 w + 15, four at a time; 16 lanes share a row ----
   f32x4 g4[4], be4[4];
@@ -344,13 +356,12 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     q = e3_row16_sum(q);
     const float rstd = rsqrtf(q * inv_n + eps1);
     if (m >= M) continue;
-    const float* prow = yp32 ? pos + (size_t)(m % pos_rows) * E3_C : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const f32x4 y = v[k] * rstd * g4[k] + be4[k];
       const size_t o = (size_t)m * E3_C + 4 * sub + 64 * k;
       *reinterpret_cast<f32x4*>(y32 + o) = y;
-      if (yp32) *reinterpret_cast<f32x4*>(yp32 + o) = y + *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
+      if (yp32) *reinterpret_cast<f32x4*>(yp32 + o) = y + pp[it][k];
     }
   }
 }

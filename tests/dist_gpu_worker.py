@@ -79,7 +79,10 @@ def main():
             err = float((got - mean).abs().max())
             if scale > 1e-6:                      # (parameters with an all-zero gradient, e.g. cls_embed: loss weight 0)
                 worst = max(worst, err / scale)
-            assert err <= 1e-4 * scale + 1e-9, (n, err, scale)
+            # 5e-4 of the gradient's scale: the reducer adds nothing beyond f32 rounding (1e-5 .. 1e-6 measured), but the two backward
+            # passes compared here are separate runs and MIOpen occasionally picks another weight-gradient solver for the 3 x 3
+            # output convolution in one of them (1.3e-4 on that parameter, one run in three)
+            assert err <= 5e-4 * scale + 1e-9, (n, err, scale)
         # ---- identical parameters on both ranks after the optimiser step ----
         for n, p in model.named_parameters():
             t = p.detach().clone()
