@@ -149,22 +149,26 @@ class ResNet(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() replace buffer objects: drop the folded-weight caches that reference them
-        self.__dict__.pop('_fold_tensors', None)
-        self.__dict__.pop('_fold_cache', None)
-        self.__dict__.pop('_fold_cache_x3', None)
+        for k in [k for k in self.__dict__ if k.startswith('_fold_')]:
+            self.__dict__.pop(k, None)
         return super()._apply(fn, *args, **kwargs)
 
     # ---- throughput-mode inference: BN folded into the convolutions, bf16 NHWC filters kept resident ----
-    def _folded(self):
+    def _folded(self, upto=None):
         """[(w, b)] per conv in execution order, bf16 channels_last, frozen BN folded in
         (w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)). Rebuilt when any
-        parameter / buffer version changes."""
-        tensors = self.__dict__.get('_fold_tensors')
+        parameter / buffer version changes. `upto` (training with frozen stages): the stem and the first `upto` res layers only,
+        keyed on THEIR tensors -- the optimiser bumps the versions of the trainable tail every step, which would otherwise re-fold
+        (and re-pack every derived image of) all ~53 convolutions per training step."""
+        ck, tk = ('_fold_cache', '_fold_tensors') if upto is None else ('_fold_cache_upto%d' % upto, '_fold_tensors_upto%d' % upto)
+        layers = self.res_layers if upto is None else self.res_layers[:upto]
+        tensors = self.__dict__.get(tk)
         if tensors is None:       # walking the module tree costs ~1 ms per forward; the tensor objects are stable
-            tensors = list(self.parameters()) + list(self.buffers())
-            self.__dict__['_fold_tensors'] = tensors
+            mods = [self] if upto is None else [self.conv1, self.bn1] + [getattr(self, n) for n in layers]
+            tensors = [t for m in mods for t in list(m.parameters()) + list(m.buffers())]
+            self.__dict__[tk] = tensors
         key = sum(t._version for t in tensors)
-        hit = self.__dict__.get('_fold_cache')
+        hit = self.__dict__.get(ck)
         if hit is not None and hit[0] == key and hit[1][0][0].device == self.conv1.weight.device:
             return hit[1]
 
@@ -177,7 +181,7 @@ class ResNet(nn.Module):
             return w.contiguous(memory_format=torch.channels_last), b, None
 
         seq = [fold(self.conv1, self.bn1)]
-        for name in self.res_layers:
+        for name in layers:
             for blk in getattr(self, name):
                 if blk.downsample is not None:
                     seq.append(fold(blk.downsample[0], blk.downsample[1]))
@@ -185,7 +189,7 @@ class ResNet(nn.Module):
                 seq.append(fold(blk.conv2, blk.bn2))
                 if isinstance(blk, Bottleneck):
                     seq.append(fold(blk.conv3, blk.bn3))
-        self.__dict__['_fold_cache'] = (key, seq)
+        self.__dict__[ck] = (key, seq)
         return seq
 
     @staticmethod
@@ -232,7 +236,7 @@ class ResNet(nn.Module):
 
     def _forward_folded(self, x, upto=None):
         import torch.nn.functional as F
-        seq = iter(self._folded())
+        seq = iter(self._folded(upto))
         mp = self.maxpool
         pool_ok = (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False)
         c1 = self.conv1
@@ -380,7 +384,7 @@ class ResNet(nn.Module):
             return self._forward_x3(x)
         outs = []
         first = 0
-        if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1
+        if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1 and not x.requires_grad
                 and not any(p.requires_grad for n in self.res_layers[:self.frozen_stages] for p in getattr(self, n).parameters())
                 and not any(p.requires_grad for p in list(self.conv1.parameters()) + list(self.bn1.parameters()))):
             # training with frozen stages (configs: frozen_stages=3, norm_eval=True): nothing before the first trainable layer is

@@ -223,13 +223,16 @@ class _GeneratorCEFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         gw = torch.zeros(w.shape, dtype=torch.float32, device=x.device)
         gb = torch.zeros(w.shape[0], dtype=torch.float32, device=x.device)
+        gwc = torch.empty(w.shape, dtype=x.dtype, device=x.device)          # one chunk's weight gradient, reused by every chunk
         g = grad_rows.float().contiguous()
         for r0 in range(0, M, C):
             r1 = min(r0 + C, M)
             lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
             dl = ops.ce_rows_backward_(lg, target[r0:r1], lse[r0:r1], g[r0:r1], ctx.ignore_index)
             torch.mm(dl, w, out=gx[r0:r1])
-            gw += torch.mm(dl.t(), x[r0:r1])
+            # summed in f32 (one rounding of each chunk's partial to the GEMM dtype: 3 chunks at configs[2], below the bf16
+            # GEMM's own rounding)
+            gw += torch.mm(dl.t(), x[r0:r1], out=gwc)
             gb += dl.sum(0, dtype=torch.float32)
         n = ctx.n_out
         return gx.to(ctx.in_dtype), gw[:n], gb[:n], None, None

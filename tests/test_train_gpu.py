@@ -355,3 +355,53 @@ def test_hungarian_indices_on_the_gpu_path_at_configs2_shapes(dev):
             assert torch.equal(neg, r_neg)
     print(f'Hungarian parity: {n * (B - 1)} problems, max |cost - oracle| = {worst_cost:.2e}, {ties} exact-cost ties')
     assert ties <= 2
+
+
+def test_frozen_folded_backbone_matches_the_autograd_recorded_path(dev, monkeypatch):
+    """Training with frozen stages (configs: `frozen_stages=3, norm_eval=True`): the stem + frozen layers on the BN-folded bf16
+    channel-last inference path (`backbones.FROZEN_FOLDED`, default on) against the autograd-recorded torch path under bf16
+    autocast -- outputs and layer4 gradients within bf16 tolerance; the fold cache of the frozen part survives an optimiser step on
+    the trainable tail (it was keyed on every parameter and re-folded all convolutions per step); an input that requires
+    a gradient takes the recorded path."""
+    from cgg_amd import backbones, registry, runtime
+    torch.manual_seed(3)
+    net = registry.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=3,
+                                       norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch')).to(dev)
+    for m in net.modules():                                    # non-trivial frozen statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    net.train()
+    x = torch.randn(2, 3, 128, 160, device=dev)
+    res = {}
+    with runtime.precision_scope('bf16'):
+        for flag in (True, False):
+            monkeypatch.setattr(backbones, 'FROZEN_FOLDED', flag)
+            for p in net.parameters():
+                p.grad = None
+            outs = net(x)
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            res[flag] = ([o.detach().float() for o in outs],
+                         {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+        assert set(res[True][1]) == set(res[False][1]) and all(n.startswith('layer4') for n in res[True][1])
+        for a, b in zip(*[res[f][0] for f in (True, False)]):
+            assert (a - b).abs().max().item() <= 0.06 * b.abs().max().item() + 0.05      # bf16 activations through 40 convolutions
+            assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() >= 0.999
+        for n, ga in res[True][1].items():
+            gb = res[False][1][n]
+            assert torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item() >= 0.98, n
+        # the frozen fold is keyed on the frozen tensors: an optimiser step on layer4 leaves it in place
+        monkeypatch.setattr(backbones, 'FROZEN_FOLDED', True)
+        net(x)
+        folded = net.__dict__['_fold_cache_upto3'][1]
+        with torch.no_grad():
+            for p in net.layer4.parameters():
+                p.add_(1e-3)
+        net(x)
+        assert net.__dict__['_fold_cache_upto3'][1] is folded
+        # an input that needs its gradient is not silently detached
+        xg = x.clone().requires_grad_(True)
+        sum((o.float() ** 2).mean() for o in net(xg)).backward()
+        assert xg.grad is not None and float(xg.grad.abs().max()) > 0
