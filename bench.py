@@ -505,10 +505,23 @@ def train_step_child(args):
         if r.returncode != 0 or not line:
             return dict(error=f'child exited {r.returncode}', stderr_tail=r.stderr[-400:])
         d = json.loads(line[-1])
+        # launches per step and the dominant kernel come from the committed per-step kernel table of the same command
+        # (profiles/r3_train_step_kernels.txt: rocprofv3 --kernel-trace of `bench.py --mode train`, last 3 steps) -- labelled as such
+        prof = {}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r3_train_step_kernels.txt')) as f:
+                rows = f.read().splitlines()
+            head = [r for r in rows if r.startswith('step (eager')][0]
+            top = rows[rows.index(head) + 2].split(None, 3)
+            prof = dict(launches_per_step=float(head.split(':')[1].split()[0]), kernel_ms_per_step=float(head.split(',')[1].split()[0]) / 1e3,
+                        dominant_kernel=dict(name=top[3].split('(')[0], ms_per_step=float(top[0]) / 1e3, launches_per_step=float(top[1]),
+                                             share_of_kernel_time=float(top[2]) / 100.0),
+                        profile_source='committed profile: profiles/r3_train_step_kernels.txt (rocprofv3 --kernel-trace of this command)')
+        except Exception:
+            pass
         return dict(value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], warmup=d['warmup'],
                     dtype=d['dtype'], workload=d['config']['workload'], loss=d.get('loss'), peak_mem_gb=d.get('peak_mem_gb'),
-                    launches_per_step=d.get('launches_per_step'), dominant_kernel=d.get('dominant_kernel'),
-                    how='python bench.py --mode train in a child process of this run')
+                    how='python bench.py --mode train in a child process of this run', **prof)
     except Exception as e:
         return dict(error=f'{type(e).__name__}: {e}')
 
