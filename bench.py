@@ -513,7 +513,9 @@ def train_step_child(args):
                 rows = f.read().splitlines()
             head = [r for r in rows if r.startswith('step (eager')][0]
             top = rows[rows.index(head) + 2].split(None, 3)
-            prof = dict(launches_per_step=float(head.split(':')[1].split()[0]), kernel_ms_per_step=float(head.split(',')[1].split()[0]) / 1e3,
+            import re
+            mh = re.search(r': ([0-9.]+) launches, ([0-9.]+) us of kernel time', head)
+            prof = dict(launches_per_step=float(mh.group(1)), kernel_ms_per_step=float(mh.group(2)) / 1e3,
                         dominant_kernel=dict(name=top[3].split('(')[0], ms_per_step=float(top[0]) / 1e3, launches_per_step=float(top[1]),
                                              share_of_kernel_time=float(top[2]) / 100.0),
                         profile_source='committed profile: profiles/r3_train_step_kernels.txt (rocprofv3 --kernel-trace of this command)')
