@@ -300,14 +300,17 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   CGG_REQUIRE(!out2 || (col2 > 0 && col2 % 32 == 0 && col2 < N && ldc2 >= N - col2), CGG_EINVAL,
               "%s: second output needs 0 < col2 < N, col2 %% 32 == 0, ldc2 >= N - col2 (col2=%d ldc2=%d)", who, col2, ldc2);
   CGG_REQUIRE(res_mod >= 0 && (!res_mod || res), CGG_EINVAL, "%s: res_mod without res", who);
-  // tile shape: the largest whose grid still covers the chip about 1.5 times (256 CUs)
+  // tile shape: the largest whose grid still has >= 192 workgroups. Measured in the 3-stage pipelined step (A/B pairs on one box,
+  // scratch/ab_tiles.sh): the larger tiles are the more efficient ones per FLOP, and the CUs a small grid leaves idle are taken by
+  // the other streams' kernels, so the step prefers FEWER, BIGGER tiles than a stand-alone launch does -- threshold 384 + smaller
+  // tiles for K <= 512 (the stand-alone optimum of the first version): 349 images/s; 192, no K rule: 358 (eager GEMM time equal);
+  // 128: 363 with +7 % eager GEMM time and +3 % latency (not taken). CGG_XG_MINTILES / CGG_XG_SMALLK override.
+  static const int mintiles = getenv("CGG_XG_MINTILES") ? atoi(getenv("CGG_XG_MINTILES")) : 192;
   auto tiles = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)); };
   int tm = 2, tn = N <= 64 ? 1 : 2;
-  if (tiles(tm, tn) < 384) tm = 1;
-  if (tiles(tm, tn) < 384 && tn == 2) tn = 1;
-  // short K loops (<= 16 chunks) are dominated by the prologue / epilogue of a workgroup, not by its MFMA loop: the next smaller
-  // tile puts 3-5 workgroups on a CU instead of 2 and overlaps them (+3 % on the step, 278 -> 286 images/s; CGG_XG_SMALLK=0 = off)
-  static const int smallk = getenv("CGG_XG_SMALLK") ? atoi(getenv("CGG_XG_SMALLK")) : 512;
+  if (tiles(tm, tn) < mintiles) tm = 1;
+  if (tiles(tm, tn) < mintiles && tn == 2) tn = 1;
+  static const int smallk = getenv("CGG_XG_SMALLK") ? atoi(getenv("CGG_XG_SMALLK")) : 0;
   if (K <= smallk) {
     if (tm == 2) tm = 1;
     else if (tn == 2) tn = 1;
