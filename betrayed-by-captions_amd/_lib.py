@@ -37,6 +37,7 @@ PROTOTYPES = {
     'cgg_attn_mask_from_logits': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_masked_xattn_workspace_bytes': (_c_i64, [_c_int] * 5),
     'cgg_masked_xattn_forward': (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
+    'cgg_masked_xattn_forward_strided': (_c_int, [_c_vp, _c_vp, _c_int, _c_i64, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_f, _c_vp]),
     'cgg_masked_xattn_forward_lse': (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
     'cgg_masked_xattn_backward_workspace_bytes': (_c_i64, [_c_int] * 5),
     'cgg_masked_xattn_backward': (_c_int, [_c_vp] * 9 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
@@ -77,6 +78,18 @@ PROTOTYPES = {
     'cgg_gemm_x3_ex': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_int] +
                        [_c_int] * 4 + [_c_vp]),
     'cgg_conv_x3_nhwc': (_c_int, [_c_vp] * 5 + [_c_int] * 10 + [_c_vp]),
+    'cgg_gemm_x3s': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int] + [_c_int] * 4 + [_c_vp]),
+    'cgg_gemm_x3s_batched': (_c_int, [_c_vp, _c_int, _c_int, _c_i64, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int] + [_c_int] * 4 + [_c_vp]),
+    'cgg_conv_x3s_nhwc': (_c_int, [_c_vp] * 4 + [_c_int, _c_vp, _c_int] + [_c_int] * 10 + [_c_vp]),
+    'cgg_x3a_encode': (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
+    'cgg_x3a_decode': (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
+    'cgg_x3_overflow_check': (_c_int, [_c_int, _c_vp, _c_vp]),
+    'cgg_gemm_x3s_force_config': (None, [_c_int]),
+    'cgg_bias_relu_maxpool_nhwc_f32_x3a': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
+    'cgg_group_norm_nhwc_f32_x3a': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int, _c_vp,
+                                             _c_i64, _c_vp, _c_vp, _c_vp]),
+    'cgg_encoder_layer_tail_x3a': (_c_int, [_c_vp] * 6 + [_c_f] + [_c_vp] * 6 + [_c_f, _c_vp, _c_int, _c_vp, _c_vp] +
+                                   [_c_int] * 3 + [_c_vp]),
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
     'cgg_msda_prologue': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),

@@ -328,7 +328,8 @@ class ResNet(nn.Module):
     def _x3_ok(self):
         def conv_ok(c):
             return (c.groups == 1 and tuple(c.dilation) == (1, 1) and c.kernel_size[0] == c.kernel_size[1]
-                    and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.in_channels % 32 == 0 and c.bias is None)
+                    and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.in_channels % 32 == 0 and c.bias is None
+                    and c.out_channels % 8 == 0 and c.kernel_size[0] * c.kernel_size[1] <= 32)
         for name in self.res_layers:
             for blk in getattr(self, name):
                 convs = [blk.conv1, blk.conv2] + ([blk.conv3] if isinstance(blk, Bottleneck) else [])
@@ -342,6 +343,7 @@ class ResNet(nn.Module):
 
     def _forward_x3(self, x):
         import torch.nn.functional as F
+        x3a = runtime.x3a_enabled()
         seq = iter(self._folded_x3())
         w, b = next(seq)
         mp, c1 = self.maxpool, self.conv1
@@ -350,14 +352,18 @@ class ResNet(nn.Module):
                 and tuple(c1.padding) == (3, 3) and tuple(c1.dilation) == (1, 1) and os.environ.get('CGG_X3_STEM', '1') != '0'):
             # stem: the MFMA convolution straight from the f32 NCHW image on the f32-class contraction + (bias, ReLU, max-pool) pass
             pk, sc = runtime.derived_cached('stem_packed_x3', (w,), lambda: ops.pack_stem_weight_x3(w))
-            x = ops.bias_relu_maxpool_nhwc_f32(ops.stem_conv7x7_x3(x, pk, sc), b)
+            x = ops.bias_relu_maxpool_nhwc_f32(ops.stem_conv7x7_x3(x, pk, sc), b, x3a=x3a)
         else:
             # (other stems: 3 input channels are not an implicit-GEMM shape) MIOpen f32 with the folded filter, then channel-last
             x = F.conv2d(x.float(), w, b, stride=c1.stride, padding=c1.padding)
             x = mp(torch.relu_(x)).permute(0, 2, 3, 1).contiguous()
+            if x3a:
+                x = ops.x3a_encode(x)
 
         def conv(x, c, relu, res=None):
             wk, bias = next(seq)
+            if x3a:     # x3a rows in, x3a rows out (residual too): the LDS-DMA implicit GEMM (csrc/x3s_gemm.hip)
+                return ops.conv_x3s_nhwc(x, wk, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], bias, res=res, relu=relu)
             return ops.conv_x3_nhwc(x, wk, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], bias, res=res, relu=relu)
 
         outs = []
@@ -373,7 +379,10 @@ class ResNet(nn.Module):
             if i in self.out_indices:
                 outs.append(x)
         # (B, C, H, W)-shaped views of the channel-last f32 activations (no copy): the pixel decoder's parity-mode stream reads
-        # them as they are; anything else can `.contiguous()` them
+        # them as they are; anything else can `.contiguous()` them. Round 4: the maps are x3a rows, tagged `ops.X3ATensor` -- the
+        # pixel decoder's x3 GEMMs consume them as stored, `ops.x3a_to_f32` gives the values
+        if x3a:
+            return tuple(ops.as_x3a(o.permute(0, 3, 1, 2)) for o in outs)
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
 
     def forward(self, x):

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     const float* __restrict__ a32, const float* __restrict__ x32, const CggX3W wo, const float* __restrict__ bo,
     const float* __restrict__ gamma0, const float* __restrict__ beta0, float eps0, const CggX3W w1, const float* __restrict__ b1,
     const CggX3W w2, const float* __restrict__ b2, const float* __restrict__ gamma1, const float* __restrict__ beta1, float eps1,
-    const float* __restrict__ pos, int pos_rows, float* __restrict__ y32, float* __restrict__ yp32, int M, int F) {
+    const float* __restrict__ pos, int pos_rows, float* __restrict__ y32, float* __restrict__ yp32, int M, int F, int x3a,
+    int* __restrict__ flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char e3_smem[];
   e3_u32x4* xfrag = reinterpret_cast<e3_u32x4*>(e3_smem);                   // row image: hi [2 m-tiles][16][64] | lo    64 KiB
   e3_u32x4* hfrag = xfrag + 2 * E3_IMG;                                      // hidden chunk: hi | lo                     64 KiB
@@ -168,8 +169,17 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   for (int it = 0; it < 4; ++it) {
     const int row = 16 * wn + 4 * it + rsub;
     const int mc = m0 + row < M ? m0 + row : M - 1;
+    if (x3a) {
+      // x3a rows (csrc/x3.h): channels c0 = 4 sub + 64 k .. + 3 are half (sub & 1) of the group c0 / 8 = [8 hi | 8 lo]
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xr[it][k] = *reinterpret_cast<const f32x4*>(x32 + (size_t)mc * E3_C + 4 * sub + 64 * k);
+      for (int k = 0; k < 4; ++k) {
+        const uint2* g = reinterpret_cast<const uint2*>(x32 + (size_t)mc * E3_C + 8 * (sub >> 1) + 64 * k) + (sub & 1);
+        cgg_x3a_decode4(g[0], g[2], xr[it][k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xr[it][k] = *reinterpret_cast<const f32x4*>(x32 + (size_t)mc * E3_C + 4 * sub + 64 * k);
+    }
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -356,6 +366,30 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     q = e3_row16_sum(q);
     const float rstd = rsqrtf(q * inv_n + eps1);
     if (m >= M) continue;
+    if (x3a) {
+      // outputs as x3a rows: the next layer's GEMM operands / residual stream in the form they are consumed
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 y = v[k] * rstd * g4[k] + be4[k];
+        const size_t o = (size_t)m * E3_C + 8 * (sub >> 1) + 64 * k;
+        uint2 h, l;
+        cgg_x3_split4(y, h, l);
+        uint2* yo = reinterpret_cast<uint2*>(y32 + o) + (sub & 1);
+        yo[0] = h;
+        yo[2] = l;
+        float am = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+        if (yp32) {
+          const f32x4 yp = y + pp[it][k];
+          cgg_x3_split4(yp, h, l);
+          uint2* po = reinterpret_cast<uint2*>(yp32 + o) + (sub & 1);
+          po[0] = h;
+          po[2] = l;
+          am = fmaxf(am, fmaxf(fmaxf(fabsf(yp[0]), fabsf(yp[1])), fmaxf(fabsf(yp[2]), fabsf(yp[3]))));
+        }
+        if (flag && !(am * CGG_X3_ASCALE <= CGG_X3A_MAX)) atomicOr(flag, 1);
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const f32x4 y = v[k] * rstd * g4[k] + be4[k];
@@ -366,11 +400,12 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   }
 }
 
-extern "C" int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, const void* wo_x3, const float* bo, const float* gamma0,
-                                         const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
-                                         const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
-                                         int pos_rows, float* y32, float* yp32, int M, int C, int F, cgg_stream_t stream) {
-  const char* who = "cgg_encoder_layer_tail_x3";
+int* cgg_x3_overflow_flag_ptr();       // x3s_gemm.hip
+
+static int e3_launch(const float* a32, const float* x32, const void* wo_x3, const float* bo, const float* gamma0,
+                     const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
+                     const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                     int pos_rows, float* y32, float* yp32, int M, int C, int F, int x3a, cgg_stream_t stream, const char* who) {
   CGG_REQUIRE(a32 && x32 && wo_x3 && bo && gamma0 && beta0 && w1_x3 && b1 && w2_x3 && b2 && gamma1 && beta1 && y32, CGG_EINVAL,
               "%s: null pointer", who);
   CGG_REQUIRE(C == E3_C, CGG_EUNSUPPORTED, "%s: C=%d (only 256 is built)", who, C);
@@ -381,15 +416,37 @@ extern "C" int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, con
                   (!pos || cgg_aligned16(pos)) && cgg_aligned16(y32) && (!yp32 || cgg_aligned16(yp32)),
               CGG_EALIGN, "%s: 16-B alignment", who);
   const size_t lds = (size_t)2 * E3_IMG * 16 + (size_t)E3_RB * E3_TS * sizeof(float);      // row images + tile (>= hidden images)
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device (a process-wide flag broke launches on a second device)
+  static bool attr_set[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_tail_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     CGG_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise dynamic LDS to %zu", who, lds);
-    attr_set = true;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(cgg_encoder_tail_x3_kernel, dim3((M + E3_RB - 1) / E3_RB), dim3(E3_NT), lds, (hipStream_t)stream, a32, x32,
                      cgg_x3_view(wo_x3, E3_C, E3_C), bo, gamma0, beta0, eps0, cgg_x3_view(w1_x3, F, E3_C), b1,
-                     cgg_x3_view(w2_x3, E3_C, F), b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M, F);
+                     cgg_x3_view(w2_x3, E3_C, F), b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M, F, x3a,
+                     x3a ? cgg_x3_overflow_flag_ptr() : nullptr);
   CGG_CHECK_LAUNCH(who);
   return CGG_OK;
+}
+
+extern "C" int cgg_encoder_layer_tail_x3(const float* a32, const float* x32, const void* wo_x3, const float* bo, const float* gamma0,
+                                         const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
+                                         const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                                         int pos_rows, float* y32, float* yp32, int M, int C, int F, cgg_stream_t stream) {
+  return e3_launch(a32, x32, wo_x3, bo, gamma0, beta0, eps0, w1_x3, b1, w2_x3, b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M,
+                   C, F, 0, stream, "cgg_encoder_layer_tail_x3");
+}
+
+// round 4: the layer input x and the outputs y / y + pos are x3a rows (csrc/x3.h); the attention rows a32 stay f32
+extern "C" int cgg_encoder_layer_tail_x3a(const float* a32, const void* x_x3a, const void* wo_x3, const float* bo,
+                                          const float* gamma0, const float* beta0, float eps0, const void* w1_x3, const float* b1,
+                                          const void* w2_x3, const float* b2, const float* gamma1, const float* beta1, float eps1,
+                                          const float* pos, int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F,
+                                          cgg_stream_t stream) {
+  return e3_launch(a32, (const float*)x_x3a, wo_x3, bo, gamma0, beta0, eps0, w1_x3, b1, w2_x3, b2, gamma1, beta1, eps1, pos, pos_rows,
+                   (float*)y_x3a, (float*)yp_x3a, M, C, F, 1, stream, "cgg_encoder_layer_tail_x3a");
 }

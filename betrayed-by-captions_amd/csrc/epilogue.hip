@@ -3,7 +3,7 @@
 //     y[r, c] = act(y[r, c] + bias[c] + res[r, c])
 // instead of the three library passes (bias add, residual add, clamp). Pure HBM streaming: every lane owns one
 // 16-byte vector (8 channels), loads are issued before any use, the bias vector comes from L1/L2.
-#include "cgg_common.h"
+#include "x3.h"
 
 template <bool BIAS, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void cgg_bias_act_kernel(uint4* __restrict__ y, const uint4* __restrict__ bias,
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void cgg_bias_relu_maxpool_kernel(const uint4*
 // parity mode's twin on f32 maps (the x3 stem's raw f32 output): 4 channels per thread
 __global__ __launch_bounds__(256) void cgg_bias_relu_maxpool_f32_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ bias,
                                                                        f32x4* __restrict__ y, int H, int W, int Ho, int Wo,
-                                                                       int c4, long long nvec) {
+                                                                       int c4, long long nvec, int x3a, int* __restrict__ flag) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // output vector: (b, oy, ox, c4)
   if (i >= nvec) return;
   const int c = (int)(i % c4);
@@ -148,22 +148,44 @@ __global__ __launch_bounds__(256) void cgg_bias_relu_maxpool_f32_kernel(const f3
   f32x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = fmaxf(m[k] + bv[k], 0.f);
-  y[i] = o;
+  if (!x3a) {
+    y[i] = o;
+    return;
+  }
+  // x3a rows (csrc/x3.h): the 4 channels are half of an 8-channel group [8 hi | 8 lo]: 8 bytes of each piece
+  uint2 h, l;
+  cgg_x3_split4(o, h, l);
+  uint2* yo = reinterpret_cast<uint2*>(y) + (i >> 1) * 4 + (i & 1);
+  yo[0] = h;
+  yo[2] = l;
+  if (flag && !(fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])) * CGG_X3_ASCALE <= CGG_X3A_MAX)) atomicOr(flag, 1);
+}
+
+int* cgg_x3_overflow_flag_ptr();       // x3s_gemm.hip
+
+static int brm_f32_launch(const float* x, const float* bias, float* y, int B, int H, int W, int C, int x3a, cgg_stream_t stream,
+                          const char* who) {
+  CGG_REQUIRE(x && bias && y, CGG_EINVAL, "%s: null pointer", who);
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CGG_EINVAL, "%s: bad sizes", who);
+  CGG_REQUIRE(C % (x3a ? 8 : 4) == 0, CGG_EUNSUPPORTED, "%s: C %% %d != 0 (C=%d)", who, x3a ? 8 : 4, C);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(bias) && cgg_aligned16(y), CGG_EALIGN, "%s: pointers must be 16-byte aligned", who);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long nvec = (long long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(cgg_bias_relu_maxpool_f32_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)x, (const f32x4*)bias, (f32x4*)y, H, W, Ho, Wo, C / 4, nvec, x3a,
+                     x3a ? cgg_x3_overflow_flag_ptr() : nullptr);
+  CGG_CHECK_LAUNCH(who);
+  return 0;
 }
 
 extern "C" int cgg_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y, int B, int H, int W, int C,
                                               cgg_stream_t stream) {
-  CGG_REQUIRE(x && bias && y, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc_f32: null pointer");
-  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CGG_EINVAL, "cgg_bias_relu_maxpool_nhwc_f32: bad sizes");
-  CGG_REQUIRE(C % 4 == 0, CGG_EUNSUPPORTED, "cgg_bias_relu_maxpool_nhwc_f32: C %% 4 != 0 (C=%d)", C);
-  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(bias) && cgg_aligned16(y), CGG_EALIGN,
-              "cgg_bias_relu_maxpool_nhwc_f32: pointers must be 16-byte aligned");
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long long nvec = (long long)B * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(cgg_bias_relu_maxpool_f32_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const f32x4*)x, (const f32x4*)bias, (f32x4*)y, H, W, Ho, Wo, C / 4, nvec);
-  CGG_CHECK_LAUNCH("cgg_bias_relu_maxpool_nhwc_f32");
-  return 0;
+  return brm_f32_launch(x, bias, y, B, H, W, C, 0, stream, "cgg_bias_relu_maxpool_nhwc_f32");
+}
+
+extern "C" int cgg_bias_relu_maxpool_nhwc_f32_x3a(const float* x, const float* bias, void* y_x3a, int B, int H, int W, int C,
+                                                  cgg_stream_t stream) {
+  return brm_f32_launch(x, bias, (float*)y_x3a, B, H, W, C, 1, stream, "cgg_bias_relu_maxpool_nhwc_f32_x3a");
 }
 
 extern "C" int cgg_bias_relu_maxpool_nhwc(const void* x, const void* bias, void* y, int B, int H, int W, int C,

@@ -3,7 +3,7 @@
 // HBM-bound: at 256x256 a (batch, group) row holds 524288 elements but there are only B*32 = 64 rows, so a
 // row-per-block reduction leaves 3/4 of the chip idle. Here every row is split into chunks (pass 1: partial
 // sum / sum of squares per chunk, full-chip), and pass 2 folds the partials and normalises.
-#include "cgg_common.h"
+#include "x3.h"
 
 #define GN_CHUNK 16384  // elements per partial
 
@@ -163,12 +163,16 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __r
   const int p0 = blockIdx.x * ppb;
   const int p1 = min(p0 + ppb, HW);
   float s = 0.f, q = 0.f;
+  // f32 maps (parity mode): sums of (x - pivot), pivot = the group's first value of the image, the same for every block -- the
+  // one-pass E[x^2] - mean^2 of the bf16 path cancels catastrophically when |mean| >> std, which torch's f32 GroupNorm
+  // (Welford / two-pass) does not
+  const float pv = XF32 ? reinterpret_cast<const float*>(x)[((size_t)b * HW * G + g) * 8] : 0.f;
   for (int p = p0 + pl; p < p1; p += PL) {
     float f[8];
     gnh_load<XF32>(x, ((size_t)b * HW + p) * G + g, f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float lo = f[2 * k], hi = f[2 * k + 1];
+      const float lo = f[2 * k] - pv, hi = f[2 * k + 1] - pv;
       s += lo + hi;
       q += lo * lo + hi * hi;
     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_stats_kernel(const uint4* __r
 
 // second level: one 64-lane wave per (b, g) sums the per-block partials -> ws[b][g][2]
 __global__ __launch_bounds__(64) void cgg_gn_nhwc_reduce_kernel(float* __restrict__ ws, int B_G2_floats, int nblk, int G,
-                                                               int B) {
+                                                               int B, const float* __restrict__ x32, int HW, float inv_n) {
   const int i = blockIdx.x;                  // (b, g)
   const int b = i / G, g = i - b * G;
   const float* part = ws + B_G2_floats + ((size_t)b * nblk * G + g) * 2;
@@ -205,8 +209,12 @@ __global__ __launch_bounds__(64) void cgg_gn_nhwc_reduce_kernel(float* __restric
     q += __shfl_xor(q, o);
   }
   if (threadIdx.x == 0) {
-    ws[(size_t)i * 2] = s;
-    ws[(size_t)i * 2 + 1] = q;
+    // -> (mean, variance). x32 != NULL: the sums are of (x - pivot) (see the stats kernel); the pivot is read HERE, before the
+    // apply pass -- which may run in place -- overwrites it
+    const float pv = x32 ? x32[((size_t)b * HW * G + g) * 8] : 0.f;
+    const float dm = s * inv_n;
+    ws[(size_t)i * 2] = pv + dm;
+    ws[(size_t)i * 2 + 1] = fmaxf(q * inv_n - dm * dm, 0.f);
   }
 }
 
@@ -229,14 +237,14 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
     const float* __restrict__ beta, int HW, int G, float inv_n, float eps, int relu,
     const float* __restrict__ lo, int lo_h, int lo_w, long long lo_bstride, int W,
     float* __restrict__ y32, long long y32_bstride, uint4* __restrict__ y16, const float* __restrict__ pos,
-    uint4* __restrict__ yp16, long long y16_bstride) {
+    uint4* __restrict__ yp16, long long y16_bstride, float* __restrict__ yp32, int x3a, int* __restrict__ flag) {
   const int b = blockIdx.y;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // vector index inside the image
   if (i >= (long long)HW * G) return;
   const int p = (int)(i / G), g = (int)(i - (long long)p * G);
   const float s = ws[((size_t)b * G + g) * 2], q = ws[((size_t)b * G + g) * 2 + 1];
-  const float mean = s * inv_n;
-  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
+  const float mean = s;                                   // the reduce kernel leaves (mean, variance) in ws
+  const float rstd = rsqrtf(q + eps);
   float f[8];
   gnh_load<XF32>(x, (size_t)b * HW * G + i, f);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 8), gb = *reinterpret_cast<const f32x4*>(gamma + g * 8 + 4);
@@ -261,13 +269,28 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
     const float* r01 = base + ((size_t)y0 * lo_w + x1) * C;
     const float* r10 = base + ((size_t)y1 * lo_w + x0) * C;
     const float* r11 = base + ((size_t)y1 * lo_w + x1) * C;
+    if (x3a & 2) {
+      // the low-resolution map is stored as x3a rows (csrc/x3.h): a group of 8 channels = [8 hi | 8 lo]
+      float a[8], c[8], d[8], e[8];
+      const cgg_u32x4* q00 = reinterpret_cast<const cgg_u32x4*>(r00);
+      const cgg_u32x4* q01 = reinterpret_cast<const cgg_u32x4*>(r01);
+      const cgg_u32x4* q10 = reinterpret_cast<const cgg_u32x4*>(r10);
+      const cgg_u32x4* q11 = reinterpret_cast<const cgg_u32x4*>(r11);
+      cgg_x3a_decode8(q00[0], q00[1], a);
+      cgg_x3a_decode8(q01[0], q01[1], c);
+      cgg_x3a_decode8(q10[0], q10[1], d);
+      cgg_x3a_decode8(q11[0], q11[1], e);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(r00 + 4 * h), c = *reinterpret_cast<const f32x4*>(r01 + 4 * h);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(r10 + 4 * h), e = *reinterpret_cast<const f32x4*>(r11 + 4 * h);
+      for (int k = 0; k < 8; ++k) f[k] += (1.f - ly) * ((1.f - lx) * a[k] + lx * c[k]) + ly * ((1.f - lx) * d[k] + lx * e[k]);
+    } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        f[4 * h + k] += (1.f - ly) * ((1.f - lx) * a[k] + lx * c[k]) + ly * ((1.f - lx) * d[k] + lx * e[k]);
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r00 + 4 * h), c = *reinterpret_cast<const f32x4*>(r01 + 4 * h);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(r10 + 4 * h), e = *reinterpret_cast<const f32x4*>(r11 + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          f[4 * h + k] += (1.f - ly) * ((1.f - lx) * a[k] + lx * c[k]) + ly * ((1.f - lx) * d[k] + lx * e[k]);
+      }
     }
   }
   if (relu) {
@@ -276,8 +299,33 @@ __global__ __launch_bounds__(256) void cgg_gn_nhwc_apply_kernel(
   }
   if (y32) {
     float* o = y32 + (size_t)b * y32_bstride + (size_t)i * 8;
-    *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
-    *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+    if (x3a & 1) {             // x3a rows: the group's hi and lo pieces
+      cgg_u32x4 h, l;
+      cgg_x3a_encode8(f, h, l);
+      reinterpret_cast<cgg_u32x4*>(o)[0] = h;
+      reinterpret_cast<cgg_u32x4*>(o)[1] = l;
+      float am = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) am = fmaxf(am, fabsf(f[k]));
+      if (flag && !(am * CGG_X3_ASCALE <= CGG_X3A_MAX)) atomicOr(flag, 1);
+    } else {
+      *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+    }
+  }
+  if (yp32) {                  // y + pos (per-token table) as x3a rows, same layout as y32
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(pos + (size_t)i * 8), pb = *reinterpret_cast<const f32x4*>(pos + (size_t)i * 8 + 4);
+    float g2[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g2[k] = f[k] + pa[k];
+      g2[k + 4] = f[k + 4] + pb[k];
+    }
+    cgg_u32x4 h, l;
+    cgg_x3a_encode8(g2, h, l);
+    cgg_u32x4* o = reinterpret_cast<cgg_u32x4*>(yp32 + (size_t)b * y32_bstride + (size_t)i * 8);
+    o[0] = h;
+    o[1] = l;
   }
   if (y16) y16[(size_t)b * y16_bstride + i] = gnh_pack(f);
   if (yp16) {
@@ -297,16 +345,20 @@ extern "C" int64_t cgg_group_norm_nhwc_workspace_bytes(int B, int HW, int groups
   return ((int64_t)B * groups * 2 + (int64_t)B * nblk * groups * 2) * (int64_t)sizeof(float);
 }
 
+int* cgg_x3_overflow_flag_ptr();       // x3s_gemm.hip
+
 static int gnh_launch(bool xf32, const void* x, const float* gamma, const float* beta, void* ws, int B, int HW,
                       int C, int groups, float eps, int relu, const float* up_src, int up_h, int up_w,
                       int64_t up_bstride, int W, float* y32, int64_t y32_bstride, void* y16,
-                      const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
+                      const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream, float* yp32 = nullptr,
+                      int x3a = 0) {
   CGG_REQUIRE(x && gamma && beta && ws, CGG_EINVAL, "cgg_group_norm_nhwc: null pointer");
   CGG_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0, CGG_EINVAL, "cgg_group_norm_nhwc: bad sizes");
   CGG_REQUIRE(C == groups * 8 && groups <= 256 && 256 % groups == 0, CGG_EUNSUPPORTED,
               "cgg_group_norm_nhwc: needs C / groups == 8 and groups | 256 (C=%d, groups=%d)", C, groups);
   CGG_REQUIRE(y32 || y16 || yp16, CGG_EINVAL, "cgg_group_norm_nhwc: no output requested");
-  CGG_REQUIRE(!yp16 || pos, CGG_EINVAL, "cgg_group_norm_nhwc: yp16 needs pos");
+  CGG_REQUIRE((!yp16 && !yp32) || pos, CGG_EINVAL, "cgg_group_norm_nhwc: yp16 / yp32 need pos");
+  CGG_REQUIRE(cgg_aligned16(yp32), CGG_EALIGN, "cgg_group_norm_nhwc: yp32 must be 16-byte aligned");
   CGG_REQUIRE(!up_src || (W > 0 && HW % W == 0 && up_h > 0 && up_w > 0), CGG_EINVAL,
               "cgg_group_norm_nhwc: bad up-sample geometry");
   CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(gamma) && cgg_aligned16(beta) && cgg_aligned16(up_src) &&
@@ -322,14 +374,16 @@ static int gnh_launch(bool xf32, const void* x, const float* gamma, const float*
   else
     hipLaunchKernelGGL(cgg_gn_nhwc_stats_kernel<false>, dim3(nblk, B), dim3(256), 0, s, (const uint4*)x, (float*)ws, HW, groups,
                        GNH_PIX, head);
-  hipLaunchKernelGGL(cgg_gn_nhwc_reduce_kernel, dim3(B * groups), dim3(64), 0, s, (float*)ws, head, nblk, groups, B);
+  const float inv_n = 1.f / ((float)HW * 8.f);
+  hipLaunchKernelGGL(cgg_gn_nhwc_reduce_kernel, dim3(B * groups), dim3(64), 0, s, (float*)ws, head, nblk, groups, B,
+                     xf32 ? (const float*)x : nullptr, HW, inv_n);
   const long long nvec = (long long)HW * groups;
   const dim3 grid((unsigned)((nvec + 255) / 256), B);
-  const float inv_n = 1.f / ((float)HW * 8.f);
 #define GNH_APPLY(UP, XF)                                                                                                   \
   hipLaunchKernelGGL((cgg_gn_nhwc_apply_kernel<UP, XF>), grid, dim3(256), 0, s, (const uint4*)x, (const float*)ws, gamma, beta,  \
                      HW, groups, inv_n, eps, relu, up_src, up_h, up_w, (long long)up_bstride, W, y32, (long long)y32_bstride,  \
-                     (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8))
+                     (uint4*)y16, pos, (uint4*)yp16, (long long)(y16_bstride / 8), yp32, x3a,                                \
+                     (x3a & 1) ? cgg_x3_overflow_flag_ptr() : nullptr)
   if (up_src && xf32) GNH_APPLY(true, true);
   else if (up_src) GNH_APPLY(true, false);
   else if (xf32) GNH_APPLY(false, true);
@@ -353,4 +407,16 @@ extern "C" int cgg_group_norm_nhwc_f32(const float* x, const float* gamma, const
                                        const float* pos, void* yp16, int64_t y16_bstride, cgg_stream_t stream) {
   return gnh_launch(true, x, gamma, beta, ws, B, HW, C, groups, eps, relu, up_src, up_h, up_w, up_bstride, W, y32, y32_bstride,
                     y16, pos, yp16, y16_bstride, stream);
+}
+
+// Parity mode's stream (round 4): GroupNorm over an f32 map with the output(s) written as x3a rows (csrc/x3.h) -- the A operand
+// of the next x3 GEMM / the encoder's residual stream -- y = GN(x) (+ up-sample(up_src), ReLU) and, optionally, yp = y + pos (the
+// first encoder layer's `query + query_pos` rows). up_src is itself an x3a map (the encoder's finest memory level).
+extern "C" int cgg_group_norm_nhwc_f32_x3a(const float* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C,
+                                           int groups, float eps, int relu, const void* up_src_x3a, int up_h, int up_w,
+                                           int64_t up_bstride, int W, void* y_x3a, int64_t y_bstride, const float* pos,
+                                           void* yp_x3a, cgg_stream_t stream) {
+  CGG_REQUIRE(y_x3a, CGG_EINVAL, "cgg_group_norm_nhwc_f32_x3a: null output");
+  return gnh_launch(true, x, gamma, beta, ws, B, HW, C, groups, eps, relu, (const float*)up_src_x3a, up_h, up_w, up_bstride, W,
+                    (float*)y_x3a, y_bstride, nullptr, pos, nullptr, 0, stream, (float*)yp_x3a, up_src_x3a ? 3 : 1);
 }

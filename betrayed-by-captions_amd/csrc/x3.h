@@ -90,3 +90,53 @@ static inline CggX3W cgg_x3_view(const void* packed, int N, int K) {
   w.scale = packed ? (const float*)(w.hi + 2 * frags) : nullptr;
   return w;
 }
+
+// ---- "x3a" rows: activations STORED pre-split (round 4) -------------------------------------------------------------------
+// A channel-last f32 tensor whose rows are consumed by the x3 GEMM is kept in HBM in the form the MFMA wants: every group of 8
+// consecutive channels (32 bytes) holds [8 x f16 hi | 8 x f16 lo] of the PRE-SCALED values a' = 16 a (hi = f16(a'), lo =
+// f16(a' - hi)) instead of 8 floats -- same bytes, same addressing ((row * ld + channel) * 4 for channel % 8 == 0), so a
+// 32-channel K chunk of a row is still one 128-byte line and goes HBM -> LDS by `buffer_load ... lds` with no conversion in
+// the GEMM loop (csrc/x3s_gemm.hip). The GEMM result is bit-identical to splitting an f32 row in the kernel (the split IS what
+// the kernel did); other consumers (residual adds, LayerNorm, up-sampling) read hi + lo, which carries 22 significant bits.
+// Range: |a| < 4094 (f16 overflow of the pre-scaled value); producers raise the overflow flag (cgg_x3_overflow_flag).
+__device__ __forceinline__ void cgg_x3a_split8_prescaled(const float* s, cgg_u32x4& hi, cgg_u32x4& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cgg_x3_split2(s[2 * k], s[2 * k + 1], h[k], l[k]);
+  hi = cgg_u32x4{h[0], h[1], h[2], h[3]};
+  lo = cgg_u32x4{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ void cgg_x3a_encode8(const float* f, cgg_u32x4& hi, cgg_u32x4& lo) {
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = f[k] * CGG_X3_ASCALE;
+  cgg_x3a_split8_prescaled(s, hi, lo);
+}
+// -> the PRE-SCALED values 16 a (exact: hi + lo has <= 23 significant bits)
+__device__ __forceinline__ void cgg_x3a_decode8_prescaled(const cgg_u32x4 hi, const cgg_u32x4 lo, float* s) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // (the element is copied to a scalar first: __builtin_bit_cast applied to the vector-element lvalue `hi[k]` read element 0
+    // for every k with hipcc 7.2)
+    const uint32_t hk = hi[k], lk = lo[k];
+    const cgg_f32x2 h = __builtin_convertvector(__builtin_bit_cast(f16x2, hk), cgg_f32x2);
+    const cgg_f32x2 l = __builtin_convertvector(__builtin_bit_cast(f16x2, lk), cgg_f32x2);
+    s[2 * k] = h[0] + l[0];
+    s[2 * k + 1] = h[1] + l[1];
+  }
+}
+__device__ __forceinline__ void cgg_x3a_decode8(const cgg_u32x4 hi, const cgg_u32x4 lo, float* f) {
+  cgg_x3a_decode8_prescaled(hi, lo, f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] *= CGG_X3_INV_ASCALE;
+}
+// 4 channels (half a group): 8-byte halves of the hi and lo pieces
+__device__ __forceinline__ void cgg_x3a_decode4(const uint2 hi, const uint2 lo, f32x4& f) {
+  const cgg_f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(f16x2, hi.x), cgg_f32x2);
+  const cgg_f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(f16x2, lo.x), cgg_f32x2);
+  const cgg_f32x2 h1 = __builtin_convertvector(__builtin_bit_cast(f16x2, hi.y), cgg_f32x2);
+  const cgg_f32x2 l1 = __builtin_convertvector(__builtin_bit_cast(f16x2, lo.y), cgg_f32x2);
+  f = f32x4{h0[0] + l0[0], h0[1] + l0[1], h1[0] + l1[0], h1[1] + l1[1]} * CGG_X3_INV_ASCALE;
+}
+// largest finite pre-scaled magnitude: beyond it the hi piece is inf
+#define CGG_X3A_MAX 65504.0f

@@ -26,7 +26,7 @@ __device__ __forceinline__ int xa_kswz(int key, int slot) { return slot ^ ((key 
 __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
     const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
     float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S, int words, int KC,
-    int nchunks, float scale, float* __restrict__ out_direct, float* __restrict__ lse) {
+    int nchunks, float scale, float* __restrict__ out_direct, float* __restrict__ lse, int ldkv, long long kv_bstride) {
   constexpr int D = 32;
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
 
-  const float* kvb = kv + (size_t)b * S * (2 * HD) + h * D;
+  const float* kvb = kv + (size_t)b * kv_bstride + h * D;      // rows [K | V] at stride ldkv (a column slice of a merged projection)
   // K / V tile: 64 keys x 128 B each; thread = 16-B chunk (2 per operand). The loads of tile t + 1 are issued BEFORE the MFMAs of
   // tile t and held in registers (branch-free: keys past the chunk re-read its last key and are zeroed): the memory latency of a
   // tile -- paid in full, twice, by the predicated load -> LDS loop this replaces -- hides under ~4 000 cycles of f32 MFMAs
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
       const int c = tid + 256 * it;
       const int key = c >> 3, slot = c & 7;
       const int s = min(s0 + key, s_end - 1);
-      const float* row = kvb + (size_t)s * (2 * HD) + slot * 4;
+      const float* row = kvb + (size_t)s * ldkv + slot * 4;
       kx[it] = *reinterpret_cast<const f32x4*>(row);
       vx[it] = *reinterpret_cast<const f32x4*>(row + HD);
     }
@@ -592,7 +592,12 @@ extern "C" int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, 
 }
 
 static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse, void* ws, int B,
-                             int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream) {
+                             int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream, int ldkv = 0,
+                             int64_t kv_bstride = 0) {
+  if (ldkv <= 0) ldkv = 2 * H * D;
+  if (kv_bstride <= 0) kv_bstride = (int64_t)S * ldkv;
+  CGG_REQUIRE(ldkv >= 2 * H * D && ldkv % 4 == 0 && kv_bstride % 4 == 0, CGG_EINVAL,
+              "cgg_masked_xattn_forward: ldkv=%d / kv_bstride=%lld", ldkv, (long long)kv_bstride);
   CGG_REQUIRE(q && kv && out && ws, CGG_EINVAL, "cgg_masked_xattn_forward: null pointer");
   CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_forward: bad sizes");
   CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward: head dim %d (only 32 is built)", D);
@@ -611,7 +616,7 @@ static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bit
   const size_t lds = (size_t)2 * XA_TK * D * sizeof(float) + (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
-                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse);
+                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
   if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 0, lse);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
@@ -622,6 +627,14 @@ extern "C" int cgg_masked_xattn_forward(const float* q, const void* kv, const ui
                                         float* out, void* ws, int B, int Q, int H, int D, int S,
                                         float scale, int kv_dtype, cgg_stream_t stream) {
   return xattn_forward_f32(q, kv, bits, out, nullptr, ws, B, Q, H, D, S, scale, kv_dtype, stream);
+}
+
+// kv rows at stride ldkv elements, images at kv_bstride: layer j's [K | V] as a 2 E-column slice of the merged projection of the
+// decoder layers that read one level (round 4: one x3 GEMM per level instead of one per layer and image)
+extern "C" int cgg_masked_xattn_forward_strided(const float* q, const float* kv, int ldkv, int64_t kv_bstride, const uint32_t* bits,
+                                                float* out, void* ws, int B, int Q, int H, int D, int S, float scale,
+                                                cgg_stream_t stream) {
+  return xattn_forward_f32(q, kv, bits, out, nullptr, ws, B, Q, H, D, S, scale, CGG_F32, stream, ldkv, kv_bstride);
 }
 
 extern "C" int cgg_masked_xattn_forward_lse(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse,

@@ -666,17 +666,25 @@ class Mask2FormerHeadOpen(nn.Module):
             mask_features = None
             H4, W4 = int(mf.shape[1]), int(mf.shape[2])
             pools = []
+            x3a_mem = all(ops.is_x3a(m) for m in memorys[:L])
             for i in range(L):
                 h, w = level_hw[i]
                 sizes.append((h, w))
-                mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
-                poss.append(self.decoder_positional_encoding.flat_unpadded(h, w, mf.device))
+                if not x3a_mem:
+                    mems.append(memorys[i] + self.level_embed.weight[i].view(1, 1, -1))
+                    poss.append(self.decoder_positional_encoding.flat_unpadded(h, w, mf.device))
                 s = H4 // h
                 pools.append(s if (h * s == H4 and w * s == W4 and s in (2, 4, 8)) else None)
             uniq = [1] + sorted({p for p in pools if p is not None})
             packed = dict(zip(uniq, ops.pack_mask_feature_nhwc_x3(mf, uniq)))
             packed_full, pooled = packed[1], [packed[p] if p is not None else None for p in pools]
+            if x3a_mem:
+                # round 4: the memories are x3a rows -- ONE LDS-DMA GEMM per level projects the K / V of every decoder layer that
+                # reads it (level embedding, key position and biases folded into a per-token table)
+                kvs = self._project_kv_x3a(memorys, sizes)
+                return dict(stream=True, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled, mask_features=None)
         else:
+            feats = [ops.x3a_to_f32(f) if ops.is_x3a(f) else f for f in feats]       # x3a backbone maps outside the x3 stream
             feats = [f.float().contiguous() if f.dtype != torch.float32 else f for f in feats]
             mask_features, memorys = pd(feats)
             mask_features = mask_features.contiguous()
@@ -718,6 +726,46 @@ class Mask2FormerHeadOpen(nn.Module):
                      and self.query_embed.weight.shape[1] % 32 == 0)
         return dict(stream=x3_stream, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled,
                     mask_features=mask_features)
+
+    def _project_kv_x3a(self, memorys, sizes):
+        """[K | V] of every decoder layer from the x3a encoder memories (`MSDeformAttnPixelDecoder._forward_stream_x3a`): per
+        level ONE `ops.gemm_x3s` over the (B, hw, C) rows against the stacked in_proj key / value weights of the layers that read
+        the level (layer i reads level i % L, mask2former_head.py:829-840). What the reference adds to the memory before the
+        projection -- the level embedding (:806) and, for the keys, the positional encoding (key_pos, :834) -- and the biases are
+        input-independent: they are folded through the weights into a per-token table (hw, n_layers * 2E) that rides in the GEMM's
+        row-periodic residual. -> list over layers of (B, hw, 2E) f32 column slices of the level's output (read through
+        `cgg_masked_xattn_forward_strided`)."""
+        layers = self.transformer_decoder.layers
+        L, nl = self.num_transformer_feat_level, self.num_transformer_decoder_layers
+        kvs = [None] * nl
+        for lvl in range(L):
+            idx = list(range(lvl, nl, L))
+            attns = [layers[i].attentions[0] for i in idx]
+            h, w = sizes[lvl]
+            mem = memorys[lvl].as_subclass(torch.Tensor)
+            B = mem.shape[0]
+            pos = self.decoder_positional_encoding.flat_unpadded(h, w, mem.device)
+            E = attns[0].embed_dims
+
+            def make(attns=attns, pos=pos, lvl=lvl, E=E):
+                le = self.level_embed.weight[lvl].double()
+                ws, tabs = [], []
+                for a in attns:
+                    w_kv, b_kv = a.kv_weight()
+                    wd, bd = w_kv.double(), b_kv.double()
+                    kb = (pos.double() + le) @ wd[:E].t() + bd[:E]
+                    vb = (le @ wd[E:].t() + bd[E:]).expand(pos.shape[0], E)
+                    ws.append(w_kv.float())
+                    tabs.append(torch.cat([kb, vb], 1))
+                return ops.pack_linear_weight_x3(torch.cat(ws, 0).contiguous()), torch.cat(tabs, 1).float().contiguous()
+
+            params = tuple(p for a in attns for p in (a.attn.in_proj_weight, a.attn.in_proj_bias)) + (self.level_embed.weight, pos)
+            wk, table = runtime.derived_cached('kv_stack_x3a', params, make)
+            nout = table.shape[1]
+            kv_all = ops.gemm_x3s(mem, wk, nout, None, res=table, res_mod=h * w).view(B, h * w, nout)
+            for j, i in enumerate(idx):
+                kvs[i] = kv_all[:, :, j * 2 * E:(j + 1) * 2 * E]
+        return kvs
 
     def _decode(self, enc, B, all_masks=True):
         """The query side: 1 + 9 `forward_head` calls and the 9 decoder layers on the encoded memories."""

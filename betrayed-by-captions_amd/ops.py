@@ -368,7 +368,6 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
     H = int(num_heads)
     D = E // H
     dev_ptr(q, 'q', torch.float32)       # refuses CPU tensors before any torch.cuda call
-    dev_ptr(kv, 'kv', torch.float32)
     if kv.shape[2] != 2 * E:
         raise CggError(f'masked_xattn: kv last dim {kv.shape[2]} != 2*{E}')
     if scale is None:
@@ -376,6 +375,16 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
     lib = _lib_()
     ws = _xattn_ws(lib.cgg_masked_xattn_workspace_bytes, q, B, Q, H, D, S)
     out = torch.empty((B, Q, E), dtype=torch.float32, device=q.device)
+    if not kv.is_contiguous() and not return_lse:
+        # a column slice of the merged [K | V] projection of the layers that read one level: rows / images at their strides
+        if not kv.is_cuda or kv.dtype != torch.float32 or kv.stride(2) != 1:
+            raise CggError('masked_xattn: a strided kv must be a float32 ROCm tensor with a contiguous last dim')
+        rc = lib.cgg_masked_xattn_forward_strided(dev_ptr(q, 'q', torch.float32), ctypes.c_void_p(kv.data_ptr()), kv.stride(1),
+                                                  kv.stride(0), dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(ws), B, Q,
+                                                  H, D, S, float(scale), stream_ptr(q.device))
+        check(rc, 'cgg_masked_xattn_forward_strided')
+        return out
+    dev_ptr(kv, 'kv', torch.float32)
     if return_lse:
         lse = torch.empty((B, H, Q), dtype=torch.float32, device=q.device)
         rc = lib.cgg_masked_xattn_forward_lse(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
@@ -980,6 +989,27 @@ def group_norm_nhwc(x, gamma, beta, groups, eps, ws, relu=False, up=None, W=0, o
     check(rc, 'cgg_group_norm_nhwc')
 
 
+def group_norm_nhwc_x3a(x, gamma, beta, groups, eps, ws, out, relu=False, up=None, W=0, pos=None, outp=None):
+    """GroupNorm of a channel-last F32 map x (B, HW, C) with the result written as x3a rows (csrc/x3.h):
+      out  = (tensor, element offset, batch stride) destination of y (may alias x);
+      outp = (tensor, element offset) destination of y + pos (same batch stride), pos = (f32 tensor, element offset) rows [HW, C];
+      up   = (x3a tensor, element offset, batch stride, h, w): low-res x3a map, bilinearly up-sampled and added before the ReLU."""
+    B, HW, C = x.shape
+    if x.dtype != torch.float32:
+        raise CggError(f'group_norm_nhwc_x3a: x dtype {x.dtype}')
+    need = _lib_().cgg_group_norm_nhwc_workspace_bytes(B, HW, int(groups))
+    if ws is None or ws.numel() * ws.element_size() < need:
+        raise CggError(f'group_norm_nhwc_x3a: workspace too small ({need} bytes needed; see group_norm_nhwc_workspace)')
+    rc = _lib_().cgg_group_norm_nhwc_f32_x3a(
+        dev_ptr(x, 'x', torch.float32), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32),
+        dev_ptr(ws, 'ws', torch.float32), B, HW, C, int(groups), float(eps), int(bool(relu)),
+        _ptr_at(up[0], up[1]) if up is not None else None, up[3] if up is not None else 0,
+        up[4] if up is not None else 0, up[2] if up is not None else 0, int(W),
+        _ptr_at(out[0], out[1]), out[2], _ptr_at(pos[0], pos[1]) if pos is not None else None,
+        _ptr_at(outp[0], outp[1]) if outp is not None else None, stream_ptr(x.device))
+    check(rc, 'cgg_group_norm_nhwc_f32_x3a')
+
+
 def pack_mask_feature_nhwc(feat, pool=1):
     """feat (B, H, W, C) bf16 channel-last -> PackedFeature (hi image only; throughput mode)."""
     B, H, W, C = feat.shape
@@ -1100,10 +1130,10 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
     return y
 
 
-def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False):
+def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False, x3a=False):
     """Parity mode's encoder layer tail in ONE launch: a (attention rows), x (layer input) (..., 256) f32 ->
     y = LN1(x1 + FFN(x1)), x1 = LN0(x + a Wo^T + bo) (and y + pos[row % len(pos)] when want_pos); wo / w1 / w2 x3 images,
-    norm_* = (gamma, beta, eps)."""
+    norm_* = (gamma, beta, eps). x3a=True: x and both outputs are x3a rows (csrc/x3.h), a stays f32."""
     C = a.shape[-1]
     M = a.numel() // C
     for t in (a, x):
@@ -1116,7 +1146,7 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     yp = torch.empty_like(a) if want_pos else None
     with _timed('encoder_tail_x3', flops=2.0 * M * (C * C + 2 * C * F), bytes=4.0 * M * C * (3 + (1 if want_pos else 0)),
                 shape=(M, C, F)):
-        rc = _lib_().cgg_encoder_layer_tail_x3(
+        rc = (_lib_().cgg_encoder_layer_tail_x3a if x3a else _lib_().cgg_encoder_layer_tail_x3)(
             dev_ptr(a), dev_ptr(x), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32),
             dev_ptr(norm0[1], 'beta0', torch.float32), float(norm0[2]), dev_ptr(w1), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2),
             dev_ptr(b2, 'b2', torch.float32), dev_ptr(norm1[0], 'gamma1', torch.float32), dev_ptr(norm1[1], 'beta1', torch.float32),
@@ -1163,6 +1193,120 @@ def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, rel
         rc = _lib_().cgg_conv_x3_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res), dev_ptr(y),
                                       B, H, W, C, N, KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
     check(rc, 'cgg_conv_x3_nhwc')
+    return y
+
+
+# ---- round 4: pre-split activation rows ("x3a", csrc/x3.h) and the LDS-DMA GEMM that consumes them (csrc/x3s_gemm.hip) ----
+X3A_F32, X3A_SPLIT = 1, 2
+
+
+class X3ATensor(torch.Tensor):
+    """float32-tagged tensor whose storage holds x3a rows (csrc/x3.h: per 8 channels [8 f16 hi | 8 f16 lo] of 16 x): the marker
+    the stream modules hand each other (a ResNet's parity-mode outputs, the encoder memories). Views keep the tag; arithmetic on
+    it is meaningless -- `x3a_to_f32` gives the values."""
+
+
+def is_x3a(t):
+    return isinstance(t, X3ATensor)
+
+
+def as_x3a(t):
+    return t.as_subclass(X3ATensor)
+
+
+def x3a_to_f32(t):
+    """values of an x3a-tagged tensor whose channel dim is contiguous in memory (e.g. the (B, C, H, W)-shaped permuted view of a
+    channel-last map) -> plain float32 tensor of the same shape."""
+    base = t.as_subclass(torch.Tensor)
+    if base.dim() == 4 and base.stride(1) == 1 and not base.is_contiguous():      # (B, C, H, W) view of (B, H, W, C)
+        return x3a_decode(base.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+    return x3a_decode(base.contiguous())
+
+
+def x3a_encode(x):
+    """f32 tensor (contiguous, numel % 8 == 0, channel groups of 8 contiguous) -> x3a tensor of the same shape / dtype tag
+    (float32 storage holding [8 f16 hi | 8 f16 lo] of 16 x per group)."""
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.numel() % 8:
+        raise CggError('x3a_encode: contiguous float32 ROCm tensor with numel % 8 == 0 expected')
+    y = torch.empty_like(x)
+    check(_lib_().cgg_x3a_encode(dev_ptr(x), dev_ptr(y), x.numel(), stream_ptr(x.device)), 'cgg_x3a_encode')
+    return y
+
+
+def x3a_decode(x):
+    """x3a tensor -> the f32 values it stands for (22 significant bits)."""
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.numel() % 8:
+        raise CggError('x3a_decode: contiguous float32-tagged ROCm tensor with numel % 8 == 0 expected')
+    y = torch.empty_like(x)
+    check(_lib_().cgg_x3a_decode(dev_ptr(x), dev_ptr(y), x.numel(), stream_ptr(x.device)), 'cgg_x3a_decode')
+    return y
+
+
+def x3_overflow_check(device, reset=True):
+    """-> True if an x3a producer on `device` has stored a value outside f16's range (|a| >= 4094) since the last reset.
+    Synchronises the current stream."""
+    v = ctypes.c_int(0)
+    with torch.cuda.device(device):
+        check(_lib_().cgg_x3_overflow_check(int(bool(reset)), ctypes.byref(v), stream_ptr(device)), 'cgg_x3_overflow_check')
+    return v.value != 0
+
+
+def _x3s_fmt(split):
+    return X3A_SPLIT if split else X3A_F32
+
+
+def gemm_x3s(a, packed, N, bias=None, res=None, res_split=False, res_mod=0, relu=False, out=None, out_split=False):
+    """a (M, K) x3a rows (row stride free, multiples of 8) x x3 image -> act(a W^T + bias (+ res)) (M, N), f32 or x3a
+    (`out_split`); res (M, N) | (res_mod, N) in f32 or x3a (`res_split`). csrc/x3s_gemm.hip."""
+    if a.dim() not in (2, 3) or a.stride(-1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
+        raise CggError('gemm_x3s: a must be a 2-D / 3-D float32-tagged ROCm tensor with a contiguous last dim, packed an x3 image')
+    rpb, bstride = 0, 0
+    if a.dim() == 3:                    # (B, R, K) view of a stack of images (row stride and image stride free): rows = B * R
+        rpb, bstride = int(a.shape[1]), int(a.stride(0))
+        M, K, lda = a.shape[0] * a.shape[1], a.shape[2], int(a.stride(1))
+    else:
+        (M, K), lda = a.shape, int(a.stride(0))
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
+        raise CggError('gemm_x3s: bad `out` view')
+    if res is not None and (res.dim() != 2 or res.stride(1) != 1 or res.shape != ((res_mod or M), N) or res.dtype != torch.float32):
+        raise CggError('gemm_x3s: bad `res` view')
+    with _timed('gemm_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * K + M * N * (2 if res is not None and not res_mod else 1)) +
+                4.0 * N * K, shape=(M, N, K)):
+        rc = _lib_().cgg_gemm_x3s_batched(ctypes.c_void_p(a.data_ptr()), lda, rpb, bstride, dev_ptr(packed),
+                                          dev_ptr(bias, 'bias', torch.float32),
+                                          ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                          res.stride(0) if res is not None else 0,
+                                          0 if res is None else _x3s_fmt(res_split), int(res_mod), ctypes.c_void_p(y.data_ptr()),
+                                          y.stride(0), _x3s_fmt(out_split), M, N, K, int(bool(relu)), stream_ptr(a.device)) \
+            if rpb else \
+            _lib_().cgg_gemm_x3s(ctypes.c_void_p(a.data_ptr()), lda, dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                 ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                 res.stride(0) if res is not None else 0,
+                                 0 if res is None else _x3s_fmt(res_split), int(res_mod), ctypes.c_void_p(y.data_ptr()),
+                                 y.stride(0), _x3s_fmt(out_split), M, N, K, int(bool(relu)), stream_ptr(a.device))
+    check(rc, 'cgg_gemm_x3s')
+    return y
+
+
+def conv_x3s_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, res_split=True, relu=False, out_split=True):
+    """x (B, H, W, C) x3a channel-last -> act(conv + bias (+ res)) (B, OH, OW, N), x3a (default) or f32: implicit GEMM on the
+    x3 image made by `pack_conv_weight_x3` (C % 32 == 0)."""
+    if x.dim() != 4 or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda or not is_x3(packed):
+        raise CggError('conv_x3s_nhwc: x must be a contiguous (B, H, W, C) float32-tagged ROCm tensor, packed an x3 image')
+    B, H, W, C = x.shape
+    KH, KW = (kernel, kernel) if isinstance(kernel, int) else kernel
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = torch.empty((B, OH, OW, N), dtype=torch.float32, device=x.device)
+    if res is not None and (tuple(res.shape) != (B, OH, OW, N) or not res.is_contiguous() or res.dtype != torch.float32):
+        raise CggError('conv_x3s_nhwc: res must be a contiguous (B, OH, OW, N) float32-tagged tensor')
+    with _timed('gemm_x3', flops=2.0 * B * OH * OW * N * C * KH * KW,
+                bytes=4.0 * (B * H * W * C + B * OH * OW * N * (2 if res is not None else 1) + N * C * KH * KW),
+                shape=(B * OH * OW, N, C * KH * KW)):
+        rc = _lib_().cgg_conv_x3s_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res),
+                                       0 if res is None else _x3s_fmt(res_split), dev_ptr(y), _x3s_fmt(out_split), B, H, W, C, N,
+                                       KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
+    check(rc, 'cgg_conv_x3s_nhwc')
     return y
 
 
@@ -1580,13 +1724,14 @@ def stem_conv7x7_x3(img, packed, wscale):
     return y
 
 
-def bias_relu_maxpool_nhwc_f32(x, bias):
-    """x (B, H, W, C) channel-last F32 raw convolution output -> relu(maxpool3x3/s2/p1(x) + bias) (B, Ho, Wo, C) f32."""
+def bias_relu_maxpool_nhwc_f32(x, bias, x3a=False):
+    """x (B, H, W, C) channel-last F32 raw convolution output -> relu(maxpool3x3/s2/p1(x) + bias) (B, Ho, Wo, C) f32, or the
+    same map as x3a rows (`x3a=True`: the layout the x3s convolutions consume)."""
     B, H, W, C = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    rc = _lib_().cgg_bias_relu_maxpool_nhwc_f32(dev_ptr(x, 'x', torch.float32), dev_ptr(bias, 'bias', torch.float32), dev_ptr(y),
-                                                B, H, W, C, stream_ptr(x.device))
+    fn = _lib_().cgg_bias_relu_maxpool_nhwc_f32_x3a if x3a else _lib_().cgg_bias_relu_maxpool_nhwc_f32
+    rc = fn(dev_ptr(x, 'x', torch.float32), dev_ptr(bias, 'bias', torch.float32), dev_ptr(y), B, H, W, C, stream_ptr(x.device))
     check(rc, 'cgg_bias_relu_maxpool_nhwc_f32')
     return y
 

@@ -813,6 +813,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
         oc = self.output_convs[0].conv
         if tuple(oc.kernel_size) != (3, 3) or tuple(oc.stride) != (1, 1) or tuple(oc.padding) != (1, 1):
             return False
+        # the stream runs the input / lateral / mask-feature convolutions as row GEMMs on `weight.flatten(1)`: 1 x 1, stride 1,
+        # ungrouped only (a custom config with anything else takes the module path)
+        for c in [cm.conv for cm in list(self.input_convs) + list(self.lateral_convs)] + [self.mask_feature, oc]:
+            if c.groups != 1 or tuple(c.dilation) != (1, 1):
+                return False
+            if c is not oc and (tuple(c.kernel_size) != (1, 1) or tuple(c.stride) != (1, 1) or tuple(c.padding) != (0, 0)):
+                return False
         return all(tuple(l.operation_order) == ('self_attn', 'norm', 'ffn', 'norm') and self._stream_ok(l)
                    and isinstance(l.norms[0], nn.LayerNorm) and l.attentions[0].embed_dims == 256 for l in self.encoder.layers)
 
@@ -866,11 +873,88 @@ class MSDeformAttnPixelDecoder(nn.Module):
             src = ops.add_layernorm_stream(y, None, n1.weight, n1.bias, n1.eps, want_bf16=False)[0]
         return src
 
+    def _encoder_stream_x3a(self, src, srcp, pos, ref, level_hw, level_start):
+        """Round 4 form of `_encoder_stream_x3`: the residual stream `src` and `srcp = src + pos` are x3a rows (csrc/x3.h). Per
+        layer: value / offsets+weights projections on the LDS-DMA GEMM (A = the rows as stored, f32 out for the gather), the f32
+        MSDeformAttn kernel, `encoder_layer_tail_x3` reading / writing x3a rows."""
+        B, N, C = src.shape
+        x3w = lambda lin: runtime.derived_cached('x3_image', (lin.weight,), lambda: ops.pack_linear_weight_x3(lin.weight))
+        for layer in self.encoder.layers:
+            attn = layer.attentions[0]
+            H = attn.num_heads
+            so, aw = attn.sampling_offsets, attn.attention_weights
+            w_cat = runtime.derived_cached('msda_wcat32', (so.weight, aw.weight),
+                                           lambda: torch.cat([so.weight, aw.weight], 0).float().contiguous())
+            b_cat = runtime.derived_cached('msda_bcat32', (so.bias, aw.bias),
+                                           lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
+            value = runtime.linear_x3s(src.view(B * N, C), attn.value_proj.weight, attn.value_proj.bias).view(B, N, H, C // H)
+            offs = runtime.linear_x3s(srcp.view(B * N, C), w_cat, b_cat).view(B, N, -1)
+            a = ops.msda_forward_fused(value, level_hw, level_start, offs, ref, attn.num_points)
+            n0, n1 = layer.norms
+            fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
+            last = layer is self.encoder.layers[-1]
+            src, srcp = ops.encoder_layer_tail_x3(a, src, x3w(attn.output_proj), attn.output_proj.bias,
+                                                  (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
+                                                  (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True)
+        return src
+
+    def _forward_stream_x3a(self, feats):
+        """`forward_stream_x3` on x3a rows: the backbone maps arrive as x3a (`ops.X3ATensor`; plain f32 maps are encoded), every
+        GEMM-consumed tensor of the stream stays x3a -- GroupNorm / the encoder tail write it, the LDS-DMA GEMMs read it -- and
+        only the tensors a non-GEMM kernel gathers from (MSDeformAttn's value / offsets, the mask feature) are f32. The memories
+        come back as x3a-tagged (B, hw_l, C) views."""
+        B = feats[0].shape[0]
+        dev = feats[0].device
+        C = 256
+        rows = lambda f: (f if ops.is_x3a(f) else ops.x3a_encode(f.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)) \
+            .as_subclass(torch.Tensor).permute(0, 2, 3, 1).reshape(-1, f.shape[1])
+        level_hw = []
+        for i in range(self.num_encoder_levels):
+            f = feats[self.num_input_levels - i - 1]
+            level_hw.append((int(f.shape[2]), int(f.shape[3])))
+        level_start, N = [], 0
+        for h, w in level_hw:
+            level_start.append(N)
+            N += h * w
+        pos = self._pos_cached(level_hw, dev)
+        ref = self._reference_points(level_hw, dev)
+        src = torch.empty((B, N, C), dtype=torch.float32, device=dev)      # x3a rows
+        srcp = torch.empty((B, N, C), dtype=torch.float32, device=dev)     # src + pos, x3a rows (the first layer's offsets input)
+        ws = ops.group_norm_nhwc_workspace(B, int(feats[0].shape[2]) * int(feats[0].shape[3]), 32, dev)   # largest map
+        for i in range(self.num_encoder_levels):
+            f = feats[self.num_input_levels - i - 1]
+            h, w = level_hw[i]
+            cm = self.input_convs[i]
+            y = runtime.linear_x3s(rows(f), cm.conv.weight.flatten(1), cm.conv.bias)
+            gn = getattr(cm, cm.norm_name)
+            ops.group_norm_nhwc_x3a(y.view(B, h * w, C), gn.weight, gn.bias, 32, gn.eps, ws, out=(src, level_start[i] * C, N * C),
+                                    pos=(pos, level_start[i] * C), outp=(srcp, level_start[i] * C))
+        src = self._encoder_stream_x3a(src, srcp, pos, ref, level_hw, level_start)
+        mems = [ops.as_x3a(src[:, s0:s0 + h * w, :]) for s0, (h, w) in zip(level_start, level_hw)]
+        # FPN: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN + ReLU, mask_feature
+        f = feats[0]
+        H4, W4 = int(f.shape[2]), int(f.shape[3])
+        lat, outc = self.lateral_convs[0], self.output_convs[0]
+        y = runtime.linear_x3s(rows(f), lat.conv.weight.flatten(1), lat.conv.bias).view(B, H4 * W4, C)
+        gn = getattr(lat, lat.norm_name)
+        hl, wl = level_hw[-1]
+        ops.group_norm_nhwc_x3a(y, gn.weight, gn.bias, 32, gn.eps, ws, out=(y, 0, H4 * W4 * C),
+                                up=(src, level_start[-1] * C, N * C, hl, wl), W=W4)                    # y: f32 -> x3a in place
+        w3 = runtime.derived_cached('x3_conv_image', (outc.conv.weight,), lambda: ops.pack_conv_weight_x3(outc.conv.weight))
+        z = ops.conv_x3s_nhwc(y.view(B, H4, W4, C), w3, C, 3, 1, 1, outc.conv.bias, out_split=False).view(B, H4 * W4, C)
+        gn = getattr(outc, outc.norm_name)
+        ops.group_norm_nhwc_x3a(z, gn.weight, gn.bias, 32, gn.eps, ws, out=(z, 0, H4 * W4 * C), relu=True)
+        mf = runtime.linear_x3s(z.view(B * H4 * W4, C), self.mask_feature.weight.flatten(1), self.mask_feature.bias)
+        return mf.view(B, H4, W4, -1), mems, level_hw
+
     def forward_stream_x3(self, feats):
         """-> (mask_feature (B, H4, W4, C) f32 channel-last, [memories (B, hw_l, C) f32 low->high res], level sizes). 1x1
         convolutions are x3 GEMMs on the (B*H*W, C) views, the 3x3 output convolution the x3 implicit GEMM, every GroupNorm the
         channel-last kernel on f32 input (the three encoder inputs normalised straight into the (B, N, C) stream, the FPN's
         `cur + up-sample(out)` in the GroupNorm's epilogue)."""
+        if runtime.x3a_enabled():
+            return self._forward_stream_x3a(feats)
+        feats = [ops.x3a_to_f32(f) if ops.is_x3a(f) else f for f in feats]
         B = feats[0].shape[0]
         dev = feats[0].device
         C = 256
@@ -913,6 +997,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return mf.view(B, H4, W4, -1), mems, level_hw
 
     def forward(self, feats):
+        feats = [ops.x3a_to_f32(f) if ops.is_x3a(f) else f for f in feats]           # x3a backbone maps (parity-mode ResNet)
         B = feats[0].shape[0]
         dev = feats[0].device
         srcs, poss, level_hw = [], [], []

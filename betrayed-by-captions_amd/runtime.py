@@ -38,11 +38,24 @@ def is_bf16():
     return _STATE['precision'] == 'bf16'
 
 
+import os as _os
+
+# read once at import (the hot path called os.environ.get per linear)
+_X3 = _os.environ.get('CGG_X3', '1') != '0'
+_X3A = _os.environ.get('CGG_X3A', '1') != '0'
+
+
 def x3_enabled():
     """Parity mode on the f32-class f16 x 3 kernels (csrc/x3.h); CGG_X3=0 restores the round-2 parity path (f32 library
     GEMMs, f32-MFMA skinny linears) for A/B measurements."""
-    import os
-    return _STATE['precision'] == 'fp32' and os.environ.get('CGG_X3', '1') != '0'
+    return _STATE['precision'] == 'fp32' and _X3
+
+
+def x3a_enabled():
+    """Round 4: the parity-mode inference stream keeps its GEMM-consumed activations as pre-split x3a rows (csrc/x3.h) and runs
+    the LDS-DMA GEMM / implicit-GEMM convolution of csrc/x3s_gemm.hip; CGG_X3A=0 restores round 3's f32 stream (cgg_gemm_x3) for
+    A/B measurements."""
+    return x3_enabled() and _X3A
 
 
 @contextlib.contextmanager
@@ -160,6 +173,18 @@ def x3_linear_ok(x, weight):
     """parity mode, no autograd, ROCm f32 rows whose K the x3 GEMM tiles (K % 32 == 0), enough rows to be worth a tile grid."""
     return (x3_enabled() and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
             and weight.shape[1] % 32 == 0 and x.shape[-1] == weight.shape[1] and x.numel() // x.shape[-1] >= 512)
+
+
+def linear_x3s(x, weight, bias=None, res=None, res_split=False, res_mod=0, relu=False, out=None, out_split=False):
+    """act(x W^T + b (+ res)) on the LDS-DMA x3 GEMM (`ops.gemm_x3s`): x = x3a rows (..., K) (2-D, or a 3-D (B, R, K) view of a
+    stack of images), result f32 or x3a (`out_split`), the weight's x3 image cached like `packed_cached`."""
+    from . import ops
+    N, K = weight.shape
+    x2 = x if x.dim() <= 3 else x.reshape(-1, K)
+    wk = derived_cached('x3_image', (weight,), lambda: ops.pack_linear_weight_x3(weight))
+    y = ops.gemm_x3s(x2, wk, N, bias.detach() if bias is not None else None, res=res, res_split=res_split, res_mod=res_mod,
+                     relu=relu, out=out.view(-1, N) if out is not None else None, out_split=out_split)
+    return out if out is not None else y.view(*x.shape[:-1], N)
 
 
 def linear_x3(x, weight, bias=None, res=None, relu=False, out=None):

@@ -191,6 +191,10 @@ int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, int S);
 int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bits, float* out,
                              void* ws, int B, int Q, int H, int D, int S, float scale,
                              int kv_dtype, cgg_stream_t stream);
+/* Same, kv f32 rows [K | V] at row stride ldkv elements (>= 2 H D) and batch stride kv_bstride: a column slice of the merged
+ * projection of several decoder layers (0 = dense). */
+int cgg_masked_xattn_forward_strided(const float* q, const float* kv, int ldkv, int64_t kv_bstride, const uint32_t* bits,
+                                     float* out, void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream);
 /* Throughput-mode variant: k [B, S, H*D] bf16 and the value projection TRANSPOSED, vt [B, H*D, S] bf16 (computed
  * as Wv x mem^T by the caller), bf16 MFMA for both contractions, f32 softmax statistics and accumulation.
  * Same mask / output / workspace contract. Requires D == 32, Q <= 128, S % 4 == 0.
@@ -437,6 +441,50 @@ int cgg_gemm_x3_ex(const float* a, int lda, const void* w_x3, const float* bias,
                    int ldc, float* out2, int ldc2, int col2, int M, int N, int K, int relu, cgg_stream_t stream);
 int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* bias, const float* res, float* out, int B, int H, int W,
                      int C, int N, int KH, int KW, int stride, int pad, int relu, cgg_stream_t stream);
+
+/* Round 4: the same contractions on PRE-SPLIT activation rows ("x3a", csrc/x3.h + csrc/x3s_gemm.hip). An x3a tensor has the shape,
+ * bytes and addressing of the f32 tensor it stands for (channel-last, channels % 8 == 0), but every group of 8 consecutive
+ * channels holds [8 x f16 hi | 8 x f16 lo] of 16 a -- the operand form of the f16 x 3 MFMA contraction -- so the GEMM moves both
+ * operands HBM -> LDS by LDS-DMA with no conversion in its loop, and its epilogue can emit the next GEMM's A operand directly.
+ *   cgg_gemm_x3s:      out[M, N] = act(a W^T * colscale + bias (+ res[m or m % res_mod])); a = x3a rows (row stride lda elements,
+ *                      lda % 8 == 0), res_fmt 0 none / 1 f32 / 2 x3a, out_fmt 1 f32 / 2 x3a; K % 32 == 0, N % 8 == 0.
+ *   cgg_conv_x3s_nhwc: implicit GEMM over a channel-last x3a map [B, H, W, C] (C % 32 == 0, KH * KW <= 32).
+ *   cgg_x3a_encode / cgg_x3a_decode: f32 <-> x3a over n contiguous elements (n % 8 == 0): API edges and tests.
+ *   cgg_x3_overflow_check: a stored x3a value must satisfy |a| < 4094 (f16 range of 16 a). Every x3a producer ORs 1 into a
+ *                      per-device flag word when it sees a larger (or non-finite) value; this copies the word to *value_host
+ *                      (synchronises the stream) and optionally clears it -- the caller turns it into an error instead of
+ *                      letting inf / NaN masks through (open_set/models/mask2former_head.py:763-849 computes in f32, which
+ *                      has no such limit).
+ *   cgg_gemm_x3s_force_config: bench / test hook, tile configuration 0..8 (-1 = by shape).
+ * Same reference call sites as cgg_gemm_x3 / cgg_conv_x3_nhwc above.                                                   */
+int cgg_gemm_x3s(const void* a_x3a, int lda, const void* w_x3, const float* bias, const void* res, int ldr, int res_fmt,
+                 int res_mod, void* out, int ldc, int out_fmt, int M, int N, int K, int relu, cgg_stream_t stream);
+/* cgg_gemm_x3s over a stack of images: row m = row (m % rows_per_image) of image m / rows_per_image, image stride a_bstride elements. */
+int cgg_gemm_x3s_batched(const void* a_x3a, int lda, int rows_per_image, int64_t a_bstride, const void* w_x3, const float* bias,
+                         const void* res, int ldr, int res_fmt, int res_mod, void* out, int ldc, int out_fmt, int M, int N, int K,
+                         int relu, cgg_stream_t stream);
+int cgg_conv_x3s_nhwc(const void* x_x3a, const void* w_x3, const float* bias, const void* res, int res_fmt, void* out,
+                      int out_fmt, int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu,
+                      cgg_stream_t stream);
+int cgg_x3a_encode(const float* x, void* out_x3a, int64_t n, cgg_stream_t stream);
+int cgg_x3a_decode(const void* x_x3a, float* out, int64_t n, cgg_stream_t stream);
+int cgg_x3_overflow_check(int reset, int* value_host, cgg_stream_t stream);
+void cgg_gemm_x3s_force_config(int cfg);
+/* x3a-producing / -consuming twins of the stream's non-GEMM kernels (round 4):
+ *   cgg_bias_relu_maxpool_nhwc_f32_x3a: the stem's (bias, ReLU, 3x3 / s2 max-pool) pass with the pooled map written as x3a (C % 8 == 0);
+ *   cgg_group_norm_nhwc_f32_x3a:        cgg_group_norm_nhwc_f32 with y (and yp = y + pos[pixel], nullable) written as x3a rows at
+ *                                       y + b * y_bstride; up_src_x3a (nullable) = the low-resolution x3a map whose bilinear x2
+ *                                       up-sample is added before the ReLU (the FPN's `cur + F.interpolate(out)`);
+ *   cgg_encoder_layer_tail_x3a:         cgg_encoder_layer_tail_x3 with the layer input x and both outputs as x3a rows.          */
+int cgg_bias_relu_maxpool_nhwc_f32_x3a(const float* x, const float* bias, void* y_x3a, int B, int H, int W, int C,
+                                       cgg_stream_t stream);
+int cgg_group_norm_nhwc_f32_x3a(const float* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C, int groups,
+                                float eps, int relu, const void* up_src_x3a, int up_h, int up_w, int64_t up_bstride, int W,
+                                void* y_x3a, int64_t y_bstride, const float* pos, void* yp_x3a, cgg_stream_t stream);
+int cgg_encoder_layer_tail_x3a(const float* a32, const void* x_x3a, const void* wo_x3, const float* bo, const float* gamma0,
+                               const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
+                               const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                               int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
 
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */

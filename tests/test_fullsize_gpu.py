@@ -26,7 +26,7 @@ import cgg_amd  # noqa: F401
 from cgg_amd import ops, registry, runtime, synthetic
 from oracle import head as OH
 
-from util import MaskTeacher, head_cfg, randomize
+from util import MaskTeacher, head_cfg, plain, randomize
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +85,7 @@ def build_detector_pair(cfg, seed, img, dev):
             m.training = False
     model = model.eval().to(dev)
     with torch.no_grad(), runtime.precision_scope('fp32'):
-        mf = head.pixel_decoder([f.float().contiguous() for f in model.extract_feat(img.to(dev))])[0]
+        mf = head.pixel_decoder([plain(f).float().contiguous() for f in model.extract_feat(img.to(dev))])[0]
         head.pixel_decoder.mask_feature.bias -= mf.mean((0, 2, 3))
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
@@ -157,7 +157,7 @@ def check_fp32_mode(dev, c, types=TYPES, backbone_tol=1e-4, panoptic=False):
         head.attn_mask_hook = teacher.hook
         try:
             feats = model.extract_feat(img)
-            berr = max((f.float().cpu() - o).abs().max().item() / max(o.abs().max().item(), 1e-6)
+            berr = max((plain(f).float().cpu() - o).abs().max().item() / max(o.abs().max().item(), 1e-6)
                        for f, o in zip(feats, c['feats']))
             pc, pe, pm = head.forward(feats, metas)
             res = model.simple_test(img, metas, rescale=True, device_results=True, with_query_indices=True)

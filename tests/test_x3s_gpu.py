@@ -1,0 +1,156 @@
+"""-m gpu tests of round 4's pre-split activation rows ("x3a", csrc/x3.h) and the LDS-DMA GEMM / implicit-GEMM convolution that
+consumes them (csrc/x3s_gemm.hip), through the C ABI: against float64 on the same (decoded) operands at f32-GEMM accuracy, against
+round 3's kernel (cgg_gemm_x3 on the f32 rows: same arithmetic, so the f32 outputs must agree to rounding of the epilogue), for
+EVERY tile configuration (forced), ragged row / column counts, zero padding of the convolution by out-of-range LDS-DMA, f32 and
+x3a residuals / outputs, the row-periodic residual, and the overflow flag. Reference arithmetic being matched: the f32 linears /
+convolutions under open_set/models/mask2former_head.py:787, 829-840 ([3P] MSDeformAttnPixelDecoder, ResNet)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cgg_amd  # noqa: F401
+from cgg_amd import ops
+from cgg_amd._lib import load
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = list(range(17))
+
+
+def _err(got, want64):
+    return (got.detach().cpu().double() - want64).abs().max().item()
+
+
+@pytest.fixture
+def force_cfg():
+    lib = load()
+    yield lib.cgg_gemm_x3s_force_config
+    lib.cgg_gemm_x3s_force_config(-1)
+
+
+def test_x3a_roundtrip_and_flag(dev):
+    g = torch.Generator().manual_seed(401)
+    x = torch.randn(64, 256, generator=g) * 3
+    x[:, ::7] *= 1e-4
+    x[0, :8] = torch.tensor([0.0, -0.0, 4093.0, -4093.0, 1e-7, -1e-7, 1.0, -1.0])
+    xd = x.to(dev)
+    ops.x3_overflow_check(dev)                            # clear
+    e = ops.x3a_encode(xd)
+    assert e.shape == xd.shape and e.dtype == torch.float32
+    back = ops.x3a_decode(e).cpu()
+    # 22 significant bits (two 11-bit pieces); pieces below f16's subnormal step (2^-24 of the pre-scaled value) are dropped
+    tol = x.abs() * 2.0**-21 + 2.0**-24 / 16
+    assert ((back - x).abs() <= tol).all(), (back - x).abs().max()
+    assert not ops.x3_overflow_check(dev)
+    # the raw words are [8 x f16 hi | 8 x f16 lo] of 16 x per 8 channels
+    raw = e.cpu().view(torch.float16).view(64, 32, 16)
+    hi, lo = raw[..., :8].reshape(64, 256), raw[..., 8:].reshape(64, 256)
+    assert torch.equal(hi.float(), (x * 16).half().float())
+    assert torch.equal(lo.float(), (x * 16 - hi.float()).half().float())
+    # out of range: flagged (and cleared by the check)
+    y = xd.clone()
+    y[3, 17] = 5000.0
+    ops.x3a_encode(y)
+    assert ops.x3_overflow_check(dev)
+    assert not ops.x3_overflow_check(dev)
+
+
+def _operands(M, N, K, seed, xs=1.0, ws=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g) * xs
+    x[:, ::5] *= 1e-3
+    w = torch.randn(N, K, generator=g) * ws / K**0.5
+    w[::3] *= 1e-2
+    b = torch.randn(N, generator=g) * xs * ws
+    return g, x, w, b
+
+
+@pytest.mark.parametrize('cfg', CONFIGS)
+@pytest.mark.parametrize('M,N,K', [(1000, 288, 256), (257, 64, 64), (300, 520, 96)])
+def test_gemm_x3s_every_config_vs_float64_and_round3(dev, force_cfg, cfg, M, N, K):
+    g, x, w, b = _operands(M, N, K, 410 + cfg)
+    res = torch.randn(M, N, generator=g)
+    xe = ops.x3a_encode(x.to(dev))
+    xdec = ops.x3a_decode(xe).cpu()                      # what the GEMM multiplies (x to 22 bits)
+    packed = ops.pack_linear_weight_x3(w.to(dev))
+    want = xdec.double() @ w.double().t() + b.double()
+    f32_err = ((xdec @ w.t() + b).double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    force_cfg(cfg)
+    y = ops.gemm_x3s(xe, packed, N, b.to(dev))
+    assert _err(y, want) <= 4 * f32_err + 2e-7 * scale, (cfg, _err(y, want), f32_err)
+    # round 3's kernel on the f32 rows does the same split in its loop: same accumulators; epilogues differ by power-of-two scaling
+    old = ops.gemm_x3(x.to(dev), packed, N, b.to(dev))
+    assert (y - old).abs().max().item() <= 1e-6 * scale
+    # ReLU + f32 residual, x3a output into a strided view; then that output as an x3a residual of a second call
+    out = torch.zeros(M, N + 8, device=dev)[:, :N]
+    ops.gemm_x3s(xe, packed, N, b.to(dev), res=res.to(dev), relu=True, out=out, out_split=True)
+    w2 = (want + res.double()).relu()
+    got = ops.x3a_decode(out.contiguous())
+    assert _err(got, w2) <= 4 * f32_err + 1e-6 * (scale + 4)
+    y3 = ops.gemm_x3s(xe, packed, N, b.to(dev), res=out, res_split=True)
+    assert _err(y3, want + got.cpu().double()) <= 4 * f32_err + 1e-6 * (scale + 4)
+    # row-periodic f32 residual (the K / V projections' per-token table)
+    tab = torch.randn(7, N, generator=g)
+    y4 = ops.gemm_x3s(xe, packed, N, None, res=tab.to(dev), res_mod=7)
+    assert _err(y4, want - b.double() + tab[torch.arange(M) % 7].double()) <= 4 * f32_err + 1e-6 * (scale + 4)
+    assert not ops.x3_overflow_check(dev)
+
+
+@pytest.mark.parametrize('cfg', CONFIGS)
+@pytest.mark.parametrize('B,H,W,C,N,k,s', [(2, 19, 23, 64, 96, 3, 1), (1, 32, 32, 32, 64, 3, 2), (2, 17, 16, 96, 40, 1, 2),
+                                           (1, 40, 24, 64, 256, 1, 1)])
+def test_conv_x3s_every_config_vs_float64(dev, force_cfg, cfg, B, H, W, C, N, k, s):
+    """Implicit GEMM incl. the zero padding (out-of-range LDS-DMA pieces must arrive as zeros), strides, ragged M."""
+    g = torch.Generator().manual_seed(430 + cfg)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(N, C, k, k, generator=g) / (C * k * k)**0.5
+    b = torch.randn(N, generator=g)
+    xe = ops.x3a_encode(x.to(dev))
+    xdec = ops.x3a_decode(xe).cpu()
+    pad = k // 2
+    want = F.conv2d(xdec.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=s, padding=pad).permute(0, 2, 3, 1)
+    f32_err = (F.conv2d(xdec.permute(0, 3, 1, 2), w, b, stride=s, padding=pad).permute(0, 2, 3, 1).double() - want).abs().max().item()
+    packed = ops.pack_conv_weight_x3(w.to(dev))
+    force_cfg(cfg)
+    # poison the LDS-visible neighbourhood: a previous launch with large values must not leak into the padding
+    ops.conv_x3s_nhwc(ops.x3a_encode(torch.full_like(x, 1000.0).to(dev)), packed, N, k, s, pad, b.to(dev), out_split=False)
+    y = ops.conv_x3s_nhwc(xe, packed, N, k, s, pad, b.to(dev), out_split=False)
+    scale = want.abs().max().item()
+    assert _err(y, want) <= 4 * f32_err + 2e-7 * scale, (cfg, _err(y, want), f32_err)
+    old = ops.conv_x3_nhwc(x.to(dev), packed, N, k, s, pad, b.to(dev))
+    assert (y - old).abs().max().item() <= 1e-6 * scale
+    # residual + ReLU, all in x3a
+    res = torch.randn(*want.shape, generator=g)
+    rese = ops.x3a_encode(res.to(dev))
+    ye = ops.conv_x3s_nhwc(xe, packed, N, k, s, pad, b.to(dev), res=rese, relu=True)
+    w2 = (want + ops.x3a_decode(rese).cpu().double()).relu()
+    assert _err(ops.x3a_decode(ye), w2) <= 4 * f32_err + 1e-6 * (scale + 4)
+    assert not ops.x3_overflow_check(dev)
+
+
+def test_gemm_x3s_overflow_raises_the_flag(dev):
+    g, x, w, b = _operands(256, 64, 64, 470)
+    xe = ops.x3a_encode(x.to(dev))
+    packed = ops.pack_linear_weight_x3(w.to(dev))
+    big = b.clone()
+    big[5] = 6000.0
+    ops.x3_overflow_check(dev)
+    ops.gemm_x3s(xe, packed, 64, big.to(dev), out_split=False)          # f32 output: no stored x3a value, no flag
+    assert not ops.x3_overflow_check(dev)
+    ops.gemm_x3s(xe, packed, 64, big.to(dev), out_split=True)
+    assert ops.x3_overflow_check(dev)
+
+
+def test_gemm_x3s_large_k_and_default_config(dev):
+    """K = 2304 (72 chunks through the stage ring), default tile choice, chunk counts that are not multiples of the ring."""
+    for M, N, K in [(2048, 256, 2304), (777, 128, 1120), (512, 512, 32)]:
+        g, x, w, b = _operands(M, N, K, 480)
+        xe = ops.x3a_encode(x.to(dev))
+        xdec = ops.x3a_decode(xe).cpu()
+        packed = ops.pack_linear_weight_x3(w.to(dev))
+        want = xdec.double() @ w.double().t() + b.double()
+        f32_err = ((xdec @ w.t() + b).double() - want).abs().max().item()
+        y = ops.gemm_x3s(xe, packed, N, b.to(dev))
+        assert _err(y, want) <= 4 * f32_err + 2e-7 * want.abs().max().item(), (M, N, K)
+        assert torch.equal(y, ops.gemm_x3s(xe, packed, N, b.to(dev)))   # bit-reproducible

@@ -178,3 +178,10 @@ def g7_inputs():
     cls_embs[-1] = 0
     pemb = torch.randn(Q, 64, generator=g)
     return emb, mp, cls_embs, pemb
+
+
+def plain(t):
+    """values of a tensor the product may hand over as x3a rows (`ops.X3ATensor`: round 4's parity-mode ResNet outputs and encoder
+    memories) -- a plain float32 tensor either way."""
+    from cgg_amd import ops
+    return ops.x3a_to_f32(t) if ops.is_x3a(t) else t
