@@ -389,7 +389,11 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
         worst = {}
         for t, m in zip(g, gm):
             worst.setdefault(m['shape'], []).append(t)
-        shapes = sorted(((sum(v) / len(v), len(v) // args.steps, k) for k, v in worst.items()), reverse=True)[:6]
+        shapes = sorted(((sum(v) / len(v), len(v) // args.steps, k) for k, v in worst.items()), reverse=True)
+        if os.environ.get('CGG_BENCH_ALL_SHAPES'):     # measurement aid: the whole per-shape table on stderr
+            for t, n, k in shapes:
+                print('gemm shape %s x%d: %.1f us' % (k, n, t * 1e3), file=sys.stderr)
+        shapes = shapes[:6]
         pr = prof.get('cgg_gemm_x3_kernel', {})
         out['gemm_x3'] = dict(
             bound='mfma', kernel='cgg_gemm_x3_kernel<CONV, TM, TN> (all instantiations: %d launches per step -- the BN-folded '

@@ -72,93 +72,172 @@ struct XsTap {                    // position of a DMA stream: chunk, channel of
   int c, c0, tap, ky, kx;         // __global__ template made hipcc 7.2 drop the kernel's host stubs)
 };
 
-// ---- epilogue of one wave: TM x TN accumulator tiles -> out. OUT / RES = 1 f32, 2 x3a (RES 0: none). Everything in the PRE-SCALED
-//      domain (16 v): cs = 16 colscale, bs = 16 bias; an x3a residual is already pre-scaled, an f32 one is multiplied. No predicates:
-//      rows >= M fall outside the buffer descriptors (stores dropped, loads 0), columns >= N are sent there explicitly. ----
-template <int TM, int TN, int OUT, int RES>
-__device__ __forceinline__ float xs_epilogue(const f32x16 (&acc)[TM][TN], float* scratch, const XsArgs& p, int mrow0, int ntile0,
-                                             int lane) {
-  const int j = lane & 31, hi5 = lane >> 5;
-  const int er = lane >> 2, esp = lane & 3;
-  const uint32_t out_bytes = (uint32_t)(((size_t)(p.M - 1) * p.ldc + p.N) * 4);
-  const __amdgpu_buffer_rsrc_t orsrc = xs_rsrc(p.out, out_bytes);
+// ---- epilogue of one wave. Everything in the PRE-SCALED domain (16 v): cs = 16 colscale, bs = 16 bias; an x3a residual is
+//      already pre-scaled, an f32 one is multiplied. The accumulator tiles of one n-tile column go to the wave's LDS scratch
+//      (unrolled: register arrays), then ONE rolled loop finishes them tile by tile -- residual, ReLU, split, 32-byte stores -- with
+//      runtime (wave-uniform) format branches: the kernel stays a few KB of code. (The first version instantiated the whole
+//      epilogue per format and tile, 70-150 KB per kernel: inside the step every launch then started with instruction-cache
+//      misses to HBM, +10 us per launch over the stand-alone timing.) No predicates: rows >= M fall outside the buffer
+//      descriptors (stores dropped, loads 0), columns >= N are sent there explicitly. ----
+struct XsEpi {
+  __amdgpu_buffer_rsrc_t orsrc, rrsrc;
+  float lo_clamp;
+  int mr0;              // residual row of (tile row lane >> 3, pass 0, m-tile 0), reduced mod res_mod
+};
+
+// mask ? b : a with mask = 0 or ~0 (v_bfi_b32)
+__device__ __forceinline__ uint32_t xs_sel(uint32_t a, uint32_t b, uint32_t mask) { return (b & mask) | (a & ~mask); }
+
+// 8 bytes of lane ^ 1 (the other half of the lane pair that shares an 8-column group)
+__device__ __forceinline__ uint2 xs_pair_swap(const uint2 v) {
+  uint2 r;
+  r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0xB1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]
+  r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0xB1, 0xf, 0xf, true);
+  return r;
+}
+
+// Finish the TM scratch tiles of one 32-column n-tile (rows mrow0 .. mrow0 + 32 TM - 1). Lane -> (row r8 + 8 pass, 16-byte piece q of
+// the row's 128 output bytes): 8 lanes cover one full line, a wave instruction 8 full lines -- every residual load and every store
+// is ONE 16-byte access per lane. A lane OWNS the 4 columns 4 q .. 4 q + 3 (half of the 8-column group q >> 1; its partner lane ^ 1
+// the other half): it finishes only those 4 values. In x3a form the group's memory image is [8 hi | 8 lo]: the even lane stores the
+// hi piece, the odd lane the lo piece, so the pair swaps 8 bytes by DPP -- each lane sends the half-piece it does not store and
+// receives the one it does (same swap, other direction, for an x3a residual). Specialised on the formats (the wave-uniform format
+// tests of the first version sat between the loads and serialised them); the tile loop is rolled, the next tile's residual pieces
+// are requested before the current tile is finished.
+// the lane's 4 residual pieces of one 32 x 32 tile: rows mres + 8 pass (mres already reduced mod res_mod; advanced to the next tile)
+__device__ __forceinline__ void xs_load_res(u32x4 (&rv)[4], const XsArgs& p, const __amdgpu_buffer_rsrc_t rrsrc, int& mres, int ncol0,
+                                            int lane) {
+  const int q = lane & 7;
+  const bool cok = ncol0 + 4 * q < p.N;
+  const uint32_t coff = (uint32_t)(ncol0 * 4 + 16 * q);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    int mr = mres + 8 * ps;
+    if (p.res_mod) {
+      mr = mr >= p.res_mod ? mr - p.res_mod : mr;
+      if (p.res_mod < 32) mr %= p.res_mod;                     // tiny periods only (tests)
+    }
+    rv[ps] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, cok ? (uint32_t)(mr * p.ldr) * 4u + coff : XS_OOB, 0, 0);
+  }
+  mres += 32;
+  if (p.res_mod) mres = p.res_mod >= 32 ? (mres >= p.res_mod ? mres - p.res_mod : mres) : mres % p.res_mod;
+}
+
+template <int RES, int OUT>
+__device__ __forceinline__ float xs_finish_column(const float* scratch, int TM_, const XsArgs& p, const XsEpi& e, int mrow0, int ncol0,
+                                                  int lane, float amax, const u32x4 (&rv0)[4], bool have_rv0) {
+  const int r8 = lane >> 3, q = lane & 7;
+  const uint32_t om = 0u - (uint32_t)(q & 1);                  // all ones in the odd lane of a pair
+  const bool cok = ncol0 + 4 * q < p.N;                        // N % 8 == 0: both lanes of a pair agree
+  const uint32_t coff = (uint32_t)(ncol0 * 4 + 16 * q);        // byte offset of the lane's piece inside a row
+  int mres = e.mr0;                                            // residual row of (tile 0, pass 0), already reduced mod res_mod
+  auto load_res = [&](u32x4 (&rv)[4]) { xs_load_res(rv, p, e.rrsrc, mres, ncol0, lane); };
+  u32x4 rv[4], rn[4];
+  if (RES) {
+    if (have_rv0) {                                            // tile 0 of the first column was requested before the main loop
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) rv[ps] = rv0[ps];
+      mres += 32;
+      if (p.res_mod) mres = p.res_mod >= 32 ? (mres >= p.res_mod ? mres - p.res_mod : mres) : mres % p.res_mod;
+    } else {
+      load_res(rv);
+    }
+  }
+#pragma unroll 1
+  for (int mt = 0; mt < TM_; ++mt) {
+    const float* sc = scratch + mt * 1024;
+    if (RES && mt + 1 < TM_) load_res(rn);
+    f32x4 v[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rr = r8 + 8 * ps;
+      v[ps] = *reinterpret_cast<const f32x4*>(sc + rr * 32 + (q ^ ((rr >> 1) & 1)) * 4);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rr = r8 + 8 * ps;
+      f32x4 w = v[ps];
+      if (RES == 1) {
+        w += __builtin_bit_cast(f32x4, rv[ps]) * CGG_X3_ASCALE;
+      } else if (RES == 2) {
+        // the lane holds hi[0..7] (even) or lo[0..7] (odd) of the group; its own 4 values need the other piece's matching half
+        // (bit-field selects on scalars: `odd ? rv[ps][2] : rv[ps][0]` was compiled into a dynamic register index -- a chain of
+        // 15 compare / select pairs per element, 20 % of the kernel's time on the ResNet's residual convolutions)
+        const uint32_t r0 = rv[ps][0], r1 = rv[ps][1], r2 = rv[ps][2], r3 = rv[ps][3];
+        const uint2 keep = {xs_sel(r0, r2, om), xs_sel(r1, r3, om)};                             // my columns of my piece
+        const uint2 send = {xs_sel(r2, r0, om), xs_sel(r3, r1, om)};                             // the partner's columns of my piece
+        const uint2 got = xs_pair_swap(send);                                                    // my columns of the partner's piece
+        const uint2 hh = {xs_sel(keep.x, got.x, om), xs_sel(keep.y, got.y, om)};
+        const uint2 ll = {xs_sel(got.x, keep.x, om), xs_sel(got.y, keep.y, om)};
+        const cgg_f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(f16x2, hh.x), cgg_f32x2);
+        const cgg_f32x2 h1 = __builtin_convertvector(__builtin_bit_cast(f16x2, hh.y), cgg_f32x2);
+        const cgg_f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(f16x2, ll.x), cgg_f32x2);
+        const cgg_f32x2 l1 = __builtin_convertvector(__builtin_bit_cast(f16x2, ll.y), cgg_f32x2);
+        w += f32x4{h0[0] + l0[0], h0[1] + l0[1], h1[0] + l1[0], h1[1] + l1[1]};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = fmaxf(w[k], e.lo_clamp);
+      const uint32_t oo = cok ? (uint32_t)((mrow0 + 32 * mt + rr) * p.ldc) * 4u + coff : XS_OOB;
+      u32x4 o;
+      if (OUT == 2) {
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(fabsf(w[0]), fabsf(w[1])), __builtin_fmaxf(fabsf(w[2]), fabsf(w[3]))));
+        uint2 h, l;
+        cgg_x3_split2(w[0], w[1], h.x, l.x);
+        cgg_x3_split2(w[2], w[3], h.y, l.y);
+        const uint2 got = xs_pair_swap(uint2{xs_sel(l.x, h.x, om), xs_sel(l.y, h.y, om)});      // even sends lo, odd sends hi
+        o = u32x4{xs_sel(h.x, got.x, om), xs_sel(h.y, got.y, om), xs_sel(got.x, l.x, om), xs_sel(got.y, l.y, om)};
+      } else {
+        o = __builtin_bit_cast(u32x4, w * CGG_X3_INV_ASCALE);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(o, e.orsrc, oo, 0, 0);
+    }
+    if (RES) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) rv[ps] = rn[ps];
+    }
+  }
+  return amax;
+}
+
+__device__ __forceinline__ XsEpi xs_epi_setup(const XsArgs& p, int mrow0, int lane) {
+  XsEpi e;
+  e.orsrc = xs_rsrc(p.out, (uint32_t)(((size_t)(p.M - 1) * p.ldc + p.N) * 4));
   const int res_rows = p.res_mod ? p.res_mod : p.M;
-  const __amdgpu_buffer_rsrc_t rrsrc = xs_rsrc(RES ? p.res : p.out, RES ? (uint32_t)(((size_t)(res_rows - 1) * p.ldr + p.N) * 4) : 0u);
-  const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
+  e.rrsrc = xs_rsrc(p.res_fmt ? p.res : p.out, p.res_fmt ? (uint32_t)(((size_t)(res_rows - 1) * p.ldr + p.N) * 4) : 0u);
+  e.lo_clamp = p.relu ? 0.f : -__builtin_inff();
+  e.mr0 = mrow0 + (lane >> 3);
+  if (p.res_fmt && p.res_mod) e.mr0 %= p.res_mod;
+  return e;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ float xs_epilogue(const f32x16 (&acc)[TM][TN], float* scratch, const XsArgs& p, const XsEpi& e, int mrow0,
+                                             int ntile0, int lane, const u32x4 (&rv0)[4]) {
+  const int j = lane & 31, hi5 = lane >> 5;
+  const int fmt = p.res_fmt * 2 + (p.out_fmt - 1);             // wave-uniform
   float amax = 0.f;
-  // residual row of (tile row er, pass 0) for mt = 0; rows advance by 16 per pass and 32 per m-tile. A row-periodic residual
-  // wraps by conditional subtraction when the period covers the tile rows, by modulo otherwise
-  int mr0 = mrow0 + er;
-  const bool wrap_sub = p.res_mod >= 32 * TM;
-  if (RES && p.res_mod) mr0 %= p.res_mod;
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
     const int ncol = (ntile0 + nt) * 32 + j;
     const bool nok = ncol < p.N;
     const float cs = nok ? p.w.scale[ncol] * CGG_X3_ASCALE : 0.f;
     const float bs = (nok && p.bias) ? p.bias[ncol] * CGG_X3_ASCALE : 0.f;
-    const int n0 = (ntile0 + nt) * 32 + 8 * esp;               // first of this lane's 8 output columns
-    const bool cok = n0 < p.N;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-      float* sc = scratch + ((nt * TM + mt) & 1) * 1024;
-      u32x4 rv[2][2];
-      if (RES) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          int mr = mr0 + 32 * mt + 16 * ps;
-          if (p.res_mod) {
-            if (wrap_sub) mr = mr >= p.res_mod ? mr - p.res_mod : mr;
-            else mr %= p.res_mod;
-          }
-          const uint32_t ro = cok ? (uint32_t)(mr * p.ldr + n0) * 4u : XS_OOB;
-          rv[ps][0] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro, 0, 0);
-          rv[ps][1] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro + 16u, 0, 0);
-        }
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi5;
-        sc[rr * 32 + (((j >> 2) ^ ((rr >> 1) & 1)) << 2) + (j & 3)] = acc[mt][nt][r] * cs + bs;
+        scratch[mt * 1024 + rr * 32 + (((j >> 2) ^ ((rr >> 1) & 1)) << 2) + (j & 3)] = acc[mt][nt][r] * cs + bs;
       }
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        const int rr = er + 16 * ps;
-        const int x = (rr >> 1) & 1;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + rr * 32 + ((2 * esp) ^ x) * 4);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + rr * 32 + ((2 * esp + 1) ^ x) * 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (RES == 1) {
-          const f32x4 r0 = __builtin_bit_cast(f32x4, rv[ps][0]), r1 = __builtin_bit_cast(f32x4, rv[ps][1]);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k] += r0[k] * CGG_X3_ASCALE;
-            v[4 + k] += r1[k] * CGG_X3_ASCALE;
-          }
-        } else if (RES == 2) {
-          float rs[8];
-          cgg_x3a_decode8_prescaled(rv[ps][0], rv[ps][1], rs);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += rs[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], lo_clamp);
-        const int m = mrow0 + 32 * mt + rr;
-        const uint32_t oo = cok ? (uint32_t)(m * p.ldc + n0) * 4u : XS_OOB;
-        if (OUT == 2) {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) amax = __builtin_fmaxf(amax, __builtin_fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
-          u32x4 h, l;
-          cgg_x3a_split8_prescaled(v, h, l);
-          __builtin_amdgcn_raw_buffer_store_b128(h, orsrc, oo, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(l, orsrc, oo + 16u, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]} * CGG_X3_INV_ASCALE), orsrc, oo,
-                                                 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]} * CGG_X3_INV_ASCALE), orsrc,
-                                                 oo + 16u, 0, 0);
-        }
-      }
+    }
+    const int ncol0 = (ntile0 + nt) * 32;
+    switch (fmt) {
+      case 0: amax = xs_finish_column<0, 1>(scratch, TM, p, e, mrow0, ncol0, lane, amax, rv0, false); break;
+      case 1: amax = xs_finish_column<0, 2>(scratch, TM, p, e, mrow0, ncol0, lane, amax, rv0, false); break;
+      case 2: amax = xs_finish_column<1, 1>(scratch, TM, p, e, mrow0, ncol0, lane, amax, rv0, nt == 0); break;
+      case 3: amax = xs_finish_column<1, 2>(scratch, TM, p, e, mrow0, ncol0, lane, amax, rv0, nt == 0); break;
+      case 4: amax = xs_finish_column<2, 1>(scratch, TM, p, e, mrow0, ncol0, lane, amax, rv0, nt == 0); break;
+      default: amax = xs_finish_column<2, 2>(scratch, TM, p, e, mrow0, ncol0, lane, amax, rv0, nt == 0); break;
     }
   }
   return amax;
@@ -177,7 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void cgg_gemm_x3s_kernel(const X
   constexpr int LDS = SA * A_SLOT + SB * B_SLOT;
   static_assert(BM % (8 * NWG) == 0 && BN % (8 * NWG) == 0, "tile rows / columns must split evenly over the waves' DMA pieces");
   static_assert(SA >= SB && SB >= 2, "A runs at least as far ahead as B");
-  static_assert(LDS >= NWG * 8192 + (KG - 1) * NWG * TM * TN * 4096, "LDS: the rings must cover the reduce buffer + epilogue scratch");
+  static_assert(LDS >= NWG * TM * 4096 + (KG - 1) * NWG * TM * TN * 4096, "LDS: the rings must cover the reduce buffer + epilogue scratch");
   static_assert(KG == 1 || KG == 2, "one or two k-groups");
   // allowed outstanding DMA instructions at the top of an iteration (issue order per iteration: B pieces, then A pieces)
   constexpr int WAIT = (DA > DB ? NA : 0) + (DB - 1) * (NA + NB);
@@ -374,6 +453,14 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void cgg_gemm_x3s_kernel(const X
     if (t + DB >= 0) issue_b();
     issue_a();
   }
+  // the residual pieces of this wave's first output tile are requested NOW: for the shallow, memory-bound shapes (K = 64 .. 256) the
+  // operand fetch and the residual fetch are two HBM latencies that would otherwise be paid one after the other
+  const XsEpi epi = xs_epi_setup(p, m0 + wm * TM * 32, lane);
+  u32x4 rv0[4];
+  if (p.res_fmt && (KG == 1 || kg == 0)) {
+    int mres = epi.mr0;
+    xs_load_res(rv0, p, epi.rrsrc, mres, (nt0 + wn * TN) * 32, lane);
+  }
   int a_rd = 0, b_rd = 0;
   for (int it = 0; it < niter; ++it) {
     xs_wait_vmcnt<WAIT>();
@@ -416,20 +503,10 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void cgg_gemm_x3s_kernel(const X
         }
   }
 
-  // ---- epilogue (per wave, no further workgroup synchronisation): scratch behind the reduce buffer ----
-  float* scratch = reinterpret_cast<float*>(xs_smem + (KG - 1) * NWG * TM * TN * 4096 + wg * 8192);
-  const int mrow0 = m0 + wm * TM * 32, ntile0 = nt0 + wn * TN;
-  float amax = 0.f;
-  if (p.out_fmt == 2) {
-    if (p.res_fmt == 2) amax = xs_epilogue<TM, TN, 2, 2>(acc, scratch, p, mrow0, ntile0, lane);
-    else if (p.res_fmt == 1) amax = xs_epilogue<TM, TN, 2, 1>(acc, scratch, p, mrow0, ntile0, lane);
-    else amax = xs_epilogue<TM, TN, 2, 0>(acc, scratch, p, mrow0, ntile0, lane);
-    if (p.flag && !(amax <= CGG_X3A_MAX)) atomicOr(p.flag, 1);
-  } else {
-    if (p.res_fmt == 2) xs_epilogue<TM, TN, 1, 2>(acc, scratch, p, mrow0, ntile0, lane);
-    else if (p.res_fmt == 1) xs_epilogue<TM, TN, 1, 1>(acc, scratch, p, mrow0, ntile0, lane);
-    else xs_epilogue<TM, TN, 1, 0>(acc, scratch, p, mrow0, ntile0, lane);
-  }
+  // ---- epilogue (per wave, no further workgroup synchronisation): TM scratch tiles per wave behind the reduce buffer ----
+  float* scratch = reinterpret_cast<float*>(xs_smem + (KG - 1) * NWG * TM * TN * 4096 + wg * (TM * 4096));
+  const float amax = xs_epilogue<TM, TN>(acc, scratch, p, epi, m0 + wm * TM * 32, nt0 + wn * TN, lane, rv0);
+  if (p.out_fmt == 2 && p.flag && !(amax <= CGG_X3A_MAX)) atomicOr(p.flag, 1);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -491,29 +568,38 @@ static int xs_go(const XsArgs& a, hipStream_t stream, const char* who) {
 //    2: 128 x 256, 8 waves, 3 slots (144 KiB)             7: 64 x 64, 4 waves, 4 slots (64 KiB)           12: 64 x 64, 2 k-groups, 4 slots (128 KiB)
 //    3: 128 x 128, 4 waves, 4 slots (128 KiB)             8: 256 x 64, 4 waves, 3 slots (120 KiB)         13: 64 x 64, 4 waves, 2 slots (32 KiB)
 //    4: 128 x 128, 4 waves, 2 slots (64 KiB)              9: 256 x 256, 8 waves, 2 slots (128 KiB)        14: 128 x 64, 4 waves, 2 slots (48 KiB)
-//                                                                                                          15: 64 x 128, 4 waves, 2 slots (48 KiB)
+//   16: 64 x 64, 2 k-groups, 2 slots (64 KiB)            17: 64 x 128, 2 k-groups, 2 slots (96 KiB)      15: 64 x 128, 4 waves, 2 slots (48 KiB)
 #define XS_CONFIGS(X)                                                                                                              \
   X(0, 4, 2, 2, 4, 1, 3, 2) X(1, 2, 2, 4, 2, 1, 3, 3) X(2, 2, 2, 2, 4, 1, 3, 3) X(3, 2, 2, 2, 2, 1, 4, 4) X(4, 2, 2, 2, 2, 1, 2, 2)   \
   X(5, 1, 2, 2, 2, 1, 4, 4) X(6, 2, 1, 2, 2, 1, 4, 4) X(7, 1, 1, 2, 2, 1, 4, 4) X(8, 4, 1, 2, 2, 1, 3, 3) X(9, 4, 2, 2, 4, 1, 2, 2)   \
   X(10, 2, 2, 2, 2, 2, 2, 2) X(11, 1, 2, 2, 2, 2, 3, 3) X(12, 1, 1, 2, 2, 2, 4, 4) X(13, 1, 1, 2, 2, 1, 2, 2)                      \
-  X(14, 2, 1, 2, 2, 1, 2, 2) X(15, 1, 2, 2, 2, 1, 2, 2) X(16, 4, 4, 2, 2, 1, 2, 2)
-#define XS_NCFG 17
-static const int xs_bm[XS_NCFG] = {256, 256, 128, 128, 128, 64, 128, 64, 256, 256, 128, 64, 64, 64, 128, 64, 256};
-static const int xs_bn[XS_NCFG] = {256, 128, 256, 128, 128, 128, 64, 64, 64, 256, 128, 128, 64, 64, 64, 128, 256};
+  X(14, 2, 1, 2, 2, 1, 2, 2) X(15, 1, 2, 2, 2, 1, 2, 2) X(16, 1, 1, 2, 2, 2, 2, 2) X(17, 1, 2, 2, 2, 2, 2, 2)
+#define XS_NCFG 18
+static const int xs_bm[XS_NCFG] = {256, 256, 128, 128, 128, 64, 128, 64, 256, 256, 128, 64, 64, 64, 128, 64, 64, 64};
+static const int xs_bn[XS_NCFG] = {256, 128, 256, 128, 128, 128, 64, 64, 64, 256, 128, 128, 64, 64, 64, 128, 64, 128};
 
 // Tile configuration by shape, from the per-shape sweep on MI355X (scratch/x3s_bench.py, profiles/r4_x3s_gemm_bench.txt). t = the
 // number of 128 x 128 output tiles. Few tiles and a deep K -> k-group configurations (two waves per SIMD on a small tile); many
 // tiles and a shallow K -> small tiles with 2 ring slots (memory-bound: several workgroups per CU overlap load / store phases);
 // the 256 x 256 tile only where the contraction is MFMA-bound (K >= 1024 with >= 1024 tiles: the FPN's 3 x 3 convolution).
-static int xs_pick(int M, int N, int K) {
+static int xs_pick(int M, int N, int K, bool has_res) {
   if (g_xs_force_cfg >= 0 && g_xs_force_cfg < XS_NCFG) return g_xs_force_cfg;
   const long long t = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  if (N <= 64) return 13;
-  if (t >= 1024) return K >= 1024 ? 9 : (K <= 128 ? 14 : 4);
-  if (t >= 512) return 2;
-  if (t >= 256) return K >= 512 ? 10 : 13;
-  if (t >= 128) return K >= 512 ? 11 : 13;
-  return K >= 512 ? 12 : 13;
+  // column tile by padding waste (N = 288: 5 x 64 wastes 11 %, 3 x 128 33 %); the wider tile on ties
+  const int w64 = (N + 63) / 64 * 64, w128 = (N + 127) / 128 * 128;
+  const bool narrow = N <= 64 || w64 < w128;
+  const bool deep = K >= 512;
+  if (narrow) {
+    if (deep && (long long)((M + 63) / 64) * ((N + 63) / 64) < 512) return 12;
+    return (M >= 16384 && K < 256) || N > 64 ? 14 : 13;
+  }
+  if (t >= 1024) return (K >= 1024 && N % 256 == 0) ? 9 : ((K <= 128 && !has_res) ? 14 : 4);
+  if (t >= 512) return (deep && N % 256 == 0) ? 2 : (N >= 512 ? 4 : 14);
+  if (t >= 256) return deep ? 10 : 13;
+  // few tiles, deep K: two k-groups on a small tile, deep rings (inside the step the operands come from HBM / the Infinity Cache,
+  // not from L2 as in a repeated stand-alone launch: 2-slot rings lose 10-15 % there)
+  if (t >= 128) return deep ? 11 : 13;
+  return deep ? 12 : 13;
 }
 
 static int xs_launch(bool conv, const char* who, const void* a, int lda, const void* w_x3, const float* bias, const void* res, int ldr,
@@ -567,7 +653,26 @@ static int xs_launch(bool conv, const char* who, const void* a, int lda, const v
   x.w_bytes = (uint32_t)(2ull * ((N + 31) / 32) * (K / 16) * 64 * 16);
   x.flag = out_fmt == 2 ? cgg_x3_overflow_flag_ptr() : nullptr;
   x.ablate = g_xs_ablate;
-  const int cfg = xs_pick(M, N, K);
+  int cfg = xs_pick(M, N, K, res != nullptr);
+  {
+    // measurement aid: CGG_XS_MAP="13:7,14:6" re-maps picked configurations (in-graph A/B of ring depths / tile shapes)
+    static int remap[XS_NCFG];
+    static bool init = false;
+    if (!init) {
+      for (int i = 0; i < XS_NCFG; ++i) remap[i] = i;
+      if (const char* e = getenv("CGG_XS_MAP")) {
+        int a, b, n = 0;
+        while (sscanf(e, "%d:%d%n", &a, &b, &n) == 2) {
+          if (a >= 0 && a < XS_NCFG && b >= 0 && b < XS_NCFG) remap[a] = b;
+          e += n;
+          if (*e == ',') ++e;
+          else break;
+        }
+      }
+      init = true;
+    }
+    if (g_xs_force_cfg < 0) cfg = remap[cfg];
+  }
   int rc = CGG_OK;
 #define XS_CASE(ID, TM, TN, WM, WN, KG, SA, SB)                                                 \
   case ID:                                                                                      \

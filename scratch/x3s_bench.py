@@ -8,11 +8,11 @@ from cgg_amd import ops
 from cgg_amd._lib import load
 dev = torch.device('cuda')
 lib = load()
-CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 and sys.argv[1] != 'auto' else list(range(17))
+CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 and sys.argv[1] != 'auto' else list(range(18))
 AUTO_ONLY = len(sys.argv) > 1 and sys.argv[1] == 'auto'
 FILT = sys.argv[2] if len(sys.argv) > 2 else ''
-BM = [256, 256, 128, 128, 128, 64, 128, 64, 256, 256, 128, 64, 64, 64, 128, 64, 256]
-BN = [256, 128, 256, 128, 128, 128, 64, 64, 64, 256, 128, 128, 64, 64, 64, 128, 256]
+BM = [256, 256, 128, 128, 128, 64, 128, 64, 256, 256, 128, 64, 64, 64, 128, 64, 64, 64]
+BN = [256, 128, 256, 128, 128, 128, 64, 64, 64, 256, 128, 128, 64, 64, 64, 128, 64, 128]
 def timeit(fn, n=30):
     for _ in range(3): fn()
     torch.cuda.synchronize()

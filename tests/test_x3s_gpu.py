@@ -14,7 +14,7 @@ from cgg_amd._lib import load
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = list(range(17))
+CONFIGS = list(range(18))
 
 
 def _err(got, want64):
