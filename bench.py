@@ -324,7 +324,7 @@ def train_main(args, cfg, model, img, metas, dev, rank, world):
             metric='images/sec (COCO-instance training step, 1024x1024, 100 queries)',
             value=B * world * args.steps / dt, unit='images/sec', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
-            vs_baseline=None, dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
+            vs_baseline=None, dtype='bf16' if args.precision == 'bf16' else 'f32 (f32 library GEMMs / convolutions under autograd; encoder linears forward + grad-input and the frozen backbone stages on the f32-class f16x3 kernels)', data='synthetic',
             config=dict(workload=f'configs[2]: R50 + {args.queries} queries, {H}x{W}, batch {B}/GPU, training step '
                                  '(forward_train with grounding + caption-generation losses, backward, gradient '
                                  'all-reduce, clip, AdamW)',
@@ -497,12 +497,13 @@ def einsum_q_sweep(dev, B, H, W):
     return res
 
 
-def train_step_child(args):
+def train_step_child(args, precision='fp32'):
     """configs[2]'s training step (`--mode train`) in a CHILD process started after this process has finished its GPU work
-    (never an exec from a GPU-initialised process); its JSON line is embedded as `train_step`."""
+    (never an exec from a GPU-initialised process); its JSON line is embedded as `train_step` (precision fp32 = the reference's
+    training arithmetic, open_set/apis/train.py:182-189) / `train_step.bf16_mode` (bf16 autocast: narrower, secondary)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'train', '--steps', str(args.train_steps), '--warmup', '3',
-           '--precision', 'bf16']
+           '--precision', precision]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -513,6 +514,8 @@ def train_step_child(args):
         # (profiles/r3_train_step_kernels.txt: rocprofv3 --kernel-trace of `bench.py --mode train`, last 3 steps) -- labelled as such
         prof = {}
         try:
+            if precision != 'bf16':
+                raise FileNotFoundError('the committed per-step kernel table is the bf16 step\'s')
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r3_train_step_kernels.txt')) as f:
                 rows = f.read().splitlines()
             head = [r for r in rows if r.startswith('step (eager')][0]
@@ -598,8 +601,6 @@ def main():
 
     import cgg_amd
     from cgg_amd import ops, runtime, synthetic
-    if args.mode == 'train' and '--precision' not in sys.argv:
-        args.precision = 'bf16'              # the training step's measured mode (round 2); fp32 with --precision fp32
     runtime.set_precision(args.precision)
     cfg, model = build_model(args, dev)
     B, H, W = args.batch, args.size, args.size
@@ -674,7 +675,10 @@ def main():
             torch.cuda.synchronize()
             del main_mode
             torch.cuda.empty_cache()
-            res['train_step'] = train_step_child(args)
+            # parity-mode (f32-class) training step first -- the arithmetic the reference trains in -- then the bf16 autocast one
+            ts = train_step_child(args, 'fp32')
+            ts['bf16_mode'] = train_step_child(args, 'bf16')
+            res['train_step'] = ts
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

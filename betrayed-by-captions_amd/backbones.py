@@ -294,36 +294,43 @@ class ResNet(nn.Module):
 
     # ---- parity-mode inference: BN folded in f32, channel-last f32 activations, every convolution after the stem on the
     #      f32-class implicit-GEMM kernel (ops.conv_x3_nhwc: f16 x 3 MFMA, csrc/x3_gemm.hip) with bias / residual / ReLU fused ----
-    def _folded_x3(self):
-        """[(x3 image | folded f32 filter for the stem, bias f32)] per conv in execution order; rebuilt when a parameter or
-        buffer version changes."""
-        tensors = self.__dict__.get('_fold_tensors')
-        if tensors is None:
-            tensors = list(self.parameters()) + list(self.buffers())
-            self.__dict__['_fold_tensors'] = tensors
-        key = sum(t._version for t in tensors)
-        hit = self.__dict__.get('_fold_cache_x3')
-        if hit is not None and hit[0] == key and hit[1][0][1].device == self.conv1.weight.device:
-            return hit[1]
-
+    def _folded_x3(self, upto=None):
+        """[(x3 image | folded f32 filter for the stem, bias f32)] per conv in execution order, for the stem and the first `upto`
+        stages (all when None). Cached PER STAGE against the versions of that stage's parameters / buffers: under training with
+        frozen stages only the trainable tail changes, and the frozen prefix is never re-folded."""
         def fold(conv, bn, stem=False):
             s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
             w = conv.weight.detach().float() * s.view(-1, 1, 1, 1)
             b = (bn.bias.detach().float() - bn.running_mean.detach().float() * s).contiguous()
             return (w.contiguous() if stem else ops.pack_conv_weight_x3(w)), b
 
-        with torch.no_grad():
-            seq = [fold(self.conv1, self.bn1, stem=True)]
-            for name in self.res_layers:
-                for blk in getattr(self, name):
-                    if blk.downsample is not None:
-                        seq.append(fold(blk.downsample[0], blk.downsample[1]))
-                    seq.append(fold(blk.conv1, blk.bn1))
-                    seq.append(fold(blk.conv2, blk.bn2))
-                    if isinstance(blk, Bottleneck):
-                        seq.append(fold(blk.conv3, blk.bn3))
-        self.__dict__['_fold_cache_x3'] = (key, seq)
-        return seq
+        def stage_seq(name):
+            if name == 'stem':
+                return [fold(self.conv1, self.bn1, stem=True)]
+            seq = []
+            for blk in getattr(self, name):
+                if blk.downsample is not None:
+                    seq.append(fold(blk.downsample[0], blk.downsample[1]))
+                seq.append(fold(blk.conv1, blk.bn1))
+                seq.append(fold(blk.conv2, blk.bn2))
+                if isinstance(blk, Bottleneck):
+                    seq.append(fold(blk.conv3, blk.bn3))
+            return seq
+
+        cache = self.__dict__.setdefault('_fold_cache_x3', {})
+        names = ['stem'] + list(self.res_layers if upto is None else self.res_layers[:upto])
+        out = []
+        for name in names:
+            mods = [self.conv1, self.bn1] if name == 'stem' else [getattr(self, name)]
+            tensors = [t for m in mods for t in list(m.parameters()) + list(m.buffers())]
+            key = (sum(t._version for t in tensors), str(self.conv1.weight.device))
+            hit = cache.get(name)
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    hit = (key, stage_seq(name))
+                cache[name] = hit
+            out.extend(hit[1])
+        return out
 
     def _x3_ok(self):
         def conv_ok(c):
@@ -341,10 +348,11 @@ class ResNet(nn.Module):
                     return False
         return self.conv1.bias is None
 
-    def _forward_x3(self, x):
+    def _forward_x3(self, x, upto=None):
+        """`upto` = number of leading stages to run (frozen-stage prefix under training): returns (outs, x) channel-last."""
         import torch.nn.functional as F
         x3a = runtime.x3a_enabled()
-        seq = iter(self._folded_x3())
+        seq = iter(self._folded_x3(upto))
         w, b = next(seq)
         mp, c1 = self.maxpool, self.conv1
         if ((mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) and x.dtype == torch.float32
@@ -368,6 +376,8 @@ class ResNet(nn.Module):
 
         outs = []
         for i, name in enumerate(self.res_layers):
+            if upto is not None and i >= upto:
+                break
             for blk in getattr(self, name):
                 identity = x if blk.downsample is None else conv(x, blk.downsample[0], False)
                 y = conv(x, blk.conv1, True)
@@ -378,6 +388,10 @@ class ResNet(nn.Module):
                     x = conv(y, blk.conv2, True, identity)
             if i in self.out_indices:
                 outs.append(x)
+        if upto is not None:
+            # frozen prefix of a training step: plain f32 channel-last maps for the autograd part that follows
+            dec = (lambda t: ops.x3a_decode(t)) if x3a else (lambda t: t)
+            return [dec(o) for o in outs], dec(x)
         # (B, C, H, W)-shaped views of the channel-last f32 activations (no copy): the pixel decoder's parity-mode stream reads
         # them as they are; anything else can `.contiguous()` them. Round 4: the maps are x3a rows, tagged `ops.X3ATensor` -- the
         # pixel decoder's x3 GEMMs consume them as stored, `ops.x3a_to_f32` gives the values
@@ -389,10 +403,23 @@ class ResNet(nn.Module):
         frozen_bn = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         if runtime.is_bf16() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda:
             return self._forward_folded(x)
-        if runtime.x3_enabled() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda and self._x3_ok():
-            return self._forward_x3(x)
+        if runtime.x3_enabled() and not torch.is_grad_enabled() and frozen_bn and x.is_cuda:
+            if self._x3_ok():
+                return self._forward_x3(x)
+            runtime.note_fallback('ResNet', 'a convolution outside the implicit-GEMM rules (groups, dilation, C % 32, N % 8): MIOpen f32')
         outs = []
         first = 0
+        if (FROZEN_FOLDED and runtime.x3_enabled() and torch.is_grad_enabled() and frozen_bn and x.is_cuda and self.frozen_stages >= 1
+                and not x.requires_grad and self._x3_ok() and x.dtype == torch.float32
+                and not any(p.requires_grad for n in self.res_layers[:self.frozen_stages] for p in getattr(self, n).parameters())
+                and not any(p.requires_grad for p in list(self.conv1.parameters()) + list(self.bn1.parameters()))):
+            # parity-mode training with frozen stages: the frozen prefix on the BN-folded f32-class x3 inference path (implicit-GEMM
+            # kernels instead of MIOpen f32 conv + BN + ReLU launches); only the trainable tail goes through autograd
+            with torch.no_grad():
+                fouts, xf = self._forward_x3(x, upto=self.frozen_stages)
+            outs = [o.permute(0, 3, 1, 2) for o in fouts]
+            x = xf.permute(0, 3, 1, 2)
+            first = self.frozen_stages
         if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1 and not x.requires_grad
                 and not any(p.requires_grad for n in self.res_layers[:self.frozen_stages] for p in getattr(self, n).parameters())
                 and not any(p.requires_grad for p in list(self.conv1.parameters()) + list(self.bn1.parameters()))):

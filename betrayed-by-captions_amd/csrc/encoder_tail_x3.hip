@@ -271,6 +271,7 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     for (int Y = 0; Y < 2; ++Y)
       hb[X][Y] = (((4 * wn + k1) * 64 + half * 32 + 2 * (X ^ k1) + 8 * (Y ^ half) + 4 * hi5 + odd) << 2) + ((j & 7) >> 1);
   const uint32_t rot = 16u * (uint32_t)odd;
+  float hmax = 0.f;                                    // largest hidden activation: beyond the f16 x 3 range it raises the overflow flag
   for (int c = 0; c < nchunk; ++c) {
     // ---- GEMM 1: hidden columns 256 c + 64 wn .. (n-tiles 8 c + 2 wn, + 1 of W1); next in the stream: this chunk's W2 slice ----
 #pragma unroll
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
           const float v0 = fmaxf(acc[mt][nt][2 * rp] * cs1 + bias1, 0.f), v1 = fmaxf(acc[mt][nt][2 * rp + 1] * cs1 + bias1, 0.f);
+          hmax = fmaxf(hmax, fmaxf(v0, v1));
           const float kept = odd ? v1 : v0, sent = odd ? v0 : v1;
           const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sent), 0xB1, 0xf, 0xf, true));  // lane ^ 1
           uint32_t ph, pl;
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     __syncthreads();                                   // hfrag is rewritten by the next chunk (and by the tile below)
   }
 
+  if (flag && !(hmax * CGG_X3_ASCALE <= CGG_X3A_MAX)) atomicOr(flag, 1);
   // ---- f32 block (* colscale + b2) -> LDS tile; the hidden images are dead ----
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -428,7 +431,7 @@ static int e3_launch(const float* a32, const float* x32, const void* wo_x3, cons
   hipLaunchKernelGGL(cgg_encoder_tail_x3_kernel, dim3((M + E3_RB - 1) / E3_RB), dim3(E3_NT), lds, (hipStream_t)stream, a32, x32,
                      cgg_x3_view(wo_x3, E3_C, E3_C), bo, gamma0, beta0, eps0, cgg_x3_view(w1_x3, F, E3_C), b1,
                      cgg_x3_view(w2_x3, E3_C, F), b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M, F, x3a,
-                     x3a ? cgg_x3_overflow_flag_ptr() : nullptr);
+                     cgg_x3_overflow_flag_ptr());
   CGG_CHECK_LAUNCH(who);
   return CGG_OK;
 }

@@ -96,9 +96,6 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
   // the loader walks the chunks in order (two ahead of the MFMAs); its position is scalar state: channel offset and filter tap
   int ld_c = 0, ld_c0 = 0, ld_ky = 0, ld_kx = 0;
   auto load_chunk = [&](u32x4 (&av)[TM][2], u32x4 (&bv)[NB]) {
-#if defined(XG_EXP) && XG_EXP == 1
-    if (ld_c > 1) { if (ld_c + 1 < nchunk) ++ld_c; return; }
-#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if constexpr (CONV) {
@@ -134,25 +131,14 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       u32x4 h, l;
-#if defined(XG_EXP) && XG_EXP == 2
-      h = av[i][0]; l = av[i][1];
-#else
       cgg_x3_split8(__builtin_bit_cast(f32x4, av[i][0]), __builtin_bit_cast(f32x4, av[i][1]), h, l);
-#endif
-#if !(defined(XG_EXP) && XG_EXP == 3)
       s[aslot[i]] = h;
       s[A_SLOTS + aslot[i]] = l;
-#else
-      if (h[0] == 0x12345678u && l[1] == 0x9abcdef0u) s[aslot[i]] = h;
-#endif
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int u = q * 256 + tid;
       const int piece = u / B_SLOTS, within = u - piece * B_SLOTS;
-#if defined(XG_EXP) && XG_EXP == 3
-      if (bv[q][0] == 0x12345678u && bv[q][1] == 0x9abcdef0u)
-#endif
       s[2 * A_SLOTS + piece * B_SLOTS + within] = bv[q];
     }
   };
@@ -304,17 +290,12 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   // scratch/ab_tiles.sh): the larger tiles are the more efficient ones per FLOP, and the CUs a small grid leaves idle are taken by
   // the other streams' kernels, so the step prefers FEWER, BIGGER tiles than a stand-alone launch does -- threshold 384 + smaller
   // tiles for K <= 512 (the stand-alone optimum of the first version): 349 images/s; 192, no K rule: 358 (eager GEMM time equal);
-  // 128: 363 with +7 % eager GEMM time and +3 % latency (not taken). CGG_XG_MINTILES / CGG_XG_SMALLK override.
+  // 128: 363 with +7 % eager GEMM time and +3 % latency (not taken). CGG_XG_MINTILES overrides.
   static const int mintiles = getenv("CGG_XG_MINTILES") ? atoi(getenv("CGG_XG_MINTILES")) : 192;
   auto tiles = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)); };
   int tm = 2, tn = N <= 64 ? 1 : 2;
   if (tiles(tm, tn) < mintiles) tm = 1;
   if (tiles(tm, tn) < mintiles && tn == 2) tn = 1;
-  static const int smallk = getenv("CGG_XG_SMALLK") ? atoi(getenv("CGG_XG_SMALLK")) : 0;
-  if (K <= smallk) {
-    if (tm == 2) tm = 1;
-    else if (tn == 2) tn = 1;
-  }
   const int tiles_n = (N + 64 * tn - 1) / (64 * tn);
   const CggX3W w = cgg_x3_view(w_x3, N, K);
   const dim3 grid((unsigned)tiles(tm, tn)), block(XG_NT);

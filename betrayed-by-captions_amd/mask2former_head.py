@@ -684,6 +684,9 @@ class Mask2FormerHeadOpen(nn.Module):
                 kvs = self._project_kv_x3a(memorys, sizes)
                 return dict(stream=True, kvs=kvs, sizes=sizes, packed_full=packed_full, pooled=pooled, mask_features=None)
         else:
+            if runtime.x3_enabled() and not torch.is_grad_enabled() and feats[0].is_cuda:
+                runtime.note_fallback('pixel decoder / head', 'stream_ready_x3() is false for this configuration: module path on f32 '
+                                      'library GEMMs')
             feats = [ops.x3a_to_f32(f) if ops.is_x3a(f) else f for f in feats]       # x3a backbone maps outside the x3 stream
             feats = [f.float().contiguous() if f.dtype != torch.float32 else f for f in feats]
             mask_features, memorys = pd(feats)

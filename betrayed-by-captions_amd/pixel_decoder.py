@@ -33,7 +33,6 @@ FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
 FUSED_TRAIN_MSDA = os.environ.get('CGG_FUSED_TRAIN_MSDA', '1') != '0'   # training: MSDeformAttn prologue inside the kernels (fwd + bwd)
 FUSED_TRAIN_LN = os.environ.get('CGG_FUSED_TRAIN_LN', '1') != '0'   # training: residual + LayerNorm as one-pass HIP fwd / bwd
 VALUE_HEAD_MAJOR = os.environ.get('CGG_VALUE_HEAD_MAJOR', '1') != '0'   # value written (B, 8, N, 32) for the MSDeformAttn gather
-X3_SPLIT_PROJ = os.environ.get('CGG_X3_SPLIT_PROJ', '0') == '1'   # parity mode: value + offsets projections as one split-output GEMM
 POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
 
 
@@ -838,21 +837,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                            lambda: torch.cat([so.weight, aw.weight], 0).float().contiguous())
             b_cat = runtime.derived_cached('msda_bcat32', (so.bias, aw.bias),
                                            lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
-            if X3_SPLIT_PROJ and C % 32 == 0:
-                # (measured SLOWER than the two launches: 266 vs 280 images/s -- off by default) value_proj and the offsets | weights projection as ONE x3 GEMM over the rows `src`: (src + pos) Wc^T + bc =
-                # src Wc^T + (pos Wc^T + bc), the bracket a per-token table that depends on the weights alone (cached)
-                vp = attn.value_proj
-                wall = runtime.derived_cached('msda_wall_x3', (vp.weight, so.weight, aw.weight),
-                                              lambda: ops.pack_linear_weight_x3(torch.cat([vp.weight, so.weight, aw.weight], 0)))
-                table = runtime.derived_cached(
-                    'msda_pos_table', (pos, vp.bias, so.weight, aw.weight, so.bias, aw.bias),
-                    lambda: torch.cat([vp.bias.float().view(1, -1).expand(N, -1),
-                                       (pos.double() @ w_cat.double().t() + b_cat.double()).float()], 1).contiguous())
-                value, offs = ops.gemm_x3_split(src.view(B * N, C), wall, C + w_cat.shape[0], C, res_table=table)
-                value, offs = value.view(B, N, H, C // H), offs.view(B, N, -1)
-            else:
-                value = lx(src, attn.value_proj.weight, attn.value_proj.bias).view(B, N, H, C // H)
-                offs = lx(srcp if srcp is not None else src + pos[None], w_cat, b_cat)
+            # (value_proj and the offsets | weights projection as ONE split-output GEMM with a per-token table -- `ops.gemm_x3_split`
+            # -- was measured slower twice, 266 vs 280 images/s: two launches)
+            value = lx(src, attn.value_proj.weight, attn.value_proj.bias).view(B, N, H, C // H)
+            offs = lx(srcp if srcp is not None else src + pos[None], w_cat, b_cat)
             a = ops.msda_forward_fused(value, level_hw, level_start, offs, ref, attn.num_points)
             n0, n1 = layer.norms
             fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
@@ -863,7 +851,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 src, srcp = ops.encoder_layer_tail_x3(a, src.contiguous(), x3w(attn.output_proj), attn.output_proj.bias,
                                                       (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
                                                       (n1.weight, n1.bias, n1.eps), pos=pos,
-                                                      want_pos=not last and not X3_SPLIT_PROJ)
+                                                      want_pos=not last)
                 continue
             srcp = None
             y = lx(a, attn.output_proj.weight, attn.output_proj.bias, res=src)

@@ -1,8 +1,13 @@
 """Process-wide execution switches of the MI355X path.
 
 precision:
-  'fp32' -- parity mode (default): f32 GEMMs (hipBLASLt), f32 MSDeformAttn values, mask logits as
-            3x bf16 MFMA on (hi, lo) split operands (f32-class accuracy), attention on f32 MFMA.
+  'fp32' -- parity mode (default). Inference (no autograd): every contraction in f32-class f16 x 3 arithmetic on the matrix
+            cores (csrc/x3.h: two f16 pieces per f32 operand, three v_mfma_f32_32x32x16_f16 per product, f32 accumulate) on
+            own kernels -- the LDS-DMA GEMM / implicit-GEMM convolution over pre-split "x3a" activation rows
+            (csrc/x3s_gemm.hip), the one-launch encoder tail, the x3 query-decoder chains, the x3 mask-logit einsum; f32
+            MSDeformAttn values / norms / softmax; f32-MFMA attention. Under autograd (training): f32 library GEMMs /
+            convolutions (hipBLASLt / MIOpen) with the HIP kernels for attention, MSDeformAttn, losses.
+            CGG_X3=0 restores round 2's f32-library parity path, CGG_X3A=0 round 3's f32-row x3 stream (A/B only).
   'bf16' -- throughput mode named by BASELINE.json's north_star: bf16 MFMA contractions
             (mask logits 1x bf16 MFMA, bf16 values for the MSDeformAttn gather, torch GEMMs/convs
             under bf16 autocast); softmax / normalisation / accumulation stay f32.
@@ -141,6 +146,61 @@ class _SplitKLinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _X3LinearFn(torch.autograd.Function):
+    """Training-time `F.linear` in PARITY mode (the reference trains in f32, open_set/apis/train.py:182-189) for the encoder
+    stream's row counts: forward y = x W^T + b and grad-input dx = dy W on the f32-class x3 GEMM (`ops.gemm_x3`, three f16 MFMAs
+    per product, as accurate as an f32 GEMM -- tests/test_x3_gpu.py); the x3 images of W and W^T are re-packed when the optimiser
+    changes the weight (cached against its version). The weight gradient dW = dy^T x reduces over ALL rows into a tiny output:
+    rows cut into S slabs, ONE batched f32 library GEMM for the partial gradients and their sum (the split of `_SplitKLinearFn`;
+    an x3 kernel for this transposed-operand contraction is not built)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+        N, K = weight.shape
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        wk = derived_cached('x3_image', (weight,), lambda: ops.pack_linear_weight_x3(weight))
+        y = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)    # (not a view: callers apply relu_ in place)
+        ops.gemm_x3(x2, wk, N, bias.detach() if bias is not None else None, out=y.view(-1, N))
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        g2 = gy.reshape(-1, N)
+        if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        M = x2.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wtk = derived_cached('x3_image_t', (weight,), lambda: ops.pack_linear_weight_x3(weight.detach().t().contiguous()))
+            gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
+            ops.gemm_x3(g2, wtk, K, out=gx.view(-1, K))
+        if ctx.needs_input_grad[1]:
+            S = next((s for s in (32, 16, 8, 4, 2) if M % s == 0 and M // s >= 4096), 1)
+            gw = torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+X3_TRAIN_ROWS = 8192               # rows from which parity-mode training linears run on the x3 GEMM (CGG_X3_TRAIN=0 disables)
+_X3_TRAIN = _os.environ.get('CGG_X3_TRAIN', '1') != '0'
+
+
+def x3_train_linear_ok(x, weight):
+    return (_X3_TRAIN and x3_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and weight.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0 and x.shape[-1] == weight.shape[1]
+            and x.numel() // x.shape[-1] >= X3_TRAIN_ROWS)
+
+
 SPLITK_WGRAD_ROWS = 32768          # rows from which the training linears use `_SplitKLinearFn` (CGG_SPLITK_WGRAD=0 disables)
 
 
@@ -166,7 +226,28 @@ def linear(x, weight, bias=None):
         return linear_bf16_train(x, weight, bias).float()
     if x3_linear_ok(x, weight):
         return linear_x3(x, weight, bias)
+    if x3_train_linear_ok(x, weight):
+        return _X3LinearFn.apply(x, weight, bias)
+    if x3_enabled() and not torch.is_grad_enabled() and x.is_cuda and x.numel() // max(x.shape[-1], 1) >= 512:
+        note_fallback('linear', f'K={weight.shape[1]} (K % 32) / dtype {x.dtype}: f32 library GEMM instead of the x3 kernel')
     return F.linear(x, weight, bias)
+
+
+# Parity mode's inference stream has shape rules (K % 32, C % 32, N % 8, 1 x 1 / 3 x 3 convolutions, GN-32 over 256 channels, ...).
+# A module that falls outside them runs on f32 LIBRARY calls instead of the x3 kernels -- correct, slower, and formerly silent:
+# every such event is counted here (bench.py reports the total as `library_fallbacks`) and logged once per kind.
+FALLBACKS = {}
+
+
+def note_fallback(kind, detail):
+    import logging
+    if kind not in FALLBACKS:
+        logging.getLogger('cgg_amd').warning('parity mode: %s left the x3 stream -- %s', kind, detail)
+    FALLBACKS[kind] = FALLBACKS.get(kind, 0) + 1
+
+
+def library_fallbacks():
+    return sum(FALLBACKS.values())
 
 
 def x3_linear_ok(x, weight):

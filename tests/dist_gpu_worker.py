@@ -18,11 +18,73 @@ import torch                        # noqa: E402
 import torch.distributed as dist    # noqa: E402
 
 
+def check_gathered_grounding_loss(model, rank, world, dev):
+    """The one place the path is not image-independent: the grounding loss contrasts every caption with every image of the
+    GLOBAL batch (open_set/models/losses/grounding_loss.py:21-30) after `gather_captions_and_preds`
+    (open_set/models/mask2former_head.py:650-684). Every rank regenerates BOTH ranks' (seeded) captions / predictions, the oracle's
+    literal restatement is evaluated in float64 on their concatenation, and the product's gathered loss + the gradient of the local
+    slice (the only part that carries one) must equal it -- for the per-layer gather and for the coalesced per-step gather."""
+    from oracle import head as OH
+    head = model.panoptic_head
+    Bl, Q, T = 2, 12, 6
+    d = head.v2l_transform.out_features
+
+    def rank_inputs(r):
+        g = torch.Generator().manual_seed(4242 + r)
+        preds = [torch.randn(Bl, Q, d, generator=g) * 0.3 for _ in range(3)]           # three decoder layers
+        embs = torch.randn(Bl, T, d, generator=g) * 0.3
+        mask = (torch.rand(Bl, T, generator=g) > 0.3).float()
+        if r == 1:
+            mask[0] = 0.0                                                             # a caption without nouns on rank 1
+        return preds, embs, mask
+
+    mine = rank_inputs(rank)
+    every = [rank_inputs(r) for r in range(world)]
+    temp = float(head.softmax_temperature)
+    for li in range(3):
+        # ---- oracle on the concatenated global batch (float64), gradient w.r.t. ALL predictions ----
+        P = torch.cat([e[0][li] for e in every], 0).double().requires_grad_(True)
+        E = torch.cat([e[1] for e in every], 0).double()
+        M = torch.cat([e[2] for e in every], 0)
+        want = OH.grounding_loss(P, E, M.double(), temp)
+        want.backward()
+        want_grad = P.grad[rank * Bl:(rank + 1) * Bl]
+        # ---- product: gather + loss on the device, backward through the local slice ----
+        p_loc = mine[0][li].to(dev).requires_grad_(True)
+        embs_l = [t for t in mine[1].to(dev)]
+        mask_l = [t for t in mine[2].to(dev)]
+        all_e, all_m, all_p = head.gather_captions_and_preds(embs_l, mask_l, p_loc)
+        assert all_p.shape[0] == world * Bl
+        got = head.loss_grounding(all_p, all_e, all_m, temp) / head.loss_grounding.loss_weight
+        got.backward()
+        assert abs(float(got) - float(want)) <= 1e-4 * (1 + abs(float(want))), (li, float(got), float(want))
+        gerr = (p_loc.grad.cpu().double() - want_grad).abs().max().item()
+        assert gerr <= 1e-4 * (want_grad.abs().max().item() + 1e-9), (li, gerr)
+    # ---- the coalesced form (3 collectives per step for all layers) gives the same per-layer operands ----
+    p_all = [t.to(dev) for t in mine[0]]
+    outs = head._gather_all_layers([t for t in mine[1].to(dev)], [t for t in mine[2].to(dev)], p_all)
+    for li, (ae, am, ap) in enumerate(outs):
+        P = torch.cat([e[0][li] for e in every], 0)
+        assert torch.equal(ap.cpu(), P) and torch.equal(ae.cpu(), torch.cat([e[1] for e in every], 0))
+        assert torch.equal(am.cpu(), torch.cat([e[2] for e in every], 0))
+    print(f'rank {rank}: gathered grounding loss == oracle on the concatenated batch (3 layers, loss 1e-4, local-slice gradient 1e-4)',
+          flush=True)
+
+
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
+    # one device per rank over RCCL when the box has them (an 8-GPU node); two ranks on device 0 over gloo otherwise (RCCL
+    # refuses two ranks on one GPU). Counting devices does not initialise the GPU.
+    ndev = torch.cuda.device_count()
+    multi = ndev >= world
+    local = int(os.environ.get('LOCAL_RANK', rank)) if multi else 0
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if multi:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    print(f'rank {rank}: backend {dist.get_backend()} on {dev} ({ndev} visible device(s))', flush=True)
     import cgg_amd  # noqa: F401
     from cgg_amd import registry, runtime, synthetic
     from cgg_amd.train import GradReducer, build_optimizer, train_step
@@ -40,6 +102,7 @@ def main():
             m.p = 0.0
     B, H, W = 2, 128, 128
     nc = cfg['panoptic_head']['num_things_classes']
+    check_gathered_grounding_loss(model, rank, world, dev)
     reducer = GradReducer(model, bucket_bytes=4 << 20)           # several buckets
     assert len(reducer.buckets) >= 3
     reducer.broadcast_parameters(model)
@@ -89,8 +152,8 @@ def main():
             dist.broadcast(t, src=0)
             assert torch.equal(t, p.detach()), ('parameters diverged', n, step)
         # the loss log is the mean over ranks
-        mine = torch.tensor([float(out['log_vars']['loss'])])
-        both = [torch.zeros(1) for _ in range(world)]
+        mine = torch.tensor([float(out['log_vars']['loss'])], device=dev if multi else 'cpu')
+        both = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(both, mine)
         assert abs(float(sum(both) / world) - float(out['log_vars']['loss'])) < 1e-4 * (1 + abs(float(mine)))
         print(f'rank {rank} step {step}: loss {logs["loss"]:.4f}, {len(reducer.buckets)} buckets in order, '

@@ -154,3 +154,54 @@ def test_gemm_x3s_large_k_and_default_config(dev):
         y = ops.gemm_x3s(xe, packed, N, b.to(dev))
         assert _err(y, want) <= 4 * f32_err + 2e-7 * want.abs().max().item(), (M, N, K)
         assert torch.equal(y, ops.gemm_x3s(xe, packed, N, b.to(dev)))   # bit-reproducible
+
+
+def test_x3_training_linear_forward_and_gradients_vs_float64(dev):
+    """runtime._X3LinearFn (parity-mode training: forward and grad-input on the x3 GEMM, weight gradient as a split-K f32 library
+    GEMM) vs float64 autograd of F.linear at an encoder-stream row count: f32-GEMM accuracy for y, dx, dW, db."""
+    from cgg_amd import runtime
+    g = torch.Generator().manual_seed(490)
+    M, K, N = 16384, 256, 288
+    x = torch.randn(2, M // 2, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    gy = torch.randn(2, M // 2, N, generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    yd = F.linear(xd, wd, bd)
+    yd.backward(gy.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    with runtime.precision_scope('fp32'):
+        assert runtime.x3_train_linear_ok(xg, wg)
+        y = runtime.linear(xg, wg, bg)
+        assert y.grad_fn is not None and 'X3Linear' in type(y.grad_fn).__name__
+        y.relu_()                                                        # callers apply activations in place: y must not be a view
+        y2 = runtime.linear(xg, wg, bg)
+        y2.backward(gy.to(dev))
+    for got, want, name in ((y2, yd, 'y'), (xg.grad, xd.grad, 'dx'), (wg.grad, wd.grad, 'dW'), (bg.grad, bd.grad, 'db')):
+        scale = want.abs().max().item()
+        err = (got.detach().cpu().double() - want.detach()).abs().max().item()
+        assert err <= 2e-5 * scale, (name, err, scale)
+
+
+def test_overflow_in_the_stream_is_reported_not_silent(dev):
+    """A stored activation beyond the f16 x 3 range (|a| >= 4094) must not pass silently as inf / NaN masks: the
+    ResNet's x3a producers raise the device flag, `ops.x3_overflow_check` reports it (tools/test.py turns it into an error)."""
+    import warnings
+    from cgg_amd import registry, runtime
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        bb = registry.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1,
+                                          norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch'))
+        bb.init_weights()
+    bb = bb.to(dev).eval()
+    img = torch.randn(1, 3, 128, 128, device=dev)
+    with torch.no_grad(), runtime.precision_scope('fp32'):
+        ops.x3_overflow_check(dev)
+        feats = bb(img)
+        torch.cuda.synchronize()
+        assert ops.is_x3a(feats[0]) and not ops.x3_overflow_check(dev)
+        assert all(torch.isfinite(ops.x3a_to_f32(f)).all() for f in feats)
+        bb.layer1[0].bn3.weight.mul_(1e5)                                # a BN-folded scale that drives layer1's output past the range
+        feats = bb(img)
+        torch.cuda.synchronize()
+        assert ops.x3_overflow_check(dev)

@@ -48,7 +48,9 @@ def parse_args(argv=None):
     p.add_argument('--samples-per-gpu', type=int, default=2)
     p.add_argument('--synthetic', type=int, default=1024, help='synthetic image size (H = W) when --data is not given')
     p.add_argument('--data', default=None, help='pkg.module:function -> iterable of (img (3,H,W) float tensor, img_meta)')
-    p.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                   help='fp32 = parity mode: every contraction in f32-class f16 x 3 arithmetic (as accurate as f32 GEMMs; activations '
+                        'must satisfy |a| < 4094 -- the run fails loudly otherwise, CGG_X3=0 lifts the limit); bf16 = throughput mode')
     p.add_argument('--no-pipeline', action='store_true', help='plain sequential simple_test (no graphs / overlap)')
     p.add_argument('--rle', action='store_true',
                    help='results in the evaluation format: masks as COCO RLE dicts (what results2json builds with pycocotools from '
@@ -240,6 +242,14 @@ def main(argv=None):
             run(group)                 # trailing short batch: sequential path (len(group) != B)
         drain()
         torch.cuda.synchronize()
+        # parity mode stores its GEMM-consumed activations as f16 x 3 pieces of 16 a: a value with |a| >= 4094 (an un-normalised
+        # input, a checkpoint with one huge BN-folded scale) becomes inf / NaN. Every producer raises a device flag; ONE read at
+        # the end of the run turns it into an error instead of silently wrong masks (the f32 reference has no such limit)
+        if args.precision == 'fp32' and runtime.x3a_enabled():
+            from cgg_amd import ops
+            if ops.x3_overflow_check(device):
+                raise SystemExit('tools/test.py: an activation left the f16 x 3 range of parity mode (|a| >= 4094): results may hold '
+                                 'inf / NaN. Re-run with CGG_X3=0 (f32 library path, no range limit).')
         if collector is not None:          # futures -> host results, in submission (= dataset) order
             flat = []
             for r in results:
