@@ -488,7 +488,8 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
 
 // Backward (f32). Lane group of DQ lanes = one (query, head): the channel reductions for
 // grad_loc / grad_attn are wave shuffles; grad_value is scattered with hardware f32 atomics.
-template <int P_>
+// GV = false: grad_loc / grad_attn only (the gather half of the split backward; grad_value comes from the tiled scatter kernel)
+template <int P_, bool GV = true>
 __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ gout, float* __restrict__ gvalue,
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
         glp[2 * i] += (float)Wl * w * dotx;
         glp[2 * i + 1] += (float)Hl * w * doty;
       }
-      if (live) {
+      if (GV && live) {
         const f32x4 wg = w * g;
         if (t.w00 != 0.f) {
           float* d = gvl + (size_t)t.o00 * rowstride;
@@ -582,6 +583,104 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
           for (int c = 0; c < 4; ++c) atomicAdd(d + c, t.w11 * wg[c]);
         }
       }
+    }
+  }
+}
+
+// grad_loc / grad_attn for P = 4 (the gather half of the split backward): per level the (query, head)'s 8 location floats and 4
+// weights arrive as three 16-byte loads, the 16 corner loads of its 4 points are all in flight before the first use, and the
+// results leave as three 16-byte read-modify-writes whose reads were requested with the corner loads (the generic kernel's per-point
+// scalar loads and `+=` chains ran this half at 2.3 ms per layer at configs[2]; the forward gathers the same taps in 0.16 ms x 6).
+__global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
+    const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc, const float* __restrict__ attw,
+    const float* __restrict__ gout, float* __restrict__ gloc, float* __restrict__ gattw, int Nv, int H, int D, int L, int Nq,
+    long long total) {
+  const int DQ = D >> 2;
+  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
+  const long long gid = (long long)bid * 256 + threadIdx.x;
+  const bool live = gid < total;
+  const long long g2 = live ? gid : total - 1;  // keep every lane in the shuffles
+  const int cq = (int)(g2 % DQ);
+  const int h = (int)((g2 / DQ) % H);
+  const long long bq = g2 / ((long long)DQ * H);
+  const int b = (int)(bq / Nq);
+  const size_t rowstride = (size_t)H * D;
+  const size_t coff = (size_t)h * D + cq * 4;
+  const float* vb = value + (size_t)b * Nv * rowstride + coff;
+  const int LP = L * 4;
+  const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
+  const float* wp = attw + ((size_t)bq * H + h) * LP;
+  float* glp = gloc + ((size_t)bq * H + h) * LP * 2;
+  float* gwp = gattw + ((size_t)bq * H + h) * LP;
+  f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + coff);
+  if (!live) g = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool owner = live && cq == 0;
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.h[l], Wl = lv.w[l];
+    const float* vl = vb + (size_t)lv.start[l] * rowstride;
+    const f32x4 xy0 = cgg_ld4(lp + 8 * l), xy1 = cgg_ld4(lp + 8 * l + 4), w4 = cgg_ld4(wp + 4 * l);
+    f32x4 ow = {0.f, 0.f, 0.f, 0.f}, ol0 = ow, ol1 = ow;
+    if (owner) {
+      ow = cgg_ld4(gwp + 4 * l);
+      ol0 = cgg_ld4(glp + 8 * l);
+      ol1 = cgg_ld4(glp + 8 * l + 4);
+    }
+    const float xs[4] = {xy0[0], xy0[2], xy1[0], xy1[2]}, ys[4] = {xy0[1], xy0[3], xy1[1], xy1[3]};
+    f32x4 v[4][4];
+    float lh[4], lw[4];
+    bool k[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float him = ys[p] * (float)Hl - 0.5f, wim = xs[p] * (float)Wl - 0.5f;
+      const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
+      const float hf = floorf(him), wf = floorf(wim);
+      const int h0 = (int)hf, w0 = (int)wf;
+      lh[p] = him - hf;
+      lw[p] = wim - wf;
+      const bool vh0 = in && h0 >= 0, vh1 = in && (h0 + 1) <= Hl - 1;
+      const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wl - 1;
+      k[p][0] = vh0 && vw0; k[p][1] = vh0 && vw1; k[p][2] = vh1 && vw0; k[p][3] = vh1 && vw1;
+      const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h0 + 1, 0), Hl - 1);
+      const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w0 + 1, 0), Wl - 1);
+      v[p][0] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw0) * rowstride);
+      v[p][1] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw1) * rowstride);
+      v[p][2] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw0) * rowstride);
+      v[p][3] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw1) * rowstride);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float hh = 1.f - lh[p], hw = 1.f - lw[p];
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 v00 = k[p][0] ? v[p][0] : z4, v01 = k[p][1] ? v[p][1] : z4;
+      const f32x4 v10 = k[p][2] ? v[p][2] : z4, v11 = k[p][3] ? v[p][3] : z4;
+      float dotv = 0.f, dotx = 0.f, doty = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float val = hh * hw * v00[c] + hh * lw[p] * v01[c] + lh[p] * hw * v10[c] + lh[p] * lw[p] * v11[c];
+        const float dw = hh * (v01[c] - v00[c]) + lh[p] * (v11[c] - v10[c]);
+        const float dh = hw * (v10[c] - v00[c]) + lw[p] * (v11[c] - v01[c]);
+        dotv += val * g[c];
+        dotx += dw * g[c];
+        doty += dh * g[c];
+      }
+      for (int o = 1; o < DQ; o <<= 1) {
+        dotv += __shfl_xor(dotv, o);
+        dotx += __shfl_xor(dotx, o);
+        doty += __shfl_xor(doty, o);
+      }
+      ow[p] += dotv;
+      if (p < 2) {
+        ol0[2 * p] += (float)Wl * w4[p] * dotx;
+        ol0[2 * p + 1] += (float)Hl * w4[p] * doty;
+      } else {
+        ol1[2 * p - 4] += (float)Wl * w4[p] * dotx;
+        ol1[2 * p - 3] += (float)Hl * w4[p] * doty;
+      }
+    }
+    if (owner) {
+      *reinterpret_cast<f32x4*>(gwp + 4 * l) = ow;
+      *reinterpret_cast<f32x4*>(glp + 8 * l) = ol0;
+      *reinterpret_cast<f32x4*>(glp + 8 * l + 4) = ol1;
     }
   }
 }
@@ -612,7 +711,10 @@ struct MsdaTilePlan {
   int nthreads;
 };
 
-template <int P_>
+// SO (scatter only) = true: grad_value only -- no value loads, no channel reductions; grad_loc / grad_attn come from
+// cgg_msda_bwd_kernel<P, false> at full occupancy (round 4: the fused form waited 59 % of its wave cycles on the corner gathers
+// with ONE 12-wave workgroup per CU -- the windows take the LDS -- and ran 6x slower than the forward's gather of the same taps)
+template <int P_, bool SO = false>
 __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
     const float* __restrict__ value, MsdaLevels lv, MsdaTilePlan pl, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ gout, float* __restrict__ gvalue,
@@ -622,6 +724,10 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
   const int P = P_ > 0 ? P_ : Prt;
   constexpr int PC = P_ > 0 ? P_ : 1;   // points per load batch
   const int DQ = D >> 2;
+  // window pixel stride in 8-byte elements: D + 2, NOT D -- with D = 32 a pixel's channels fill exactly one 256-byte LDS bank row,
+  // so the same channel of ANY two pixels shared a bank and the 8 queries of a wave conflicted 8 ways on every ds_add_u64
+  // (PMC, round 4: SQ_LDS_BANK_CONFLICT = 58 % of SQ_LDS_IDX_ACTIVE)
+  const int DP = D + 2;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
   const int tile = bid % pl.ntile;
@@ -730,6 +836,16 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
         int h0[PC], w0[PC];
         bool k[PC][4];
         int ro[PC][4];
+        // P_ == 4: the level's 4 + 8 grad_attn / grad_loc values of this (query, head) leave as three 16-byte read-modify-writes
+        // whose reads are requested HERE, with the corner loads (the per-point `+=` was a dependent global load -> add -> store
+        // chain, 36 per (query, head), that stalled all 64 lanes of the wave each time)
+        const bool owner = !SO && live && cq == 0;
+        f32x4 ow = {0.f, 0.f, 0.f, 0.f}, ol0 = ow, ol1 = ow;
+        if (P_ == 4 && owner) {
+          ow = cgg_ld4(gwp + 4 * l);
+          ol0 = cgg_ld4(glp + 8 * l);
+          ol1 = cgg_ld4(glp + 8 * l + 4);
+        }
 #pragma unroll
         for (int p = 0; p < PC; ++p) {
           const int i = l * P + p0 + p;
@@ -748,32 +864,46 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
           const int ch0 = min(max(h0[p], 0), Hl - 1), ch1 = min(max(h0[p] + 1, 0), Hl - 1);
           const int cw0 = min(max(w0[p], 0), Wl - 1), cw1 = min(max(w0[p] + 1, 0), Wl - 1);
           ro[p][0] = ch0 * Wl + cw0; ro[p][1] = ch0 * Wl + cw1; ro[p][2] = ch1 * Wl + cw0; ro[p][3] = ch1 * Wl + cw1;
+          if (!SO) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[p][q] = cgg_ld4(vl + (size_t)ro[p][q] * rowstride);
+            for (int q = 0; q < 4; ++q) v[p][q] = cgg_ld4(vl + (size_t)ro[p][q] * rowstride);
+          }
         }
 #pragma unroll
         for (int p = 0; p < PC; ++p) {
           const int i = l * P + p0 + p;
           const float hh = 1.f - lh[p], hw = 1.f - lw[p];
-          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 v00 = k[p][0] ? v[p][0] : z4, v01 = k[p][1] ? v[p][1] : z4;
-          const f32x4 v10 = k[p][2] ? v[p][2] : z4, v11 = k[p][3] ? v[p][3] : z4;
           float dotv = 0.f, dotx = 0.f, doty = 0.f;
+          if (!SO) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v00 = k[p][0] ? v[p][0] : z4, v01 = k[p][1] ? v[p][1] : z4;
+            const f32x4 v10 = k[p][2] ? v[p][2] : z4, v11 = k[p][3] ? v[p][3] : z4;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float val = hh * hw * v00[c] + hh * lw[p] * v01[c] + lh[p] * hw * v10[c] + lh[p] * lw[p] * v11[c];
-            const float dw = hh * (v01[c] - v00[c]) + lh[p] * (v11[c] - v10[c]);
-            const float dh = hw * (v10[c] - v00[c]) + lw[p] * (v11[c] - v01[c]);
-            dotv += val * g[c];
-            dotx += dw * g[c];
-            doty += dh * g[c];
+            for (int c = 0; c < 4; ++c) {
+              const float val = hh * hw * v00[c] + hh * lw[p] * v01[c] + lh[p] * hw * v10[c] + lh[p] * lw[p] * v11[c];
+              const float dw = hh * (v01[c] - v00[c]) + lh[p] * (v11[c] - v10[c]);
+              const float dh = hw * (v10[c] - v00[c]) + lw[p] * (v11[c] - v01[c]);
+              dotv += val * g[c];
+              dotx += dw * g[c];
+              doty += dh * g[c];
+            }
+            for (int o = 1; o < DQ; o <<= 1) {
+              dotv += __shfl_xor(dotv, o);
+              dotx += __shfl_xor(dotx, o);
+              doty += __shfl_xor(doty, o);
+            }
           }
-          for (int o = 1; o < DQ; o <<= 1) {
-            dotv += __shfl_xor(dotv, o);
-            dotx += __shfl_xor(dotx, o);
-            doty += __shfl_xor(doty, o);
-          }
-          if (live && cq == 0) {
+          if (SO) {
+          } else if (P_ == 4) {
+            ow[p] += dotv;
+            if (p < 2) {
+              ol0[2 * p] += (float)Wl * wt[p] * dotx;
+              ol0[2 * p + 1] += (float)Hl * wt[p] * doty;
+            } else {
+              ol1[2 * p - 4] += (float)Wl * wt[p] * dotx;
+              ol1[2 * p - 3] += (float)Hl * wt[p] * doty;
+            }
+          } else if (live && cq == 0) {
             // grad_loc / grad_attn follow the accumulate-into-prezeroed contract of the C ABI
             gwp[i] += dotv;
             glp[2 * i] += (float)Wl * wt[p] * dotx;
@@ -791,7 +921,7 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
   if (K) {                                                                                              \
     const float cw_ = (WT);                                                                             \
     if ((IY) && (IX)) {                                                                                 \
-      unsigned long long* d = wl + (size_t)((HY) * ww + (WX)) * D;                                      \
+      unsigned long long* d = wl + (size_t)((HY) * ww + (WX)) * DP;                                     \
       _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                   \
         const double m_ = fma((double)cw_, wgd[c], kMagic);                                             \
         atomicAdd(d + c, (unsigned long long)(__double_as_longlong(m_) - __double_as_longlong(kMagic))); \
@@ -808,6 +938,11 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
 #undef CGG_SCATTER
           }
         }
+        if (P_ == 4 && owner) {
+          *reinterpret_cast<f32x4*>(gwp + 4 * l) = ow;
+          *reinterpret_cast<f32x4*>(glp + 8 * l) = ol0;
+          *reinterpret_cast<f32x4*>(glp + 8 * l + 4) = ol1;
+        }
       }
     }
   }
@@ -822,9 +957,9 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
     const unsigned long long* wl = win + pl.off[l];
     const int nf = ww * ww * D;
     for (int i = tid; i < nf; i += nth) {
-      const long long a = (long long)wl[i];
+      const int px = i / D, ch = i - px * D;
+      const long long a = (long long)wl[px * DP + ch];
       if (a != 0) {
-        const int px = i / D, ch = i - px * D;
         const int iy = oy + px / ww, ix = ox + px % ww;      // inside the image whenever a != 0
         atomicAdd(gvl + (size_t)(iy * Wl + ix) * rowstride + ch, (float)((double)a * inv));
       }
@@ -853,7 +988,7 @@ static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, in
     for (int l = 0; l < L; ++l) {
       pl->ww[l] = c * pl->s[l] + 2 * R;
       pl->off[l] = (int)f;
-      f += (long long)pl->ww[l] * pl->ww[l] * D;
+      f += (long long)pl->ww[l] * pl->ww[l] * (D + 2);       // pixel stride D + 2 (bank spreading, see the kernel)
       nq += (long long)c * pl->s[l] * c * pl->s[l];
     }
     if (f * 8 <= 144 * 1024) {
@@ -1036,7 +1171,25 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
   if (D % 4 == 0 && msda_tile_plan(lv, L, D, P, Nq, Nv, &pl)) {
     const size_t lds = (size_t)pl.total * sizeof(unsigned long long);
     const int nblk = B * H * pl.ntile;
-    auto kern = (P == 4) ? cgg_msda_bwd_tiled_kernel<4> : cgg_msda_bwd_tiled_kernel<0>;
+    // split backward (default; CGG_MSDA_BWD_FUSED=1 = the one-kernel form, A/B only): grad_loc / grad_attn by the gather kernel at
+    // full occupancy, grad_value by the tiled kernel in scatter-only form
+    static const bool fused = getenv("CGG_MSDA_BWD_FUSED") != nullptr;
+    if (!fused) {
+      const long long total = (long long)B * Nq * H * DQ;
+      const int nb = (int)((total + 255) / 256);
+      if (P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn))
+        hipLaunchKernelGGL(cgg_msda_bwd_gather4_kernel, dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
+                           grad_loc, grad_attn, Nv, H, D, L, Nq, total);
+      else if (P == 4)
+        hipLaunchKernelGGL((cgg_msda_bwd_kernel<4, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
+                           grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+      else
+        hipLaunchKernelGGL((cgg_msda_bwd_kernel<0, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
+                           grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+      CGG_CHECK_LAUNCH("cgg_msda_backward(gather)");
+    }
+    auto kern = fused ? ((P == 4) ? cgg_msda_bwd_tiled_kernel<4, false> : cgg_msda_bwd_tiled_kernel<0, false>)
+                      : ((P == 4) ? cgg_msda_bwd_tiled_kernel<4, true> : cgg_msda_bwd_tiled_kernel<0, true>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

@@ -544,3 +544,52 @@ def test_configs4_panoptic_detector_bf16_runs(dev, cfg4):
     # (measured: 0.67 / 0.99 on the two images -- one large stuff segment differs on the first). bf16 mode cannot promise more
     # than "most segments survive"; parity mode's map is EXACT (test above). Bounded so that it cannot silently get worse.
     assert min(same) >= 0.55 and max(same) >= 0.9, rec
+
+
+def test_configs2_forward_train_slice_vs_oracle(dev):
+    """one FULL-SIZE slice of configs[2] (COCO-instance training step) against the oracle -- the head's
+    `forward_train` at 1024 x 1024 (level sizes 32^2 / 64^2 / 128^2, 256^2 mask logits), 100 queries, 6 encoder + 9 decoder layers,
+    12 544 matching points, batch 2, in parity mode: all 70 losses (7 x 10 decoder outputs) within 2e-3 (tie-aware: the oracle's attention masks injected, own
+    bits checked outside the margin). The encoder linears run on the x3 training GEMM here (43 008 rows >= runtime.X3_TRAIN_ROWS).
+    Reference: open_set/models/mask2former_head.py:851-921 (forward_train), :393-629 (loss)."""
+    from util import Bank, build_heads
+    cfg = synthetic.model_config(num_things=65, num_stuff=0, num_unknown=17, num_queries=100, depth=50)
+    hc = head_cfg(cfg)
+    prod, orc = build_heads(cfg, seed=77)
+    prod = prod.to(dev).train()
+    orc.train()
+    for m in list(prod.modules()) + list(orc.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B, H, W = 2, 1024, 1024
+    feats = synthetic.backbone_feats(B, H, W, channels=(256, 512, 1024, 2048), seed=91)
+    metas = synthetic.img_metas(B, H, W)
+    batch = synthetic.train_batch(B, H, W, num_classes=hc['num_things_classes'], max_inst=12, seed=92)
+    teacher = MaskTeacher(orc)
+    orc.point_hook = Bank(9)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        oc, oe, om = teacher.run_oracle(lambda: orc.forward(feats, metas))
+        olosses = orc.loss(oc, oe, om, batch['gt_labels'], [m.long() for m in batch['gt_masks']], batch['gt_caption_ids'],
+                           batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
+    prod.point_hook = Bank(9)
+    prod.attn_mask_hook = teacher.hook
+    to = lambda lst: [t.to(dev) for t in lst]   # noqa: E731
+    with runtime.precision_scope('fp32'):
+        losses = prod.forward_train([f.to(dev).requires_grad_(True) for f in feats], metas, to(batch['gt_bboxes']),
+                                    to(batch['gt_labels']), to(batch['gt_masks']), None, to(batch['gt_caption_ids']),
+                                    to(batch['gt_caption_mask']), to(batch['gt_caption_nouns_ids']),
+                                    to(batch['gt_caption_nouns_mask']))
+        sum(losses.values()).backward()                        # the full-size backward runs (finite gradients)
+    prod.attn_mask_hook = None
+    teacher.check()
+    assert set(losses) == set(olosses) and len(losses) == 70      # 7 losses x 10 decoder outputs
+    worst = 0.0
+    for k in sorted(losses):
+        a, b = float(losses[k]), float(olosses[k])
+        worst = max(worst, abs(a - b) / (1 + abs(b)))
+        assert abs(a - b) <= 2e-3 * (1 + abs(b)), (k, a, b)
+    for n, p in prod.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    print(f'configs[2] full-size forward_train: {len(losses)} losses within {worst:.1e} (relative, bound 2e-3)')

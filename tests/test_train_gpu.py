@@ -280,8 +280,10 @@ def test_train_driver_runs_resumes_and_checkpoints(dev, tmp_path):
     assert it == 5
 
 
-def test_hungarian_indices_on_the_gpu_path_at_configs2_shapes(dev):
-    """north_star: "bit-exact class/mask assignment indices". The production target path (`_targets_batched`: device cost
+@pytest.mark.parametrize('h,H,B', [(128, 512, 16), (256, 1024, 4)])
+def test_hungarian_indices_on_the_gpu_path_at_configs2_shapes(dev, h, H, B):
+    """(second case, round 4: configs[2]'s real image / logit size -- 1024^2 images, 256^2 mask logits -- on 4 images.)
+    north_star: "bit-exact class/mask assignment indices". The production target path (`_targets_batched`: device cost
     matrices for all layers x images, one D2H, cgg_linear_sum_assignment_f32) against the oracle's per-(layer, image)
     `get_target_single` (reference: open_set/assigners/mask_hungarian_assigner.py:100-143, mask2former_head.py:320-390) at
     configs[2] shapes -- batch 16, 100 queries, 12 544 points, 1..20 ground-truth instances, all 10 decoder outputs, the same
@@ -293,12 +295,12 @@ def test_hungarian_indices_on_the_gpu_path_at_configs2_shapes(dev):
         warnings.simplefilter('ignore')
         prod, orc = build_heads(cfg)
     prod = prod.to(dev).train()
-    n, B, Q, h, w, H, W = 10, 16, 100, 128, 128, 512, 512
+    n, Q, w, W = 10, 100, h, H
     K1 = prod.class_embs.shape[0]
     g = torch.Generator().manual_seed(2024)
     batch = synthetic.train_batch(B, H, W, num_classes=cfg['panoptic_head']['num_things_classes'], max_inst=20, vocab=500, seed=77)
     gt_labels, gt_masks = batch['gt_labels'], [m.long() for m in batch['gt_masks']]
-    gt_labels[3], gt_masks[3] = gt_labels[3][:0], gt_masks[3][:0]                # one image without ground truth
+    gt_labels[3], gt_masks[3] = gt_labels[3][:0], gt_masks[3][:0]                # one image without ground truth (index 3 < B)
     # predictions: every GT instance has a few queries that follow it (noisy), the rest is noise -> real competition
     cls = [torch.randn(B, Q, K1, generator=g) for _ in range(n)]
     emb = [torch.randn(B, Q, K1, generator=g) * 2 for _ in range(n)]

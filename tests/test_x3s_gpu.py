@@ -201,7 +201,8 @@ def test_overflow_in_the_stream_is_reported_not_silent(dev):
         torch.cuda.synchronize()
         assert ops.is_x3a(feats[0]) and not ops.x3_overflow_check(dev)
         assert all(torch.isfinite(ops.x3a_to_f32(f)).all() for f in feats)
-        bb.layer1[0].bn3.weight.mul_(1e5)                                # a BN-folded scale that drives layer1's output past the range
+        # a BN-folded scale that drives layer1's output past the range (fill_, not mul_: a block's last BN is zero-initialised)
+        bb.layer1[0].bn3.weight.fill_(1e5)
         feats = bb(img)
         torch.cuda.synchronize()
         assert ops.x3_overflow_check(dev)

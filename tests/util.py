@@ -185,3 +185,17 @@ def plain(t):
     memories) -- a plain float32 tensor either way."""
     from cgg_amd import ops
     return ops.x3a_to_f32(t) if ops.is_x3a(t) else t
+
+
+class Bank:
+    """deterministic random-point source shared by product (device) and oracle (cpu): per-kind call counters."""
+
+    def __init__(self, seed):
+        self.seed, self.count = seed, {}
+
+    def __call__(self, kind, shape, device):
+        import torch
+        i = self.count.get(kind, 0)
+        self.count[kind] = i + 1
+        g = torch.Generator().manual_seed(self.seed + 1000 * i + {'target': 1, 'oversample': 2, 'random': 3}[kind])
+        return torch.rand(*shape, generator=g).to(device)
