@@ -559,6 +559,18 @@ class Mask2FormerHeadOpen(nn.Module):
 
     def _finish_encode(self, enc):
         """The tail of `_encode` for a deferred stream encoding: packed (full + pooled) mask feature and K / V."""
+        if enc.get('x3a'):
+            sizes, memorys = enc['sizes'], enc['memorys']
+            mf = enc['mf'] if 'mf' in enc else self.pixel_decoder.stream_fpn_x3a(*enc['fpn'])
+            H4, W4 = int(mf.shape[1]), int(mf.shape[2])
+            pools = []
+            for h, w in sizes:
+                s = H4 // h
+                pools.append(s if (h * s == H4 and w * s == W4 and s in (2, 4, 8)) else None)
+            uniq = [1] + sorted({p for p in pools if p is not None})
+            packed = dict(zip(uniq, ops.pack_mask_feature_nhwc_x3(mf, uniq)))
+            return dict(stream=True, kvs=self._project_kv_x3a(memorys, sizes), sizes=sizes, packed_full=packed[1],
+                        pooled=[packed[p] if p is not None else None for p in pools], mask_features=None)
         kv16, sizes = enc['kv16'], enc['sizes']
         mf = enc['mf'] if 'mf' in enc else self.pixel_decoder.stream_fpn(*enc['fpn'])
         L = self.num_transformer_feat_level
@@ -662,6 +674,12 @@ class Mask2FormerHeadOpen(nn.Module):
               and all(l.stream_ready() for l in self.transformer_decoder.layers)):
             # parity-mode inference: channel-last f32 all the way on the f32-class x3 kernels; the mask feature only ever
             # exists as its packed x3 images (full + pooled, one launch)
+            if defer_tail and runtime.x3a_enabled():
+                # pipeline balancing (parity mode): mask-feature packing + K / V projections (defer_tail = 1), and the FPN too
+                # (defer_tail = 2), run at the head of the decode stage (`_finish_encode`)
+                mf, memorys, level_hw = pd.forward_stream_x3(feats, defer_fpn=defer_tail == 2)
+                return dict(stream=True, deferred=True, x3a=True, memorys=memorys, sizes=[level_hw[i] for i in range(L)],
+                            **({'fpn': mf} if defer_tail == 2 else {'mf': mf}))
             mf, memorys, level_hw = pd.forward_stream_x3(feats)
             mask_features = None
             H4, W4 = int(mf.shape[1]), int(mf.shape[2])

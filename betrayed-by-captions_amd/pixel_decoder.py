@@ -886,7 +886,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                                   (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True)
         return src
 
-    def _forward_stream_x3a(self, feats):
+    def _forward_stream_x3a(self, feats, defer_fpn=False):
         """`forward_stream_x3` on x3a rows: the backbone maps arrive as x3a (`ops.X3ATensor`; plain f32 maps are encoded), every
         GEMM-consumed tensor of the stream stays x3a -- GroupNorm / the encoder tail write it, the LDS-DMA GEMMs read it -- and
         only the tensors a non-GEMM kernel gathers from (MSDeformAttn's value / offsets, the mask feature) are f32. The memories
@@ -919,29 +919,38 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                     pos=(pos, level_start[i] * C), outp=(srcp, level_start[i] * C))
         src = self._encoder_stream_x3a(src, srcp, pos, ref, level_hw, level_start)
         mems = [ops.as_x3a(src[:, s0:s0 + h * w, :]) for s0, (h, w) in zip(level_start, level_hw)]
-        # FPN: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN + ReLU, mask_feature
-        f = feats[0]
-        H4, W4 = int(f.shape[2]), int(f.shape[3])
-        lat, outc = self.lateral_convs[0], self.output_convs[0]
-        y = runtime.linear_x3s(rows(f), lat.conv.weight.flatten(1), lat.conv.bias).view(B, H4 * W4, C)
-        gn = getattr(lat, lat.norm_name)
-        hl, wl = level_hw[-1]
-        ops.group_norm_nhwc_x3a(y, gn.weight, gn.bias, 32, gn.eps, ws, out=(y, 0, H4 * W4 * C),
-                                up=(src, level_start[-1] * C, N * C, hl, wl), W=W4)                    # y: f32 -> x3a in place
-        w3 = runtime.derived_cached('x3_conv_image', (outc.conv.weight,), lambda: ops.pack_conv_weight_x3(outc.conv.weight))
-        z = ops.conv_x3s_nhwc(y.view(B, H4, W4, C), w3, C, 3, 1, 1, outc.conv.bias, out_split=False).view(B, H4 * W4, C)
-        gn = getattr(outc, outc.norm_name)
-        ops.group_norm_nhwc_x3a(z, gn.weight, gn.bias, 32, gn.eps, ws, out=(z, 0, H4 * W4 * C), relu=True)
-        mf = runtime.linear_x3s(z.view(B * H4 * W4, C), self.mask_feature.weight.flatten(1), self.mask_feature.bias)
-        return mf.view(B, H4, W4, -1), mems, level_hw
+        fpn = (rows(feats[0]), int(feats[0].shape[2]), int(feats[0].shape[3]), src, level_start[-1], N, level_hw[-1], ws)
+        if defer_fpn:        # pipeline balancing: the FPN (0.75 ms of throughput kernels at configs[1]) runs in the next stage
+            return fpn, mems, level_hw
+        return self.stream_fpn_x3a(*fpn), mems, level_hw
 
-    def forward_stream_x3(self, feats):
+    def stream_fpn_x3a(self, frows, H4, W4, src, fine_start, N, fine_hw, ws):
+        """FPN of the x3a stream: lateral 1x1 + GN on the stride-4 map, + bilinear up-sample of the finest encoder level, 3x3 + GN +
+        ReLU, mask_feature -> (B, H4, W4, C) f32."""
+        C = 256
+        B = src.shape[0]
+        if True:
+            lat, outc = self.lateral_convs[0], self.output_convs[0]
+            hl, wl = fine_hw
+            level_start = [fine_start]
+            y = runtime.linear_x3s(frows, lat.conv.weight.flatten(1), lat.conv.bias).view(B, H4 * W4, C)
+            gn = getattr(lat, lat.norm_name)
+            ops.group_norm_nhwc_x3a(y, gn.weight, gn.bias, 32, gn.eps, ws, out=(y, 0, H4 * W4 * C),
+                                    up=(src, level_start[-1] * C, N * C, hl, wl), W=W4)                # y: f32 -> x3a in place
+            w3 = runtime.derived_cached('x3_conv_image', (outc.conv.weight,), lambda: ops.pack_conv_weight_x3(outc.conv.weight))
+            z = ops.conv_x3s_nhwc(y.view(B, H4, W4, C), w3, C, 3, 1, 1, outc.conv.bias, out_split=False).view(B, H4 * W4, C)
+            gn = getattr(outc, outc.norm_name)
+            ops.group_norm_nhwc_x3a(z, gn.weight, gn.bias, 32, gn.eps, ws, out=(z, 0, H4 * W4 * C), relu=True)
+            mf = runtime.linear_x3s(z.view(B * H4 * W4, C), self.mask_feature.weight.flatten(1), self.mask_feature.bias)
+            return mf.view(B, H4, W4, -1)
+
+    def forward_stream_x3(self, feats, defer_fpn=False):
         """-> (mask_feature (B, H4, W4, C) f32 channel-last, [memories (B, hw_l, C) f32 low->high res], level sizes). 1x1
         convolutions are x3 GEMMs on the (B*H*W, C) views, the 3x3 output convolution the x3 implicit GEMM, every GroupNorm the
         channel-last kernel on f32 input (the three encoder inputs normalised straight into the (B, N, C) stream, the FPN's
         `cur + up-sample(out)` in the GroupNorm's epilogue)."""
         if runtime.x3a_enabled():
-            return self._forward_stream_x3a(feats)
+            return self._forward_stream_x3a(feats, defer_fpn=defer_fpn)
         feats = [ops.x3a_to_f32(f) if ops.is_x3a(f) else f for f in feats]
         B = feats[0].shape[0]
         dev = feats[0].device

@@ -378,6 +378,52 @@ def main():
         t_points=rc2.draws[0], t_labels=tgt_single[0], t_mask_weights=tgt_single[3], t_pos=tgt_single[4],
         t_neg=tgt_single[5])
 
+    # ---- G11: the head's non-default caption-target / loss-assembly branches no shipped config sets (VERDICT r3 missing 6):
+    #      gen_only / gen_mask / gen_replace_obj_nouns (mask2former_head.py:562-580: the in-place edit of the caption ids the
+    #      generator is trained on), learnable_temperature (:228), loss_only_last (:448), freeze_v2l (:242-244). The reference's
+    #      own `loss_single` / `loss` / `init_weights` run with each flag; stored: the edited ids, the caption-generation loss,
+    #      the loss-dict keys, the temperature parameter and the requires_grad pattern ----
+    g11 = {}
+    for flag in ('gen_only_obj_nouns', 'gen_mask_obj_nouns', 'gen_replace_obj_nouns'):
+        hf = OM.attrify(dict(head_cfg(cfg), **{flag: True}))
+        rh = m2f.Mask2FormerHeadOpen(**hf).train()
+        rh.load_state_dict(ref_head.state_dict())
+        for mod in rh.modules():
+            if isinstance(mod, nn.Dropout):
+                mod.p = 0.0
+        ids = [t.clone() for t in cap_ids]
+        torch.manual_seed(1234)
+        ce, _ = rh.extract_word_embeddings(ids, cap_mask, 'bert')
+        ne, _ = rh.extract_word_embeddings(noun_ids, noun_mask, 'bert')
+        try:
+            ls = rh.loss_single(cls_l[li], emb_l[li], mask_l[li], gt_labels, gt_masks, ids, ce, cap_mask, noun_ids, ne, noun_mask, metas)
+            g11[f'{flag}_loss'] = ls[3].detach().reshape(())
+        except IndexError:
+            # gen_replace writes token 4874 ('object' in BERT's vocabulary); the fixture's toy generator has fewer tokens, so the
+            # reference's cross-entropy refuses the target -- the in-place edit (what is pinned here) has already happened
+            g11[f'{flag}_loss'] = torch.tensor(float('nan'))
+        g11[f'{flag}_ids'] = torch.stack(ids)                 # edited IN PLACE by the reference
+    hf = OM.attrify(dict(head_cfg(cfg), learnable_temperature=True, softmax_temperature=7.0, loss_only_last=True, freeze_v2l=True))
+    rh = m2f.Mask2FormerHeadOpen(**hf).train()
+    rh.init_weights()
+    g11['frozen'] = json.dumps(sorted(n for n, p_ in rh.named_parameters() if not p_.requires_grad and not n.startswith('bert')
+                                      and 'class_embs' not in n))
+    g11['temperature_is_param'] = int(isinstance(rh.softmax_temperature, nn.Parameter) and rh.softmax_temperature.requires_grad)
+    g11['temperature'] = rh.softmax_temperature.detach().reshape(-1)
+    rh.load_state_dict(dict(ref_head.state_dict(), softmax_temperature=rh.softmax_temperature.detach()))
+    for mod in rh.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    with torch.no_grad():
+        g11['temp_logits'] = rh._get_cls_emb_logits(emb_l[li])
+    torch.manual_seed(1234)
+    ids = [t.clone() for t in cap_ids]
+    ce, _ = rh.extract_word_embeddings(ids, cap_mask, 'bert')
+    ne, _ = rh.extract_word_embeddings(noun_ids, noun_mask, 'bert')
+    ld = rh.loss(cls_l, emb_l, mask_l, gt_labels, gt_masks, ids, ce, cap_mask, noun_ids, ne, noun_mask, metas)
+    g11['last_only_keys'] = json.dumps(sorted(ld.keys()))
+    npz('g11_head_flags.npz', layer=li, **g11)
+
     # ---- G7: fusion head post-processing (instance + panoptic) ----
     fcfg = dict(cfg['panoptic_fusion_head'])
     fcfg.pop('type')

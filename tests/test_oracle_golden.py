@@ -1,6 +1,7 @@
 """CPU tests (-m "not gpu"): the oracle -- and the product's pure-host logic (losses, assigner, caption
 transformer, target / loss assembly) -- against the golden vectors produced by executing the reference's own
 files (tests/golden/make_golden.py). This is what PINS the oracle."""
+import copy
 import json
 import os
 import warnings
@@ -409,3 +410,70 @@ def test_swin_product_module_equals_dense_oracle():
         for a, b in zip(got, want):
             assert a.shape == b.shape
             assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (a - b).abs().max().item()
+
+
+def test_g11_non_default_head_flags_match_reference():
+    """Fixture G11 (tests/golden/make_golden.py, produced by the reference's own `loss_single` / `loss` / `init_weights`): the
+    head branches no shipped config sets -- gen_only / gen_mask / gen_replace_obj_nouns (mask2former_head.py:562-580: the in-place
+    edit of the caption ids the generator is trained on, and the caption-generation loss that follows), learnable_temperature
+    (:228, :645), loss_only_last (:448), freeze_v2l (:242-244). Product host logic on the CPU."""
+    import json
+    cfg, B, H, W, feats, metas, _, _ = g4_inputs()
+    z = gold('g11_head_flags.npz')
+    g4 = gold('g4_head_forward.npz')
+    g6 = gold('g6_loss_single.npz')
+    li = int(z['layer'])
+    cls, emb, mask = g4['cls'][li], g4['emb'][li], g4['mask'][li]
+    gt_labels, gt_masks, cap_ids, cap_mask, noun_ids, noun_mask = g6_inputs(H, W)
+    draws = [g6[f'draw{i}'] for i in range(int(g6['n_draws']))]
+
+    def build(**flags):
+        c = copy.deepcopy(cfg)
+        c['panoptic_head'].update(flags)
+        ph = _product_head(c).train()
+        for mod in ph.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return ph
+
+    for flag in ('gen_only_obj_nouns', 'gen_mask_obj_nouns', 'gen_replace_obj_nouns'):
+        ph = build(**{flag: True})
+        ids = [c.clone() for c in cap_ids]
+        edited = ph._caption_targets(ids, noun_ids)
+        assert torch.equal(edited, z[f'{flag}_ids']), flag                     # the reference's in-place edit, id for id
+        assert torch.equal(torch.stack(ids), z[f'{flag}_ids'])                 # ... and in place, as upstream
+        want = float(z[f'{flag}_loss'])
+        if want == want:                                                       # (gen_replace: token 4874 exceeds the toy vocabulary)
+            ph.point_hook = Replay(draws)
+            with torch.no_grad():
+                ids = [c.clone() for c in cap_ids]
+                pe, _ = ph.extract_word_embeddings(ids, cap_mask, 'bert')
+                ne, _ = ph.extract_word_embeddings(noun_ids, noun_mask, 'bert')
+                pl = ph.loss_single(cls, emb, mask, gt_labels, gt_masks, ids, pe, cap_mask, noun_ids, ne, noun_mask, metas)
+            assert abs(float(pl[3]) - want) <= 2e-5 * (1 + abs(want)), (flag, float(pl[3]), want)
+    # learnable temperature + last-layer-only loss dict + frozen v2l
+    c = copy.deepcopy(cfg)
+    c['panoptic_head'].update(learnable_temperature=True, softmax_temperature=7.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fresh = registry.build_head(head_cfg(c))                                   # as built: the temperature is a parameter = 7.0
+    assert isinstance(fresh.softmax_temperature, torch.nn.Parameter) and fresh.softmax_temperature.requires_grad == bool(z['temperature_is_param'])
+    assert torch.equal(fresh.softmax_temperature.detach().reshape(-1), z['temperature'])
+    ph = build(learnable_temperature=True, softmax_temperature=7.0, loss_only_last=True, freeze_v2l=True)
+    with torch.no_grad():
+        ph.softmax_temperature.copy_(z['temperature'])                             # (`randomize` touched it with the other parameters)
+        got = ph._get_cls_emb_logits(emb)
+    assert (got - z['temp_logits']).abs().max().item() <= 1e-5 * (1 + z['temp_logits'].abs().max().item())
+    ph.init_weights()
+    randomize(ph, seed=0)
+    frozen = sorted(n for n, p in ph.named_parameters() if not p.requires_grad and not n.startswith('bert') and 'class_embs' not in n)
+    assert frozen == json.loads(str(z['frozen'])), (frozen, str(z['frozen']))
+    ph.point_hook = None                       # (the key set does not depend on the random points)
+    with torch.no_grad():
+        ids = [c.clone() for c in cap_ids]
+        pe, _ = ph.extract_word_embeddings(ids, cap_mask, 'bert')
+        ne, _ = ph.extract_word_embeddings(noun_ids, noun_mask, 'bert')
+        ph.force_reference_targets = True
+        ld = ph.loss(list(g4['cls']), list(g4['emb']), list(g4['mask']), gt_labels, gt_masks, ids, pe, cap_mask, noun_ids, ne,
+                     noun_mask, metas)
+    assert sorted(ld.keys()) == json.loads(str(z['last_only_keys']))
