@@ -372,7 +372,7 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
     timed = ('HIP events around the launches in the same %d steps re-run eagerly right after the timed region (events cannot be '
              'recorded inside a hipGraph replay); raw means' % args.steps)
     out = {}
-    prof = committed_profile('r3_fp32_kernels.json') or {}
+    prof = committed_profile('r4_fp32_kernels.json') or committed_profile('r3_fp32_kernels.json') or {}
 
     def ms_list(name):
         return [s.elapsed_time(e) for s, e in events.get(name, [])]
@@ -394,11 +394,12 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
             for t, n, k in shapes:
                 print('gemm shape %s x%d: %.1f us' % (k, n, t * 1e3), file=sys.stderr)
         shapes = shapes[:6]
-        pr = prof.get('cgg_gemm_x3_kernel', {})
+        pr = prof.get('cgg_gemm_x3s_kernel', prof.get('cgg_gemm_x3_kernel', {}))
         out['gemm_x3'] = dict(
-            bound='mfma', kernel='cgg_gemm_x3_kernel<CONV, TM, TN> (all instantiations: %d launches per step -- the BN-folded '
-                                 'ResNet convolutions, the pixel decoder\'s 1x1 / 3x3 convolutions, value / offset / K-V '
-                                 'projections)' % per_step,
+            bound='mfma', kernel='cgg_gemm_x3s_kernel<CONV, TM, TN, WM, WN, KG, SA, SB> (LDS-DMA GEMM / implicit-GEMM convolution over '
+                                 'pre-split x3a rows; all instantiations: %d launches per step -- the BN-folded ResNet convolutions, the '
+                                 'pixel decoder\'s 1x1 / 3x3 convolutions, value / offset / merged K-V projections; CGG_X3A=0: round 3\'s '
+                                 'cgg_gemm_x3_kernel)' % per_step,
             achieved=tf, peak=X3_PEAK_TF, unit='TFLOP/s', frac=tf / X3_PEAK_TF,
             peak_note='f32-class f16 x 3 arithmetic issues 3 v_mfma_f32_32x32x16_f16 per product: peak = dense f16 MFMA peak '
                       '2500 TF / 3; achieved = ALGORITHMIC flops (2 M N K) / time',
@@ -647,6 +648,11 @@ def main():
     sweep = None
     if rank == 0 and (H, W) == (1024, 1024) and not args.no_einsum_sweep:
         sweep = einsum_q_sweep(dev, B, H, W)
+    # the x3a range guard: a value outside +-4094 anywhere in the timed steps raised the device flag (tools/test.py aborts on it)
+    overflow = bool(ops.x3_overflow_check(dev, reset=True)) if args.precision == 'fp32' else None
+    if overflow:
+        print('bench.py: x3a overflow flag raised -- an activation left the representable range; the result is INVALID',
+              file=sys.stderr)
     if rank == 0:
         f32 = args.precision == 'fp32'
         res = dict(metric='images/sec (COCO-shaped 1024x1024, 100 queries, forward-only)',
@@ -660,8 +666,15 @@ def main():
                                global_batch=B * world, parallelism=f'replicas x{world}',
                                precision=args.precision + (' = parity mode: every contraction of the path in f32-class arithmetic '
                                                            '(two f16 pieces per f32 operand, three f16 MFMAs per product, f32 '
-                                                           'accumulation: as accurate as an f32 GEMM, tests/test_x3_gpu.py); '
-                                                           'softmax / norms / sampling f32' if f32 else ''),
+                                                           'accumulation: as accurate as an f32 GEMM, tests/test_x3_gpu.py, '
+                                                           'tests/test_x3s_gpu.py); softmax / norms / sampling f32. Parity bar: '
+                                                           '1e-3 per layer with the oracle\'s attention masks injected / 2e-2 end '
+                                                           'to end without injection (mask-threshold flips feed back through 9 '
+                                                           'layers), integer outputs bit-exact' if f32 else ''),
+                               activation_format=('x3a: activations stored pre-split (8 x f16 hi | 8 x f16 lo of 16 a per 8 channels, '
+                                                  '|a| < 4094, device overflow flag checked after the timed region)'
+                                                  if (f32 and runtime.x3a_enabled()) else 'f32'),
+                               x3_overflow=overflow, library_fallbacks=dict(count=runtime.library_fallbacks(), sites=dict(runtime.FALLBACKS)),
                                hip_graph=main_mode['hip_graph'], ranks_share_devices=bool(args.shared_devices),
                                pipeline=main_mode['how'],
                                timed_region=f'{args.steps} steps, repeated {args.repeats}x back to back; median region '

@@ -1108,7 +1108,8 @@ def test_mask_logits_exact_f32_kernel(dev, B, Q, h, w, pool, monkeypatch):
     f16 x 3 split kernel -- tests/test_x3_gpu.py) vs float64: logits to f32 rounding (1e-6 of the operand scale),
     attention-mask bits equal to (interpolated logit < 0) away from rounding, for the full-resolution and the pooled feature,
     ragged pixel tiles and more than 128 queries."""
-    monkeypatch.setenv('CGG_X3', '0')
+    from cgg_amd import runtime
+    monkeypatch.setattr(runtime, '_X3', False)       # read once at import: the test flips the module switch, not the environment
     g = torch.Generator().manual_seed(90 + Q)
     C = 256
     E = torch.randn(B, Q, C, generator=g)
