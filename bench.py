@@ -512,12 +512,12 @@ def train_step_child(args, precision='fp32'):
             return dict(error=f'child exited {r.returncode}', stderr_tail=r.stderr[-400:])
         d = json.loads(line[-1])
         # launches per step and the dominant kernel come from the committed per-step kernel table of the same command
-        # (profiles/r3_train_step_kernels.txt: rocprofv3 --kernel-trace of `bench.py --mode train`, last 3 steps) -- labelled as such
+        # (profiles/r4_train_step_kernels_<precision>.txt: rocprofv3 --kernel-trace of `bench.py --mode train --precision <p>`,
+        # last 3 steps) -- labelled as such
         prof = {}
         try:
-            if precision != 'bf16':
-                raise FileNotFoundError('the committed per-step kernel table is the bf16 step\'s')
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r3_train_step_kernels.txt')) as f:
+            table = 'r4_train_step_kernels_%s.txt' % precision
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', table)) as f:
                 rows = f.read().splitlines()
             head = [r for r in rows if r.startswith('step (eager')][0]
             top = rows[rows.index(head) + 2].split(None, 3)
@@ -526,7 +526,7 @@ def train_step_child(args, precision='fp32'):
             prof = dict(launches_per_step=float(mh.group(1)), kernel_ms_per_step=float(mh.group(2)) / 1e3,
                         dominant_kernel=dict(name=top[3].split('(')[0], ms_per_step=float(top[0]) / 1e3, launches_per_step=float(top[1]),
                                              share_of_kernel_time=float(top[2]) / 100.0),
-                        profile_source='committed profile: profiles/r3_train_step_kernels.txt (rocprofv3 --kernel-trace of this command)')
+                        profile_source=f'committed profile: profiles/{table} (rocprofv3 --kernel-trace of this command)')
         except Exception:
             pass
         return dict(value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], warmup=d['warmup'],

@@ -65,22 +65,24 @@ if os.path.exists(p):
             summary[f]['sq_means_per_launch'] = {k: sum(v) / len(v) for k, v in d.items()}
 
 
-def copy_filtered(path, out):
-    """the committed counter files keep the rows of the four kernel families only (the raw passes are 1.6-12 MB)"""
-    rows = list(csv.DictReader(open(path)))
-    with open(out, 'w', newline='') as fh:
-        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        for r in rows:
+def aggregate(paths, out):
+    """ONE committed table for all counter passes: per (kernel instantiation, grid, counter) the launch count, mean, min and max of the
+    per-dispatch values of the four kernel families (the raw per-dispatch passes are 1.3-10 MB each and stay in gpurun_out/)"""
+    agg = collections.defaultdict(list)
+    for n, path in paths:
+        for r in csv.DictReader(open(path)):
             if any(f in r['Kernel_Name'] for f in FAM):
-                r['Kernel_Name'] = r['Kernel_Name'][:80]
-                w.writerow(r)
+                agg[(n, r['Kernel_Name'][:70], r.get('Grid_Size', ''), r['Counter_Name'])].append(float(r['Counter_Value']))
+    with open(out, 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['pass', 'kernel', 'grid_size', 'counter', 'dispatches', 'mean', 'min', 'max'])
+        for k in sorted(agg):
+            v = agg[k]
+            w.writerow(list(k) + [len(v), '%.6g' % (sum(v) / len(v)), '%.6g' % min(v), '%.6g' % max(v)])
 
 
-for c, n in (('sq', 'sq'), ('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write'), ('l2', 'l2'), ('grbm', 'grbm')):
-    p = os.path.join(src, f'pmc_{c}.csv')
-    if os.path.exists(p):
-        copy_filtered(p, os.path.join(dst, f'r4_fp32_pmc_{n}_counter_collection.csv'))
+paths = [(n, os.path.join(src, f'pmc_{c}.csv')) for c, n in (('sq', 'sq'), ('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write'), ('l2', 'l2'), ('grbm', 'grbm'))]
+aggregate([(n, p) for n, p in paths if os.path.exists(p)], os.path.join(dst, 'r4_fp32_pmc_counters_by_kernel.csv'))
 json.dump(summary, open(os.path.join(dst, 'r4_fp32_kernels.json'), 'w'), indent=1)
 rows = list(csv.DictReader(open(os.path.join(dst, 'r4_fp32_bench_kernel_stats.csv'))))
 rows.sort(key=lambda r: -int(r['TotalDurationNs']))
