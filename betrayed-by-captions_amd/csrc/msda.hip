@@ -709,6 +709,7 @@ struct MsdaTilePlan {
   int total;     // window elements (8 B each)
   int kbase;     // 50 - ceil(log2(max taps per tile))
   int nthreads;
+  int dsub;      // channels of a head per workgroup (scatter-only form: D / dsub workgroups share a (tile, image, head))
 };
 
 // SO (scatter only) = true: grad_value only -- no value loads, no channel reductions; grad_loc / grad_attn come from
@@ -723,16 +724,19 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
   __shared__ float red[2][16];
   const int P = P_ > 0 ? P_ : Prt;
   constexpr int PC = P_ > 0 ? P_ : 1;   // points per load batch
-  const int DQ = D >> 2;
-  // window pixel stride in 8-byte elements: D + 2, NOT D -- with D = 32 a pixel's channels fill exactly one 256-byte LDS bank row,
+  const int DS = pl.dsub;               // this workgroup's channel slice of the head
+  const int DQ = DS >> 2;
+  const int nsub = D / DS;
+  // window pixel stride in 8-byte elements: DS + 2, NOT DS -- with D = 32 a pixel's channels fill exactly one 256-byte LDS bank row,
   // so the same channel of ANY two pixels shared a bank and the 8 queries of a wave conflicted 8 ways on every ds_add_u64
   // (PMC, round 4: SQ_LDS_BANK_CONFLICT = 58 % of SQ_LDS_IDX_ACTIVE)
-  const int DP = D + 2;
+  const int DP = DS + 2;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = bid % pl.ntile;
-  const int h = (bid / pl.ntile) % H;
-  const int b = bid / (pl.ntile * H);
+  const int cbase = (bid % nsub) * DS;
+  const int tile = (bid / nsub) % pl.ntile;
+  const int h = (bid / (nsub * pl.ntile)) % H;
+  const int b = bid / (nsub * pl.ntile * H);
   const int tyi = tile / pl.tx, txi = tile % pl.tx;
   for (int i = tid; i < pl.total; i += nth) win[i] = 0ull;
 
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
     const int qi = r / DQ, cq = r % DQ;
     const int n = lv.start[lq] + (y0[lq] + qi / tw[lq]) * lv.w[lq] + x0[lq] + qi % tw[lq];
     const long long bq = (long long)b * Nq + n;
-    const f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + (size_t)h * D + cq * 4);
+    const f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + (size_t)h * D + cbase + cq * 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       mg = fmaxf(mg, fabsf(g[c]));
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
     const int qi = r / DQ, cq = r % DQ;
     const int n = lv.start[lq] + (y0[lq] + qi / tw[lq]) * lv.w[lq] + x0[lq] + qi % tw[lq];
     const long long bq = (long long)b * Nq + n;
-    const size_t coff = (size_t)h * D + cq * 4;
+    const size_t coff = (size_t)h * D + cbase + cq * 4;
     const float* vb = value + (size_t)b * Nv * rowstride + coff;
     float* gvb = gvalue + (size_t)b * Nv * rowstride + coff;
     const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
@@ -953,11 +957,11 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
   for (int l = 0; l < L; ++l) {
     const int Wl = lv.w[l], ww = pl.ww[l];
     const int ox = txi * pl.c * pl.s[l] - pl.R, oy = tyi * pl.c * pl.s[l] - pl.R;
-    float* gvl = gvalue + ((size_t)b * Nv + lv.start[l]) * rowstride + (size_t)h * D;
+    float* gvl = gvalue + ((size_t)b * Nv + lv.start[l]) * rowstride + (size_t)h * D + cbase;
     const unsigned long long* wl = win + pl.off[l];
-    const int nf = ww * ww * D;
+    const int nf = ww * ww * DS;
     for (int i = tid; i < nf; i += nth) {
-      const int px = i / D, ch = i - px * D;
+      const int px = i / DS, ch = i - px * DS;
       const long long a = (long long)wl[px * DP + ch];
       if (a != 0) {
         const int iy = oy + px / ww, ix = ox + px % ww;      // inside the image whenever a != 0
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
 }
 
 // Choose (c, R) so that the windows fit in LDS; returns false if the pyramid is not tileable.
-static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, int Nv, MsdaTilePlan* pl) {
+static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, int Nv, MsdaTilePlan* pl, int dsub) {
   if (Nq != Nv || L < 1 || L > 8) return false;
   int lc = 0;
   long long tot = 0;
@@ -988,10 +992,11 @@ static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, in
     for (int l = 0; l < L; ++l) {
       pl->ww[l] = c * pl->s[l] + 2 * R;
       pl->off[l] = (int)f;
-      f += (long long)pl->ww[l] * pl->ww[l] * (D + 2);       // pixel stride D + 2 (bank spreading, see the kernel)
+      f += (long long)pl->ww[l] * pl->ww[l] * (dsub + 2);    // pixel stride dsub + 2 (bank spreading, see the kernel)
       nq += (long long)c * pl->s[l] * c * pl->s[l];
     }
-    if (f * 8 <= 144 * 1024) {
+    if (f * 8 <= (dsub == D ? 144 * 1024 : 160 * 1024 * dsub / D)) {
+      pl->dsub = dsub;
       pl->c = c;
       pl->R = R;
       pl->tx = (lv.w[lc] + c - 1) / c;
@@ -1002,7 +1007,7 @@ static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, in
       int hr = 0;
       while ((1ll << hr) < taps) ++hr;
       pl->kbase = 50 - hr;
-      const long long slots = nq * (D / 4);
+      const long long slots = nq * (dsub / 4);
       long long nt = (slots + 63) / 64 * 64;
       pl->nthreads = (int)(nt < 64 ? 64 : (nt > 768 ? 768 : nt));
       return pl->kbase >= 24;
@@ -1168,12 +1173,17 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
   rc = msda_read_levels(spatial_shapes, level_start, L, Nv, s, &lv, "cgg_msda_backward");
   if (rc) return rc;
   MsdaTilePlan pl;
-  if (D % 4 == 0 && msda_tile_plan(lv, L, D, P, Nq, Nv, &pl)) {
+  // split backward (default; CGG_MSDA_BWD_FUSED=1 = the one-kernel form, A/B only): grad_loc / grad_attn by the gather kernel at
+  // full occupancy, grad_value by the tiled kernel in scatter-only form
+  static const bool fused = getenv("CGG_MSDA_BWD_FUSED") != nullptr;
+  // scatter-only form: a (tile, image, head) is shared by D / 16 workgroups that own 16 channels each -- the lanes' tap geometry is
+  // per lane either way, the windows shrink to 72 KB so two workgroups fit a CU (3.65 -> 3.43 ms at configs[2] shapes; 8-channel
+  // slices: 4.9 ms, the flush falls apart into 32-B pieces). The scatter loop itself is bound by the LDS atomic unit (~4 ds_add_u64
+  // lanes per clock per CU measured: 4.2 G adds = 1.8 ms), which co-residency does not change
+  const int dsub = (!fused && D % 16 == 0) ? 16 : D;
+  if (D % 4 == 0 && msda_tile_plan(lv, L, D, P, Nq, Nv, &pl, dsub)) {
     const size_t lds = (size_t)pl.total * sizeof(unsigned long long);
-    const int nblk = B * H * pl.ntile;
-    // split backward (default; CGG_MSDA_BWD_FUSED=1 = the one-kernel form, A/B only): grad_loc / grad_attn by the gather kernel at
-    // full occupancy, grad_value by the tiled kernel in scatter-only form
-    static const bool fused = getenv("CGG_MSDA_BWD_FUSED") != nullptr;
+    const int nblk = B * H * pl.ntile * (D / dsub);
     if (!fused) {
       const long long total = (long long)B * Nq * H * DQ;
       const int nb = (int)((total + 255) / 256);
