@@ -1130,10 +1130,31 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
     return y
 
 
-def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False, x3a=False):
+_TAIL_V2_PERM = {}
+
+
+def tail_v2_k_permutation(K, device):
+    """Column order of the K axis of W1 / W2 for `encoder_layer_tail_x3(..., v2=True)`: inside every 32-block the order in which an
+    MFMA accumulator tile's registers enumerate its rows (csrc/encoder_tail_x3v2.hip, `cgg_encoder_tail_v2_perm32`)."""
+    key = (int(K), str(device))
+    if key not in _TAIL_V2_PERM:
+        p32 = (ctypes.c_int32 * 32)()
+        check(_lib_().cgg_encoder_tail_v2_perm32(ctypes.cast(p32, ctypes.c_void_p)), 'cgg_encoder_tail_v2_perm32')
+        base = torch.tensor(list(p32), dtype=torch.long)
+        _TAIL_V2_PERM[key] = (torch.arange(0, K, 32).view(-1, 1) + base.view(1, -1)).reshape(-1).to(device)
+    return _TAIL_V2_PERM[key]
+
+
+def pack_tail_v2_weight_x3(w):
+    """x3 image of w[:, perm] -- W1 / W2 of the register-chained encoder tail."""
+    return pack_linear_weight_x3(w.detach().float()[:, tail_v2_k_permutation(w.shape[1], w.device)].contiguous())
+
+
+def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False, x3a=False, v2=False):
     """Parity mode's encoder layer tail in ONE launch: a (attention rows), x (layer input) (..., 256) f32 ->
     y = LN1(x1 + FFN(x1)), x1 = LN0(x + a Wo^T + bo) (and y + pos[row % len(pos)] when want_pos); wo / w1 / w2 x3 images,
-    norm_* = (gamma, beta, eps). x3a=True: x and both outputs are x3a rows (csrc/x3.h), a stays f32."""
+    norm_* = (gamma, beta, eps). x3a=True: x and both outputs are x3a rows (csrc/x3.h), a stays f32. v2=True (needs x3a): the
+    register-chained kernel (csrc/encoder_tail_x3v2.hip); w1 / w2 are then `pack_tail_v2_weight_x3` images."""
     C = a.shape[-1]
     M = a.numel() // C
     for t in (a, x):
@@ -1146,7 +1167,10 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     yp = torch.empty_like(a) if want_pos else None
     with _timed('encoder_tail_x3', flops=2.0 * M * (C * C + 2 * C * F), bytes=4.0 * M * C * (3 + (1 if want_pos else 0)),
                 shape=(M, C, F)):
-        rc = (_lib_().cgg_encoder_layer_tail_x3a if x3a else _lib_().cgg_encoder_layer_tail_x3)(
+        if v2 and not x3a:
+            raise CggError('encoder_layer_tail_x3: v2 reads / writes x3a rows')
+        fn = _lib_().cgg_encoder_layer_tail_x3a_v2 if v2 else (_lib_().cgg_encoder_layer_tail_x3a if x3a else _lib_().cgg_encoder_layer_tail_x3)
+        rc = fn(
             dev_ptr(a), dev_ptr(x), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32),
             dev_ptr(norm0[1], 'beta0', torch.float32), float(norm0[2]), dev_ptr(w1), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2),
             dev_ptr(b2, 'b2', torch.float32), dev_ptr(norm1[0], 'gamma1', torch.float32), dev_ptr(norm1[1], 'beta1', torch.float32),

@@ -881,9 +881,12 @@ class MSDeformAttnPixelDecoder(nn.Module):
             n0, n1 = layer.norms
             fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
             last = layer is self.encoder.layers[-1]
+            v2 = runtime.tail_v2_enabled() and C == 256 and fc1.weight.shape[0] % 32 == 0 and fc1.weight.shape[0] <= 2048
+            ffw = (lambda lin: runtime.derived_cached('x3_image_tail_v2', (lin.weight,),
+                                                      lambda: ops.pack_tail_v2_weight_x3(lin.weight))) if v2 else x3w
             src, srcp = ops.encoder_layer_tail_x3(a, src, x3w(attn.output_proj), attn.output_proj.bias,
-                                                  (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
-                                                  (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True)
+                                                  (n0.weight, n0.bias, n0.eps), ffw(fc1), fc1.bias, ffw(fc2), fc2.bias,
+                                                  (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True, v2=v2)
         return src
 
     def _forward_stream_x3a(self, feats, defer_fpn=False):

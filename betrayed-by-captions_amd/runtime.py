@@ -56,6 +56,15 @@ def x3_enabled():
     return _STATE['precision'] == 'fp32' and _X3
 
 
+_TAIL_V2 = _os.environ.get('CGG_TAIL_V2', '0') == '1'
+
+
+def tail_v2_enabled():
+    """CGG_TAIL_V2=1: the register-chained encoder tail (csrc/encoder_tail_x3v2.hip) in the x3a stream instead of the LDS-image kernel
+    (A/B only: measured slower, 274 vs 198 us per launch at configs[1])."""
+    return _TAIL_V2
+
+
 def x3a_enabled():
     """Round 4: the parity-mode inference stream keeps its GEMM-consumed activations as pre-split x3a rows (csrc/x3.h) and runs
     the LDS-DMA GEMM / implicit-GEMM convolution of csrc/x3s_gemm.hip; CGG_X3A=0 restores round 3's f32 stream (cgg_gemm_x3) for

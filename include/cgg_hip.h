@@ -485,6 +485,16 @@ int cgg_encoder_layer_tail_x3a(const float* a32, const void* x_x3a, const void* 
                                const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
                                const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
                                int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
+/* The same operator as a register-chained kernel (csrc/encoder_tail_x3v2.hip: a wavefront owns 32 rows for the whole chain, every
+ * GEMM computed transposed so that an accumulator tile IS the next GEMM's B operand; the weights are the only LDS traffic, one
+ * LDS-DMA ring per workgroup). C == 256, F % 32 == 0, F <= 2048. w1p_x3 / w2p_x3 are the x3 images of W1[:, perm] / W2[:, perm],
+ * perm = perm32 applied inside every 32-block of the K axis (cgg_encoder_tail_v2_perm32 fills int32 perm32[32], host memory).
+ * Replaces the same reference lines as cgg_encoder_layer_tail_x3 ([3P] BaseTransformerLayer, mask2former_head.py:112-117). */
+int cgg_encoder_layer_tail_x3a_v2(const float* a32, const void* x_x3a, const void* wo_x3, const float* bo, const float* gamma0,
+                                  const float* beta0, float eps0, const void* w1p_x3, const float* b1, const void* w2p_x3,
+                                  const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
+                                  int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
+int cgg_encoder_tail_v2_perm32(int32_t* perm32);
 
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */

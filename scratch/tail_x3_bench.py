@@ -27,7 +27,15 @@ def chain():
     h = ops.gemm_x3(x1, pk[1], F, b1, relu=True)
     y = ops.gemm_x3(h, pk[2], C, b2, res=x1)
     return ops.add_layernorm_stream(y, None, n1[0], n1[1], 1e-5, want_bf16=False)[0]
+xe = ops.x3a_encode(x)
+pv = [pk[0], ops.pack_tail_v2_weight_x3(w1), ops.pack_tail_v2_weight_x3(w2)]
+def fused_x3a(): return ops.encoder_layer_tail_x3(a, xe, pk[0], bo, n0, pk[1], b1, pk[2], b2, n1, pos=pos, want_pos=True, x3a=True)
+def fused_v2(): return ops.encoder_layer_tail_x3(a, xe, pv[0], bo, n0, pv[1], b1, pv[2], b2, n1, pos=pos, want_pos=True, x3a=True, v2=True)
 tf, tc = timeit(fused), timeit(chain)
+ta, tv = timeit(fused_x3a), timeit(fused_v2)
 fl = 2.0 * M * (C * C + 2 * C * F)
 print('fused %.1f us (%.1f TF eff = %.3f of the f16 x 3 peak 833 TF), chain %.1f us; max |diff| %.2e' % (
     tf, fl / tf / 1e6, fl / tf / 1e6 / 833.3, tc, (fused()[0] - chain()).abs().max().item()))
+print('x3a rows: LDS-image kernel %.1f us (%.3f), register-chained v2 %.1f us (%.1f TF eff = %.3f of the peak); max |v2 - v1| %.2e' % (
+    ta, fl / ta / 1e6 / 833.3, tv, fl / tv / 1e6, fl / tv / 1e6 / 833.3,
+    (ops.x3a_decode(fused_v2()[0]) - ops.x3a_decode(fused_x3a()[0])).abs().max().item()))

@@ -206,3 +206,44 @@ def test_overflow_in_the_stream_is_reported_not_silent(dev):
         feats = bb(img)
         torch.cuda.synchronize()
         assert ops.x3_overflow_check(dev)
+
+
+@pytest.mark.parametrize('M,N,FF', [(43008, 21504, 1024), (4071, 1357, 1024), (100, 50, 512), (64, 64, 256), (129, 129, 32)])
+def test_encoder_layer_tail_v2_vs_float64_and_first_kernel(dev, M, N, FF):
+    """cgg_encoder_layer_tail_x3a_v2 (register-chained: transposed GEMMs, accumulator tile = next B operand, K-permuted W1 / W2
+    images, LDS-DMA weight ring) vs float64 on the same x3a-rounded inputs and vs the LDS-image kernel on x3a rows: 2e-5 of the
+    unit-scale outputs; ragged row counts (partial last wave and partial last workgroup); y + pos; reproducible; no overflow flag."""
+    g = torch.Generator().manual_seed(700 + FF)
+    C = 256
+    r = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k)
+    a, x, pos = r(M, C), r(M, C), r(N, C)
+    wo, bo = r(C, C, k=1 / 16), r(C, k=0.1)
+    w1, b1 = r(FF, C, k=1 / 16), r(FF, k=0.1)
+    w2, b2 = r(C, FF, k=1 / 32), r(C, k=0.1)
+    n0 = (1 + 0.1 * r(C), 0.1 * r(C), 1e-5)
+    n1 = (1 + 0.1 * r(C), 0.1 * r(C), 1e-5)
+    t = lambda v: v.to(dev)
+    xe = ops.x3a_encode(t(x))
+    xd = ops.x3a_decode(xe).cpu().double()               # what the kernel reads: x to 22 bits
+    d = lambda v: v.double()
+    F = torch.nn.functional
+    x1 = F.layer_norm(xd + d(a) @ d(wo).t() + d(bo), (C,), d(n0[0]), d(n0[1]), 1e-5)
+    want = F.layer_norm(x1 + torch.relu(x1 @ d(w1).t() + d(b1)) @ d(w2).t() + d(b2), (C,), d(n1[0]), d(n1[1]), 1e-5)
+    ops.x3_overflow_check(dev, reset=True)
+    pk = [ops.pack_linear_weight_x3(t(w)) for w in (wo, w1, w2)]
+    pv = [pk[0], ops.pack_tail_v2_weight_x3(t(w1)), ops.pack_tail_v2_weight_x3(t(w2))]
+    args = lambda p: (t(a), xe, p[0], t(bo), (t(n0[0]), t(n0[1]), 1e-5), p[1], t(b1), p[2], t(b2), (t(n1[0]), t(n1[1]), 1e-5))
+    y, yp = ops.encoder_layer_tail_x3(*args(pv), pos=t(pos), want_pos=True, x3a=True, v2=True)
+    yd, ypd = ops.x3a_decode(y), ops.x3a_decode(yp)
+    assert _err(yd, want) <= 2e-5, _err(yd, want)
+    assert _err(ypd, want + d(pos)[torch.arange(M) % N]) <= 2e-5
+    if FF % 256 == 0:                                     # the LDS-image kernel works on 256-wide hidden chunks
+        y0, yp0 = ops.encoder_layer_tail_x3(*args(pk), pos=t(pos), want_pos=True, x3a=True)
+        assert _err(yd, ops.x3a_decode(y0).cpu().double()) <= 1e-5
+    y2, none = ops.encoder_layer_tail_x3(*args(pv), x3a=True, v2=True)
+    assert none is None and torch.equal(y.view(torch.int32), y2.view(torch.int32))
+    assert not ops.x3_overflow_check(dev, reset=True)
+    # a hidden activation beyond the f16 x 3 range raises the flag
+    ops.encoder_layer_tail_x3(t(a), xe, pv[0], t(bo), (t(n0[0]), t(n0[1]), 1e-5), pv[1], t(b1) + 5000.0, pv[2], t(b2),
+                              (t(n1[0]), t(n1[1]), 1e-5), x3a=True, v2=True)
+    assert ops.x3_overflow_check(dev, reset=True)
