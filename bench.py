@@ -15,13 +15,17 @@ the environment and `--gpus` must agree with WORLD_SIZE (it fails loudly otherwi
 
 Prints ONE JSON line (rank 0). `value` is PARITY mode (`--precision fp32`, the default): every contraction of the path in
 f32-class arithmetic on the f16 matrix cores (csrc/x3.h), the mode the 1e-3 / bit-exact parity tests run in. Extra objects:
-  roofline      -- the dominant kernel of that step, the x3 GEMM / implicit-GEMM convolution family (cgg_gemm_x3_kernel), from HIP
+  roofline      -- the dominant kernel of that step, the x3 GEMM / implicit-GEMM convolution family (cgg_gemm_x3s_kernel: LDS-DMA GEMM
+                   over pre-split x3a rows, round 4), from HIP
                    events on the launch stream around every launch of the K steps re-run eagerly after the timed region;
                    kernels.* hold the encoder layer tail, the mask-logit einsum and MSDeformAttn the same way;
                    `traffic` / `rocprof` fields come from the committed rocprofv3 runs of this command (labelled as such).
   einsum_mfma_target -- BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200, % of MFMA peak.
   bf16_mode     -- the same step in throughput mode (bf16 MFMA): secondary, never `value`.
-  train_step    -- configs[2]'s training step, run in a child process.
+  train_step    -- configs[2]'s training step, run in child processes: the parity-mode (f32-class) step is the object itself, the
+                   bf16 autocast step its `bf16_mode` member.
+`python bench.py --mode train [--precision fp32|bf16] --gpus N` measures the image-parallel training step alone: N ranks (started
+the same way as above), batch 16 per rank, gradients all-reduced over RCCL in 64-MiB buckets (`train.GradReducer`), weak scaling.
   cpu_baseline  -- the oracle (torch CPU restatement of the reference path, kind "port") on one image of the
                    same workload on this box's host cores.
 """

@@ -17,6 +17,8 @@ from .registry import BACKBONES
 FUSED_BOTTLENECK = os.environ.get('CGG_FUSED_BOTTLENECK', '1') != '0'
 # training: frozen stem + stages on the BN-folded inference path under no_grad (CGG_FROZEN_FOLDED=0 = autograd-recorded torch path)
 FROZEN_FOLDED = os.environ.get('CGG_FROZEN_FOLDED', '1') != '0'
+# parity mode: the 7x7 stem on the x3 MFMA kernel (CGG_X3_STEM=0 = MIOpen f32 convolution, A/B)
+X3_STEM = os.environ.get('CGG_X3_STEM', '1') != '0'
 
 
 class Bottleneck(nn.Module):
@@ -357,7 +359,7 @@ class ResNet(nn.Module):
         mp, c1 = self.maxpool, self.conv1
         if ((mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) and x.dtype == torch.float32
                 and x.is_contiguous() and tuple(c1.weight.shape) == (64, 3, 7, 7) and tuple(c1.stride) == (2, 2)
-                and tuple(c1.padding) == (3, 3) and tuple(c1.dilation) == (1, 1) and os.environ.get('CGG_X3_STEM', '1') != '0'):
+                and tuple(c1.padding) == (3, 3) and tuple(c1.dilation) == (1, 1) and X3_STEM):
             # stem: the MFMA convolution straight from the f32 NCHW image on the f32-class contraction + (bias, ReLU, max-pool) pass
             pk, sc = runtime.derived_cached('stem_packed_x3', (w,), lambda: ops.pack_stem_weight_x3(w))
             x = ops.bias_relu_maxpool_nhwc_f32(ops.stem_conv7x7_x3(x, pk, sc), b, x3a=x3a)

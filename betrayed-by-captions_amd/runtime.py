@@ -211,14 +211,14 @@ def x3_train_linear_ok(x, weight):
 
 
 SPLITK_WGRAD_ROWS = 32768          # rows from which the training linears use `_SplitKLinearFn` (CGG_SPLITK_WGRAD=0 disables)
+_SPLITK_WGRAD = _os.environ.get('CGG_SPLITK_WGRAD', '1') != '0'      # read once, like every switch of this module
 
 
 def linear_bf16_train(x, weight, bias=None):
     """bf16 `F.linear` for the training step (returns bf16): split-K weight gradient for huge row counts, autocast otherwise."""
-    import os
     import torch.nn.functional as F
     rows = x.numel() // x.shape[-1]
-    if rows >= SPLITK_WGRAD_ROWS and weight.requires_grad and os.environ.get('CGG_SPLITK_WGRAD', '1') != '0':
+    if rows >= SPLITK_WGRAD_ROWS and weight.requires_grad and _SPLITK_WGRAD:
         return _SplitKLinearFn.apply(x, weight, bias)
     with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
         return F.linear(x, weight, bias)
