@@ -415,6 +415,7 @@ __device__ __forceinline__ void msda_point_gather_f32(msda_v2f (&acc)[4], const 
   }
 }
 
+template <bool T2D>
 __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ rows, const float* __restrict__ ref,
     int ld, float* __restrict__ out, int Nv, int Nq, unsigned total) {
@@ -425,10 +426,20 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
   const unsigned blk = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x), t = threadIdx.x;
   const int cq = (int)(t & 3u);
   const int h = (int)((blk & 1u) * 4u + (t >> 6));
-  const unsigned bq = (blk >> 1) * 16u + ((t >> 2) & 15u);
+  unsigned bq = (blk >> 1) * 16u + ((t >> 2) & 15u);
   if (bq >= total / 32u) return;          // whole quads
   const unsigned b = bq / (unsigned)Nq;
-  const int q = (int)(bq - b * (unsigned)Nq);
+  int q = (int)(bq - b * (unsigned)Nq);
+  if constexpr (T2D) {
+    // the wave's 16 queries are a 4 x 4 pixel tile of their level instead of a 16 x 1 strip (every level: W, H % 4 == 0,
+    // start % 16 == 0; queries == pixels): the taps of a tile fall into a (4 + 2 r)^2 window instead of (16 + 2 r) x (1 + 2 r)
+    const int g = q >> 4, i = q & 15;
+    const int l = (g << 4) >= lv.start[2] ? 2 : ((g << 4) >= lv.start[1] ? 1 : 0);
+    const int gl = g - (lv.start[l] >> 4), tx_n = lv.w[l] >> 2;
+    const int ty = gl / tx_n, tx = gl - ty * tx_n;
+    q = lv.start[l] + (4 * ty + (i >> 2)) * lv.w[l] + 4 * tx + (i & 3);
+    bq = b * (unsigned)Nq + (unsigned)q;
+  }
   constexpr int rowstride = H * D;
   // lane cq owns channels 4 cq .. + 3 and 16 + 4 cq .. + 3: each of a tap's two loads covers a CONTIGUOUS 64-byte half line per quad
   const float* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * 4;
@@ -1067,8 +1078,17 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
   const long long total8 = (long long)B * Nq * H * (D / 8);
   if (dtype == CGG_F32 && fused && st && H == 8 && D == 32 && ld % 4 == 0 && cgg_aligned16(loc) && !generic_only &&
       (long long)Nv * H * D < (1ll << 31) && total8 < (1ll << 31)) {
-    hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s, (const float*)value,
-                       lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
+    // 4 x 4 query tiles per wave when the queries are the pixels of a pyramid whose levels allow it (the encoder): bit-identical
+    // outputs; 118 -> 118 us with the initialisation's offsets, 131 -> 121 us with +-1 px of noise on them (round 4, VERDICT r3 item 5:
+    // the kernel stays L2-request-rate bound -- every tap is a 128-B request, 14.5 M per launch -- so <= 80 us is out of reach)
+    bool t2d = Nq == Nv && Nq % 16 == 0;
+    for (int l = 0; l < L && t2d; ++l) t2d = lv.w[l] % 4 == 0 && lv.h[l] % 4 == 0 && lv.start[l] % 16 == 0;
+    if (t2d)
+      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<true>, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s,
+                         (const float*)value, lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
+    else
+      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<false>, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s,
+                         (const float*)value, lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
     CGG_CHECK_LAUNCH("cgg_msda_forward");
     return CGG_OK;
   }

@@ -31,3 +31,10 @@ rows16 = rows.bfloat16()
 a = ops.msda_forward_fused(value, shapes, starts, rows, ref, 4)
 print('f32 %.1f us   bf16 hm %.1f us' % (timeit(lambda: ops.msda_forward_fused(value, shapes, starts, rows, ref, 4)),
                                          timeit(lambda: ops.msda_forward_fused_bf16(v_hm, shapes, starts, rows16, ref, 4, head_major=True))))
+import hashlib
+print('f32 output sha1', hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest()[:16], 'T2D' if os.environ.get('CGG_MSDA_T2D') else 'strip')
+# trained-like offsets: init grid + noise
+rows2 = rows.clone(); rows2[..., :192] += torch.randn(B, N, 192, generator=g).to(dev) * 1.0
+a2 = ops.msda_forward_fused(value, shapes, starts, rows2, ref, 4)
+print('noisy offsets: f32 %.1f us sha1 %s' % (timeit(lambda: ops.msda_forward_fused(value, shapes, starts, rows2, ref, 4)),
+                                             hashlib.sha1(a2.cpu().numpy().tobytes()).hexdigest()[:16]))
