@@ -32,7 +32,7 @@ def run_cfgs(fn, M, N):
     ts = {}
     if not AUTO_ONLY:
         for c in CFGS:
-            if BN[c] >= 2 * N and BN[c] > 64: continue       # tile far wider than the problem
+            if BN[c % 100] >= 2 * N and BN[c % 100] > 64: continue       # tile far wider than the problem
             lib.cgg_gemm_x3s_force_config(c)
             ts[c] = timeit(fn)
     lib.cgg_gemm_x3s_force_config(-1)
