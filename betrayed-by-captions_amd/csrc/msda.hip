@@ -415,7 +415,10 @@ __device__ __forceinline__ void msda_point_gather_f32(msda_v2f (&acc)[4], const 
   }
 }
 
-template <bool T2D>
+// T2D: 0 = a wave is 16 consecutive queries, the block's 4 waves are 4 heads; 1 = a wave is a 4 x 4 pixel tile of its level, the
+// block's 4 waves are 4 heads of it; 2 = a wave is a 4 x 4 tile, the block's 4 waves are the four tiles of an 8 x 8 pixel block
+// of ONE head (their taps share a (8 + 2 r)^2 window of lines), blockIdx enumerates (8 x 8 block, head)
+template <int T2D>
 __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ rows, const float* __restrict__ ref,
     int ld, float* __restrict__ out, int Nv, int Nq, unsigned total) {
@@ -425,12 +428,24 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
   // L1; a block = 4 heads of a 16-query group, two blocks per group (the geometry of the head-major bf16 kernel): 127 -> 121 us
   const unsigned blk = (unsigned)cgg_xcd_remap(blockIdx.x, gridDim.x), t = threadIdx.x;
   const int cq = (int)(t & 3u);
-  const int h = (int)((blk & 1u) * 4u + (t >> 6));
+  int h = (int)((blk & 1u) * 4u + (t >> 6));
   unsigned bq = (blk >> 1) * 16u + ((t >> 2) & 15u);
+  if constexpr (T2D == 2) {
+    // blk = (image, 8 x 8 block of a level, head); wave w = tile (w >> 1, w & 1) of the block
+    h = (int)(blk & 7u);
+    const unsigned blocks_img = (unsigned)Nq >> 6;
+    const unsigned bb = blk >> 3, bimg = bb / blocks_img, bl = bb - bimg * blocks_img;     // block index inside the image
+    const int l = (int)(bl << 6) >= lv.start[2] ? 2 : ((int)(bl << 6) >= lv.start[1] ? 1 : 0);
+    const int g8 = (int)bl - (lv.start[l] >> 6), bx_n = lv.w[l] >> 3;
+    const int by = g8 / bx_n, bx = g8 - by * bx_n;
+    const int w = (int)(t >> 6), i = (int)((t >> 2) & 15u);
+    const int py = 8 * by + 4 * (w >> 1) + (i >> 2), px = 8 * bx + 4 * (w & 1) + (i & 3);
+    bq = bimg * (unsigned)Nq + (unsigned)(lv.start[l] + py * lv.w[l] + px);
+  }
   if (bq >= total / 32u) return;          // whole quads
   const unsigned b = bq / (unsigned)Nq;
   int q = (int)(bq - b * (unsigned)Nq);
-  if constexpr (T2D) {
+  if constexpr (T2D == 1) {
     // the wave's 16 queries are a 4 x 4 pixel tile of their level instead of a 16 x 1 strip (every level: W, H % 4 == 0,
     // start % 16 == 0; queries == pixels): the taps of a tile fall into a (4 + 2 r)^2 window instead of (16 + 2 r) x (1 + 2 r)
     const int g = q >> 4, i = q & 15;
@@ -1078,17 +1093,29 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
   const long long total8 = (long long)B * Nq * H * (D / 8);
   if (dtype == CGG_F32 && fused && st && H == 8 && D == 32 && ld % 4 == 0 && cgg_aligned16(loc) && !generic_only &&
       (long long)Nv * H * D < (1ll << 31) && total8 < (1ll << 31)) {
-    // 4 x 4 query tiles per wave when the queries are the pixels of a pyramid whose levels allow it (the encoder): bit-identical
-    // outputs; 118 -> 118 us with the initialisation's offsets, 131 -> 121 us with +-1 px of noise on them (round 4, VERDICT r3 item 5:
-    // the kernel stays L2-request-rate bound -- every tap is a 128-B request, 14.5 M per launch -- so <= 80 us is out of reach)
+    // Query -> lane mapping when the queries are the pixels of a pyramid whose levels allow it (the encoder), all bit-identical
+    // (round 4; scratch/msda_f32_bench.py, init offsets / +-1 px of noise on them):
+    //   16 x 1 strips, a block = 4 heads of a strip (round 3)                                   118-119 us / 132 us
+    //   4 x 4 tiles per wave, a block = 4 heads of a tile                                        118 us     / 122 us
+    //   4 x 4 tiles per wave, a block = the four tiles of an 8 x 8 pixel block of ONE head       114 us     / 116 us
+    //   ... with the occupancy capped at 4 blocks per CU by a 36-KB dynamic LDS request          109 us     / 111 us
+    // (caps of 26 / 32 / 40 KB: 112 / 110 / 110 us; 44-53 KB = 3 blocks: 114 us; 64 KB = 2 blocks: 134 us). The block's taps then
+    // share a (8 + 2 r)^2 window of 128-B lines that a 16-wave CU keeps in its L1; the kernel stays L2-request bound (every tap
+    // of the first toucher is a 128-B request), <= 80 us is out of reach for f32 values.
     bool t2d = Nq == Nv && Nq % 16 == 0;
     for (int l = 0; l < L && t2d; ++l) t2d = lv.w[l] % 4 == 0 && lv.h[l] % 4 == 0 && lv.start[l] % 16 == 0;
-    if (t2d)
-      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<true>, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s,
-                         (const float*)value, lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
+    bool t8 = t2d && Nq % 64 == 0;
+    for (int l = 0; l < L && t8; ++l) t8 = lv.w[l] % 8 == 0 && lv.h[l] % 8 == 0 && lv.start[l] % 64 == 0;
+    const unsigned nb = 2 * (unsigned)(((long long)B * Nq + 15) / 16);
+    if (t8)
+      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<2>, dim3(nb), dim3(256), 36000, s, (const float*)value, lv, loc, ref, ld, out,
+                         Nv, Nq, (unsigned)total8);
+    else if (t2d)
+      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<1>, dim3(nb), dim3(256), 0, s, (const float*)value, lv, loc, ref, ld, out,
+                         Nv, Nq, (unsigned)total8);
     else
-      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<false>, dim3(2 * (unsigned)(((long long)B * Nq + 15) / 16)), dim3(256), 0, s,
-                         (const float*)value, lv, loc, ref, ld, out, Nv, Nq, (unsigned)total8);
+      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<0>, dim3(nb), dim3(256), 0, s, (const float*)value, lv, loc, ref, ld, out,
+                         Nv, Nq, (unsigned)total8);
     CGG_CHECK_LAUNCH("cgg_msda_forward");
     return CGG_OK;
   }

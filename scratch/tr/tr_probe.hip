@@ -1,0 +1,21 @@
+// ds_read_b64_tr_b16 semantics probe (gfx950): LDS element i holds the value i; lane l passes the address of elements 4 l .. 4 l + 3;
+// prints which LDS elements each lane receives.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__global__ void k(unsigned short* out) {
+  __shared__ unsigned short lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (unsigned short)i;
+  __syncthreads();
+  int l = threadIdx.x;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + l * 4));
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
+}
+int main() {
+  unsigned short* d; unsigned short h[256];
+  hipMalloc(&d, 512);
+  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
+  hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
+  for (int l = 0; l < 64; ++l) printf("lane %2d: %4d %4d %4d %4d\n", l, h[4 * l], h[4 * l + 1], h[4 * l + 2], h[4 * l + 3]);
+  return 0;
+}

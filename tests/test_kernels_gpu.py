@@ -97,8 +97,14 @@ def test_msda_bf16_value(dev):
     assert (got - want).abs().max().item() <= 1e-4  # same bf16-rounded values, f32 arithmetic
 
 
-def test_msda_fused_prologue(dev):
-    shapes = [(8, 8), (16, 16), (32, 32)]
+@pytest.mark.parametrize('shapes', [
+    [(8, 8), (16, 16), (32, 32)],      # every level % 8: a block = the four 4 x 4 tiles of an 8 x 8 pixel block of one head
+    [(4, 4), (12, 12), (20, 20)],      # % 4 only: 4 x 4 tiles per wave, a block = 4 heads
+    [(5, 7), (10, 14), (20, 28)],      # ragged: 16 x 1 strips
+])
+def test_msda_fused_prologue(dev, shapes):
+    """The f32 stream kernel (offsets / logits rows in, softmax + reference-point arithmetic fused) in its three query -> lane
+    mappings (csrc/msda.hip, round 4) against the [3P] op's definition (`ref.msda_core`)."""
     starts, Nv = _levels(shapes)
     B, H, D, L, P = 2, 8, 32, 3, 4
     Nq = Nv
