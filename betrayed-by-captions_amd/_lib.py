@@ -38,6 +38,7 @@ PROTOTYPES = {
     'cgg_masked_xattn_workspace_bytes': (_c_i64, [_c_int] * 5),
     'cgg_masked_xattn_forward': (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
     'cgg_masked_xattn_forward_strided': (_c_int, [_c_vp, _c_vp, _c_int, _c_i64, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_f, _c_vp]),
+    'cgg_masked_xattn_forward_x3': (_c_int, [_c_vp, _c_vp, _c_int, _c_i64, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_f, _c_vp]),
     'cgg_masked_xattn_forward_lse': (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
     'cgg_masked_xattn_backward_workspace_bytes': (_c_i64, [_c_int] * 5),
     'cgg_masked_xattn_backward': (_c_int, [_c_vp] * 9 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),

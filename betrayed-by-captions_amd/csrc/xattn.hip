@@ -591,9 +591,14 @@ extern "C" int64_t cgg_masked_xattn_workspace_bytes(int B, int Q, int H, int D, 
   return (int64_t)B * H * nch * Q * (D + 2) * (int64_t)sizeof(float);
 }
 
+void cgg_xattn_partial_x3_launch(int nch, int H, int B, size_t mask_lds, hipStream_t s, const float* q, const float* kv,
+                                 const uint32_t* bits, float* ws_o, float* ws_ml, int Q, int S, int words, int KC, float scale,
+                                 float* out_direct, float* lse, int ldkv, long long kv_bstride);      // xattn_x3.hip
+
+// x3 != 0: the partial pass on the f32-class f16 x 3 contraction (xattn_x3.hip) instead of the f32 MFMA
 static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse, void* ws, int B,
                              int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream, int ldkv = 0,
-                             int64_t kv_bstride = 0) {
+                             int64_t kv_bstride = 0, int x3 = 0) {
   if (ldkv <= 0) ldkv = 2 * H * D;
   if (kv_bstride <= 0) kv_bstride = (int64_t)S * ldkv;
   CGG_REQUIRE(ldkv >= 2 * H * D && ldkv % 4 == 0 && kv_bstride % 4 == 0, CGG_EINVAL,
@@ -615,10 +620,14 @@ static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bit
   float* ws_ml = ws_o + (size_t)B * H * nch * Q * D;
   const size_t lds = (size_t)2 * XA_TK * D * sizeof(float) + (size_t)nmt * 32 * (KC / 32 + 1) * 4;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
-                     bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
+  if (x3)
+    cgg_xattn_partial_x3_launch(nch, H, B, (size_t)nmt * 32 * (KC / 32 + 1) * 4, s, q, (const float*)kv, bits, ws_o, ws_ml, Q, S, words, KC,
+                                scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
+  else
+    hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
+                       bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
-  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, 0, lse);
+  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, x3 ? 1 : 0, x3 ? nullptr : lse);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
   return CGG_OK;
 }
@@ -635,6 +644,13 @@ extern "C" int cgg_masked_xattn_forward_strided(const float* q, const float* kv,
                                                 float* out, void* ws, int B, int Q, int H, int D, int S, float scale,
                                                 cgg_stream_t stream) {
   return xattn_forward_f32(q, kv, bits, out, nullptr, ws, B, Q, H, D, S, scale, CGG_F32, stream, ldkv, kv_bstride);
+}
+
+// The same operator with both products on the f32-class f16 x 3 contraction (csrc/x3.h; |q scale|, |k|, |v| < 4094): parity mode's
+// inference path. ldkv / kv_bstride as in cgg_masked_xattn_forward_strided (0 = contiguous (B, S, 2 E) rows).
+extern "C" int cgg_masked_xattn_forward_x3(const float* q, const float* kv, int ldkv, int64_t kv_bstride, const uint32_t* bits,
+                                           float* out, void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream) {
+  return xattn_forward_f32(q, kv, bits, out, nullptr, ws, B, Q, H, D, S, scale, CGG_F32, stream, ldkv, kv_bstride, 1);
 }
 
 extern "C" int cgg_masked_xattn_forward_lse(const float* q, const void* kv, const uint32_t* bits, float* out, float* lse,

@@ -195,6 +195,8 @@ class MSDeformAttnRowsFunction(torch.autograd.Function):
 # parity mode: contract the mask logits in exact f32 (f32 MFMA) instead of 3 x bf16 on (hi, lo) pairs; CGG_EXACT_F32_LOGITS=0
 # restores the split kernel (A/B)
 EXACT_F32_LOGITS = os.environ.get('CGG_EXACT_F32_LOGITS', '1') != '0'
+# parity mode's inference cross-attention on the f16 x 3 contraction (CGG_XATTN_X3=0 = the f32-MFMA kernel, A/B)
+XATTN_X3 = os.environ.get('CGG_XATTN_X3', '1') != '0'
 
 
 def _throughput_mode():
@@ -375,6 +377,16 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
     lib = _lib_()
     ws = _xattn_ws(lib.cgg_masked_xattn_workspace_bytes, q, B, Q, H, D, S)
     out = torch.empty((B, Q, E), dtype=torch.float32, device=q.device)
+    from . import runtime
+    if XATTN_X3 and not return_lse and runtime.x3_enabled() and kv.is_cuda and kv.dtype == torch.float32 \
+            and kv.stride(2) == 1 and kv.stride(1) % 4 == 0 and kv.stride(0) % 4 == 0:
+        # parity mode, inference: both products on the f32-class f16 x 3 contraction (csrc/xattn_x3.hip); kv may be a column
+        # slice of a merged projection (rows / images at their strides)
+        rc = lib.cgg_masked_xattn_forward_x3(dev_ptr(q, 'q', torch.float32), ctypes.c_void_p(kv.data_ptr()), kv.stride(1), kv.stride(0),
+                                             dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(ws), B, Q, H, D, S, float(scale),
+                                             stream_ptr(q.device))
+        check(rc, 'cgg_masked_xattn_forward_x3')
+        return out
     if not kv.is_contiguous() and not return_lse:
         # a column slice of the merged [K | V] projection of the layers that read one level: rows / images at their strides
         if not kv.is_cuda or kv.dtype != torch.float32 or kv.stride(2) != 1:

@@ -195,6 +195,10 @@ int cgg_masked_xattn_forward(const float* q, const void* kv, const uint32_t* bit
  * projection of several decoder layers (0 = dense). */
 int cgg_masked_xattn_forward_strided(const float* q, const float* kv, int ldkv, int64_t kv_bstride, const uint32_t* bits,
                                      float* out, void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream);
+/* cgg_masked_xattn_forward(_strided) with S^T = K Q^T and O^T = V^T P^T on the f32-class f16 x 3 contraction (csrc/xattn_x3.hip):
+ * parity mode's inference path for mask2former_head.py:829-840. ldkv / kv_bstride = 0: contiguous (B, S, 2 E) rows. */
+int cgg_masked_xattn_forward_x3(const float* q, const float* kv, int ldkv, int64_t kv_bstride, const uint32_t* bits, float* out,
+                                void* ws, int B, int Q, int H, int D, int S, float scale, cgg_stream_t stream);
 /* Throughput-mode variant: k [B, S, H*D] bf16 and the value projection TRANSPOSED, vt [B, H*D, S] bf16 (computed
  * as Wv x mem^T by the caller), bf16 MFMA for both contractions, f32 softmax statistics and accumulation.
  * Same mask / output / workspace contract. Requires D == 32, Q <= 128, S % 4 == 0.

@@ -247,3 +247,45 @@ def test_encoder_layer_tail_v2_vs_float64_and_first_kernel(dev, M, N, FF):
     ops.encoder_layer_tail_x3(t(a), xe, pv[0], t(bo), (t(n0[0]), t(n0[1]), 1e-5), pv[1], t(b1) + 5000.0, pv[2], t(b2),
                               (t(n1[0]), t(n1[1]), 1e-5), x3a=True, v2=True)
     assert ops.x3_overflow_check(dev, reset=True)
+
+
+@pytest.mark.parametrize('B,Q,S', [(2, 100, 16384), (1, 100, 1050), (2, 37, 200), (1, 128, 4096)])
+def test_masked_xattn_x3_vs_float64_and_f32_kernel(dev, B, Q, S, monkeypatch):
+    """cgg_masked_xattn_forward_x3 (S^T = K Q^T and O^T = V^T P^T on the f16 x 3 contraction, V^T by ds_read_b64_tr_b16 transpose
+    reads in accumulator key order) vs the float64 definition of the masked attention core (mask2former_head.py:829-840) and vs the
+    f32-MFMA kernel: both within 2e-5 of the O(1) outputs (the f32 kernel's own error vs float64 is the yardstick); ragged key
+    counts, an un-masked row, a single visible key, kv as a strided column slice of a wider projection."""
+    g = torch.Generator().manual_seed(33 + S)
+    E, H = 256, 8
+    q = torch.randn(B, Q, E, generator=g)
+    kv_wide = torch.randn(B, S, 3 * 2 * E, generator=g)                  # three layers' [K | V] side by side
+    kv = kv_wide[..., 2 * E:4 * E]                                       # layer 1's slice: strided rows
+    mask = torch.rand(B, Q, S, generator=g) < 0.6
+    mask[0, 1] = False
+    mask[0, 2] = True
+    mask[0, 2, S - 1] = False
+    d = lambda t: t.double()
+    k64, v64 = d(kv[..., :E]), d(kv[..., E:])
+    logits = torch.einsum('bqhd,bshd->bhqs', d(q).view(B, Q, H, 32), k64.reshape(B, S, H, 32)) / 32 ** 0.5
+    logits = logits.masked_fill(mask[:, None], float('-inf'))
+    want = torch.einsum('bhqs,bshd->bqhd', logits.softmax(-1), v64.reshape(B, S, H, 32)).reshape(B, Q, E)
+    words = (S + 31) // 32
+    padded = torch.zeros(B, Q, words * 32, dtype=torch.bool)
+    padded[..., :S] = mask
+    w = (padded.view(B, Q, words, 32).long() << torch.arange(32)).sum(-1)
+    bits = w.where(w < 2 ** 31, w - 2 ** 32).to(torch.int32).to(dev)
+    kvd = kv_wide.to(dev)[..., 2 * E:4 * E]
+    assert not kvd.is_contiguous()
+    ops.x3_overflow_check(dev, reset=True)
+    got = ops.masked_xattn(q.to(dev), kvd, bits, H)
+    monkeypatch.setattr(ops, 'XATTN_X3', False)
+    f32 = ops.masked_xattn(q.to(dev), kvd, bits, H)
+    e_x3, e_f32 = _err(got, want), _err(f32, want)
+    assert e_x3 <= max(2e-5, 4 * e_f32), (e_x3, e_f32)
+    assert not ops.x3_overflow_check(dev, reset=True)
+    monkeypatch.setattr(ops, 'XATTN_X3', True)
+    assert torch.equal(got, ops.masked_xattn(q.to(dev), kvd, bits, H))          # reproducible
+    big = kvd.clone()
+    big[0, 0, 5] = 5000.0
+    ops.masked_xattn(q.to(dev), big, bits, H)
+    assert ops.x3_overflow_check(dev, reset=True)
