@@ -1,0 +1,170 @@
+// Round 4, training in parity mode: the weight gradient of a linear layer, dW[n][k] = sum_m dY[m][n] X[m][k], on the f32-class
+// f16 x 3 contraction (x3.h) -- what autograd computes as `grad_output.t() @ input` for the F.linear calls under
+// open_set/models/mask2former_head.py:787 ([3P] MSDeformAttn encoder layers: value_proj / sampling_offsets / attention_weights /
+// output_proj / FFN, 344 064 rows at configs[2]). hipBLASLt's f32 GEMM runs this at the f32 MFMA peak (144 TF measured).
+//
+// Both operands are row-major with the CONTRACTION index m as the slow one, the layout an MFMA operand cannot take directly (a lane
+// needs 8 consecutive m of one column). The 32-row x 128-column tiles of dY and X are split into f16 pairs on their way into LDS,
+// stored row-major, and read back as MFMA fragments by `ds_read_b64_tr_b16` transpose reads (within a 16-lane group, lane c
+// receives element c % 4 of the 8-byte chunks addressed by lanes 4 j + c / 4: probed on the device, scratch/tr/tr_probe.hip):
+// a 16-lane group fetches 4 consecutive rows m x 16 columns and each lane ends up with its column's 4 m-values.
+//
+// Workgroup = 4 waves (2 x 2), tile 128 (n) x 128 (k), wave 64 x 64 = 2 x 2 MFMA tiles; grid.y = SPLIT contiguous row ranges whose
+// partial tiles go to ws[split][N][K] (plain stores: deterministic; the caller sums over the splits). Global loads of chunk c + 1
+// are in flight (registers) while chunk c is multiplied; one LDS buffer of 40 KiB (row stride 320 B: four consecutive rows fall
+// into disjoint bank groups for the transpose reads).
+#include "x3.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t wg_u32x4;
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
+typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
+
+#define WG_RS 320                 // LDS row stride in bytes (128 f16 + 64 B pad)
+#define WG_PLANE (32 * WG_RS)     // one 32-row plane
+
+__device__ __forceinline__ wg_u32x4 wg_tr_frag(const unsigned char* plane, int row0, int colbyte) {
+  // rows row0 .. row0 + 3 (first half) and row0 + 4 .. row0 + 7 (second half) of this lane's column group
+  const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(plane + row0 * WG_RS + colbyte));
+  const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(plane + (row0 + 4) * WG_RS + colbyte));
+  const uint2 au = __builtin_bit_cast(uint2, a), bu = __builtin_bit_cast(uint2, b);
+  return wg_u32x4{au.x, au.y, bu.x, bu.y};
+}
+
+__global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                           float* __restrict__ ws, int M, int N, int K, int tiles_k,
+                                                           int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WG_PLANE];       // Yh | Yl | Xh | Xl
+  unsigned char* Yh = lds;
+  unsigned char* Yl = lds + WG_PLANE;
+  unsigned char* Xh = lds + 2 * WG_PLANE;
+  unsigned char* Xl = lds + 3 * WG_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int m_begin = blockIdx.y * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+
+  // staging: thread = (row r8 + 8 i, 16-byte column group c4) of both tiles
+  const int r8 = tid >> 5, c4 = tid & 31;
+  const int ny = n0 + 4 * c4, kx = k0 + 4 * c4;
+  const bool yok = ny < N, xok = kx < K;                  // N, K % 4 == 0: a group is inside or outside
+  const float* yp = dy + (yok ? ny : 0);
+  const float* xp = x + (xok ? kx : 0);
+  f32x4 yv[4], xv[4];
+  auto load = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + r8 + 8 * i;
+      const int mc = m < m_end ? m : m_end - 1;
+      yv[i] = *reinterpret_cast<const f32x4*>(yp + (size_t)mc * ldy);
+      xv[i] = *reinterpret_cast<const f32x4*>(xp + (size_t)mc * ldx);
+    }
+  };
+  auto stage = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool live = m0 + r8 + 8 * i < m_end;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      uint2 h, l;
+      cgg_x3_split4((live && yok) ? yv[i] : z, h, l);
+      const int o = (r8 + 8 * i) * WG_RS + 8 * c4;
+      *reinterpret_cast<uint2*>(Yh + o) = h;
+      *reinterpret_cast<uint2*>(Yl + o) = l;
+      cgg_x3_split4((live && xok) ? xv[i] : z, h, l);
+      *reinterpret_cast<uint2*>(Xh + o) = h;
+      *reinterpret_cast<uint2*>(Xl + o) = l;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transpose-read geometry: 16-lane group g: column block 16 (g & 1), row half u = g >> 1; lane's chunk = row (i16 >> 2), columns
+  // 4 (i16 & 3) .. + 3 of the block
+  const int g = lane >> 4, u = g >> 1, i16 = lane & 15;
+  const int colb = 2 * (16 * (g & 1) + 4 * (i16 & 3));      // byte offset inside a 32-column MFMA tile
+  const int rowl = 8 * u + (i16 >> 2);
+
+  if (m_begin < m_end) load(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+    __syncthreads();                       // the previous chunk's fragments are read
+    stage(m0);
+    __syncthreads();
+    if (m0 + 32 < m_end) load(m0 + 32);    // workgroup-uniform
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      wg_u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int cy = 2 * (wn * 64 + t * 32) + colb, cx = 2 * (wk * 64 + t * 32) + colb;
+        ah[t] = wg_tr_frag(Yh, 16 * s + rowl, cy);
+        al[t] = wg_tr_frag(Yl, 16 * s + rowl, cy);
+        bh[t] = wg_tr_frag(Xh, 16 * s + rowl, cx);
+        bl[t] = wg_tr_frag(Xl, 16 * s + rowl, cx);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cgg_x3_mfma(acc[a][b], ah[a], al[a], bh[b], bl[b]);
+    }
+  }
+
+  // partial tile -> ws[split][n][k]; lane (k column j, half hi5), register r <-> n row 8 (r >> 2) + 4 hi5 + (r & 3)
+  const int j = lane & 31, hi5 = lane >> 5;
+  float* wsp = ws + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kc = k0 + wk * 64 + b * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + a * 32 + 8 * (r >> 2) + 4 * hi5 + (r & 3);
+        if (n < N && kc < K) wsp[(size_t)n * K + kc] = acc[a][b][r] * (1.f / 256.f);
+      }
+    }
+}
+
+// rows per split and number of splits for (M, N, K): ~1024 workgroups, row ranges multiples of 32
+static void wgrad_plan(int M, int N, int K, int* splits, int* rows_per_split) {
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int sp = (1024 + tiles - 1) / tiles;
+  const int max_sp = (M + 255) / 256;                  // at least 256 rows per split
+  if (sp > max_sp) sp = max_sp;
+  if (sp < 1) sp = 1;
+  int rps = ((M + sp - 1) / sp + 31) / 32 * 32;
+  *rows_per_split = rps;
+  *splits = (M + rps - 1) / rps;
+}
+
+extern "C" int64_t cgg_wgrad_x3_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int sp, rps;
+  wgrad_plan(M, N, K, &sp, &rps);
+  return (int64_t)sp * N * K * (int64_t)sizeof(float);
+}
+
+// ws (cgg_wgrad_x3_workspace_bytes) receives `*splits_out` partial (N, K) f32 matrices; dW = their sum (fixed order: the caller's
+// reduction). dy (M, N) rows at stride ldy, x (M, K) rows at stride ldx, f32, |values| < 4094; N, K, ldy, ldx multiples of 4.
+extern "C" int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, int* splits_out, int M, int N, int K,
+                            cgg_stream_t stream) {
+  CGG_REQUIRE(dy && x && ws && splits_out, CGG_EINVAL, "cgg_wgrad_x3: null pointer");
+  CGG_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K, CGG_EINVAL, "cgg_wgrad_x3: bad sizes");
+  CGG_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0, CGG_EUNSUPPORTED,
+              "cgg_wgrad_x3: N=%d, K=%d and the row strides must be multiples of 4", N, K);
+  CGG_REQUIRE(cgg_aligned16(dy) && cgg_aligned16(x) && cgg_aligned16(ws), CGG_EALIGN, "cgg_wgrad_x3: 16-B alignment");
+  int sp, rps;
+  wgrad_plan(M, N, K, &sp, &rps);
+  *splits_out = sp;
+  const int tiles_k = (K + 127) / 128, tiles_n = (N + 127) / 128;
+  hipLaunchKernelGGL(cgg_wgrad_x3_kernel, dim3(tiles_n * tiles_k, sp), dim3(256), 0, (hipStream_t)stream, dy, ldy, x, ldx, ws, M, N, K,
+                     tiles_k, rps);
+  CGG_CHECK_LAUNCH("cgg_wgrad_x3");
+  return CGG_OK;
+}

@@ -160,8 +160,8 @@ class _X3LinearFn(torch.autograd.Function):
     stream's row counts: forward y = x W^T + b and grad-input dx = dy W on the f32-class x3 GEMM (`ops.gemm_x3`, three f16 MFMAs
     per product, as accurate as an f32 GEMM -- tests/test_x3_gpu.py); the x3 images of W and W^T are re-packed when the optimiser
     changes the weight (cached against its version). The weight gradient dW = dy^T x reduces over ALL rows into a tiny output:
-    rows cut into S slabs, ONE batched f32 library GEMM for the partial gradients and their sum (the split of `_SplitKLinearFn`;
-    an x3 kernel for this transposed-operand contraction is not built)."""
+    `ops.wgrad_x3` (csrc/wgrad_x3.hip: both row-major operands through `ds_read_b64_tr_b16` transpose reads, row ranges split over
+    the grid, partial tiles summed in fixed order); CGG_X3_WGRAD=0 = one batched f32 library GEMM over S row slabs (round 3)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -193,8 +193,11 @@ class _X3LinearFn(torch.autograd.Function):
             gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
             ops.gemm_x3(g2, wtk, K, out=gx.view(-1, K))
         if ctx.needs_input_grad[1]:
-            S = next((s for s in (32, 16, 8, 4, 2) if M % s == 0 and M // s >= 4096), 1)
-            gw = torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)).sum(0)
+            if _X3_WGRAD:
+                gw = ops.wgrad_x3(g2, x2)              # transpose-read x3 kernel (csrc/wgrad_x3.hip), partial tiles summed in fixed order
+            else:
+                S = next((s for s in (32, 16, 8, 4, 2) if M % s == 0 and M // s >= 4096), 1)
+                gw = torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb
@@ -202,6 +205,7 @@ class _X3LinearFn(torch.autograd.Function):
 
 X3_TRAIN_ROWS = 8192               # rows from which parity-mode training linears run on the x3 GEMM (CGG_X3_TRAIN=0 disables)
 _X3_TRAIN = _os.environ.get('CGG_X3_TRAIN', '1') != '0'
+_X3_WGRAD = _os.environ.get('CGG_X3_WGRAD', '1') != '0'
 
 
 def x3_train_linear_ok(x, weight):

@@ -500,6 +500,15 @@ int cgg_encoder_layer_tail_x3a_v2(const float* a32, const void* x_x3a, const voi
                                   int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
 int cgg_encoder_tail_v2_perm32(int32_t* perm32);
 
+/* Training in parity mode: the weight gradient of a linear layer, dW[n][k] = sum_m dy[m][n] x[m][k] -- autograd's
+ * `grad_output.t() @ input` behind the F.linear calls of the [3P] MSDeformAttn encoder layers (mask2former_head.py:787) -- on the
+ * f32-class f16 x 3 contraction; both row-major operands reach the MFMA through LDS transpose reads (csrc/wgrad_x3.hip). ws
+ * (cgg_wgrad_x3_workspace_bytes) receives *splits_out partial (N, K) f32 matrices over contiguous row ranges; dW is their sum.
+ * dy (M, N) rows at stride ldy, x (M, K) rows at stride ldx; N, K, ldy, ldx % 4 == 0; |values| < 4094. */
+int64_t cgg_wgrad_x3_workspace_bytes(int M, int N, int K);
+int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, int* splits_out, int M, int N, int K,
+                 cgg_stream_t stream);
+
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */
 int cgg_add_layernorm_ex(const void* a, int a_dtype, const void* b, int b_dtype, const float* gamma, const float* beta,

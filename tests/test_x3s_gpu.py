@@ -289,3 +289,22 @@ def test_masked_xattn_x3_vs_float64_and_f32_kernel(dev, B, Q, S, monkeypatch):
     big[0, 0, 5] = 5000.0
     ops.masked_xattn(q.to(dev), big, bits, H)
     assert ops.x3_overflow_check(dev, reset=True)
+
+
+@pytest.mark.parametrize('M,N,K', [(43008, 256, 256), (8192, 288, 256), (5000, 1024, 256), (4099, 256, 1024), (300, 36, 68)])
+def test_wgrad_x3_vs_float64(dev, M, N, K):
+    """cgg_wgrad_x3 (dW = dy^T x through LDS transpose reads, x3 arithmetic, row ranges split over the grid) vs float64: the error of
+    an f32 GEMM of the same operands is the yardstick (<= 4x + a rounding floor); ragged row counts (partial chunks, partial
+    splits), column counts that are not multiples of the 128-wide tile, strided rows, reproducible (fixed-order sum)."""
+    g = torch.Generator().manual_seed(M + N)
+    dy_w = torch.randn(M, N + 8, generator=g) * 0.3
+    x_w = torch.randn(M, K + 4, generator=g)
+    dy, x = dy_w[:, :N], x_w[:, 4:]                      # strided rows (x starts 16 B into its row)
+    want = dy.double().t() @ x.double()
+    f32_err = ((dy.t() @ x).double() - want).abs().max().item()
+    dyd, xd = dy_w.to(dev)[:, :N], x_w.to(dev)[:, 4:]
+    got = ops.wgrad_x3(dyd, xd)
+    assert tuple(got.shape) == (N, K)
+    err = _err(got, want)
+    assert err <= 4 * f32_err + 2e-7 * want.abs().max().item(), (err, f32_err)
+    assert torch.equal(got, ops.wgrad_x3(dyd, xd))
