@@ -1094,6 +1094,14 @@ def is_x3(packed):
     return isinstance(packed, X3Image)
 
 
+def _x3_check(packed, N, K, who):
+    """An x3 image carries no shape: its byte size must be the one `cgg_x3_packed_bytes(N, K)` prescribes (a wrong
+    (N, K) made the kernel read past the image)."""
+    want = _lib_().cgg_x3_packed_bytes(int(N), int(K))
+    if want <= 0 or packed.numel() * packed.element_size() != want:
+        raise CggError(f'{who}: the x3 image holds {packed.numel() * packed.element_size()} bytes, an (N={N}, K={K}) weight needs {want}')
+
+
 def _x3_fn(name, *packed):
     """C entry point `cgg_<name>_bf16` or its f32-class twin `cgg_<name>_x3`; all packed operands must be of one kind."""
     kinds = {is_x3(p) for p in packed if p is not None}
@@ -1127,6 +1135,7 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
     if a.dim() != 2 or a.stride(1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
         raise CggError('gemm_x3: a must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
     M, K = a.shape
+    _x3_check(packed, N, K, 'gemm_x3')
     y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
     if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
         raise CggError('gemm_x3: bad `out` view')
@@ -1217,6 +1226,7 @@ def gemm_x3_split(a, packed, N, col2, bias=None, res_table=None):
     if a.dim() != 2 or a.stride(1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
         raise CggError('gemm_x3_split: a must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
     M, K = a.shape
+    _x3_check(packed, N, K, 'gemm_x3_split')
     y1 = torch.empty((M, col2), dtype=torch.float32, device=a.device)
     y2 = torch.empty((M, N - col2), dtype=torch.float32, device=a.device)
     if res_table is not None and (res_table.dim() != 2 or res_table.shape[1] != N or not res_table.is_contiguous()
@@ -1239,6 +1249,7 @@ def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, rel
     B, H, W, C = x.shape
     KH, KW = (kernel, kernel) if isinstance(kernel, int) else kernel
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    _x3_check(packed, N, C * KH * KW, 'conv_x3_nhwc')
     y = torch.empty((B, OH, OW, N), dtype=torch.float32, device=x.device)
     if res is not None and (tuple(res.shape) != (B, OH, OW, N) or not res.is_contiguous() or res.dtype != torch.float32):
         raise CggError('conv_x3_nhwc: res must be a contiguous (B, OH, OW, N) float32 tensor')
@@ -1321,6 +1332,7 @@ def gemm_x3s(a, packed, N, bias=None, res=None, res_split=False, res_mod=0, relu
         M, K, lda = a.shape[0] * a.shape[1], a.shape[2], int(a.stride(1))
     else:
         (M, K), lda = a.shape, int(a.stride(0))
+    _x3_check(packed, N, K, 'gemm_x3s')
     y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
     if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
         raise CggError('gemm_x3s: bad `out` view')
@@ -1352,6 +1364,7 @@ def conv_x3s_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, re
     B, H, W, C = x.shape
     KH, KW = (kernel, kernel) if isinstance(kernel, int) else kernel
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    _x3_check(packed, N, C * KH * KW, 'conv_x3s_nhwc')
     y = torch.empty((B, OH, OW, N), dtype=torch.float32, device=x.device)
     if res is not None and (tuple(res.shape) != (B, OH, OW, N) or not res.is_contiguous() or res.dtype != torch.float32):
         raise CggError('conv_x3s_nhwc: res must be a contiguous (B, OH, OW, N) float32-tagged tensor')

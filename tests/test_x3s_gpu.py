@@ -308,3 +308,18 @@ def test_wgrad_x3_vs_float64(dev, M, N, K):
     err = _err(got, want)
     assert err <= 4 * f32_err + 2e-7 * want.abs().max().item(), (err, f32_err)
     assert torch.equal(got, ops.wgrad_x3(dyd, xd))
+
+
+def test_x3_image_shape_is_checked(dev):
+    """An x3 image carries no (N, K): the GEMM / convolution wrappers compare its byte size with what the call's shape needs
+     instead of letting the kernel read past it."""
+    w = torch.randn(256, 512, device=dev)
+    pk = ops.pack_linear_weight_x3(w)
+    a = torch.randn(64, 256, device=dev)
+    with pytest.raises(Exception, match='x3 image holds'):
+        ops.gemm_x3(a, pk, 256)                                   # K = 256, the image was packed for K = 512
+    with pytest.raises(Exception, match='x3 image holds'):
+        ops.gemm_x3s(ops.x3a_encode(a), pk, 512)                  # N, K swapped
+    x = ops.x3a_encode(torch.randn(1, 8, 8, 64, device=dev))
+    with pytest.raises(Exception, match='x3 image holds'):
+        ops.conv_x3s_nhwc(x, pk, 256, 3, 1, 1)
