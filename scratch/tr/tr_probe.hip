@@ -1,4 +1,4 @@
-// ds_read_b64_tr_b16 semantics probe (gfx950): LDS element i holds the value i; lane l passes the address of elements 4 l .. 4 l + 3;
+// ds_read_b64_tr_b16 semantics probe (gfx950; build: hipcc --offload-arch=gfx950 -O2 -o scratch/tr/tr_probe scratch/tr/tr_probe.hip): LDS element i holds the value i; lane l passes the address of elements 4 l .. 4 l + 3;
 // prints which LDS elements each lane receives.
 #include <hip/hip_runtime.h>
 #include <cstdio>
