@@ -30,8 +30,11 @@ class RleCollector:
         self.num_classes = dict(num_classes)
         self.depth = depth
         import os
-        # the encoder's cost is per RUN; depth batches are encoded concurrently, each on this many host threads
-        self.rle_threads = rle_threads or max(4, min(64, (os.cpu_count() or 8) // 4))
+        from . import runtime
+        # the encoder's cost is per RUN; `depth` batches are encoded concurrently, each on this many host threads. The budget is
+        # the CPUs the process may really use (cgroup quota, not `nproc`): oversubscribing it gets every thread throttled
+        self.rle_threads = rle_threads or int(os.environ.get('CGG_RLE_THREADS', 0)) or \
+            max(2, min(16, (runtime.effective_cpu_count() - 2) // max(depth, 1)))
         self.copy_stream = torch.cuda.Stream(self.device)
         self.pool = cf.ThreadPoolExecutor(max_workers=depth)
         self._slots = [dict(buffers={}, event=None, future=None) for _ in range(depth)]

@@ -1921,7 +1921,7 @@ def rle_encode_bitmasks(bits, width, threads=8):
         return []
     lib = _lib_()
     offs = np.empty(n + 1, dtype=np.int64)
-    cap = max(1 << 16, n * 256)
+    cap = max(1 << 16, n * 4096)          # ~2 KB per mask at 1024^2 with this benchmark's noisy masks: a too-small buffer encodes twice
     while True:
         out = np.empty(cap, dtype=np.uint8)
         total = lib.cgg_rle_encode_bitmasks(ctypes.c_void_p(arr.ctypes.data), n, H, W, H * rb, rb, int(threads),

@@ -50,6 +50,33 @@ _X3 = _os.environ.get('CGG_X3', '1') != '0'
 _X3A = _os.environ.get('CGG_X3A', '1') != '0'
 
 
+def effective_cpu_count():
+    """CPUs this process may actually burn: min(os.cpu_count(), the scheduler affinity, the cgroup CPU quota). On the GPU boxes
+    `nproc` says 256 while the container's cgroup grants 16 CPUs (`cpu.max` = 1600000 100000): 64 busy helper threads are then
+    throttled by the CFS for up to 100 ms at a time (measured round 4: the host RLE path ran at 45-70 images/s instead of 330)."""
+    n = _os.cpu_count() or 1
+    try:
+        n = min(n, len(_os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                      # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()[:2]
+            if q != 'max':
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:     # cgroup v1
+                q = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def x3_enabled():
     """Parity mode on the f32-class f16 x 3 kernels (csrc/x3.h); CGG_X3=0 restores the round-2 parity path (f32 library
     GEMMs, f32-MFMA skinny linears) for A/B measurements."""
