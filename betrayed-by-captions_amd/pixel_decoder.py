@@ -86,7 +86,10 @@ class ConvModule(nn.Module):
         self.activate = build_act(dict(act_cfg, inplace=True)) if act_cfg is not None else None
 
     def forward(self, x):
-        x = self.conv(x.contiguous())
+        if runtime.x3_train_conv3x3_ok(self.conv, x):
+            x = runtime.conv3x3_x3_train(x, self.conv)          # parity-mode training: x3 forward / grad-input / grad-weight
+        else:
+            x = self.conv(x.contiguous())
         norm = getattr(self, self.norm_name) if self.norm_name is not None else None
         if isinstance(norm, nn.GroupNorm) and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
             # inference: HIP GroupNorm (+ fused ReLU), full-chip two-pass reduction

@@ -230,6 +230,65 @@ class _X3LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _X3Conv3x3Fn(torch.autograd.Function):
+    """Training-time 3x3 / stride 1 / pad 1 convolution (no bias) in PARITY mode on the f32-class x3 kernels -- the FPN output
+    convolution of the pixel decoder ([3P] MSDeformAttnPixelDecoder.output_convs, 256 -> 256 at 256^2: 30.8 ms of MIOpen f32
+    implicit GEMMs per step at configs[2], 10 % of the step). Forward and grad-input are `ops.conv_x3s_nhwc` on channel-last x3a
+    maps (grad-input = the convolution of grad_output with the flipped, transposed filter); the weight gradient is nine
+    `ops.wgrad_x3` contractions, one per filter tap, over the ZERO-PADDED channel-last maps: with both maps padded by one pixel a
+    tap is a constant row offset between two row-major matrices (border rows of grad_output are zero, so nothing leaks across
+    rows or images). Layout changes (NCHW <-> NHWC copies, padding) are paid explicitly: ~3 ms of the ~17 ms this costs."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import ops
+        N = weight.shape[0]
+        xl = x.detach().permute(0, 2, 3, 1).contiguous()
+        wk = derived_cached('x3_conv_image', (weight,), lambda: ops.pack_conv_weight_x3(weight))
+        y = ops.conv_x3s_nhwc(ops.x3a_encode(xl), wk, N, 3, 1, 1, None, out_split=False)
+        ctx.save_for_backward(xl, weight)
+        return y.permute(0, 3, 1, 2)                     # NCHW view of the channel-last result
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.nn.functional as F
+        from . import ops
+        xl, weight = ctx.saved_tensors
+        B, H, W, C = xl.shape
+        N = weight.shape[0]
+        gl = gy.permute(0, 2, 3, 1).contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = derived_cached('x3_conv_image_dgrad', (weight,),
+                                lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
+            gx = ops.conv_x3s_nhwc(ops.x3a_encode(gl), wt, C, 3, 1, 1, None, out_split=False).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            xp = F.pad(xl, (0, 0, 1, 1, 1, 1)).view(-1, C)               # rows of the (B, H + 2, W + 2) grid
+            gp = F.pad(gl, (0, 0, 1, 1, 1, 1)).view(-1, N)
+            Mp = xp.shape[0]
+            lo, hi = W + 3, Mp - (W + 3)                                 # rows outside are border rows: grad_output is zero there
+            gw = torch.empty((N, 3, 3, C), dtype=torch.float32, device=xl.device)
+            for ky in range(3):
+                for kx in range(3):
+                    off = (ky - 1) * (W + 2) + (kx - 1)
+                    gw[:, ky, kx, :] = ops.wgrad_x3(gp[lo:hi], xp[lo + off:hi + off])
+            gw = gw.permute(0, 3, 1, 2)
+        return gx, gw
+
+
+def x3_train_conv3x3_ok(conv, x):
+    """parity mode under autograd, a 3x3 / s1 / p1 / ungrouped / bias-free convolution whose channel counts the x3 kernels tile,
+    large enough to be worth the layout changes."""
+    return (_X3_TRAIN and _X3A and x3_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 32 == 0
+            and conv.out_channels % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 65536 and x.shape[2] >= 4 and x.shape[3] >= 4)
+
+
+def conv3x3_x3_train(x, conv):
+    return _X3Conv3x3Fn.apply(x, conv.weight)
+
+
 X3_TRAIN_ROWS = 8192               # rows from which parity-mode training linears run on the x3 GEMM (CGG_X3_TRAIN=0 disables)
 _X3_TRAIN = _os.environ.get('CGG_X3_TRAIN', '1') != '0'
 _X3_WGRAD = _os.environ.get('CGG_X3_WGRAD', '1') != '0'

@@ -323,3 +323,32 @@ def test_x3_image_shape_is_checked(dev):
     x = ops.x3a_encode(torch.randn(1, 8, 8, 64, device=dev))
     with pytest.raises(Exception, match='x3 image holds'):
         ops.conv_x3s_nhwc(x, pk, 256, 3, 1, 1)
+
+
+@pytest.mark.parametrize('B,C,N,H,W', [(2, 64, 96, 20, 28), (1, 32, 32, 9, 5), (2, 256, 256, 32, 32)])
+def test_x3_training_conv3x3_forward_and_gradients_vs_float64(dev, B, C, N, H, W):
+    """runtime._X3Conv3x3Fn (parity-mode training: forward and grad-input on the x3 implicit GEMM, grad-weight as nine x3
+    transpose-read contractions over the zero-padded channel-last maps) vs float64 autograd of F.conv2d: errors of the order of an
+    f32 convolution's; NCHW in, NCHW-shaped (channel-last strided) out."""
+    from cgg_amd import runtime
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(N, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    go = torch.randn(B, N, H, W, generator=g)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(go.double())
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y32 = F.conv2d(x32, w32, None, 1, 1)
+    y32.backward(go)
+    f = lambda a, b: (a.double() - b).abs().max().item()
+    ref_err = (f(y32, y64), f(x32.grad, x64.grad), f(w32.grad, w64.grad))
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    with runtime.precision_scope('fp32'):
+        y = runtime._X3Conv3x3Fn.apply(xd, wd)
+        assert tuple(y.shape) == (B, N, H, W)
+        y.backward(go.to(dev))
+    got = (f(y.detach().cpu(), y64), f(xd.grad.cpu(), x64.grad), f(wd.grad.cpu(), w64.grad))
+    scale = (y64.abs().max().item(), x64.grad.abs().max().item(), w64.grad.abs().max().item())
+    for e, r, s in zip(got, ref_err, scale):
+        assert e <= 4 * r + 3e-7 * s, (got, ref_err, scale)
