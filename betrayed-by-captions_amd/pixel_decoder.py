@@ -179,6 +179,12 @@ class FFN(nn.Module):
         self.dropout_layer = nn.Dropout(dropout_layer['drop_prob']) if dropout_layer else nn.Identity()
         self.add_identity = add_identity
 
+    def forward_noidentity(self, x):
+        """Training, parity mode: W2 relu(W1 x + b1) + b2 WITHOUT the residual (it is added inside the fused LayerNorm); the two
+        linears go through `runtime.linear` (x3 forward / grad-input / grad-weight for the encoder's row counts)."""
+        h = torch.relu_(runtime.linear(x, self.layers[0][0].weight, self.layers[0][0].bias))
+        return runtime.linear(h, self.layers[1].weight, self.layers[1].bias)
+
     def forward_bf16_noidentity(self, x):
         """Training, bf16 mode: W2 relu(W1 x + b1) + b2 in bf16 WITHOUT the residual (it is added inside the fused LayerNorm)."""
         h = F.relu(runtime.linear_bf16_train(x, self.layers[0][0].weight, self.layers[0][0].bias))
@@ -274,6 +280,9 @@ class MultiScaleDeformableAttention(nn.Module):
             # training in throughput mode: bf16 operands like the inference stream (whose kernel reads bf16 offset rows);
             # the f32 GEMM and its two backward GEMMs cost 11 ms per step at configs[2]
             offs_logits = runtime.linear(src_pos, w_cat, b_cat)
+        elif runtime.x3_train_linear_ok(src_pos, w_cat):
+            # parity-mode training: f32-class on the x3 kernels (forward, grad-input, grad-weight) like the other encoder linears
+            offs_logits = runtime.linear(src_pos, w_cat, b_cat)
         else:
             # offsets / logits decide WHERE to sample: f32 in parity mode and in the f32-value inference path
             offs_logits = F.linear(src_pos, w_cat, b_cat)
@@ -302,7 +311,9 @@ class MultiScaleDeformableAttention(nn.Module):
             out = ops.msda_forward_fused(value.contiguous(), level_hw, level_start,
                                          offs_logits.contiguous(), ref_points, self.num_points)
         if not add_identity:
-            return runtime.linear_bf16_train(out, self.output_proj.weight, self.output_proj.bias)
+            if runtime.is_bf16():
+                return runtime.linear_bf16_train(out, self.output_proj.weight, self.output_proj.bias)
+            return runtime.linear(out, self.output_proj.weight, self.output_proj.bias)
         out = runtime.linear(out, self.output_proj.weight, self.output_proj.bias)
         return src + self.dropout(out)
 
@@ -1047,8 +1058,20 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     nxt = ops.add_layernorm_train(mid, ffn.forward_bf16_noidentity(mid16), layer.norms[1], pos=pos_c,
                                                   want_bf16=not last, want_pos=not last)
                     src, src16, srcp16 = nxt if not last else (nxt, None, None)
+            # parity-mode training: the same one-pass residual + LayerNorm kernels (forward and backward) on f32 branch outputs
+            fused_ln32 = (not fused_ln and FUSED_TRAIN_LN and not runtime.is_bf16() and torch.is_grad_enabled() and src.is_cuda
+                          and src.dtype == torch.float32 and src.shape[-1] == 256
+                          and all(l.attentions[0].dropout.p == 0 and l.ffns[0].plain_relu_ffn()
+                                  and isinstance(l.norms[0], nn.LayerNorm) and isinstance(l.norms[1], nn.LayerNorm)
+                                  and ops.add_layernorm_train_ok(src, src, l.norms[0]) and ops.add_layernorm_train_ok(src, src, l.norms[1])
+                                  for l in self.encoder.layers))
             for layer in ([] if fused_ln else self.encoder.layers):
                 attn = layer.attentions[0]
+                if fused_ln32:
+                    out = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start, add_identity=False)
+                    mid = ops.add_layernorm_train(src, out.float(), layer.norms[0])
+                    src = ops.add_layernorm_train(mid, layer.ffns[0].forward_noidentity(mid).float(), layer.norms[1])
+                    continue
                 src = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start)
                 src = layer.norms[0](src)
                 src = layer.ffns[0](src)
