@@ -31,8 +31,8 @@ __device__ __forceinline__ wg_u32x4 wg_tr_frag(const unsigned char* plane, int r
 }
 
 __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                                           float* __restrict__ ws, int M, int N, int K, int tiles_k,
-                                                           int rows_per_split) {
+                                                           float* __restrict__ ws, float* __restrict__ ws_bias, int M, int N, int K,
+                                                           int tiles_k, int rows_per_split) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WG_PLANE];       // Yh | Yl | Xh | Xl
   unsigned char* Yh = lds;
   unsigned char* Yl = lds + WG_PLANE;
@@ -61,12 +61,16 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
       xv[i] = *reinterpret_cast<const f32x4*>(xp + (size_t)mc * ldx);
     }
   };
+  // bias gradient = the column sums of dy: the workgroups of the first k-tile column add up what they stage anyway (f32)
+  const bool want_bias = ws_bias != nullptr && tile_k == 0;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto stage = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool live = m0 + r8 + 8 * i < m_end;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       uint2 h, l;
+      if (want_bias && live && yok) bsum += yv[i];
       cgg_x3_split4((live && yok) ? yv[i] : z, h, l);
       const int o = (r8 + 8 * i) * WG_RS + 8 * c4;
       *reinterpret_cast<uint2*>(Yh + o) = h;
@@ -115,6 +119,20 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
     }
   }
 
+  if (want_bias) {
+    // the 8 row groups of a column group (threads c4, c4 + 32, ...) -> LDS (the tile planes are dead) -> one sum per column
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 32) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) t += red[tid + 32 * r];
+      const int n = n0 + 4 * tid;
+      if (n < N) *reinterpret_cast<f32x4*>(ws_bias + (size_t)blockIdx.y * N + n) = t;
+    }
+  }
   // partial tile -> ws[split][n][k]; lane (k column j, half hi5), register r <-> n row 8 (r >> 2) + 4 hi5 + (r & 3)
   const int j = lane & 31, hi5 = lane >> 5;
   float* wsp = ws + (size_t)blockIdx.y * N * K;
@@ -152,8 +170,8 @@ extern "C" int64_t cgg_wgrad_x3_workspace_bytes(int M, int N, int K) {
 
 // ws (cgg_wgrad_x3_workspace_bytes) receives `*splits_out` partial (N, K) f32 matrices; dW = their sum (fixed order: the caller's
 // reduction). dy (M, N) rows at stride ldy, x (M, K) rows at stride ldx, f32, |values| < 4094; N, K, ldy, ldx multiples of 4.
-extern "C" int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, int* splits_out, int M, int N, int K,
-                            cgg_stream_t stream) {
+static int wgrad_launch(const float* dy, int ldy, const float* x, int ldx, float* ws, float* ws_bias, int* splits_out, int M, int N,
+                        int K, cgg_stream_t stream) {
   CGG_REQUIRE(dy && x && ws && splits_out, CGG_EINVAL, "cgg_wgrad_x3: null pointer");
   CGG_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K, CGG_EINVAL, "cgg_wgrad_x3: bad sizes");
   CGG_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0, CGG_EUNSUPPORTED,
@@ -163,8 +181,21 @@ extern "C" int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, f
   wgrad_plan(M, N, K, &sp, &rps);
   *splits_out = sp;
   const int tiles_k = (K + 127) / 128, tiles_n = (N + 127) / 128;
-  hipLaunchKernelGGL(cgg_wgrad_x3_kernel, dim3(tiles_n * tiles_k, sp), dim3(256), 0, (hipStream_t)stream, dy, ldy, x, ldx, ws, M, N, K,
-                     tiles_k, rps);
+  hipLaunchKernelGGL(cgg_wgrad_x3_kernel, dim3(tiles_n * tiles_k, sp), dim3(256), 0, (hipStream_t)stream, dy, ldy, x, ldx, ws, ws_bias, M,
+                     N, K, tiles_k, rps);
   CGG_CHECK_LAUNCH("cgg_wgrad_x3");
   return CGG_OK;
+}
+
+extern "C" int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, int* splits_out, int M, int N, int K,
+                            cgg_stream_t stream) {
+  return wgrad_launch(dy, ldy, x, ldx, ws, nullptr, splits_out, M, N, K, stream);
+}
+
+// ... and the bias gradient db[n] = sum_m dy[m][n] from the same pass: ws_bias receives *splits_out partial (N) f32 rows
+// (ws_bias >= splits x N floats, 16-B aligned; the splits are those of cgg_wgrad_x3_workspace_bytes / (N K 4)).
+extern "C" int cgg_wgrad_bias_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, float* ws_bias, int* splits_out, int M,
+                                 int N, int K, cgg_stream_t stream) {
+  CGG_REQUIRE(ws_bias && cgg_aligned16(ws_bias), CGG_EINVAL, "cgg_wgrad_bias_x3: ws_bias must be a 16-B aligned buffer");
+  return wgrad_launch(dy, ldy, x, ldx, ws, ws_bias, splits_out, M, N, K, stream);
 }

@@ -1201,9 +1201,10 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     return y, yp
 
 
-def wgrad_x3(dy, x):
+def wgrad_x3(dy, x, want_bias=False):
     """dW (N, K) = dy^T x for dy (M, N), x (M, K) f32 rows (contiguous last dim, row strides % 4 == 0; N, K % 4 == 0) on the
-    f32-class f16 x 3 contraction with transpose reads (csrc/wgrad_x3.hip): the weight gradient of a linear layer."""
+    f32-class f16 x 3 contraction with transpose reads (csrc/wgrad_x3.hip): the weight gradient of a linear layer.
+    want_bias: -> (dW, db) with db (N) = dy.sum(0) from the same pass over dy."""
     if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or dy.dtype != torch.float32 or x.dtype != torch.float32 \
             or not dy.is_cuda or dy.stride(1) != 1 or x.stride(1) != 1:
         raise CggError('wgrad_x3: dy (M, N) and x (M, K) must be float32 ROCm matrices with contiguous rows')
@@ -1213,11 +1214,19 @@ def wgrad_x3(dy, x):
     nbytes = lib.cgg_wgrad_x3_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
     splits = ctypes.c_int(0)
+    wsb = torch.empty((nbytes // (4 * N * K)) * N, dtype=torch.float32, device=dy.device) if want_bias else None
     with _timed('wgrad_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K), shape=(M, N, K)):
-        rc = lib.cgg_wgrad_x3(ctypes.c_void_p(dy.data_ptr()), dy.stride(0), ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(ws),
-                              ctypes.byref(splits), M, N, K, stream_ptr(dy.device))
+        if want_bias:
+            rc = lib.cgg_wgrad_bias_x3(ctypes.c_void_p(dy.data_ptr()), dy.stride(0), ctypes.c_void_p(x.data_ptr()), x.stride(0),
+                                       dev_ptr(ws), dev_ptr(wsb), ctypes.byref(splits), M, N, K, stream_ptr(dy.device))
+        else:
+            rc = lib.cgg_wgrad_x3(ctypes.c_void_p(dy.data_ptr()), dy.stride(0), ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(ws),
+                                  ctypes.byref(splits), M, N, K, stream_ptr(dy.device))
     check(rc, 'cgg_wgrad_x3')
-    return ws.view(splits.value, N, K).sum(0) if splits.value > 1 else ws.view(N, K).clone()
+    gw = ws.view(splits.value, N, K).sum(0) if splits.value > 1 else ws.view(N, K).clone()
+    if want_bias:
+        return gw, wsb.view(-1, N)[:splits.value].sum(0)
+    return gw
 
 
 def gemm_x3_split(a, packed, N, col2, bias=None, res_table=None):

@@ -220,12 +220,14 @@ class _X3LinearFn(torch.autograd.Function):
             gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
             ops.gemm_x3(g2, wtk, K, out=gx.view(-1, K))
         if ctx.needs_input_grad[1]:
-            if _X3_WGRAD:
+            if _X3_WGRAD and ctx.has_bias and ctx.needs_input_grad[2] and N % 4 == 0:
+                gw, gb = ops.wgrad_x3(g2, x2, want_bias=True)      # the bias gradient from the same pass over grad_output
+            elif _X3_WGRAD:
                 gw = ops.wgrad_x3(g2, x2)              # transpose-read x3 kernel (csrc/wgrad_x3.hip), partial tiles summed in fixed order
             else:
                 S = next((s for s in (32, 16, 8, 4, 2) if M % s == 0 and M // s >= 4096), 1)
                 gw = torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)).sum(0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb
 
@@ -261,7 +263,9 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = derived_cached('x3_conv_image_dgrad', (weight,),
                                 lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
-            gx = ops.conv_x3s_nhwc(ops.x3a_encode(gl), wt, C, 3, 1, 1, None, out_split=False).permute(0, 3, 1, 2)
+            # (contiguous NCHW: a channel-last-strided gradient sent the producer's backward -- the FPN's bilinear up-sample -- down
+            # torch's NHWC kernel, 4.3 ms instead of 1.4)
+            gx = ops.conv_x3s_nhwc(ops.x3a_encode(gl), wt, C, 3, 1, 1, None, out_split=False).permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[1]:
             xp = F.pad(xl, (0, 0, 1, 1, 1, 1)).view(-1, C)               # rows of the (B, H + 2, W + 2) grid
             gp = F.pad(gl, (0, 0, 1, 1, 1, 1)).view(-1, N)

@@ -508,6 +508,10 @@ int cgg_encoder_tail_v2_perm32(int32_t* perm32);
 int64_t cgg_wgrad_x3_workspace_bytes(int M, int N, int K);
 int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, int* splits_out, int M, int N, int K,
                  cgg_stream_t stream);
+/* ... with the bias gradient db[n] = sum_m dy[m][n] (autograd's `grad_output.sum(0)`) from the same pass over dy: ws_bias
+ * (>= splits x N floats, splits = workspace bytes / (4 N K)) receives one partial row per split. */
+int cgg_wgrad_bias_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, float* ws_bias, int* splits_out, int M, int N,
+                      int K, cgg_stream_t stream);
 
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */

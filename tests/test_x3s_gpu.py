@@ -308,6 +308,10 @@ def test_wgrad_x3_vs_float64(dev, M, N, K):
     err = _err(got, want)
     assert err <= 4 * f32_err + 2e-7 * want.abs().max().item(), (err, f32_err)
     assert torch.equal(got, ops.wgrad_x3(dyd, xd))
+    gw2, gb = ops.wgrad_x3(dyd, xd, want_bias=True)                 # bias gradient from the same pass
+    assert torch.equal(gw2, got)
+    wb = dy.double().sum(0)
+    assert _err(gb, wb) <= 4 * (dy.sum(0).double() - wb).abs().max().item() + 1e-6 * dy.abs().double().sum(0).max().item()
 
 
 def test_x3_image_shape_is_checked(dev):
