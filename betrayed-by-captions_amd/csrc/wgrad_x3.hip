@@ -19,34 +19,45 @@ typedef __attribute__((ext_vector_type(4))) uint32_t wg_u32x4;
 typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
 typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
 
-#define WG_RS 320                 // LDS row stride in bytes (128 f16 + 64 B pad)
-#define WG_PLANE (32 * WG_RS)     // one 32-row plane
-
+template <int RS>
 __device__ __forceinline__ wg_u32x4 wg_tr_frag(const unsigned char* plane, int row0, int colbyte) {
   // rows row0 .. row0 + 3 (first half) and row0 + 4 .. row0 + 7 (second half) of this lane's column group
-  const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(plane + row0 * WG_RS + colbyte));
-  const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(plane + (row0 + 4) * WG_RS + colbyte));
+  const wg_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(plane + row0 * RS + colbyte));
+  const wg_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(plane + (row0 + 4) * RS + colbyte));
   const uint2 au = __builtin_bit_cast(uint2, a), bu = __builtin_bit_cast(uint2, b);
   return wg_u32x4{au.x, au.y, bu.x, bu.y};
 }
 
-__global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                                           float* __restrict__ ws, float* __restrict__ ws_bias, int M, int N, int K,
-                                                           int tiles_k, int rows_per_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WG_PLANE];       // Yh | Yl | Xh | Xl
+// Tile BT x BT (128: 2 x 2 waves of 2 x 2 MFMA tiles; 256: 2 x 4 waves of 4 x 2 MFMA tiles -- each operand is then read once per
+// 256 output rows / columns instead of once per 128: the 128-wide tile moved 1.4 GB for a 256 x 256 weight, 5.6 TB/s)
+template <int BT>
+__global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(const float* __restrict__ dy, int ldy,
+                                                                             const float* __restrict__ x, int ldx,
+                                                                             float* __restrict__ ws, float* __restrict__ ws_bias,
+                                                                             int M, int N, int K, int tiles_k, int rows_per_split) {
+  constexpr int NT = BT == 128 ? 256 : 512;           // threads
+  constexpr int WK = BT == 128 ? 2 : 4;               // waves along k (2 along n)
+  constexpr int TA = BT == 128 ? 2 : 4, TB = 2;       // MFMA tiles per wave along n / k
+  constexpr int RS = 2 * BT + 64;                     // LDS row stride in bytes (BT f16 + 64 B pad: four consecutive rows fall into
+                                                      // disjoint bank groups for the transpose reads)
+  constexpr int WG_PLANE = 32 * RS;
+  constexpr int CG = BT / 4;                          // 16-byte column groups per row
+  constexpr int RPI = NT / CG;                        // rows staged per pass (8)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];            // Yh | Yl | Xh | Xl
   unsigned char* Yh = lds;
   unsigned char* Yl = lds + WG_PLANE;
   unsigned char* Xh = lds + 2 * WG_PLANE;
   unsigned char* Xl = lds + 3 * WG_PLANE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave / WK, wk = wave - wn * WK;
   const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
-  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int n0 = tile_n * BT, k0 = tile_k * BT;
   const int m_begin = blockIdx.y * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
 
   // staging: thread = (row r8 + 8 i, 16-byte column group c4) of both tiles
-  const int r8 = tid >> 5, c4 = tid & 31;
+  const int r8 = tid / CG, c4 = tid - r8 * CG;
+  static_assert(RPI == 8, "eight rows per staging pass");
   const int ny = n0 + 4 * c4, kx = k0 + 4 * c4;
   const bool yok = ny < N, xok = kx < K;                  // N, K % 4 == 0: a group is inside or outside
   const float* yp = dy + (yok ? ny : 0);
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
       uint2 h, l;
       if (want_bias && live && yok) bsum += yv[i];
       cgg_x3_split4((live && yok) ? yv[i] : z, h, l);
-      const int o = (r8 + 8 * i) * WG_RS + 8 * c4;
+      const int o = (r8 + 8 * i) * RS + 8 * c4;
       *reinterpret_cast<uint2*>(Yh + o) = h;
       *reinterpret_cast<uint2*>(Yl + o) = l;
       cgg_x3_split4((live && xok) ? xv[i] : z, h, l);
@@ -81,11 +92,11 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TA][TB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -103,19 +114,23 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
     if (m0 + 32 < m_end) load(m0 + 32);    // workgroup-uniform
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      wg_u32x4 ah[2], al[2], bh[2], bl[2];
+      wg_u32x4 ah[TA], al[TA], bh[TB], bl[TB];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int cy = 2 * (wn * 64 + t * 32) + colb, cx = 2 * (wk * 64 + t * 32) + colb;
-        ah[t] = wg_tr_frag(Yh, 16 * s + rowl, cy);
-        al[t] = wg_tr_frag(Yl, 16 * s + rowl, cy);
-        bh[t] = wg_tr_frag(Xh, 16 * s + rowl, cx);
-        bl[t] = wg_tr_frag(Xl, 16 * s + rowl, cx);
+      for (int t = 0; t < TA; ++t) {
+        const int cy = 2 * (wn * 32 * TA + t * 32) + colb;
+        ah[t] = wg_tr_frag<RS>(Yh, 16 * s + rowl, cy);
+        al[t] = wg_tr_frag<RS>(Yl, 16 * s + rowl, cy);
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int t = 0; t < TB; ++t) {
+        const int cx = 2 * (wk * 32 * TB + t * 32) + colb;
+        bh[t] = wg_tr_frag<RS>(Xh, 16 * s + rowl, cx);
+        bl[t] = wg_tr_frag<RS>(Xl, 16 * s + rowl, cx);
+      }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) cgg_x3_mfma(acc[a][b], ah[a], al[a], bh[b], bl[b]);
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) cgg_x3_mfma(acc[a][b], ah[a], al[a], bh[b], bl[b]);
     }
   }
 
@@ -125,10 +140,10 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
     f32x4* red = reinterpret_cast<f32x4*>(lds);
     red[tid] = bsum;
     __syncthreads();
-    if (tid < 32) {
+    if (tid < CG) {
       f32x4 t = red[tid];
 #pragma unroll
-      for (int r = 1; r < 8; ++r) t += red[tid + 32 * r];
+      for (int r = 1; r < 8; ++r) t += red[tid + CG * r];
       const int n = n0 + 4 * tid;
       if (n < N) *reinterpret_cast<f32x4*>(ws_bias + (size_t)blockIdx.y * N + n) = t;
     }
@@ -137,22 +152,26 @@ __global__ __launch_bounds__(256) void cgg_wgrad_x3_kernel(const float* __restri
   const int j = lane & 31, hi5 = lane >> 5;
   float* wsp = ws + (size_t)blockIdx.y * N * K;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int kc = k0 + wk * 64 + b * 32 + j;
+    for (int b = 0; b < TB; ++b) {
+      const int kc = k0 + wk * 32 * TB + b * 32 + j;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + a * 32 + 8 * (r >> 2) + 4 * hi5 + (r & 3);
+        const int n = n0 + wn * 32 * TA + a * 32 + 8 * (r >> 2) + 4 * hi5 + (r & 3);
         if (n < N && kc < K) wsp[(size_t)n * K + kc] = acc[a][b][r] * (1.f / 256.f);
       }
     }
 }
 
-// rows per split and number of splits for (M, N, K): ~1024 workgroups, row ranges multiples of 32
+// tile edge: 256 when both extents are multiples of it (every operand byte is then read by half as many workgroups)
+static int wgrad_tile(int N, int K) { return (N % 256 == 0 && K % 256 == 0) ? 256 : 128; }
+
+// rows per split and number of splits for (M, N, K): ~1024 workgroups of 4 waves / ~512 of 8, row ranges multiples of 32
 static void wgrad_plan(int M, int N, int K, int* splits, int* rows_per_split) {
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int sp = (1024 + tiles - 1) / tiles;
+  const int bt = wgrad_tile(N, K);
+  const int tiles = ((N + bt - 1) / bt) * ((K + bt - 1) / bt);
+  int sp = ((bt == 128 ? 1024 : 512) + tiles - 1) / tiles;
   const int max_sp = (M + 255) / 256;                  // at least 256 rows per split
   if (sp > max_sp) sp = max_sp;
   if (sp < 1) sp = 1;
@@ -180,9 +199,24 @@ static int wgrad_launch(const float* dy, int ldy, const float* x, int ldx, float
   int sp, rps;
   wgrad_plan(M, N, K, &sp, &rps);
   *splits_out = sp;
-  const int tiles_k = (K + 127) / 128, tiles_n = (N + 127) / 128;
-  hipLaunchKernelGGL(cgg_wgrad_x3_kernel, dim3(tiles_n * tiles_k, sp), dim3(256), 0, (hipStream_t)stream, dy, ldy, x, ldx, ws, ws_bias, M,
-                     N, K, tiles_k, rps);
+  const int bt = wgrad_tile(N, K);
+  const int tiles_k = (K + bt - 1) / bt, tiles_n = (N + bt - 1) / bt;
+  if (bt == 128) {
+    hipLaunchKernelGGL(cgg_wgrad_x3_kernel<128>, dim3(tiles_n * tiles_k, sp), dim3(256), 4 * 32 * (2 * 128 + 64), (hipStream_t)stream, dy,
+                       ldy, x, ldx, ws, ws_bias, M, N, K, tiles_k, rps);
+  } else {
+    const int lds = 4 * 32 * (2 * 256 + 64);           // 72 KiB: above the default dynamic-LDS limit
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute((const void*)cgg_wgrad_x3_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_wgrad_x3: cannot raise dynamic LDS to %d", lds);
+      if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(cgg_wgrad_x3_kernel<256>, dim3(tiles_n * tiles_k, sp), dim3(512), lds, (hipStream_t)stream, dy, ldy, x, ldx, ws,
+                       ws_bias, M, N, K, tiles_k, rps);
+  }
   CGG_CHECK_LAUNCH("cgg_wgrad_x3");
   return CGG_OK;
 }
