@@ -24,7 +24,9 @@ for _ in range(2): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if 'conv' in e.key.lower()]
+import sys as _s
+pat = _s.argv[1].split(',') if len(_s.argv) > 1 else ['conv']
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if any(p_ in e.key.lower() for p_ in pat)]
 rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:25]:
     print(f'{e.key[:44]:44s} n={e.count:3d} dev {e.device_time_total / 1e3:8.2f} ms  {str(e.input_shapes)[:150]}')
