@@ -97,6 +97,7 @@ PROTOTYPES = {
     'cgg_wgrad_x3_workspace_bytes': (_c_i64, [_c_int] * 3),
     'cgg_wgrad_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_wgrad_bias_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
+    'cgg_transpose_f32': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
     'cgg_msda_prologue': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),

@@ -265,3 +265,66 @@ extern "C" int cgg_subsample_nhwc(const void* x, void* y, int B, int H, int W, i
   CGG_CHECK_LAUNCH("cgg_subsample_nhwc");
   return 0;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Batched 2-D transpose of f32 matrices, in (B, R, C) -> out (B, C, R): the NCHW <-> NHWC layout changes around the x3 training
+// convolution (runtime._X3Conv3x3Fn; torch's strided copy ran them at ~2 TB/s: 1.1 ms per 1-GB map, eight of them per step at
+// configs[2]). 64 x 64 tiles through LDS (row stride 65 floats: conflict-free column reads), 256 threads, 16-byte global accesses on
+// both sides when R and C are multiples of 4 (scalar edge path otherwise).
+__global__ __launch_bounds__(256) void cgg_transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
+                                                                int tiles_c, int tiles_r) {
+  __shared__ float tile[64][65];
+  const int t = threadIdx.x;
+  const int bid = blockIdx.x;
+  const int b = bid / (tiles_c * tiles_r);
+  const int rem = bid - b * tiles_c * tiles_r;
+  const int tr = rem / tiles_c, tc = rem - tr * tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const float* ib = in + (size_t)b * R * C;
+  float* ob = out + (size_t)b * R * C;
+  const bool vec = (R % 4 == 0) && (C % 4 == 0);
+  // load: thread -> (row t / 16 + 16 i, 4 columns 4 (t % 16))
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (t >> 4) + 16 * i, c = 4 * (t & 15);
+    const int gr = r0 + r, gc = c0 + c;
+    if (vec) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr < R && gc < C) v = *reinterpret_cast<const f32x4*>(ib + (size_t)gr * C + gc);
+      tile[r][c] = v[0];
+      tile[r][c + 1] = v[1];
+      tile[r][c + 2] = v[2];
+      tile[r][c + 3] = v[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[r][c + e] = (gr < R && gc + e < C) ? ib[(size_t)gr * C + gc + e] : 0.f;
+    }
+  }
+  __syncthreads();
+  // store: thread -> (output row = input column t / 16 + 16 i, 4 output columns = input rows 4 (t % 16))
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (t >> 4) + 16 * i, r = 4 * (t & 15);
+    const int gc = c0 + c, gr = r0 + r;
+    if (gc >= C) continue;
+    if (vec) {
+      if (gr < R) *reinterpret_cast<f32x4*>(ob + (size_t)gc * R + gr) = f32x4{tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gr + e < R) ob[(size_t)gc * R + gr + e] = tile[r + e][c];
+    }
+  }
+}
+
+extern "C" int cgg_transpose_f32(const float* in, float* out, int B, int R, int C, cgg_stream_t stream) {
+  CGG_REQUIRE(in && out, CGG_EINVAL, "cgg_transpose_f32: null pointer");
+  CGG_REQUIRE(B > 0 && R > 0 && C > 0, CGG_EINVAL, "cgg_transpose_f32: bad sizes");
+  CGG_REQUIRE(cgg_aligned16(in) && cgg_aligned16(out), CGG_EALIGN, "cgg_transpose_f32: 16-B alignment");
+  const int tiles_c = (C + 63) / 64, tiles_r = (R + 63) / 64;
+  const long long nb = (long long)B * tiles_c * tiles_r;
+  CGG_REQUIRE(nb < (1ll << 31), CGG_EUNSUPPORTED, "cgg_transpose_f32: too many tiles");
+  hipLaunchKernelGGL(cgg_transpose_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, R, C, tiles_c, tiles_r);
+  CGG_CHECK_LAUNCH("cgg_transpose_f32");
+  return CGG_OK;
+}

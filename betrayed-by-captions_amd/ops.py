@@ -1201,6 +1201,31 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     return y, yp
 
 
+def transpose_f32(x):
+    """x (B, R, C) contiguous f32 -> (B, C, R) contiguous (csrc/epilogue.hip: tiled through LDS); `nchw_to_nhwc` / `nhwc_to_nchw`
+    are this on the (B, C, H W) / (B, H W, C) views."""
+    if x.dim() != 3 or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda:
+        raise CggError('transpose_f32: contiguous (B, R, C) float32 ROCm tensor expected')
+    B, R, C = x.shape
+    y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    check(_lib_().cgg_transpose_f32(dev_ptr(x), dev_ptr(y), B, R, C, stream_ptr(x.device)), 'cgg_transpose_f32')
+    return y
+
+
+def nchw_to_nhwc(x):
+    """(B, C, H, W) f32 (any strides) -> (B, H, W, C) contiguous."""
+    B, C, H, W = x.shape
+    if x.permute(0, 2, 3, 1).is_contiguous():
+        return x.permute(0, 2, 3, 1)
+    return transpose_f32(x.contiguous().view(B, C, H * W)).view(B, H, W, C)
+
+
+def nhwc_to_nchw(x):
+    """(B, H, W, C) contiguous f32 -> (B, C, H, W) contiguous."""
+    B, H, W, C = x.shape
+    return transpose_f32(x.view(B, H * W, C)).view(B, C, H, W)
+
+
 def wgrad_x3(dy, x, want_bias=False):
     """dW (N, K) = dy^T x for dy (M, N), x (M, K) f32 rows (contiguous last dim, row strides % 4 == 0; N, K % 4 == 0) on the
     f32-class f16 x 3 contraction with transpose reads (csrc/wgrad_x3.hip): the weight gradient of a linear layer.

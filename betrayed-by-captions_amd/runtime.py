@@ -245,11 +245,11 @@ class _X3Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x, weight):
         from . import ops
         N = weight.shape[0]
-        xl = x.detach().permute(0, 2, 3, 1).contiguous()
+        xl = ops.nchw_to_nhwc(x.detach())                # tiled transpose (torch's strided copy: ~2 TB/s)
         wk = derived_cached('x3_conv_image', (weight,), lambda: ops.pack_conv_weight_x3(weight))
         y = ops.conv_x3s_nhwc(ops.x3a_encode(xl), wk, N, 3, 1, 1, None, out_split=False)
         ctx.save_for_backward(xl, weight)
-        return y.permute(0, 3, 1, 2)                     # NCHW view of the channel-last result
+        return ops.nhwc_to_nchw(y)                       # contiguous NCHW: what the GroupNorm behind it wants
 
     @staticmethod
     def backward(ctx, gy):
@@ -258,14 +258,14 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         xl, weight = ctx.saved_tensors
         B, H, W, C = xl.shape
         N = weight.shape[0]
-        gl = gy.permute(0, 2, 3, 1).contiguous()
+        gl = ops.nchw_to_nhwc(gy)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             wt = derived_cached('x3_conv_image_dgrad', (weight,),
                                 lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
             # (contiguous NCHW: a channel-last-strided gradient sent the producer's backward -- the FPN's bilinear up-sample -- down
             # torch's NHWC kernel, 4.3 ms instead of 1.4)
-            gx = ops.conv_x3s_nhwc(ops.x3a_encode(gl), wt, C, 3, 1, 1, None, out_split=False).permute(0, 3, 1, 2).contiguous()
+            gx = ops.nhwc_to_nchw(ops.conv_x3s_nhwc(ops.x3a_encode(gl), wt, C, 3, 1, 1, None, out_split=False))
         if ctx.needs_input_grad[1]:
             xp = F.pad(xl, (0, 0, 1, 1, 1, 1)).view(-1, C)               # rows of the (B, H + 2, W + 2) grid
             gp = F.pad(gl, (0, 0, 1, 1, 1, 1)).view(-1, N)

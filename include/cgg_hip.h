@@ -500,6 +500,10 @@ int cgg_encoder_layer_tail_x3a_v2(const float* a32, const void* x_x3a, const voi
                                   int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
 int cgg_encoder_tail_v2_perm32(int32_t* perm32);
 
+/* Batched transpose of f32 matrices, in (B, R, C) -> out (B, C, R): the NCHW <-> NHWC layout changes around the x3 kernels under
+ * autograd (torch `x.permute(0, 2, 3, 1).contiguous()` and back), 64 x 64 tiles through LDS. */
+int cgg_transpose_f32(const float* in, float* out, int B, int R, int C, cgg_stream_t stream);
+
 /* Training in parity mode: the weight gradient of a linear layer, dW[n][k] = sum_m dy[m][n] x[m][k] -- autograd's
  * `grad_output.t() @ input` behind the F.linear calls of the [3P] MSDeformAttn encoder layers (mask2former_head.py:787) -- on the
  * f32-class f16 x 3 contraction; both row-major operands reach the MFMA through LDS transpose reads (csrc/wgrad_x3.hip). ws

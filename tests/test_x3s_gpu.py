@@ -356,3 +356,16 @@ def test_x3_training_conv3x3_forward_and_gradients_vs_float64(dev, B, C, N, H, W
     scale = (y64.abs().max().item(), x64.grad.abs().max().item(), w64.grad.abs().max().item())
     for e, r, s in zip(got, ref_err, scale):
         assert e <= 4 * r + 3e-7 * s, (got, ref_err, scale)
+
+
+@pytest.mark.parametrize('B,R,C', [(2, 256, 4096), (3, 70, 129), (1, 64, 64), (2, 5, 1000), (16, 256, 1024)])
+def test_transpose_f32_is_exact(dev, B, R, C):
+    """cgg_transpose_f32 (the NCHW <-> NHWC layout changes around the x3 training convolution): bit-exact, ragged tiles, the scalar
+    edge path (R or C not a multiple of 4)."""
+    x = torch.randn(B, R, C, device=dev)
+    assert torch.equal(ops.transpose_f32(x), x.transpose(1, 2).contiguous())
+    if C % 16 == 0:                                      # the (B, C, H, W) <-> (B, H, W, C) wrappers on the same data
+        nchw = x.view(B, R, 16, C // 16)
+        nhwc = ops.nchw_to_nhwc(nchw)
+        assert torch.equal(nhwc, nchw.permute(0, 2, 3, 1).contiguous())
+        assert torch.equal(ops.nhwc_to_nchw(nhwc), nchw)
