@@ -85,19 +85,21 @@ PROTOTYPES = {
     'cgg_x3a_encode': (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_x3a_decode': (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_x3_overflow_check': (_c_int, [_c_int, _c_vp, _c_vp]),
-    'cgg_gemm_x3s_force_config': (None, [_c_int]),
+    'cgg_gemm_x3s_cfg': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int] + [_c_int] * 5 + [_c_vp]),
+    'cgg_conv_x3s_nhwc_cfg': (_c_int, [_c_vp] * 4 + [_c_int, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp]),
     'cgg_bias_relu_maxpool_nhwc_f32_x3a': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_group_norm_nhwc_f32_x3a': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int, _c_vp,
                                              _c_i64, _c_vp, _c_vp, _c_vp]),
     'cgg_encoder_layer_tail_x3a': (_c_int, [_c_vp] * 6 + [_c_f] + [_c_vp] * 6 + [_c_f, _c_vp, _c_int, _c_vp, _c_vp] +
                                    [_c_int] * 3 + [_c_vp]),
-    'cgg_encoder_layer_tail_x3a_v2': (_c_int, [_c_vp] * 6 + [_c_f] + [_c_vp] * 6 + [_c_f, _c_vp, _c_int, _c_vp, _c_vp] +
-                                      [_c_int] * 3 + [_c_vp]),
-    'cgg_encoder_tail_v2_perm32': (_c_int, [_c_vp]),
     'cgg_wgrad_x3_workspace_bytes': (_c_i64, [_c_int] * 3),
     'cgg_wgrad_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_wgrad_bias_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_transpose_f32': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    'cgg_absmax_f32': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    'cgg_gemm_x3_scaled': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 4 + [_c_vp]),
+    'cgg_conv_x3_nhwc_scaled': (_c_int, [_c_vp] * 6 + [_c_int] * 10 + [_c_vp]),
+    'cgg_wgrad_x3_scaled': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_layernorm_chain': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                      _c_vp, _c_int, _c_int, _c_int, _c_i64, _c_vp]),
     'cgg_msda_prologue': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),

@@ -86,6 +86,9 @@ class ResNet(nn.Module):
         self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
         self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
         self.init_cfg = init_cfg
+        # parity-mode inference: hand the maps over as x3a rows (`ops.X3ATensor`, csrc/x3.h) instead of plain float32. OFF by
+        # default -- only a consumer that reads x3a (the detector, when its head's pixel decoder does) switches it on
+        self.x3a_outputs = False
         stem = stem_channels or base_channels
         self.conv1 = nn.Conv2d(in_channels, stem, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(stem)
@@ -397,8 +400,12 @@ class ResNet(nn.Module):
         # (B, C, H, W)-shaped views of the channel-last f32 activations (no copy): the pixel decoder's parity-mode stream reads
         # them as they are; anything else can `.contiguous()` them. Round 4: the maps are x3a rows, tagged `ops.X3ATensor` -- the
         # pixel decoder's x3 GEMMs consume them as stored, `ops.x3a_to_f32` gives the values
-        if x3a:
+        if x3a and self.x3a_outputs:
             return tuple(ops.as_x3a(o.permute(0, 3, 1, 2)) for o in outs)
+        if x3a:
+            # module boundary: a caller that has not opted in gets plain float32 values -- x3a storage holds f16 pairs,
+            # arithmetic on the raw tensor would be garbage without an error
+            return tuple(ops.x3a_decode(o).permute(0, 3, 1, 2) for o in outs)
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
 
     def forward(self, x):

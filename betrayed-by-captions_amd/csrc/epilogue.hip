@@ -328,3 +328,50 @@ extern "C" int cgg_transpose_f32(const float* in, float* out, int B, int R, int 
   CGG_CHECK_LAUNCH("cgg_transpose_f32");
   return CGG_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// max |x| over an (M, N) f32 matrix (row stride ld) -> *amax (device scalar): the per-tensor pre-scale of the f32-class x3
+// contractions' grad_output operands (x3.h "per-tensor pre-scale"; runtime._X3LinearFn.backward / _X3Conv3x3Fn.backward: autograd's
+// grad_output behind the F.linear / conv calls of open_set/models/mask2former_head.py:787). One streaming pass, 16-byte loads,
+// wave max by DPP-free shuffles, one u32 atomicMax per wave (|x| as a bit pattern is monotone; a NaN compares above inf and
+// selects the default scale downstream).
+__global__ __launch_bounds__(256) void cgg_absmax_f32_kernel(const float* __restrict__ x, long long ld4, long long n4_per_row,
+                                                             long long total4, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  const f32x4* xv = reinterpret_cast<const f32x4*>(x);
+  const bool dense = ld4 == n4_per_row;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < total4; u += (long long)gridDim.x * 256) {
+    long long off = u;
+    if (!dense) {
+      const long long r = u / n4_per_row;
+      off = r * ld4 + (u - r * n4_per_row);
+    }
+    const f32x4 v = xv[off];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t b = __builtin_bit_cast(uint32_t, v[k]) & 0x7fffffffu;
+      m = b > m ? b : m;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, s, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+extern "C" int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax, cgg_stream_t stream) {
+  CGG_REQUIRE(x && amax, CGG_EINVAL, "cgg_absmax_f32: null pointer");
+  CGG_REQUIRE(M > 0 && N > 0 && ld >= N, CGG_EINVAL, "cgg_absmax_f32: bad sizes");
+  CGG_REQUIRE(N % 4 == 0 && ld % 4 == 0 && cgg_aligned16(x), CGG_EUNSUPPORTED, "cgg_absmax_f32: N, ld %% 4 and 16-B alignment");
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
+  CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_absmax_f32: memset failed");
+  const long long total4 = (long long)M * (N / 4);
+  long long nb = (total4 + 256 * 8 - 1) / (256 * 8);
+  nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
+  hipLaunchKernelGGL(cgg_absmax_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)(ld / 4),
+                     (long long)(N / 4), total4, reinterpret_cast<uint32_t*>(amax));
+  CGG_CHECK_LAUNCH("cgg_absmax_f32");
+  return CGG_OK;
+}

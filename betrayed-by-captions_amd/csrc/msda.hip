@@ -1103,6 +1103,14 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
     // share a (8 + 2 r)^2 window of 128-B lines that a 16-wave CU keeps in its L1; the kernel stays L2-request bound (every tap
     // of the first toucher is a 128-B request), <= 80 us is out of reach for f32 values.
     bool t2d = Nq == Nv && Nq % 16 == 0;
+    // the 2-D mappings rebuild q as start[l] + tile arithmetic: the levels must tile [0, Nq) in ascending order without gaps
+    // (msda_read_levels only checks st + h w <= Nv; a gapped / reordered table would compute some queries twice and skip others)
+    long long expect = 0;
+    for (int l = 0; l < L && t2d; ++l) {
+      t2d = lv.start[l] == expect;
+      expect += (long long)lv.h[l] * lv.w[l];
+    }
+    t2d = t2d && expect == Nq;
     for (int l = 0; l < L && t2d; ++l) t2d = lv.w[l] % 4 == 0 && lv.h[l] % 4 == 0 && lv.start[l] % 16 == 0;
     bool t8 = t2d && Nq % 64 == 0;
     for (int l = 0; l < L && t8; ++l) t8 = lv.w[l] % 8 == 0 && lv.h[l] % 8 == 0 && lv.start[l] % 64 == 0;

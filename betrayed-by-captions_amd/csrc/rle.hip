@@ -23,6 +23,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -146,17 +147,30 @@ class RlePool {
     job->f = &f;
     {
       std::lock_guard<std::mutex> g(m_);
+      if (owner_pid_ != getpid()) {                   // a forked child inherits `workers_` but none of the threads: start over
+        workers_.clear();
+        queue_.clear();
+        owner_pid_ = getpid();
+      }
       grow(helpers);
       const int k = helpers < (int)workers_.size() ? helpers : (int)workers_.size();
-      job->pending.store(k);
-      for (int i = 0; i < k; ++i)
-        queue_.push_back([job]() {
-          (*job->f)();
-          if (job->pending.fetch_sub(1) == 1) {
-            std::lock_guard<std::mutex> g2(job->m);
-            job->cv.notify_all();
-          }
-        });
+      // `pending` counts the tasks that were actually queued: a push_back that throws (bad_alloc) leaves the ones queued so far
+      // valid (they hold `job` by shared_ptr and f outlives them: this function does not return before pending == 0)
+      for (int i = 0; i < k; ++i) {
+        try {
+          job->pending.fetch_add(1);
+          queue_.push_back([job]() {
+            (*job->f)();
+            if (job->pending.fetch_sub(1) == 1) {
+              std::lock_guard<std::mutex> g2(job->m);
+              job->cv.notify_all();
+            }
+          });
+        } catch (...) {
+          job->pending.fetch_sub(1);
+          break;
+        }
+      }
     }
     cv_.notify_all();
     f();                                              // the caller works too
@@ -191,6 +205,7 @@ class RlePool {
   std::condition_variable cv_;
   std::deque<std::function<void()>> queue_;
   std::vector<std::thread> workers_;
+  pid_t owner_pid_ = getpid();
 };
 
 RlePool& rle_pool() {
@@ -230,6 +245,10 @@ extern "C" int64_t cgg_rle_encode_bitmasks(const uint8_t* bits, int n, int H, in
     work();
   } else {
     rle_pool().run(threads - 1, work);
+  }
+  if (failed.load()) {                    // (dropped with the move to the pool in round 4: a failed mask came back as an empty RLE)
+    cgg_set_error("cgg_rle_encode_bitmasks: encoding failed (allocation failure inside a worker)");
+    return -(int64_t)CGG_EINVAL;
   }
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {

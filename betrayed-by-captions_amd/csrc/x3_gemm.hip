@@ -40,8 +40,12 @@ template <bool CONV, int TM, int TN>
 __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4) void cgg_gemm_x3_kernel(
     const float* __restrict__ A, int lda, const CggX3W w, const float* __restrict__ bias, const float* __restrict__ res, int ldr,
     float* __restrict__ out, int ldc, int M, int N, int K, int relu, int tiles_n, int n_tiles32, XgConv cv, uint32_t a_bytes,
-    uint32_t w_bytes, int res_mod, float* __restrict__ out2, int ldc2, int col2) {
+    uint32_t w_bytes, int res_mod, float* __restrict__ out2, int ldc2, int col2, const float* __restrict__ a_amax) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
+  // A pre-scale: 2^4 (activations) or, when the caller hands the tensor's max |value| (device scalar), the power of two that puts
+  // it near 2^9 (grad_output operands: x3.h "per-tensor pre-scale"); the epilogue un-scales by 16 / sa on top of colscale
+  const float sa = a_amax ? cgg_x3_scale_from_amax(*a_amax) : CGG_X3_ASCALE;
+  const float unsa = CGG_X3_ASCALE / sa;
   constexpr int A_SLOTS = 2 * TM * 2 * 64;                 // one piece of the A stage: [2 TM m-tiles][2 k-steps][64 lanes] x 16 B
   constexpr int B_SLOTS = 2 * TN * 2 * 64;
   constexpr int STAGE = 2 * (A_SLOTS + B_SLOTS);           // A hi | A lo | B hi | B lo
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       u32x4 h, l;
-      cgg_x3_split8(__builtin_bit_cast(f32x4, av[i][0]), __builtin_bit_cast(f32x4, av[i][1]), h, l);
+      cgg_x3_split8_s(__builtin_bit_cast(f32x4, av[i][0]), __builtin_bit_cast(f32x4, av[i][1]), sa, h, l);
       s[aslot[i]] = h;
       s[A_SLOTS + aslot[i]] = l;
     }
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
   for (int nt = 0; nt < TN; ++nt) {
     const int n = (nt0 + TN * wn + nt) * 32 + j;
     const bool nok = full || n < N;
-    const float cs = nok ? w.scale[n] : 0.f;
+    const float cs = nok ? w.scale[n] * unsa : 0.f;
     const float bs = (nok && bias) ? bias[n] : 0.f;
     // columns from col2 on (a multiple of 32: uniform per n-tile) go to the second output
     const bool second = out2 != nullptr && n >= col2;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
 
 static int xg_launch(bool conv, const char* who, const float* a, int lda, const void* w_x3, const float* bias, const float* res,
                      int ldr, float* out, int ldc, int M, int N, int K, int relu, const XgConv& cv, cgg_stream_t stream,
-                     int res_mod = 0, float* out2 = nullptr, int ldc2 = 0, int col2 = 0) {
+                     int res_mod = 0, float* out2 = nullptr, int ldc2 = 0, int col2 = 0, const float* a_amax = nullptr) {
   CGG_REQUIRE(a && w_x3 && out, CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "%s: bad sizes", who);
   CGG_REQUIRE(K % XG_BK == 0, CGG_EUNSUPPORTED, "%s: K=%d must be a multiple of %d", who, K, XG_BK);
@@ -306,7 +310,7 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   const uint32_t w_bytes = (uint32_t)(2ull * ((N + 31) / 32) * (K / 16) * 64 * 16);
 #define XG_GO(CONV, TM, TN)                                                                                                   \
   hipLaunchKernelGGL((cgg_gemm_x3_kernel<CONV, TM, TN>), grid, block, 0, (hipStream_t)stream, a, lda, w, bias, res, ldr, out, ldc, \
-                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes, res_mod, out2, ldc2, col2)
+                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes, res_mod, out2, ldc2, col2, a_amax)
 #define XG_PICK(CONV)                    \
   do {                                   \
     if (tm == 2 && tn == 2) XG_GO(CONV, 2, 2); \
@@ -347,4 +351,27 @@ extern "C" int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* b
   CGG_REQUIRE(OH > 0 && OW > 0, CGG_EINVAL, "cgg_conv_x3_nhwc: empty output");
   const XgConv cv = {H, W, C, OH, OW, KW, stride, pad};
   return xg_launch(true, "cgg_conv_x3_nhwc", x, 0, w_x3, bias, res, N, out, N, B * OH * OW, N, KH * KW * C, relu, cv, stream);
+}
+
+// ... with the A operand pre-scaled per TENSOR: a_amax = device scalar holding max |a| (cgg_absmax_f32), nullable = the fixed 2^4.
+// For operands that are not unit scale -- grad_output of the training linears / convolutions (x3.h "per-tensor pre-scale").
+extern "C" int cgg_gemm_x3_scaled(const float* a, int lda, const float* a_amax, const void* w_x3, const float* bias, const float* res,
+                                  int ldr, float* out, int ldc, int M, int N, int K, int relu, cgg_stream_t stream) {
+  const XgConv cv = {0, 0, 0, 0, 0, 0, 0, 0};
+  CGG_REQUIRE(lda >= K, CGG_EINVAL, "cgg_gemm_x3_scaled: lda=%d < K", lda);
+  return xg_launch(false, "cgg_gemm_x3_scaled", a, lda, w_x3, bias, res, ldr, out, ldc, M, N, K, relu, cv, stream, 0, nullptr, 0, 0,
+                   a_amax);
+}
+
+extern "C" int cgg_conv_x3_nhwc_scaled(const float* x, const float* x_amax, const void* w_x3, const float* bias, const float* res,
+                                       float* out, int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu,
+                                       cgg_stream_t stream) {
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, CGG_EINVAL,
+              "cgg_conv_x3_nhwc_scaled: bad sizes");
+  CGG_REQUIRE(C % XG_BK == 0, CGG_EUNSUPPORTED, "cgg_conv_x3_nhwc_scaled: C=%d must be a multiple of %d", C, XG_BK);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  CGG_REQUIRE(OH > 0 && OW > 0, CGG_EINVAL, "cgg_conv_x3_nhwc_scaled: empty output");
+  const XgConv cv = {H, W, C, OH, OW, KW, stride, pad};
+  return xg_launch(true, "cgg_conv_x3_nhwc_scaled", x, 0, w_x3, bias, res, N, out, N, B * OH * OW, N, KH * KW * C, relu, cv, stream, 0,
+                   nullptr, 0, 0, x_amax);
 }

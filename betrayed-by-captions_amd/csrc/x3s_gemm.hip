@@ -48,7 +48,6 @@ struct XsArgs {
   XsConv cv;
   uint32_t a_bytes, w_bytes;
   int* flag;                      // overflow flag word (x3a output)
-  int ablate;                     // measurement only (cgg_gemm_x3s_force_config >= 100): 1 = no DMA in the loop, 2 = no MFMAs
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xs_rsrc(const void* p, uint32_t bytes) {
@@ -465,11 +464,9 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void cgg_gemm_x3s_kernel(const X
   for (int it = 0; it < niter; ++it) {
     xs_wait_vmcnt<WAIT>();
     xs_barrier();
-    if (p.ablate != 1) {
-      issue_b();
-      issue_a();
-    }
-    if (p.ablate != 2 && (KG == 1 || KG * it + kg < nchunk)) compute(abase + a_rd * A_SLOT, bbase + b_rd * B_SLOT);
+    issue_b();
+    issue_a();
+    if (KG == 1 || KG * it + kg < nchunk) compute(abase + a_rd * A_SLOT, bbase + b_rd * B_SLOT);
     a_rd = a_rd + 1 == SA ? 0 : a_rd + 1;
     b_rd = b_rd + 1 == SB ? 0 : b_rd + 1;
   }
@@ -510,11 +507,8 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void cgg_gemm_x3s_kernel(const X
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
-static int g_xs_force_cfg = -1, g_xs_ablate = 0;
-extern "C" void cgg_gemm_x3s_force_config(int cfg) {      // cfg + 100 a: ablation a (1 = no DMA in the loop, 2 = no MFMAs); results are garbage
-  g_xs_ablate = cfg >= 100 ? cfg / 100 : 0;
-  g_xs_force_cfg = cfg >= 100 ? cfg % 100 : cfg;
-}
+// (round 5: the tile configuration of a call is an ARGUMENT of the *_cfg entry points -- no process-global override, no
+// measurement-only branches in the production loop; the library keeps no mutable state besides the per-device overflow flag word)
 
 // the device-side overflow flag of the x3a producers (one word per process and device, zeroed at creation; read by
 // cgg_x3_overflow_check)
@@ -583,7 +577,6 @@ static const int xs_bn[XS_NCFG] = {256, 128, 256, 128, 128, 128, 64, 64, 64, 256
 // tiles and a shallow K -> small tiles with 2 ring slots (memory-bound: several workgroups per CU overlap load / store phases);
 // the 256 x 256 tile only where the contraction is MFMA-bound (K >= 1024 with >= 1024 tiles: the FPN's 3 x 3 convolution).
 static int xs_pick(int M, int N, int K, bool has_res) {
-  if (g_xs_force_cfg >= 0 && g_xs_force_cfg < XS_NCFG) return g_xs_force_cfg;
   const long long t = (long long)((M + 127) / 128) * ((N + 127) / 128);
   // column tile by padding waste (N = 288: 5 x 64 wastes 11 %, 3 x 128 33 %); the wider tile on ties
   const int w64 = (N + 63) / 64 * 64, w128 = (N + 127) / 128 * 128;
@@ -604,7 +597,7 @@ static int xs_pick(int M, int N, int K, bool has_res) {
 
 static int xs_launch(bool conv, const char* who, const void* a, int lda, const void* w_x3, const float* bias, const void* res, int ldr,
                      int res_fmt, int res_mod, void* out, int ldc, int out_fmt, int M, int N, int K, int relu, const XsConv& cv,
-                     cgg_stream_t stream, int a_rpb = 0, int64_t a_bstride = 0) {
+                     cgg_stream_t stream, int a_rpb = 0, int64_t a_bstride = 0, int force_cfg = -1) {
   CGG_REQUIRE(a && w_x3 && out, CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(a_rpb >= 0 && (a_rpb == 0 || (!conv && a_bstride >= (int64_t)(a_rpb - 1) * lda + K && a_bstride % 8 == 0)), CGG_EINVAL,
               "%s: bad batched A (rows per image %d, image stride %lld)", who, a_rpb, (long long)a_bstride);
@@ -652,27 +645,8 @@ static int xs_launch(bool conv, const char* who, const void* a, int lda, const v
   x.a_bytes = (uint32_t)a_bytes;
   x.w_bytes = (uint32_t)(2ull * ((N + 31) / 32) * (K / 16) * 64 * 16);
   x.flag = out_fmt == 2 ? cgg_x3_overflow_flag_ptr() : nullptr;
-  x.ablate = g_xs_ablate;
-  int cfg = xs_pick(M, N, K, res != nullptr);
-  {
-    // measurement aid: CGG_XS_MAP="13:7,14:6" re-maps picked configurations (in-graph A/B of ring depths / tile shapes)
-    static int remap[XS_NCFG];
-    static bool init = false;
-    if (!init) {
-      for (int i = 0; i < XS_NCFG; ++i) remap[i] = i;
-      if (const char* e = getenv("CGG_XS_MAP")) {
-        int a, b, n = 0;
-        while (sscanf(e, "%d:%d%n", &a, &b, &n) == 2) {
-          if (a >= 0 && a < XS_NCFG && b >= 0 && b < XS_NCFG) remap[a] = b;
-          e += n;
-          if (*e == ',') ++e;
-          else break;
-        }
-      }
-      init = true;
-    }
-    if (g_xs_force_cfg < 0) cfg = remap[cfg];
-  }
+  CGG_REQUIRE(force_cfg < XS_NCFG, CGG_EINVAL, "%s: tile configuration %d (0 .. %d, or -1 = by shape)", who, force_cfg, XS_NCFG - 1);
+  const int cfg = force_cfg >= 0 ? force_cfg : xs_pick(M, N, K, res != nullptr);
   int rc = CGG_OK;
 #define XS_CASE(ID, TM, TN, WM, WN, KG, SA, SB)                                                 \
   case ID:                                                                                      \
@@ -694,6 +668,17 @@ extern "C" int cgg_gemm_x3s(const void* a_x3a, int lda, const void* w_x3, const 
                    stream);
 }
 
+// ... with the tile configuration chosen by the caller (0 .. 17; -1 = by shape): tests sweep every instantiation, benches compare
+// them -- an argument, not process state
+extern "C" int cgg_gemm_x3s_cfg(const void* a_x3a, int lda, const void* w_x3, const float* bias, const void* res, int ldr, int res_fmt,
+                                int res_mod, void* out, int ldc, int out_fmt, int M, int N, int K, int relu, int cfg,
+                                cgg_stream_t stream) {
+  const XsConv cv = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  CGG_REQUIRE(lda >= K, CGG_EINVAL, "cgg_gemm_x3s_cfg: lda=%d < K", lda);
+  return xs_launch(false, "cgg_gemm_x3s_cfg", a_x3a, lda, w_x3, bias, res, ldr, res_fmt, res_mod, out, ldc, out_fmt, M, N, K, relu, cv,
+                   stream, 0, 0, cfg);
+}
+
 // A = a stack of images: row m is row m % rows_per_image of image m / rows_per_image (image stride a_bstride elements) -- the
 // (B, N, C) encoder memory read one level at a time without a copy, the row-periodic residual (res_mod = rows_per_image) being the
 // level's per-token table
@@ -706,9 +691,8 @@ extern "C" int cgg_gemm_x3s_batched(const void* a_x3a, int lda, int rows_per_ima
                    cv, stream, rows_per_image, a_bstride);
 }
 
-extern "C" int cgg_conv_x3s_nhwc(const void* x_x3a, const void* w_x3, const float* bias, const void* res, int res_fmt, void* out,
-                                 int out_fmt, int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu,
-                                 cgg_stream_t stream) {
+static int xs_conv(const void* x_x3a, const void* w_x3, const float* bias, const void* res, int res_fmt, void* out, int out_fmt, int B,
+                   int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu, int cfg, cgg_stream_t stream) {
   CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, CGG_EINVAL,
               "cgg_conv_x3s_nhwc: bad sizes");
   CGG_REQUIRE(C % 32 == 0, CGG_EUNSUPPORTED, "cgg_conv_x3s_nhwc: C=%d must be a multiple of 32", C);
@@ -717,11 +701,22 @@ extern "C" int cgg_conv_x3s_nhwc(const void* x_x3a, const void* w_x3, const floa
   if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {       // a 1 x 1 convolution IS the row GEMM (no per-row pixel arithmetic)
     const XsConv cv0 = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     return xs_launch(false, "cgg_conv_x3s_nhwc", x_x3a, C, w_x3, bias, res, N, res_fmt, 0, out, N, out_fmt, B * H * W, N, C, relu, cv0,
-                     stream);
+                     stream, 0, 0, cfg);
   }
   const XsConv cv = {H, W, C, OH, OW, KW, stride, pad, KH * KW};
   return xs_launch(true, "cgg_conv_x3s_nhwc", x_x3a, 0, w_x3, bias, res, N, res_fmt, 0, out, N, out_fmt, B * OH * OW, N,
-                   KH * KW * C, relu, cv, stream);
+                   KH * KW * C, relu, cv, stream, 0, 0, cfg);
+}
+
+extern "C" int cgg_conv_x3s_nhwc(const void* x_x3a, const void* w_x3, const float* bias, const void* res, int res_fmt, void* out,
+                                 int out_fmt, int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu,
+                                 cgg_stream_t stream) {
+  return xs_conv(x_x3a, w_x3, bias, res, res_fmt, out, out_fmt, B, H, W, C, N, KH, KW, stride, pad, relu, -1, stream);
+}
+extern "C" int cgg_conv_x3s_nhwc_cfg(const void* x_x3a, const void* w_x3, const float* bias, const void* res, int res_fmt, void* out,
+                                     int out_fmt, int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu,
+                                     int cfg, cgg_stream_t stream) {
+  return xs_conv(x_x3a, w_x3, bias, res, res_fmt, out, out_fmt, B, H, W, C, N, KH, KW, stride, pad, relu, cfg, stream);
 }
 
 // ---- f32 <-> x3a rows (API edges and tests; inside the stream every producer writes x3a itself) ----

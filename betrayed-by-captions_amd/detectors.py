@@ -58,7 +58,16 @@ class MaskFormerOpen(nn.Module):
         self.panoptic_head.init_weights()
 
     def extract_feat(self, img):
-        x = self.backbone(img)
+        # x3a hand-over (parity-mode ResNet -> pixel decoder, csrc/x3.h) only when this detector's head is the direct consumer:
+        # a neck, or any other user of `self.backbone`, gets plain float32 maps
+        if hasattr(self.backbone, 'x3a_outputs'):
+            self.backbone.x3a_outputs = (not self.with_neck and hasattr(self, 'panoptic_head')
+                                         and hasattr(getattr(self.panoptic_head, 'pixel_decoder', None), 'forward_stream_x3'))
+        try:
+            x = self.backbone(img)
+        finally:
+            if hasattr(self.backbone, 'x3a_outputs'):
+                self.backbone.x3a_outputs = False
         if self.with_neck:
             x = self.neck(x)
         return x

@@ -1129,9 +1129,27 @@ def pack_conv_weight_x3(weight):
     return pack_linear_weight_x3(weight.detach().float().permute(0, 2, 3, 1).reshape(N, -1))
 
 
-def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
+def absmax(x):
+    """max |x| of a float32 ROCm matrix / tensor (last dim contiguous, % 4) -> device scalar (1,) f32: the per-tensor pre-scale
+    of the x3 contractions' grad_output operands (`gemm_x3(..., amax=)`, `wgrad_x3(..., amax=)`; csrc/x3.h)."""
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise CggError('absmax: float32 ROCm tensor expected')
+    x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
+    if x2.dim() != 2 or x2.stride(1) != 1:
+        raise CggError('absmax: a 2-D view with a contiguous last dim expected')
+    if x2.is_contiguous() and x2.numel() % 4 == 0:
+        x2 = x2.view(1, -1)                       # dense: one long row
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    M, N = x2.shape
+    check(_lib_().cgg_absmax_f32(ctypes.c_void_p(x2.data_ptr()), int(x2.stride(0)) if M > 1 else N, M, N, dev_ptr(out),
+                                 stream_ptr(x.device)), 'cgg_absmax_f32')
+    return out
+
+
+def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None, amax=None):
     """a (M, K) f32 rows (row stride free, last dim contiguous) x x3 image -> act(a W^T + bias (+ res)) (M, N) f32:
-    parity mode's large linear (csrc/x3_gemm.hip)."""
+    parity mode's large linear (csrc/x3_gemm.hip). amax: device scalar max |a| (`absmax`) -> a is pre-scaled per tensor instead
+    of by the fixed 2^4 (operands that are not unit scale: gradients)."""
     if a.dim() != 2 or a.stride(1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
         raise CggError('gemm_x3: a must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
     M, K = a.shape
@@ -1143,39 +1161,25 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None):
         raise CggError('gemm_x3: bad `res` view')
     with _timed('gemm_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * K + M * N * (2 if res is not None else 1)) + 4.0 * N * K,
                 shape=(M, N, K)):
-        rc = _lib_().cgg_gemm_x3(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
-                                 ctypes.c_void_p(res.data_ptr()) if res is not None else None,
-                                 res.stride(0) if res is not None else 0, ctypes.c_void_p(y.data_ptr()), y.stride(0), M, N, K,
-                                 int(bool(relu)), stream_ptr(a.device))
+        if amax is not None:
+            rc = _lib_().cgg_gemm_x3_scaled(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(amax, 'amax', torch.float32),
+                                            dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                            ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                            res.stride(0) if res is not None else 0, ctypes.c_void_p(y.data_ptr()), y.stride(0), M, N,
+                                            K, int(bool(relu)), stream_ptr(a.device))
+        else:
+            rc = _lib_().cgg_gemm_x3(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                     ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                     res.stride(0) if res is not None else 0, ctypes.c_void_p(y.data_ptr()), y.stride(0), M, N, K,
+                                     int(bool(relu)), stream_ptr(a.device))
     check(rc, 'cgg_gemm_x3')
     return y
 
 
-_TAIL_V2_PERM = {}
-
-
-def tail_v2_k_permutation(K, device):
-    """Column order of the K axis of W1 / W2 for `encoder_layer_tail_x3(..., v2=True)`: inside every 32-block the order in which an
-    MFMA accumulator tile's registers enumerate its rows (csrc/encoder_tail_x3v2.hip, `cgg_encoder_tail_v2_perm32`)."""
-    key = (int(K), str(device))
-    if key not in _TAIL_V2_PERM:
-        p32 = (ctypes.c_int32 * 32)()
-        check(_lib_().cgg_encoder_tail_v2_perm32(ctypes.cast(p32, ctypes.c_void_p)), 'cgg_encoder_tail_v2_perm32')
-        base = torch.tensor(list(p32), dtype=torch.long)
-        _TAIL_V2_PERM[key] = (torch.arange(0, K, 32).view(-1, 1) + base.view(1, -1)).reshape(-1).to(device)
-    return _TAIL_V2_PERM[key]
-
-
-def pack_tail_v2_weight_x3(w):
-    """x3 image of w[:, perm] -- W1 / W2 of the register-chained encoder tail."""
-    return pack_linear_weight_x3(w.detach().float()[:, tail_v2_k_permutation(w.shape[1], w.device)].contiguous())
-
-
-def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False, x3a=False, v2=False):
+def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False, x3a=False):
     """Parity mode's encoder layer tail in ONE launch: a (attention rows), x (layer input) (..., 256) f32 ->
     y = LN1(x1 + FFN(x1)), x1 = LN0(x + a Wo^T + bo) (and y + pos[row % len(pos)] when want_pos); wo / w1 / w2 x3 images,
-    norm_* = (gamma, beta, eps). x3a=True: x and both outputs are x3a rows (csrc/x3.h), a stays f32. v2=True (needs x3a): the
-    register-chained kernel (csrc/encoder_tail_x3v2.hip); w1 / w2 are then `pack_tail_v2_weight_x3` images."""
+    norm_* = (gamma, beta, eps). x3a=True: x and both outputs are x3a rows (csrc/x3.h), a stays f32."""
     C = a.shape[-1]
     M = a.numel() // C
     for t in (a, x):
@@ -1188,9 +1192,7 @@ def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, 
     yp = torch.empty_like(a) if want_pos else None
     with _timed('encoder_tail_x3', flops=2.0 * M * (C * C + 2 * C * F), bytes=4.0 * M * C * (3 + (1 if want_pos else 0)),
                 shape=(M, C, F)):
-        if v2 and not x3a:
-            raise CggError('encoder_layer_tail_x3: v2 reads / writes x3a rows')
-        fn = _lib_().cgg_encoder_layer_tail_x3a_v2 if v2 else (_lib_().cgg_encoder_layer_tail_x3a if x3a else _lib_().cgg_encoder_layer_tail_x3)
+        fn = _lib_().cgg_encoder_layer_tail_x3a if x3a else _lib_().cgg_encoder_layer_tail_x3
         rc = fn(
             dev_ptr(a), dev_ptr(x), dev_ptr(wo), dev_ptr(bo, 'bo', torch.float32), dev_ptr(norm0[0], 'gamma0', torch.float32),
             dev_ptr(norm0[1], 'beta0', torch.float32), float(norm0[2]), dev_ptr(w1), dev_ptr(b1, 'b1', torch.float32), dev_ptr(w2),
@@ -1226,10 +1228,11 @@ def nhwc_to_nchw(x):
     return transpose_f32(x.view(B, H * W, C)).view(B, C, H, W)
 
 
-def wgrad_x3(dy, x, want_bias=False):
+def wgrad_x3(dy, x, want_bias=False, amax=None):
     """dW (N, K) = dy^T x for dy (M, N), x (M, K) f32 rows (contiguous last dim, row strides % 4 == 0; N, K % 4 == 0) on the
     f32-class f16 x 3 contraction with transpose reads (csrc/wgrad_x3.hip): the weight gradient of a linear layer.
-    want_bias: -> (dW, db) with db (N) = dy.sum(0) from the same pass over dy."""
+    want_bias: -> (dW, db) with db (N) = dy.sum(0) from the same pass over dy. amax: device scalar max |dy| (`absmax`) -> dy is
+    pre-scaled per tensor instead of by the fixed 2^4 (gradients are not unit scale, csrc/x3.h)."""
     if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or dy.dtype != torch.float32 or x.dtype != torch.float32 \
             or not dy.is_cuda or dy.stride(1) != 1 or x.stride(1) != 1:
         raise CggError('wgrad_x3: dy (M, N) and x (M, K) must be float32 ROCm matrices with contiguous rows')
@@ -1241,7 +1244,11 @@ def wgrad_x3(dy, x, want_bias=False):
     splits = ctypes.c_int(0)
     wsb = torch.empty((nbytes // (4 * N * K)) * N, dtype=torch.float32, device=dy.device) if want_bias else None
     with _timed('wgrad_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K), shape=(M, N, K)):
-        if want_bias:
+        if amax is not None:
+            rc = lib.cgg_wgrad_x3_scaled(ctypes.c_void_p(dy.data_ptr()), dy.stride(0), dev_ptr(amax, 'amax', torch.float32),
+                                         ctypes.c_void_p(x.data_ptr()), x.stride(0), dev_ptr(ws), dev_ptr(wsb), ctypes.byref(splits),
+                                         M, N, K, stream_ptr(dy.device))
+        elif want_bias:
             rc = lib.cgg_wgrad_bias_x3(ctypes.c_void_p(dy.data_ptr()), dy.stride(0), ctypes.c_void_p(x.data_ptr()), x.stride(0),
                                        dev_ptr(ws), dev_ptr(wsb), ctypes.byref(splits), M, N, K, stream_ptr(dy.device))
         else:
@@ -1275,9 +1282,9 @@ def gemm_x3_split(a, packed, N, col2, bias=None, res_table=None):
     return y1, y2
 
 
-def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, relu=False):
+def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, relu=False, amax=None):
     """x (B, H, W, C) f32 channel-last (contiguous) -> act(conv + bias (+ res)) (B, OH, OW, N) f32 as an implicit GEMM on the
-    x3 image made by `pack_conv_weight_x3` (C % 32 == 0)."""
+    x3 image made by `pack_conv_weight_x3` (C % 32 == 0). amax: device scalar max |x| -> per-tensor pre-scale (gradient maps)."""
     if x.dim() != 4 or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda or not is_x3(packed):
         raise CggError('conv_x3_nhwc: x must be a contiguous (B, H, W, C) float32 ROCm tensor, packed an x3 image')
     B, H, W, C = x.shape
@@ -1290,8 +1297,13 @@ def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, rel
     with _timed('gemm_x3', flops=2.0 * B * OH * OW * N * C * KH * KW,
                 bytes=4.0 * (B * H * W * C + B * OH * OW * N * (2 if res is not None else 1) + N * C * KH * KW),
                 shape=(B * OH * OW, N, C * KH * KW)):
-        rc = _lib_().cgg_conv_x3_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res), dev_ptr(y),
-                                      B, H, W, C, N, KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
+        if amax is not None:
+            rc = _lib_().cgg_conv_x3_nhwc_scaled(dev_ptr(x), dev_ptr(amax, 'amax', torch.float32), dev_ptr(packed),
+                                                 dev_ptr(bias, 'bias', torch.float32), dev_ptr(res), dev_ptr(y), B, H, W, C, N, KH, KW,
+                                                 int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
+        else:
+            rc = _lib_().cgg_conv_x3_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res), dev_ptr(y),
+                                          B, H, W, C, N, KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
     check(rc, 'cgg_conv_x3_nhwc')
     return y
 
@@ -1355,7 +1367,7 @@ def _x3s_fmt(split):
     return X3A_SPLIT if split else X3A_F32
 
 
-def gemm_x3s(a, packed, N, bias=None, res=None, res_split=False, res_mod=0, relu=False, out=None, out_split=False):
+def gemm_x3s(a, packed, N, bias=None, res=None, res_split=False, res_mod=0, relu=False, out=None, out_split=False, cfg=-1):
     """a (M, K) x3a rows (row stride free, multiples of 8) x x3 image -> act(a W^T + bias (+ res)) (M, N), f32 or x3a
     (`out_split`); res (M, N) | (res_mod, N) in f32 or x3a (`res_split`). csrc/x3s_gemm.hip."""
     if a.dim() not in (2, 3) or a.stride(-1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
@@ -1381,16 +1393,16 @@ def gemm_x3s(a, packed, N, bias=None, res=None, res_split=False, res_mod=0, relu
                                           0 if res is None else _x3s_fmt(res_split), int(res_mod), ctypes.c_void_p(y.data_ptr()),
                                           y.stride(0), _x3s_fmt(out_split), M, N, K, int(bool(relu)), stream_ptr(a.device)) \
             if rpb else \
-            _lib_().cgg_gemm_x3s(ctypes.c_void_p(a.data_ptr()), lda, dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
-                                 ctypes.c_void_p(res.data_ptr()) if res is not None else None,
-                                 res.stride(0) if res is not None else 0,
-                                 0 if res is None else _x3s_fmt(res_split), int(res_mod), ctypes.c_void_p(y.data_ptr()),
-                                 y.stride(0), _x3s_fmt(out_split), M, N, K, int(bool(relu)), stream_ptr(a.device))
+            _lib_().cgg_gemm_x3s_cfg(ctypes.c_void_p(a.data_ptr()), lda, dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                     ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                     res.stride(0) if res is not None else 0,
+                                     0 if res is None else _x3s_fmt(res_split), int(res_mod), ctypes.c_void_p(y.data_ptr()),
+                                     y.stride(0), _x3s_fmt(out_split), M, N, K, int(bool(relu)), int(cfg), stream_ptr(a.device))
     check(rc, 'cgg_gemm_x3s')
     return y
 
 
-def conv_x3s_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, res_split=True, relu=False, out_split=True):
+def conv_x3s_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, res_split=True, relu=False, out_split=True, cfg=-1):
     """x (B, H, W, C) x3a channel-last -> act(conv + bias (+ res)) (B, OH, OW, N), x3a (default) or f32: implicit GEMM on the
     x3 image made by `pack_conv_weight_x3` (C % 32 == 0)."""
     if x.dim() != 4 or not x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda or not is_x3(packed):
@@ -1405,9 +1417,9 @@ def conv_x3s_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, re
     with _timed('gemm_x3', flops=2.0 * B * OH * OW * N * C * KH * KW,
                 bytes=4.0 * (B * H * W * C + B * OH * OW * N * (2 if res is not None else 1) + N * C * KH * KW),
                 shape=(B * OH * OW, N, C * KH * KW)):
-        rc = _lib_().cgg_conv_x3s_nhwc(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res),
-                                       0 if res is None else _x3s_fmt(res_split), dev_ptr(y), _x3s_fmt(out_split), B, H, W, C, N,
-                                       KH, KW, int(stride), int(pad), int(bool(relu)), stream_ptr(x.device))
+        rc = _lib_().cgg_conv_x3s_nhwc_cfg(dev_ptr(x), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32), dev_ptr(res),
+                                           0 if res is None else _x3s_fmt(res_split), dev_ptr(y), _x3s_fmt(out_split), B, H, W, C, N,
+                                           KH, KW, int(stride), int(pad), int(bool(relu)), int(cfg), stream_ptr(x.device))
     check(rc, 'cgg_conv_x3s_nhwc')
     return y
 

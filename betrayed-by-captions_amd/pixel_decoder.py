@@ -814,8 +814,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
         if self.num_input_levels - self.num_encoder_levels != 1 or self.mask_feature.out_channels != 256:
             return False
         for f in feats:
-            if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 4 and f.permute(0, 2, 3, 1).is_contiguous()
-                    and f.shape[1] % 32 == 0):
+            # channel-last views (the parity-mode ResNet's hand-over, x3a-tagged or plain) are read as they are; NCHW-contiguous
+            # maps (any other backbone, tests, `smoke()`) are transposed once by `ops.nchw_to_nhwc` on the way in
+            if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 4 and f.shape[1] % 32 == 0
+                    and (f.permute(0, 2, 3, 1).is_contiguous() or f.is_contiguous())):
                 return False
         for cm in list(self.input_convs) + list(self.lateral_convs) + list(self.output_convs):
             gn = getattr(cm, cm.norm_name, None) if cm.norm_name else None
@@ -895,12 +897,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             n0, n1 = layer.norms
             fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
             last = layer is self.encoder.layers[-1]
-            v2 = runtime.tail_v2_enabled() and C == 256 and fc1.weight.shape[0] % 32 == 0 and fc1.weight.shape[0] <= 2048
-            ffw = (lambda lin: runtime.derived_cached('x3_image_tail_v2', (lin.weight,),
-                                                      lambda: ops.pack_tail_v2_weight_x3(lin.weight))) if v2 else x3w
             src, srcp = ops.encoder_layer_tail_x3(a, src, x3w(attn.output_proj), attn.output_proj.bias,
-                                                  (n0.weight, n0.bias, n0.eps), ffw(fc1), fc1.bias, ffw(fc2), fc2.bias,
-                                                  (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True, v2=v2)
+                                                  (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
+                                                  (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True)
         return src
 
     def _forward_stream_x3a(self, feats, defer_fpn=False):
@@ -911,7 +910,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         B = feats[0].shape[0]
         dev = feats[0].device
         C = 256
-        rows = lambda f: (f if ops.is_x3a(f) else ops.x3a_encode(f.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)) \
+        rows = lambda f: (f if ops.is_x3a(f) else ops.x3a_encode(ops.nchw_to_nhwc(f).contiguous()).permute(0, 3, 1, 2)) \
             .as_subclass(torch.Tensor).permute(0, 2, 3, 1).reshape(-1, f.shape[1])
         level_hw = []
         for i in range(self.num_encoder_levels):
@@ -988,7 +987,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             f = feats[self.num_input_levels - i - 1]
             h, w = level_hw[i]
             cm = self.input_convs[i]
-            y = runtime.linear_x3(f.permute(0, 2, 3, 1).reshape(B * h * w, f.shape[1]), cm.conv.weight.flatten(1), cm.conv.bias)
+            y = runtime.linear_x3(ops.nchw_to_nhwc(f).reshape(B * h * w, f.shape[1]), cm.conv.weight.flatten(1), cm.conv.bias)
             gn = getattr(cm, cm.norm_name)
             ops.group_norm_nhwc(y.view(B, h * w, C), gn.weight, gn.bias, 32, gn.eps, ws, out32=(src, level_start[i] * C, N * C))
         src = self._encoder_stream_x3(src, pos, ref, level_hw, level_start)
@@ -997,7 +996,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         f = feats[0]
         H4, W4 = int(f.shape[2]), int(f.shape[3])
         lat, outc = self.lateral_convs[0], self.output_convs[0]
-        y = runtime.linear_x3(f.permute(0, 2, 3, 1).reshape(B * H4 * W4, f.shape[1]), lat.conv.weight.flatten(1), lat.conv.bias)
+        y = runtime.linear_x3(ops.nchw_to_nhwc(f).reshape(B * H4 * W4, f.shape[1]), lat.conv.weight.flatten(1), lat.conv.bias)
         gn = getattr(lat, lat.norm_name)
         hl, wl = level_hw[-1]
         y = y.view(B, H4 * W4, C)

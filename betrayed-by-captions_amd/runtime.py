@@ -83,15 +83,6 @@ def x3_enabled():
     return _STATE['precision'] == 'fp32' and _X3
 
 
-_TAIL_V2 = _os.environ.get('CGG_TAIL_V2', '0') == '1'
-
-
-def tail_v2_enabled():
-    """CGG_TAIL_V2=1: the register-chained encoder tail (csrc/encoder_tail_x3v2.hip) in the x3a stream instead of the LDS-image kernel
-    (A/B only: measured slower, 274 vs 198 us per launch at configs[1])."""
-    return _TAIL_V2
-
-
 def x3a_enabled():
     """Round 4: the parity-mode inference stream keeps its GEMM-consumed activations as pre-split x3a rows (csrc/x3.h) and runs
     the LDS-DMA GEMM / implicit-GEMM convolution of csrc/x3s_gemm.hip; CGG_X3A=0 restores round 3's f32 stream (cgg_gemm_x3) for
@@ -215,15 +206,20 @@ class _X3LinearFn(torch.autograd.Function):
             g2 = g2.contiguous()
         M = x2.shape[0]
         gx = gw = gb = None
+        # grad_output is not unit scale (|g| ~ 1e-4 .. 1e-8 behind a normalised loss): its f16 pieces are taken after a per-tensor
+        # power-of-two pre-scale from max |g| (ONE streaming pass, shared by the grad-input GEMM and the weight-gradient kernel)
+        # instead of the activations' fixed 2^4 (with 2^4 a gradient of 1e-6 kept ~10 of its 22 bits); CGG_X3_GSCALE=0
+        # restores the fixed scale for A/B
+        amax = ops.absmax(g2) if _X3_GSCALE and N % 4 == 0 else None
         if ctx.needs_input_grad[0]:
             wtk = derived_cached('x3_image_t', (weight,), lambda: ops.pack_linear_weight_x3(weight.detach().t().contiguous()))
             gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
-            ops.gemm_x3(g2, wtk, K, out=gx.view(-1, K))
+            ops.gemm_x3(g2, wtk, K, out=gx.view(-1, K), amax=amax)
         if ctx.needs_input_grad[1]:
             if _X3_WGRAD and ctx.has_bias and ctx.needs_input_grad[2] and N % 4 == 0:
-                gw, gb = ops.wgrad_x3(g2, x2, want_bias=True)      # the bias gradient from the same pass over grad_output
+                gw, gb = ops.wgrad_x3(g2, x2, want_bias=True, amax=amax)      # the bias gradient from the same pass over grad_output
             elif _X3_WGRAD:
-                gw = ops.wgrad_x3(g2, x2)              # transpose-read x3 kernel (csrc/wgrad_x3.hip), partial tiles summed in fixed order
+                gw = ops.wgrad_x3(g2, x2, amax=amax)   # transpose-read x3 kernel (csrc/wgrad_x3.hip), partial tiles summed in fixed order
             else:
                 S = next((s for s in (32, 16, 8, 4, 2) if M % s == 0 and M // s >= 4096), 1)
                 gw = torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)).sum(0)
@@ -259,8 +255,15 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         B, H, W, C = xl.shape
         N = weight.shape[0]
         gl = ops.nchw_to_nhwc(gy)
+        gl = gl if gl.is_contiguous() else gl.contiguous()
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        amax = ops.absmax(gl.view(-1, N)) if _X3_GSCALE else None        # per-tensor pre-scale of grad_output (see _X3LinearFn)
+        if ctx.needs_input_grad[0] and amax is not None:
+            wt = derived_cached('x3_conv_image_dgrad', (weight,),
+                                lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
+            # f32 rows split in the kernel with the per-tensor scale (the x3a form bakes the fixed 2^4 into the stored pieces)
+            gx = ops.nhwc_to_nchw(ops.conv_x3_nhwc(gl, wt, C, 3, 1, 1, amax=amax))
+        elif ctx.needs_input_grad[0]:
             wt = derived_cached('x3_conv_image_dgrad', (weight,),
                                 lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
             # (contiguous NCHW: a channel-last-strided gradient sent the producer's backward -- the FPN's bilinear up-sample -- down
@@ -275,7 +278,7 @@ class _X3Conv3x3Fn(torch.autograd.Function):
             for ky in range(3):
                 for kx in range(3):
                     off = (ky - 1) * (W + 2) + (kx - 1)
-                    gw[:, ky, kx, :] = ops.wgrad_x3(gp[lo:hi], xp[lo + off:hi + off])
+                    gw[:, ky, kx, :] = ops.wgrad_x3(gp[lo:hi], xp[lo + off:hi + off], amax=amax)
             gw = gw.permute(0, 3, 1, 2)
         return gx, gw
 
@@ -286,22 +289,28 @@ def x3_train_conv3x3_ok(conv, x):
     return (_X3_TRAIN and _X3A and x3_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 32 == 0
-            and conv.out_channels % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 65536 and x.shape[2] >= 4 and x.shape[3] >= 4)
+            and conv.out_channels % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 65536 and x.shape[2] >= 4 and x.shape[3] >= 4
+            # the kernels address their operands through 32-bit buffer descriptors: the zero-padded maps of the weight-gradient
+            # contraction are the largest operand (from B = 64 at 256^2 x 256 the call raised instead of running on MIOpen)
+            and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * max(conv.in_channels, conv.out_channels) * 4 < _X3_MAX_BYTES)
 
 
 def conv3x3_x3_train(x, conv):
     return _X3Conv3x3Fn.apply(x, conv.weight)
 
 
+_X3_MAX_BYTES = 0xFFFFFF00          # operand span the x3 kernels can address (32-bit buffer descriptors); larger -> library path
 X3_TRAIN_ROWS = 8192               # rows from which parity-mode training linears run on the x3 GEMM (CGG_X3_TRAIN=0 disables)
 _X3_TRAIN = _os.environ.get('CGG_X3_TRAIN', '1') != '0'
 _X3_WGRAD = _os.environ.get('CGG_X3_WGRAD', '1') != '0'
+_X3_GSCALE = _os.environ.get('CGG_X3_GSCALE', '1') != '0'          # per-tensor pre-scale of grad_output in the x3 training kernels
 
 
 def x3_train_linear_ok(x, weight):
     return (_X3_TRAIN and x3_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
             and weight.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0 and x.shape[-1] == weight.shape[1]
-            and x.numel() // x.shape[-1] >= X3_TRAIN_ROWS)
+            and x.numel() // x.shape[-1] >= X3_TRAIN_ROWS
+            and (x.numel() // x.shape[-1]) * max(weight.shape) * 4 < _X3_MAX_BYTES)
 
 
 SPLITK_WGRAD_ROWS = 32768          # rows from which the training linears use `_SplitKLinearFn` (CGG_SPLITK_WGRAD=0 disables)

@@ -459,7 +459,9 @@ int cgg_conv_x3_nhwc(const float* x, const void* w_x3, const float* bias, const 
  *                      (synchronises the stream) and optionally clears it -- the caller turns it into an error instead of
  *                      letting inf / NaN masks through (open_set/models/mask2former_head.py:763-849 computes in f32, which
  *                      has no such limit).
- *   cgg_gemm_x3s_force_config: bench / test hook, tile configuration 0..8 (-1 = by shape).
+ *   cgg_gemm_x3s_cfg / cgg_conv_x3s_nhwc_cfg: the same calls with the tile configuration (0 .. 17; -1 = by shape) as an ARGUMENT:
+ *                      tests sweep every instantiation, benches compare them. (Round 4's process-global
+ *                      cgg_gemm_x3s_force_config is gone: the library keeps no mutable state besides the overflow flag word.)
  * Same reference call sites as cgg_gemm_x3 / cgg_conv_x3_nhwc above.                                                   */
 int cgg_gemm_x3s(const void* a_x3a, int lda, const void* w_x3, const float* bias, const void* res, int ldr, int res_fmt,
                  int res_mod, void* out, int ldc, int out_fmt, int M, int N, int K, int relu, cgg_stream_t stream);
@@ -473,7 +475,11 @@ int cgg_conv_x3s_nhwc(const void* x_x3a, const void* w_x3, const float* bias, co
 int cgg_x3a_encode(const float* x, void* out_x3a, int64_t n, cgg_stream_t stream);
 int cgg_x3a_decode(const void* x_x3a, float* out, int64_t n, cgg_stream_t stream);
 int cgg_x3_overflow_check(int reset, int* value_host, cgg_stream_t stream);
-void cgg_gemm_x3s_force_config(int cfg);
+int cgg_gemm_x3s_cfg(const void* a_x3a, int lda, const void* w_x3, const float* bias, const void* res, int ldr, int res_fmt,
+                     int res_mod, void* out, int ldc, int out_fmt, int M, int N, int K, int relu, int cfg, cgg_stream_t stream);
+int cgg_conv_x3s_nhwc_cfg(const void* x_x3a, const void* w_x3, const float* bias, const void* res, int res_fmt, void* out,
+                          int out_fmt, int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu, int cfg,
+                          cgg_stream_t stream);
 /* x3a-producing / -consuming twins of the stream's non-GEMM kernels (round 4):
  *   cgg_bias_relu_maxpool_nhwc_f32_x3a: the stem's (bias, ReLU, 3x3 / s2 max-pool) pass with the pooled map written as x3a (C % 8 == 0);
  *   cgg_group_norm_nhwc_f32_x3a:        cgg_group_norm_nhwc_f32 with y (and yp = y + pos[pixel], nullable) written as x3a rows at
@@ -489,16 +495,6 @@ int cgg_encoder_layer_tail_x3a(const float* a32, const void* x_x3a, const void* 
                                const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
                                const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
                                int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
-/* The same operator as a register-chained kernel (csrc/encoder_tail_x3v2.hip: a wavefront owns 32 rows for the whole chain, every
- * GEMM computed transposed so that an accumulator tile IS the next GEMM's B operand; the weights are the only LDS traffic, one
- * LDS-DMA ring per workgroup). C == 256, F % 32 == 0, F <= 2048. w1p_x3 / w2p_x3 are the x3 images of W1[:, perm] / W2[:, perm],
- * perm = perm32 applied inside every 32-block of the K axis (cgg_encoder_tail_v2_perm32 fills int32 perm32[32], host memory).
- * Replaces the same reference lines as cgg_encoder_layer_tail_x3 ([3P] BaseTransformerLayer, mask2former_head.py:112-117). */
-int cgg_encoder_layer_tail_x3a_v2(const float* a32, const void* x_x3a, const void* wo_x3, const float* bo, const float* gamma0,
-                                  const float* beta0, float eps0, const void* w1p_x3, const float* b1, const void* w2p_x3,
-                                  const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
-                                  int pos_rows, void* y_x3a, void* yp_x3a, int M, int C, int F, cgg_stream_t stream);
-int cgg_encoder_tail_v2_perm32(int32_t* perm32);
 
 /* Batched transpose of f32 matrices, in (B, R, C) -> out (B, C, R): the NCHW <-> NHWC layout changes around the x3 kernels under
  * autograd (torch `x.permute(0, 2, 3, 1).contiguous()` and back), 64 x 64 tiles through LDS. */
@@ -516,6 +512,20 @@ int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, i
  * (>= splits x N floats, splits = workspace bytes / (4 N K)) receives one partial row per split. */
 int cgg_wgrad_bias_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, float* ws_bias, int* splits_out, int M, int N,
                       int K, cgg_stream_t stream);
+
+/* Per-tensor pre-scale of the x3 contractions' grad_output operands (round 5). The fixed 2^4 pre-scale of csrc/x3.h suits O(1)
+ * activations; autograd's grad_output behind the F.linear / conv calls of mask2former_head.py:787 is not unit scale (|g| ~ 1e-6
+ * keeps ~10 of the pair's 22 bits). cgg_absmax_f32 writes max |x| over an (M, N) f32 matrix (row stride ld; N, ld % 4 == 0) to the
+ * device scalar *amax in one streaming pass; the *_scaled entry points pre-scale that operand by 2^(9 - floor(log2 amax)) instead
+ * of 2^4 and fold the inverse into their epilogue (exact). amax pointers are nullable (= the fixed 2^4). Otherwise the
+ * contracts of cgg_gemm_x3 / cgg_conv_x3_nhwc / cgg_wgrad_x3 / cgg_wgrad_bias_x3 (ws_bias nullable here). */
+int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax, cgg_stream_t stream);
+int cgg_gemm_x3_scaled(const float* a, int lda, const float* a_amax, const void* w_x3, const float* bias, const float* res, int ldr,
+                       float* out, int ldc, int M, int N, int K, int relu, cgg_stream_t stream);
+int cgg_conv_x3_nhwc_scaled(const float* x, const float* x_amax, const void* w_x3, const float* bias, const float* res, float* out,
+                            int B, int H, int W, int C, int N, int KH, int KW, int stride, int pad, int relu, cgg_stream_t stream);
+int cgg_wgrad_x3_scaled(const float* dy, int ldy, const float* dy_amax, const float* x, int ldx, float* ws, float* ws_bias,
+                        int* splits_out, int M, int N, int K, cgg_stream_t stream);
 
 /* Encoder-stream residual LayerNorm (N == 256): y = LN(a + b) * gamma + beta, a / b f32 or bf16 (b nullable), with up
  * to three outputs written in the same pass: y32 (f32), y16 = bf16(y), yp16 = bf16(y + pos[row % pos_rows]).  */

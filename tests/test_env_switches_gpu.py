@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = ['', 'CGG_X3=0', 'CGG_X3A=0', 'CGG_X3_STEM=0', 'CGG_FUSED_TAIL=0', 'CGG_MSDA_GENERIC=1', 'CGG_MSDA_V1=1',
-            'CGG_EXACT_F32_LOGITS=0', 'CGG_XG_MINTILES=1024', 'CGG_XS_MAP=13:7,14:6,4:3,12:16,11:17', 'CGG_TAIL_V2=1', 'CGG_XATTN_X3=0']
+            'CGG_EXACT_F32_LOGITS=0', 'CGG_XG_MINTILES=1024', 'CGG_XATTN_X3=0']
 
 
 @pytest.mark.parametrize('switch', SWITCHES)

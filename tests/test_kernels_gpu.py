@@ -123,6 +123,26 @@ def test_msda_fused_prologue(dev, shapes):
     assert (got - want).abs().max().item() <= 1e-4
 
 
+def test_msda_fused_prologue_reordered_levels(dev):
+    """the 2-D query -> lane mappings assume that the levels tile [0, Nq) in ascending order. A level table that is
+    legal for the op (every level inside the value rows) but stored in another order must fall back to the strip mapping and give
+    the same result as the standard layout."""
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    starts, Nv = _levels(shapes)
+    B, H, D, L, P = 2, 8, 32, 3, 4
+    g = torch.Generator().manual_seed(15)
+    value = torch.randn(B, Nv, H, D, generator=g)
+    raw = torch.randn(B, Nv, H * L * P * 3, generator=g)
+    refp = torch.rand(Nv, 2, generator=g)
+    std = ops.msda_forward_fused(value.to(dev), shapes, starts, raw.to(dev), refp.to(dev), P).cpu()
+    # the same three maps stored finest-first: starts = [5 * 256, 256 * 4, 0]
+    parts = [value[:, s:s + h * w] for s, (h, w) in zip(starts, shapes)]
+    vperm = torch.cat(parts[::-1], 1).contiguous()
+    pstarts = [shapes[2][0] * shapes[2][1] + shapes[1][0] * shapes[1][1], shapes[2][0] * shapes[2][1], 0]
+    got = ops.msda_forward_fused(vperm.to(dev), shapes, pstarts, raw.to(dev), refp.to(dev), P).cpu()
+    assert torch.equal(got, std)
+
+
 def test_msda_backward_vs_autograd(dev):
     shapes = [(6, 6), (12, 12)]
     value, ss, st, loc, aw = _msda_inputs(2, shapes, 4, 16, 4, 90, seed=6)

@@ -168,6 +168,14 @@ def main(argv=None):
             schedule.apply(it)
             logs = train_step(model, optimizer, reducer, data, grad_clip)
             it += 1
+            if (it % args.log_interval == 0 or it == max_iters) and args.precision == 'fp32' and runtime.x3_enabled():
+                # parity mode's f16 x 3 kernels hold activations up to |a| < 4094 (csrc/x3.h): beyond it the forward turns into
+                # inf / NaN; name the cause once per logging interval instead of letting a NaN loss speak for itself
+                from cgg_amd import ops
+                if ops.x3_overflow_check(device, reset=True):
+                    raise RuntimeError(f'iteration {it}: an activation left the range of the f32-class f16 x 3 kernels '
+                                       '(|a| >= 4094, csrc/x3.h) -- the losses since the last check are invalid; re-run with '
+                                       'CGG_X3_TRAIN=0 (f32 library GEMMs) or --precision bf16')
             if rank == 0 and (it % args.log_interval == 0 or it == max_iters):
                 dt = (time.perf_counter() - t0) / max(it - start_iter, 1)
                 rec = dict(iter=it, time=round(dt, 4), lr=optimizer.param_groups[0]['lr'],
