@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void cgg_absmax_f32_kernel(const float* __rest
     const f32x4 v = xv[off];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint32_t b = __builtin_bit_cast(uint32_t, v[k]) & 0x7fffffffu;
+      const float f = v[k];      // (copied to a scalar first: __builtin_bit_cast on the vector-element lvalue reads element 0, hipcc 7.2)
+      const uint32_t b = __builtin_bit_cast(uint32_t, f) & 0x7fffffffu;
       m = b > m ? b : m;
     }
   }

@@ -123,13 +123,16 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_locations, 
     gv = torch.zeros_like(value)
     gl = torch.zeros_like(sampling_locations)
     gw = torch.zeros_like(attention_weights)
-    rc = _lib_().cgg_msda_backward(
-        dev_ptr(value, 'value', torch.float32), dev_ptr(spatial_shapes, 'spatial_shapes', torch.int64),
-        dev_ptr(level_start_index, 'level_start_index', torch.int64),
-        dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
-        dev_ptr(attention_weights, 'attention_weights', torch.float32),
-        dev_ptr(grad_output, 'grad_output', torch.float32), dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B,
-        Nv, H, D, L, Nq, P, stream_ptr(value.device))
+    # algorithmic bytes: value + locations + weights + grad_output in, the three gradients out
+    nbytes = 4.0 * (2 * value.numel() + 2 * sampling_locations.numel() + 2 * attention_weights.numel() + grad_output.numel())
+    with _timed('msda_backward', bytes=nbytes, flops=0.0, shape=(B, Nq, H, D, L, P)):
+        rc = _lib_().cgg_msda_backward(
+            dev_ptr(value, 'value', torch.float32), dev_ptr(spatial_shapes, 'spatial_shapes', torch.int64),
+            dev_ptr(level_start_index, 'level_start_index', torch.int64),
+            dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
+            dev_ptr(attention_weights, 'attention_weights', torch.float32),
+            dev_ptr(grad_output, 'grad_output', torch.float32), dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B,
+            Nv, H, D, L, Nq, P, stream_ptr(value.device))
     check(rc, 'cgg_msda_backward')
     return gv, gl, gw
 

@@ -29,9 +29,14 @@ class StagePipeline:
     example  -- an example input batch (shape / dtype / device are frozen into the graphs)
     """
 
-    def __init__(self, stages, example, slots=None, warmup=2, priorities=None, streams=None):
+    def __init__(self, stages, example, slots=None, warmup=2, priorities=None, streams=None, tail=None):
+        """tail -- optional callable applied EAGERLY (not captured) to the last graph stage's output: post-processing with
+                   data-dependent host reads (the panoptic fusion head reads segment counts: no hipGraph can hold that). It runs
+                   on its own stream ONE BATCH BEHIND the graph stages -- `submit(k + 1)` first enqueues batch k + 1's graphs, then
+                   runs batch k's tail -- so the host waits of the tail overlap the next batch's device work."""
         self.stages = list(stages)
         n = len(self.stages)
+        self.tail = tail
         self.slots = slots if slots is not None else max(2, n)
         dev = example.device
         self.dev = dev
@@ -70,6 +75,25 @@ class StagePipeline:
                     self.outs[i][s] = x
                     torch.cuda.synchronize(dev)
         self.results = self.outs[-1]
+        self._tail_pending = None
+        if tail is not None:
+            self.tail_stream = torch.cuda.Stream(dev)
+            self.tail_done = [torch.cuda.Event() for _ in range(self.slots)]
+            self.results = [None] * self.slots
+            self._tail_ran = [False] * self.slots
+            with torch.no_grad():                                 # warm-up (allocator, first-call setup) on the tail stream
+                self.tail_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(self.tail_stream):
+                    tail(self.outs[-1][0])
+                torch.cuda.synchronize(dev)
+
+    def _run_tail(self, slot):
+        st = self.tail_stream
+        with torch.no_grad(), torch.cuda.stream(st):
+            st.wait_event(self.done[-1][slot])
+            self.results[slot] = self.tail(self.outs[-1][slot])
+            self.tail_done[slot].record(st)
+        self._tail_ran[slot] = True
 
     def submit(self, x):
         s = self._n % self.slots
@@ -86,21 +110,36 @@ class StagePipeline:
                     st.wait_event(self.done[i + 1][s])            # the slot's previous batch has left the next stage
                 else:
                     st.wait_event(self.done[i][s])
+                    if self.tail is not None and self._tail_ran[s]:
+                        st.wait_event(self.tail_done[s])          # the slot's previous batch has left the eager tail
                 if i == 0 and x is not self.inputs[s]:
                     self.inputs[s].copy_(x, non_blocking=True)
                 self.graphs[i][s].replay()
                 self.done[i][s].record(st)
+        if self.tail is not None:
+            prev, self._tail_pending = self._tail_pending, s
+            if prev is not None:
+                self._run_tail(prev)                              # one batch behind: its host reads overlap this batch's graphs
         return s
 
     def wait(self, slot):
         """Block the CALLER'S stream (not the host) until `results[slot]` is complete; returns the results."""
+        if self.tail is not None:
+            if self._tail_pending == slot:
+                self._run_tail(slot)
+                self._tail_pending = None
+            torch.cuda.current_stream(self.dev).wait_event(self.tail_done[slot])
+            return self.results[slot]
         torch.cuda.current_stream(self.dev).wait_event(self.done[-1][slot])
         return self.results[slot]
 
     def flush(self):
         """Make the caller's stream wait for everything submitted so far."""
         cur = torch.cuda.current_stream(self.dev)
-        for st in self.streams:
+        if self.tail is not None and self._tail_pending is not None:
+            self._run_tail(self._tail_pending)
+            self._tail_pending = None
+        for st in self.streams + ([self.tail_stream] if self.tail is not None else []):
             cur.wait_stream(st)
 
 
@@ -109,6 +148,16 @@ def detector_pipeline(model, example, metas, stages=3, defer_tail=True, **decode
     3 stages = (backbone | head encode | decode + post-processing). `defer_tail` moves the K / V projections and the
     mask-feature packing from the encode stage (the longer one) to the head of the decode stage."""
     head = model.panoptic_head
+    if getattr(model.panoptic_fusion_head, 'panoptic_mode', False):
+        # panoptic post-processing reads data-dependent sizes on the host (kept queries, segment areas): the graph stages end with
+        # the query decoder, the fusion head runs eagerly one batch behind (`StagePipeline(tail=...)`)
+        post = lambda out: model.stage_post(out, metas, **decode_kwargs)      # noqa: E731
+        if stages in (2, 4):
+            fns = [lambda x: model.stage_encode(x, defer_tail=defer_tail), lambda enc: model.stage_head(enc, metas, **decode_kwargs)]
+        else:
+            fns = [model.extract_feat, lambda f: head._encode(f, defer_tail=defer_tail),
+                   lambda enc: model.stage_head(enc, metas, **decode_kwargs)]
+        return StagePipeline(fns, example, tail=post)
     if stages == 2:
         fns = [lambda x: model.stage_encode(x, defer_tail=defer_tail),
                lambda enc: model.stage_decode(enc, metas, **decode_kwargs)]
