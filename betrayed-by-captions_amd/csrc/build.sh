@@ -10,7 +10,7 @@ OBJS=""
 pids=""
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/cgg_common.h" -nt "$o" ] || [ "$HERE/x3.h" -nt "$o" ] || [ "$HERE/../../include/cgg_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/cgg_common.h" -nt "$o" ] || [ "$HERE/x3.h" -nt "$o" ] || [ "$HERE/msda_common.h" -nt "$o" ] || [ "$HERE/../../include/cgg_hip.h" -nt "$o" ]; then
     # a source may ask for extra compiler flags on a "// build-flags: ..." line (e.g. the MFMA VGPR form)
     extra="$(grep -m1 '^// build-flags:' "$f" | sed 's|^// build-flags:||')"
     $HIPCC $FLAGS $extra -c "$f" -o "$o" &

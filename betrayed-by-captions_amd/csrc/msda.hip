@@ -9,55 +9,7 @@
 //   * the 1-KiB output row leaves as one contiguous store per wave.
 // Blocks are remapped so that each XCD walks ONE contiguous range of queries (row-major within a
 // level): its private 4-MiB L2 then only has to hold a spatial band of every value level.
-#include "cgg_common.h"
-
-struct MsdaLevels {
-  int h[8];
-  int w[8];
-  int start[8];
-};
-
-__device__ __forceinline__ f32x4 cgg_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 cgg_ld4(const uint16_t* p) {
-  const uint2 u = *reinterpret_cast<const uint2*>(p);
-  f32x4 r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-             __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-  return r;
-}
-
-// Four corner addresses (clamped into the map) + four weights (zeroed outside) of one sample.
-struct MsdaTap {
-  int o00, o01, o10, o11;  // row index (y*W+x) inside the level
-  float w00, w01, w10, w11;
-  float lh, lw;            // fractional parts (for backward)
-  bool in;                 // sample inside (-1, H) x (-1, W)
-};
-
-__device__ __forceinline__ MsdaTap cgg_msda_tap(float x, float y, int Hl, int Wl) {
-  MsdaTap t;
-  const float him = y * (float)Hl - 0.5f;
-  const float wim = x * (float)Wl - 0.5f;
-  t.in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
-  const float hf = floorf(him), wf = floorf(wim);
-  const int h0 = (int)hf, w0 = (int)wf;
-  const int h1 = h0 + 1, w1 = w0 + 1;
-  t.lh = him - hf;
-  t.lw = wim - wf;
-  const float hh = 1.f - t.lh, hw = 1.f - t.lw;
-  const bool vh0 = t.in && h0 >= 0, vh1 = t.in && h1 <= Hl - 1;
-  const bool vw0 = w0 >= 0, vw1 = w1 <= Wl - 1;
-  t.w00 = (vh0 && vw0) ? hh * hw : 0.f;
-  t.w01 = (vh0 && vw1) ? hh * t.lw : 0.f;
-  t.w10 = (vh1 && vw0) ? t.lh * hw : 0.f;
-  t.w11 = (vh1 && vw1) ? t.lh * t.lw : 0.f;
-  const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h1, 0), Hl - 1);
-  const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w1, 0), Wl - 1);
-  t.o00 = ch0 * Wl + cw0;
-  t.o01 = ch0 * Wl + cw1;
-  t.o10 = ch1 * Wl + cw0;
-  t.o11 = ch1 * Wl + cw1;
-  return t;
-}
+#include "msda_common.h"
 
 __device__ __forceinline__ float msda_x(float v) { return v; }
 __device__ __forceinline__ float msda_x(uint16_t v) { return cgg_bf2f(v); }
@@ -711,337 +663,6 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
   }
 }
 
-// Tiled backward for the encoder's self-attention case (queries == the pixels of the value pyramid, integer
-// scale between levels): one block = (image-space tile, batch, head). The tile is c x c pixels of the coarsest
-// level and the co-located (c*s_l)^2 pixels of every finer level, so ALL its queries sample around the same
-// image region. grad_value is accumulated in LDS windows (tile footprint + R-pixel halo per level) and leaves the
-// block ONCE per window element as line-coalesced global f32 atomics; taps that fall outside the windows (large
-// learned offsets) go straight to global atomics, so the result does not depend on the locality assumption --
-// only the speed does.
-//
-// The LDS accumulators are 64-bit FIXED POINT, not f32: measured on MI355X, ds_add_f32 retires ~0.3 lane-ops per
-// clock per CU (the f32 version of this kernel took 21.5 ms per layer at configs[2] shapes, 18 ms of it in the
-// LDS atomics) while ds_add_u64 runs at the integer rate (4.7 ms for the same work). Every contribution
-// x = corner_weight * attn_weight * grad_out is scaled by 2^k, k chosen per block from max|attn_weight| *
-// max|grad_out| over the tile so that the worst-case sum of all the tile's taps stays below 2^51, and converted
-// with the 1.5*2^52 magic-number add: resolution 2^-40 of the tile's largest contribution (finer than f32), and
-// the in-window sum is order-independent, i.e. deterministic. A tile whose bound is 0, Inf or NaN skips the
-// windows (all its taps use the global f32 atomics, which propagate non-finite values as the reference does).
-struct MsdaTilePlan {
-  int c, R, tx, ty, ntile;
-  int s[8];      // W_l / W_coarse
-  int ww[8];     // window width  = c*s + 2R
-  int off[8];    // element offset of level l's window in LDS
-  int total;     // window elements (8 B each)
-  int kbase;     // 50 - ceil(log2(max taps per tile))
-  int nthreads;
-  int dsub;      // channels of a head per workgroup (scatter-only form: D / dsub workgroups share a (tile, image, head))
-};
-
-// SO (scatter only) = true: grad_value only -- no value loads, no channel reductions; grad_loc / grad_attn come from
-// cgg_msda_bwd_kernel<P, false> at full occupancy (round 4: the fused form waited 59 % of its wave cycles on the corner gathers
-// with ONE 12-wave workgroup per CU -- the windows take the LDS -- and ran 6x slower than the forward's gather of the same taps)
-template <int P_, bool SO = false>
-__global__ __launch_bounds__(768) void cgg_msda_bwd_tiled_kernel(
-    const float* __restrict__ value, MsdaLevels lv, MsdaTilePlan pl, const float* __restrict__ loc,
-    const float* __restrict__ attw, const float* __restrict__ gout, float* __restrict__ gvalue,
-    float* __restrict__ gloc, float* __restrict__ gattw, int Nv, int H, int D, int L, int Nq, int Prt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long win[];
-  __shared__ float red[2][16];
-  const int P = P_ > 0 ? P_ : Prt;
-  constexpr int PC = P_ > 0 ? P_ : 1;   // points per load batch
-  const int DS = pl.dsub;               // this workgroup's channel slice of the head
-  const int DQ = DS >> 2;
-  const int nsub = D / DS;
-  // window pixel stride in 8-byte elements: DS + 2, NOT DS -- with D = 32 a pixel's channels fill exactly one 256-byte LDS bank row,
-  // so the same channel of ANY two pixels shared a bank and the 8 queries of a wave conflicted 8 ways on every ds_add_u64
-  // (PMC, round 4: SQ_LDS_BANK_CONFLICT = 58 % of SQ_LDS_IDX_ACTIVE)
-  const int DP = DS + 2;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
-  const int cbase = (bid % nsub) * DS;
-  const int tile = (bid / nsub) % pl.ntile;
-  const int h = (bid / (nsub * pl.ntile)) % H;
-  const int b = bid / (nsub * pl.ntile * H);
-  const int tyi = tile / pl.tx, txi = tile % pl.tx;
-  for (int i = tid; i < pl.total; i += nth) win[i] = 0ull;
-
-  const size_t rowstride = (size_t)H * D;
-  const int LP = L * P;
-  // slots of the tile, all query levels flattened: slot -> (query level, pixel in the tile rect, channel quad)
-  __shared__ int nsl[8], tw[8], x0[8], y0[8];
-  int nslots = 0;
-  for (int l = 0; l < L; ++l) {
-    const int e = pl.c * pl.s[l];
-    const int xx = txi * e, yy = tyi * e;
-    const int tww = min(e, lv.w[l] - xx);
-    const int ns = tww * min(e, lv.h[l] - yy) * DQ;
-    if (tid == 0) {
-      x0[l] = xx;
-      y0[l] = yy;
-      tw[l] = tww;
-      nsl[l] = ns;
-    }
-    nslots += ns;
-  }
-  __syncthreads();
-  const int nround = (nslots + 63) & ~63;
-
-  // ---- pass 0: bound M >= |attn_weight * grad_out| over the tile -> fixed-point scale 2^k ----
-  float mg = 0.f, mw = 0.f;
-  bool bad = false;
-  for (int sl = tid; sl < nslots; sl += nth) {
-    int lq = 0, r = sl;
-    while (r >= nsl[lq]) { r -= nsl[lq]; ++lq; }
-    const int qi = r / DQ, cq = r % DQ;
-    const int n = lv.start[lq] + (y0[lq] + qi / tw[lq]) * lv.w[lq] + x0[lq] + qi % tw[lq];
-    const long long bq = (long long)b * Nq + n;
-    const f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + (size_t)h * D + cbase + cq * 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      mg = fmaxf(mg, fabsf(g[c]));
-      bad |= !(fabsf(g[c]) <= 3.0e38f);
-    }
-    const float* wp = attw + ((size_t)bq * H + h) * LP;
-    for (int i = cq; i < LP; i += DQ) {
-      mw = fmaxf(mw, fabsf(wp[i]));
-      bad |= !(fabsf(wp[i]) <= 3.0e38f);
-    }
-  }
-  if (bad) mg = __builtin_inff();
-  for (int o = 32; o > 0; o >>= 1) {
-    mg = fmaxf(mg, __shfl_xor(mg, o));
-    mw = fmaxf(mw, __shfl_xor(mw, o));
-  }
-  if ((tid & 63) == 0) {
-    red[0][tid >> 6] = mg;
-    red[1][tid >> 6] = mw;
-  }
-  __syncthreads();   // also orders the window zero-fill before the first ds_add
-  mg = 0.f;
-  mw = 0.f;
-  for (int i = 0; i < (nth >> 6); ++i) {
-    mg = fmaxf(mg, red[0][i]);
-    mw = fmaxf(mw, red[1][i]);
-  }
-  const float M = mg * mw;
-  const bool use_lds = (M > 0.f) && (M <= 3.0e38f);
-  int kexp = 0;
-  if (use_lds) {
-    int e;
-    (void)frexpf(M, &e);              // M < 2^e
-    kexp = pl.kbase - e;              // |x * 2^k| < 2^kbase; sum over <= 2^(50-kbase) taps < 2^50
-  }
-  const double scale = ldexp(1.0, kexp);
-  const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
-
-  for (int sl = tid; sl < nround; sl += nth) {      // wave-uniform trip count (nth % 64 == 0)
-    const bool live = sl < nslots;
-    int lq = 0, r = live ? sl : 0;
-    while (r >= nsl[lq]) { r -= nsl[lq]; ++lq; }
-    const int qi = r / DQ, cq = r % DQ;
-    const int n = lv.start[lq] + (y0[lq] + qi / tw[lq]) * lv.w[lq] + x0[lq] + qi % tw[lq];
-    const long long bq = (long long)b * Nq + n;
-    const size_t coff = (size_t)h * D + cbase + cq * 4;
-    const float* vb = value + (size_t)b * Nv * rowstride + coff;
-    float* gvb = gvalue + (size_t)b * Nv * rowstride + coff;
-    const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
-    const float* wp = attw + ((size_t)bq * H + h) * LP;
-    float* glp = gloc + ((size_t)bq * H + h) * LP * 2;
-    float* gwp = gattw + ((size_t)bq * H + h) * LP;
-    f32x4 g = cgg_ld4(gout + (size_t)bq * rowstride + coff);
-    if (!live) g = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < L; ++l) {
-      const int Hl = lv.h[l], Wl = lv.w[l];
-      const float* vl = vb + (size_t)lv.start[l] * rowstride;
-      float* gvl = gvb + (size_t)lv.start[l] * rowstride;
-      const int ox = txi * pl.c * pl.s[l] - pl.R, oy = tyi * pl.c * pl.s[l] - pl.R;
-      const int ww = use_lds ? pl.ww[l] : 0;           // ww == 0: every tap takes the global path
-      unsigned long long* wl = win + pl.off[l] + cq * 4;
-      // all P_ points of this level: geometry + the 4*P_ corner loads are issued before any use, so one
-      // L2 round trip covers the level instead of P_ dependent ones
-      for (int p0 = 0; p0 < P; p0 += PC) {
-        f32x4 v[PC][4];
-        float lh[PC], lw[PC], wt[PC];
-        int h0[PC], w0[PC];
-        bool k[PC][4];
-        int ro[PC][4];
-        // P_ == 4: the level's 4 + 8 grad_attn / grad_loc values of this (query, head) leave as three 16-byte read-modify-writes
-        // whose reads are requested HERE, with the corner loads (the per-point `+=` was a dependent global load -> add -> store
-        // chain, 36 per (query, head), that stalled all 64 lanes of the wave each time)
-        const bool owner = !SO && live && cq == 0;
-        f32x4 ow = {0.f, 0.f, 0.f, 0.f}, ol0 = ow, ol1 = ow;
-        if (P_ == 4 && owner) {
-          ow = cgg_ld4(gwp + 4 * l);
-          ol0 = cgg_ld4(glp + 8 * l);
-          ol1 = cgg_ld4(glp + 8 * l + 4);
-        }
-#pragma unroll
-        for (int p = 0; p < PC; ++p) {
-          const int i = l * P + p0 + p;
-          const float x = lp[2 * i], y = lp[2 * i + 1];
-          wt[p] = wp[i];
-          const float him = y * (float)Hl - 0.5f, wim = x * (float)Wl - 0.5f;
-          const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
-          const float hf = floorf(him), wf = floorf(wim);
-          h0[p] = (int)hf;
-          w0[p] = (int)wf;
-          lh[p] = him - hf;
-          lw[p] = wim - wf;
-          const bool vh0 = in && h0[p] >= 0, vh1 = in && (h0[p] + 1) <= Hl - 1;
-          const bool vw0 = w0[p] >= 0, vw1 = (w0[p] + 1) <= Wl - 1;
-          k[p][0] = vh0 && vw0; k[p][1] = vh0 && vw1; k[p][2] = vh1 && vw0; k[p][3] = vh1 && vw1;
-          const int ch0 = min(max(h0[p], 0), Hl - 1), ch1 = min(max(h0[p] + 1, 0), Hl - 1);
-          const int cw0 = min(max(w0[p], 0), Wl - 1), cw1 = min(max(w0[p] + 1, 0), Wl - 1);
-          ro[p][0] = ch0 * Wl + cw0; ro[p][1] = ch0 * Wl + cw1; ro[p][2] = ch1 * Wl + cw0; ro[p][3] = ch1 * Wl + cw1;
-          if (!SO) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[p][q] = cgg_ld4(vl + (size_t)ro[p][q] * rowstride);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < PC; ++p) {
-          const int i = l * P + p0 + p;
-          const float hh = 1.f - lh[p], hw = 1.f - lw[p];
-          float dotv = 0.f, dotx = 0.f, doty = 0.f;
-          if (!SO) {
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v00 = k[p][0] ? v[p][0] : z4, v01 = k[p][1] ? v[p][1] : z4;
-            const f32x4 v10 = k[p][2] ? v[p][2] : z4, v11 = k[p][3] ? v[p][3] : z4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float val = hh * hw * v00[c] + hh * lw[p] * v01[c] + lh[p] * hw * v10[c] + lh[p] * lw[p] * v11[c];
-              const float dw = hh * (v01[c] - v00[c]) + lh[p] * (v11[c] - v10[c]);
-              const float dh = hw * (v10[c] - v00[c]) + lw[p] * (v11[c] - v01[c]);
-              dotv += val * g[c];
-              dotx += dw * g[c];
-              doty += dh * g[c];
-            }
-            for (int o = 1; o < DQ; o <<= 1) {
-              dotv += __shfl_xor(dotv, o);
-              dotx += __shfl_xor(dotx, o);
-              doty += __shfl_xor(doty, o);
-            }
-          }
-          if (SO) {
-          } else if (P_ == 4) {
-            ow[p] += dotv;
-            if (p < 2) {
-              ol0[2 * p] += (float)Wl * wt[p] * dotx;
-              ol0[2 * p + 1] += (float)Hl * wt[p] * doty;
-            } else {
-              ol1[2 * p - 4] += (float)Wl * wt[p] * dotx;
-              ol1[2 * p - 3] += (float)Hl * wt[p] * doty;
-            }
-          } else if (live && cq == 0) {
-            // grad_loc / grad_attn follow the accumulate-into-prezeroed contract of the C ABI
-            gwp[i] += dotv;
-            glp[2 * i] += (float)Wl * wt[p] * dotx;
-            glp[2 * i + 1] += (float)Hl * wt[p] * doty;
-          }
-          if (live) {
-            const f32x4 wg = wt[p] * g;
-            double wgd[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) wgd[c] = (double)wg[c] * scale;
-            const int wy0 = h0[p] - oy, wx0 = w0[p] - ox;      // window coords of corner (h0, w0)
-            const bool iy0 = (unsigned)wy0 < (unsigned)ww, iy1 = (unsigned)(wy0 + 1) < (unsigned)ww;
-            const bool ix0 = (unsigned)wx0 < (unsigned)ww, ix1 = (unsigned)(wx0 + 1) < (unsigned)ww;
-#define CGG_SCATTER(K, HY, WX, IY, IX, RO, WT)                                                         \
-  if (K) {                                                                                              \
-    const float cw_ = (WT);                                                                             \
-    if ((IY) && (IX)) {                                                                                 \
-      unsigned long long* d = wl + (size_t)((HY) * ww + (WX)) * DP;                                     \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                   \
-        const double m_ = fma((double)cw_, wgd[c], kMagic);                                             \
-        atomicAdd(d + c, (unsigned long long)(__double_as_longlong(m_) - __double_as_longlong(kMagic))); \
-      }                                                                                                 \
-    } else {                                                                                            \
-      float* d = gvl + (size_t)(RO) * rowstride;                                                        \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) atomicAdd(d + c, cw_ * wg[c]);                      \
-    }                                                                                                   \
-  }
-            CGG_SCATTER(k[p][0], wy0, wx0, iy0, ix0, ro[p][0], hh * hw)
-            CGG_SCATTER(k[p][1], wy0, wx0 + 1, iy0, ix1, ro[p][1], hh * lw[p])
-            CGG_SCATTER(k[p][2], wy0 + 1, wx0, iy1, ix0, ro[p][2], lh[p] * hw)
-            CGG_SCATTER(k[p][3], wy0 + 1, wx0 + 1, iy1, ix1, ro[p][3], lh[p] * lw[p])
-#undef CGG_SCATTER
-          }
-        }
-        if (P_ == 4 && owner) {
-          *reinterpret_cast<f32x4*>(gwp + 4 * l) = ow;
-          *reinterpret_cast<f32x4*>(glp + 8 * l) = ol0;
-          *reinterpret_cast<f32x4*>(glp + 8 * l + 4) = ol1;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (!use_lds) return;
-  // flush: one global atomic per touched window element, 128-B lines per 32 lanes
-  const double inv = ldexp(1.0, -kexp);
-  for (int l = 0; l < L; ++l) {
-    const int Wl = lv.w[l], ww = pl.ww[l];
-    const int ox = txi * pl.c * pl.s[l] - pl.R, oy = tyi * pl.c * pl.s[l] - pl.R;
-    float* gvl = gvalue + ((size_t)b * Nv + lv.start[l]) * rowstride + (size_t)h * D + cbase;
-    const unsigned long long* wl = win + pl.off[l];
-    const int nf = ww * ww * DS;
-    for (int i = tid; i < nf; i += nth) {
-      const int px = i / DS, ch = i - px * DS;
-      const long long a = (long long)wl[px * DP + ch];
-      if (a != 0) {
-        const int iy = oy + px / ww, ix = ox + px % ww;      // inside the image whenever a != 0
-        atomicAdd(gvl + (size_t)(iy * Wl + ix) * rowstride + ch, (float)((double)a * inv));
-      }
-    }
-  }
-}
-
-// Choose (c, R) so that the windows fit in LDS; returns false if the pyramid is not tileable.
-static bool msda_tile_plan(const MsdaLevels& lv, int L, int D, int P, int Nq, int Nv, MsdaTilePlan* pl, int dsub) {
-  if (Nq != Nv || L < 1 || L > 8) return false;
-  int lc = 0;
-  long long tot = 0;
-  for (int l = 0; l < L; ++l) {
-    if (lv.w[l] < lv.w[lc]) lc = l;
-    tot += (long long)lv.h[l] * lv.w[l];
-  }
-  if (tot != Nv) return false;
-  for (int l = 0; l < L; ++l) {
-    if (lv.w[l] % lv.w[lc] || lv.h[l] % lv.h[lc] || lv.w[l] / lv.w[lc] != lv.h[l] / lv.h[lc]) return false;
-    pl->s[l] = lv.w[l] / lv.w[lc];
-  }
-  const int cand[4][2] = {{2, 4}, {2, 3}, {1, 3}, {1, 2}};
-  for (int k = 0; k < 4; ++k) {
-    const int c = cand[k][0], R = cand[k][1];
-    long long f = 0, nq = 0;
-    for (int l = 0; l < L; ++l) {
-      pl->ww[l] = c * pl->s[l] + 2 * R;
-      pl->off[l] = (int)f;
-      f += (long long)pl->ww[l] * pl->ww[l] * (dsub + 2);    // pixel stride dsub + 2 (bank spreading, see the kernel)
-      nq += (long long)c * pl->s[l] * c * pl->s[l];
-    }
-    if (f * 8 <= (dsub == D ? 144 * 1024 : 160 * 1024 * dsub / D)) {
-      pl->dsub = dsub;
-      pl->c = c;
-      pl->R = R;
-      pl->tx = (lv.w[lc] + c - 1) / c;
-      pl->ty = (lv.h[lc] + c - 1) / c;
-      pl->ntile = pl->tx * pl->ty;
-      pl->total = (int)f;
-      long long taps = nq * L * P;       // upper bound of contributions to one window element
-      int hr = 0;
-      while ((1ll << hr) < taps) ++hr;
-      pl->kbase = 50 - hr;
-      const long long slots = nq * (dsub / 4);
-      long long nt = (slots + 63) / 64 * 64;
-      pl->nthreads = (int)(nt < 64 ? 64 : (nt > 768 ? 768 : nt));
-      return pl->kbase >= 24;
-    }
-  }
-  return false;
-}
-
 // -------------------------------------------------------------------------------------------------
 static int msda_read_levels(const int64_t* spatial_shapes, const int64_t* level_start, int L,
                             int Nv, hipStream_t s, MsdaLevels* lv, const char* who) {
@@ -1210,6 +831,10 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
                          P, value_dtype, fused != 0, (hipStream_t)stream);
 }
 
+static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
+                           const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
+                           int L, int Nq, int P, hipStream_t s);
+
 extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shapes,
                                  const int64_t* level_start, const float* sampling_loc,
                                  const float* attn_weight, const float* grad_out, float* grad_value,
@@ -1227,44 +852,35 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
   hipStream_t s = (hipStream_t)stream;
   rc = msda_read_levels(spatial_shapes, level_start, L, Nv, s, &lv, "cgg_msda_backward");
   if (rc) return rc;
-  MsdaTilePlan pl;
-  // split backward (default; CGG_MSDA_BWD_FUSED=1 = the one-kernel form, A/B only): grad_loc / grad_attn by the gather kernel at
-  // full occupancy, grad_value by the tiled kernel in scatter-only form
-  static const bool fused = getenv("CGG_MSDA_BWD_FUSED") != nullptr;
-  // scatter-only form: a (tile, image, head) is shared by D / 16 workgroups that own 16 channels each -- the lanes' tap geometry is
-  // per lane either way, the windows shrink to 72 KB so two workgroups fit a CU (3.65 -> 3.43 ms at configs[2] shapes; 8-channel
-  // slices: 4.9 ms, the flush falls apart into 32-B pieces). The scatter loop itself is bound by the LDS atomic unit (~4 ds_add_u64
-  // lanes per clock per CU measured: 4.2 G adds = 1.8 ms), which co-residency does not change
-  const int dsub = (!fused && D % 16 == 0) ? 16 : D;
-  if (D % 4 == 0 && msda_tile_plan(lv, L, D, P, Nq, Nv, &pl, dsub)) {
-    const size_t lds = (size_t)pl.total * sizeof(unsigned long long);
-    const int nblk = B * H * pl.ntile * (D / dsub);
-    if (!fused) {
-      const long long total = (long long)B * Nq * H * DQ;
-      const int nb = (int)((total + 255) / 256);
-      if (P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn))
-        hipLaunchKernelGGL(cgg_msda_bwd_gather4_kernel, dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
-                           grad_loc, grad_attn, Nv, H, D, L, Nq, total);
-      else if (P == 4)
-        hipLaunchKernelGGL((cgg_msda_bwd_kernel<4, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
-                           grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
-      else
-        hipLaunchKernelGGL((cgg_msda_bwd_kernel<0, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
-                           grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
-      CGG_CHECK_LAUNCH("cgg_msda_backward(gather)");
-    }
-    auto kern = fused ? ((P == 4) ? cgg_msda_bwd_tiled_kernel<4, false> : cgg_msda_bwd_tiled_kernel<0, false>)
-                      : ((P == 4) ? cgg_msda_bwd_tiled_kernel<4, true> : cgg_msda_bwd_tiled_kernel<0, true>);
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(pl.nthreads), lds, s, value, lv, pl, sampling_loc, attn_weight, grad_out,
-                       grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P);
-    CGG_CHECK_LAUNCH("cgg_msda_backward(tiled)");
+  return msda_bwd_launch(value, lv, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv, H, D, L, Nq, P, s);
+}
+
+// Split backward: grad_value by the sorted-scatter kernel (msda_bwd.hip) when the pyramid is tileable (the encoder's
+// self-attention: queries == pixels of the value pyramid), grad_loc / grad_attn by the gather kernel at full occupancy; any other
+// geometry: the generic one-kernel form with global f32 atomics for grad_value.
+static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
+                           const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
+                           int L, int Nq, int P, hipStream_t s) {
+  const int DQ = D / 4;
+  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
+  int rc = generic_only ? CGG_EUNSUPPORTED
+                        : msda_bwd_sorted_launch(lv, sampling_loc, attn_weight, grad_out, grad_value, B, Nv, H, D, L, Nq, P, s);
+  if (rc == CGG_OK) {
+    const long long total = (long long)B * Nq * H * DQ;
+    const int nb = (int)((total + 255) / 256);
+    if (P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn))
+      hipLaunchKernelGGL(cgg_msda_bwd_gather4_kernel, dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
+                         grad_loc, grad_attn, Nv, H, D, L, Nq, total);
+    else if (P == 4)
+      hipLaunchKernelGGL((cgg_msda_bwd_kernel<4, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
+                         grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+    else
+      hipLaunchKernelGGL((cgg_msda_bwd_kernel<0, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
+                         grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+    CGG_CHECK_LAUNCH("cgg_msda_backward(gather)");
     return CGG_OK;
   }
+  if (rc != CGG_EUNSUPPORTED) return rc;
   const long long total = (long long)B * Nq * H * DQ;
   const int nblk = (int)((total + 255) / 256);
   if (P == 4)
@@ -1275,6 +891,30 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
                        attn_weight, grad_out, grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
   CGG_CHECK_LAUNCH("cgg_msda_backward");
   return CGG_OK;
+}
+
+// cgg_msda_backward with the level table from the HOST (level_hw = [h0, w0, h1, w1, ...], level_start): no device->host copy and
+// no stream synchronisation per call (the mmcv-contract entry point above reads its int64 device tensors back, once per call --
+// six stalls per training step in the encoder's backward), graph-capturable.
+extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start,
+                                            const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                            float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
+                                            int Nq, int P, cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_backward_hostlevels", value, sampling_loc, attn_weight, grad_out, B, Nv, H, D, L, Nq, P, CGG_F32);
+  if (rc) return rc;
+  CGG_REQUIRE(level_hw && level_start && grad_value && grad_loc && grad_attn, CGG_EINVAL, "cgg_msda_backward_hostlevels: null pointer");
+  const int DQ = D / 4;
+  CGG_REQUIRE((DQ & (DQ - 1)) == 0 && DQ <= 64, CGG_EUNSUPPORTED, "cgg_msda_backward_hostlevels: D/4=%d must be a power of two <= 64", DQ);
+  MsdaLevels lv;
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = level_start[l];
+    CGG_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0 && lv.start[l] >= 0 && (long long)lv.start[l] + (long long)lv.h[l] * lv.w[l] <= Nv,
+                CGG_EINVAL, "cgg_msda_backward_hostlevels: level %d does not fit Nv=%d", l, Nv);
+  }
+  return msda_bwd_launch(value, lv, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv, H, D, L, Nq, P,
+                         (hipStream_t)stream);
 }
 
 // Throughput-mode encoder stream: bf16 value, bf16 raw [offsets | logits] rows (a bf16 GEMM's output), bf16 output

@@ -137,6 +137,25 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_locations, 
     return gv, gl, gw
 
 
+def msda_backward_hostlevels(value, level_hw, level_start, sampling_locations, attention_weights, grad_output):
+    """`msda_backward` with the level table as host integers: no device tensors for the shapes, no read-back / stream
+    synchronisation inside the call (csrc/msda.hip `cgg_msda_backward_hostlevels`)."""
+    B, Nv, H, D, L, Nq, P = _msda_dims(value, sampling_locations)
+    gv = torch.zeros_like(value)
+    gl = torch.zeros_like(sampling_locations)
+    gw = torch.zeros_like(attention_weights)
+    nbytes = 4.0 * (2 * value.numel() + 2 * sampling_locations.numel() + 2 * attention_weights.numel() + grad_output.numel())
+    hw = _int_array([v for pair in level_hw for v in pair])
+    st = _int_array(level_start)
+    with _timed('msda_backward', bytes=nbytes, flops=0.0, shape=(B, Nq, H, D, L, P)):
+        rc = _lib_().cgg_msda_backward_hostlevels(
+            dev_ptr(value, 'value', torch.float32), hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
+            dev_ptr(attention_weights, 'attention_weights', torch.float32), dev_ptr(grad_output, 'grad_output', torch.float32),
+            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, stream_ptr(value.device))
+    check(rc, 'cgg_msda_backward_hostlevels')
+    return gv, gl, gw
+
+
 class MultiScaleDeformableAttnFunction(torch.autograd.Function):
     """Drop-in for [3P] mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction
     (same positional signature incl. the unused im2col_step)."""
@@ -183,9 +202,7 @@ class MSDeformAttnRowsFunction(torch.autograd.Function):
         aw = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=value.device)
         check(_lib_().cgg_msda_prologue(dev_ptr(rows, 'rows', torch.float32), ld, dev_ptr(ref_points, 'ref', torch.float32), hw,
                                         dev_ptr(loc), dev_ptr(aw), B, Nq, H, L, P, stream_ptr(value.device)), 'cgg_msda_prologue')
-        shapes = torch.tensor(level_hw, dtype=torch.int64, device=value.device)
-        starts = torch.tensor(level_start, dtype=torch.int64, device=value.device)
-        gv, gl, gw = msda_backward(value, shapes, starts, loc, aw, grad_out.contiguous())
+        gv, gl, gw = msda_backward_hostlevels(value, level_hw, level_start, loc, aw, grad_out.contiguous())
         grows = torch.empty_like(rows)
         check(_lib_().cgg_msda_prologue_backward(dev_ptr(gl), dev_ptr(gw), dev_ptr(rows), ld, hw, dev_ptr(grows), B, Nq, H, L, P,
                                                  stream_ptr(value.device)), 'cgg_msda_prologue_backward')
