@@ -635,27 +635,38 @@ def einsum_q_sweep(dev, B, H, W):
     res = []
     for Q in (100, 200):
         emb = torch.randn(B, Q, 256, generator=g).to(dev)
-        for mode, split in (('bf16 MFMA, f32 logits out', False), ('f32-class f16 x 3 MFMA, f32 logits out', True)):
+        # `fused` = the consumer in the epilogue, logits NEVER stored: the full-resolution contraction with the attention-mask rule
+        # (mask2former_head.py:749-759: threshold) applied to the accumulators, one bit per (query, pixel) out -- the form SURVEY 7
+        # names as the only one that can approach the MFMA roofline (the stored-f32-logits form is HBM-bound at AI = 56-100 FLOP/B).
+        # 10 back-to-back calls per sample = the 10 forward_head calls of a forward (the 67-MB bf16 feature stays cache-resident)
+        for mode, split, fused in (('bf16 MFMA, f32 logits out', False, False), ('f32-class f16 x 3 MFMA, f32 logits out', True, False),
+                                   ('bf16 MFMA, consumer fused: threshold bits out, logits never stored', False, True),
+                                   ('f32-class f16 x 3 MFMA, consumer fused: threshold bits out, logits never stored', True, True)):
             with runtime.precision_scope('fp32' if split else 'bf16'):
                 packed = ops.pack_mask_feature(feat, 1, split)
+                if split:
+                    packed.f32 = None                      # the f16 x 3 kernel (the exact-f32 path keeps an un-packed copy)
+                call = (lambda: ops.mask_logits(emb, packed, want_logits=False, want_bits=True)) if fused else \
+                    (lambda: ops.mask_logits(emb, packed))
                 for _ in range(5):
-                    ops.mask_logits(emb, packed)
+                    call()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 for _ in range(20):
-                    ops.mask_logits(emb, packed)
+                    call()
                 e.record()
                 torch.cuda.synchronize()
             ms = s.elapsed_time(e) / 20
             fl = 2.0 * B * Q * 256 * HW4
-            by = B * (256 * HW4 * (4 if split else 2) + Q * 256 * 4 + Q * HW4 * 4)
+            by = B * (256 * HW4 * (4 if split else 2) + Q * 256 * 4 + (Q * HW4 // 8 if fused else Q * HW4 * 4))
             peak = X3_PEAK_TF if split else MFMA_BF16_PEAK_TF
             tf = fl / (ms * 1e-3) / 1e12
             ai = fl / by
             res.append(dict(queries=Q, mode=mode, launch_ms=ms, tflops=tf, frac_mfma_peak=tf / peak, mfma_peak_tf=peak,
                             frac_hbm_roofline_attainable=tf / min(peak, ai * HBM_PEAK_GBS / 1e3), GBs=by / (ms * 1e-3) / 1e9,
-                            frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, launches_q_split=2 if (split and Q > 128) else 1))
+                            frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=by, flops=fl,
+                            arithmetic_intensity=ai, launches_q_split=2 if (split and Q > 128) else 1))
     # what this device's memory system delivers to a pure read + write stream of the same size class (torch device copy, 128 MiB
     # in + 128 MiB out): the practical ceiling the `GBs` figures above sit under (the 8 TB/s of `frac_hbm_peak` is the pin rate)
     src = torch.empty(32 << 20, dtype=torch.float32, device=dev).normal_()

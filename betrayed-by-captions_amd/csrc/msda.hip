@@ -569,6 +569,13 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
 // weights arrive as three 16-byte loads, the 16 corner loads of its 4 points are all in flight before the first use, and the
 // results leave as three 16-byte read-modify-writes whose reads were requested with the corner loads (the generic kernel's per-point
 // scalar loads and `+=` chains ran this half at 2.3 ms per layer at configs[2]; the forward gathers the same taps in 0.16 ms x 6).
+// ACC = false (round 5, the autograd path): grad_loc / grad_attn are WRITTEN, not accumulated -- no read of the old values, no
+// zero-fill before the call (the accumulate contract of the mmcv entry point costs 0.4 GB of reads + 0.4 GB of fills per call at
+// configs[2] shapes). PATCH = true (H == 8, D == 32, queries == pixels of a pyramid whose levels tile [0, Nq), w % 8, h % 4,
+// start % 32 == 0): a block = ONE head of an 8 x 4 pixel patch of a level, the 8 heads of a patch in adjacent blocks -- the
+// corner lines of neighbouring queries' taps are shared in L1 / L2 as in the forward's 2-D mapping, and the 8 blocks of a patch read
+// the same loc / weight / grad_out rows.
+template <bool ACC, bool PATCH>
 __global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ gout, float* __restrict__ gloc, float* __restrict__ gattw, int Nv, int H, int D, int L, int Nq,
@@ -576,11 +583,26 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
   const int DQ = D >> 2;
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
   const long long gid = (long long)bid * 256 + threadIdx.x;
-  const bool live = gid < total;
+  bool live = gid < total;
   const long long g2 = live ? gid : total - 1;  // keep every lane in the shuffles
-  const int cq = (int)(g2 % DQ);
-  const int h = (int)((g2 / DQ) % H);
-  const long long bq = g2 / ((long long)DQ * H);
+  int cq = (int)(g2 % DQ);
+  int h = (int)((g2 / DQ) % H);
+  long long bq = g2 / ((long long)DQ * H);
+  if constexpr (PATCH) {
+    const int t = threadIdx.x;
+    cq = t & 7;
+    h = bid & 7;
+    const int bb = bid >> 3, per_img = Nq >> 5;
+    const int bimg = bb / per_img, bl = bb - bimg * per_img;
+    int l = 0;
+    for (int k = 1; k < L; ++k)
+      if ((bl << 5) >= lv.start[k]) l = k;
+    const int g = bl - (lv.start[l] >> 5), px_n = lv.w[l] >> 3;
+    const int py = g / px_n, px = g - py * px_n;
+    const int pair = t >> 3;
+    bq = (long long)bimg * Nq + lv.start[l] + (4 * py + (pair >> 3)) * lv.w[l] + 8 * px + (pair & 7);
+    live = true;
+  }
   const int b = (int)(bq / Nq);
   const size_t rowstride = (size_t)H * D;
   const size_t coff = (size_t)h * D + cq * 4;
@@ -598,7 +620,7 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
     const float* vl = vb + (size_t)lv.start[l] * rowstride;
     const f32x4 xy0 = cgg_ld4(lp + 8 * l), xy1 = cgg_ld4(lp + 8 * l + 4), w4 = cgg_ld4(wp + 4 * l);
     f32x4 ow = {0.f, 0.f, 0.f, 0.f}, ol0 = ow, ol1 = ow;
-    if (owner) {
+    if (ACC && owner) {
       ow = cgg_ld4(gwp + 4 * l);
       ol0 = cgg_ld4(glp + 8 * l);
       ol1 = cgg_ld4(glp + 8 * l + 4);
@@ -833,7 +855,7 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
 
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
-                           int L, int Nq, int P, hipStream_t s);
+                           int L, int Nq, int P, hipStream_t s, bool overwrite = false);
 
 extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shapes,
                                  const int64_t* level_start, const float* sampling_loc,
@@ -860,7 +882,7 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
 // geometry: the generic one-kernel form with global f32 atomics for grad_value.
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
-                           int L, int Nq, int P, hipStream_t s) {
+                           int L, int Nq, int P, hipStream_t s, bool overwrite) {
   const int DQ = D / 4;
   static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
   int rc = generic_only ? CGG_EUNSUPPORTED
@@ -868,10 +890,22 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
   if (rc == CGG_OK) {
     const long long total = (long long)B * Nq * H * DQ;
     const int nb = (int)((total + 255) / 256);
-    if (P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn))
-      hipLaunchKernelGGL(cgg_msda_bwd_gather4_kernel, dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
-                         grad_loc, grad_attn, Nv, H, D, L, Nq, total);
-    else if (P == 4)
+    if (P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn)) {
+      // 8 x 4 pixel patches of one head per block when the pyramid allows it (see the kernel)
+      bool patch = H == 8 && D == 32 && Nq == Nv && Nq % 32 == 0;
+      long long expect = 0;
+      for (int l = 0; l < L && patch; ++l) {
+        patch = lv.start[l] == expect && lv.w[l] % 8 == 0 && lv.h[l] % 4 == 0 && lv.start[l] % 32 == 0;
+        expect += (long long)lv.h[l] * lv.w[l];
+      }
+      patch = patch && expect == Nq;
+#define CGG_G4(ACC, PATCH)                                                                                                      \
+  hipLaunchKernelGGL((cgg_msda_bwd_gather4_kernel<ACC, PATCH>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, \
+                     grad_out, grad_loc, grad_attn, Nv, H, D, L, Nq, total)
+      if (overwrite) { if (patch) CGG_G4(false, true); else CGG_G4(false, false); }
+      else           { if (patch) CGG_G4(true, true); else CGG_G4(true, false); }
+#undef CGG_G4
+    } else if (P == 4)
       hipLaunchKernelGGL((cgg_msda_bwd_kernel<4, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
                          grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
     else
@@ -899,7 +933,7 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
 extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start,
                                             const float* sampling_loc, const float* attn_weight, const float* grad_out,
                                             float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
-                                            int Nq, int P, cgg_stream_t stream) {
+                                            int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream) {
   int rc = msda_check("cgg_msda_backward_hostlevels", value, sampling_loc, attn_weight, grad_out, B, Nv, H, D, L, Nq, P, CGG_F32);
   if (rc) return rc;
   CGG_REQUIRE(level_hw && level_start && grad_value && grad_loc && grad_attn, CGG_EINVAL, "cgg_msda_backward_hostlevels: null pointer");
@@ -913,8 +947,29 @@ extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* l
     CGG_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0 && lv.start[l] >= 0 && (long long)lv.start[l] + (long long)lv.h[l] * lv.w[l] <= Nv,
                 CGG_EINVAL, "cgg_msda_backward_hostlevels: level %d does not fit Nv=%d", l, Nv);
   }
+  // overwrite_loc_attn: grad_loc / grad_attn are written, not accumulated (no zero-fill needed) -- honoured when the split
+  // backward with the P == 4 gather kernel runs; *overwrite_loc_attn is only a PERMISSION, so callers that pass it must not rely
+  // on accumulation and must still zero the two tensors unless cgg_msda_backward_overwrites(...) says the fast path applies
+  const bool tileable = msda_bwd_sorted_ok(lv, B, Nv, H, D, L, Nq, P);
+  const bool ow = overwrite_loc_attn && tileable && P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) &&
+                  cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn) && getenv("CGG_MSDA_GENERIC") == nullptr;
+  CGG_REQUIRE(!overwrite_loc_attn || ow, CGG_EUNSUPPORTED,
+              "cgg_msda_backward_hostlevels: overwrite_loc_attn needs the split backward (tileable pyramid, D == 32, P == 4, aligned)");
   return msda_bwd_launch(value, lv, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv, H, D, L, Nq, P,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, ow);
+}
+
+// 1 when cgg_msda_backward_hostlevels(..., overwrite_loc_attn = 1) is valid for this geometry (pointer alignment aside)
+extern "C" int cgg_msda_backward_overwrites(const int32_t* level_hw, const int32_t* level_start, int B, int Nv, int H, int D, int L,
+                                            int Nq, int P) {
+  if (!level_hw || !level_start || L < 1 || L > 8) return 0;
+  MsdaLevels lv;
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = level_start[l];
+  }
+  return (P == 4 && getenv("CGG_MSDA_GENERIC") == nullptr && msda_bwd_sorted_ok(lv, B, Nv, H, D, L, Nq, P)) ? 1 : 0;
 }
 
 // Throughput-mode encoder stream: bf16 value, bf16 raw [offsets | logits] rows (a bf16 GEMM's output), bf16 output

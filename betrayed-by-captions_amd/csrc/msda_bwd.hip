@@ -25,26 +25,31 @@ struct MsdaSortPlan {
   int maxpix;        // largest window, pixels
 };
 
-template <int NT>
+// NT threads; every thread owns at most MAXIT taps (items) whose geometry stays in registers across the sort's barriers
+template <int NT, int MAXIT>
 __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, MsdaSortPlan pl, const float* __restrict__ loc,
                                                                 const float* __restrict__ attw, const float* __restrict__ gout,
                                                                 float* __restrict__ gvalue, int Nv, int H, int L, int Nq, int P) {
   constexpr int D = 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* gs = smem;                                                       // [maxslots][32] grad_out rows of the tile's queries
-  uint2* rec = reinterpret_cast<uint2*>(gs + (size_t)pl.maxslots * D);    // [maxslots * P * 4] (slot, coefficient bits), sorted by pixel
+  uint2* rec = reinterpret_cast<uint2*>(gs + (size_t)pl.maxslots * D);    // [maxslots * P * 4]: sorted in-window records from the
+                                                                          // front, out-of-window records from the back
   uint32_t* cnt = reinterpret_cast<uint32_t*>(rec + (size_t)pl.maxslots * P * 4);
   uint32_t* beg = cnt + pl.maxpix;
-  uint32_t* cur = beg + pl.maxpix;
-  int* qn = reinterpret_cast<int*>(cur + pl.maxpix);                      // [maxslots] query index of a slot
-  __shared__ int nsl[8];
+  int* qn = reinterpret_cast<int*>(beg + pl.maxpix);                      // [maxslots] query index of a slot
   __shared__ uint32_t wsum[NT / 64];
+  __shared__ uint32_t nfb;                                                // out-of-window corners of this workgroup
   const int tid = threadIdx.x;
+  // workgroup order: (image, tile) slowest, then head, then destination level -- the 8 x L workgroups that read the same rows of
+  // grad_out / sampling_loc / attn_weight (one 128-B / 32-B / 16-B piece each of the tile's 1-KB / 768-B / 384-B rows) run side by
+  // side on one XCD, so the rows come from HBM once (first version: level fastest, head slow -> every line re-fetched per head,
+  // ~3.2 GB of L2 fills per call at configs[2] shapes)
   const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
   const int ld = bid % L;                                                 // destination level
-  const int tile = (bid / L) % pl.ntile;
-  const int h = (bid / (L * pl.ntile)) % H;
-  const int b = bid / (L * pl.ntile * H);
+  const int h = (bid / L) % H;
+  const int tile = (bid / (L * H)) % pl.ntile;
+  const int b = bid / (L * H * pl.ntile);
   const int tyi = tile / pl.tx, txi = tile % pl.tx;
   const size_t rowstride = (size_t)H * D;
 
@@ -54,8 +59,7 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     const int e = pl.c * pl.s[l];
     const int xx = txi * e, yy = tyi * e;
     const int tww = min(e, lv.w[l] - xx), thh = min(e, lv.h[l] - yy);
-    const int ns = tww * thh;
-    if (tid == 0) nsl[l] = ns;
+    const int ns = tww > 0 && thh > 0 ? tww * thh : 0;
     for (int i = tid; i < ns; i += NT) qn[nslots + i] = lv.start[l] + (yy + i / tww) * lv.w[l] + xx + i % tww;
     nslots += ns;
   }
@@ -66,62 +70,64 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
   const int ww = ed + 2 * pl.R;
   const int npix = ww * ww;
   for (int i = tid; i < npix; i += NT) cnt[i] = 0u;
+  if (tid == 0) nfb = 0u;
   __syncthreads();
-  // ---- stage grad_out[b, q, h, 0:32] of every slot (16-byte loads, 128-byte rows) ----
+
+  float* gvl = gvalue + ((size_t)b * Nv + lv.start[ld]) * rowstride + (size_t)h * D;
+  const int nitems = nslots * P;
+  // ---- this thread's taps: locations / weights requested first (the longest latency), then the grad_out rows are staged ----
+  float tx_[MAXIT], ty_[MAXIT], tw_[MAXIT];
+  int tslot[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int item = tid + it * NT;
+    const bool live = item < nitems;
+    const int slot = live ? item / P : 0;
+    const int p = live ? item - slot * P : 0;
+    const size_t idx = ((((size_t)b * Nq + qn[slot]) * H + h) * L + ld) * P + p;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + 2 * idx);
+    tx_[it] = xy.x;
+    ty_[it] = xy.y;
+    tw_[it] = live ? attw[idx] : 0.f;
+    tslot[it] = live ? slot : -1;
+  }
   for (int i = tid; i < nslots * 8; i += NT) {
     const int slot = i >> 3, cq = i & 7;
     const f32x4 g = cgg_ld4(gout + ((size_t)b * Nq + qn[slot]) * rowstride + (size_t)h * D + cq * 4);
     *reinterpret_cast<f32x4*>(gs + slot * D + cq * 4) = g;
   }
-  __syncthreads();
-
-  float* gvl = gvalue + ((size_t)b * Nv + lv.start[ld]) * rowstride + (size_t)h * D;
-  const int nitems = nslots * P;
-  // one tap's corners: window pixel (or -1 = outside the window -> global path; -2 = not a valid corner) and coefficient
-  auto corners = [&](int item, int& slot, int (&pix)[4], float (&cf)[4], int (&ro)[4]) {
-    slot = item / P;
-    const int p = item - slot * P;
-    const size_t idx = ((((size_t)b * Nq + qn[slot]) * H + h) * L + ld) * P + p;
-    const float x = loc[2 * idx], y = loc[2 * idx + 1], w = attw[idx];
-    const float him = y * (float)Hd - 0.5f, wim = x * (float)Wd - 0.5f;
-    const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hd) && (wim < (float)Wd);
+  // ---- pass 1: corner geometry; histogram over the window pixels with the corner's RANK inside its pixel as the return value ----
+  // per corner: dst >= 0: window pixel, -1: not a valid corner, <= -2: outside the window, -(row index in the level) - 2
+  int dst[MAXIT][4];
+  uint32_t rank[MAXIT][4];
+  float cf[MAXIT][4];
+  const int cap = pl.maxslots * P * 4;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const float him = ty_[it] * (float)Hd - 0.5f, wim = tx_[it] * (float)Wd - 0.5f;
+    const bool in = tslot[it] >= 0 && (him > -1.f) && (wim > -1.f) && (him < (float)Hd) && (wim < (float)Wd);
     const float hf = floorf(him), wf = floorf(wim);
     const int h0 = (int)hf, w0 = (int)wf;
     const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
     const bool vh0 = in && h0 >= 0, vh1 = in && (h0 + 1) <= Hd - 1;
     const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wd - 1;
     const bool k[4] = {vh0 && vw0, vh0 && vw1, vh1 && vw0, vh1 && vw1};
-    cf[0] = w * hh * hw;
-    cf[1] = w * hh * lw;
-    cf[2] = w * lh * hw;
-    cf[3] = w * lh * lw;
+    cf[it][0] = tw_[it] * hh * hw;
+    cf[it][1] = tw_[it] * hh * lw;
+    cf[it][2] = tw_[it] * lh * hw;
+    cf[it][3] = tw_[it] * lh * lw;
     const int wy0 = h0 - oy, wx0 = w0 - ox;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int wy = wy0 + (q >> 1), wx = wx0 + (q & 1);
       const bool inw = (unsigned)wy < (unsigned)ww && (unsigned)wx < (unsigned)ww;
-      pix[q] = !k[q] ? -2 : (inw ? wy * ww + wx : -1);
-      ro[q] = (h0 + (q >> 1)) * Wd + w0 + (q & 1);
-    }
-  };
-
-  // ---- pass 1: histogram over the window pixels; corners outside the window take the global path now ----
-  for (int item = tid; item < nitems; item += NT) {
-    int slot, pix[4], ro[4];
-    float cf[4];
-    corners(item, slot, pix, cf, ro);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (pix[q] >= 0) {
-        atomicAdd(&cnt[pix[q]], 1u);
-      } else if (pix[q] == -1) {
-        float* d = gvl + (size_t)ro[q] * rowstride;
-        for (int c = 0; c < D; ++c) atomicAdd(d + c, cf[q] * gs[slot * D + c]);
-      }
+      dst[it][q] = !k[q] ? -1 : (inw ? wy * ww + wx : -((h0 + (q >> 1)) * Wd + w0 + (q & 1)) - 2);
+      rank[it][q] = 0u;
+      if (dst[it][q] >= 0) rank[it][q] = atomicAdd(&cnt[dst[it][q]], 1u);
     }
   }
-  __syncthreads();
-  // ---- exclusive scan of the histogram (block-wide: per-thread serial chunks, wave shuffles, wave totals through LDS) ----
+  __syncthreads();       // histogram complete, grad_out rows staged
+  // ---- exclusive scan of the histogram (per-thread serial chunks, wave shuffles, wave totals through LDS) ----
   {
     const int per = (npix + NT - 1) / NT;
     const int i0 = tid * per;
@@ -142,22 +148,24 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     for (int i = 0; i < per; ++i)
       if (i0 + i < npix) {
         beg[i0 + i] = run;
-        cur[i0 + i] = run;
         run += cnt[i0 + i];
       }
   }
   __syncthreads();
-  // ---- pass 2: the records into pixel order ----
-  for (int item = tid; item < nitems; item += NT) {
-    int slot, pix[4], ro[4];
-    float cf[4];
-    corners(item, slot, pix, cf, ro);
+  // ---- pass 2: the records into pixel order (position = pixel's begin + rank: no second atomic); corners outside the window are
+  //      appended from the back of the same buffer as (slot | row << 12, coefficient) ----
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (pix[q] >= 0) {
-        const uint32_t pos = atomicAdd(&cur[pix[q]], 1u);
-        rec[pos] = make_uint2((uint32_t)slot, __float_as_uint(cf[q]));
+  for (int it = 0; it < MAXIT; ++it) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = dst[it][q];
+      if (d >= 0) {
+        rec[beg[d] + rank[it][q]] = make_uint2((uint32_t)tslot[it], __float_as_uint(cf[it][q]));
+      } else if (d <= -2) {
+        const uint32_t i = atomicAdd(&nfb, 1u);
+        rec[cap - 1 - (int)i] = make_uint2((uint32_t)tslot[it] | ((uint32_t)(-d - 2) << 12), __float_as_uint(cf[it][q]));
       }
+    }
   }
   __syncthreads();
   // ---- destination-stationary sums: half-wave = one window pixel, lane = channel ----
@@ -183,12 +191,24 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     const int iy = oy + pix / ww, ix = ox + pix % ww;          // inside the image: only valid corners were counted
     atomicAdd(gvl + (size_t)(iy * Wd + ix) * rowstride + lane, (a0 + a1) + (a2 + a3));
   }
+  // ---- corners outside the window: one 128-byte atomic each (large learned offsets: correctness does not depend on locality) ----
+  const int nf = (int)nfb;
+  for (int i = hwid; i < nf; i += NHW) {
+    const uint2 r0 = rec[cap - 1 - i];
+    atomicAdd(gvl + (size_t)(r0.x >> 12) * rowstride + lane, __uint_as_float(r0.y) * gs[(r0.x & 0xfffu) * D + lane]);
+  }
 }
 
-int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B, int Nv,
-                           int H, int D, int L, int Nq, int P, hipStream_t s) {
-  if (D != 32 || Nq != Nv || L < 1 || L > 8 || P < 1 || P > 16) return CGG_EUNSUPPORTED;
+static int msda_sort_plan(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P, MsdaSortPlan& pl, size_t& lds);
+
+bool msda_bwd_sorted_ok(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P) {
   MsdaSortPlan pl;
+  size_t lds;
+  return msda_sort_plan(lv, B, Nv, H, D, L, Nq, P, pl, lds) == CGG_OK;
+}
+
+static int msda_sort_plan(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P, MsdaSortPlan& pl, size_t& lds) {
+  if (D != 32 || Nq != Nv || L < 1 || L > 8 || P < 1 || P > 16) return CGG_EUNSUPPORTED;
   int lc = 0;
   long long tot = 0;
   for (int l = 0; l < L; ++l) {
@@ -206,7 +226,7 @@ int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* 
   static const int force_c = getenv("CGG_MSDA_BWD_C") ? atoi(getenv("CGG_MSDA_BWD_C")) : 0;
   static const int force_r = getenv("CGG_MSDA_BWD_R") ? atoi(getenv("CGG_MSDA_BWD_R")) : 0;
   const int cands[3] = {4, 2, 1};
-  size_t lds = 0;
+  lds = 0;
   bool ok = false;
   for (int k = 0; k < 3 && !ok; ++k) {
     const int c = force_c > 0 ? force_c : cands[k];
@@ -219,8 +239,8 @@ int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* 
       const int ww = e + 2 * R;
       maxpix = ww * ww > maxpix ? ww * ww : maxpix;
     }
-    lds = (size_t)slots * 32 * 4 + (size_t)slots * P * 4 * 8 + (size_t)maxpix * 3 * 4 + (size_t)slots * 4;
-    if (lds <= 150 * 1024 && slots <= 4096) {
+    lds = (size_t)slots * 32 * 4 + (size_t)slots * P * 4 * 8 + (size_t)maxpix * 2 * 4 + (size_t)slots * 4;
+    if (lds <= 150 * 1024 && slots < 4096 && slots * P <= 3 * 512) {
       pl.c = c;
       pl.R = R;
       pl.maxslots = (int)slots;
@@ -235,8 +255,21 @@ int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* 
   pl.ntile = pl.tx * pl.ty;
   const long long nblk = (long long)B * H * pl.ntile * L;
   if (nblk >= (1ll << 31)) return CGG_EUNSUPPORTED;
-  const bool big = pl.maxslots * P > 1024;
-  auto kern = big ? cgg_msda_bwd_sorted_kernel<512> : cgg_msda_bwd_sorted_kernel<256>;
+  for (int l = 0; l < L; ++l)
+    if ((long long)lv.h[l] * lv.w[l] >= (1ll << 20)) return CGG_EUNSUPPORTED;      // out-of-window records pack the row index in 20 bits
+  return CGG_OK;
+}
+
+int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B, int Nv,
+                           int H, int D, int L, int Nq, int P, hipStream_t s) {
+  MsdaSortPlan pl;
+  size_t lds;
+  const int rc = msda_sort_plan(lv, B, Nv, H, D, L, Nq, P, pl, lds);
+  if (rc != CGG_OK) return rc;
+  const long long nblk = (long long)B * H * pl.ntile * L;
+  const int items = pl.maxslots * P;
+  const bool big = items > 2 * 256;
+  auto kern = big ? cgg_msda_bwd_sorted_kernel<512, 3> : (items > 256 ? cgg_msda_bwd_sorted_kernel<256, 2> : cgg_msda_bwd_sorted_kernel<256, 1>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

@@ -141,17 +141,20 @@ def msda_backward_hostlevels(value, level_hw, level_start, sampling_locations, a
     """`msda_backward` with the level table as host integers: no device tensors for the shapes, no read-back / stream
     synchronisation inside the call (csrc/msda.hip `cgg_msda_backward_hostlevels`)."""
     B, Nv, H, D, L, Nq, P = _msda_dims(value, sampling_locations)
-    gv = torch.zeros_like(value)
-    gl = torch.zeros_like(sampling_locations)
-    gw = torch.zeros_like(attention_weights)
-    nbytes = 4.0 * (2 * value.numel() + 2 * sampling_locations.numel() + 2 * attention_weights.numel() + grad_output.numel())
     hw = _int_array([v for pair in level_hw for v in pair])
     st = _int_array(level_start)
+    # split backward on a tileable pyramid: grad_loc / grad_attn are written by the gather kernel (no zero-fill, no read of old values)
+    ow = bool(_lib_().cgg_msda_backward_overwrites(hw, st, B, Nv, H, D, L, Nq, P)) and \
+        sampling_locations.data_ptr() % 16 == 0 and attention_weights.data_ptr() % 16 == 0
+    gv = torch.zeros_like(value)
+    gl = torch.empty_like(sampling_locations) if ow else torch.zeros_like(sampling_locations)
+    gw = torch.empty_like(attention_weights) if ow else torch.zeros_like(attention_weights)
+    nbytes = 4.0 * (2 * value.numel() + 2 * sampling_locations.numel() + 2 * attention_weights.numel() + grad_output.numel())
     with _timed('msda_backward', bytes=nbytes, flops=0.0, shape=(B, Nq, H, D, L, P)):
         rc = _lib_().cgg_msda_backward_hostlevels(
             dev_ptr(value, 'value', torch.float32), hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
             dev_ptr(attention_weights, 'attention_weights', torch.float32), dev_ptr(grad_output, 'grad_output', torch.float32),
-            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, stream_ptr(value.device))
+            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow), stream_ptr(value.device))
     check(rc, 'cgg_msda_backward_hostlevels')
     return gv, gl, gw
 

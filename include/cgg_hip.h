@@ -116,11 +116,15 @@ int cgg_msda_backward(const float* value, const int64_t* spatial_shapes, const i
 
 /* ... with the level table from the host (level_hw = [h0, w0, h1, w1, ...]): no device->host read-back per call, graph-capturable
  * (what the training-time autograd Function of the encoder calls). Round 5: grad_value comes from a sorted-scatter kernel
- * (csrc/msda_bwd.hip) whenever the queries are the pixels of the value pyramid (D == 32, integer scale between levels). */
+ * (csrc/msda_bwd.hip) whenever the queries are the pixels of the value pyramid (D == 32, integer scale between levels).
+ * overwrite_loc_attn != 0: grad_loc / grad_attn are WRITTEN instead of accumulated (they need not be zeroed; grad_value still
+ * must be) -- only valid where cgg_msda_backward_overwrites(...) returns 1 for the same geometry, CGG_EUNSUPPORTED otherwise. */
 int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start,
                                  const float* sampling_loc, const float* attn_weight, const float* grad_out,
                                  float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
-                                 int Nq, int P, cgg_stream_t stream);
+                                 int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream);
+int cgg_msda_backward_overwrites(const int32_t* level_hw, const int32_t* level_start, int B, int Nv, int H, int D, int L, int Nq,
+                                 int P);
 
 /* ------------------------------------------------------------------------------------------------
  * K3/K4/K5  Mask logits: mask_pred[b,q,h,w] = sum_c mask_embed[b,q,c] * mask_feature[b,c,h,w]

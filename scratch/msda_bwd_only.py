@@ -22,12 +22,15 @@ norm = torch.tensor([[w, h] for h, w in hw], dtype=torch.float32).view(1, 1, 1, 
 loc = (ref.view(1, N, 1, 1, 1, 2) + off / norm).contiguous().to(dev)
 attw = torch.softmax(torch.randn(B, N, H, L * P, generator=g), -1).view(B, N, H, L, P).contiguous().to(dev)
 gout = torch.randn(B, N, H * D, generator=g).to(dev)
-for _ in range(2):
-    ops.msda_backward(value, shapes, start, loc, attw, gout)
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(iters):
-    ops.msda_backward(value, shapes, start, loc, attw, gout)
-e.record(); torch.cuda.synchronize()
-print(f'msda_backward B=16 (offset std {std} px): {s.elapsed_time(e) / iters * 1e3:.0f} us per call (incl. 3 zero-fills)')
+starts = [0, 1024, 1024 + 4096]
+for name, fn in (('mmcv-contract entry (device level table, accumulate)', lambda: ops.msda_backward(value, shapes, start, loc, attw, gout)),
+                 ('host-level entry (autograd path: grad_loc / grad_attn written)', lambda: ops.msda_backward_hostlevels(value, hw, starts, loc, attw, gout))):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    print(f'msda_backward B=16 (offset std {std} px), {name}: {s.elapsed_time(e) / iters * 1e3:.0f} us per call (incl. zero-fills)')

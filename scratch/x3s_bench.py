@@ -29,14 +29,13 @@ def report(tag, count, fl, t_old, ts, t_auto):
     cols = ' '.join(f'{c}:{ts[c]:6.1f}' for c in sorted(ts))
     print(f'{tag:40s} x{count} old {t_old:6.1f} ({fl / t_old / 1e6:5.0f} TF) auto {t_auto:6.1f} ({fl / t_auto / 1e6:5.0f} TF) best cfg {best} {tb:6.1f} ({fl / tb / 1e6:5.0f} TF) | {cols}', flush=True)
 def run_cfgs(fn, M, N):
+    # round 5: the tile configuration is a call argument (`cfg=`), no process-global override
     ts = {}
     if not AUTO_ONLY:
         for c in CFGS:
             if BN[c % 100] >= 2 * N and BN[c % 100] > 64: continue       # tile far wider than the problem
-            lib.cgg_gemm_x3s_force_config(c)
-            ts[c] = timeit(fn)
-    lib.cgg_gemm_x3s_force_config(-1)
-    return ts, timeit(fn)
+            ts[c] = timeit(lambda: fn(c))
+    return ts, timeit(lambda: fn(-1))
 def gemm(M, N, K, count=1, tag='gemm', res=False):
     name = f'{tag} {M}x{N}x{K}'
     if FILT and FILT not in name: return
@@ -44,7 +43,7 @@ def gemm(M, N, K, count=1, tag='gemm', res=False):
     pk = ops.pack_linear_weight_x3(w); xe = ops.x3a_encode(x)
     y = torch.empty(M, N, device=dev)
     t_old = timeit(lambda: ops.gemm_x3(x, pk, N, b, out=y))
-    ts, ta = run_cfgs(lambda: ops.gemm_x3s(xe, pk, N, b, out=y, out_split=True), M, N)
+    ts, ta = run_cfgs(lambda c: ops.gemm_x3s(xe, pk, N, b, out=y, out_split=True, cfg=c), M, N)
     report(name, count, 2.0 * M * N * K, t_old, ts, ta)
 def conv(B, H, C, N, k, s, count=1, res=False):
     name = f'conv {B}x{H}x{H}x{C} -> {N} k{k} s{s}' + (' +res' if res else '')
@@ -55,7 +54,7 @@ def conv(B, H, C, N, k, s, count=1, res=False):
     r = torch.randn(B, OH, OH, N, device=dev) if res else None
     re_ = ops.x3a_encode(r) if res else None
     t_old = timeit(lambda: ops.conv_x3_nhwc(x, pk, N, k, s, k // 2, b, res=r, relu=True))
-    ts, ta = run_cfgs(lambda: ops.conv_x3s_nhwc(xe, pk, N, k, s, k // 2, b, res=re_, relu=True), B * OH * OH, N)
+    ts, ta = run_cfgs(lambda c: ops.conv_x3s_nhwc(xe, pk, N, k, s, k // 2, b, res=re_, relu=True, cfg=c), B * OH * OH, N)
     report(name, count, 2.0 * B * OH * OH * N * C * k * k, t_old, ts, ta)
 # ---- ResNet-50 at 1024^2, batch 2 (after the stem: 256^2 x 64) ----
 conv(2, 256, 64, 256, 1, 1, 1); conv(2, 256, 64, 256, 1, 1, 3, res=True); conv(2, 256, 64, 64, 1, 1, 1); conv(2, 256, 64, 64, 3, 1, 3); conv(2, 256, 256, 64, 1, 1, 2)

@@ -194,6 +194,45 @@ def test_msda_backward_self_attention_tiled(dev, shapes, H, D, P, spread):
     assert (ga.cpu() - a64.grad.float()).abs().max().item() <= 2e-4
     d = (gl.cpu() - l64.grad.float()).abs()
     assert d.max().item() <= 5e-3 * max(1.0, l64.grad.abs().max().item())
+    # round 5: the host-level-table entry point (no read-back; grad_loc / grad_attn WRITTEN by the gather kernel where the split
+    # backward applies, un-zeroed outputs) gives the same three gradients
+    gv2, gl2, ga2 = ops.msda_backward_hostlevels(value.to(dev), shapes, starts, loc.to(dev), aw.to(dev), go.to(dev))
+    assert (gv2.cpu() - v64.grad.float()).abs().max().item() <= 2e-4
+    assert torch.equal(ga2, ga) and torch.equal(gl2, gl)
+
+
+@pytest.mark.parametrize('B,shapes,spread', [(2, [(16, 16), (32, 32), (64, 64)], 0.0),     # full 4 x 4 tiles (c = 4), patch-mapped gather
+                                             (1, [(12, 20), (24, 40), (48, 80)], 0.6),     # ragged tile grid, most taps outside the windows
+                                             (3, [(8, 8), (16, 16), (32, 32)], 0.2)])
+def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread):
+    """csrc/msda_bwd.hip at encoder-like sizes: the corner records of a tile sorted by destination pixel, destination-stationary
+    sums, out-of-window corners through the record list's tail -- against float64 autograd of the op's definition, local offsets
+    and far-away samples mixed; two runs differ only by f32 summation order."""
+    g = torch.Generator().manual_seed(61 + B)
+    starts, Nv = _levels(shapes)
+    L, H, D, P = len(shapes), 8, 32, 4
+    value = torch.randn(B, Nv, H, D, generator=g)
+    refs = []
+    for (h, w) in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    refp = torch.cat(refs, 0)
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    off = (torch.rand(B, Nv, H, L, P, 2, generator=g) - 0.5) * 8.0
+    loc = refp[None, :, None, None, None, :] + off / wh[None, None, None, :, None, :]
+    far = torch.rand(B, Nv, H, L, P, 1, generator=g) < spread
+    loc = torch.where(far, torch.rand(B, Nv, H, L, P, 2, generator=g) * 1.4 - 0.2, loc)
+    aw = torch.softmax(torch.randn(B, Nv, H, L * P, generator=g), -1).view(B, Nv, H, L, P)
+    go = torch.randn(B, Nv, H * D, generator=g) * 1e-3                   # a real gradient magnitude
+    v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, aw))
+    ref.msda_core(v64, torch.tensor(shapes), l64, a64).backward(go.double())
+    gv, gl, ga = ops.msda_backward_hostlevels(value.to(dev), shapes, starts, loc.to(dev), aw.to(dev), go.to(dev))
+    sc = v64.grad.abs().max().item()
+    assert (gv.cpu().double() - v64.grad).abs().max().item() <= 2e-5 * sc
+    assert (ga.cpu().double() - a64.grad).abs().max().item() <= 2e-4 * a64.grad.abs().max().item()
+    assert (gl.cpu().double() - l64.grad).abs().max().item() <= 5e-3 * l64.grad.abs().max().item()
+    gv2, _, _ = ops.msda_backward_hostlevels(value.to(dev), shapes, starts, loc.to(dev), aw.to(dev), go.to(dev))
+    assert (gv2 - gv).abs().max().item() <= 1e-5 * sc
 
 
 # ------------------------------------------------------------------------------------------------
