@@ -168,28 +168,38 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     }
   }
   __syncthreads();
-  // ---- destination-stationary sums: half-wave = one window pixel, lane = channel ----
+  // ---- destination-stationary sums: half-wave = FOUR window pixels at a time (independent chains: a pixel's walk is a serial
+  //      cnt -> beg -> record -> grad_out row chain of LDS latencies, ~0.2 us per pixel when walked one by one -- 63 pixels per
+  //      half-wave made this phase 2/3 of the kernel's time in the first version), lane = channel ----
   const int lane = tid & 31, hwid = tid >> 5;
   constexpr int NHW = NT / 32;
-  for (int pix = hwid; pix < npix; pix += NHW) {
-    const int n = (int)cnt[pix];
-    if (n == 0) continue;
-    const uint2* r = rec + beg[pix];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = 0;
-    for (; i + 3 < n; i += 4) {
-      const uint2 r0 = r[i], r1 = r[i + 1], r2 = r[i + 2], r3 = r[i + 3];
-      a0 = fmaf(__uint_as_float(r0.y), gs[r0.x * D + lane], a0);
-      a1 = fmaf(__uint_as_float(r1.y), gs[r1.x * D + lane], a1);
-      a2 = fmaf(__uint_as_float(r2.y), gs[r2.x * D + lane], a2);
-      a3 = fmaf(__uint_as_float(r3.y), gs[r3.x * D + lane], a3);
+  for (int pix0 = hwid * 4; pix0 < npix; pix0 += NHW * 4) {
+    int n[4];
+    const uint2* r[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int nmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = pix0 + k;
+      n[k] = pix < npix ? (int)cnt[pix] : 0;
+      r[k] = rec + (pix < npix ? beg[pix] : 0u);
+      nmax = n[k] > nmax ? n[k] : nmax;
     }
-    for (; i < n; ++i) {
-      const uint2 r0 = r[i];
-      a0 = fmaf(__uint_as_float(r0.y), gs[r0.x * D + lane], a0);
+    for (int i = 0; i < nmax; ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i < n[k]) {
+          const uint2 rr = r[k][i];
+          acc[k] = fmaf(__uint_as_float(rr.y), gs[rr.x * D + lane], acc[k]);
+        }
     }
-    const int iy = oy + pix / ww, ix = ox + pix % ww;          // inside the image: only valid corners were counted
-    atomicAdd(gvl + (size_t)(iy * Wd + ix) * rowstride + lane, (a0 + a1) + (a2 + a3));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (n[k] > 0) {
+        const int pix = pix0 + k;
+        const int iy = oy + pix / ww, ix = ox + pix % ww;      // inside the image: only valid corners were counted
+        atomicAdd(gvl + (size_t)(iy * Wd + ix) * rowstride + lane, acc[k]);
+      }
   }
   // ---- corners outside the window: one 128-byte atomic each (large learned offsets: correctness does not depend on locality) ----
   const int nf = (int)nfb;
@@ -225,7 +235,9 @@ static int msda_sort_plan(const MsdaLevels& lv, int B, int Nv, int H, int D, int
   // pixels per tile pixel = fewer flush atomics); CGG_MSDA_BWD_C / _R override (measurement)
   static const int force_c = getenv("CGG_MSDA_BWD_C") ? atoi(getenv("CGG_MSDA_BWD_C")) : 0;
   static const int force_r = getenv("CGG_MSDA_BWD_R") ? atoi(getenv("CGG_MSDA_BWD_R")) : 0;
-  const int cands[3] = {4, 2, 1};
+  // c = 2 first: 25 KB of LDS per workgroup, five or six workgroups per CU overlap each other's load / sort / sum phases (measured
+  // at configs[2] shapes, +-2 px offsets: c = 2 1.70 ms, c = 4 2.57 ms per call -- the 93-KB c = 4 tile runs one workgroup per CU)
+  const int cands[3] = {2, 4, 1};
   lds = 0;
   bool ok = false;
   for (int k = 0; k < 3 && !ok; ++k) {
@@ -268,14 +280,15 @@ int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* 
   if (rc != CGG_OK) return rc;
   const long long nblk = (long long)B * H * pl.ntile * L;
   const int items = pl.maxslots * P;
-  const bool big = items > 2 * 256;
-  auto kern = big ? cgg_msda_bwd_sorted_kernel<512, 3> : (items > 256 ? cgg_msda_bwd_sorted_kernel<256, 2> : cgg_msda_bwd_sorted_kernel<256, 1>);
+  const int nt = items > 2 * 384 ? 512 : (items > 256 ? 384 : 256);
+  auto kern = nt == 512 ? cgg_msda_bwd_sorted_kernel<512, 3> : (nt == 384 ? (items > 384 ? cgg_msda_bwd_sorted_kernel<384, 2> : cgg_msda_bwd_sorted_kernel<384, 1>)
+                                                                          : cgg_msda_bwd_sorted_kernel<256, 1>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
     return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(big ? 512 : 256), lds, s, lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(nt), lds, s, lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P);
   CGG_CHECK_LAUNCH("cgg_msda_backward(sorted scatter)");
   return CGG_OK;
 }

@@ -40,7 +40,8 @@ template <bool CONV, int TM, int TN>
 __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4) void cgg_gemm_x3_kernel(
     const float* __restrict__ A, int lda, const CggX3W w, const float* __restrict__ bias, const float* __restrict__ res, int ldr,
     float* __restrict__ out, int ldc, int M, int N, int K, int relu, int tiles_n, int n_tiles32, XgConv cv, uint32_t a_bytes,
-    uint32_t w_bytes, int res_mod, float* __restrict__ out2, int ldc2, int col2, const float* __restrict__ a_amax) {
+    uint32_t w_bytes, int res_mod, float* __restrict__ out2, int ldc2, int col2, const float* __restrict__ a_amax, int res_mask,
+    float* __restrict__ out_amax) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // A pre-scale: 2^4 (activations) or, when the caller hands the tensor's max |value| (device scalar), the power of two that puts
   // it near 2^9 (grad_output operands: x3.h "per-tensor pre-scale"); the epilogue un-scales by 16 / sa on top of colscale
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
 
   // ---- epilogue: acc[mt][nt][r] = C[m0 + 32 (TM wm + mt) + (r & 3) + 8 (r >> 2) + 4 hi5][32 (nt0 + TN wn + nt) + j] ----
   const bool full = m0 + BM <= M && (nt0 + 2 * TN) * 32 <= N;        // workgroup-uniform: interior tiles skip the bounds checks
+  float lmax = 0.f;                                                  // max |stored value| of this lane (out_amax)
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
     const int n = (nt0 + TN * wn + nt) * 32 + j;
@@ -255,9 +257,10 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[mt][nt][r] * cs + bs;
-          if (res) v += rv[r];
+          if (res) v = res_mask ? (rv[r] > 0.f ? v : 0.f) : v + rv[r];      // res_mask: the ReLU backward of the layer behind (res = its output)
           if (relu) v = fmaxf(v, 0.f);
           orow[(size_t)((r & 3) + 8 * (r >> 2)) * ldo] = v;
+          lmax = fmaxf(lmax, fabsf(v));
         }
         continue;
       }
@@ -268,19 +271,28 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
           float v = acc[mt][nt][r] * cs + bs;
           if (res) {
             const int mr = res_mod > 0 ? (mrow + dr) % res_mod : mrow + dr;      // res_mod: residual rows repeat (per-token table)
-            v += res[(size_t)mr * ldr + n];
+            const float rvv = res[(size_t)mr * ldr + n];
+            v = res_mask ? (rvv > 0.f ? v : 0.f) : v + rvv;
           }
           if (relu) v = fmaxf(v, 0.f);
           orow[(size_t)dr * ldo] = v;
+          lmax = fmaxf(lmax, fabsf(v));
         }
       }
     }
+  }
+  // max |out| for the NEXT contraction's per-tensor pre-scale (x3.h): one atomic per wave; |v| as a bit pattern is monotone
+  if (out_amax) {
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sft, 64));
+    if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out_amax), __float_as_uint(lmax));
   }
 }
 
 static int xg_launch(bool conv, const char* who, const float* a, int lda, const void* w_x3, const float* bias, const float* res,
                      int ldr, float* out, int ldc, int M, int N, int K, int relu, const XgConv& cv, cgg_stream_t stream,
-                     int res_mod = 0, float* out2 = nullptr, int ldc2 = 0, int col2 = 0, const float* a_amax = nullptr) {
+                     int res_mod = 0, float* out2 = nullptr, int ldc2 = 0, int col2 = 0, const float* a_amax = nullptr, int res_mask = 0,
+                     float* out_amax = nullptr) {
   CGG_REQUIRE(a && w_x3 && out, CGG_EINVAL, "%s: null pointer", who);
   CGG_REQUIRE(M > 0 && N > 0 && K > 0, CGG_EINVAL, "%s: bad sizes", who);
   CGG_REQUIRE(K % XG_BK == 0, CGG_EUNSUPPORTED, "%s: K=%d must be a multiple of %d", who, K, XG_BK);
@@ -310,7 +322,7 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   const uint32_t w_bytes = (uint32_t)(2ull * ((N + 31) / 32) * (K / 16) * 64 * 16);
 #define XG_GO(CONV, TM, TN)                                                                                                   \
   hipLaunchKernelGGL((cgg_gemm_x3_kernel<CONV, TM, TN>), grid, block, 0, (hipStream_t)stream, a, lda, w, bias, res, ldr, out, ldc, \
-                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes, res_mod, out2, ldc2, col2, a_amax)
+                     M, N, K, relu, tiles_n, (N + 31) / 32, cv, (uint32_t)a_bytes, w_bytes, res_mod, out2, ldc2, col2, a_amax, res_mask, out_amax)
 #define XG_PICK(CONV)                    \
   do {                                   \
     if (tm == 2 && tn == 2) XG_GO(CONV, 2, 2); \
@@ -374,4 +386,21 @@ extern "C" int cgg_conv_x3_nhwc_scaled(const float* x, const float* x_amax, cons
   const XgConv cv = {H, W, C, OH, OW, KW, stride, pad};
   return xg_launch(true, "cgg_conv_x3_nhwc_scaled", x, 0, w_x3, bias, res, N, out, N, B * OH * OW, N, KH * KW * C, relu, cv, stream, 0,
                    nullptr, 0, 0, x_amax);
+}
+
+// Backward-side GEMM of a fused training layer: cgg_gemm_x3_scaled with (a) `mask` (M, N, row stride ldm; nullable): the result is
+// zeroed where mask <= 0 -- the ReLU backward of the layer whose OUTPUT `mask` is (autograd's threshold_backward behind the FFN's
+// first linear, [3P] FFN in the MSDeformAttn encoder layers, mask2former_head.py:787) -- and (b) out_amax (device scalar,
+// nullable): max |out| written by the epilogue (zeroed here first) so that the next contraction's per-tensor pre-scale costs no
+// extra pass over the tensor.
+extern "C" int cgg_gemm_x3_bwd(const float* a, int lda, const float* a_amax, const void* w_x3, const float* mask, int ldm, float* out,
+                               int ldc, float* out_amax, int M, int N, int K, cgg_stream_t stream) {
+  const XgConv cv = {0, 0, 0, 0, 0, 0, 0, 0};
+  CGG_REQUIRE(lda >= K, CGG_EINVAL, "cgg_gemm_x3_bwd: lda=%d < K", lda);
+  if (out_amax) {
+    hipError_t e = hipMemsetAsync(out_amax, 0, sizeof(float), (hipStream_t)stream);
+    CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_gemm_x3_bwd: memset failed");
+  }
+  return xg_launch(false, "cgg_gemm_x3_bwd", a, lda, w_x3, nullptr, mask, ldm, out, ldc, M, N, K, 0, cv, stream, 0, nullptr, 0, 0, a_amax,
+                   mask ? 1 : 0, out_amax);
 }

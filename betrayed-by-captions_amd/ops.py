@@ -1152,11 +1152,22 @@ def pack_conv_weight_x3(weight):
     return pack_linear_weight_x3(weight.detach().float().permute(0, 2, 3, 1).reshape(N, -1))
 
 
-def absmax(x):
+ABSMAX_SAMPLE_STRIDE = 8          # `absmax(x, sample=True)` looks at every 8th 1-KiB block of tensors >= 16 MiB
+
+
+def absmax(x, sample=False):
     """max |x| of a float32 ROCm matrix / tensor (last dim contiguous, % 4) -> device scalar (1,) f32: the per-tensor pre-scale
-    of the x3 contractions' grad_output operands (`gemm_x3(..., amax=)`, `wgrad_x3(..., amax=)`; csrc/x3.h)."""
+    of the x3 contractions' grad_output operands (`gemm_x3(..., amax=)`, `wgrad_x3(..., amax=)`; csrc/x3.h).
+    sample=True (large dense tensors only): 8 x the maximum over every 8th 1-KiB block -- an eighth of the memory pass; the factor 8
+    is headroom for what was not looked at (the scale is a power of two: any value that neither overflows f16 nor starves the low
+    piece gives the same accuracy; an un-sampled outlier > 2^9 x the sampled maximum turns into inf in the consumer, loudly)."""
     if x.dtype != torch.float32 or not x.is_cuda:
         raise CggError('absmax: float32 ROCm tensor expected')
+    if sample and x.is_contiguous() and x.numel() >= (4 << 20) and x.data_ptr() % 16 == 0:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        check(_lib_().cgg_absmax_sampled_f32(ctypes.c_void_p(x.data_ptr()), x.numel(), ABSMAX_SAMPLE_STRIDE, dev_ptr(out),
+                                             stream_ptr(x.device)), 'cgg_absmax_sampled_f32')
+        return out
     x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
     if x2.dim() != 2 or x2.stride(1) != 1:
         raise CggError('absmax: a 2-D view with a contiguous last dim expected')
@@ -1197,6 +1208,30 @@ def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None, amax=None):
                                      int(bool(relu)), stream_ptr(a.device))
     check(rc, 'cgg_gemm_x3')
     return y
+
+
+def gemm_x3_bwd(g, packed, N, amax=None, mask=None, out=None, want_amax=False):
+    """Backward-side x3 GEMM (csrc/x3_gemm.hip `cgg_gemm_x3_bwd`): out (M, N) = g (M, K) W^T with g pre-scaled per tensor (`amax`),
+    the result zeroed where `mask` (M, N) <= 0 (ReLU backward of the layer whose output `mask` is) and, with want_amax, max |out|
+    from the epilogue as a device scalar -> (out, out_amax | None)."""
+    if g.dim() != 2 or g.stride(1) != 1 or g.dtype != torch.float32 or not g.is_cuda or not is_x3(packed):
+        raise CggError('gemm_x3_bwd: g must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
+    M, K = g.shape
+    _x3_check(packed, N, K, 'gemm_x3_bwd')
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=g.device)
+    if y.dim() != 2 or y.stride(1) != 1 or y.shape != (M, N) or y.dtype != torch.float32:
+        raise CggError('gemm_x3_bwd: bad `out` view')
+    if mask is not None and (mask.dim() != 2 or mask.stride(1) != 1 or mask.shape != (M, N) or mask.dtype != torch.float32):
+        raise CggError('gemm_x3_bwd: bad `mask` view')
+    oa = torch.empty(1, dtype=torch.float32, device=g.device) if want_amax else None
+    with _timed('gemm_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * K + M * N * (2 if mask is not None else 1)) + 4.0 * N * K,
+                shape=(M, N, K)):
+        rc = _lib_().cgg_gemm_x3_bwd(ctypes.c_void_p(g.data_ptr()), g.stride(0), dev_ptr(amax, 'amax', torch.float32), dev_ptr(packed),
+                                     ctypes.c_void_p(mask.data_ptr()) if mask is not None else None,
+                                     mask.stride(0) if mask is not None else 0, ctypes.c_void_p(y.data_ptr()), y.stride(0),
+                                     dev_ptr(oa), M, N, K, stream_ptr(g.device))
+    check(rc, 'cgg_gemm_x3_bwd')
+    return y, oa
 
 
 def encoder_layer_tail_x3(a, x, wo, bo, norm0, w1, b1, w2, b2, norm1, pos=None, want_pos=False, x3a=False):

@@ -182,8 +182,11 @@ class FFN(nn.Module):
     def forward_noidentity(self, x):
         """Training, parity mode: W2 relu(W1 x + b1) + b2 WITHOUT the residual (it is added inside the fused LayerNorm); the two
         linears go through `runtime.linear` (x3 forward / grad-input / grad-weight for the encoder's row counts)."""
-        h = torch.relu_(runtime.linear(x, self.layers[0][0].weight, self.layers[0][0].bias))
-        return runtime.linear(h, self.layers[1].weight, self.layers[1].bias)
+        l0, l1 = self.layers[0][0], self.layers[1]
+        if runtime.x3_train_ffn_ok(x, l0.weight, l0.bias, l1.weight, l1.bias):
+            return runtime.ffn_x3_train(x, l0.weight, l0.bias, l1.weight, l1.bias)      # one autograd node: ReLU / its backward / amax fused
+        h = torch.relu_(runtime.linear(x, l0.weight, l0.bias))
+        return runtime.linear(h, l1.weight, l1.bias)
 
     def forward_bf16_noidentity(self, x):
         """Training, bf16 mode: W2 relu(W1 x + b1) + b2 in bf16 WITHOUT the residual (it is added inside the fused LayerNorm)."""

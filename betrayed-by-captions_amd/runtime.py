@@ -210,7 +210,7 @@ class _X3LinearFn(torch.autograd.Function):
         # power-of-two pre-scale from max |g| (ONE streaming pass, shared by the grad-input GEMM and the weight-gradient kernel)
         # instead of the activations' fixed 2^4 (with 2^4 a gradient of 1e-6 kept ~10 of its 22 bits); CGG_X3_GSCALE=0
         # restores the fixed scale for A/B
-        amax = ops.absmax(g2) if _X3_GSCALE and N % 4 == 0 else None
+        amax = ops.absmax(g2, sample=True) if _X3_GSCALE and N % 4 == 0 else None
         if ctx.needs_input_grad[0]:
             wtk = derived_cached('x3_image_t', (weight,), lambda: ops.pack_linear_weight_x3(weight.detach().t().contiguous()))
             gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
@@ -226,6 +226,60 @@ class _X3LinearFn(torch.autograd.Function):
         if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb
+
+
+class _X3FfnFn(torch.autograd.Function):
+    """Training-time FFN branch y = W2 relu(W1 x + b1) + b2 of an encoder layer ([3P] FFN behind mask2former_head.py:787) in PARITY
+    mode as ONE autograd node on the x3 kernels. Compared with two `_X3LinearFn`s around `torch.relu_`: the ReLU is the first GEMM's
+    epilogue (no clamp pass over the (rows, F) hidden tensor: 1.4 GB at configs[2]), its backward is the grad-input GEMM's epilogue
+    (`ops.gemm_x3_bwd(mask=h)`: no threshold_backward pass), and that epilogue also reports max |grad_hidden| for the next two
+    contractions' pre-scale (no absmax pass): -9 ms per step at configs[2]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        from . import ops
+        F_, K = w1.shape
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        w1k = derived_cached('x3_image', (w1,), lambda: ops.pack_linear_weight_x3(w1))
+        w2k = derived_cached('x3_image', (w2,), lambda: ops.pack_linear_weight_x3(w2))
+        h = ops.gemm_x3(x2, w1k, F_, b1.detach(), relu=True)
+        y = torch.empty((*x.shape[:-1], w2.shape[0]), dtype=torch.float32, device=x.device)
+        ops.gemm_x3(h, w2k, w2.shape[0], b2.detach(), out=y.view(-1, w2.shape[0]))
+        ctx.save_for_backward(x2, h, w1, w2)
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x2, h, w1, w2 = ctx.saved_tensors
+        F_, K = w1.shape
+        N = w2.shape[0]
+        g2 = gy.reshape(-1, N)
+        if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        amax = ops.absmax(g2, sample=True) if _X3_GSCALE else None
+        gw2, gb2 = ops.wgrad_x3(g2, h, want_bias=True, amax=amax)
+        w2t = derived_cached('x3_image_t', (w2,), lambda: ops.pack_linear_weight_x3(w2.detach().t().contiguous()))
+        gh, amax_h = ops.gemm_x3_bwd(g2, w2t, F_, amax=amax, mask=h, want_amax=_X3_GSCALE)       # d / d(pre-activation)
+        gw1, gb1 = ops.wgrad_x3(gh, x2, want_bias=True, amax=amax_h)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            w1t = derived_cached('x3_image_t', (w1,), lambda: ops.pack_linear_weight_x3(w1.detach().t().contiguous()))
+            gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
+            ops.gemm_x3(gh, w1t, K, out=gx.view(-1, K), amax=amax_h)
+        return gx, gw1, gb1, gw2, gb2
+
+
+def x3_train_ffn_ok(x, w1, b1, w2, b2):
+    return (x3_train_linear_ok(x, w1) and b1 is not None and b2 is not None and w2.shape[1] == w1.shape[0] and w2.shape[0] % 32 == 0
+            and w1.shape[0] % 32 == 0 and w1.requires_grad and w2.requires_grad and b1.requires_grad and b2.requires_grad)
+
+
+def ffn_x3_train(x, w1, b1, w2, b2):
+    return _X3FfnFn.apply(x, w1, b1, w2, b2)
 
 
 class _X3Conv3x3Fn(torch.autograd.Function):
@@ -257,7 +311,7 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         gl = ops.nchw_to_nhwc(gy)
         gl = gl if gl.is_contiguous() else gl.contiguous()
         gx = gw = None
-        amax = ops.absmax(gl.view(-1, N)) if _X3_GSCALE else None        # per-tensor pre-scale of grad_output (see _X3LinearFn)
+        amax = ops.absmax(gl.view(-1, N), sample=True) if _X3_GSCALE else None        # per-tensor pre-scale of grad_output (see _X3LinearFn)
         if ctx.needs_input_grad[0] and amax is not None:
             wt = derived_cached('x3_conv_image_dgrad', (weight,),
                                 lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))

@@ -301,6 +301,47 @@ def test_x3_training_linear_gradients_at_real_gradient_magnitudes(dev, mag):
         assert rel(fixed, w64.grad) > 10 * got[1]
 
 
+@pytest.mark.parametrize('mag', [1.0, 1e-6])
+def test_x3_training_ffn_node_vs_float64(dev, mag):
+    """runtime._X3FfnFn (round 5: the encoder FFN branch W2 relu(W1 x + b1) + b2 as one autograd node -- ReLU in the first GEMM's
+    epilogue, its backward as a mask in the grad-input GEMM's epilogue, max |grad_hidden| from that epilogue for the next
+    contractions' pre-scale) vs float64 autograd, at unit and at real gradient magnitudes; the f32 autograd of the same formulation
+    is the yardstick."""
+    from cgg_amd import runtime
+    M, K, Fh = 8192, 256, 1024
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g)
+    w1, b1 = torch.randn(Fh, K, generator=g) / K ** 0.5, torch.randn(Fh, generator=g) * 0.1
+    w2, b2 = torch.randn(K, Fh, generator=g) / Fh ** 0.5, torch.randn(K, generator=g) * 0.1
+    gy = torch.randn(M, K, generator=g) * mag
+
+    def run(dt, device):
+        ts = [t.to(device=device, dtype=dt).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = F.linear(torch.relu(F.linear(ts[0], ts[1], ts[2])), ts[3], ts[4])
+        y.backward(gy.to(device=device, dtype=dt))
+        return y, [t.grad for t in ts]
+    y64, g64 = run(torch.float64, 'cpu')
+    y32, g32 = run(torch.float32, 'cpu')
+    ts = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    with runtime.precision_scope('fp32'):
+        assert runtime.x3_train_ffn_ok(*ts)
+        y = runtime.ffn_x3_train(*ts)
+        y.backward(gy.to(dev))
+    rel = lambda a, r: ((a.double().cpu() - r).abs().max() / r.abs().max()).item()
+    assert rel(y.detach(), y64) <= 4 * rel(y32.detach(), y64) + 1e-6
+    for got, want, f32 in zip([t.grad for t in ts], g64, g32):
+        assert rel(got, want) <= 4 * rel(f32, want) + 2e-6, (mag, rel(got, want), rel(f32, want))
+
+
+def test_absmax_sampled_reports_headroom(dev):
+    x = torch.randn(1 << 23, device=dev)                       # 32 MiB: the sampled pass
+    full, samp = ops.absmax(x).item(), ops.absmax(x, sample=True).item()
+    assert full == x.abs().max().item()
+    assert samp >= full and samp <= 8 * full                   # 8 x the maximum of every 8th block: never below the true maximum here
+    small = torch.randn(1000, 64, device=dev)
+    assert ops.absmax(small, sample=True).item() == small.abs().max().item()     # small tensors: the exact pass
+
+
 def test_absmax_strided_and_zero(dev):
     x = torch.randn(300, 72, device=dev)
     x[17, 40] = -123.5
