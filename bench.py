@@ -641,12 +641,15 @@ def einsum_q_sweep(dev, B, H, W):
         # 10 back-to-back calls per sample = the 10 forward_head calls of a forward (the 67-MB bf16 feature stays cache-resident)
         for mode, split, fused in (('bf16 MFMA, f32 logits out', False, False), ('f32-class f16 x 3 MFMA, f32 logits out', True, False),
                                    ('bf16 MFMA, consumer fused: threshold bits out, logits never stored', False, True),
-                                   ('f32-class f16 x 3 MFMA, consumer fused: threshold bits out, logits never stored', True, True)):
+                                   ('f32-class f16 x 3 MFMA, consumer fused: threshold bits out, logits never stored', True, True),
+                                   ('bf16 MFMA, consumer fused + query tiles stationary in registers (cgg_mask_logits_bits_astat): '
+                                    'threshold bits out, logits never stored', False, 'astat')):
             with runtime.precision_scope('fp32' if split else 'bf16'):
                 packed = ops.pack_mask_feature(feat, 1, split)
                 if split:
                     packed.f32 = None                      # the f16 x 3 kernel (the exact-f32 path keeps an un-packed copy)
-                call = (lambda: ops.mask_logits(emb, packed, want_logits=False, want_bits=True)) if fused else \
+                call = (lambda: ops.mask_logits_bits_astat(emb, packed)) if fused == 'astat' else \
+                    (lambda: ops.mask_logits(emb, packed, want_logits=False, want_bits=True)) if fused else \
                     (lambda: ops.mask_logits(emb, packed))
                 for _ in range(5):
                     call()

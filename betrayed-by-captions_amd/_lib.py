@@ -32,6 +32,7 @@ PROTOTYPES = {
     'cgg_msda_backward_overwrites': (_c_int, [_c_vp] * 2 + [_c_int] * 7),
     'cgg_pack_mask_feature': (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     'cgg_mask_logits': (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
+    'cgg_mask_logits_bits_astat': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_mask_logits_f32': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
     'cgg_mask_logits_backward_workspace_bytes': (_c_i64, [_c_int] * 4),
     'cgg_mask_logits_backward': (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),

@@ -295,6 +295,20 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
     return out, bits
 
 
+def mask_logits_bits_astat(embed, packed):
+    """embed (B, Q, 256) f32 x bf16 PackedFeature -> attn-mask bits (B, Q, words) int32 of (logit < 0), consumer-fused: the query
+    tiles stay in registers, the logits are never stored (csrc/mask_logits_astat.hip). Same bits as `mask_logits(..., want_bits=True)`."""
+    B, Q, C = embed.shape
+    if B != packed.B or C != packed.C or packed.lo is not None:
+        raise CggError('mask_logits_bits_astat: bf16 PackedFeature of the same batch / channels expected')
+    bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device)
+    with _timed('mask_logits_bits_astat'):
+        rc = _lib_().cgg_mask_logits_bits_astat(dev_ptr(embed, 'mask_embed', torch.float32), dev_ptr(packed.hi), dev_ptr(bits), B, Q, C,
+                                                packed.npix, stream_ptr(embed.device))
+    check(rc, 'cgg_mask_logits_bits_astat')
+    return bits
+
+
 def mask_logits_backward_ok(embed, feat):
     """shapes the HIP backward kernels cover (otherwise the caller keeps the torch contractions)."""
     return (embed.is_cuda and embed.dtype == torch.float32 and feat.dtype == torch.float32 and embed.shape[-1] == 256

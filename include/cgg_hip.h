@@ -176,6 +176,12 @@ int cgg_mask_logits_backward(const float* embed, const float* feat, const float*
 
 /* rows of `bits` that block every key are cleared (open_set/models/mask2former_head.py:825-826).
  *   bits [rows, words] u32, npix valid bits per row.                                             */
+/* Round 5: the consumer-fused form with the QUERY operand stationary in registers (csrc/mask_logits_astat.hip) -- bf16 MFMA,
+ * attn-mask bits (logit < 0, mask2former_head.py:749-759) straight from the accumulators, the logits never stored: the form of the
+ * einsum that is not bound by its f32 output (67.2 MB of algorithmic bytes at configs[1] instead of 119.6 MB).
+ * embed (B, Q, 256) f32, hi = packed bf16 feature, bits (B, Q, ceil(npix / 32)) u32; Q <= 256. Same bits as cgg_mask_logits. */
+int cgg_mask_logits_bits_astat(const float* embed, const void* hi, uint32_t* bits, int B, int Q, int C, int npix,
+                               cgg_stream_t stream);
 int cgg_attn_mask_fix_full_rows(uint32_t* bits, int rows, int npix, cgg_stream_t stream);
 
 /* generic path for level sizes that are not an even integer divisor of the mask-feature size:

@@ -248,6 +248,21 @@ def test_mask_logits_split_within_1e3(dev, B, Q, H, W):
     assert err <= 1e-3, err  # north_star: mask logits within 1e-3 (values are O(16) here)
 
 
+@pytest.mark.parametrize('B,Q,H,W', [(2, 100, 64, 64), (1, 200, 64, 96), (2, 37, 20, 28), (1, 128, 16, 24), (1, 256, 40, 33)])
+def test_mask_logits_bits_astat_equals_streamed_kernel(dev, B, Q, H, W):
+    """cgg_mask_logits_bits_astat (query tiles stationary in registers, threshold consumer in the epilogue, logits never stored)
+    gives exactly the bits of cgg_mask_logits' bf16 mode (same bf16 operands, same MFMA order) -- one / two query-tile groups,
+    ragged last tile, rows that are not a multiple of 32 -- and those are `bf16-operand logit < 0`."""
+    g = torch.Generator().manual_seed(12 + Q)
+    embed = torch.randn(B, Q, 256, generator=g)
+    feat = torch.randn(B, 256, H, W, generator=g)
+    packed = ops.pack_mask_feature(feat.to(dev), pool=1, split=False)
+    logits, want = ops.mask_logits(embed.to(dev), packed, want_logits=True, want_bits=True)
+    got = ops.mask_logits_bits_astat(embed.to(dev), packed)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.unpack_bits(got, H * W).view(B, Q, H, W), logits < 0)
+
+
 def test_mask_logits_bf16_mode(dev):
     g = torch.Generator().manual_seed(11)
     B, Q, H, W = 2, 100, 32, 48
