@@ -63,22 +63,23 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
     const f32x4* __restrict__ eb4 = reinterpret_cast<const f32x4*>(embed + (size_t)b * Q * C);
     uint2* a2 = reinterpret_cast<uint2*>(a_lds);
     const int nf = MT * 32 * (C / 4), nvalid = Q * (C / 4);
-    for (int f0 = tid; f0 < nf; f0 += 256 * 4) {
-      f32x4 ev[4];
+    // ALL of this thread's loads first (<= 64 float4: the A / accumulator registers are not live yet), then the conversions: one
+    // L2 round trip instead of one per group of four (with one workgroup per CU nothing else hides them: the looped form cost ~10 us)
+    constexpr int NF = 2 * MTW * 8;                            // float4 per thread for MT = 2 MTW query tiles
+    f32x4 ev[NF];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int f = f0 + 256 * u;
-        ev[u] = (f < nvalid) ? eb4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + 256 * u;
+      ev[u] = (f < nvalid) ? eb4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int f = f0 + 256 * u;
-        if (f < nf) {
-          const int q = f >> 6, c4 = f & 63;
-          const int slot = ((q >> 5) * MLA_KS + (c4 >> 2)) * 64 + (q & 31) + 32 * ((c4 >> 1) & 1);
-          a2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(cgg_f2bf(ev[u][0]), cgg_f2bf(ev[u][1])),
-                                               cgg_pack2(cgg_f2bf(ev[u][2]), cgg_f2bf(ev[u][3])));
-        }
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + 256 * u;
+      if (f < nf) {
+        const int q = f >> 6, c4 = f & 63;
+        const int slot = ((q >> 5) * MLA_KS + (c4 >> 2)) * 64 + (q & 31) + 32 * ((c4 >> 1) & 1);
+        a2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(cgg_f2bf(ev[u][0]), cgg_f2bf(ev[u][1])),
+                                             cgg_pack2(cgg_f2bf(ev[u][2]), cgg_f2bf(ev[u][3])));
       }
     }
   }

@@ -168,38 +168,29 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     }
   }
   __syncthreads();
-  // ---- destination-stationary sums: half-wave = FOUR window pixels at a time (independent chains: a pixel's walk is a serial
-  //      cnt -> beg -> record -> grad_out row chain of LDS latencies, ~0.2 us per pixel when walked one by one -- 63 pixels per
-  //      half-wave made this phase 2/3 of the kernel's time in the first version), lane = channel ----
+  // ---- destination-stationary sums: half-wave = one window pixel, lane = channel. A pixel's records are walked FOUR at a time: the
+  //      four record reads go out together, then the four grad_out-row reads, then four FMAs into independent sums (a one-record
+  //      loop is a serial record -> row -> FMA chain of two LDS latencies per record: 0.58 ms of the kernel's 1.2 ms at configs[2]
+  //      shapes; interleaving four PIXELS instead measured slower -- their record counts differ) ----
   const int lane = tid & 31, hwid = tid >> 5;
   constexpr int NHW = NT / 32;
-  for (int pix0 = hwid * 4; pix0 < npix; pix0 += NHW * 4) {
-    int n[4];
-    const uint2* r[4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int nmax = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int pix = pix0 + k;
-      n[k] = pix < npix ? (int)cnt[pix] : 0;
-      r[k] = rec + (pix < npix ? beg[pix] : 0u);
-      nmax = n[k] > nmax ? n[k] : nmax;
+  for (int pix = hwid; pix < npix; pix += NHW) {
+    const int n = (int)cnt[pix];
+    if (n == 0) continue;
+    const uint2* r = rec + beg[pix];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = 0; i < n; i += 4) {
+      // the tail re-reads the last record with coefficient 0 (no branch inside the group)
+      const int i1 = min(i + 1, n - 1), i2 = min(i + 2, n - 1), i3 = min(i + 3, n - 1);
+      const uint2 r0 = r[i], r1 = r[i1], r2 = r[i2], r3 = r[i3];
+      const float g0 = gs[r0.x * D + lane], g1 = gs[r1.x * D + lane], g2 = gs[r2.x * D + lane], g3 = gs[r3.x * D + lane];
+      a0 = fmaf(__uint_as_float(r0.y), g0, a0);
+      a1 = fmaf(i + 1 < n ? __uint_as_float(r1.y) : 0.f, g1, a1);
+      a2 = fmaf(i + 2 < n ? __uint_as_float(r2.y) : 0.f, g2, a2);
+      a3 = fmaf(i + 3 < n ? __uint_as_float(r3.y) : 0.f, g3, a3);
     }
-    for (int i = 0; i < nmax; ++i) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i < n[k]) {
-          const uint2 rr = r[k][i];
-          acc[k] = fmaf(__uint_as_float(rr.y), gs[rr.x * D + lane], acc[k]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (n[k] > 0) {
-        const int pix = pix0 + k;
-        const int iy = oy + pix / ww, ix = ox + pix % ww;      // inside the image: only valid corners were counted
-        atomicAdd(gvl + (size_t)(iy * Wd + ix) * rowstride + lane, acc[k]);
-      }
+    const int iy = oy + pix / ww, ix = ox + pix % ww;          // inside the image: only valid corners were counted
+    atomicAdd(gvl + (size_t)(iy * Wd + ix) * rowstride + lane, (a0 + a1) + (a2 + a3));
   }
   // ---- corners outside the window: one 128-byte atomic each (large learned offsets: correctness does not depend on locality) ----
   const int nf = (int)nfb;
@@ -280,9 +271,10 @@ int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* 
   if (rc != CGG_OK) return rc;
   const long long nblk = (long long)B * H * pl.ntile * L;
   const int items = pl.maxslots * P;
-  const int nt = items > 2 * 384 ? 512 : (items > 256 ? 384 : 256);
-  auto kern = nt == 512 ? cgg_msda_bwd_sorted_kernel<512, 3> : (nt == 384 ? (items > 384 ? cgg_msda_bwd_sorted_kernel<384, 2> : cgg_msda_bwd_sorted_kernel<384, 1>)
-                                                                          : cgg_msda_bwd_sorted_kernel<256, 1>);
+  // 256 threads where two taps per thread cover the tile (c = 2: 336 taps), 512 for the c = 4 tile; 384-thread workgroups with one
+  // tap per thread measured the same (2.96 vs 2.85 ms per backward call at configs[2] shapes)
+  const int nt = items > 512 ? 512 : 256;
+  auto kern = nt == 512 ? cgg_msda_bwd_sorted_kernel<512, 3> : (items > 256 ? cgg_msda_bwd_sorted_kernel<256, 2> : cgg_msda_bwd_sorted_kernel<256, 1>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

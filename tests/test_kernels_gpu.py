@@ -198,7 +198,8 @@ def test_msda_backward_self_attention_tiled(dev, shapes, H, D, P, spread):
     # backward applies, un-zeroed outputs) gives the same three gradients
     gv2, gl2, ga2 = ops.msda_backward_hostlevels(value.to(dev), shapes, starts, loc.to(dev), aw.to(dev), go.to(dev))
     assert (gv2.cpu() - v64.grad.float()).abs().max().item() <= 2e-4
-    assert torch.equal(ga2, ga) and torch.equal(gl2, gl)
+    # (written vs accumulated-into-zero: two instantiations of the gather kernel, the compiler contracts their FMAs differently)
+    assert (ga2 - ga).abs().max().item() <= 1e-5 * ga.abs().max().item() and (gl2 - gl).abs().max().item() <= 1e-5 * gl.abs().max().item()
 
 
 @pytest.mark.parametrize('B,shapes,spread', [(2, [(16, 16), (32, 32), (64, 64)], 0.0),     # full 4 x 4 tiles (c = 4), patch-mapped gather

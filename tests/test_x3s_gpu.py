@@ -316,13 +316,13 @@ def test_x3_training_ffn_node_vs_float64(dev, mag):
     gy = torch.randn(M, K, generator=g) * mag
 
     def run(dt, device):
-        ts = [t.to(device=device, dtype=dt).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        ts = [t.detach().clone().to(device=device, dtype=dt).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
         y = F.linear(torch.relu(F.linear(ts[0], ts[1], ts[2])), ts[3], ts[4])
         y.backward(gy.to(device=device, dtype=dt))
         return y, [t.grad for t in ts]
     y64, g64 = run(torch.float64, 'cpu')
     y32, g32 = run(torch.float32, 'cpu')
-    ts = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ts = [t.detach().clone().to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
     with runtime.precision_scope('fp32'):
         assert runtime.x3_train_ffn_ok(*ts)
         y = runtime.ffn_x3_train(*ts)
