@@ -8,7 +8,7 @@
 // stored (round-5 measurement: Q = 200 bits-only 37.0 us vs 38.4 us with f32 logits out -- the store is not the bound).
 // Here a wavefront owns up to FOUR query tiles (128 queries) for the whole launch: their 64 A fragments live in 256 VGPRs (one wave
 // per SIMD, the 512-register budget), the pixel tiles stream through as 16 coalesced 1-KiB loads each (the packed image of
-// cgg_pack_mask_feature*: every B fragment is one global_load_dwordx4 per lane, no LDS), two register sets deep (the next tile in
+// cgg_pack_mask_feature*: every B fragment is one global_load_dwordx4 per lane, no LDS), three register sets deep (two tiles in
 // flight behind the one being multiplied). Per MFMA the CU moves 256 B instead of 1 KiB, all of it through the vector memory path; LDS is only used once, to
 // turn mask_embed into fragment order. Q > 128: two wave groups hold query tiles [0, 4) and [4, MT), the two waves of a pair walk
 // the same pixel tiles (the second read of a tile hits L2).
@@ -128,20 +128,25 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
     }
   };
 
-  // ---- (2) stream: two register sets -- the next tile is in flight while this one is multiplied (a third set does not fit the
-  //      512-register budget beside 256 A registers; the four waves of a CU keep 64 KB in flight, 16 MB over the chip = HBM
-  //      bandwidth x latency, so the stream stays bandwidth-bound even where a wave waits) ----
+  // ---- (2) stream: three register sets -- two tiles in flight behind the one being multiplied (2 x 0.85 us of MFMA time against
+  //      an HBM latency that one wave per SIMD cannot hide by occupancy); 256 A + 3 x 64 B + 16 accumulator registers = 502 of 512 ----
   int run0 = tbeg;
-  for (int t = tbeg; t < tend; t += 2) {
+  u32x4 b2[MLA_KS];
+  if (tbeg + 2 < tend) mla_load_tile(b2, fb, tbeg + 2, nt);
+  for (int t = tbeg; t < tend; t += 3) {
     do_tile(b0, t, t - run0);
-    if (t + 2 < tend) mla_load_tile(b0, fb, t + 2, nt);
+    if (t + 3 < tend) mla_load_tile(b0, fb, t + 3, nt);
     if (t + 1 < tend) {
       do_tile(b1, t + 1, t + 1 - run0);
-      if (t + 3 < tend) mla_load_tile(b1, fb, t + 3, nt);
+      if (t + 4 < tend) mla_load_tile(b1, fb, t + 4, nt);
     }
-    if (t + 2 - run0 >= MLA_RUN || t + 2 >= tend) {            // MLA_RUN is even: a run ends on a pair boundary
-      flush(run0, min(tend, t + 2) - run0);
-      run0 = t + 2;
+    if (t + 2 < tend) {
+      do_tile(b2, t + 2, t + 2 - run0);
+      if (t + 5 < tend) mla_load_tile(b2, fb, t + 5, nt);
+    }
+    if (t + 3 - run0 + 3 > MLA_RUN || t + 3 >= tend) {
+      flush(run0, min(tend, t + 3) - run0);
+      run0 = t + 3;
     }
   }
 }

@@ -56,7 +56,7 @@ def patched(args, cfg, model, img, metas, dev, rank, world, steps=None, warmup=N
     for name, (n, t) in sorted(byop.items(), key=lambda kv: -kv[1][1])[:40]:
         print('%9.1f us %5d  %s' % (t, n, name))
     print('== by (op, shapes, call site) ==')
-    for (name, shp, site), (n, t, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:110]:
+    for (name, shp, site), (n, t, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:260]:
         print('%9.1f us %5d  %-28s %-90s %s' % (t, n, name[:28], shp, site))
     return dict(value=0)
 
