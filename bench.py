@@ -660,13 +660,37 @@ def einsum_q_sweep(dev, B, H, W):
                     call()
                 e.record()
                 torch.cuda.synchronize()
-            ms = s.elapsed_time(e) / 20
+                ms_eager = s.elapsed_time(e) / 20
+                # the same 20 launches replayed from ONE hipGraph (how the forward runs them): an eager Python loop issues a launch
+                # every ~8-10 us, which is the floor of `launch_ms_eager` for kernels shorter than that
+                ms = ms_eager
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        call()
+                    torch.cuda.current_stream().wait_stream(side)
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        for _ in range(20):
+                            call()
+                    gr.replay()
+                    torch.cuda.synchronize()
+                    s.record()
+                    for _ in range(5):
+                        gr.replay()
+                    e.record()
+                    torch.cuda.synchronize()
+                    ms = s.elapsed_time(e) / 100
+                except Exception as ex:          # loud: the line says which figure it carries
+                    print(f'bench.py: einsum sweep graph capture failed ({type(ex).__name__}: {ex}); eager timing', file=sys.stderr)
             fl = 2.0 * B * Q * 256 * HW4
             by = B * (256 * HW4 * (4 if split else 2) + Q * 256 * 4 + (Q * HW4 // 8 if fused else Q * HW4 * 4))
             peak = X3_PEAK_TF if split else MFMA_BF16_PEAK_TF
             tf = fl / (ms * 1e-3) / 1e12
             ai = fl / by
-            res.append(dict(queries=Q, mode=mode, launch_ms=ms, tflops=tf, frac_mfma_peak=tf / peak, mfma_peak_tf=peak,
+            res.append(dict(queries=Q, mode=mode, launch_ms=ms, launch_ms_eager_loop=ms_eager,
+                            timed='20 launches back to back in one hipGraph, 5 replays' if ms != ms_eager else 'eager launches', tflops=tf, frac_mfma_peak=tf / peak, mfma_peak_tf=peak,
                             frac_hbm_roofline_attainable=tf / min(peak, ai * HBM_PEAK_GBS / 1e3), GBs=by / (ms * 1e-3) / 1e9,
                             frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=by, flops=fl,
                             arithmetic_intensity=ai, launches_q_split=2 if (split and Q > 128) else 1))

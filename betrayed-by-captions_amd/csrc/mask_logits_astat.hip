@@ -8,7 +8,7 @@
 // stored (round-5 measurement: Q = 200 bits-only 37.0 us vs 38.4 us with f32 logits out -- the store is not the bound).
 // Here a wavefront owns up to FOUR query tiles (128 queries) for the whole launch: their 64 A fragments live in 256 VGPRs (one wave
 // per SIMD, the 512-register budget), the pixel tiles stream through as 16 coalesced 1-KiB loads each (the packed image of
-// cgg_pack_mask_feature*: every B fragment is one global_load_dwordx4 per lane, no LDS), three register sets deep (two tiles in
+// cgg_pack_mask_feature*: every B fragment is one global_load_dwordx4 per lane, no LDS), two register sets deep (the next tile in
 // flight behind the one being multiplied). Per MFMA the CU moves 256 B instead of 1 KiB, all of it through the vector memory path; LDS is only used once, to
 // turn mask_embed into fragment order. Q > 128: two wave groups hold query tiles [0, 4) and [4, MT), the two waves of a pair walk
 // the same pixel tiles (the second read of a tile hits L2).
@@ -17,6 +17,7 @@
 // ballots, staged per wave in LDS and written as contiguous pieces of the rows; the logits are never stored (the forward's last
 // layer, which needs them, keeps cgg_mask_logits). The kernel's HBM traffic is the packed feature (67 MB at 1024^2, batch 2): arithmetic intensity 97 (Q = 100) / 190 (Q = 200) FLOP/B instead of 56 / 78.
 #include "x3.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
   // ---- (0) the first two tiles are requested before the prologue: their HBM latency hides under it ----
   u32x4 b0[MLA_KS], b1[MLA_KS];
   if (tbeg < tend) mla_load_tile(b0, fb, tbeg, nt);
-  if (tbeg + 1 < tend) mla_load_tile(b1, fb, tbeg + 1, nt);
+  if (tbeg + 1 < tend) mla_load_tile(b1, fb, tbeg + 1, nt);      // (MLA_RUN >= 2: inside the first run)
 
   // ---- (1) prologue: mask_embed[b] -> bf16 A fragments in LDS (float4 (q, c4) -> slot (q / 32, c4 / 4, q % 32 + 32 ((c4 / 2) & 1)),
   //      half c4 & 1), rows >= Q are zero; then this wave's MTW x 16 fragments into registers ----
@@ -99,26 +100,56 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
   uint32_t* __restrict__ bb = bits + ((size_t)b * Q + mt0 * 32) * T;
   const int nrows = min(MTW * 32, Q - mt0 * 32);               // uniform
 
-  // one pixel tile: MTW x 16 MFMAs against the register-resident query tiles, threshold consumer per query tile
-  auto do_tile = [&](const u32x4 (&cur)[MLA_KS], int tt, int slot) {
+  // one pixel tile: MTW x 16 MFMAs against the register-resident query tiles. The threshold consumer of query tile i is interleaved,
+  // step by step, with the MFMAs of query tile i + 1 (two accumulators): a wave issues in order, and with one wave per SIMD the
+  // 16 ballots + 32 v_writelane of a tile's epilogue would otherwise run while the matrix pipe idles (measured before the
+  // interleave: 0.5 us per (tile, query tile) unit against 0.21 us of MFMA time).
+  // Threshold consumer: 16 ballots -> the 32 rows' words gathered into ONE register (lane = row) by v_writelane, one LDS store per
+  // query tile (a predicated store per ballot = 16 exec-mask branches per query tile cost 0.9 us per unit).
+  auto epi_step = [&](const f32x16& acc, int r, bool pin, uint32_t& wv) {
+    const unsigned long long m = __ballot(pin && acc[r] < 0.f);
+    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);     // lanes 0-31 voted for row ql, lanes 32-63 for row ql + 4
+    // (inline asm is opaque to the hazard recognizer: the s_nop covers "VALU writes an SGPR -> v_writelane reads it" -- without it
+    // ONE of the 32 words of a query tile came out as all-ones, the one whose compare the scheduler had put right in front)
+    switch (r) {
+#define MLA_WL(R)                                                                                         \
+  case R:                                                                                                 \
+    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"                 \
+                 : "+v"(wv)                                                                               \
+                 : "s"(mlo), "s"(mhi), "n"(((R) & 3) + 8 * ((R) >> 2)), "n"(((R) & 3) + 8 * ((R) >> 2) + 4)); \
+    break;
+      MLA_WL(0) MLA_WL(1) MLA_WL(2) MLA_WL(3) MLA_WL(4) MLA_WL(5) MLA_WL(6) MLA_WL(7)
+      MLA_WL(8) MLA_WL(9) MLA_WL(10) MLA_WL(11) MLA_WL(12) MLA_WL(13) MLA_WL(14) MLA_WL(15)
+#undef MLA_WL
+    }
+  };
+  auto do_tile = [&](auto nmt_c, const u32x4 (&cur)[MLA_KS], int tt, int slot) {
+    constexpr int NMT = decltype(nmt_c)::value;                // query tiles of this wave's group (compile time: straight-line code)
     const bool pin = tt * 32 + col < npix;
-    uint32_t* srow = stage + (4 * hi5) * MLA_RUN + slot;       // per lane: its half's first row, this tile's column
+    f32x16 accC, accN;
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      if (mt0 + i >= MT) break;                                // wave-uniform
-      f32x16 acc;
+    for (int r = 0; r < 16; ++r) accC[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ks = 0; ks < MLA_KS; ++ks)
+      accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0][ks]), __builtin_bit_cast(bf16x8, cur[ks]), accC, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < MLA_KS; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[i][ks]), __builtin_bit_cast(bf16x8, cur[ks]), acc, 0, 0,
-                                                      0);
+    for (int i = 0; i < NMT; ++i) {
+      uint32_t wv = 0u;
+      if (i + 1 < NMT) {                                     // (compile time after unrolling)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned long long m = __ballot(pin && acc[r] < 0.f);
-        const uint32_t w = hi5 ? (uint32_t)(m >> 32) : (uint32_t)m;     // lanes 0-31: row ql, 32-63: ql + 4
-        if (col == 0) srow[(i * 32 + (r & 3) + 8 * (r >> 2)) * MLA_RUN] = w;
+        for (int r = 0; r < 16; ++r) accN[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < MLA_KS; ++ks) {
+          accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[i + 1 < MTW ? i + 1 : i][ks]),
+                                                         __builtin_bit_cast(bf16x8, cur[ks]), accN, 0, 0, 0);
+          epi_step(accC, ks, pin, wv);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epi_step(accC, r, pin, wv);
       }
+      if (lane < 32) stage[(i * 32 + lane) * MLA_RUN + slot] = wv;
+      accC = accN;
     }
   };
   auto flush = [&](int t0, int n) {                            // tiles [t0, t0 + n) of the run -> bits rows
@@ -128,27 +159,35 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
     }
   };
 
-  // ---- (2) stream: three register sets -- two tiles in flight behind the one being multiplied (2 x 0.85 us of MFMA time against
-  //      an HBM latency that one wave per SIMD cannot hide by occupancy); 256 A + 3 x 64 B + 16 accumulator registers = 502 of 512 ----
-  int run0 = tbeg;
-  u32x4 b2[MLA_KS];
-  if (tbeg + 2 < tend) mla_load_tile(b2, fb, tbeg + 2, nt);
-  for (int t = tbeg; t < tend; t += 3) {
-    do_tile(b0, t, t - run0);
-    if (t + 3 < tend) mla_load_tile(b0, fb, t + 3, nt);
-    if (t + 1 < tend) {
-      do_tile(b1, t + 1, t + 1 - run0);
-      if (t + 4 < tend) mla_load_tile(b1, fb, t + 4, nt);
+  // ---- (2) stream: two register sets (the next tile in flight behind the one being multiplied; a third set measured the same:
+  //      35.8 vs 36.0 us -- the stream was never the bound) + two accumulators: 256 A + 2 x 64 B + 32 accumulator registers ----
+  // Runs of <= MLA_RUN tiles: the tile loop of a run contains NO stores (the words wait in LDS), the run's flush follows it. With the
+  // flush inside the tile loop the compiler's s_waitcnt pass saw stores of unknown count outstanding at the loop header and fell
+  // back to vmcnt(0) in front of the first MFMA of every pair: the prefetched tile was waited for as well, i.e. half of the loads
+  // had no compute to hide behind (stream and MFMA time added up: 35 us at Q = 200 instead of max(stream, compute) + prologue).
+  auto stream_tiles = [&](auto nmt_c) {
+    for (int run0 = tbeg; run0 < tend; run0 += MLA_RUN) {
+      const int rend = min(tend, run0 + MLA_RUN);
+      if (run0 != tbeg) {                                      // (the first run's tiles were requested before the prologue)
+        mla_load_tile(b0, fb, run0, nt);
+        if (run0 + 1 < rend) mla_load_tile(b1, fb, run0 + 1, nt);
+      }
+      for (int t = run0; t < rend; t += 2) {
+        do_tile(nmt_c, b0, t, t - run0);
+        if (t + 2 < rend) mla_load_tile(b0, fb, t + 2, nt);
+        if (t + 1 < rend) {
+          do_tile(nmt_c, b1, t + 1, t + 1 - run0);
+          if (t + 3 < rend) mla_load_tile(b1, fb, t + 3, nt);
+        }
+      }
+      flush(run0, rend - run0);
     }
-    if (t + 2 < tend) {
-      do_tile(b2, t + 2, t + 2 - run0);
-      if (t + 5 < tend) mla_load_tile(b2, fb, t + 5, nt);
-    }
-    if (t + 3 - run0 + 3 > MLA_RUN || t + 3 >= tend) {
-      flush(run0, min(tend, t + 3) - run0);
-      run0 = t + 3;
-    }
-  }
+  };
+  const int nmt = min(MTW, MT - mt0);                          // wave-uniform
+  if (nmt == 4) stream_tiles(std::integral_constant<int, 4>{});
+  else if (nmt == 3) stream_tiles(std::integral_constant<int, 3>{});
+  else if (nmt == 2) stream_tiles(std::integral_constant<int, 2>{});
+  else if (nmt == 1) stream_tiles(std::integral_constant<int, 1>{});
 }
 
 // Consumer-fused bf16 form of cgg_mask_logits with the query operand stationary: embed (B, Q, 256) f32, hi = packed bf16 feature

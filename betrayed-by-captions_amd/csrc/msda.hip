@@ -126,85 +126,6 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_kernel(
   }
 }
 
-// Encoder-stream specialisation (bf16 value / bf16 [offsets | logits] rows / bf16 output, L = 3, P = 4, D = 32): the same
-// arithmetic in the same order as cgg_msda_fwd_kernel<uint16_t, 3, 4, true, uint16_t, uint16_t> (bit-identical output), but
-// the (query, head)'s 24 offsets and 12 logits are fetched with 3 x 16-byte + 3 x 8-byte vector loads instead of 60
-// two-byte loads per lane (the generic kernel re-reads the logits for the max, the sum and every point): 54 of the 108
-// memory instructions of a lane disappear, and the probabilities exp(w - max) are computed once.
-__global__ __launch_bounds__(256) void cgg_msda_fwd_stream_kernel(
-    const uint16_t* __restrict__ value, MsdaLevels lv, const uint16_t* __restrict__ rows, const float* __restrict__ ref,
-    int ld, uint16_t* __restrict__ out, int Nv, int H, int Nq, long long total) {
-  constexpr int D = 32, CPL = 8, DQ = 4, L = 3, P = 4, LP = 12;
-  const int bid = cgg_xcd_remap(blockIdx.x, gridDim.x);
-  const long long gid = (long long)bid * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int cq = (int)(gid % DQ);
-  const int h = (int)((gid / DQ) % H);
-  const long long bq = gid / ((long long)DQ * H);
-  const int b = (int)(bq / Nq);
-  const int q = (int)(bq - (long long)b * Nq);
-  const size_t rowstride = (size_t)H * D;
-  const uint16_t* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * CPL;
-  const uint16_t* row = rows + (size_t)bq * ld;
-  const uint16_t* lp = row + (size_t)h * LP * 2;                       // 24 offsets: 48 bytes, 16-byte aligned
-  const uint16_t* wp = row + (size_t)H * LP * 2 + (size_t)h * LP;      // 12 logits: 24 bytes, 8-byte aligned
-  const float rx = ref[2 * q], ry = ref[2 * q + 1];
-  float e[LP];
-  {
-    const uint2 a = *reinterpret_cast<const uint2*>(wp), c = *reinterpret_cast<const uint2*>(wp + 4),
-                d = *reinterpret_cast<const uint2*>(wp + 8);
-    const uint32_t u[6] = {a.x, a.y, c.x, c.y, d.x, d.y};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      e[2 * i] = __uint_as_float(u[i] << 16);
-      e[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
-    }
-  }
-  float smax = e[0];
-#pragma unroll
-  for (int i = 1; i < LP; ++i) smax = fmaxf(smax, e[i]);
-  float ssum = 0.f;
-#pragma unroll
-  for (int i = 0; i < LP; ++i) {
-    e[i] = __expf(e[i] - smax);
-    ssum += e[i];
-  }
-  const float sinv = 1.f / ssum;
-
-  float acc[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
-#pragma unroll 1
-  for (int l = 0; l < L; ++l) {
-    const int Hl = lv.h[l], Wl = lv.w[l];
-    const uint16_t* vl = vb + (size_t)lv.start[l] * rowstride;
-    const uint4 o = *reinterpret_cast<const uint4*>(lp + 8 * l);       // (x, y) of the level's 4 points
-    const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
-    float wl[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) wl[p] = (l == 0 ? e[p] : (l == 1 ? e[4 + p] : e[8 + p])) * sinv;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const float x = rx + __uint_as_float(ow[p] << 16) / (float)Wl;
-      const float y = ry + __uint_as_float(ow[p] & 0xffff0000u) / (float)Hl;
-      const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
-      float sacc[CPL];
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) sacc[c] = 0.f;
-      MsdaVec<uint16_t>::fma(sacc, t.w00, vl + (size_t)t.o00 * rowstride);
-      MsdaVec<uint16_t>::fma(sacc, t.w01, vl + (size_t)t.o01 * rowstride);
-      MsdaVec<uint16_t>::fma(sacc, t.w10, vl + (size_t)t.o10 * rowstride);
-      MsdaVec<uint16_t>::fma(sacc, t.w11, vl + (size_t)t.o11 * rowstride);
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) acc[c] = fmaf(wl[p], sacc[c], acc[c]);
-    }
-  }
-  uint16_t* op = out + (size_t)bq * rowstride + (size_t)h * D + cq * CPL;
-  *reinterpret_cast<uint4*>(op) =
-      make_uint4(cgg_pack2(cgg_f2bf(acc[0]), cgg_f2bf(acc[1])), cgg_pack2(cgg_f2bf(acc[2]), cgg_f2bf(acc[3])),
-                 cgg_pack2(cgg_f2bf(acc[4]), cgg_f2bf(acc[5])), cgg_pack2(cgg_f2bf(acc[6]), cgg_f2bf(acc[7])));
-}
-
 // Second encoder-stream specialisation. PMC (profiles/r2_pmc_sq_*): the kernel above is INSTRUCTION-ISSUE bound -- the
 // SIMDs issue ~100 % of the kernel's cycles (a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles), 20 % of the
 // wave cycles wait on memory -- so this version removes instructions instead of bytes:
@@ -998,11 +919,10 @@ static int msda_fused_bf16_impl(bool head_major, const void* value, const int32_
   const long long total = (long long)B * Nq * H * (D / 8);
   const int nblk = (int)((total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
-  // A/B switches: CGG_MSDA_GENERIC=1 -> generic kernel, CGG_MSDA_V1=1 -> vector-row kernel, default -> quad-shared taps
+  // CGG_MSDA_GENERIC=1 forces the generic kernel (the fallback of every other shape; tests run it on the stream's shapes too)
   static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
-  static const bool v1_only = getenv("CGG_MSDA_V1") != nullptr;
   const bool fast_ok = L == 3 && P == 4 && D == 32 && ld % 8 == 0 && cgg_aligned16(offs_logits) && !generic_only;
-  const bool quad_ok = fast_ok && !v1_only && H == 8 && (long long)Nv * H * D < (1ll << 31) && total < (1ll << 31);
+  const bool quad_ok = fast_ok && H == 8 && (long long)Nv * H * D < (1ll << 31) && total < (1ll << 31);
   CGG_REQUIRE(!head_major || quad_ok, CGG_EUNSUPPORTED,
               "cgg_msda_forward_fused_bf16_hm: head-major values need H=8, D=32, L=3, P=4 (H=%d D=%d L=%d P=%d)", H, D, L, P);
   if (quad_ok && head_major)
@@ -1011,9 +931,6 @@ static int msda_fused_bf16_impl(bool head_major, const void* value, const int32_
   else if (quad_ok)
     hipLaunchKernelGGL(cgg_msda_fwd_stream2_kernel<false>, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
                        (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, Nq, (unsigned)total);
-  else if (fast_ok)
-    hipLaunchKernelGGL(cgg_msda_fwd_stream_kernel, dim3(nblk), dim3(256), 0, s, (const uint16_t*)value, lv,
-                       (const uint16_t*)offs_logits, ref_points, ld, (uint16_t*)out, Nv, H, Nq, total);
   else if (L == 3 && P == 4)
     hipLaunchKernelGGL((cgg_msda_fwd_kernel<uint16_t, 3, 4, true, uint16_t, uint16_t>), dim3(nblk), dim3(256), 0, s,
                        (const uint16_t*)value, lv, (const uint16_t*)offs_logits, (const uint16_t*)nullptr, ref_points,

@@ -222,10 +222,11 @@ static int msda_sort_plan(const MsdaLevels& lv, int B, int Nv, int H, int D, int
     pl.s[l] = lv.w[l] / lv.w[lc];
   }
   for (int l = L; l < 8; ++l) pl.s[l] = 0;
-  // tile edge c (coarsest-level pixels) and halo R: the largest tile whose buffers fit the LDS budget (bigger tiles = fewer window
-  // pixels per tile pixel = fewer flush atomics); CGG_MSDA_BWD_C / _R override (measurement)
-  static const int force_c = getenv("CGG_MSDA_BWD_C") ? atoi(getenv("CGG_MSDA_BWD_C")) : 0;
-  static const int force_r = getenv("CGG_MSDA_BWD_R") ? atoi(getenv("CGG_MSDA_BWD_R")) : 0;
+  // tile edge c (coarsest-level pixels) and halo R = 4 pixels (the reference's initialisation puts point p at p + 1 pixels from the
+  // reference point: 4 covers it). Measured at configs[2] shapes (offset std 0.5 px, per backward call): c = 2 2.84 ms, c = 4
+  // 4.04 ms (93 KB of LDS: one workgroup per CU), R = 2 / 3 with c = 2: 2.71 / 2.87 ms; the window flush (one 128-byte global atomic
+  // per window pixel) is 0.06 ms of it -- the atomics are NOT the bound, the per-workgroup phase latencies are
+  const int force_c = 0, force_r = 0;
   // c = 2 first: 25 KB of LDS per workgroup, five or six workgroups per CU overlap each other's load / sort / sum phases (measured
   // at configs[2] shapes, +-2 px offsets: c = 2 1.70 ms, c = 4 2.57 ms per call -- the 93-KB c = 4 tile runs one workgroup per CU)
   const int cands[3] = {2, 4, 1};

@@ -306,8 +306,8 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
   // scratch/ab_tiles.sh): the larger tiles are the more efficient ones per FLOP, and the CUs a small grid leaves idle are taken by
   // the other streams' kernels, so the step prefers FEWER, BIGGER tiles than a stand-alone launch does -- threshold 384 + smaller
   // tiles for K <= 512 (the stand-alone optimum of the first version): 349 images/s; 192, no K rule: 358 (eager GEMM time equal);
-  // 128: 363 with +7 % eager GEMM time and +3 % latency (not taken). CGG_XG_MINTILES overrides.
-  static const int mintiles = getenv("CGG_XG_MINTILES") ? atoi(getenv("CGG_XG_MINTILES")) : 192;
+  // 128: 363 with +7 % eager GEMM time and +3 % latency (not taken).
+  const int mintiles = 192;
   auto tiles = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)); };
   int tm = 2, tn = N <= 64 ? 1 : 2;
   if (tiles(tm, tn) < mintiles) tm = 1;
