@@ -100,7 +100,6 @@ PROTOTYPES = {
     'cgg_wgrad_bias_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_transpose_f32': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     'cgg_absmax_f32': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
-    'cgg_absmax_sampled_f32': (_c_int, [_c_vp, _c_i64, _c_int, _c_vp, _c_vp]),
     'cgg_gemm_x3_bwd': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_gemm_x3_scaled': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 4 + [_c_vp]),
     'cgg_conv_x3_nhwc_scaled': (_c_int, [_c_vp] * 6 + [_c_int] * 10 + [_c_vp]),

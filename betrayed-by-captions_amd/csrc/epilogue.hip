@@ -336,7 +336,7 @@ extern "C" int cgg_transpose_f32(const float* in, float* out, int B, int R, int 
 // wave max by DPP-free shuffles, one u32 atomicMax per wave (|x| as a bit pattern is monotone; a NaN compares above inf and
 // selects the default scale downstream).
 __global__ __launch_bounds__(256) void cgg_absmax_f32_kernel(const float* __restrict__ x, long long ld4, long long n4_per_row,
-                                                             long long total4, uint32_t* __restrict__ out, uint32_t exp_bias) {
+                                                             long long total4, uint32_t* __restrict__ out) {
   uint32_t m = 0;
   const f32x4* xv = reinterpret_cast<const f32x4*>(x);
   const bool dense = ld4 == n4_per_row;
@@ -359,37 +359,7 @@ __global__ __launch_bounds__(256) void cgg_absmax_f32_kernel(const float* __rest
     const uint32_t o = (uint32_t)__shfl_xor((int)m, s, 64);
     m = o > m ? o : m;
   }
-  // exp_bias: the sampled form reports 2^exp_bias x the sampled maximum (headroom for what it did not look at)
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m + (exp_bias << 23));
-}
-
-// ... over a SAMPLE of the tensor: every `stride`-th 1-KiB block of the dense element sequence (rows of a dense matrix cut into
-// 256-float blocks). For the per-tensor pre-scale only (x3.h): the scale derived from a sampled maximum leaves 2^9 of headroom
-// (it REPORTS 8 x the sampled maximum, so the consumer's scale targets 2^6..2^7 instead of 2^9..2^10), any power of two that neither overflows nor starves the low piece gives the same accuracy, and
-// an un-sampled outlier beyond the headroom raises the x3 overflow flag in the consuming kernel instead of passing silently.
-// 1/8 of a 1.4-GB gradient is a 35-us pass instead of 280 us (6.7 ms per training step at configs[2] with the full passes).
-extern "C" int cgg_absmax_sampled_f32(const float* x, int64_t n, int stride, float* amax, cgg_stream_t stream) {
-  CGG_REQUIRE(x && amax, CGG_EINVAL, "cgg_absmax_sampled_f32: null pointer");
-  CGG_REQUIRE(n > 0 && stride >= 1 && cgg_aligned16(x), CGG_EINVAL, "cgg_absmax_sampled_f32: bad arguments");
-  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
-  CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_absmax_sampled_f32: memset failed");
-  // blocks of 256 floats = 64 float4: view as a matrix of `nblk / stride` rows of 64 float4 at row stride 64 * stride float4
-  const long long nblk = n / 256;
-  if (nblk < (long long)stride * 8) {        // small tensors: the full pass
-    const long long n4 = n / 4;
-    if (n4 == 0) return CGG_OK;
-    hipLaunchKernelGGL(cgg_absmax_f32_kernel, dim3((unsigned)((n4 + 2047) / 2048 > 2048 ? 2048 : (n4 + 2047) / 2048)), dim3(256), 0,
-                       (hipStream_t)stream, x, n4, n4, n4, reinterpret_cast<uint32_t*>(amax), 0u);
-    CGG_CHECK_LAUNCH("cgg_absmax_sampled_f32");
-    return CGG_OK;
-  }
-  const long long rows = nblk / stride, total4 = rows * 64;
-  long long nb = (total4 + 2047) / 2048;
-  nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
-  hipLaunchKernelGGL(cgg_absmax_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)64 * stride,
-                     (long long)64, total4, reinterpret_cast<uint32_t*>(amax), 3u);
-  CGG_CHECK_LAUNCH("cgg_absmax_sampled_f32");
-  return CGG_OK;
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 extern "C" int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax, cgg_stream_t stream) {
@@ -402,7 +372,7 @@ extern "C" int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax,
   long long nb = (total4 + 256 * 8 - 1) / (256 * 8);
   nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
   hipLaunchKernelGGL(cgg_absmax_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)(ld / 4),
-                     (long long)(N / 4), total4, reinterpret_cast<uint32_t*>(amax), 0u);
+                     (long long)(N / 4), total4, reinterpret_cast<uint32_t*>(amax));
   CGG_CHECK_LAUNCH("cgg_absmax_f32");
   return CGG_OK;
 }

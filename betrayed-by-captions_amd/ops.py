@@ -1166,22 +1166,12 @@ def pack_conv_weight_x3(weight):
     return pack_linear_weight_x3(weight.detach().float().permute(0, 2, 3, 1).reshape(N, -1))
 
 
-ABSMAX_SAMPLE_STRIDE = 8          # `absmax(x, sample=True)` looks at every 8th 1-KiB block of tensors >= 16 MiB
-
-
-def absmax(x, sample=False):
+def absmax(x):
     """max |x| of a float32 ROCm matrix / tensor (last dim contiguous, % 4) -> device scalar (1,) f32: the per-tensor pre-scale
-    of the x3 contractions' grad_output operands (`gemm_x3(..., amax=)`, `wgrad_x3(..., amax=)`; csrc/x3.h).
-    sample=True (large dense tensors only): 8 x the maximum over every 8th 1-KiB block -- an eighth of the memory pass; the factor 8
-    is headroom for what was not looked at (the scale is a power of two: any value that neither overflows f16 nor starves the low
-    piece gives the same accuracy; an un-sampled outlier > 2^9 x the sampled maximum turns into inf in the consumer, loudly)."""
+    of the x3 contractions' grad_output operands (`gemm_x3(..., amax=)`, `wgrad_x3(..., amax=)`; csrc/x3.h). Exact: one streaming
+    pass over the tensor (a sampled maximum is NOT safe for gradients -- they are sparse, see runtime._X3LinearFn.backward)."""
     if x.dtype != torch.float32 or not x.is_cuda:
         raise CggError('absmax: float32 ROCm tensor expected')
-    if sample and x.is_contiguous() and x.numel() >= (4 << 20) and x.data_ptr() % 16 == 0:
-        out = torch.empty(1, dtype=torch.float32, device=x.device)
-        check(_lib_().cgg_absmax_sampled_f32(ctypes.c_void_p(x.data_ptr()), x.numel(), ABSMAX_SAMPLE_STRIDE, dev_ptr(out),
-                                             stream_ptr(x.device)), 'cgg_absmax_sampled_f32')
-        return out
     x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
     if x2.dim() != 2 or x2.stride(1) != 1:
         raise CggError('absmax: a 2-D view with a contiguous last dim expected')

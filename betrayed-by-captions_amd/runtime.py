@@ -207,10 +207,12 @@ class _X3LinearFn(torch.autograd.Function):
         M = x2.shape[0]
         gx = gw = gb = None
         # grad_output is not unit scale (|g| ~ 1e-4 .. 1e-8 behind a normalised loss): its f16 pieces are taken after a per-tensor
-        # power-of-two pre-scale from max |g| (ONE streaming pass, shared by the grad-input GEMM and the weight-gradient kernel)
+        # power-of-two pre-scale from max |g| (ONE exact streaming pass, shared by the grad-input GEMM and the weight-gradient kernel;
+        # a SAMPLED maximum was tried and is unsafe: encoder gradients are sparse -- most rows ~0, a few boundary rows 10^6 x larger --
+        # so every 8th row can miss all of them and the true maximum then overflows f16: NaN weight gradients at configs[2] shapes)
         # instead of the activations' fixed 2^4 (with 2^4 a gradient of 1e-6 kept ~10 of its 22 bits); CGG_X3_GSCALE=0
         # restores the fixed scale for A/B
-        amax = ops.absmax(g2, sample=True) if _X3_GSCALE and N % 4 == 0 else None
+        amax = ops.absmax(g2) if _X3_GSCALE and N % 4 == 0 else None
         if ctx.needs_input_grad[0]:
             wtk = derived_cached('x3_image_t', (weight,), lambda: ops.pack_linear_weight_x3(weight.detach().t().contiguous()))
             gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
@@ -260,7 +262,7 @@ class _X3FfnFn(torch.autograd.Function):
         g2 = gy.reshape(-1, N)
         if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:
             g2 = g2.contiguous()
-        amax = ops.absmax(g2, sample=True) if _X3_GSCALE else None
+        amax = ops.absmax(g2) if _X3_GSCALE else None
         gw2, gb2 = ops.wgrad_x3(g2, h, want_bias=True, amax=amax)
         w2t = derived_cached('x3_image_t', (w2,), lambda: ops.pack_linear_weight_x3(w2.detach().t().contiguous()))
         gh, amax_h = ops.gemm_x3_bwd(g2, w2t, F_, amax=amax, mask=h, want_amax=_X3_GSCALE)       # d / d(pre-activation)
@@ -311,7 +313,7 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         gl = ops.nchw_to_nhwc(gy)
         gl = gl if gl.is_contiguous() else gl.contiguous()
         gx = gw = None
-        amax = ops.absmax(gl.view(-1, N), sample=True) if _X3_GSCALE else None        # per-tensor pre-scale of grad_output (see _X3LinearFn)
+        amax = ops.absmax(gl.view(-1, N)) if _X3_GSCALE else None        # per-tensor pre-scale of grad_output (see _X3LinearFn)
         if ctx.needs_input_grad[0] and amax is not None:
             wt = derived_cached('x3_conv_image_dgrad', (weight,),
                                 lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))

@@ -538,9 +538,6 @@ int cgg_wgrad_bias_x3(const float* dy, int ldy, const float* x, int ldx, float* 
  * of 2^4 and fold the inverse into their epilogue (exact). amax pointers are nullable (= the fixed 2^4). Otherwise the
  * contracts of cgg_gemm_x3 / cgg_conv_x3_nhwc / cgg_wgrad_x3 / cgg_wgrad_bias_x3 (ws_bias nullable here). */
 int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax, cgg_stream_t stream);
-/* ... from every `stride`-th 1-KiB block of n contiguous floats, reported x 8 (headroom for the un-sampled part: the consumer's
- * pre-scale then targets 2^6..2^7; an outlier beyond 2^9 x the sampled maximum overflows to inf -- loudly -- in the consumer). */
-int cgg_absmax_sampled_f32(const float* x, int64_t n, int stride, float* amax, cgg_stream_t stream);
 /* cgg_gemm_x3_scaled for the backward of a fused training layer: `mask` (M, N; nullable) zeroes the result where mask <= 0 (the
  * ReLU backward of the layer whose output `mask` is), out_amax (device scalar, nullable) receives max |out| from the epilogue. */
 int cgg_gemm_x3_bwd(const float* a, int lda, const float* a_amax, const void* w_x3, const float* mask, int ldm, float* out, int ldc,
