@@ -174,7 +174,7 @@ def cpu_baseline(args, cfg, model, img_cpu):
 
 
 def committed_profile(name):
-    """A summary committed under profiles/ by scratch/collect_profiles_r3.sh (rocprofv3 runs of THIS command on an MI355X;
+    """A summary committed under profiles/ by scratch/collect_profiles_r5.sh + publish_profiles_r5.py (rocprofv3 runs of THIS command on an MI355X;
     counters cannot be collected from inside the process). Every field taken from it is labelled `source: committed profile`."""
     path = os.path.join(ROOT, 'profiles', name)
     if not os.path.exists(path):
@@ -549,7 +549,8 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
     timed = ('HIP events around the launches in the same %d steps re-run eagerly right after the timed region (events cannot be '
              'recorded inside a hipGraph replay); raw means' % args.steps)
     out = {}
-    prof = committed_profile('r4_fp32_kernels.json') or committed_profile('r3_fp32_kernels.json') or {}
+    prof = committed_profile('r5_cfg4_kernels.json' if getattr(args, 'workload', 'cfg1') == 'cfg4' else 'r5_fp32_kernels.json') or \
+        (committed_profile('r4_fp32_kernels.json') if getattr(args, 'workload', 'cfg1') == 'cfg1' else None) or {}
 
     def ms_list(name):
         return [s.elapsed_time(e) for s, e in events.get(name, [])]
@@ -754,10 +755,14 @@ def train_step_child(args, precision='fp32', workload='cfg2'):
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', table)) as f:
                 rows = f.read().splitlines()
             head = [r for r in rows if r.startswith('step (eager')][0]
-            top = rows[rows.index(head) + 2].split(None, 3)
+            hdr = next(i for i, r in enumerate(rows) if r.split()[:2] == ['us/step', 'calls'])
+            top = rows[hdr + 1].split(None, 3)
             import re
             mh = re.search(r': ([0-9.]+) launches, ([0-9.]+) us of kernel time', head)
+            own = [r for r in rows if r.startswith('hand-written (cgg_*)')]
+            mo = re.search(r'= ([0-9.]+) % of the kernel time', own[0]) if own else None
             prof = dict(launches_per_step=float(mh.group(1)), kernel_ms_per_step=float(mh.group(2)) / 1e3,
+                        hand_written_share_of_kernel_time=float(mo.group(1)) / 100.0 if mo else None,
                         dominant_kernel=dict(name=top[3].split('(')[0], ms_per_step=float(top[0]) / 1e3, launches_per_step=float(top[1]),
                                              share_of_kernel_time=float(top[2]) / 100.0),
                         profile_source=f'committed profile: profiles/{table} (rocprofv3 --kernel-trace of this command)')

@@ -30,6 +30,8 @@ def point_sample(inp, points):
     add = points.dim() == 3
     if add:
         points = points.unsqueeze(2)
+    if inp.dtype != points.dtype:         # (a float64 run of the oracle, tests: the float32 GT masks follow the points' dtype)
+        inp = inp.to(points.dtype)
     out = F.grid_sample(inp, 2.0 * points - 1.0, align_corners=False)
     return out.squeeze(3) if add else out
 
@@ -331,7 +333,10 @@ class OracleHead(nn.Module):
         if getattr(self, 'trace', None) is not None:      # test hook: resized logits + mask before the fix-up
             self.trace['attn_logits'].append(am.flatten(2).detach().clone())
         am = am.flatten(2).unsqueeze(1).repeat((1, self.num_heads, 1, 1)).flatten(0, 1)
-        return cls_pred, emb, mask_pred, (am.sigmoid() < 0.5).detach()
+        blocked = (am.sigmoid() < 0.5).detach()
+        if getattr(self, 'inject', None):                 # test hook: the mask decisions of ANOTHER run of the same model (a float64 run
+            blocked = self.inject.pop(0).to(blocked.device)   # that must follow the float32 run's near-zero threshold decisions)
+        return cls_pred, emb, mask_pred, blocked
 
     def forward(self, feats, img_metas):
         B = len(img_metas)

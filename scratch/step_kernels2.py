@@ -33,6 +33,8 @@ span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3
 print('delimiter: %s' % delim[:100])
 print('step (eager, serial): %.0f launches, %.1f us of kernel time, %.1f us wall per step (mean of %d steps)'
       % (len(seg) / n, tot / n, span / n, n))
+own = sum(v[0] for k, v in agg.items() if 'cgg_' in k.split('(')[0])
+print('hand-written (cgg_*) kernels: %.1f us per step = %.1f %% of the kernel time' % (own / n, 100 * own / tot))
 print('%9s %6s %6s  %s' % ('us/step', 'calls', '%', 'kernel'))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
     print('%9.1f %6.1f %6.1f  %s' % (v[0] / n, v[1] / n, 100 * v[0] / tot, k))

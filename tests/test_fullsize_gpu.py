@@ -597,6 +597,23 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
                        batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
     sum(olosses.values()).backward()
     ograds = {k: (None if p.grad is None else p.grad.clone()) for k, p in orc.named_parameters()}
+    # float64 run of the same oracle with the float32 run's attention-mask decisions injected: the TRUTH both float32 implementations are
+    # measured against (a gradient that is a small difference of large sums carries ~1e-3 of float32 summation noise at this size in
+    # the oracle itself -- the oracle's own distance from float64 is the yardstick, as for the kernels)
+    heads = orc.num_heads
+    orc64 = copy.deepcopy(orc).double()
+    orc64.trace = None
+    orc64.inject = [(lg < 0).unsqueeze(1).repeat(1, heads, 1, 1).flatten(0, 1) for lg in teacher.logits]
+    bank64 = Bank(9)
+    orc64.point_hook = lambda kind, shape, device: bank64(kind, shape, device).double()      # the same draws
+    feats64 = [f.double().requires_grad_(True) for f in feats]
+    c64, e64, m64 = orc64.forward(feats64, metas)
+    l64 = orc64.loss(c64, e64, m64, batch['gt_labels'], [m.long() for m in batch['gt_masks']], batch['gt_caption_ids'],
+                     batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
+    sum(l64.values()).backward()
+    g64 = {k: (None if p.grad is None else p.grad.float()) for k, p in orc64.named_parameters()}
+    f64 = [f.grad.float() for f in feats64]
+    del orc64, c64, e64, m64, l64
     t_oracle = time.perf_counter() - t0
     prod.point_hook = Bank(9)
     prod.attn_mask_hook = teacher.hook
@@ -617,30 +634,36 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
         worst = max(worst, abs(a - b) / (1 + abs(b)))
         assert abs(a - b) <= 2e-3 * (1 + abs(b)), (k, a, b)
     named = dict(prod.named_parameters())
-    gworst = {}
+    gworst, oworst = {}, {}
     for key in HEAD_GRAD_KEYS:
-        g, og = named[key].grad, ograds[key]
-        assert g is not None and og is not None and torch.isfinite(g).all() and g.abs().sum() > 0, key
-        scale = og.abs().max().item()
-        err = (g.cpu() - og).abs().max().item()
-        gworst[key] = err / max(scale, 1e-30)
-    for pf, of in zip(pfeats, ofeats):                        # gradients w.r.t. the backbone features
-        scale = of.grad.abs().max().item()
-        err = (pf.grad.cpu() - of.grad).abs().max().item()
-        gworst['feat%s' % (tuple(pf.shape[1:]),)] = err / max(scale, 1e-30)
-    # bound: 1e-3 of each gradient's scale; 2e-3 for the sampling-offset parameters, whose gradient is a DIFFERENCE of neighbouring
-    # bilinear taps summed over 43 008+ queries (the f32 oracle's own summation order moves it by ~1e-3 at this size; 1.02e-3 measured)
-    bad = {k: v for k, v in gworst.items() if v > (2e-3 if 'sampling_offsets' in k else 1e-3)}
-    assert not bad, (bad, gworst)
+        g, og, tg = named[key].grad, ograds[key], g64[key]
+        assert g is not None and og is not None and tg is not None and torch.isfinite(g).all() and g.abs().sum() > 0, key
+        scale = max(tg.abs().max().item(), 1e-30)
+        gworst[key] = (g.cpu() - tg).abs().max().item() / scale
+        oworst[key] = (og - tg).abs().max().item() / scale
+    for pf, of, tf in zip(pfeats, ofeats, f64):               # gradients w.r.t. the backbone features
+        scale = max(tf.abs().max().item(), 1e-30)
+        k = 'feat%s' % (tuple(pf.shape[1:]),)
+        gworst[k] = (pf.grad.cpu() - tf).abs().max().item() / scale
+        oworst[k] = (of.grad - tf).abs().max().item() / scale
+    # bound per gradient, against the FLOAT64 oracle: 1e-3 of the gradient's scale, or 4 x the float32 oracle's own distance from
+    # float64 where that is larger (sampling-offset / level-encoding / feature-map gradients are small differences of sums over
+    # 43 008+ rows: the float32 oracle itself sits at 1e-3 .. 7e-3 there)
+    print(f'{name} gradient errors vs the float64 oracle, relative to each gradient\'s scale (product | float32 oracle):',
+          json.dumps({k: [float('%.3g' % gworst[k]), float('%.3g' % oworst[k])] for k in sorted(gworst)}))
+    bad = {k: (v, oworst[k]) for k, v in gworst.items() if v > max(1e-3, 4 * oworst[k])}
+    assert not bad, bad
     for n, p in prod.named_parameters():
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), n
     gw = max((v, k) for k, v in gworst.items())
     print(f'{name} full-size forward_train (B={B}, Q={hc["num_queries"]}): {len(losses)} losses within {worst:.1e} (relative, bound '
-          f'2e-3); {len(gworst)} gradients within {gw[0]:.1e} of their scale (worst: {gw[1]}; bound 1e-3); oracle fwd + bwd {t_oracle:.0f} s')
+          f'2e-3); {len(gworst)} gradients within {gw[0]:.1e} of their float64 value\'s scale (worst: {gw[1]}, float32 oracle there: {oworst[gw[1]]:.1e}; bound max(1e-3, 4 x the '
+          f'float32 oracle\'s own error)); oracle float32 + float64 fwd + bwd {t_oracle:.0f} s')
     _write_report(name.replace('[', '').replace(']', '') + '_train_slice',
                   dict(losses_worst_rel=worst, grad_worst_rel=gw[0], grad_worst_key=gw[1], oracle_seconds=t_oracle,
-                       grad_rel_err={k: float('%.3g' % v) for k, v in gworst.items()}))
+                       grad_rel_err_vs_float64={k: float('%.3g' % v) for k, v in gworst.items()},
+                       float32_oracle_rel_err_vs_float64={k: float('%.3g' % v) for k, v in oworst.items()}))
 
 
 def test_configs2_forward_train_slice_vs_oracle(dev):
