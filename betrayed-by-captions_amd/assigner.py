@@ -63,7 +63,12 @@ def get_uncertain_point_coords_with_randomness(mask_pred, labels, num_points, ov
     unc = get_uncertainty(point_logits, labels)
     num_uncertain = int(importance_sample_ratio * num_points)
     num_random = num_points - num_uncertain
-    idx = torch.topk(unc[:, 0, :], k=num_uncertain, dim=1)[1]
+    u2 = unc[:, 0, :]
+    if u2.is_cuda and u2.dtype == torch.float32 and u2.stride(1) == 1 and 0 < num_uncertain <= u2.shape[1]:
+        from . import ops
+        idx = ops.topk_select(u2, num_uncertain)          # the SET of the most uncertain points (the loss does not read their order)
+    else:
+        idx = torch.topk(u2, k=num_uncertain, dim=1)[1]
     shift = num_sampled * torch.arange(n, dtype=torch.long, device=mask_pred.device)
     idx = idx + shift[:, None]
     point_coords = point_coords.view(-1, 2)[idx.view(-1), :].view(n, num_uncertain, 2)

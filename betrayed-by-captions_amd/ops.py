@@ -1166,6 +1166,19 @@ def pack_conv_weight_x3(weight):
     return pack_linear_weight_x3(weight.detach().float().permute(0, 2, 3, 1).reshape(N, -1))
 
 
+def topk_select(x, k):
+    """x (rows, N) float32 ROCm (last dim contiguous) -> (rows, k) int64: the indices of each row's k largest values as a SET
+    (no order, ties at the threshold arbitrary) -- csrc/topk_select.hip, a radix select instead of torch.topk's sort."""
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1 or not 0 < k <= x.shape[1]:
+        raise CggError('topk_select: (rows, N) float32 ROCm matrix with a contiguous last dim and 0 < k <= N expected')
+    rows, N = x.shape
+    out = torch.empty((rows, k), dtype=torch.int64, device=x.device)
+    if rows:
+        check(_lib_().cgg_topk_select(ctypes.c_void_p(x.data_ptr()), int(x.stride(0)), rows, N, int(k), dev_ptr(out),
+                                      stream_ptr(x.device)), 'cgg_topk_select')
+    return out
+
+
 def absmax(x):
     """max |x| of a float32 ROCm matrix / tensor (last dim contiguous, % 4) -> device scalar (1,) f32: the per-tensor pre-scale
     of the x3 contractions' grad_output operands (`gemm_x3(..., amax=)`, `wgrad_x3(..., amax=)`; csrc/x3.h). Exact: one streaming

@@ -531,6 +531,11 @@ int cgg_wgrad_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, i
 int cgg_wgrad_bias_x3(const float* dy, int ldy, const float* x, int ldx, float* ws, float* ws_bias, int* splits_out, int M, int N,
                       int K, cgg_stream_t stream);
 
+/* Top-k SELECTION per row: idx[r, 0:k] = indices of the k largest x[r, 0:N] (row stride ld), in NO particular order, ties at the
+ * threshold broken arbitrarily -- the importance sampling of the mask losses ([3P] mmdet get_uncertain_point_coords_with_randomness,
+ * called at mask2former_head.py:605, keeps the 9 408 most uncertain of 37 632 random points per matched query; torch.topk sorts). */
+int cgg_topk_select(const float* x, int ld, int rows, int N, int k, int64_t* idx, cgg_stream_t stream);
+
 /* Per-tensor pre-scale of the x3 contractions' grad_output operands (round 5). The fixed 2^4 pre-scale of csrc/x3.h suits O(1)
  * activations; autograd's grad_output behind the F.linear / conv calls of mask2former_head.py:787 is not unit scale (|g| ~ 1e-6
  * keeps ~10 of the pair's 22 bits). cgg_absmax_f32 writes max |x| over an (M, N) f32 matrix (row stride ld; N, ld % 4 == 0) to the

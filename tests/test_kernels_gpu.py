@@ -264,6 +264,29 @@ def test_mask_logits_bits_astat_equals_streamed_kernel(dev, B, Q, H, W):
     assert torch.equal(ops.unpack_bits(got, H * W).view(B, Q, H, W), logits < 0)
 
 
+@pytest.mark.parametrize('rows,N,k', [(184, 37632, 9408), (3, 1000, 1), (5, 777, 777), (2, 4096, 1000), (1, 70, 33)])
+def test_topk_select_is_the_topk_set(dev, rows, N, k):
+    """cgg_topk_select (radix select, no order) vs torch.topk: the same SET of indices per row when the k-th value is unique, the
+    same multiset of VALUES with ties (a quantised row: many equal keys at the threshold), negative / positive / zero values."""
+    g = torch.Generator().manual_seed(rows + N)
+    x = -torch.randn(rows, N, generator=g).abs()                    # the uncertainty's sign convention: -|logit|
+    x[0, : min(N, 50)] = 0.0                                          # exact zeros (the largest values) -- ties above the threshold
+    xd = x.to(dev)
+    got = ops.topk_select(xd, k)
+    assert got.shape == (rows, k) and got.dtype == torch.int64
+    want = torch.topk(xd, k, dim=1)[1]
+    for r in range(rows):
+        assert len(set(got[r].tolist())) == k                       # k distinct indices
+    assert torch.equal(torch.sort(xd.gather(1, got), 1)[0], torch.sort(xd.gather(1, want), 1)[0])
+    q = (torch.randn(rows, N, generator=g) * 4).round().to(dev)      # heavy ties, both signs
+    gq = ops.topk_select(q, k)
+    assert torch.equal(torch.sort(q.gather(1, gq), 1)[0], torch.sort(q.gather(1, torch.topk(q, k, dim=1)[1]), 1)[0])
+    wide = torch.randn(rows, N + 8, generator=g).to(dev)[:, 3:3 + N] if N + 8 > 11 else None      # strided rows
+    if wide is not None and wide.stride(1) == 1:
+        gw = ops.topk_select(wide, k)
+        assert torch.equal(torch.sort(wide.gather(1, gw), 1)[0], torch.sort(wide.gather(1, torch.topk(wide, k, dim=1)[1]), 1)[0])
+
+
 def test_mask_logits_bf16_mode(dev):
     g = torch.Generator().manual_seed(11)
     B, Q, H, W = 2, 100, 32, 48
