@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the CGG decoder + mask-prediction hot path on MI355X.
 
-A "step" = one forward of `Mask2FormerOpen.simple_test` (R50 backbone -> MSDeformAttn pixel decoder ->
-9-layer masked-attention query decoder -> mask logits -> open-vocabulary instance post-processing for
-all / novel / base class sets) over one synthetic COCO-shaped batch that is already resident in HBM;
-results stay on the device (BASELINE.json configs[1]: R50, 100 queries, 1024x1024, batch 2, forward-only).
-N > 1: one process per GPU (torch.distributed / RCCL only for the barrier), every rank runs its own
-replica on its own batch -> weak scaling, no data-path collective (inference: "replicas only").
+`--workload cfg1` (default, BASELINE.json configs[1] = the metric's config): a "step" = one forward of `Mask2FormerOpen.simple_test`
+(R50 backbone -> MSDeformAttn pixel decoder -> 9-layer masked-attention query decoder -> mask logits -> open-vocabulary instance
+post-processing for all / novel / base class sets) over one synthetic COCO-shaped batch (1024 x 1024, batch 2, 100 queries) that is
+already resident in HBM; results stay on the device. N > 1: one process per GPU (torch.distributed / RCCL only for the barrier), every
+rank runs its own replica on its own batch -> weak scaling, no data-path collective (inference: "replicas only"); the N ranks then also
+take configs[2]'s image-parallel training step over RCCL (`train_step.n_gpus = N`).
+Other workloads: cfg2 = configs[2] (R50 training step, batch 16), cfg3 = configs[3] (Swin-B + 200 queries training step, batch 4 = one
+GPU's share of the DDP batch 32), cfg4 = configs[4] (COCO-panoptic forward, 1333 x 800 padded to 800 x 1344, batch 2).
 
 Launch: `python bench.py --gpus N` starts the N ranks ITSELF (child processes created before the parent touches the
 GPU; rank r binds device r, RCCL for the barrier / max-over-ranks); under an external launcher
@@ -15,17 +17,17 @@ the environment and `--gpus` must agree with WORLD_SIZE (it fails loudly otherwi
 
 Prints ONE JSON line (rank 0). `value` is PARITY mode (`--precision fp32`, the default): every contraction of the path in
 f32-class arithmetic on the f16 matrix cores (csrc/x3.h), the mode the 1e-3 / bit-exact parity tests run in. Extra objects:
-  roofline      -- the dominant kernel of that step, the x3 GEMM / implicit-GEMM convolution family (cgg_gemm_x3s_kernel: LDS-DMA GEMM
-                   over pre-split x3a rows, round 4), from HIP
-                   events on the launch stream around every launch of the K steps re-run eagerly after the timed region;
-                   kernels.* hold the encoder layer tail, the mask-logit einsum and MSDeformAttn the same way;
+  roofline      -- the dominant kernel family of that step, the x3 GEMM / implicit-GEMM convolution family (cgg_gemm_x3s_kernel: LDS-DMA
+                   GEMM over pre-split x3a rows), from HIP events on the launch stream around every launch of the K steps re-run eagerly
+                   after the timed region; kernels.* hold the encoder layer tail, the mask-logit einsum and MSDeformAttn the same way;
                    `traffic` / `rocprof` fields come from the committed rocprofv3 runs of this command (labelled as such).
-  einsum_mfma_target -- BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200, % of MFMA peak.
-  bf16_mode     -- the same step in throughput mode (bf16 MFMA): secondary, never `value`.
+  einsum_mfma_target -- BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200 (stored-logits and consumer-fused
+                   forms, incl. the query-stationary kernel), 20 launches in one hipGraph, % of MFMA peak.
+  bf16_mode     -- the same step in throughput mode (bf16 MFMA): secondary, never `value`; with the bf16 agreement record of this config.
   train_step    -- configs[2]'s training step, run in child processes: the parity-mode (f32-class) step is the object itself, the
-                   bf16 autocast step its `bf16_mode` member.
-`python bench.py --mode train [--precision fp32|bf16] --gpus N` measures the image-parallel training step alone: N ranks (started
-the same way as above), batch 16 per rank, gradients all-reduced over RCCL in 64-MiB buckets (`train.GradReducer`), weak scaling.
+                   bf16 autocast step its `bf16_mode` member; each with `roofline` / `kernels` from live events.
+  extra         -- configs[3] (training step, both precisions) and configs[4] (panoptic forward, parity + bf16) measured the same way
+                   in child processes (`python bench.py --workload cfg3|cfg4`).
   cpu_baseline  -- the oracle (torch CPU restatement of the reference path, kind "port") on one image of the
                    same workload on this box's host cores.
 """

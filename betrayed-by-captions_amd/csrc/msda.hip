@@ -10,6 +10,7 @@
 // Blocks are remapped so that each XCD walks ONE contiguous range of queries (row-major within a
 // level): its private 4-MiB L2 then only has to hold a spatial band of every value level.
 #include "msda_common.h"
+#include <type_traits>
 
 __device__ __forceinline__ float msda_x(float v) { return v; }
 __device__ __forceinline__ float msda_x(uint16_t v) { return cgg_bf2f(v); }
@@ -145,6 +146,17 @@ __device__ __forceinline__ float msda_quad_bcast(float v) {
 template <int CTRL>
 __device__ __forceinline__ int msda_quad_bcast(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float msda_quad_bcast_ctrl(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 8 lanes of an aligned lane octet by DPP (no LDS): every lane ends up with the octet's sum
+__device__ __forceinline__ void msda_reduce8(float& v) {
+  v += msda_quad_bcast_ctrl<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v += msda_quad_bcast_ctrl<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v += msda_quad_bcast_ctrl<0x141>(v);      // row_half_mirror
 }
 
 template <int PSEL>
@@ -496,8 +508,11 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
 // start % 32 == 0): a block = ONE head of an 8 x 4 pixel patch of a level, the 8 heads of a patch in adjacent blocks -- the
 // corner lines of neighbouring queries' taps are shared in L1 / L2 as in the forward's 2-D mapping, and the 8 blocks of a patch read
 // the same loc / weight / grad_out rows.
+#ifndef MSDA_GATHER_WAVES
+#define MSDA_GATHER_WAVES 4  // register budget in waves per SIMD; measured per call at B=16: 4 -> 2.96 ms, 5 -> 4.21 ms, 6 -> 5.26 ms (5 and 6 spill)
+#endif
 template <bool ACC, bool PATCH>
-__global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_GATHER_WAVES))) void cgg_msda_bwd_gather4_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ gout, float* __restrict__ gloc, float* __restrict__ gattw, int Nv, int H, int D, int L, int Nq,
     long long total) {
@@ -547,61 +562,81 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_gather4_kernel(
       ol1 = cgg_ld4(glp + 8 * l + 4);
     }
     const float xs[4] = {xy0[0], xy0[2], xy1[0], xy1[2]}, ys[4] = {xy0[1], xy0[3], xy1[1], xy1[3]};
-    f32x4 v[4][4];
-    float lh[4], lw[4];
-    bool k[4][4];
+    // the level's four points in two PAIRS (8 corner loads in flight each): all 16 at once needed 130+ registers = 3 waves per SIMD
+    auto pair = [&](auto p0c) {
+      constexpr int P0 = decltype(p0c)::value;
+      f32x4 v[2][4];
+      float lh[2], lw[2];
+      bool k[2][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const float him = ys[p] * (float)Hl - 0.5f, wim = xs[p] * (float)Wl - 0.5f;
-      const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
-      const float hf = floorf(him), wf = floorf(wim);
-      const int h0 = (int)hf, w0 = (int)wf;
-      lh[p] = him - hf;
-      lw[p] = wim - wf;
-      const bool vh0 = in && h0 >= 0, vh1 = in && (h0 + 1) <= Hl - 1;
-      const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wl - 1;
-      k[p][0] = vh0 && vw0; k[p][1] = vh0 && vw1; k[p][2] = vh1 && vw0; k[p][3] = vh1 && vw1;
-      const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h0 + 1, 0), Hl - 1);
-      const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w0 + 1, 0), Wl - 1);
-      v[p][0] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw0) * rowstride);
-      v[p][1] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw1) * rowstride);
-      v[p][2] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw0) * rowstride);
-      v[p][3] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw1) * rowstride);
-    }
+      for (int pp = 0; pp < 2; ++pp) {
+        const int p = P0 + pp;
+        const float him = ys[p] * (float)Hl - 0.5f, wim = xs[p] * (float)Wl - 0.5f;
+        const bool in = (him > -1.f) && (wim > -1.f) && (him < (float)Hl) && (wim < (float)Wl);
+        const float hf = floorf(him), wf = floorf(wim);
+        const int h0 = (int)hf, w0 = (int)wf;
+        lh[pp] = him - hf;
+        lw[pp] = wim - wf;
+        const bool vh0 = in && h0 >= 0, vh1 = in && (h0 + 1) <= Hl - 1;
+        const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wl - 1;
+        k[pp][0] = vh0 && vw0; k[pp][1] = vh0 && vw1; k[pp][2] = vh1 && vw0; k[pp][3] = vh1 && vw1;
+        const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h0 + 1, 0), Hl - 1);
+        const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w0 + 1, 0), Wl - 1);
+        v[pp][0] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw0) * rowstride);
+        v[pp][1] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw1) * rowstride);
+        v[pp][2] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw0) * rowstride);
+        v[pp][3] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw1) * rowstride);
+      }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const float hh = 1.f - lh[p], hw = 1.f - lw[p];
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 v00 = k[p][0] ? v[p][0] : z4, v01 = k[p][1] ? v[p][1] : z4;
-      const f32x4 v10 = k[p][2] ? v[p][2] : z4, v11 = k[p][3] ? v[p][3] : z4;
-      // the three gradients are combinations of FOUR corner dots d_k = sum_c v_k[c] g[c] (bilinear interpolation is linear in the
-      // corner values): 16 FMAs + 4 reductions per point instead of forming val / d val / dx / d val / dy per channel (~64 VALU)
-      float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
+      for (int pp = 0; pp < 2; ++pp) {
+        constexpr int PB = P0;
+        const int p = PB + pp;
+        const float hh = 1.f - lh[pp], hw = 1.f - lw[pp];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 v00 = k[pp][0] ? v[pp][0] : z4, v01 = k[pp][1] ? v[pp][1] : z4;
+        const f32x4 v10 = k[pp][2] ? v[pp][2] : z4, v11 = k[pp][3] ? v[pp][3] : z4;
+        // the three gradients are combinations of FOUR corner dots d_k = sum_c v_k[c] g[c] (bilinear interpolation is linear in the
+        // corner values): 16 FMAs + 4 reductions per point instead of forming val / d val / dx / d val / dy per channel (~64 VALU)
+        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        d00 = fmaf(v00[c], g[c], d00);
-        d01 = fmaf(v01[c], g[c], d01);
-        d10 = fmaf(v10[c], g[c], d10);
-        d11 = fmaf(v11[c], g[c], d11);
+        for (int c = 0; c < 4; ++c) {
+          d00 = fmaf(v00[c], g[c], d00);
+          d01 = fmaf(v01[c], g[c], d01);
+          d10 = fmaf(v10[c], g[c], d10);
+          d11 = fmaf(v11[c], g[c], d11);
+        }
+        if constexpr (PATCH) {
+          // D == 32: the 8 lanes of a (query, head) reduce by three DPP moves (quad xor 1, quad xor 2, row_half_mirror: after the two
+          // quad steps every lane holds its quad's sum and lane i of 8 reads lane 7 - i = the other quad) -- `__shfl_xor` is a
+          // ds_bpermute on this target: 144 LDS-pipe instructions per wave in the first version of this kernel
+          msda_reduce8(d00);
+          msda_reduce8(d01);
+          msda_reduce8(d10);
+          msda_reduce8(d11);
+        } else {
+          for (int o = 1; o < DQ; o <<= 1) {
+            d00 += __shfl_xor(d00, o);
+            d01 += __shfl_xor(d01, o);
+            d10 += __shfl_xor(d10, o);
+            d11 += __shfl_xor(d11, o);
+          }
+        }
+        const float dotv = hh * (hw * d00 + lw[pp] * d01) + lh[pp] * (hw * d10 + lw[pp] * d11);
+        const float dotx = hh * (d01 - d00) + lh[pp] * (d11 - d10);
+        const float doty = hw * (d10 - d00) + lw[pp] * (d11 - d01);
+        ow[p] += dotv;
+        if (PB == 0) {
+          ol0[2 * pp] += (float)Wl * w4[p] * dotx;
+          ol0[2 * pp + 1] += (float)Hl * w4[p] * doty;
+        } else {
+          ol1[2 * pp] += (float)Wl * w4[p] * dotx;
+          ol1[2 * pp + 1] += (float)Hl * w4[p] * doty;
+        }
       }
-      for (int o = 1; o < DQ; o <<= 1) {
-        d00 += __shfl_xor(d00, o);
-        d01 += __shfl_xor(d01, o);
-        d10 += __shfl_xor(d10, o);
-        d11 += __shfl_xor(d11, o);
-      }
-      const float dotv = hh * (hw * d00 + lw[p] * d01) + lh[p] * (hw * d10 + lw[p] * d11);
-      const float dotx = hh * (d01 - d00) + lh[p] * (d11 - d10);
-      const float doty = hw * (d10 - d00) + lw[p] * (d11 - d01);
-      ow[p] += dotv;
-      if (p < 2) {
-        ol0[2 * p] += (float)Wl * w4[p] * dotx;
-        ol0[2 * p + 1] += (float)Hl * w4[p] * doty;
-      } else {
-        ol1[2 * p - 4] += (float)Wl * w4[p] * dotx;
-        ol1[2 * p - 3] += (float)Hl * w4[p] * doty;
-      }
-    }
+    };
+    pair(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pair(std::integral_constant<int, 2>{});
     if (owner) {
       *reinterpret_cast<f32x4*>(gwp + 4 * l) = ow;
       *reinterpret_cast<f32x4*>(glp + 8 * l) = ol0;

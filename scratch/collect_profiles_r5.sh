@@ -45,7 +45,8 @@ train)
   for w in cfg2 cfg3; do for p in fp32 bf16; do
     rm -rf /tmp/trainprof_${w}_$p
     rocprofv3 --kernel-trace --output-format csv -d /tmp/trainprof_${w}_$p -- python3 $R/bench.py --workload $w --steps 4 --warmup 2 --precision $p > $O/${w}_train_under_rocprof_$p.log 2>&1
-    python3 $R/scratch/step_kernels2.py /tmp/trainprof_${w}_$p NormTwoOps 3 7 > $O/${w}_train_step_kernels_$p.txt 2>&1
+    # (bench.py runs 2 warm-up + 4 timed + 1 event-timed step = 7 steps; the clip's NormTwoOps launches per step depend on the bucket count)
+    python3 $R/scratch/step_kernels2.py /tmp/trainprof_${w}_$p NormTwoOps 3 auto:7 > $O/${w}_train_step_kernels_$p.txt 2>&1
   done; done
   head -30 $O/cfg2_train_step_kernels_fp32.txt | cut -c1-150 ;;
 msda)

@@ -1,7 +1,7 @@
 """Per-step kernel table from a rocprofv3 kernel trace of an EAGER bench run (any precision mode):
 `bench.py --graph 0 --pipeline 0 --steps K --warmup W ... ` -- the trace's launches are cut into steps at every launch of a
 delimiter kernel (argv[2]; default: the first kernel, in time order, that is launched exactly once per step in the tail of
-the trace) and the LAST n steps are averaged.  usage: step_kernels2.py <trace dir> [delimiter substring] [n] [delimiter launches per step]"""
+the trace) and the LAST n steps are averaged.  usage: step_kernels2.py <trace dir> [delimiter substring] [n] [delimiter launches per step | auto:<steps run>]"""
 import collections
 import csv
 import glob
@@ -21,7 +21,12 @@ if delim is None:
     m = min(cnt[k] for k in ok)
     delim = next(r['Kernel_Name'] for r in tail if r['Kernel_Name'] in ok and cnt[r['Kernel_Name']] == m)
 idx = [i for i, r in enumerate(rows) if delim in r['Kernel_Name']]
-per = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+per = 1
+if len(sys.argv) > 4:
+    if sys.argv[4].startswith('auto:'):       # auto:<steps the traced process ran>: delimiter launches per step = their count / steps
+        per = max(1, round(len(idx) / int(sys.argv[4][5:])))
+    else:
+        per = int(sys.argv[4])
 seg = rows[idx[-n * per - 1]:idx[-1]]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in seg:
