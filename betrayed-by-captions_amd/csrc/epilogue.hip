@@ -340,20 +340,30 @@ __global__ __launch_bounds__(256) void cgg_absmax_f32_kernel(const float* __rest
   uint32_t m = 0;
   const f32x4* xv = reinterpret_cast<const f32x4*>(x);
   const bool dense = ld4 == n4_per_row;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < total4; u += (long long)gridDim.x * 256) {
+  const long long stride = (long long)gridDim.x * 256;
+  auto at = [&](long long u) -> f32x4 {
     long long off = u;
     if (!dense) {
       const long long r = u / n4_per_row;
       off = r * ld4 + (u - r * n4_per_row);
     }
-    const f32x4 v = xv[off];
+    return __builtin_nontemporal_load(xv + off);
+  };
+  auto take = [&](const f32x4& v) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float f = v[k];      // (copied to a scalar first: __builtin_bit_cast on the vector-element lvalue reads element 0, hipcc 7.2)
       const uint32_t b = __builtin_bit_cast(uint32_t, f) & 0x7fffffffu;
       m = b > m ? b : m;
     }
+  };
+  // four independent 16-B loads in flight per lane (one per trip measured 2.4 TB/s on the 352-MB gradient maps)
+  long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; u + 3 * stride < total4; u += 4 * stride) {
+    const f32x4 v0 = at(u), v1 = at(u + stride), v2 = at(u + 2 * stride), v3 = at(u + 3 * stride);
+    take(v0); take(v1); take(v2); take(v3);
   }
+  for (; u < total4; u += stride) take(at(u));
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
     const uint32_t o = (uint32_t)__shfl_xor((int)m, s, 64);

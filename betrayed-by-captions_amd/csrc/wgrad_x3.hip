@@ -14,6 +14,7 @@
 // are in flight (registers) while chunk c is multiplied; one LDS buffer of 40 KiB (row stride 320 B: four consecutive rows fall
 // into disjoint bank groups for the transpose reads).
 #include "x3.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t wg_u32x4;
 typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
@@ -79,21 +80,34 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
   // bias gradient = the column sums of dy: the workgroups of the first k-tile column add up what they stage anyway (f32)
   const bool want_bias = ws_bias != nullptr && tile_k == 0;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  auto stage = [&](int m0) {
+  // interior tiles (every column group inside N and K) and chunks with all 32 rows live skip the zero-fill selects: 48 of the
+  // ~200 VALU instructions a chunk cost next to its 48 MFMAs (workgroup-uniform conditions)
+  const bool colfull = n0 + BT <= N && k0 + BT <= K;
+  auto stage_t = [&](int m0, auto fullc_t) {
+    constexpr bool FULLC = decltype(fullc_t)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool live = m0 + r8 + 8 * i < m_end;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 y = yv[i], xx = xv[i];
+      if constexpr (!FULLC) {
+        const bool live = m0 + r8 + 8 * i < m_end;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        y = (live && yok) ? y : z;
+        xx = (live && xok) ? xx : z;
+      }
       uint2 h, l;
-      if (want_bias && live && yok) bsum += yv[i];
-      cgg_x3_split4_s((live && yok) ? yv[i] : z, sy, h, l);
+      if (want_bias) bsum += y;
+      cgg_x3_split4_s(y, sy, h, l);
       const int o = (r8 + 8 * i) * RS + 8 * c4;
       *reinterpret_cast<uint2*>(Yh + o) = h;
       *reinterpret_cast<uint2*>(Yl + o) = l;
-      cgg_x3_split4((live && xok) ? xv[i] : z, h, l);
+      cgg_x3_split4(xx, h, l);
       *reinterpret_cast<uint2*>(Xh + o) = h;
       *reinterpret_cast<uint2*>(Xl + o) = l;
     }
+  };
+  auto stage = [&](int m0) {
+    if (colfull && m0 + 32 <= m_end) stage_t(m0, std::true_type{});
+    else stage_t(m0, std::false_type{});
   };
 
   f32x16 acc[TA][TB];
@@ -155,6 +169,24 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
   // partial tile -> ws[split][n][k]; lane (k column j, half hi5), register r <-> n row 8 (r >> 2) + 4 hi5 + (r & 3)
   const int j = lane & 31, hi5 = lane >> 5;
   float* wsp = ws + (size_t)blockIdx.y * N * K;
+  if (colfull && (size_t)N * K * 4u < 0xFFFFFF00ull) {
+    // interior tile: buffer stores, the row term of the address in a scalar register (one multiply + one store per element; the
+    // generic form below computes a 64-bit address and two bounds tests per element)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(wsp, 0, (uint32_t)((size_t)N * K * 4u), 0x00020000);
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn), wk_u = __builtin_amdgcn_readfirstlane(wk);
+    const uint32_t voff = (uint32_t)(4 * hi5 * K + j) * 4u;
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        const int kc0 = k0 + wk_u * 32 * TB + b * 32, nr0 = n0 + wn_u * 32 * TA + a * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[a][b][r] * unscale), rw, voff,
+                                                (uint32_t)((nr0 + 8 * (r >> 2) + (r & 3)) * K + kc0) * 4u, 0);
+      }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll

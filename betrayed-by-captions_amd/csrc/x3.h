@@ -43,10 +43,10 @@ __device__ __forceinline__ void cgg_x3_split2(float a, float b, uint32_t& hi, ui
 }
 
 // 4 activations (un-scaled) -> 8-byte halves of an A-fragment slot
+__device__ __forceinline__ void cgg_x3_split2_s(float a, float b, float sc, uint32_t& hi, uint32_t& lo);
 __device__ __forceinline__ void cgg_x3_split4(const f32x4 v, uint2& hi, uint2& lo) {
-  const f32x4 s = v * CGG_X3_ASCALE;
-  cgg_x3_split2(s[0], s[1], hi.x, lo.x);
-  cgg_x3_split2(s[2], s[3], hi.y, lo.y);
+  cgg_x3_split2_s(v[0], v[1], CGG_X3_ASCALE, hi.x, lo.x);
+  cgg_x3_split2_s(v[2], v[3], CGG_X3_ASCALE, hi.y, lo.y);
 }
 
 // ---- per-tensor pre-scale (round 5) -----------------------------------------------------------------------------
@@ -64,10 +64,22 @@ __device__ __forceinline__ float cgg_x3_scale_from_amax(float amax) {
   se = se > 100 ? 100 : (se < -100 ? -100 : se);
   return __builtin_bit_cast(float, (uint32_t)(se + 127) << 23);
 }
+// (a, b) scaled by the power of two sc -> hi / lo pairs, same bits as cgg_x3_split2(a sc, b sc). The residual sc a - hi comes from
+// ONE mixed-precision fma per value (v_fma_mixlo / mixhi_f16: f32 a, f32 sc, f16 hi half -> f16; sc a - hi is exact in f32, so the
+// only rounding is the final one to f16, as before) instead of cvt_f32_f16 + subtract + cvt_pk, and the hi piece from one more (f16(sc a)): 2 VALU per value instead of 3.5 --
+// the split is the main loop's VALU load in the kernels that take f32 operands (training GEMMs: 2.4 VALU per MFMA before).
+__device__ __forceinline__ void cgg_x3_split2_s(float a, float b, float sc, uint32_t& hi, uint32_t& lo) {
+  uint32_t h, l;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a), "v"(sc));      // f16(sc a), RNE
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(b), "v"(sc));
+  hi = h;
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sc), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sc), "v"(hi));
+  lo = l;
+}
 __device__ __forceinline__ void cgg_x3_split4_s(const f32x4 v, float sc, uint2& hi, uint2& lo) {
-  const f32x4 s = v * sc;
-  cgg_x3_split2(s[0], s[1], hi.x, lo.x);
-  cgg_x3_split2(s[2], s[3], hi.y, lo.y);
+  cgg_x3_split2_s(v[0], v[1], sc, hi.x, lo.x);
+  cgg_x3_split2_s(v[2], v[3], sc, hi.y, lo.y);
 }
 __device__ __forceinline__ void cgg_x3_split8_s(const f32x4 v0, const f32x4 v1, float sc, cgg_u32x4& hi, cgg_u32x4& lo) {
   uint2 h0, l0, h1, l1;

@@ -224,6 +224,56 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
   // ---- epilogue: acc[mt][nt][r] = C[m0 + 32 (TM wm + mt) + (r & 3) + 8 (r >> 2) + 4 hi5][32 (nt0 + TN wn + nt) + j] ----
   const bool full = m0 + BM <= M && (nt0 + 2 * TN) * 32 <= N;        // workgroup-uniform: interior tiles skip the bounds checks
   float lmax = 0.f;                                                  // max |stored value| of this lane (out_amax)
+  // Interior tiles of outputs below 4 GiB (every training-size call): buffer stores whose row term is a SCALAR offset. The generic
+  // path below spends ~13 VALU / scalar instructions per stored element (64-bit address arithmetic, per-element flag branches);
+  // with K = 256 that was as many VALU instructions as the whole main loop (counters: 6.7 VALU per MFMA at K = 256, N = 1024).
+  // Here: one fma, one max (ReLU as a floor of 0 / -inf), one max for out_amax, one buffer store.
+  const size_t o_span = (size_t)M * (size_t)ldc * 4u, o2_span = out2 ? (size_t)M * (size_t)ldc2 * 4u : 0;
+  const size_t r_span = res ? (size_t)M * (size_t)ldr * 4u : 0;
+  if (full && res_mod == 0 && o_span < 0xFFFFFF00ull && o2_span < 0xFFFFFF00ull && r_span < 0xFFFFFF00ull) {
+    const float floor_v = relu ? 0.f : -__builtin_inff();
+    const __amdgpu_buffer_rsrc_t rres = xg_rsrc(res ? res : out, 0xFFFFFF00u);
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int ncol0 = __builtin_amdgcn_readfirstlane((nt0 + TN * wn + nt) * 32);      // first column of the tile (wave-uniform)
+      const int n = ncol0 + j;
+      const float cs = w.scale[n] * unsa;
+      const float bs = bias ? bias[n] : 0.f;
+      const bool second = out2 != nullptr && ncol0 >= col2;
+      const int ldo = second ? ldc2 : ldc;
+      const __amdgpu_buffer_rsrc_t rout = xg_rsrc(second ? out2 - col2 : out, 0xFFFFFF00u);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) {
+        const int mrow0 = __builtin_amdgcn_readfirstlane(m0 + 32 * (TM * wm + mt));      // wave-uniform
+        const uint32_t voff = (uint32_t)((4 * hi5) * ldo + n) * 4u;
+        const uint32_t rvoff = (uint32_t)((4 * hi5) * ldr + n) * 4u;
+        float rv[16];
+        if (res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rres, rvoff, (uint32_t)(mrow0 + (r & 3) + 8 * (r >> 2)) * (uint32_t)ldr * 4u, 0));
+        }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[mt][nt][r], cs, bs);
+        if (res && res_mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = rv[r] > 0.f ? v[r] : 0.f;      // ReLU backward of the layer behind (res = its output)
+        } else if (res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += rv[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = __builtin_amdgcn_fmed3f(v[r], floor_v, __builtin_inff());      // one instruction (fmaxf adds a canonicalising max)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[r]), rout, voff,
+                                                (uint32_t)(mrow0 + (r & 3) + 8 * (r >> 2)) * (uint32_t)ldo * 4u, 0);
+          lmax = fmaxf(lmax, fabsf(v[r]));
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
     const int n = (nt0 + TN * wn + nt) * 32 + j;
@@ -280,6 +330,7 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
         }
       }
     }
+  }
   }
   // max |out| for the NEXT contraction's per-tensor pre-scale (x3.h): one atomic per wave; |v| as a bit pattern is monotone
   if (out_amax) {

@@ -701,7 +701,8 @@ def test_configs3_detector_train_step_runs(dev):
     B, H, W = 4, 1024, 1024
     img = synthetic.structured_images(B, H, W, seed=5).to(dev)
     metas = synthetic.img_metas(B, H, W)
-    batch = synthetic.train_batch(B, H, W, num_classes=65, seed=6, device=dev)
+    # (labels index the head's class tables: num_things_classes of the built config, not the 65 + 17 of the split)
+    batch = synthetic.train_batch(B, H, W, num_classes=cfg['panoptic_head']['num_things_classes'], seed=6, device=dev)
     with runtime.precision_scope('fp32'):
         out = model.train_step(dict(img=img, img_metas=metas, **batch))
         out['loss'].backward()

@@ -4,6 +4,8 @@ round 3's kernel (cgg_gemm_x3 on the f32 rows: same arithmetic, so the f32 outpu
 EVERY tile configuration (forced), ragged row / column counts, zero padding of the convolution by out-of-range LDS-DMA, f32 and
 x3a residuals / outputs, the row-periodic residual, and the overflow flag. Reference arithmetic being matched: the f32 linears /
 convolutions under open_set/models/mask2former_head.py:787, 829-840 ([3P] MSDeformAttnPixelDecoder, ResNet)."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -397,3 +399,25 @@ def test_transpose_f32_is_exact(dev, B, R, C):
         nhwc = ops.nchw_to_nhwc(nchw)
         assert torch.equal(nhwc, nchw.permute(0, 2, 3, 1).contiguous())
         assert torch.equal(ops.nhwc_to_nchw(nhwc), nchw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mag', [1.0, 1e-3, 1e-5, 3e-7, 100.0])
+def test_in_kernel_split_is_the_stored_split_bit_for_bit(dev, mag):
+    """The kernels that take f32 rows split them with mixed-precision fmas (v_fma_mixlo / mixhi_f16, x3.h `cgg_x3_split2_s`); the
+    stored x3a form is made with convert / subtract / convert. Through an identity weight the GEMM returns hi + lo of every element
+    exactly, so both must agree bit for bit -- including magnitudes whose low piece is an f16 subnormal -- and the per-tensor
+    pre-scale form must equal its definition (s = 2^(9 - floor(log2 amax)), hi = f16(s a), lo = f16(s a - hi))."""
+    g = torch.Generator().manual_seed(int(mag * 1e7) % 9973 + 1)
+    a = (torch.randn(256, 64, generator=g) * mag).to(dev)
+    pk = ops.pack_linear_weight_x3(torch.eye(64, device=dev))
+    y = ops.gemm_x3(a, pk, 64)
+    assert torch.equal(y, ops.x3a_decode(ops.x3a_encode(a)))
+    amax = ops.absmax(a)
+    ys = ops.gemm_x3(a, pk, 64, amax=amax)
+    s = 2.0 ** (9 - math.floor(math.log2(float(a.abs().max()))))
+    t = a.cpu().double() * s
+    hi = t.float().half()
+    lo = (t.float() - hi.float()).half()
+    ref = ((hi.double() + lo.double()) / s).float()
+    assert torch.equal(ys.cpu(), ref)
