@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void cgg_msda_bwd_kernel(
 // corner lines of neighbouring queries' taps are shared in L1 / L2 as in the forward's 2-D mapping, and the 8 blocks of a patch read
 // the same loc / weight / grad_out rows.
 #ifndef MSDA_GATHER_WAVES
-#define MSDA_GATHER_WAVES 4  // register budget in waves per SIMD; measured per call at B=16: 4 -> 2.96 ms, 5 -> 4.21 ms, 6 -> 5.26 ms (5 and 6 spill)
+#define MSDA_GATHER_WAVES 4  // minimum waves per SIMD asked of the register allocator (the kernel needs 85 registers: 5 waves; budgets 5 / 6 measured the same / 2 % slower)
 #endif
 template <bool ACC, bool PATCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_GATHER_WAVES))) void cgg_msda_bwd_gather4_kernel(
@@ -539,10 +539,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_GATHER
     bq = (long long)bimg * Nq + lv.start[l] + (4 * py + (pair >> 3)) * lv.w[l] + 8 * px + (pair & 7);
     live = true;
   }
-  const int b = (int)(bq / Nq);
+  // (PATCH: a block is one head of one 8 x 4 patch -- image and head are block-uniform, the level base stays in scalar registers)
+  const int b = PATCH ? __builtin_amdgcn_readfirstlane((int)(bq / Nq)) : (int)(bq / Nq);
   const size_t rowstride = (size_t)H * D;
   const size_t coff = (size_t)h * D + cq * 4;
-  const float* vb = value + (size_t)b * Nv * rowstride + coff;
+  const float* vb = value + (size_t)b * Nv * rowstride + (PATCH ? (size_t)h * D : coff);
+  const uint32_t lane_b = PATCH ? (uint32_t)cq * 16u : 0u;      // PATCH: the lane's channel offset goes into the 32-bit corner offsets
   const int LP = L * 4;
   const float* lp = loc + ((size_t)bq * H + h) * LP * 2;
   const float* wp = attw + ((size_t)bq * H + h) * LP;
@@ -562,6 +564,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_GATHER
       ol1 = cgg_ld4(glp + 8 * l + 4);
     }
     const float xs[4] = {xy0[0], xy0[2], xy1[0], xy1[2]}, ys[4] = {xy0[1], xy0[3], xy1[1], xy1[3]};
+    const msda_v2f glo = {g[0], g[1]}, ghi = {g[2], g[3]};
+    const uint32_t rs_b = (uint32_t)rowstride * 4u, row_b = (uint32_t)Wl * rs_b;      // bytes per pixel / per pixel row of the level
     // the level's four points in two PAIRS (8 corner loads in flight each): all 16 at once needed 130+ registers = 3 waves per SIMD
     auto pair = [&](auto p0c) {
       constexpr int P0 = decltype(p0c)::value;
@@ -580,31 +584,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_GATHER
         const bool vh0 = in && h0 >= 0, vh1 = in && (h0 + 1) <= Hl - 1;
         const bool vw0 = w0 >= 0, vw1 = (w0 + 1) <= Wl - 1;
         k[pp][0] = vh0 && vw0; k[pp][1] = vh0 && vw1; k[pp][2] = vh1 && vw0; k[pp][3] = vh1 && vw1;
+        // corner addresses as 32-bit byte offsets from the level base (a level of (B, Nv, H, 32) f32 values is far below 4 GiB):
+        // one multiply for the clamped top-left corner, the other three differ by 0 / one pixel / one row (the clamps only ever
+        // collapse a step to 0) -- the four size_t products per point were ~80 of the ~500 VALU instructions per level
         const int ch0 = min(max(h0, 0), Hl - 1), ch1 = min(max(h0 + 1, 0), Hl - 1);
         const int cw0 = min(max(w0, 0), Wl - 1), cw1 = min(max(w0 + 1, 0), Wl - 1);
-        v[pp][0] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw0) * rowstride);
-        v[pp][1] = cgg_ld4(vl + (size_t)(ch0 * Wl + cw1) * rowstride);
-        v[pp][2] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw0) * rowstride);
-        v[pp][3] = cgg_ld4(vl + (size_t)(ch1 * Wl + cw1) * rowstride);
+        const uint32_t o00 = (uint32_t)(ch0 * Wl + cw0) * rs_b + lane_b;
+        const uint32_t dxo = cw1 != cw0 ? rs_b : 0u, dyo = ch1 != ch0 ? row_b : 0u;
+        const char* vlb = reinterpret_cast<const char*>(vl);
+        v[pp][0] = cgg_ld4(reinterpret_cast<const float*>(vlb + o00));
+        v[pp][1] = cgg_ld4(reinterpret_cast<const float*>(vlb + (o00 + dxo)));
+        v[pp][2] = cgg_ld4(reinterpret_cast<const float*>(vlb + (o00 + dyo)));
+        v[pp][3] = cgg_ld4(reinterpret_cast<const float*>(vlb + (o00 + dyo + dxo)));
       }
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp) {
         constexpr int PB = P0;
         const int p = PB + pp;
         const float hh = 1.f - lh[pp], hw = 1.f - lw[pp];
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 v00 = k[pp][0] ? v[pp][0] : z4, v01 = k[pp][1] ? v[pp][1] : z4;
-        const f32x4 v10 = k[pp][2] ? v[pp][2] : z4, v11 = k[pp][3] ? v[pp][3] : z4;
+        // (a corner outside the map was loaded from its clamped in-range address: its DOT is dropped below, four selects per point
+        // instead of sixteen on the loaded channels)
+        const f32x4 v00 = v[pp][0], v01 = v[pp][1], v10 = v[pp][2], v11 = v[pp][3];
         // the three gradients are combinations of FOUR corner dots d_k = sum_c v_k[c] g[c] (bilinear interpolation is linear in the
         // corner values): 16 FMAs + 4 reductions per point instead of forming val / d val / dx / d val / dy per channel (~64 VALU)
-        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          d00 = fmaf(v00[c], g[c], d00);
-          d01 = fmaf(v01[c], g[c], d01);
-          d10 = fmaf(v10[c], g[c], d10);
-          d11 = fmaf(v11[c], g[c], d11);
-        }
+        // (packed: the natural register pairs of a loaded vector times (g0, g1) / (g2, g3), one horizontal add per corner -- the
+        // per-channel form made the compiler pair channels of DIFFERENT corners and shuffle registers for it)
+        auto dot4 = [&](const f32x4& vv) {
+          msda_v2f t = msda_v2f{vv[0], vv[1]} * glo;
+          t = __builtin_elementwise_fma(msda_v2f{vv[2], vv[3]}, ghi, t);
+          return t[0] + t[1];
+        };
+        float d00 = dot4(v00), d01 = dot4(v01), d10 = dot4(v10), d11 = dot4(v11);
+        d00 = k[pp][0] ? d00 : 0.f;
+        d01 = k[pp][1] ? d01 : 0.f;
+        d10 = k[pp][2] ? d10 : 0.f;
+        d11 = k[pp][3] ? d11 : 0.f;
         if constexpr (PATCH) {
           // D == 32: the 8 lanes of a (query, head) reduce by three DPP moves (quad xor 1, quad xor 2, row_half_mirror: after the two
           // quad steps every lane holds its quad's sum and lane i of 8 reads lane 7 - i = the other quad) -- `__shfl_xor` is a

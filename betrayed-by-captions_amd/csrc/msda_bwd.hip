@@ -26,16 +26,19 @@ struct MsdaSortPlan {
 };
 
 // NT threads; every thread owns at most MAXIT taps (items) whose geometry stays in registers across the sort's barriers
-template <int NT, int MAXIT>
+// (PT = points per level as a compile-time constant, 0 = the run-time value: the tap -> (slot, point) split is a division otherwise)
+template <int NT, int MAXIT, int PT>
 __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, MsdaSortPlan pl, const float* __restrict__ loc,
                                                                 const float* __restrict__ attw, const float* __restrict__ gout,
-                                                                float* __restrict__ gvalue, int Nv, int H, int L, int Nq, int P) {
+                                                                float* __restrict__ gvalue, int Nv, int H, int L, int Nq, int P_rt) {
   constexpr int D = 32;
+  const int P = PT ? PT : P_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* gs = smem;                                                       // [maxslots][32] grad_out rows of the tile's queries
   uint2* rec = reinterpret_cast<uint2*>(gs + (size_t)pl.maxslots * D);    // [maxslots * P * 4]: sorted in-window records from the
                                                                           // front, out-of-window records from the back
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(rec + (size_t)pl.maxslots * P * 4);
+  const int cap = pl.maxslots * P * 4 + 3 * pl.maxpix;                    // + up to 3 zero records per window pixel (groups of 4)
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(rec + (size_t)cap);
   uint32_t* beg = cnt + pl.maxpix;
   int* qn = reinterpret_cast<int*>(beg + pl.maxpix);                      // [maxslots] query index of a slot
   __shared__ uint32_t wsum[NT / 64];
@@ -60,7 +63,12 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     const int xx = txi * e, yy = tyi * e;
     const int tww = min(e, lv.w[l] - xx), thh = min(e, lv.h[l] - yy);
     const int ns = tww > 0 && thh > 0 ? tww * thh : 0;
-    for (int i = tid; i < ns; i += NT) qn[nslots + i] = lv.start[l] + (yy + i / tww) * lv.w[l] + xx + i % tww;
+    if ((tww & (tww - 1)) == 0) {            // (workgroup-uniform) power-of-two row: no integer division
+      const int sh = __builtin_ctz(tww > 0 ? tww : 1);
+      for (int i = tid; i < ns; i += NT) qn[nslots + i] = lv.start[l] + (yy + (i >> sh)) * lv.w[l] + xx + (i & (tww - 1));
+    } else {
+      for (int i = tid; i < ns; i += NT) qn[nslots + i] = lv.start[l] + (yy + i / tww) * lv.w[l] + xx + i % tww;
+    }
     nslots += ns;
   }
   // window of the destination level
@@ -101,7 +109,6 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
   int dst[MAXIT][4];
   uint32_t rank[MAXIT][4];
   float cf[MAXIT][4];
-  const int cap = pl.maxslots * P * 4;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const float him = ty_[it] * (float)Hd - 0.5f, wim = tx_[it] * (float)Wd - 0.5f;
@@ -127,13 +134,14 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     }
   }
   __syncthreads();       // histogram complete, grad_out rows staged
-  // ---- exclusive scan of the histogram (per-thread serial chunks, wave shuffles, wave totals through LDS) ----
+  // ---- exclusive scan of the histogram, every pixel's list rounded up to a multiple of FOUR records (the sum loop below walks
+  //      groups of four without a tail test; the pad records are written after pass 2) ----
   {
     const int per = (npix + NT - 1) / NT;
     const int i0 = tid * per;
     uint32_t sum = 0;
     for (int i = 0; i < per; ++i)
-      if (i0 + i < npix) sum += cnt[i0 + i];
+      if (i0 + i < npix) sum += (cnt[i0 + i] + 3u) & ~3u;
     uint32_t inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     for (int i = 0; i < per; ++i)
       if (i0 + i < npix) {
         beg[i0 + i] = run;
-        run += cnt[i0 + i];
+        run += (cnt[i0 + i] + 3u) & ~3u;
       }
   }
   __syncthreads();
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     for (int q = 0; q < 4; ++q) {
       const int d = dst[it][q];
       if (d >= 0) {
-        rec[beg[d] + rank[it][q]] = make_uint2((uint32_t)tslot[it], __float_as_uint(cf[it][q]));
+        rec[beg[d] + rank[it][q]] = make_uint2((uint32_t)tslot[it] * (D * 4u), __float_as_uint(cf[it][q]));      // .x = byte offset of the staged row
       } else if (d <= -2) {
         const uint32_t i = atomicAdd(&nfb, 1u);
         rec[cap - 1 - (int)i] = make_uint2((uint32_t)tslot[it] | ((uint32_t)(-d - 2) << 12), __float_as_uint(cf[it][q]));
@@ -168,29 +176,54 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, 
     }
   }
   __syncthreads();
-  // ---- destination-stationary sums: half-wave = one window pixel, lane = channel. A pixel's records are walked FOUR at a time: the
-  //      four record reads go out together, then the four grad_out-row reads, then four FMAs into independent sums (a one-record
-  //      loop is a serial record -> row -> FMA chain of two LDS latencies per record: 0.58 ms of the kernel's 1.2 ms at configs[2]
-  //      shapes; interleaving four PIXELS instead measured slower -- their record counts differ) ----
+  // pad records: coefficient 0 on the row of the pixel's FIRST record (a row that reaches this pixel anyway: a non-finite grad_out
+  // row must not leak into pixels it does not touch through 0 x inf)
+  for (int i = tid; i < npix; i += NT) {
+    const uint32_t n = cnt[i];
+    if (n & 3u) {
+      const uint32_t b0 = beg[i], x0 = rec[b0].x;
+      for (uint32_t k = n; k < ((n + 3u) & ~3u); ++k) rec[b0 + k] = make_uint2(x0, 0u);
+    }
+  }
+  __syncthreads();
+  // ---- destination-stationary sums: half-wave = one window pixel, lane = channel. A pixel's records are walked FOUR at a time: two
+  //      16-byte record reads, four grad_out-row reads, four FMAs into independent sums (a one-record loop is a serial record ->
+  //      row -> FMA chain of two LDS latencies per record). The kernel was VALU-bound (counters: 2760 VALU instructions per wave, the
+  //      VALU pipes ~100 % busy): lists padded to groups of four, row byte offsets in the records and an incremental (row, column)
+  //      of the window pixel take the tail selects, the index multiplies and the two integer divisions out of this loop ----
   const int lane = tid & 31, hwid = tid >> 5;
   constexpr int NHW = NT / 32;
+  // (eight lanes per pixel with four channels each -- a wavefront walking 8 pixels at a time -- cut the VALU count by another
+  // 20 % but its four dword atomics per lane are 32 scattered line requests per 8 pixels instead of 8 full lines: 2.5 ms vs 1.24)
+  const char* gsb = reinterpret_cast<const char*>(gs) + lane * 4;
+  // (walking a compacted list of the NON-EMPTY pixels instead -- one LDS read for begin / count / destination, no visits to empty
+  // halo pixels -- measured slower, 1.44 vs 1.28 ms: this phase, 0.74 ms of the kernel, is bound by the LDS pipe, ~2/3 of it the
+  // broadcast reads of the records themselves: 16 bytes x 64 lanes per two records whatever the number of distinct addresses)
+  int wy = hwid / ww, wx = hwid - wy * ww;                     // window coordinates of this half-wave's pixel
+  const int dy = NHW / ww, dx = NHW - dy * ww;                 // (dx < ww: at most one wrap per step)
   for (int pix = hwid; pix < npix; pix += NHW) {
     const int n = (int)cnt[pix];
-    if (n == 0) continue;
-    const uint2* r = rec + beg[pix];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int i = 0; i < n; i += 4) {
-      // the tail re-reads the last record with coefficient 0 (no branch inside the group)
-      const int i1 = min(i + 1, n - 1), i2 = min(i + 2, n - 1), i3 = min(i + 3, n - 1);
-      const uint2 r0 = r[i], r1 = r[i1], r2 = r[i2], r3 = r[i3];
-      const float g0 = gs[r0.x * D + lane], g1 = gs[r1.x * D + lane], g2 = gs[r2.x * D + lane], g3 = gs[r3.x * D + lane];
-      a0 = fmaf(__uint_as_float(r0.y), g0, a0);
-      a1 = fmaf(i + 1 < n ? __uint_as_float(r1.y) : 0.f, g1, a1);
-      a2 = fmaf(i + 2 < n ? __uint_as_float(r2.y) : 0.f, g2, a2);
-      a3 = fmaf(i + 3 < n ? __uint_as_float(r3.y) : 0.f, g3, a3);
+    if (n > 0) {
+      const uint4* r = reinterpret_cast<const uint4*>(rec + beg[pix]);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int i = 0; i < n; i += 4, r += 2) {
+        const uint4 ra = r[0], rb = r[1];
+        const float g0 = *reinterpret_cast<const float*>(gsb + ra.x), g1 = *reinterpret_cast<const float*>(gsb + ra.z);
+        const float g2 = *reinterpret_cast<const float*>(gsb + rb.x), g3 = *reinterpret_cast<const float*>(gsb + rb.z);
+        a0 = fmaf(__uint_as_float(ra.y), g0, a0);
+        a1 = fmaf(__uint_as_float(ra.w), g1, a1);
+        a2 = fmaf(__uint_as_float(rb.y), g2, a2);
+        a3 = fmaf(__uint_as_float(rb.w), g3, a3);
+      }
+      // inside the image: only valid corners were counted
+      atomicAdd(gvl + (size_t)((oy + wy) * Wd + ox + wx) * rowstride + lane, (a0 + a1) + (a2 + a3));
     }
-    const int iy = oy + pix / ww, ix = ox + pix % ww;          // inside the image: only valid corners were counted
-    atomicAdd(gvl + (size_t)(iy * Wd + ix) * rowstride + lane, (a0 + a1) + (a2 + a3));
+    wy += dy;
+    wx += dx;
+    if (wx >= ww) {
+      wx -= ww;
+      ++wy;
+    }
   }
   // ---- corners outside the window: one 128-byte atomic each (large learned offsets: correctness does not depend on locality) ----
   const int nf = (int)nfb;
@@ -243,7 +276,7 @@ static int msda_sort_plan(const MsdaLevels& lv, int B, int Nv, int H, int D, int
       const int ww = e + 2 * R;
       maxpix = ww * ww > maxpix ? ww * ww : maxpix;
     }
-    lds = (size_t)slots * 32 * 4 + (size_t)slots * P * 4 * 8 + (size_t)maxpix * 2 * 4 + (size_t)slots * 4;
+    lds = (size_t)slots * 32 * 4 + ((size_t)slots * P * 4 + 3 * (size_t)maxpix) * 8 + (size_t)maxpix * 2 * 4 + (size_t)slots * 4;
     if (lds <= 150 * 1024 && slots < 4096 && slots * P <= 3 * 512) {
       pl.c = c;
       pl.R = R;
@@ -275,7 +308,9 @@ int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* 
   // 256 threads where two taps per thread cover the tile (c = 2: 336 taps), 512 for the c = 4 tile; 384-thread workgroups with one
   // tap per thread measured the same (2.96 vs 2.85 ms per backward call at configs[2] shapes)
   const int nt = items > 512 ? 512 : 256;
-  auto kern = nt == 512 ? cgg_msda_bwd_sorted_kernel<512, 3> : (items > 256 ? cgg_msda_bwd_sorted_kernel<256, 2> : cgg_msda_bwd_sorted_kernel<256, 1>);
+  auto kern = nt == 512 ? cgg_msda_bwd_sorted_kernel<512, 3, 0>
+              : (items > 256 ? (P == 4 ? cgg_msda_bwd_sorted_kernel<256, 2, 4> : cgg_msda_bwd_sorted_kernel<256, 2, 0>)
+                             : cgg_msda_bwd_sorted_kernel<256, 1, 0>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
