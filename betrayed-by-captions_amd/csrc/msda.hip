@@ -300,6 +300,32 @@ __device__ __forceinline__ void msda_point_gather_f32(msda_v2f (&acc)[4], const 
   }
 }
 
+// ... with the level base in scalar registers and the taps as 32-bit BYTE offsets (T2D == 2: image and head are block-uniform): the
+// loads take the `saddr + voffset` form, no 64-bit pointer arithmetic per tap (28 + 17 of the ~200 VALU instructions per level)
+template <int PSEL>
+__device__ __forceinline__ void msda_point_gather_f32_b(msda_v2f (&acc)[4], const char* __restrict__ vlb, const uint32_t (&my_o)[4],
+                                                        const float (&my_w)[4], uint32_t lane_b) {
+  constexpr int CTRL = PSEL | (PSEL << 2) | (PSEL << 4) | (PSEL << 6);
+  f32x4 u[4][2];
+  float w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t o = (uint32_t)msda_quad_bcast<CTRL>((int)my_o[k]) + lane_b;      // (the lane's own channel offset: AFTER the broadcast)
+    w[k] = msda_quad_bcast<CTRL>(my_w[k]);
+    u[k][0] = *reinterpret_cast<const f32x4*>(vlb + o);
+    u[k][1] = *reinterpret_cast<const f32x4*>(vlb + o + 64u);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const msda_v2f ww = {w[k], w[k]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const msda_v2f vv = {u[k][c >> 1][2 * (c & 1)], u[k][c >> 1][2 * (c & 1) + 1]};
+      acc[c] = __builtin_elementwise_fma(vv, ww, acc[c]);
+    }
+  }
+}
+
 // T2D: 0 = a wave is 16 consecutive queries, the block's 4 waves are 4 heads; 1 = a wave is a 4 x 4 pixel tile of its level, the
 // block's 4 waves are 4 heads of it; 2 = a wave is a 4 x 4 tile, the block's 4 waves are the four tiles of an 8 x 8 pixel block
 // of ONE head (their taps share a (8 + 2 r)^2 window of lines), blockIdx enumerates (8 x 8 block, head)
@@ -343,6 +369,10 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
   constexpr int rowstride = H * D;
   // lane cq owns channels 4 cq .. + 3 and 16 + 4 cq .. + 3: each of a tap's two loads covers a CONTIGUOUS 64-byte half line per quad
   const float* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * 4;
+  // T2D == 2: image and head are block-uniform -> the level base lives in scalar registers, the lane's channel offset in the taps
+  const float* vbu = value + (size_t)__builtin_amdgcn_readfirstlane((int)b) * Nv * rowstride +
+                     (size_t)__builtin_amdgcn_readfirstlane(h) * D;
+  const uint32_t lane_b = (uint32_t)cq * 16u;
   const float* row = rows + (size_t)bq * ld;
   const float* lp = row + (size_t)h * LP * 2 + 2 * cq;                 // this lane's point: (x, y) of point cq, + 8 per level
   const float* wp = row + (size_t)H * LP * 2 + (size_t)h * LP;
@@ -385,12 +415,22 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     const float y = ry + o.y / (float)Hl;
     const MsdaTap t = cgg_msda_tap(x, y, Hl, Wl);
     const float wl = l == 0 ? pw[0] : (l == 1 ? pw[1] : pw[2]);
-    const int my_o[4] = {t.o00 * rowstride, t.o01 * rowstride, t.o10 * rowstride, t.o11 * rowstride};
     const float my_w[4] = {t.w00 * wl, t.w01 * wl, t.w10 * wl, t.w11 * wl};
-    msda_point_gather_f32<0>(acc, vl, my_o, my_w);
-    msda_point_gather_f32<1>(acc, vl, my_o, my_w);
-    msda_point_gather_f32<2>(acc, vl, my_o, my_w);
-    msda_point_gather_f32<3>(acc, vl, my_o, my_w);
+    if constexpr (T2D == 2) {
+      const char* vlb = reinterpret_cast<const char*>(vbu + (size_t)lv.start[l] * rowstride);
+      const uint32_t my_ob[4] = {(uint32_t)t.o00 * (rowstride * 4u), (uint32_t)t.o01 * (rowstride * 4u),
+                                 (uint32_t)t.o10 * (rowstride * 4u), (uint32_t)t.o11 * (rowstride * 4u)};
+      msda_point_gather_f32_b<0>(acc, vlb, my_ob, my_w, lane_b);
+      msda_point_gather_f32_b<1>(acc, vlb, my_ob, my_w, lane_b);
+      msda_point_gather_f32_b<2>(acc, vlb, my_ob, my_w, lane_b);
+      msda_point_gather_f32_b<3>(acc, vlb, my_ob, my_w, lane_b);
+    } else {
+      const int my_o[4] = {t.o00 * rowstride, t.o01 * rowstride, t.o10 * rowstride, t.o11 * rowstride};
+      msda_point_gather_f32<0>(acc, vl, my_o, my_w);
+      msda_point_gather_f32<1>(acc, vl, my_o, my_w);
+      msda_point_gather_f32<2>(acc, vl, my_o, my_w);
+      msda_point_gather_f32<3>(acc, vl, my_o, my_w);
+    }
   }
   float* op = out + (size_t)bq * (H * D) + (size_t)h * D + cq * 4;
   *reinterpret_cast<f32x4*>(op) = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
