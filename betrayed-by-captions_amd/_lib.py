@@ -115,6 +115,7 @@ PROTOTYPES = {
     'cgg_decoder_kv_proj_bf16': (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [_c_vp]),
     'cgg_add_layernorm_backward_partials': (ctypes.c_int64, [_c_int]),
     'cgg_add_layernorm_backward': (_c_int, [_c_vp] * 5 + [_c_int, _c_vp, _c_f] + [_c_vp] * 3 + [_c_int, _c_int, _c_vp]),
+    'cgg_add_layernorm_backward_amax': (_c_int, [_c_vp] * 5 + [_c_int, _c_vp, _c_f] + [_c_vp] * 4 + [_c_int, _c_int, _c_vp]),
     'cgg_bottleneck64_bf16': (_c_int, [_c_vp] * 8 + [_c_int] * 5 + [_c_vp]),
     'cgg_encoder_proj_pack': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp]),
     'cgg_encoder_proj_bf16': (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
                                                                    const uint16_t* __restrict__ dy16b, const float* __restrict__ a,
                                                                    const BT* __restrict__ b, const float* __restrict__ gamma,
                                                                    float eps, float* __restrict__ dx, uint16_t* __restrict__ dx16,
-                                                                   float* __restrict__ partial, int rows) {
+                                                                   float* __restrict__ partial, int rows, float* __restrict__ dx_amax) {
   __shared__ float red[4][512];
+  float lmax = 0.f;                                                          // max |dx| of this lane (dx_amax)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 15, rsub = lane >> 4;
   f32x4 g4[4], dg[4], db[4];
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
       for (int k = 0; k < 4; ++k) {
         const f32x4 d = (y[k] * g4[k] - c1 - s[k] * c2) * rstd;
         *reinterpret_cast<f32x4*>(dx + off + 64 * k) = d;
+        lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
         if (dx16)
           *reinterpret_cast<uint2*>(dx16 + off + 64 * k) =
               make_uint2(cgg_pack2(cgg_f2bf(d[0]), cgg_f2bf(d[1])), cgg_pack2(cgg_f2bf(d[2]), cgg_f2bf(d[3])));
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
         db[k] += y[k];
       }
     }
+  }
+  // max |dx| for the per-tensor pre-scale of the contractions that consume dx as grad_output (x3.h): one atomic per wavefront
+  if (dx_amax) {
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sft, 64));
+    if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dx_amax), __float_as_uint(lmax));
   }
   // column sums: the 4 row groups of a wavefront (lanes sub, sub + 16, + 32, + 48), then the 4 wavefronts through LDS
 #pragma unroll
@@ -117,9 +125,9 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
 
 extern "C" int64_t cgg_add_layernorm_backward_partials(int rows) { return rows > 0 ? (int64_t)((rows + LNB_ROWS - 1) / LNB_ROWS) : 0; }
 
-extern "C" int cgg_add_layernorm_backward(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b,
-                                          int b_dtype, const float* gamma, float eps, float* dx, void* dx16, float* partial,
-                                          int rows, int N, cgg_stream_t stream) {
+static int lnb_launch(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b, int b_dtype,
+                      const float* gamma, float eps, float* dx, void* dx16, float* partial, int rows, int N, float* dx_amax,
+                      cgg_stream_t stream) {
   CGG_REQUIRE((dy || dy16a || dy16b) && a && gamma && dx && partial, CGG_EINVAL, "cgg_add_layernorm_backward: null pointer");
   CGG_REQUIRE(rows > 0 && N == 256, CGG_EUNSUPPORTED, "cgg_add_layernorm_backward: rows=%d N=%d (only N = 256 is built)", rows, N);
   CGG_REQUIRE(b_dtype == CGG_F32 || b_dtype == CGG_BF16, CGG_EUNSUPPORTED, "cgg_add_layernorm_backward: b dtype %d", b_dtype);
@@ -128,12 +136,30 @@ extern "C" int cgg_add_layernorm_backward(const float* dy, const void* dy16a, co
               CGG_EALIGN, "cgg_add_layernorm_backward: 16-B alignment");
   const dim3 grid((rows + LNB_ROWS - 1) / LNB_ROWS), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (dx_amax) {
+    hipError_t e = hipMemsetAsync(dx_amax, 0, sizeof(float), s);
+    CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_add_layernorm_backward: memset failed");
+  }
   if (b_dtype == CGG_BF16)
     hipLaunchKernelGGL(cgg_add_layernorm_bwd_kernel<uint16_t>, grid, block, 0, s, dy, (const uint16_t*)dy16a, (const uint16_t*)dy16b, a, (const uint16_t*)b, gamma, eps, dx,
-                       (uint16_t*)dx16, partial, rows);
+                       (uint16_t*)dx16, partial, rows, dx_amax);
   else
     hipLaunchKernelGGL(cgg_add_layernorm_bwd_kernel<float>, grid, block, 0, s, dy, (const uint16_t*)dy16a, (const uint16_t*)dy16b, a, (const float*)b, gamma, eps, dx,
-                       (uint16_t*)dx16, partial, rows);
+                       (uint16_t*)dx16, partial, rows, dx_amax);
   CGG_CHECK_LAUNCH("cgg_add_layernorm_backward");
   return CGG_OK;
+}
+
+extern "C" int cgg_add_layernorm_backward(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b,
+                                          int b_dtype, const float* gamma, float eps, float* dx, void* dx16, float* partial,
+                                          int rows, int N, cgg_stream_t stream) {
+  return lnb_launch(dy, dy16a, dy16b, a, b, b_dtype, gamma, eps, dx, dx16, partial, rows, N, nullptr, stream);
+}
+
+// ... and max |dx| as a device scalar (dx_amax, written by the call) for the x3 contractions that take dx as grad_output
+extern "C" int cgg_add_layernorm_backward_amax(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b,
+                                               int b_dtype, const float* gamma, float eps, float* dx, void* dx16, float* partial,
+                                               float* dx_amax, int rows, int N, cgg_stream_t stream) {
+  CGG_REQUIRE(dx_amax, CGG_EINVAL, "cgg_add_layernorm_backward_amax: null dx_amax");
+  return lnb_launch(dy, dy16a, dy16b, a, b, b_dtype, gamma, eps, dx, dx16, partial, rows, N, dx_amax, stream);
 }

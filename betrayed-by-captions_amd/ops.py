@@ -197,19 +197,27 @@ class MSDeformAttnRowsFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         value, rows, ref_points = ctx.saved_tensors
         level_hw, level_start, P = ctx.geom
-        B, Nv, H, D = value.shape
-        _, Nq, ld = rows.shape
-        L = len(level_hw)
-        hw = _int_array([v for pair in level_hw for v in pair])
-        loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=value.device)
-        aw = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=value.device)
-        check(_lib_().cgg_msda_prologue(dev_ptr(rows, 'rows', torch.float32), ld, dev_ptr(ref_points, 'ref', torch.float32), hw,
-                                        dev_ptr(loc), dev_ptr(aw), B, Nq, H, L, P, stream_ptr(value.device)), 'cgg_msda_prologue')
-        gv, gl, gw = msda_backward_hostlevels(value, level_hw, level_start, loc, aw, grad_out.contiguous())
-        grows = torch.empty_like(rows)
-        check(_lib_().cgg_msda_prologue_backward(dev_ptr(gl), dev_ptr(gw), dev_ptr(rows), ld, hw, dev_ptr(grows), B, Nq, H, L, P,
-                                                 stream_ptr(value.device)), 'cgg_msda_prologue_backward')
+        gv, grows = msda_rows_backward(value, rows, ref_points, level_hw, level_start, P, grad_out)
         return gv, grows, None, None, None, None
+
+
+def msda_rows_backward(value, rows, ref_points, level_hw, level_start, P, grad_out):
+    """Backward of `msda_forward_fused` on the raw projection rows: (grad_value (B, Nv, H, D), grad_rows (B, Nq, 3 H L P)) for
+    grad_out (B, Nq, H D) -- the prologue kernel (loc, softmax), the MSDeformAttn backward kernels, the kernel mapping
+    (grad_loc, grad_attn) back to the rows."""
+    B, Nv, H, D = value.shape
+    _, Nq, ld = rows.shape
+    L = len(level_hw)
+    hw = _int_array([v for pair in level_hw for v in pair])
+    loc = torch.empty((B, Nq, H, L, P, 2), dtype=torch.float32, device=value.device)
+    aw = torch.empty((B, Nq, H, L, P), dtype=torch.float32, device=value.device)
+    check(_lib_().cgg_msda_prologue(dev_ptr(rows, 'rows', torch.float32), ld, dev_ptr(ref_points, 'ref', torch.float32), hw,
+                                    dev_ptr(loc), dev_ptr(aw), B, Nq, H, L, P, stream_ptr(value.device)), 'cgg_msda_prologue')
+    gv, gl, gw = msda_backward_hostlevels(value, level_hw, level_start, loc, aw, grad_out.contiguous())
+    grows = torch.empty_like(rows)
+    check(_lib_().cgg_msda_prologue_backward(dev_ptr(gl), dev_ptr(gw), dev_ptr(rows), ld, hw, dev_ptr(grows), B, Nq, H, L, P,
+                                             stream_ptr(value.device)), 'cgg_msda_prologue_backward')
+    return gv, grows
 
 
 # ------------------------------------------------------------------------------------------------
@@ -895,9 +903,10 @@ def encoder_layer_tail(a16, x16, wop, bo, norm0, w1p, b1, w2p, b2, norm1, pos=No
     return y32, y16, yp16
 
 
-def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False, dy16a=None, dy16b=None):
-    """Backward of LN(a + b) over the last dim (256) for the upstream gradient dy (f32) + dy16a + dy16b (bf16; any subset):
-    returns (dx f32, bf16(dx) | None, dgamma, dbeta); d/da = d/db = dx."""
+def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False, dy16a=None, dy16b=None, want_amax=False):
+    """Backward of LN(a + b) (b None: LN(a)) over the last dim (256) for the upstream gradient dy (f32) + dy16a + dy16b (bf16; any
+    subset): returns (dx f32, bf16(dx) | None, dgamma, dbeta); d/da = d/db = dx. want_amax: -> (..., max |dx| as a device scalar),
+    the pre-scale of the x3 contractions that consume dx as grad_output (no `absmax` pass)."""
     N = a.shape[-1]
     rows = a.numel() // N
     dx = torch.empty(a.shape, dtype=torch.float32, device=a.device)
@@ -905,6 +914,16 @@ def add_layernorm_backward(dy, a, b, gamma, eps, want_bf16=False, dy16a=None, dy
     nb = _lib_().cgg_add_layernorm_backward_partials(rows)
     partial = torch.empty((nb, 2 * N), dtype=torch.float32, device=a.device)
     bdt = CGG_BF16 if (b is not None and b.dtype == torch.bfloat16) else CGG_F32
+    if want_amax:
+        amax = torch.empty(1, dtype=torch.float32, device=a.device)
+        rc = _lib_().cgg_add_layernorm_backward_amax(dev_ptr(dy, 'dy', torch.float32), dev_ptr(dy16a, 'dy16a', torch.bfloat16),
+                                                     dev_ptr(dy16b, 'dy16b', torch.bfloat16), dev_ptr(a, 'a', torch.float32),
+                                                     dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32), float(eps),
+                                                     dev_ptr(dx), dev_ptr(dx16), dev_ptr(partial), dev_ptr(amax), rows, N,
+                                                     stream_ptr(a.device))
+        check(rc, 'cgg_add_layernorm_backward_amax')
+        sums = partial.sum(0)
+        return dx, dx16, sums[:N], sums[N:], amax
     rc = _lib_().cgg_add_layernorm_backward(dev_ptr(dy, 'dy', torch.float32), dev_ptr(dy16a, 'dy16a', torch.bfloat16),
                                             dev_ptr(dy16b, 'dy16b', torch.bfloat16), dev_ptr(a, 'a', torch.float32),
                                             dev_ptr(b, 'b'), bdt, dev_ptr(gamma, 'gamma', torch.float32), float(eps),

@@ -1069,6 +1069,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                   for l in self.encoder.layers))
             for layer in ([] if fused_ln else self.encoder.layers):
                 attn = layer.attentions[0]
+                if fused_ln32 and FUSED_TRAIN_MSDA and runtime.x3_layer_nodes_ok(layer, src):
+                    # one autograd node per half layer: residuals and gradient fan-in inside GEMM epilogues, LayerNorm of one tensor
+                    src = runtime.encoder_layer_x3_train(layer, src, pos, ref, level_hw, level_start)
+                    continue
                 if fused_ln32:
                     out = attn.forward_fused(src, src + pos[None], ref, level_hw, level_start, add_identity=False)
                     mid = ops.add_layernorm_train(src, out.float(), layer.norms[0])

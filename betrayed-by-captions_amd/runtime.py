@@ -275,6 +275,146 @@ class _X3FfnFn(torch.autograd.Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+_X3_LAYER_NODES = _os.environ.get('CGG_X3_LAYER_NODES', '1') != '0'      # A/B: the per-block nodes below vs. linear / FFN / LayerNorm nodes
+
+
+def _rows(x, K):
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    return x2
+
+
+def _x3_img(w):
+    from . import ops
+    return derived_cached('x3_image', (w,), lambda: ops.pack_linear_weight_x3(w))
+
+
+def _x3_img_t(w):
+    from . import ops
+    return derived_cached('x3_image_t', (w,), lambda: ops.pack_linear_weight_x3(w.detach().t().contiguous()))
+
+
+class _X3FfnBlockFn(torch.autograd.Function):
+    """y = LayerNorm(x + W2 relu(W1 x + b1) + b2): the FFN half of a post-norm encoder layer ([3P] BaseTransformerLayer behind
+    open_set/models/mask2former_head.py:787) as ONE autograd node in PARITY-mode training. Against `_X3FfnFn` + `_AddLayerNormFn`:
+    the residual is the second GEMM's epilogue (`res=`), so LayerNorm reads ONE tensor z forward and backward and only z is saved;
+    the backward's two gradient paths into x (through the FFN and through the residual) meet in the last grad-input GEMM's epilogue
+    instead of an autograd accumulation pass over (rows, 256); the LayerNorm backward kernel reports max |dz| for the pre-scale of the
+    contractions behind it (no `absmax` pass). Per layer at configs[2]: one add pass, one absmax pass and 352 MB of LayerNorm
+    backward reads less."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+        from . import ops
+        F_, K = w1.shape
+        x2 = _rows(x, K)
+        h = ops.gemm_x3(x2, _x3_img(w1), F_, b1.detach(), relu=True)
+        z = ops.gemm_x3(h, _x3_img(w2), K, b2.detach(), res=x2)
+        y = ops.add_layernorm_stream(z, None, gamma.detach(), beta.detach(), eps, want_f32=True, want_bf16=False)[0]
+        ctx.save_for_backward(x2, h, z, w1, w2, gamma)
+        ctx.eps = eps
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x2, h, z, w1, w2, gamma = ctx.saved_tensors
+        F_, K = w1.shape
+        gz, _, dgamma, dbeta, amax = ops.add_layernorm_backward(_rows(gy, K), z, None, gamma, ctx.eps, want_amax=True)
+        gw2, gb2 = ops.wgrad_x3(gz, h, want_bias=True, amax=amax)
+        gh, amax_h = ops.gemm_x3_bwd(gz, _x3_img_t(w2), F_, amax=amax, mask=h, want_amax=True)      # d / d(pre-activation)
+        gw1, gb1 = ops.wgrad_x3(gh, x2, want_bias=True, amax=amax_h)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.gemm_x3(gh, _x3_img_t(w1), K, res=gz, amax=amax_h).view(gy.shape)             # FFN path + residual path
+        return gx, gw1, gb1, gw2, gb2, dgamma, dbeta, None
+
+
+class _X3MsdaBlockFn(torch.autograd.Function):
+    """y = LayerNorm(src + output_proj(MSDeformAttn(value_proj(src), [sampling_offsets | attention_weights](src + pos)))): the
+    self-attention half of an encoder layer ([3P] MultiScaleDeformableAttention + norm) as ONE autograd node in PARITY-mode training.
+    Forward: three x3 GEMMs (the residual in the output projection's epilogue), the fused-prologue sampling kernel, LayerNorm of one
+    tensor. Backward, hand-ordered: LayerNorm backward (-> dz, max |dz|), output projection grad-input / grad-weight, the MSDeformAttn
+    backward kernels, then the THREE gradient paths into src (residual, value_proj, offsets / logits) are summed by the epilogues of the
+    two grad-input GEMMs (`res=`, the second one in place) -- autograd's accumulation passes and the (B, N, 256) gradient of
+    `src + pos` never exist; pos' gradient is (sum over the batch of d rows) W, a (N, 288) reduction and a small GEMM."""
+
+    @staticmethod
+    def forward(ctx, src, pos, ref, wv, bv, w_off, b_off, w_att, b_att, wo, bo, gamma, beta, eps, num_heads, level_hw, level_start,
+                num_points):
+        from . import ops
+        B, N, C = src.shape
+        src2 = _rows(src, C)
+        srcp = (src.detach() + pos.detach()[None]).view(-1, C)
+        value = ops.gemm_x3(src2, _x3_img(wv), C, bv.detach())
+        pk_cat, b_cat, n_cat = packed_cached((w_off, w_att), (b_off, b_att))
+        rows = ops.gemm_x3(srcp, pk_cat, n_cat, b_cat)
+        geom = (tuple(tuple(int(v) for v in hw) for hw in level_hw), tuple(int(s) for s in level_start), int(num_points))
+        core = ops.msda_forward_fused(value.view(B, N, num_heads, C // num_heads), geom[0], geom[1], rows.view(B, N, n_cat), ref,
+                                      geom[2])
+        z = ops.gemm_x3(core.view(-1, C), _x3_img(wo), C, bo.detach(), res=src2)
+        y = ops.add_layernorm_stream(z, None, gamma.detach(), beta.detach(), eps, want_f32=True, want_bf16=False)[0]
+        ctx.save_for_backward(src2, srcp, value, rows, core, z, ref, wv, w_off, w_att, wo, gamma)
+        ctx.geom, ctx.eps, ctx.heads, ctx.shape = geom, eps, num_heads, (B, N, C)
+        return y.view(B, N, C)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        src2, srcp, value, rows, core, z, ref, wv, w_off, w_att, wo, gamma = ctx.saved_tensors
+        B, N, C = ctx.shape
+        H = ctx.heads
+        level_hw, level_start, P = ctx.geom
+        n_off, n_cat = w_off.shape[0], w_off.shape[0] + w_att.shape[0]
+        gz, _, dgamma, dbeta, amax = ops.add_layernorm_backward(_rows(gy, C), z, None, gamma, ctx.eps, want_amax=True)
+        gwo, gbo = ops.wgrad_x3(gz, core.view(-1, C), want_bias=True, amax=amax)
+        gcore = ops.gemm_x3(gz, _x3_img_t(wo), C, amax=amax)
+        gv, grows = ops.msda_rows_backward(value.view(B, N, H, C // H), rows.view(B, N, n_cat), ref, level_hw, level_start, P,
+                                           gcore.view(B, N, C))
+        gv2, gr2 = gv.view(-1, C), grows.view(-1, n_cat)
+        amax_v = ops.absmax(gv2)
+        gwv, gbv = ops.wgrad_x3(gv2, src2, want_bias=True, amax=amax_v)
+        gsrc = ops.gemm_x3(gv2, _x3_img_t(wv), C, res=gz, amax=amax_v)                     # residual + value_proj paths
+        amax_r = ops.absmax(gr2)
+        gw_cat, gb_cat = ops.wgrad_x3(gr2, srcp, want_bias=True, amax=amax_r)
+        w_cat_t = derived_cached('x3_image_t_cat', (w_off, w_att),
+                                 lambda: ops.pack_linear_weight_x3(torch.cat([w_off.detach(), w_att.detach()], 0).t().contiguous()))
+        ops.gemm_x3(gr2, w_cat_t, C, res=gsrc, out=gsrc, amax=amax_r)                      # + offsets / logits path, in place
+        gpos = None
+        if ctx.needs_input_grad[1]:
+            gpos = grows.view(B, N, n_cat).sum(0) @ torch.cat([w_off.detach(), w_att.detach()], 0)
+        return (gsrc.view(B, N, C) if ctx.needs_input_grad[0] else None, gpos, None, gwv, gbv, gw_cat[:n_off], gb_cat[:n_off],
+                gw_cat[n_off:], gb_cat[n_off:], gwo, gbo, dgamma, dbeta, None, None, None, None, None)
+
+
+def x3_layer_nodes_ok(layer, src):
+    """PARITY-mode training of a post-norm (self_attn, norm, ffn, norm) encoder layer on the two block nodes above."""
+    attn, ffn = layer.attentions[0], layer.ffns[0]
+    lin1, lin2 = ffn.layers[0][0], ffn.layers[1]
+    C = src.shape[-1]
+    w_cat_rows = attn.sampling_offsets.weight.shape[0] + attn.attention_weights.weight.shape[0]
+    return (_X3_LAYER_NODES and _X3_GSCALE and _X3_WGRAD and src.dim() == 3 and C == 256
+            and x3_train_linear_ok(src, attn.value_proj.weight) and x3_train_linear_ok(src, attn.output_proj.weight)
+            and x3_train_ffn_ok(src, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+            and attn.sampling_offsets.weight.shape[1] == C and w_cat_rows % 32 == 0
+            and all(m.bias is not None for m in (attn.value_proj, attn.output_proj, attn.sampling_offsets, attn.attention_weights))
+            and attn.num_levels * attn.num_points <= 16
+            and w_cat_rows == 3 * attn.num_heads * attn.num_levels * attn.num_points
+            and src.shape[0] * src.shape[1] * max(w_cat_rows, lin1.weight.shape[0]) * 4 < _X3_MAX_BYTES)
+
+
+def encoder_layer_x3_train(layer, src, pos, ref, level_hw, level_start):
+    attn, ffn = layer.attentions[0], layer.ffns[0]
+    lin1, lin2 = ffn.layers[0][0], ffn.layers[1]
+    n0, n1 = layer.norms[0], layer.norms[1]
+    mid = _X3MsdaBlockFn.apply(src, pos, ref, attn.value_proj.weight, attn.value_proj.bias, attn.sampling_offsets.weight,
+                               attn.sampling_offsets.bias, attn.attention_weights.weight, attn.attention_weights.bias,
+                               attn.output_proj.weight, attn.output_proj.bias, n0.weight, n0.bias, n0.eps, attn.num_heads, level_hw,
+                               level_start, attn.num_points)
+    return _X3FfnBlockFn.apply(mid, lin1.weight, lin1.bias, lin2.weight, lin2.bias, n1.weight, n1.bias, n1.eps)
+
+
 def x3_train_ffn_ok(x, w1, b1, w2, b2):
     return (x3_train_linear_ok(x, w1) and b1 is not None and b2 is not None and w2.shape[1] == w1.shape[0] and w2.shape[0] % 32 == 0
             and w1.shape[0] % 32 == 0 and w1.requires_grad and w2.requires_grad and b1.requires_grad and b2.requires_grad)

@@ -569,6 +569,11 @@ int64_t cgg_add_layernorm_backward_partials(int rows);
 int cgg_add_layernorm_backward(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b, int b_dtype,
                                const float* gamma, float eps, float* dx, void* dx16, float* partial, int rows, int N,
                                cgg_stream_t stream);
+/* ... and max |dx| as a device scalar (dx_amax, written by the call; b nullable = plain LayerNorm(a)): the per-tensor pre-scale of
+ * the f16 x 3 contractions that take dx as grad_output (cgg_gemm_x3_scaled / cgg_wgrad_x3_scaled) without a pass over dx. */
+int cgg_add_layernorm_backward_amax(const float* dy, const void* dy16a, const void* dy16b, const float* a, const void* b, int b_dtype,
+                                    const float* gamma, float eps, float* dx, void* dx16, float* partial, float* dx_amax, int rows,
+                                    int N, cgg_stream_t stream);
 
 /* Input projections of one MSDeformAttn encoder layer as ONE launch ([3P] MultiScaleDeformableAttention.forward:
  * value_proj / sampling_offsets / attention_weights; layers built at open_set/models/mask2former_head.py:112-117):

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_x3s_gpu.py -x -q -m gpu -k "encoder_block" 2>&1 | tail -15
+python -m pytest tests/test_train_gpu.py -x -q -m gpu 2>&1 | tail -4
+python -m pytest tests/test_fullsize_gpu.py -x -q -m gpu -k "configs2_forward_train" 2>&1 | tail -4
+python bench.py --workload cfg2 --steps 5 --warmup 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg2 fp32', d['value'], d['ms_per_step'], d['loss'])"

@@ -421,3 +421,51 @@ def test_in_kernel_split_is_the_stored_split_bit_for_bit(dev, mag):
     lo = (t.float() - hi.float()).half()
     ref = ((hi.double() + lo.double()) / s).float()
     assert torch.equal(ys.cpu(), ref)
+
+
+@pytest.mark.gpu
+def test_encoder_block_nodes_match_the_unfused_nodes_and_float64(dev, monkeypatch):
+    """PARITY-mode training of the pixel decoder's encoder layers on the two per-block autograd nodes (`runtime._X3MsdaBlockFn`,
+    `_X3FfnBlockFn`: residuals and gradient fan-in in GEMM epilogues, LayerNorm of one tensor, max |dz| from the LayerNorm backward)
+    against the previous node structure (linear / FFN / add-LayerNorm nodes, CGG_X3_LAYER_NODES=0): same outputs, and every parameter
+    / input gradient within f32 reassociation of each other at real gradient magnitudes (the upstream gradient is 1e-5-scale)."""
+    from cgg_amd import runtime, synthetic
+    from cgg_amd.pixel_decoder import MSDeformAttnPixelDecoder
+    cfg = dict(synthetic.model_config(num_things=8, num_stuff=0, num_unknown=0, num_queries=10, enc_layers=2)['panoptic_head']['pixel_decoder'])
+    cfg.pop('type')
+    torch.manual_seed(3)
+    pd = MSDeformAttnPixelDecoder(in_channels=[32, 64, 96, 128], strides=[4, 8, 16, 32], feat_channels=256, out_channels=256, **cfg)
+    pd.init_weights()
+    with torch.no_grad():          # (the reference initialises the offset / logit weights to zero: the `src + pos` path would carry no gradient)
+        for layer in pd.encoder.layers:
+            a = layer.attentions[0]
+            a.sampling_offsets.weight.normal_(0, 0.02)
+            a.attention_weights.weight.normal_(0, 0.05)
+    pd = pd.to(dev).train()
+    B = 8
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.randn(B, c, 128 // s, 128 // s, generator=g).to(dev) for c, s in zip((32, 64, 96, 128), (1, 2, 4, 8))]
+    params = [p for n, p in pd.named_parameters() if n.startswith('encoder.') or n.startswith('level_encoding')]
+    gm = (torch.randn(B, 256, 128, 128, generator=g) * 1e-5).to(dev)
+
+    def run(nodes):
+        monkeypatch.setattr(runtime, '_X3_LAYER_NODES', nodes)
+        for p in pd.parameters():
+            p.grad = None
+        with runtime.precision_scope('fp32'):
+            mf, outs = pd(feats)
+        (mf * gm).sum().backward()
+        return mf.detach().clone(), [p.grad.detach().clone() for p in params]
+
+    calls = []
+    real = runtime._X3MsdaBlockFn.apply
+    monkeypatch.setattr(runtime._X3MsdaBlockFn, 'apply', staticmethod(lambda *a: (calls.append(1), real(*a))[1]))
+    mf1, g1 = run(True)
+    assert len(calls) == 2, 'the block nodes did not run'
+    mf0, g0 = run(False)
+    assert len(calls) == 2
+    assert (mf1 - mf0).abs().max().item() <= 2e-5 * mf0.abs().max().item()
+    for (n, _), a, b in zip([(n, p) for n, p in pd.named_parameters() if n.startswith('encoder.') or n.startswith('level_encoding')], g1, g0):
+        ref = b.abs().max().item()
+        assert ref > 0 and torch.isfinite(a).all(), n
+        assert (a - b).abs().max().item() <= 2e-4 * ref, (n, (a - b).abs().max().item(), ref)
