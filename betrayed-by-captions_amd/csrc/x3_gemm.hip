@@ -24,7 +24,8 @@
 // without the fragment reads + MFMAs 182 us, with none of the three 71 us (split + LDS writes + barriers alone); N = 1024: 846 /
 // 610 / 736 / 578 / 747 / 264 us. The phases ADD instead of overlapping: the store epilogue (0.35 / 1.4 GB) costs its full HBM
 // time, the split / LDS-write phase and the MFMA phase of a chunk run back to back in each of the 2 workgroups a CU holds. Cache-
-// policy bits on the stores (sc0 / nt / sc1) changed nothing (+-2 %).
+// policy bits on the stores (sc0 / nt / sc1) changed nothing (+-2 %); 128 x 64 / 64 x 128 / 64 x 64 tiles (3-4 workgroups per CU) are 15-40 %
+// slower at these shapes.
 #include "x3.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
