@@ -29,6 +29,7 @@ PROTOTYPES = {
     'cgg_msda_forward_hostlevels': (_c_int, [_c_vp] * 6 + [_c_int] + [_c_vp] + [_c_int] * 9 + [_c_vp]),
     'cgg_msda_backward': (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp]),
     'cgg_msda_backward_hostlevels': (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
+    'cgg_msda_backward_hostlevels_2s': (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp, _c_vp]),
     'cgg_msda_backward_overwrites': (_c_int, [_c_vp] * 2 + [_c_int] * 7),
     'cgg_pack_mask_feature': (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     'cgg_mask_logits': (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),

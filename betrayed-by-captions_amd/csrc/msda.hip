@@ -869,7 +869,7 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
 
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
-                           int L, int Nq, int P, hipStream_t s, bool overwrite = false);
+                           int L, int Nq, int P, hipStream_t s, bool overwrite = false, hipStream_t side = nullptr);
 
 extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shapes,
                                  const int64_t* level_start, const float* sampling_loc,
@@ -896,12 +896,29 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
 // geometry: the generic one-kernel form with global f32 atomics for grad_value.
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
-                           int L, int Nq, int P, hipStream_t s, bool overwrite) {
+                           int L, int Nq, int P, hipStream_t s, bool overwrite, hipStream_t side) {
   const int DQ = D / 4;
   static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
+  // side != null: the gather kernel (grad_loc / grad_attn) runs on `side` next to the sorted-scatter kernel (grad_value) on `s` --
+  // they share inputs only; one is bound by the LDS pipe, the other by VALU issue and L1 gathers. Fork / join by events: `side`
+  // starts after everything enqueued on `s` so far, `s` continues after the gather.
+  hipEvent_t fork = nullptr, join = nullptr;
+  if (side && !generic_only && msda_bwd_sorted_ok(lv, B, Nv, H, D, L, Nq, P)) {
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess) {
+      if (fork) (void)hipEventDestroy(fork);
+      if (join) (void)hipEventDestroy(join);
+      fork = join = nullptr;
+      side = nullptr;
+    }
+  } else {
+    side = nullptr;
+  }
   int rc = generic_only ? CGG_EUNSUPPORTED
                         : msda_bwd_sorted_launch(lv, sampling_loc, attn_weight, grad_out, grad_value, B, Nv, H, D, L, Nq, P, s);
   if (rc == CGG_OK) {
+    hipStream_t s_main = s;
+    if (side) s = side;
     const long long total = (long long)B * Nq * H * DQ;
     const int nb = (int)((total + 255) / 256);
     if (P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) && cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn)) {
@@ -925,8 +942,18 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
     else
       hipLaunchKernelGGL((cgg_msda_bwd_kernel<0, false>), dim3(nb), dim3(256), 0, s, value, lv, sampling_loc, attn_weight, grad_out,
                          grad_value, grad_loc, grad_attn, Nv, H, D, L, Nq, P, total);
+    if (side) {
+      const bool ok = hipEventRecord(join, side) == hipSuccess && hipStreamWaitEvent(s_main, join, 0) == hipSuccess;
+      (void)hipEventDestroy(fork);
+      (void)hipEventDestroy(join);
+      CGG_REQUIRE(ok, CGG_EINVAL, "cgg_msda_backward: joining the side stream failed");
+    }
     CGG_CHECK_LAUNCH("cgg_msda_backward(gather)");
     return CGG_OK;
+  }
+  if (fork) {                                    // (the sorted kernel refused after all: nothing ran on `side`)
+    (void)hipEventDestroy(fork);
+    (void)hipEventDestroy(join);
   }
   if (rc != CGG_EUNSUPPORTED) return rc;
   const long long total = (long long)B * Nq * H * DQ;
@@ -944,10 +971,10 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
 // cgg_msda_backward with the level table from the HOST (level_hw = [h0, w0, h1, w1, ...], level_start): no device->host copy and
 // no stream synchronisation per call (the mmcv-contract entry point above reads its int64 device tensors back, once per call --
 // six stalls per training step in the encoder's backward), graph-capturable.
-extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start,
-                                            const float* sampling_loc, const float* attn_weight, const float* grad_out,
-                                            float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
-                                            int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream) {
+static int msda_bwd_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start, const float* sampling_loc,
+                               const float* attn_weight, const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
+                               int B, int Nv, int H, int D, int L, int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream,
+                               cgg_stream_t side_stream) {
   int rc = msda_check("cgg_msda_backward_hostlevels", value, sampling_loc, attn_weight, grad_out, B, Nv, H, D, L, Nq, P, CGG_F32);
   if (rc) return rc;
   CGG_REQUIRE(level_hw && level_start && grad_value && grad_loc && grad_attn, CGG_EINVAL, "cgg_msda_backward_hostlevels: null pointer");
@@ -970,7 +997,26 @@ extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* l
   CGG_REQUIRE(!overwrite_loc_attn || ow, CGG_EUNSUPPORTED,
               "cgg_msda_backward_hostlevels: overwrite_loc_attn needs the split backward (tileable pyramid, D == 32, P == 4, aligned)");
   return msda_bwd_launch(value, lv, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv, H, D, L, Nq, P,
-                         (hipStream_t)stream, ow);
+                         (hipStream_t)stream, ow, (hipStream_t)side_stream);
+}
+
+extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start,
+                                            const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                            float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
+                                            int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream) {
+  return msda_bwd_hostlevels(value, level_hw, level_start, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv,
+                             H, D, L, Nq, P, overwrite_loc_attn, stream, nullptr);
+}
+
+// ... with the two kernels of the split backward on TWO streams: grad_value (sorted scatter) on `stream`, grad_loc / grad_attn
+// (gather) on `side_stream`, forked after the work enqueued on `stream` so far and joined back into it before the call returns (no
+// host synchronisation; every result is ordered on `stream`). side_stream == stream or null = cgg_msda_backward_hostlevels.
+extern "C" int cgg_msda_backward_hostlevels_2s(const float* value, const int32_t* level_hw, const int32_t* level_start,
+                                               const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                               float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
+                                               int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream, cgg_stream_t side_stream) {
+  return msda_bwd_hostlevels(value, level_hw, level_start, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv,
+                             H, D, L, Nq, P, overwrite_loc_attn, stream, side_stream == stream ? nullptr : side_stream);
 }
 
 // 1 when cgg_msda_backward_hostlevels(..., overwrite_loc_attn = 1) is valid for this geometry (pointer alignment aside)

@@ -150,13 +150,28 @@ def msda_backward_hostlevels(value, level_hw, level_start, sampling_locations, a
     gl = torch.empty_like(sampling_locations) if ow else torch.zeros_like(sampling_locations)
     gw = torch.empty_like(attention_weights) if ow else torch.zeros_like(attention_weights)
     nbytes = 4.0 * (2 * value.numel() + 2 * sampling_locations.numel() + 2 * attention_weights.numel() + grad_output.numel())
+    # split backward: the gather kernel (grad_loc / grad_attn) on a second stream next to the sorted-scatter kernel (grad_value); the
+    # C call forks / joins by events, every result is ordered on the caller's stream (CGG_MSDA_BWD_2S=0: one stream)
+    side = _msda_side_stream(value.device) if (ow and MSDA_BWD_2S) else None
     with _timed('msda_backward', bytes=nbytes, flops=0.0, shape=(B, Nq, H, D, L, P)):
-        rc = _lib_().cgg_msda_backward_hostlevels(
+        rc = _lib_().cgg_msda_backward_hostlevels_2s(
             dev_ptr(value, 'value', torch.float32), hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
             dev_ptr(attention_weights, 'attention_weights', torch.float32), dev_ptr(grad_output, 'grad_output', torch.float32),
-            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow), stream_ptr(value.device))
-    check(rc, 'cgg_msda_backward_hostlevels')
+            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow), stream_ptr(value.device),
+            ctypes.c_void_p(side.cuda_stream) if side is not None else None)
+    check(rc, 'cgg_msda_backward_hostlevels_2s')
     return gv, gl, gw
+
+
+MSDA_BWD_2S = os.environ.get('CGG_MSDA_BWD_2S', '1') != '0'
+_MSDA_SIDE = {}
+
+
+def _msda_side_stream(dev):
+    s = _MSDA_SIDE.get(dev)
+    if s is None:
+        s = _MSDA_SIDE[dev] = torch.cuda.Stream(dev)
+    return s
 
 
 class MultiScaleDeformableAttnFunction(torch.autograd.Function):

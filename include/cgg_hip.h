@@ -123,6 +123,12 @@ int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, co
                                  const float* sampling_loc, const float* attn_weight, const float* grad_out,
                                  float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
                                  int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream);
+/* ... with the split backward's two kernels on two streams (grad_value on `stream`, grad_loc / grad_attn on `side_stream`, forked
+ * from and joined back into `stream` by events inside the call; side_stream null or == stream: the one-stream form). */
+int cgg_msda_backward_hostlevels_2s(const float* value, const int32_t* level_hw, const int32_t* level_start,
+                                 const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                 float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
+                                 int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream, cgg_stream_t side_stream);
 int cgg_msda_backward_overwrites(const int32_t* level_hw, const int32_t* level_start, int B, int Nv, int H, int D, int L, int Nq,
                                  int P);
 

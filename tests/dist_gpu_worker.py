@@ -108,6 +108,15 @@ def main():
     reducer.broadcast_parameters(model)
     optimizer = build_optimizer(model, dict(type='AdamW', lr=1e-3, weight_decay=0.05))
     ref = copy.deepcopy(model)                                   # the same weights, no reducer attached: "local" gradients
+    # one throw-away forward + backward: on a cold box the libraries' first calls of a GEMM / convolution shape run another solution
+    # than every later call (seen once as a 3.5e-3 difference between the two compared backward passes on one caption-FFN weight,
+    # first test of a fresh box); the comparison below is about the reducer, not about library warm-up
+    wb = synthetic.train_batch(B, H, W, num_classes=nc, max_inst=4, vocab=500, seed=49 + rank, device=dev)
+    wg = torch.Generator().manual_seed(5 + rank)
+    ref.train_step(dict(img=torch.randn(B, 3, H, W, generator=wg).to(dev), img_metas=synthetic.img_metas(B, H, W), **wb))['loss'].backward()
+    for p in ref.parameters():
+        p.grad = None
+    torch.cuda.synchronize()
     for step in range(2):
         batch = synthetic.train_batch(B, H, W, num_classes=nc, max_inst=4, vocab=500, seed=50 + 10 * step + rank, device=dev)
         if rank == 1 and step == 0:                              # rank 1: one image without any ground truth
