@@ -56,8 +56,8 @@ class MultiHeadSelfAttention(nn.Module):
     def __init__(self, in_dim, nb_heads):
         super().__init__()
         self.nbr_heads, self.heads_dim = nb_heads, in_dim // nb_heads
-        self.qkv_layer = nn.Linear(in_dim, 3 * in_dim)
-        self.out_layer = nn.Linear(in_dim, in_dim)
+        self.qkv_layer = runtime.ParityLinear(in_dim, 3 * in_dim)
+        self.out_layer = runtime.ParityLinear(in_dim, in_dim)
 
     def forward(self, src, mask=None, key_padding_mask=None):
         B, L, _ = src.shape
@@ -71,10 +71,10 @@ class MultiHeadCrossAttention(nn.Module):
     def __init__(self, in_dim, nb_heads):
         super().__init__()
         self.nbr_heads, self.heads_dim = nb_heads, in_dim // nb_heads
-        self.to_qry = nn.Linear(in_dim, in_dim)
-        self.to_key = nn.Linear(in_dim, in_dim)
-        self.to_val = nn.Linear(in_dim, in_dim)
-        self.to_out = nn.Linear(in_dim, in_dim)
+        self.to_qry = runtime.ParityLinear(in_dim, in_dim)
+        self.to_key = runtime.ParityLinear(in_dim, in_dim)
+        self.to_val = runtime.ParityLinear(in_dim, in_dim)
+        self.to_out = runtime.ParityLinear(in_dim, in_dim)
 
     def forward(self, qry, key, val, mask=None, key_padding_mask=None):
         B, Lq, _ = qry.shape
@@ -98,7 +98,7 @@ class FeedForwardNetwork(nn.Module):
         for i, (a, b) in enumerate(zip(layer_cfg[:-1], layer_cfg[1:])):
             act = nn.Softmax(dim=-1) if activations[i] == 5 else _ACTS.get(activations[i], nn.Identity)()
             self.linears.append(nn.Sequential(
-                nn.Linear(a, b), nn.Dropout(drop_vals[i]) if drop_vals[i] > 0.0 else nn.Identity(), act))
+                runtime.ParityLinear(a, b), nn.Dropout(drop_vals[i]) if drop_vals[i] > 0.0 else nn.Identity(), act))
 
     def forward(self, x):
         for blk in self.linears:
@@ -245,11 +245,11 @@ class CaptionTransformer(nn.Module):
     def __init__(self, nb_layers, input_dim, hidden_dim, ff_dim, nb_heads, drop_val, pre_norm, seq_length,
                  nb_tokens):
         super().__init__()
-        self.adapter = nn.Linear(input_dim, hidden_dim) if input_dim != hidden_dim else nn.Identity()
+        self.adapter = runtime.ParityLinear(input_dim, hidden_dim) if input_dim != hidden_dim else nn.Identity()
         self.position_encoder = PositionalEncoding(seq_length, hidden_dim)
         self.transformer_decoder = TransformerDecoder(nb_layers=nb_layers, in_dim=hidden_dim, ff_dim=ff_dim,
                                                       nb_heads=nb_heads, drop_val=drop_val, pre_norm=pre_norm)
-        self.generator = nn.Linear(hidden_dim, nb_tokens)
+        self.generator = runtime.ParityLinear(hidden_dim, nb_tokens)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):

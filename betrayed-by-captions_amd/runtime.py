@@ -509,6 +509,27 @@ def x3_train_linear_ok(x, weight):
             and (x.numel() // x.shape[-1]) * max(weight.shape) * 4 < _X3_MAX_BYTES)
 
 
+X3_TRAIN_ROWS_MODULE = 1024        # rows from which `ParityLinear` modules (caption transformer) take the x3 node in parity-mode training
+
+
+class ParityLinear(torch.nn.Linear):
+    """`nn.Linear` (same parameters / state_dict keys) whose PARITY-mode training forward + backward run on the f32-class x3 node
+    (`_X3LinearFn`: forward, grad-input and weight / bias gradient) once the row count makes the kernels worth it; every other
+    case (inference, bf16 mode, CPU, odd shapes) is `F.linear`. Measured on the caption transformer's shapes at configs[2]
+    (forward + backward, `scratch/linear_shapes_bench.py`): 1.1-1.6 x the f32 library GEMMs, and closer to float64."""
+
+    def forward(self, x):
+        import torch.nn.functional as F
+        w = self.weight
+        rows = x.numel() // max(x.shape[-1], 1)
+        if (_X3_TRAIN and x3_enabled() and not is_bf16() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+                and w.dtype == torch.float32 and w.shape[1] % 32 == 0 and w.shape[0] % 32 == 0 and x.shape[-1] == w.shape[1]
+                and rows >= X3_TRAIN_ROWS_MODULE and rows * max(w.shape) * 4 < _X3_MAX_BYTES
+                and (x.requires_grad or w.requires_grad)):
+            return _X3LinearFn.apply(x, w, self.bias)
+        return F.linear(x, w, self.bias)
+
+
 SPLITK_WGRAD_ROWS = 32768          # rows from which the training linears use `_SplitKLinearFn` (CGG_SPLITK_WGRAD=0 disables)
 _SPLITK_WGRAD = _os.environ.get('CGG_SPLITK_WGRAD', '1') != '0'      # read once, like every switch of this module
 
