@@ -100,6 +100,7 @@ PROTOTYPES = {
     'cgg_wgrad_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_wgrad_bias_x3': (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_transpose_f32': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    'cgg_nchw_to_nhwc_pad1_f32': (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp]),
     'cgg_topk_select': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     'cgg_absmax_f32': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     'cgg_gemm_x3_bwd': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 3 + [_c_vp]),

@@ -271,8 +271,12 @@ extern "C" int cgg_subsample_nhwc(const void* x, void* y, int B, int H, int W, i
 // convolution (runtime._X3Conv3x3Fn; torch's strided copy ran them at ~2 TB/s: 1.1 ms per 1-GB map, eight of them per step at
 // configs[2]). 64 x 64 tiles through LDS (row stride 65 floats: conflict-free column reads), 256 threads, 16-byte global accesses on
 // both sides when R and C are multiples of 4 (scalar edge path otherwise).
+// PADW > 0 (the NCHW -> zero-padded NHWC form): the output rows are the pixels of a (H + 2) x (PADW + 2) grid with a one-pixel
+// border the kernel does not touch -- input column c = y PADW + x lands in output row (y + 1) (PADW + 2) + x + 1, batch stride
+// `out_bstride` floats.
+template <bool PAD>
 __global__ __launch_bounds__(256) void cgg_transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
-                                                                int tiles_c, int tiles_r) {
+                                                                int tiles_c, int tiles_r, int padw, long long out_bstride) {
   __shared__ float tile[64][65];
   const int t = threadIdx.x;
   const int bid = blockIdx.x;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void cgg_transpose_f32_kernel(const float* __r
   const int tr = rem / tiles_c, tc = rem - tr * tiles_c;
   const int r0 = tr * 64, c0 = tc * 64;
   const float* ib = in + (size_t)b * R * C;
-  float* ob = out + (size_t)b * R * C;
+  float* ob = out + (PAD ? (size_t)b * (size_t)out_bstride : (size_t)b * R * C);
   const bool vec = (R % 4 == 0) && (C % 4 == 0);
   // load: thread -> (row t / 16 + 16 i, 4 columns 4 (t % 16))
 #pragma unroll
@@ -307,12 +311,17 @@ __global__ __launch_bounds__(256) void cgg_transpose_f32_kernel(const float* __r
     const int c = (t >> 4) + 16 * i, r = 4 * (t & 15);
     const int gc = c0 + c, gr = r0 + r;
     if (gc >= C) continue;
+    size_t orow = (size_t)gc;
+    if constexpr (PAD) {
+      const int y = gc / padw, x = gc - y * padw;
+      orow = (size_t)(y + 1) * (size_t)(padw + 2) + (size_t)(x + 1);
+    }
     if (vec) {
-      if (gr < R) *reinterpret_cast<f32x4*>(ob + (size_t)gc * R + gr) = f32x4{tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]};
+      if (gr < R) *reinterpret_cast<f32x4*>(ob + orow * R + gr) = f32x4{tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]};
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (gr + e < R) ob[(size_t)gc * R + gr + e] = tile[r + e][c];
+        if (gr + e < R) ob[orow * R + gr + e] = tile[r + e][c];
     }
   }
 }
@@ -324,8 +333,26 @@ extern "C" int cgg_transpose_f32(const float* in, float* out, int B, int R, int 
   const int tiles_c = (C + 63) / 64, tiles_r = (R + 63) / 64;
   const long long nb = (long long)B * tiles_c * tiles_r;
   CGG_REQUIRE(nb < (1ll << 31), CGG_EUNSUPPORTED, "cgg_transpose_f32: too many tiles");
-  hipLaunchKernelGGL(cgg_transpose_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, R, C, tiles_c, tiles_r);
+  hipLaunchKernelGGL(cgg_transpose_f32_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, R, C, tiles_c,
+                     tiles_r, 0, 0ll);
   CGG_CHECK_LAUNCH("cgg_transpose_f32");
+  return CGG_OK;
+}
+
+// in (B, C, H, W) f32 contiguous -> the INTERIOR of out (B, H + 2, W + 2, C): channel-last with a one-pixel border that this call does
+// not write (the caller zeroes it once): the padded channel-last maps of the x3 training convolution (runtime._X3Conv3x3Fn: the
+// weight-gradient taps pair rows of the two padded maps at constant offsets) without a separate padding copy of a 1-GB map.
+extern "C" int cgg_nchw_to_nhwc_pad1_f32(const float* in, float* out, int B, int C, int H, int W, cgg_stream_t stream) {
+  CGG_REQUIRE(in && out, CGG_EINVAL, "cgg_nchw_to_nhwc_pad1_f32: null pointer");
+  CGG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 31), CGG_EINVAL, "cgg_nchw_to_nhwc_pad1_f32: bad sizes");
+  CGG_REQUIRE(cgg_aligned16(in) && cgg_aligned16(out), CGG_EALIGN, "cgg_nchw_to_nhwc_pad1_f32: 16-B alignment");
+  const int R = C, Cc = H * W;
+  const int tiles_c = (Cc + 63) / 64, tiles_r = (R + 63) / 64;
+  const long long nb = (long long)B * tiles_c * tiles_r;
+  CGG_REQUIRE(nb < (1ll << 31), CGG_EUNSUPPORTED, "cgg_nchw_to_nhwc_pad1_f32: too many tiles");
+  hipLaunchKernelGGL(cgg_transpose_f32_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc, tiles_c,
+                     tiles_r, W, (long long)(H + 2) * (W + 2) * C);
+  CGG_CHECK_LAUNCH("cgg_nchw_to_nhwc_pad1_f32");
   return CGG_OK;
 }
 

@@ -1331,6 +1331,22 @@ def nchw_to_nhwc(x):
     return transpose_f32(x.contiguous().view(B, C, H * W)).view(B, H, W, C)
 
 
+def nchw_to_nhwc_pad1(x):
+    """(B, C, H, W) f32 -> (B, H + 2, W + 2, C) channel-last with a ZERO one-pixel border (interior by the tiled transpose kernel,
+    border by four thin fills): what `F.pad(nchw_to_nhwc(x), (0, 0, 1, 1, 1, 1))` returns, without the 1-GB padding copy."""
+    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
+        raise CggError('nchw_to_nhwc_pad1: (B, C, H, W) float32 ROCm tensor expected')
+    B, C, H, W = x.shape
+    x = x.contiguous()
+    y = torch.empty((B, H + 2, W + 2, C), dtype=torch.float32, device=x.device)
+    y[:, 0].zero_()
+    y[:, H + 1].zero_()
+    y[:, 1:H + 1, 0].zero_()
+    y[:, 1:H + 1, W + 1].zero_()
+    check(_lib_().cgg_nchw_to_nhwc_pad1_f32(dev_ptr(x), dev_ptr(y), B, C, H, W, stream_ptr(x.device)), 'cgg_nchw_to_nhwc_pad1_f32')
+    return y
+
+
 def nhwc_to_nchw(x):
     """(B, H, W, C) contiguous f32 -> (B, C, H, W) contiguous."""
     B, H, W, C = x.shape

@@ -431,50 +431,51 @@ class _X3Conv3x3Fn(torch.autograd.Function):
     maps (grad-input = the convolution of grad_output with the flipped, transposed filter); the weight gradient is nine
     `ops.wgrad_x3` contractions, one per filter tap, over the ZERO-PADDED channel-last maps: with both maps padded by one pixel a
     tap is a constant row offset between two row-major matrices (border rows of grad_output are zero, so nothing leaks across
-    rows or images). Layout changes (NCHW <-> NHWC copies, padding) are paid explicitly: ~3 ms of the ~17 ms this costs."""
+    rows or images). Layout changes are paid explicitly: the tiled transposes write the padded channel-last maps directly
+    (`ops.nchw_to_nhwc_pad1`), ~2 ms of the ~15 ms this costs."""
 
     @staticmethod
     def forward(ctx, x, weight):
         from . import ops
         N = weight.shape[0]
-        xl = ops.nchw_to_nhwc(x.detach())                # tiled transpose (torch's strided copy: ~2 TB/s)
+        # the input goes channel-last straight into its ZERO-PADDED form (B, H + 2, W + 2, C): the forward convolution then runs
+        # with pad 0 (the same zeros the implicit padding supplied) and the backward's weight-gradient taps need no padding copy
+        xp = ops.nchw_to_nhwc_pad1(x.detach())
         wk = derived_cached('x3_conv_image', (weight,), lambda: ops.pack_conv_weight_x3(weight))
-        y = ops.conv_x3s_nhwc(ops.x3a_encode(xl), wk, N, 3, 1, 1, None, out_split=False)
-        ctx.save_for_backward(xl, weight)
+        y = ops.conv_x3s_nhwc(ops.x3a_encode(xp), wk, N, 3, 1, 0, None, out_split=False)
+        ctx.save_for_backward(xp, weight)
         return ops.nhwc_to_nchw(y)                       # contiguous NCHW: what the GroupNorm behind it wants
 
     @staticmethod
     def backward(ctx, gy):
-        import torch.nn.functional as F
         from . import ops
-        xl, weight = ctx.saved_tensors
-        B, H, W, C = xl.shape
+        xp, weight = ctx.saved_tensors
+        B, Hp, Wp, C = xp.shape
+        H, W = Hp - 2, Wp - 2
         N = weight.shape[0]
-        gl = ops.nchw_to_nhwc(gy)
-        gl = gl if gl.is_contiguous() else gl.contiguous()
+        gp = ops.nchw_to_nhwc_pad1(gy)                    # (B, H + 2, W + 2, N), zero border
         gx = gw = None
-        amax = ops.absmax(gl.view(-1, N)) if _X3_GSCALE else None        # per-tensor pre-scale of grad_output (see _X3LinearFn)
-        if ctx.needs_input_grad[0] and amax is not None:
+        # per-tensor pre-scale of grad_output (see _X3LinearFn); the zero border does not change the maximum
+        amax = ops.absmax(gp.view(-1, N)) if _X3_GSCALE else None
+        if ctx.needs_input_grad[0]:
             wt = derived_cached('x3_conv_image_dgrad', (weight,),
                                 lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
-            # f32 rows split in the kernel with the per-tensor scale (the x3a form bakes the fixed 2^4 into the stored pieces)
-            gx = ops.nhwc_to_nchw(ops.conv_x3_nhwc(gl, wt, C, 3, 1, 1, amax=amax))
-        elif ctx.needs_input_grad[0]:
-            wt = derived_cached('x3_conv_image_dgrad', (weight,),
-                                lambda: ops.pack_conv_weight_x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous()))
-            # (contiguous NCHW: a channel-last-strided gradient sent the producer's backward -- the FPN's bilinear up-sample -- down
-            # torch's NHWC kernel, 4.3 ms instead of 1.4)
-            gx = ops.nhwc_to_nchw(ops.conv_x3s_nhwc(ops.x3a_encode(gl), wt, C, 3, 1, 1, None, out_split=False))
+            if amax is not None:
+                # f32 rows split in the kernel with the per-tensor scale (the x3a form bakes the fixed 2^4 into the stored pieces)
+                gx = ops.nhwc_to_nchw(ops.conv_x3_nhwc(gp, wt, C, 3, 1, 0, amax=amax))
+            else:
+                # (contiguous NCHW: a channel-last-strided gradient sent the producer's backward -- the FPN's bilinear up-sample -- down
+                # torch's NHWC kernel, 4.3 ms instead of 1.4)
+                gx = ops.nhwc_to_nchw(ops.conv_x3s_nhwc(ops.x3a_encode(gp), wt, C, 3, 1, 0, None, out_split=False))
         if ctx.needs_input_grad[1]:
-            xp = F.pad(xl, (0, 0, 1, 1, 1, 1)).view(-1, C)               # rows of the (B, H + 2, W + 2) grid
-            gp = F.pad(gl, (0, 0, 1, 1, 1, 1)).view(-1, N)
-            Mp = xp.shape[0]
-            lo, hi = W + 3, Mp - (W + 3)                                 # rows outside are border rows: grad_output is zero there
-            gw = torch.empty((N, 3, 3, C), dtype=torch.float32, device=xl.device)
+            xr, gr = xp.view(-1, C), gp.view(-1, N)       # rows of the (B, H + 2, W + 2) grid
+            Mp = xr.shape[0]
+            lo, hi = W + 3, Mp - (W + 3)                  # rows outside are border rows: grad_output is zero there
+            gw = torch.empty((N, 3, 3, C), dtype=torch.float32, device=xp.device)
             for ky in range(3):
                 for kx in range(3):
                     off = (ky - 1) * (W + 2) + (kx - 1)
-                    gw[:, ky, kx, :] = ops.wgrad_x3(gp[lo:hi], xp[lo + off:hi + off], amax=amax)
+                    gw[:, ky, kx, :] = ops.wgrad_x3(gr[lo:hi], xr[lo + off:hi + off], amax=amax)
             gw = gw.permute(0, 3, 1, 2)
         return gx, gw
 

@@ -523,6 +523,9 @@ int cgg_encoder_layer_tail_x3a(const float* a32, const void* x_x3a, const void* 
 /* Batched transpose of f32 matrices, in (B, R, C) -> out (B, C, R): the NCHW <-> NHWC layout changes around the x3 kernels under
  * autograd (torch `x.permute(0, 2, 3, 1).contiguous()` and back), 64 x 64 tiles through LDS. */
 int cgg_transpose_f32(const float* in, float* out, int B, int R, int C, cgg_stream_t stream);
+/* in (B, C, H, W) f32 contiguous -> the interior of out (B, H + 2, W + 2, C) (channel-last, one-pixel border NOT written: the caller
+ * zeroes it): padded channel-last maps for the x3 training convolution's weight-gradient taps without a padding copy. */
+int cgg_nchw_to_nhwc_pad1_f32(const float* in, float* out, int B, int C, int H, int W, cgg_stream_t stream);
 
 /* Training in parity mode: the weight gradient of a linear layer, dW[n][k] = sum_m dy[m][n] x[m][k] -- autograd's
  * `grad_output.t() @ input` behind the F.linear calls of the [3P] MSDeformAttn encoder layers (mask2former_head.py:787) -- on the

@@ -469,3 +469,14 @@ def test_encoder_block_nodes_match_the_unfused_nodes_and_float64(dev, monkeypatc
         ref = b.abs().max().item()
         assert ref > 0 and torch.isfinite(a).all(), n
         assert (a - b).abs().max().item() <= 2e-4 * ref, (n, (a - b).abs().max().item(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,H,W', [(1, 64, 8, 8), (2, 96, 5, 7), (3, 256, 32, 20)])
+def test_nchw_to_nhwc_pad1_is_the_padded_permutation(dev, B, C, H, W):
+    """`ops.nchw_to_nhwc_pad1` (tiled transpose straight into the padded channel-last map of the x3 training convolution) ==
+    F.pad(x.permute(0, 2, 3, 1), one zero pixel around), exactly."""
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(B + H)).to(dev)
+    got = ops.nchw_to_nhwc_pad1(x)
+    want = F.pad(x.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    assert got.shape == want.shape and torch.equal(got, want)
