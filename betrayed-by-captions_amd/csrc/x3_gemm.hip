@@ -25,7 +25,9 @@
 // 610 / 736 / 578 / 747 / 264 us. The phases ADD instead of overlapping: the store epilogue (0.35 / 1.4 GB) costs its full HBM
 // time, the split / LDS-write phase and the MFMA phase of a chunk run back to back in each of the 2 workgroups a CU holds. Cache-
 // policy bits on the stores (sc0 / nt / sc1) changed nothing (+-2 %); 128 x 64 / 64 x 128 / 64 x 64 tiles (3-4 workgroups per CU) are 15-40 %
-// slower at these shapes.
+// slower at these shapes, and so are 256 x 128 / 128 x 256 / 256 x 256 tiles (TM / TN = 4: 128 x 128 per wave, 256 accumulators in AGPRs,
+// one workgroup of 4 waves per CU, compiler-scheduled): 258 / 269 / 259 us at K = 256, N = 256 and 950 / 902 / 840 us at N = 1024 --
+// with one wave per SIMD every LDS / memory wait is exposed; that tile needs hand-placed waits and prefetch, not a template argument.
 #include "x3.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
