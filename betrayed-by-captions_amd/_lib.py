@@ -131,6 +131,9 @@ PROTOTYPES = {
     'cgg_add_layernorm_ex': (_c_int, [_c_vp, _c_int, _c_vp, _c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 +
                              [_c_int, _c_int, _c_f, _c_vp]),
     'cgg_group_norm_nhwc_workspace_bytes': (_c_i64, [_c_int] * 3),
+    'cgg_group_norm_nhwc_backward_workspace_bytes': (_c_i64, [_c_int] * 3),
+    'cgg_group_norm_nhwc_f32_backward': (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_f, _c_int] + [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
+    'cgg_group_norm_nhwc_f32_padout': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int, _c_vp, _c_vp]),
     'cgg_group_norm_nhwc': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,
                                        _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_group_norm_nhwc_f32': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,

@@ -69,6 +69,27 @@ class LowResMasks:
             yield self[i]
 
 
+_PINNED, _COPY_STREAMS = {}, {}
+
+
+def _pinned_like(t):
+    """Pinned host buffer of t's shape / dtype, reused across steps (allocating pinned memory synchronises the device)."""
+    k = (tuple(t.shape), t.dtype)
+    b = _PINNED.get(k)
+    if b is None:
+        if len(_PINNED) > 16:
+            _PINNED.clear()
+        b = _PINNED[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    return b
+
+
+def _copy_stream(dev):
+    s = _COPY_STREAMS.get(dev)
+    if s is None:
+        s = _COPY_STREAMS[dev] = torch.cuda.Stream(dev)
+    return s
+
+
 class LazyMasks:
     """Training-time stand-in for one layer's (B, Q, h, w) `mask_pred`: keeps the factors of the einsum
     (mask2former_head.py:748) instead of its 100-query result. The loss only ever reads mask logits (a) at 12 544 shared
@@ -938,7 +959,7 @@ class Mask2FormerHeadOpen(nn.Module):
                 and type(a.cls_cost) is ClassificationCost and type(a.cls_emb_cost) is ClassificationCost
                 and type(a.mask_cost) is CrossEntropyLossCost and type(a.dice_cost) is DiceCost)
 
-    def _targets_batched(self, all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f):
+    def _targets_batched(self, all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f, overlap=None):
         """`_get_target_single` (mask2former_head.py:320-390) for every (layer, image) at once.
         The reference runs 2 point-samplings, 4 cost terms, a device->host sync and ~10 indexing kernels per
         (layer, image): 160 times at configs[2]. Here: predictions are sampled per LAYER (all images in one
@@ -946,7 +967,11 @@ class Mask2FormerHeadOpen(nn.Module):
         converted once per step), the cost matrices of an image's 10 layers are batched matmuls, ONE transfer
         brings all costs to the host for scipy's Hungarian solver, ONE transfer takes the targets back.
         Random points are drawn in the reference's order (layer-major, then image) so pinned draws line up.
-        Returns per layer: (labels (B,Q) long, mask_weights (B,Q) f32, pos_b, pos_g (npos,) long, num_pos)."""
+        Returns per layer: (labels (B,Q) long, mask_weights (B,Q) f32, pos_b, pos_g (npos,) long, num_pos).
+        overlap: optional callable run AFTER the cost matrices' device->host copy is enqueued (on a side stream, pinned target) and
+        BEFORE the host waits for it: device work that does not depend on the targets (the caption branch) then executes while the
+        host waits, solves the assignments and enqueues the loss kernels -- otherwise the device idles from the copy to the first
+        loss kernel. Its return value is stored in `self._overlap_result`."""
         n, B, Q = len(all_cls_scores), all_cls_scores[0].shape[0], all_cls_scores[0].shape[1]
         dev = all_cls_scores[0].device
         P = self.num_points
@@ -1003,11 +1028,38 @@ class Mask2FormerHeadOpen(nn.Module):
                 if getattr(self, 'cost_trace', None) is not None:      # test hook: the (n, Q, G) cost matrices of image b
                     self.cost_trace.append((b, cost.detach().float().clone()))
                 costs.append(cost.float().reshape(-1))                                        # (n*Q*G,)
-            flat = torch.cat(costs).cpu() if costs else None                                  # the ONE sync
+            flat = None
+            if costs and overlap is not None and costs[0].is_cuda:
+                flat_dev = torch.cat(costs)
+                flat = _pinned_like(flat_dev)
+                cur, side = torch.cuda.current_stream(dev), _copy_stream(dev)
+                side.wait_stream(cur)
+                lab_dev = torch.cat([g.reshape(-1) for g in gt_labels_list]).to(torch.int64)
+                lab_host = _pinned_like(lab_dev)          # (a `.cpu()` per image after `overlap` would wait for the work it enqueued)
+                with torch.cuda.stream(side):
+                    flat.copy_(flat_dev, non_blocking=True)
+                    lab_host.copy_(lab_dev, non_blocking=True)
+                    arrived = torch.cuda.Event()
+                    arrived.record(side)
+                flat_dev.record_stream(side)
+                lab_dev.record_stream(side)
+        if overlap is not None:
+            self._overlap_result = overlap()              # (with autograd: the caption branch is part of the graph)
+        with torch.no_grad():
+            if flat is not None:
+                arrived.synchronize()                                                         # the ONE sync
+            elif costs:
+                flat = torch.cat(costs).cpu()                                                 # the ONE sync
         import numpy as np
         labels_np = np.full((n, B, Q), self.num_classes, dtype=np.int64)
         weights_np = np.zeros((n, B, Q), dtype=np.float32)
-        gl_host = [g.cpu().numpy() if s else None for g, s in zip(gt_labels_list, shapes)] if costs else []
+        if costs and overlap is not None and costs[0].is_cuda:
+            gl_host, o = [], 0
+            for s_ in shapes:
+                gl_host.append(lab_host[o:o + s_].numpy() if s_ else None)
+                o += s_
+        else:
+            gl_host = [g.cpu().numpy() if s else None for g, s in zip(gt_labels_list, shapes)] if costs else []
         pos_b = [[] for _ in range(n)]
         pos_g = [[] for _ in range(n)]
         pos_q = [[] for _ in range(n)]
@@ -1298,6 +1350,29 @@ class Mask2FormerHeadOpen(nn.Module):
                 loss_dict[f'd{li}.{k}'] = v * self.loss_aux_weight
         return loss_dict
 
+    def _caption_generation_losses(self, n, B, all_cls_emb_preds, gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list,
+                                   gt_caption_nouns_ids_list):
+        """loss_caption_generation of all n layers from ONE pass of the caption generator (see `_loss_batched`)."""
+        cap_losses = [None] * n
+        if not self.use_caption_generation:
+            return cap_losses
+        emb = torch.stack(gt_caption_embs_list, dim=0)
+        msk = torch.stack(gt_caption_mask_list, dim=0).bool()
+        T1 = emb.shape[1] - 1
+        ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)[:, 1:].flatten(0, 1)
+        cg, lcg = self.caption_generator, self.loss_caption_generation
+        kw = dict(tgt=emb[:, :-1, :].repeat(n, 1, 1), memory=torch.cat(list(all_cls_emb_preds), 0),
+                  tgt_key_padding_mask=torch.logical_not(msk[:, :-1]).repeat(n, 1))
+        if emb.is_cuda and hasattr(cg, 'generator_ce_rows') and getattr(lcg, 'rows_ok', lambda: False)():
+            # generator + cross-entropy without the (n*B*34, 30522) logits: HIP row kernels over GEMM row chunks
+            hidden = cg.forward_hidden(**kw).flatten(0, 1)                                   # (n*B*(T-1), hidden)
+            rows = cg.generator_ce_rows(hidden, ids.repeat(n), lcg.ignore_index).view(n, B * T1)
+            cap_losses = [lcg.forward_rows(rows[li], ids) for li in range(n)]
+        else:
+            logits = cg(**kw)[1].view(n, B * T1, -1)                                         # (n, B*(T-1), V)
+            cap_losses = [lcg(logits[li], ids) for li in range(n)]
+        return cap_losses
+
     def _loss_batched(self, all_cls_scores, all_cls_emb_preds, emb_logits, all_mask_preds, gt_labels_list,
                       gt_masks_list, gt_caption_ids_list, gt_caption_embs_list, gt_caption_mask_list,
                       gt_caption_nouns_ids_list, gt_caption_nouns_embs_list, gt_caption_nouns_mask_list, img_metas):
@@ -1312,33 +1387,25 @@ class Mask2FormerHeadOpen(nn.Module):
         if gt_f and gt_f[0].is_cuda and len({tuple(g.shape[-2:]) for g in gt_f}) == 1 and sum(g.shape[0] for g in gt_f) > 0:
             counts = torch.tensor([0] + [g.shape[0] for g in gt_f[:-1]], device=gt_f[0].device)
             gt_cat = (torch.cat(gt_f, 0).contiguous(), torch.cumsum(counts, 0))     # planes of all images + first plane of image b
-        targets = self._targets_batched(all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f)
+
+        def caption_branch():
+            # independent of the Hungarian targets: enqueued while the cost matrices travel to the host (see `_targets_batched`)
+            gathered = [None] * n
+            if self.use_caption:
+                gathered = self._gather_all_layers(gt_caption_nouns_embs_list, gt_caption_nouns_mask_list,
+                                                   all_cls_emb_preds)
+            return gathered, self._caption_generation_losses(n, B, all_cls_emb_preds, gt_caption_ids_list, gt_caption_embs_list,
+                                                             gt_caption_mask_list, gt_caption_nouns_ids_list)
+
+        self._overlap_result = None
+        targets = self._targets_batched(all_cls_scores, emb_logits, all_mask_preds, gt_labels_list, gt_f, overlap=caption_branch)
+        gathered, cap_losses = self._overlap_result
+        self._overlap_result = None
         pos_counts = [float(t[4]) for t in targets]
         if dist.is_available() and dist.is_initialized():
             ntm = reduce_mean(all_cls_scores[0].new_tensor(pos_counts)).clamp(min=1).tolist()
         else:
             ntm = [max(c, 1.0) for c in pos_counts]
-        gathered = [None] * n
-        if self.use_caption:
-            gathered = self._gather_all_layers(gt_caption_nouns_embs_list, gt_caption_nouns_mask_list,
-                                               all_cls_emb_preds)
-        cap_losses = [None] * n
-        if self.use_caption_generation:
-            emb = torch.stack(gt_caption_embs_list, dim=0)
-            msk = torch.stack(gt_caption_mask_list, dim=0).bool()
-            T1 = emb.shape[1] - 1
-            ids = self._caption_targets(gt_caption_ids_list, gt_caption_nouns_ids_list)[:, 1:].flatten(0, 1)
-            cg, lcg = self.caption_generator, self.loss_caption_generation
-            kw = dict(tgt=emb[:, :-1, :].repeat(n, 1, 1), memory=torch.cat(list(all_cls_emb_preds), 0),
-                      tgt_key_padding_mask=torch.logical_not(msk[:, :-1]).repeat(n, 1))
-            if emb.is_cuda and hasattr(cg, 'generator_ce_rows') and getattr(lcg, 'rows_ok', lambda: False)():
-                # generator + cross-entropy without the (n*B*34, 30522) logits: HIP row kernels over GEMM row chunks
-                hidden = cg.forward_hidden(**kw).flatten(0, 1)                                   # (n*B*(T-1), hidden)
-                rows = cg.generator_ce_rows(hidden, ids.repeat(n), lcg.ignore_index).view(n, B * T1)
-                cap_losses = [lcg.forward_rows(rows[li], ids) for li in range(n)]
-            else:
-                logits = cg(**kw)[1].view(n, B * T1, -1)                                         # (n, B*(T-1), V)
-                cap_losses = [lcg(logits[li], ids) for li in range(n)]
         if all(isinstance(m, LazyMasks) for m in all_mask_preds):
             LazyMasks.preselect(list(all_mask_preds), [t[5] for t in targets])
         results = []

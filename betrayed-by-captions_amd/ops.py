@@ -1093,6 +1093,80 @@ def group_norm_nhwc_x3a(x, gamma, beta, groups, eps, ws, out, relu=False, up=Non
     check(rc, 'cgg_group_norm_nhwc_f32_x3a')
 
 
+def zero_border_map(B, H, W, C, device):
+    """(B, H + 2, W + 2, C) f32 channel-last map whose one-pixel border is zero and whose interior is uninitialised (four thin fills)."""
+    y = torch.empty((B, H + 2, W + 2, C), dtype=torch.float32, device=device)
+    y[:, 0].zero_()
+    y[:, H + 1].zero_()
+    y[:, 1:H + 1, 0].zero_()
+    y[:, 1:H + 1, W + 1].zero_()
+    return y
+
+
+def group_norm_nhwc_padout(x, gamma, beta, groups, eps, ws, hw, y_padded, relu=False, lo=None, lo_hw=None):
+    """`group_norm_nhwc` of f32 rows x (B, HW, C) (+ bilinear up-sample of lo (B, lo_h lo_w, C)) with y written into the interior of
+    `y_padded` (B, H + 2, W + 2, C) (`zero_border_map`): the x3 training convolution's padded input without a padding copy."""
+    B, HW, C = x.shape
+    H, W = int(hw[0]), int(hw[1])
+    if x.dtype != torch.float32 or not x.is_contiguous() or tuple(y_padded.shape) != (B, H + 2, W + 2, C) or not y_padded.is_contiguous():
+        raise CggError('group_norm_nhwc_padout: x (B, HW, C) float32 contiguous and y_padded (B, H + 2, W + 2, C) expected')
+    if lo is not None and (not lo.is_contiguous() or lo.dtype != torch.float32):
+        raise CggError('group_norm_nhwc_padout: lo must be contiguous float32 rows')
+    check(_lib_().cgg_group_norm_nhwc_f32_padout(
+        dev_ptr(x), dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(beta, 'beta', torch.float32), dev_ptr(ws), B, HW, C, int(groups),
+        float(eps), int(bool(relu)), dev_ptr(lo) if lo is not None else None, int(lo_hw[0]) if lo is not None else 0,
+        int(lo_hw[1]) if lo is not None else 0, int(lo.shape[1]) * C if lo is not None else 0, W, dev_ptr(y_padded),
+        stream_ptr(x.device)), 'cgg_group_norm_nhwc_f32_padout')
+
+
+def group_norm_nhwc_backward(x, y, dy, stats, gamma, groups, eps, relu, hw, lo_hw=None, dx_padded=None):
+    """Backward of the channel-last f32 GroupNorm (`cgg_group_norm_nhwc_f32_backward`): x, dy (and y when relu) (B, HW, C), stats
+    (B * groups * 2) = the forward workspace's head. -> (dx, dgamma, dbeta, dlo | None); dx_padded: a `zero_border_map` that receives
+    dx in its interior (then returned as dx)."""
+    B, HW, C = x.shape
+    lib = _lib_()
+    ws = torch.empty(max(lib.cgg_group_norm_nhwc_backward_workspace_bytes(B, HW, int(groups)) // 4, 1), dtype=torch.float32, device=x.device)
+    dx = dx_padded if dx_padded is not None else torch.empty_like(x)
+    tot = torch.empty((B, int(groups), 16), dtype=torch.float32, device=x.device)
+    dlo = torch.empty((B, lo_hw[0] * lo_hw[1], C), dtype=torch.float32, device=x.device) if lo_hw is not None else None
+    check(lib.cgg_group_norm_nhwc_f32_backward(dev_ptr(x), dev_ptr(y) if relu else None, dev_ptr(dy), dev_ptr(stats),
+                                               dev_ptr(gamma, 'gamma', torch.float32), dev_ptr(ws), B, HW, C, int(groups), float(eps),
+                                               int(bool(relu)), dev_ptr(dx), dev_ptr(tot), dev_ptr(dlo) if dlo is not None else None,
+                                               lo_hw[0] if lo_hw else 0, lo_hw[1] if lo_hw else 0, int(hw[1]),
+                                               int(dx_padded is not None), stream_ptr(x.device)), 'cgg_group_norm_nhwc_f32_backward')
+    t = tot.sum(0)                                        # (groups, 16)
+    return dx, t[:, :8].reshape(C), t[:, 8:].reshape(C), dlo
+
+
+class GroupNormRowsFn(torch.autograd.Function):
+    """y = act(GroupNorm(x) [+ bilinear up-sample of `lo`]) on CHANNEL-LAST f32 rows for the training step (parity mode;
+    `cgg_group_norm_nhwc_f32` forward, `cgg_group_norm_nhwc_f32_backward`): x (B, HW, C) with C / groups == 8, lo (B, lo_h * lo_w, C) |
+    None (the [3P] lateral ConvModule has no activation: relu only without `lo`, the output ConvModule). Returns y (B, HW, C)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu, lo, hw, lo_hw):
+        B, HW, C = x.shape
+        x = x.contiguous()
+        ws = group_norm_nhwc_workspace(B, HW, groups, x.device)
+        y = torch.empty_like(x)
+        up = None
+        if lo is not None:
+            lo = lo.contiguous()
+            up = (lo, 0, lo.shape[1] * C, int(lo_hw[0]), int(lo_hw[1]))
+        group_norm_nhwc(x, gamma.detach(), beta.detach(), groups, eps, ws, relu=relu, up=up, W=int(hw[1]), out32=(y, 0, HW * C))
+        stats = ws[:B * groups * 2].clone()
+        ctx.save_for_backward(x, y if relu else x.new_empty(0), stats, gamma)
+        ctx.cfg = (int(groups), float(eps), bool(relu), tuple(hw), tuple(lo_hw) if lo is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, stats, gamma = ctx.saved_tensors
+        groups, eps, relu, hw, lo_hw = ctx.cfg
+        dx, dgamma, dbeta, dlo = group_norm_nhwc_backward(x, y, gy.contiguous(), stats, gamma, groups, eps, relu, hw, lo_hw)
+        return dx, dgamma, dbeta, None, None, None, dlo, None, None
+
+
 def pack_mask_feature_nhwc(feat, pool=1):
     """feat (B, H, W, C) bf16 channel-last -> PackedFeature (hi image only; throughput mode)."""
     B, H, W, C = feat.shape
@@ -1338,11 +1412,7 @@ def nchw_to_nhwc_pad1(x):
         raise CggError('nchw_to_nhwc_pad1: (B, C, H, W) float32 ROCm tensor expected')
     B, C, H, W = x.shape
     x = x.contiguous()
-    y = torch.empty((B, H + 2, W + 2, C), dtype=torch.float32, device=x.device)
-    y[:, 0].zero_()
-    y[:, H + 1].zero_()
-    y[:, 1:H + 1, 0].zero_()
-    y[:, 1:H + 1, W + 1].zero_()
+    y = zero_border_map(B, H, W, C, x.device)
     check(_lib_().cgg_nchw_to_nhwc_pad1_f32(dev_ptr(x), dev_ptr(y), B, C, H, W, stream_ptr(x.device)), 'cgg_nchw_to_nhwc_pad1_f32')
     return y
 

@@ -1082,8 +1082,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 src = layer.norms[0](src)
                 src = layer.ffns[0](src)
                 src = layer.norms[1](src)
-        outs = [x.transpose(1, 2).reshape(B, -1, h, w)
-                for x, (h, w) in zip(src.split([h * w for h, w in level_hw], dim=1), level_hw)]
+        level_rows = src.split([h * w for h, w in level_hw], dim=1)
+        outs = [x.transpose(1, 2).reshape(B, -1, h, w) for x, (h, w) in zip(level_rows, level_hw)]
+        if (self.num_input_levels - self.num_encoder_levels == 1 and len(outs) >= self.num_outs
+                and runtime.x3_fpn_level_ok(self, feats[0], level_hw[-1])):
+            # parity-mode training: the FPN level stays channel-last on own kernels (lateral / mask-feature 1 x 1 as x3 row GEMMs, both
+            # GroupNorms, the up-sample + add, the ReLU and the x3 3 x 3 convolution in one autograd node: `runtime._X3FpnLevelFn`)
+            return runtime.fpn_level_x3_train(self, feats[0], level_rows[-1], level_hw[-1]), outs[:self.num_outs]
         for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
             x = feats[i]
             with runtime.autocast():

@@ -480,6 +480,138 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         return gx, gw
 
 
+_X3_FPN_ROWS = _os.environ.get('CGG_X3_FPN_ROWS', '1') != '0'      # parity-mode training: the finest FPN level channel-last on own kernels (A/B)
+
+
+class _NchwToRowsFn(torch.autograd.Function):
+    """(B, C, H, W) f32 -> channel-last rows (B, H W, C) by the tiled transpose kernel (and back for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        B, C, H, W = x.shape
+        ctx.hw = (H, W)
+        return ops.nchw_to_nhwc(x.detach()).reshape(B, H * W, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        B, HW, C = g.shape
+        return ops.nhwc_to_nchw(g.contiguous().view(B, ctx.hw[0], ctx.hw[1], C))
+
+
+class _RowsToNchwFn(torch.autograd.Function):
+    """channel-last rows (B, H W, C) -> contiguous (B, C, H, W) by the tiled transpose kernel (and back for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, hw):
+        from . import ops
+        B, HW, C = x.shape
+        return ops.nhwc_to_nchw(x.detach().contiguous().view(B, hw[0], hw[1], C))
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        B, C, H, W = g.shape
+        return ops.nchw_to_nhwc(g).reshape(B, H * W, C), None
+
+
+class _X3FpnLevelFn(torch.autograd.Function):
+    """y = relu(GN2(conv3x3(GN1(cur) + up(lo)))) on channel-last f32 rows: the [3P] MSDeformAttnPixelDecoder FPN step behind a lateral
+    1 x 1 convolution (lateral GroupNorm, + bilinear up-sample of the coarser level, output ConvModule = 3 x 3 convolution + GroupNorm +
+    ReLU; open_set/models/mask2former_head.py:787) as ONE autograd node in PARITY-mode training. The 256^2 level of configs[2] costs
+    ~38 ms per step as library modules on NCHW maps (MIOpen 1 x 1 / transposes, torch GroupNorm, add, up-sample, ReLU and their
+    backward kernels, layout copies around the x3 convolution). Here: both GroupNorms are the channel-last kernels of csrc/norm.hip
+    (forward with the up-sample + add / the ReLU fused, backward `cgg_group_norm_nhwc_f32_backward` incl. the up-sample's transpose);
+    GN1 writes straight into the zero-bordered map the x3 convolution reads with pad 0, GN2's backward writes grad_output of the
+    convolution straight into its zero-bordered form -- the maps the nine weight-gradient taps pair row by row -- so no layout or
+    padding copy exists at all. cur (B, H W, C) = lateral convolution output, lo (B, h w, C) = coarser level (both channel-last rows)."""
+
+    @staticmethod
+    def forward(ctx, cur, lo, g1, b1, wc, g2, b2, groups, eps1, eps2, hw, lo_hw):
+        from . import ops
+        B, HW, C = cur.shape
+        H, W = int(hw[0]), int(hw[1])
+        N = wc.shape[0]
+        cur, lo = cur.contiguous(), lo.contiguous()
+        ws = ops.group_norm_nhwc_workspace(B, HW, groups, cur.device)
+        y1p = ops.zero_border_map(B, H, W, C, cur.device)
+        ops.group_norm_nhwc_padout(cur, g1.detach(), b1.detach(), groups, eps1, ws, (H, W), y1p, lo=lo, lo_hw=lo_hw)
+        stats1 = ws[:B * groups * 2].clone()
+        wk = derived_cached('x3_conv_image', (wc,), lambda: ops.pack_conv_weight_x3(wc))
+        y2 = ops.conv_x3s_nhwc(ops.x3a_encode(y1p), wk, N, 3, 1, 0, None, out_split=False).view(B, HW, N)
+        y3 = torch.empty_like(y2)
+        ops.group_norm_nhwc(y2, g2.detach(), b2.detach(), groups, eps2, ws, relu=True, W=W, out32=(y3, 0, HW * N))
+        stats2 = ws[:B * groups * 2].clone()
+        ctx.save_for_backward(cur, stats1, y1p, y2, stats2, y3, g1, wc, g2)
+        ctx.cfg = (int(groups), float(eps1), float(eps2), (H, W), tuple(int(v) for v in lo_hw))
+        return y3
+
+    @staticmethod
+    def backward(ctx, g3):
+        from . import ops
+        cur, stats1, y1p, y2, stats2, y3, g1, wc, g2 = ctx.saved_tensors
+        groups, eps1, eps2, (H, W), lo_hw = ctx.cfg
+        B, HW, C = cur.shape
+        N = wc.shape[0]
+        gp = ops.zero_border_map(B, H, W, N, cur.device)
+        _, dg2, db2, _ = ops.group_norm_nhwc_backward(y2, y3, g3.contiguous(), stats2, g2, groups, eps2, True, (H, W), dx_padded=gp)
+        amax = ops.absmax(gp.view(-1, N)) if _X3_GSCALE else None
+        wt = derived_cached('x3_conv_image_dgrad', (wc,),
+                            lambda: ops.pack_conv_weight_x3(wc.detach().flip(2, 3).transpose(0, 1).contiguous()))
+        if amax is not None:
+            gy1 = ops.conv_x3_nhwc(gp, wt, C, 3, 1, 0, amax=amax)
+        else:
+            gy1 = ops.conv_x3s_nhwc(ops.x3a_encode(gp), wt, C, 3, 1, 0, None, out_split=False)
+        xr, gr = y1p.view(-1, C), gp.view(-1, N)
+        Mp = xr.shape[0]
+        lo_, hi_ = W + 3, Mp - (W + 3)                    # rows outside are border rows: grad_output is zero there
+        gw = torch.empty((N, 3, 3, C), dtype=torch.float32, device=cur.device)
+        for ky in range(3):
+            for kx in range(3):
+                off = (ky - 1) * (W + 2) + (kx - 1)
+                gw[:, ky, kx, :] = ops.wgrad_x3(gr[lo_:hi_], xr[lo_ + off:hi_ + off], amax=amax)
+        dcur, dg1, db1, dlo = ops.group_norm_nhwc_backward(cur, None, gy1.view(B, HW, C), stats1, g1, groups, eps1, False, (H, W),
+                                                           lo_hw=lo_hw)
+        return dcur, dlo, dg1, db1, gw.permute(0, 3, 1, 2), dg2, db2, None, None, None, None, None
+
+
+def x3_fpn_level_ok(pd, x, lo_hw):
+    """PARITY-mode training of the pixel decoder's single FPN level (lateral 1 x 1 + GN, + up-sample, 3 x 3 + GN + ReLU, mask-feature
+    1 x 1) on channel-last rows and own kernels: `_X3FpnLevelFn` + `_X3LinearFn`s."""
+    import torch.nn as nn
+    if not (_X3_FPN_ROWS and _X3_TRAIN and _X3A and _X3_WGRAD and x3_enabled() and not is_bf16() and torch.is_grad_enabled() and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and len(pd.lateral_convs) == 1):
+        return False
+    lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
+    gn1 = getattr(lat, lat.norm_name, None) if lat.norm_name else None
+    gn2 = getattr(outc, outc.norm_name, None) if outc.norm_name else None
+    B, Cin, H, W = x.shape
+    C = lat.conv.out_channels
+    ok = (isinstance(gn1, nn.GroupNorm) and isinstance(gn2, nn.GroupNorm) and gn1.num_groups * 8 == C == gn2.num_channels
+          and gn1.num_groups == gn2.num_groups and 256 % gn1.num_groups == 0 and lat.activate is None and isinstance(outc.activate, nn.ReLU)
+          and lat.conv.bias is None and outc.conv.bias is None and tuple(lat.conv.kernel_size) == (1, 1) and tuple(mf.kernel_size) == (1, 1)
+          and lat.conv.groups == 1 and mf.groups == 1 and tuple(lat.conv.stride) == (1, 1) and tuple(mf.stride) == (1, 1)
+          and x3_train_conv3x3_ok(outc.conv, x.new_empty((B, C, H, W)))
+          and Cin % 32 == 0 and C % 32 == 0 and mf.out_channels % 32 == 0 and B * H * W >= X3_TRAIN_ROWS
+          and B * H * W * max(Cin, C, mf.out_channels) * 4 < _X3_MAX_BYTES and lo_hw[0] > 0 and lo_hw[1] > 0)
+    return bool(ok)
+
+
+def fpn_level_x3_train(pd, x, lo_rows, lo_hw):
+    """mask_feature (B, C_out, H, W) of the pixel decoder from the stride-4 backbone map x (B, Cin, H, W) and the finest encoder memory
+    level lo_rows (B, h w, C) -- see `x3_fpn_level_ok`."""
+    lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
+    gn1, gn2 = getattr(lat, lat.norm_name), getattr(outc, outc.norm_name)
+    B, Cin, H, W = x.shape
+    xr = _NchwToRowsFn.apply(x)
+    cur = _X3LinearFn.apply(xr, lat.conv.weight.flatten(1), None)
+    y = _X3FpnLevelFn.apply(cur, lo_rows, gn1.weight, gn1.bias, outc.conv.weight, gn2.weight, gn2.bias, gn1.num_groups, gn1.eps, gn2.eps,
+                            (H, W), tuple(lo_hw))
+    m = _X3LinearFn.apply(y, mf.weight.flatten(1), mf.bias)
+    return _RowsToNchwFn.apply(m, (H, W))
+
+
 def x3_train_conv3x3_ok(conv, x):
     """parity mode under autograd, a 3x3 / s1 / p1 / ungrouped / bias-free convolution whose channel counts the x3 kernels tile,
     large enough to be worth the layout changes."""

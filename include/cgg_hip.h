@@ -515,6 +515,22 @@ int cgg_bias_relu_maxpool_nhwc_f32_x3a(const float* x, const float* bias, void* 
 int cgg_group_norm_nhwc_f32_x3a(const float* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C, int groups,
                                 float eps, int relu, const void* up_src_x3a, int up_h, int up_w, int64_t up_bstride, int W,
                                 void* y_x3a, int64_t y_bstride, const float* pos, void* yp_x3a, cgg_stream_t stream);
+
+/* Backward of cgg_group_norm_nhwc_f32 (training, parity mode: the pixel decoder's finest FPN level kept channel-last; replaces
+ * autograd's native_group_norm_backward + threshold_backward + upsample_bilinear2d_backward on NCHW copies behind the [3P]
+ * MSDeformAttnPixelDecoder lateral / output ConvModules): x, dy (and y = the forward's output when relu) (B, HW, C) f32 channel-last,
+ * stats = the forward workspace's head (B, groups, 2) = (mean, variance), ws >= cgg_group_norm_nhwc_backward_workspace_bytes.
+ * -> dx (B, HW, C); tot (B, groups, 16): per-image pieces of (dgamma | dbeta) (dgamma[8 g + k] = sum_b tot[b][g][k], dbeta[8 g + k] =
+ * sum_b tot[b][g][8 + k]); dlo (nullable, only without relu): gradient of the (B, lo_h, lo_w, C) map the forward up-sampled and added. */
+int64_t cgg_group_norm_nhwc_backward_workspace_bytes(int B, int HW, int groups);
+int cgg_group_norm_nhwc_f32_backward(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, void* ws,
+                                     int B, int HW, int C, int groups, float eps, int relu, float* dx, float* tot, float* dlo, int lo_h,
+                                     int lo_w, int W, int dx_padded, cgg_stream_t stream);
+/* cgg_group_norm_nhwc_f32 with y written into the interior of a (B, H + 2, W + 2, C) channel-last map whose one-pixel border the caller
+ * zeroed (W = map width); dx_padded above is the same layout for the backward's dx: the padded maps of the x3 training convolution. */
+int cgg_group_norm_nhwc_f32_padout(const float* x, const float* gamma, const float* beta, void* ws, int B, int HW, int C, int groups,
+                                   float eps, int relu, const float* up_src, int up_h, int up_w, int64_t up_bstride, int W,
+                                   float* y_padded, cgg_stream_t stream);
 int cgg_encoder_layer_tail_x3a(const float* a32, const void* x_x3a, const void* wo_x3, const float* bo, const float* gamma0,
                                const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
                                const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,

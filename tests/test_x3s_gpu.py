@@ -480,3 +480,85 @@ def test_nchw_to_nhwc_pad1_is_the_padded_permutation(dev, B, C, H, W):
     got = ops.nchw_to_nhwc_pad1(x)
     want = F.pad(x.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu,up', [(True, False), (False, True), (False, False)])
+def test_group_norm_rows_forward_backward_vs_float64(dev, relu, up):
+    """Channel-last f32 GroupNorm for training (`ops.GroupNormRowsFn`: forward with the fused ReLU / bilinear up-sample + add,
+    backward `cgg_group_norm_nhwc_f32_backward` incl. the up-sample's transpose) against torch in float64 on NCHW copies."""
+    B, C, H, W, G = 3, 64, 24, 20, 8
+    g = torch.Generator().manual_seed(17 + relu + 2 * up)
+    x = (torch.randn(B, H * W, C, generator=g) * 2 + 0.5).to(dev).requires_grad_()
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev).requires_grad_()
+    beta = torch.randn(C, generator=g).to(dev).requires_grad_()
+    lo = torch.randn(B, (H // 2) * (W // 2), C, generator=g).to(dev).requires_grad_() if up else None
+    gy = torch.randn(B, H * W, C, generator=g).to(dev)
+    y = ops.GroupNormRowsFn.apply(x, gamma, beta, G, 1e-5, relu, lo, (H, W), (H // 2, W // 2))
+    y.backward(gy)
+    xd = x.detach().double().view(B, H, W, C).permute(0, 3, 1, 2).requires_grad_()
+    gd, bd = gamma.detach().double().requires_grad_(), beta.detach().double().requires_grad_()
+    ref = F.group_norm(xd, G, gd, bd, 1e-5)
+    if up:
+        lod = lo.detach().double().view(B, H // 2, W // 2, C).permute(0, 3, 1, 2).requires_grad_()
+        ref = ref + F.interpolate(lod, size=(H, W), mode='bilinear', align_corners=False)
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(gy.double().view(B, H, W, C).permute(0, 3, 1, 2))
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B, -1, C)      # noqa: E731
+    assert (y.double() - rows(ref)).abs().max().item() <= 1e-5
+    for got, want in [(x.grad, rows(xd.grad)), (gamma.grad, gd.grad), (beta.grad, bd.grad)] + ([(lo.grad, rows(lod.grad))] if up else []):
+        assert (got.double() - want).abs().max().item() <= 2e-5 * (want.abs().max().item() + 1e-9), (relu, up)
+
+
+@pytest.mark.gpu
+def test_fpn_level_rows_path_vs_float64(dev):
+    """PARITY-mode training of the pixel decoder's FPN level on channel-last rows (`runtime.fpn_level_x3_train`: x3 row GEMMs for the
+    lateral / mask-feature 1 x 1 convolutions, `_X3FpnLevelFn` for GroupNorm + up-sample + 3 x 3 convolution + GroupNorm + ReLU)
+    against the same composite in float64 torch ops (F.conv2d / group_norm / interpolate on NCHW): mask_feature and every gradient
+    (the level's parameters, the backbone map, the coarser level) at a 1e-5-scale upstream gradient."""
+    from cgg_amd import runtime, synthetic
+    from cgg_amd.pixel_decoder import MSDeformAttnPixelDecoder
+    cfg = dict(synthetic.model_config(num_things=8, num_stuff=0, num_unknown=0, num_queries=10, enc_layers=1)['panoptic_head']['pixel_decoder'])
+    cfg.pop('type')
+    torch.manual_seed(5)
+    pd = MSDeformAttnPixelDecoder(in_channels=[32, 64, 96, 128], strides=[4, 8, 16, 32], feat_channels=256, out_channels=256, **cfg)
+    pd.init_weights()
+    pd = pd.to(dev).train()
+    B, H, W = 6, 96, 128                           # (B H W >= 65 536: the x3 convolution's size rule)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, 32, H, W, generator=g).to(dev).requires_grad_()
+    lo = torch.randn(B, (H // 2) * (W // 2), 256, generator=g).to(dev).requires_grad_()
+    gm = (torch.randn(B, 256, H, W, generator=g) * 1e-5).to(dev)
+    lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
+    params = dict(lat_w=lat.conv.weight, gn1_w=lat.gn.weight, gn1_b=lat.gn.bias, conv_w=outc.conv.weight, gn2_w=outc.gn.weight,
+                  gn2_b=outc.gn.bias, mf_w=mf.weight, mf_b=mf.bias)
+    with runtime.precision_scope('fp32'):
+        assert runtime.x3_fpn_level_ok(pd, x, (H // 2, W // 2))
+        got = runtime.fpn_level_x3_train(pd, x, lo, (H // 2, W // 2))
+    (got * gm).sum().backward()
+    grads = {k: v.grad.detach().double() for k, v in params.items()}
+    grads['x'], grads['lo'] = x.grad.double(), lo.grad.double()
+
+    def composite(dt):
+        d = {k: v.detach().to(dt).requires_grad_() for k, v in params.items()}
+        xd, lod = x.detach().to(dt).requires_grad_(), lo.detach().to(dt).requires_grad_()
+        t = F.group_norm(F.conv2d(xd, d['lat_w']), 32, d['gn1_w'], d['gn1_b'], lat.gn.eps)
+        t = t + F.interpolate(lod.view(B, H // 2, W // 2, 256).permute(0, 3, 1, 2), size=(H, W), mode='bilinear', align_corners=False)
+        t = torch.relu(F.group_norm(F.conv2d(t, d['conv_w'], padding=1), 32, d['gn2_w'], d['gn2_b'], outc.gn.eps))
+        out = F.conv2d(t, d['mf_w'], d['mf_b'])
+        (out * gm.to(dt)).sum().backward()
+        gr = {k: v.grad.double() for k, v in d.items()}
+        gr['x'], gr['lo'] = xd.grad.double(), lod.grad.double()
+        return out.detach().double(), gr
+
+    ref, want = composite(torch.float64)
+    _, lib32 = composite(torch.float32)                    # the same composite on torch's f32 library kernels: the yardstick
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    for k in want:
+        scale = want[k].abs().max().item()
+        err = (grads[k] - want[k]).abs().max().item()
+        err32 = (lib32[k] - want[k]).abs().max().item()
+        # gradients through two GroupNorms are cancelling sums over 73 728 pixels: f32 library kernels are 1e-4 .. 1e-3 of scale from
+        # float64 on the weights; the channel-last path must be no worse than twice that (or 3e-5)
+        assert scale > 0 and err <= max(3e-5 * scale, 2.0 * err32), (k, err, err32, scale)
