@@ -609,7 +609,15 @@ def fpn_level_x3_train(pd, x, lo_rows, lo_hw):
     y = _X3FpnLevelFn.apply(cur, lo_rows, gn1.weight, gn1.bias, outc.conv.weight, gn2.weight, gn2.bias, gn1.num_groups, gn1.eps, gn2.eps,
                             (H, W), tuple(lo_hw))
     m = _X3LinearFn.apply(y, mf.weight.flatten(1), mf.bias)
-    return _RowsToNchwFn.apply(m, (H, W))
+    out = _RowsToNchwFn.apply(m, (H, W))
+    # the channel-last form the map was computed in, for consumers that sample it channel-last (the head's loss points): saves them a
+    # 1-GB strided copy back
+    out._cgg_nhwc = m.detach().view(B, H, W, m.shape[-1])
+    return out
+
+
+X3_CONV_ROWS = 65536      # output pixels from which a 3 x 3 training convolution takes the x3 node (16 384 -- the trainable ResNet stage's
+                          # 512-channel convolutions at 32^2 -- measured the same as MIOpen: 212.4 vs 212.1 ms per configs[2] step)
 
 
 def x3_train_conv3x3_ok(conv, x):
@@ -618,7 +626,7 @@ def x3_train_conv3x3_ok(conv, x):
     return (_X3_TRAIN and _X3A and x3_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 32 == 0
-            and conv.out_channels % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 65536 and x.shape[2] >= 4 and x.shape[3] >= 4
+            and conv.out_channels % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= X3_CONV_ROWS and x.shape[2] >= 4 and x.shape[3] >= 4
             # the kernels address their operands through 32-bit buffer descriptors: the zero-padded maps of the weight-gradient
             # contraction are the largest operand (from B = 64 at 256^2 x 256 the call raised instead of running on MIOpen)
             and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * max(conv.in_channels, conv.out_channels) * 4 < _X3_MAX_BYTES)
