@@ -480,6 +480,7 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         return gx, gw
 
 
+_X3_FPN_ROWS_BF16 = _os.environ.get('CGG_X3_FPN_ROWS_BF16', '1') != '0'      # ... also in throughput (bf16) mode: 170.4 -> 166.0 ms per configs[2] step
 _X3_FPN_ROWS = _os.environ.get('CGG_X3_FPN_ROWS', '1') != '0'      # parity-mode training: the finest FPN level channel-last on own kernels (A/B)
 
 
@@ -580,8 +581,9 @@ def x3_fpn_level_ok(pd, x, lo_hw):
     """PARITY-mode training of the pixel decoder's single FPN level (lateral 1 x 1 + GN, + up-sample, 3 x 3 + GN + ReLU, mask-feature
     1 x 1) on channel-last rows and own kernels: `_X3FpnLevelFn` + `_X3LinearFn`s."""
     import torch.nn as nn
-    if not (_X3_FPN_ROWS and _X3_TRAIN and _X3A and _X3_WGRAD and x3_enabled() and not is_bf16() and torch.is_grad_enabled() and x.is_cuda
-            and x.dtype == torch.float32 and x.dim() == 4 and len(pd.lateral_convs) == 1):
+    bf = is_bf16() and _X3 and _X3_FPN_ROWS_BF16      # throughput mode may take the (more accurate) f32-class level too
+    if not (_X3_FPN_ROWS and _X3_TRAIN and _X3A and _X3_WGRAD and (x3_enabled() or bf) and torch.is_grad_enabled() and x.is_cuda
+            and x.dtype in ((torch.float32, torch.bfloat16) if bf else (torch.float32,)) and x.dim() == 4 and len(pd.lateral_convs) == 1):
         return False
     lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
     gn1 = getattr(lat, lat.norm_name, None) if lat.norm_name else None
@@ -592,7 +594,7 @@ def x3_fpn_level_ok(pd, x, lo_hw):
           and gn1.num_groups == gn2.num_groups and 256 % gn1.num_groups == 0 and lat.activate is None and isinstance(outc.activate, nn.ReLU)
           and lat.conv.bias is None and outc.conv.bias is None and tuple(lat.conv.kernel_size) == (1, 1) and tuple(mf.kernel_size) == (1, 1)
           and lat.conv.groups == 1 and mf.groups == 1 and tuple(lat.conv.stride) == (1, 1) and tuple(mf.stride) == (1, 1)
-          and x3_train_conv3x3_ok(outc.conv, x.new_empty((B, C, H, W)))
+          and (bf or x3_train_conv3x3_ok(outc.conv, x.new_empty((B, C, H, W))))
           and Cin % 32 == 0 and C % 32 == 0 and mf.out_channels % 32 == 0 and B * H * W >= X3_TRAIN_ROWS
           and B * H * W * max(Cin, C, mf.out_channels) * 4 < _X3_MAX_BYTES and lo_hw[0] > 0 and lo_hw[1] > 0)
     return bool(ok)
@@ -604,9 +606,9 @@ def fpn_level_x3_train(pd, x, lo_rows, lo_hw):
     lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
     gn1, gn2 = getattr(lat, lat.norm_name), getattr(outc, outc.norm_name)
     B, Cin, H, W = x.shape
-    xr = _NchwToRowsFn.apply(x)
+    xr = _NchwToRowsFn.apply(x.float())
     cur = _X3LinearFn.apply(xr, lat.conv.weight.flatten(1), None)
-    y = _X3FpnLevelFn.apply(cur, lo_rows, gn1.weight, gn1.bias, outc.conv.weight, gn2.weight, gn2.bias, gn1.num_groups, gn1.eps, gn2.eps,
+    y = _X3FpnLevelFn.apply(cur, lo_rows.float(), gn1.weight, gn1.bias, outc.conv.weight, gn2.weight, gn2.bias, gn1.num_groups, gn1.eps, gn2.eps,
                             (H, W), tuple(lo_hw))
     m = _X3LinearFn.apply(y, mf.weight.flatten(1), mf.bias)
     out = _RowsToNchwFn.apply(m, (H, W))
