@@ -73,14 +73,14 @@ _PINNED, _COPY_STREAMS = {}, {}
 
 
 def _pinned_like(t):
-    """Pinned host buffer of t's shape / dtype, reused across steps (allocating pinned memory synchronises the device)."""
-    k = (tuple(t.shape), t.dtype)
-    b = _PINNED.get(k)
-    if b is None:
-        if len(_PINNED) > 16:
-            _PINNED.clear()
-        b = _PINNED[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    return b
+    """Pinned host view of t's shape / dtype on ONE growing buffer per dtype, reused across steps (the number of ground-truth
+    instances changes every step; allocating pinned memory synchronises the device)."""
+    n = t.numel()
+    b = _PINNED.get(t.dtype)
+    if b is None or b.numel() < n:
+        cap = 1 << max(int(n - 1).bit_length(), 10)
+        b = _PINNED[t.dtype] = torch.empty(cap, dtype=t.dtype, pin_memory=True)
+    return b[:n].view(t.shape)
 
 
 def _copy_stream(dev):
