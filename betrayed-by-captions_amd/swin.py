@@ -33,9 +33,9 @@ class WindowMSA(nn.Module):
         idx = _double_step_seq(2 * Ww - 1, Wh, 1, Ww)
         idx = (idx + idx.T).flip(1).contiguous()
         self.register_buffer('relative_position_index', idx)
-        self.qkv = nn.Linear(embed_dims, embed_dims * 3, bias=qkv_bias)
+        self.qkv = runtime.ParityLinear(embed_dims, embed_dims * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop_rate)
-        self.proj = nn.Linear(embed_dims, embed_dims)
+        self.proj = runtime.ParityLinear(embed_dims, embed_dims)
         self.proj_drop = nn.Dropout(proj_drop_rate)
 
     def forward(self, x, mask=None):
@@ -119,9 +119,9 @@ class _SwinFFN(nn.Module):
 
     def __init__(self, embed_dims, feedforward_channels, drop_rate=0., drop_path_rate=0.):
         super().__init__()
-        self.layers = nn.Sequential(nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.GELU(),
+        self.layers = nn.Sequential(nn.Sequential(runtime.ParityLinear(embed_dims, feedforward_channels), nn.GELU(),
                                                   nn.Dropout(drop_rate)),
-                                    nn.Linear(feedforward_channels, embed_dims), nn.Dropout(drop_rate))
+                                    runtime.ParityLinear(feedforward_channels, embed_dims), nn.Dropout(drop_rate))
         self.drop_path_rate = drop_path_rate
 
     def forward(self, x, identity):
@@ -155,7 +155,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.sampler = nn.Unfold(kernel_size=2, stride=2)
         self.norm = nn.LayerNorm(4 * in_channels)
-        self.reduction = nn.Linear(4 * in_channels, out_channels, bias=False)
+        self.reduction = runtime.ParityLinear(4 * in_channels, out_channels, bias=False)
 
     def forward(self, x, input_size):
         B, L, C = x.shape
