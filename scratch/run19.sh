@@ -1,6 +1,6 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_fullsize_gpu.py -x -q -m gpu -k "configs3" 2>&1 | tail -2
-for p in fp32 bf16; do python bench.py --workload cfg3 --steps 5 --warmup 3 --precision $p 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3 $p', d['value'], d['ms_per_step'], d['loss'])"; done
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf /tmp/tp3
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tp3 -- python3 $R/bench.py --workload cfg3 --steps 4 --warmup 2 --precision fp32 > /dev/null 2>&1
+python3 $R/scratch/step_kernels2.py /tmp/tp3 NormTwoOps 3 auto:7 2>&1 | head -40 | cut -c1-170
