@@ -1033,10 +1033,10 @@ class Mask2FormerHeadOpen(nn.Module):
             if costs and overlap is not None and costs[0].is_cuda:
                 flat_dev = torch.cat(costs)
                 flat = _pinned_like(flat_dev)
-                cur, side = torch.cuda.current_stream(dev), _copy_stream(dev)
-                side.wait_stream(cur)
                 lab_dev = torch.cat([g.reshape(-1) for g in gt_labels_list]).to(torch.int64)
                 lab_host = _pinned_like(lab_dev)          # (a `.cpu()` per image after `overlap` would wait for the work it enqueued)
+                cur, side = torch.cuda.current_stream(dev), _copy_stream(dev)
+                side.wait_stream(cur)                     # AFTER both sources are enqueued on the caller's stream
                 with torch.cuda.stream(side):
                     flat.copy_(flat_dev, non_blocking=True)
                     lab_host.copy_(lab_dev, non_blocking=True)
