@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void cgg_add_layernorm_bwd_kernel(const float*
   if (dx_amax) {
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sft, 64));
-    if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dx_amax), __float_as_uint(lmax));
+    if (lane == 0 && __float_as_uint(lmax) > __hip_atomic_load(reinterpret_cast<unsigned int*>(dx_amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned int*>(dx_amax), __float_as_uint(lmax));      // (only when it can raise the running maximum)
   }
   // column sums: the 4 row groups of a wavefront (lanes sub, sub + 16, + 32, + 48), then the 4 wavefronts through LDS
 #pragma unroll

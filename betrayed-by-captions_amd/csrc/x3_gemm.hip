@@ -346,7 +346,9 @@ __global__ __launch_bounds__(XG_NT, (TM + TN == 4) ? 2 : (TM + TN == 3) ? 3 : 4)
   if (out_amax) {
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sft, 64));
-    if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out_amax), __float_as_uint(lmax));
+    // (only when it can raise the running maximum: 21 504 wavefront atomics on one address serialise)
+    if (lane == 0 && __float_as_uint(lmax) > __hip_atomic_load(reinterpret_cast<unsigned int*>(out_amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned int*>(out_amax), __float_as_uint(lmax));
   }
 }
 
