@@ -151,6 +151,7 @@ PROTOTYPES = {
     'cgg_linear_sum_assignment_f32': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     'cgg_point_sample_planes': (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
     'cgg_point_sample_planes_backward': (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
+    'cgg_point_sample_planes_backward_rows': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     'cgg_point_sample_nhwc': (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     'cgg_subsample_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_bias_relu_maxpool_nhwc': (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),

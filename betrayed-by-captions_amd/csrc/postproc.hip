@@ -950,6 +950,63 @@ extern "C" int cgg_point_sample_planes_backward(const float* grad_out, const int
   return CGG_OK;
 }
 
+// ... the same gradient WITHOUT global atomics for the case every row has its own plane (index == NULL: the loss' mask planes of the
+// positives): a workgroup owns a band of `band` rows of ONE plane in LDS, scans the row's P points, adds the taps that fall into its
+// band with LDS float atomics and writes the band out once, coalesced -- every element of grad_planes is written, no zero-fill. The
+// atomic form above ran at 21 G atomics/s (436 us for 184 planes x 12 544 points at configs[2], 10 calls per training step).
+__global__ __launch_bounds__(256) void cgg_point_sample_planes_bwd_tiled_kernel(const float* __restrict__ gout, const float* __restrict__ pts,
+                                                                               float* __restrict__ gplanes, int H, int W, int P, int band) {
+  extern __shared__ float tile[];                     // band x W
+  const int j = blockIdx.y;
+  const int r0 = blockIdx.x * band, r1 = min(H, r0 + band);
+  const int n = (r1 - r0) * W;
+  for (int i = threadIdx.x; i < n; i += 256) tile[i] = 0.f;
+  __syncthreads();
+  const float* pj = pts + (size_t)j * P * 2;
+  const float* gj = gout + (size_t)j * P;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float2 xy = *reinterpret_cast<const float2*>(pj + 2 * p);
+    const float gx = __fsub_rn(__fmul_rn(xy.x, 2.0f), 1.0f), gy = __fsub_rn(__fmul_rn(xy.y, 2.0f), 1.0f);
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 2.f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 2.f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    if (y0 + 1 < r0 || y0 >= r1) continue;            // neither tap row in this band
+    const float tx = __fsub_rn(ix, fx), ty = __fsub_rn(iy, fy);
+    const float ux = __fsub_rn(__fadd_rn(fx, 1.f), ix), uy = __fsub_rn(__fadd_rn(fy, 1.f), iy);
+    const float g = gj[p];
+    const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool yin0 = y0 >= r0 && y0 < r1, yin1 = y0 + 1 >= r0 && y0 + 1 < r1;
+    float* t0 = tile + (y0 - r0) * W + x0;
+    if (xin0 && yin0) atomicAdd(t0, __fmul_rn(__fmul_rn(ux, uy), g));
+    if (xin1 && yin0) atomicAdd(t0 + 1, __fmul_rn(__fmul_rn(tx, uy), g));
+    if (xin0 && yin1) atomicAdd(t0 + W, __fmul_rn(__fmul_rn(ux, ty), g));
+    if (xin1 && yin1) atomicAdd(t0 + W + 1, __fmul_rn(__fmul_rn(tx, ty), g));
+  }
+  __syncthreads();
+  float* o = gplanes + ((size_t)j * H + r0) * W;
+  if (n % 4 == 0 && ((uintptr_t)o & 15) == 0) {
+    for (int i = threadIdx.x; i < n / 4; i += 256) reinterpret_cast<f32x4*>(o)[i] = reinterpret_cast<const f32x4*>(tile)[i];
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) o[i] = tile[i];
+  }
+}
+
+// grad_planes (rows, H, W) is OVERWRITTEN (no zero-fill needed): row j's gradient goes to plane j.
+extern "C" int cgg_point_sample_planes_backward_rows(const float* grad_out, const float* pts, float* grad_planes, int H, int W, int rows,
+                                                     int P, cgg_stream_t stream) {
+  CGG_REQUIRE(grad_out && pts && grad_planes, CGG_EINVAL, "cgg_point_sample_planes_backward_rows: null pointer");
+  CGG_REQUIRE(H > 0 && W > 0 && rows > 0 && P > 0 && W <= 16384 && rows <= 65535, CGG_EINVAL, "cgg_point_sample_planes_backward_rows: bad sizes");
+  CGG_REQUIRE(((uintptr_t)pts & 7) == 0, CGG_EALIGN, "cgg_point_sample_planes_backward_rows: points must be 8-byte aligned");
+  int band = 16384 / W;                               // 64 KiB of LDS per workgroup (two per CU)
+  band = band < 1 ? 1 : (band > H ? H : band);
+  const int nbands = (H + band - 1) / band;
+  hipLaunchKernelGGL(cgg_point_sample_planes_bwd_tiled_kernel, dim3(nbands, rows), dim3(256), (size_t)band * W * sizeof(float),
+                     (hipStream_t)stream, grad_out, pts, grad_planes, H, W, P, band);
+  CGG_CHECK_LAUNCH("cgg_point_sample_planes_backward_rows");
+  return CGG_OK;
+}
+
 extern "C" int cgg_point_sample_nhwc(const float* feat, const float* pts, float* out, int B, int H, int W, int C, int P,
                                      cgg_stream_t stream) {
   CGG_REQUIRE(feat && pts && out, CGG_EINVAL, "cgg_point_sample_nhwc: null pointer");

@@ -2101,6 +2101,14 @@ class _PointSampleRowsFn(torch.autograd.Function):
     def backward(ctx, gout):
         (points,) = ctx.saved_tensors
         rows, H, W = ctx.shape
+        if rows and rows <= 65535 and W <= 16384:
+            # every row has its own plane: band-stationary LDS accumulation, planes written once (no zero-fill, no global atomics)
+            gp = torch.empty((rows, H, W), dtype=torch.float32, device=gout.device)
+            check(_lib_().cgg_point_sample_planes_backward_rows(dev_ptr(gout.contiguous().float(), 'grad', torch.float32),
+                                                                dev_ptr(points, 'points', torch.float32), dev_ptr(gp), H, W, rows,
+                                                                points.shape[1], stream_ptr(gout.device)),
+                  'cgg_point_sample_planes_backward_rows')
+            return gp, None
         gp = torch.zeros((rows, H, W), dtype=torch.float32, device=gout.device)
         if rows:
             check(_lib_().cgg_point_sample_planes_backward(dev_ptr(gout.contiguous().float(), 'grad', torch.float32), None,

@@ -738,6 +738,10 @@ int cgg_point_sample_planes(const float* planes, const int32_t* index, const flo
  * F.grid_sample's backward (which also computes the unused grid gradient) at open_set/models/mask2former_head.py:609-620. */
 int cgg_point_sample_planes_backward(const float* grad_out, const int32_t* index, const float* pts, float* grad_planes, int N,
                                      int H, int W, int rows, int P, cgg_stream_t stream);
+/* ... for rows that each have their OWN plane (the loss' mask planes of the positives): grad_planes (rows, H, W) is overwritten -- no
+ * zero-fill, no global atomics (a workgroup accumulates a band of one plane in LDS and writes it once). */
+int cgg_point_sample_planes_backward_rows(const float* grad_out, const float* pts, float* grad_planes, int H, int W, int rows, int P,
+                                          cgg_stream_t stream);
 
 /* Stem convolution of the BN-folded [3P] mmdet ResNet (conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) straight from
  * the f32 NCHW image: out[B, Ho, Wo, 64] bf16 channel-last = RAW convolution (no bias; bf16 operands, f32 accumulation),

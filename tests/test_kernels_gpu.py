@@ -1552,12 +1552,13 @@ def test_msda_rows_function_matches_unfused_autograd(dev):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
 
 
-def test_point_sample_rows_forward_backward_vs_grid_sample(dev):
+@pytest.mark.parametrize('rows,H,W,P', [(37, 64, 96, 500), (5, 256, 256, 3000), (3, 50, 1000, 700)])
+def test_point_sample_rows_forward_backward_vs_grid_sample(dev, rows, H, W, P):
     """Single-channel point sampling with the scatter backward == F.grid_sample (bilinear, zeros, align_corners=False) and
     its autograd on the same points, incl. points outside [0, 1] (zero padding): forward 1e-6, gradient 1e-5 (atomic order)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(17)
-    rows, H, W, P = 37, 64, 96, 500
+    # (backward: a workgroup per band of 16 384 / W plane rows in LDS -- one band, four bands, 16-row bands of a wide map)
     planes = torch.randn(rows, H, W, generator=g).to(dev).requires_grad_(True)
     pts = (torch.rand(rows, P, 2, generator=g) * 1.2 - 0.1).to(dev)
     gout = torch.randn(rows, P, generator=g).to(dev)
