@@ -23,6 +23,20 @@ __device__ __forceinline__ int xa_kswz(int key, int slot) { return slot ^ ((key 
 // partial pass: one workgroup = (key chunk, head, batch); wave w owns queries [32w, 32w+32).
 // ws_o  [B, H, nchunks, Q, D]  un-normalised O;  ws_ml [B, H, nchunks, Q, 2]  (m, l)
 // -------------------------------------------------------------------------------------------------
+// BF (throughput-mode TRAINING): the same kernel with bf16 MFMA operands -- every group of four v_mfma_f32_32x32x2_f32 steps (a lane's
+// four consecutive k values) becomes ONE v_mfma_f32_32x32x8_bf16 on the converted 4-vectors; accumulators, layouts, softmax and
+// the f32 K / V rows in memory are unchanged. 1/8 of the MFMA time: the f32 pipe was this kernel's bound (0.4 of its 157-TF peak).
+typedef __attribute__((ext_vector_type(4))) short xa_s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 xa_bf2;
+typedef __attribute__((ext_vector_type(2))) float xa_f2;
+__device__ __forceinline__ xa_s16x4 xa_cvt4(float a, float b, float c, float d) {
+  const xa_f2 lo = {a, b}, hi = {c, d};
+  const uint2 u = {__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, xa_bf2)),
+                   __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, xa_bf2))};
+  return __builtin_bit_cast(xa_s16x4, u);
+}
+
+template <bool BF>
 __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
     const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
     float* __restrict__ ws_o, float* __restrict__ ws_ml, int Q, int H, int S, int words, int KC,
@@ -116,9 +130,14 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
       for (int s4 = 0; s4 < 4; ++s4) {
         const f32x4 ka =
             *reinterpret_cast<const f32x4*>(Ks + krow * D + xa_kswz(krow, hi * 4 + s4) * 4);
+        if constexpr (BF) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(xa_cvt4(ka[0], ka[1], ka[2], ka[3]),
+                                                        xa_cvt4(qf[4 * s4], qf[4 * s4 + 1], qf[4 * s4 + 2], qf[4 * s4 + 3]), sc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          sc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[4 * s4 + e], sc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e)
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[4 * s4 + e], sc, 0, 0, 0);
+        }
       }
       // ---- mask + online softmax (lane = query j; 16 keys in-register, partner lane^32 has the rest)
       const uint32_t mw = Ms[qi * cws + ((s0 - s_begin + kt) >> 5)];
@@ -146,11 +165,20 @@ __global__ __launch_bounds__(256) void cgg_xattn_partial_f32(
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] *= alpha;
       // ---- O^T[d][query] += V^T[d][key] P^T[key][query] : 16 x v_mfma_f32_32x32x2_f32 ----
+      if constexpr (BF) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ki = kt + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float va = Vs[ki * D + j];
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(va, sc[r], o, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          const int k0 = kt + 8 * g + 4 * hi;            // the lane's four keys of k-step g: the rows its accumulators 4 g .. 4 g + 3 hold
+          o = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(xa_cvt4(Vs[k0 * D + j], Vs[(k0 + 1) * D + j], Vs[(k0 + 2) * D + j], Vs[(k0 + 3) * D + j]),
+                                                       xa_cvt4(sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]), o, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ki = kt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float va = Vs[ki * D + j];
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(va, sc[r], o, 0, 0, 0);
+        }
       }
     }
   }
@@ -607,9 +635,10 @@ static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bit
   CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_forward: bad sizes");
   CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward: head dim %d (only 32 is built)", D);
   CGG_REQUIRE(Q <= 128, CGG_EUNSUPPORTED, "cgg_masked_xattn_forward: Q=%d > 128", Q);
-  CGG_REQUIRE(kv_dtype == CGG_F32, CGG_EUNSUPPORTED,
+  CGG_REQUIRE(kv_dtype == CGG_F32 || kv_dtype == CGG_F32_BF16MFMA, CGG_EUNSUPPORTED,
               "cgg_masked_xattn_forward: kv dtype %d (f32 here; bf16 via cgg_masked_xattn_forward_bf16)",
               kv_dtype);
+  const bool bfm = kv_dtype == CGG_F32_BF16MFMA && !x3;      // f32 rows in memory, bf16 MFMA operands (throughput-mode training)
   CGG_REQUIRE(cgg_aligned16(q) && cgg_aligned16(kv) && cgg_aligned16(ws), CGG_EALIGN,
               "cgg_masked_xattn_forward: q / kv / ws must be 16-B aligned");
   int KC, nch;
@@ -623,8 +652,11 @@ static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bit
   if (x3)
     cgg_xattn_partial_x3_launch(nch, H, B, (size_t)nmt * 32 * (KC / 32 + 1) * 4, s, q, (const float*)kv, bits, ws_o, ws_ml, Q, S, words, KC,
                                 scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
+  else if (bfm)
+    hipLaunchKernelGGL(cgg_xattn_partial_f32<true>, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
+                       bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
   else
-    hipLaunchKernelGGL(cgg_xattn_partial_f32, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
+    hipLaunchKernelGGL(cgg_xattn_partial_f32<false>, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
                        bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
   if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, x3 ? 1 : 0, x3 ? nullptr : lse);

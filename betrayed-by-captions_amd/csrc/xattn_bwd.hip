@@ -24,6 +24,20 @@
 
 __device__ __forceinline__ int xb_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// BF (throughput-mode training, kv_dtype CGG_F32_BF16MFMA): every group of four 32x32x2 f32 steps -- a lane's four consecutive k
+// values, which is also how the accumulator rows are grouped (xb_row(4 g + e, hi) = 8 g + 4 hi + e) -- becomes one
+// v_mfma_f32_32x32x8_bf16 on the converted 4-vectors; 80 -> 20 MFMAs per (32 queries x 32 keys) at 8 x the rate, layouts unchanged.
+typedef __attribute__((ext_vector_type(4))) short xb_s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 xb_bf2;
+typedef __attribute__((ext_vector_type(2))) float xb_f2;
+__device__ __forceinline__ xb_s16x4 xb_cvt4(float a, float b, float c, float d) {
+  const xb_f2 lo = {a, b}, hi = {c, d};
+  const uint2 u = {__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, xb_bf2)),
+                   __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, xb_bf2))};
+  return __builtin_bit_cast(xb_s16x4, u);
+}
+
+template <bool BF>
 __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ kv, const uint32_t* __restrict__ bits,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ gout,
@@ -138,10 +152,17 @@ __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
       for (int t = 0; t < 4; ++t) {
         const f32x4 qa = *reinterpret_cast<const f32x4*>(qrow + 4 * t);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(grow + 4 * t);
+        if constexpr (BF) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(xb_cvt4(qa[0], qa[1], qa[2], qa[3]),
+                                                        xb_cvt4(kf[4 * t], kf[4 * t + 1], kf[4 * t + 2], kf[4 * t + 3]), sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(xb_cvt4(ga[0], ga[1], ga[2], ga[3]),
+                                                        xb_cvt4(vf[4 * t], vf[4 * t + 1], vf[4 * t + 2], vf[4 * t + 3]), dp, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[4 * t + e], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[4 * t + e], dp, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[4 * t + e], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[4 * t + e], dp, 0, 0, 0);
+          }
         }
       }
       // ---- P and dS for (query xb_row(r, hi), this lane's key) ----
@@ -155,11 +176,24 @@ __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
         dp[r] = p * (dp[r] - Ds[qq]);                // dS
       }
       // ---- dV^T[d][key] += dO^T[d][query] P[query][key],  dK^T[d][key] += (scale Q)^T[d][query] dS[query][key] ----
+      if constexpr (BF) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qq = qt * 32 + xb_row(r, hi);
-        dvt = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[qq * XB_LD + j], sc[r], dvt, 0, 0, 0);
-        dkt = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qq * XB_LD + j], dp[r], dkt, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          const int q0 = qt * 32 + 8 * g + 4 * hi;       // the lane's four queries of k-step g = xb_row(4 g + e, hi)
+          dvt = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(
+              xb_cvt4(Gs[q0 * XB_LD + j], Gs[(q0 + 1) * XB_LD + j], Gs[(q0 + 2) * XB_LD + j], Gs[(q0 + 3) * XB_LD + j]),
+              xb_cvt4(sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]), dvt, 0, 0, 0);
+          dkt = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(
+              xb_cvt4(Qs[q0 * XB_LD + j], Qs[(q0 + 1) * XB_LD + j], Qs[(q0 + 2) * XB_LD + j], Qs[(q0 + 3) * XB_LD + j]),
+              xb_cvt4(dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]), dkt, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qt * 32 + xb_row(r, hi);
+          dvt = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[qq * XB_LD + j], sc[r], dvt, 0, 0, 0);
+          dkt = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qq * XB_LD + j], dp[r], dkt, 0, 0, 0);
+        }
       }
       // ---- dQ[query][d] += dS[query][key] K[key][d]: dS through the per-wave LDS tile as A operand ----
 #pragma unroll
@@ -171,9 +205,16 @@ __global__ __launch_bounds__(256) void cgg_xattn_bwd_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const f32x4 da = *reinterpret_cast<const f32x4*>(Tt + j * XB_LD + 16 * hi + 4 * t);
+        if constexpr (BF) {
+          const int k0 = 16 * hi + 4 * t;
+          acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(
+              xb_cvt4(da[0], da[1], da[2], da[3]),
+              xb_cvt4(Kt[k0 * XB_LD + j], Kt[(k0 + 1) * XB_LD + j], Kt[(k0 + 2) * XB_LD + j], Kt[(k0 + 3) * XB_LD + j]), acc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], Kt[(16 * hi + 4 * t + e) * XB_LD + j], acc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], Kt[(16 * hi + 4 * t + e) * XB_LD + j], acc, 0, 0, 0);
+        }
       }
       dq[qt] = acc;
       __builtin_amdgcn_wave_barrier();               // Tt is rewritten by the next query tile
@@ -245,7 +286,8 @@ extern "C" int cgg_masked_xattn_backward(const float* q, const void* kv, const u
   CGG_REQUIRE(B > 0 && Q > 0 && H > 0 && S > 0, CGG_EINVAL, "cgg_masked_xattn_backward: bad sizes");
   CGG_REQUIRE(D == 32, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: head dim %d (only 32 is built)", D);
   CGG_REQUIRE(Q <= 128, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: Q=%d > 128", Q);
-  CGG_REQUIRE(kv_dtype == CGG_F32, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: kv dtype %d (f32 only)", kv_dtype);
+  CGG_REQUIRE(kv_dtype == CGG_F32 || kv_dtype == CGG_F32_BF16MFMA, CGG_EUNSUPPORTED, "cgg_masked_xattn_backward: kv dtype %d (f32 rows only)",
+              kv_dtype);
   CGG_REQUIRE(cgg_aligned16(q) && cgg_aligned16(kv) && cgg_aligned16(out) && cgg_aligned16(grad_out) &&
                   cgg_aligned16(grad_q) && cgg_aligned16(grad_kv) && cgg_aligned16(ws),
               CGG_EALIGN, "cgg_masked_xattn_backward: all tensors must be 16-B aligned");
@@ -256,12 +298,18 @@ extern "C" int cgg_masked_xattn_backward(const float* q, const void* kv, const u
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cgg_xattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cgg_xattn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cgg_xattn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(cgg_xattn_bwd_kernel, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv, bits, out, lse,
-                     grad_out, (float*)grad_kv, (float*)ws, Q, H, S, words, KC, nch, scale);
+  if (kv_dtype == CGG_F32_BF16MFMA)
+    hipLaunchKernelGGL(cgg_xattn_bwd_kernel<true>, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv, bits, out, lse, grad_out,
+                       (float*)grad_kv, (float*)ws, Q, H, S, words, KC, nch, scale);
+  else
+    hipLaunchKernelGGL(cgg_xattn_bwd_kernel<false>, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv, bits, out, lse, grad_out,
+                       (float*)grad_kv, (float*)ws, Q, H, S, words, KC, nch, scale);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_backward(main)");
   const long long total = (long long)B * Q * H * D;
   hipLaunchKernelGGL(cgg_xattn_bwd_reduce_dq, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ws,

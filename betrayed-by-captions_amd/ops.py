@@ -461,7 +461,7 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
         lse = torch.empty((B, H, Q), dtype=torch.float32, device=q.device)
         rc = lib.cgg_masked_xattn_forward_lse(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
                                               dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(lse), dev_ptr(ws),
-                                              B, Q, H, D, S, float(scale), CGG_F32, stream_ptr(q.device))
+                                              B, Q, H, D, S, float(scale), _xattn_train_dtype(), stream_ptr(q.device))
         check(rc, 'cgg_masked_xattn_forward_lse')
         return out, lse
     rc = lib.cgg_masked_xattn_forward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
@@ -469,6 +469,17 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
                                       Q, H, D, S, float(scale), CGG_F32, stream_ptr(q.device))
     check(rc, 'cgg_masked_xattn_forward')
     return out
+
+
+CGG_F32_BF16MFMA = 2                 # include/cgg_hip.h: f32 rows in memory, bf16 MFMA operands (training kernels of throughput mode)
+XATTN_BF16_TRAIN = os.environ.get('CGG_XATTN_BF16_TRAIN', '1') != '0'
+
+
+def _xattn_train_dtype():
+    """kv_dtype of the training cross-attention kernels: throughput (bf16) mode multiplies on bf16 MFMA operands (f32 accumulate,
+    f32 rows in memory) like its GEMMs do; parity mode on the exact f32 MFMA."""
+    from . import runtime
+    return CGG_F32_BF16MFMA if (runtime.is_bf16() and XATTN_BF16_TRAIN) else CGG_F32
 
 
 def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None):
@@ -498,7 +509,7 @@ def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None
     rc = lib.cgg_masked_xattn_backward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
                                        dev_ptr(bits, 'bits', torch.int32), dev_ptr(out, 'out', torch.float32),
                                        dev_ptr(lse, 'lse', torch.float32), dev_ptr(grad_out, 'grad_out', torch.float32),
-                                       dev_ptr(gq), dev_ptr(gkv), dev_ptr(ws), B, Q, H, D, S, float(scale), CGG_F32,
+                                       dev_ptr(gq), dev_ptr(gkv), dev_ptr(ws), B, Q, H, D, S, float(scale), _xattn_train_dtype(),
                                        stream_ptr(q.device))
     check(rc, 'cgg_masked_xattn_backward')
     return gq, gkv

@@ -38,6 +38,9 @@ extern "C" {
 /* dtype tags */
 #define CGG_F32 0
 #define CGG_BF16 1
+/* kv_dtype of cgg_masked_xattn_forward_lse / cgg_masked_xattn_backward only: f32 rows in memory, products on bf16 MFMA operands
+ * (f32 accumulate) -- the throughput-mode training variant of the two kernels */
+#define CGG_F32_BF16MFMA 2
 
 typedef void* cgg_stream_t; /* hipStream_t */
 

@@ -1603,3 +1603,40 @@ def test_bottleneck64_fused_vs_float64(dev, B, H, W):
     err = (y.double() - ref64).abs()
     assert (err / ref64.abs().clamp_min(1.0)).max().item() <= 0.03
     assert (err / ref64.abs().clamp_min(1.0)).mean().item() <= 2e-3
+
+
+@pytest.mark.parametrize('B,Q,S,H', [(2, 100, 1050, 8), (1, 33, 16384, 8), (2, 100, 100, 8)])
+def test_masked_xattn_training_kernels_on_bf16_mfma_operands(dev, B, Q, S, H):
+    """Throughput-mode training: `cgg_masked_xattn_forward_lse` / `cgg_masked_xattn_backward` with kv_dtype CGG_F32_BF16MFMA (f32 rows
+    in memory, products on bf16 MFMA operands, f32 accumulation) against float64 autograd of the same formulation: bf16 operand
+    rounding (2^-9 per factor) bounds the error -- output and gradients within 2e-2 of their scale, cosine > 0.9999."""
+    from cgg_amd import runtime
+    from cgg_amd.query_decoder import pack_bool_mask
+    g = torch.Generator().manual_seed(31 + S)
+    D = 32
+    E = H * D
+    q = torch.randn(B, Q, E, generator=g)
+    kv = torch.randn(B, S, 2 * E, generator=g)
+    go = torch.randn(B, Q, E, generator=g)
+    mask = torch.rand(B, Q, S, generator=g) < 0.6
+    mask[0, 1] = False
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = (qd * D**-0.5).view(B, Q, H, D).transpose(1, 2)
+    kh = kvd[..., :E].view(B, S, H, D).transpose(1, 2)
+    vh = kvd[..., E:].view(B, S, H, D).transpose(1, 2)
+    att = (qh @ kh.transpose(-1, -2)).masked_fill(mask[:, None], float('-inf'))
+    want = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Q, E)
+    wgq, wgkv = torch.autograd.grad(want, (qd, kvd), go.double())
+    bits = pack_bool_mask(mask).contiguous().to(dev)
+    with runtime.precision_scope('bf16'):
+        assert ops._xattn_train_dtype() == ops.CGG_F32_BF16MFMA
+        out, lse = ops.masked_xattn(q.to(dev), kv.to(dev), bits, H, return_lse=True)
+        gq, gkv = ops.masked_xattn_backward(q.to(dev), kv.to(dev), bits, out, lse, go.to(dev), H)
+    with runtime.precision_scope('fp32'):
+        assert ops._xattn_train_dtype() == 0
+    for got, ref_, name in ((out, want.detach(), 'out'), (gq, wgq, 'grad_q'), (gkv, wgkv, 'grad_kv')):
+        gd = got.cpu().double()
+        scale = ref_.abs().max().item()
+        assert (gd - ref_).abs().max().item() <= 2e-2 * scale, (name, (gd - ref_).abs().max().item(), scale)
+        cos = float((gd * ref_).sum() / (gd.norm() * ref_.norm()))
+        assert cos > 0.9999, (name, cos)
