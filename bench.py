@@ -456,7 +456,7 @@ def train_run(args, cfg, model, img, metas, dev, rank, world, steps=None, warmup
             metric=f'images/sec (training step, {H}x{W}, {args.queries} queries)',
             value=B * world * steps / dt, unit='images/sec', n_gpus=world, steps=steps,
             warmup=warmup, ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling='weak',
-            vs_baseline=None, dtype='bf16' if args.precision == 'bf16' else 'f32 (f32 library GEMMs / convolutions under autograd; encoder linears forward + grad-input + grad-weight, the FPN 3x3 convolution and the frozen backbone stages on the f32-class f16x3 kernels)', data='synthetic',
+            vs_baseline=None, dtype='bf16 (bf16 GEMMs / MFMA operands, f32 accumulate; the FPN level and MSDeformAttn in f32-class / f32)' if args.precision == 'bf16' else 'f32 (encoder layers, the FPN level, caption-transformer / Swin linears and the frozen backbone stages on the f32-class f16x3 kernels: forward, grad-input, grad-weight; the rest f32 library GEMMs / convolutions under autograd)', data='synthetic',
             config=dict(workload=f'{WORKLOADS[args.workload]["name"]} '
                                  '(forward_train with grounding + caption-generation losses, backward, gradient '
                                  'all-reduce, clip, AdamW)',
