@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256) void cgg_xattn_combine_wave(const float* __res
   if (half == 0) {
     const int b = bh / H, h = bh - b * H;
     out[((size_t)b * Q + qq) * (H * D) + h * D + d] = num / den;   // den == 0 -> NaN, as the reference
-    if (lse != nullptr && d == 0) lse[(size_t)bh * Q + qq] = M + logf(den);   // natural-log domain callers only
+    if (lse != nullptr && d == 0)       // natural-log rows either way (the x3 partial pass keeps its maxima in log2 units)
+      lse[(size_t)bh * Q + qq] = log2_domain ? (M + log2f(den)) * 0.6931471805599453f : M + logf(den);
   }
 }
 
@@ -659,7 +660,7 @@ static int xattn_forward_f32(const float* q, const void* kv, const uint32_t* bit
     hipLaunchKernelGGL(cgg_xattn_partial_f32<false>, dim3(nch, H, B), dim3(256), lds, s, q, (const float*)kv,
                        bits, ws_o, ws_ml, Q, H, S, words, KC, nch, scale, nch == 1 ? out : nullptr, lse, ldkv, (long long)kv_bstride);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(partial)");
-  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, x3 ? 1 : 0, x3 ? nullptr : lse);
+  if (nch > 1) xattn_combine_launch(ws_o, ws_ml, out, B, Q, H, D, nch, s, x3 ? 1 : 0, lse);
   CGG_CHECK_LAUNCH("cgg_masked_xattn_forward(combine)");
   return CGG_OK;
 }
@@ -689,6 +690,8 @@ extern "C" int cgg_masked_xattn_forward_lse(const float* q, const void* kv, cons
                                             void* ws, int B, int Q, int H, int D, int S, float scale, int kv_dtype,
                                             cgg_stream_t stream) {
   CGG_REQUIRE(lse, CGG_EINVAL, "cgg_masked_xattn_forward_lse: null lse");
+  if (kv_dtype == CGG_F32_X3)          // parity-mode training: the forward on the f16 x 3 contraction, the same saved rows
+    return xattn_forward_f32(q, kv, bits, out, lse, ws, B, Q, H, D, S, scale, CGG_F32, stream, 0, 0, 1);
   return xattn_forward_f32(q, kv, bits, out, lse, ws, B, Q, H, D, S, scale, kv_dtype, stream);
 }
 

@@ -461,7 +461,7 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
         lse = torch.empty((B, H, Q), dtype=torch.float32, device=q.device)
         rc = lib.cgg_masked_xattn_forward_lse(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
                                               dev_ptr(bits, 'bits', torch.int32), dev_ptr(out), dev_ptr(lse), dev_ptr(ws),
-                                              B, Q, H, D, S, float(scale), _xattn_train_dtype(), stream_ptr(q.device))
+                                              B, Q, H, D, S, float(scale), _xattn_train_dtype(forward=True), stream_ptr(q.device))
         check(rc, 'cgg_masked_xattn_forward_lse')
         return out, lse
     rc = lib.cgg_masked_xattn_forward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
@@ -472,14 +472,19 @@ def masked_xattn(q, kv, bits, num_heads, scale=None, return_lse=False):
 
 
 CGG_F32_BF16MFMA = 2                 # include/cgg_hip.h: f32 rows in memory, bf16 MFMA operands (training kernels of throughput mode)
+CGG_F32_X3 = 3                       # cgg_masked_xattn_forward_lse only: the forward on the f32-class f16 x 3 contraction
 XATTN_BF16_TRAIN = os.environ.get('CGG_XATTN_BF16_TRAIN', '1') != '0'
+XATTN_X3_TRAIN = os.environ.get('CGG_XATTN_X3_TRAIN', '1') != '0'
 
 
-def _xattn_train_dtype():
+def _xattn_train_dtype(forward=False):
     """kv_dtype of the training cross-attention kernels: throughput (bf16) mode multiplies on bf16 MFMA operands (f32 accumulate,
-    f32 rows in memory) like its GEMMs do; parity mode on the exact f32 MFMA."""
+    f32 rows in memory) like its GEMMs do; parity mode runs the forward on the f32-class f16 x 3 contraction (the inference kernel,
+    which also writes the log-sum-exp rows) and the backward on the exact f32 MFMA."""
     from . import runtime
-    return CGG_F32_BF16MFMA if (runtime.is_bf16() and XATTN_BF16_TRAIN) else CGG_F32
+    if runtime.is_bf16():
+        return CGG_F32_BF16MFMA if XATTN_BF16_TRAIN else CGG_F32
+    return CGG_F32_X3 if (forward and XATTN_X3_TRAIN and XATTN_X3 and runtime.x3_enabled()) else CGG_F32
 
 
 def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None):

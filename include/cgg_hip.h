@@ -41,6 +41,7 @@ extern "C" {
 /* kv_dtype of cgg_masked_xattn_forward_lse / cgg_masked_xattn_backward only: f32 rows in memory, products on bf16 MFMA operands
  * (f32 accumulate) -- the throughput-mode training variant of the two kernels */
 #define CGG_F32_BF16MFMA 2
+#define CGG_F32_X3 3 /* cgg_masked_xattn_forward_lse only: f32 rows, products on the f16 x 3 contraction (csrc/x3.h) */
 
 typedef void* cgg_stream_t; /* hipStream_t */
 

@@ -1640,3 +1640,38 @@ def test_masked_xattn_training_kernels_on_bf16_mfma_operands(dev, B, Q, S, H):
         assert (gd - ref_).abs().max().item() <= 2e-2 * scale, (name, (gd - ref_).abs().max().item(), scale)
         cos = float((gd * ref_).sum() / (gd.norm() * ref_.norm()))
         assert cos > 0.9999, (name, cos)
+
+
+@pytest.mark.parametrize('B,Q,S,H', [(2, 100, 1050, 8), (1, 33, 16384, 8), (2, 100, 100, 8)])
+def test_masked_xattn_parity_training_forward_on_x3_saves_the_same_rows(dev, B, Q, S, H):
+    """Parity-mode training: `cgg_masked_xattn_forward_lse` with kv_dtype CGG_F32_X3 (the inference kernel of csrc/xattn_x3.hip, one
+    chunk or combined) writes the output AND the natural-log log-sum-exp rows; with the exact-f32-MFMA backward on top, output, rows
+    and both gradients stay f32-class against float64 autograd (1e-5 / 1e-4 of scale)."""
+    from cgg_amd import runtime
+    from cgg_amd.query_decoder import pack_bool_mask
+    g = torch.Generator().manual_seed(77 + S)
+    D = 32
+    E = H * D
+    q = torch.randn(B, Q, E, generator=g)
+    kv = torch.randn(B, S, 2 * E, generator=g)
+    go = torch.randn(B, Q, E, generator=g)
+    mask = torch.rand(B, Q, S, generator=g) < 0.6
+    mask[0, 1] = False
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = (qd * D**-0.5).view(B, Q, H, D).transpose(1, 2)
+    kh = kvd[..., :E].view(B, S, H, D).transpose(1, 2)
+    vh = kvd[..., E:].view(B, S, H, D).transpose(1, 2)
+    att = (qh @ kh.transpose(-1, -2)).masked_fill(mask[:, None], float('-inf'))
+    want = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Q, E)
+    want_lse = att.logsumexp(-1).detach()                     # (B, H, Q)
+    wgq, wgkv = torch.autograd.grad(want, (qd, kvd), go.double())
+    bits = pack_bool_mask(mask).contiguous().to(dev)
+    with runtime.precision_scope('fp32'):
+        assert ops._xattn_train_dtype(forward=True) == ops.CGG_F32_X3 and ops._xattn_train_dtype() == 0
+        out, lse = ops.masked_xattn(q.to(dev), kv.to(dev), bits, H, return_lse=True)
+        gq, gkv = ops.masked_xattn_backward(q.to(dev), kv.to(dev), bits, out, lse, go.to(dev), H)
+    assert (lse.cpu().double() - want_lse).abs().max().item() <= 1e-5 * max(1.0, want_lse.abs().max().item())
+    for got, ref_, name, tol in ((out, want.detach(), 'out', 1e-5), (gq, wgq, 'grad_q', 1e-4), (gkv, wgkv, 'grad_kv', 1e-4)):
+        gd = got.cpu().double()
+        scale = ref_.abs().max().item()
+        assert (gd - ref_).abs().max().item() <= tol * scale, (name, (gd - ref_).abs().max().item(), scale)
