@@ -10,6 +10,7 @@ The arithmetic is a compact functional forward over those parameters (one fused 
 self and cross attention); GEMMs go through hipBLASLt (bf16 autocast in throughput mode).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -174,9 +175,18 @@ class _GeneratorCEFn(torch.autograd.Function):
     row chunks of logits come from a library GEMM against the padded generator weight into ONE reused buffer and are
     consumed by `cgg_ce_rows_forward` (log-sum-exp + row loss). Backward recomputes a chunk, `cgg_ce_rows_backward` turns
     it in place into g_row (softmax - onehot), and the two gradient GEMMs read it. bf16 logits / f32 statistics in
-    throughput mode (what bf16 autocast of the reference formulation computes), f32 in parity mode."""
+    throughput mode (what bf16 autocast of the reference formulation computes), f32 in parity mode -- there the logits GEMM (forward
+    and the backward's recomputation) and the weight / bias gradient run on the f32-class x3 kernels (`ops.gemm_x3`, `ops.wgrad_x3`:
+    (2048, 768) x (768, 30528) in ~0.35 ms instead of the f32 library's 0.84); the grad-input GEMM (768 output columns: 96 tiles,
+    too few workgroups for the x3 kernel) stays on the library. CGG_X3_GENERATOR=0 restores the library GEMMs."""
 
     CHUNK = 2048
+    X3 = os.environ.get('CGG_X3_GENERATOR', '1') != '0'
+
+    @staticmethod
+    def _x3_ok(x, w):
+        return (_GeneratorCEFn.X3 and runtime._X3_TRAIN and runtime.x3_enabled() and x.dtype == torch.float32 and x.is_cuda
+                and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and x.shape[0] >= 256)
 
     @staticmethod
     def _operands(weight, bias, dt):
@@ -201,13 +211,19 @@ class _GeneratorCEFn(torch.autograd.Function):
         buf = torch.empty((C, w.shape[0]), dtype=dt, device=x.device)
         loss = torch.empty(M, dtype=torch.float32, device=x.device)
         lse = torch.empty(M, dtype=torch.float32, device=x.device)
+        wk = runtime.derived_cached('generator_ce_x3', (weight, bias), lambda: ops.pack_linear_weight_x3(w)) \
+            if _GeneratorCEFn._x3_ok(x, w) else None
         for r0 in range(0, M, C):
             r1 = min(r0 + C, M)
-            lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
+            if wk is not None:
+                lg = ops.gemm_x3(x[r0:r1], wk, w.shape[0], b, out=buf[:r1 - r0])
+            else:
+                lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
             l, s = ops.ce_rows_forward(lg, target[r0:r1], ignore_index)
             loss[r0:r1] = l
             lse[r0:r1] = s
         ctx.save_for_backward(x, w, b, target, lse)
+        ctx.wk = wk
         ctx.ignore_index = ignore_index
         ctx.n_out = weight.shape[0]
         ctx.in_dtype = hidden.dtype
@@ -223,13 +239,23 @@ class _GeneratorCEFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         gw = torch.zeros(w.shape, dtype=torch.float32, device=x.device)
         gb = torch.zeros(w.shape[0], dtype=torch.float32, device=x.device)
-        gwc = torch.empty(w.shape, dtype=x.dtype, device=x.device)          # one chunk's weight gradient, reused by every chunk
+        wk = ctx.wk
+        gwc = torch.empty(w.shape, dtype=x.dtype, device=x.device) if wk is None else None   # one chunk's weight gradient, reused
         g = grad_rows.float().contiguous()
         for r0 in range(0, M, C):
             r1 = min(r0 + C, M)
-            lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
+            if wk is not None:
+                lg = ops.gemm_x3(x[r0:r1], wk, w.shape[0], b, out=buf[:r1 - r0])
+            else:
+                lg = torch.addmm(b, x[r0:r1], w.t(), out=buf[:r1 - r0])
             dl = ops.ce_rows_backward_(lg, target[r0:r1], lse[r0:r1], g[r0:r1], ctx.ignore_index)
             torch.mm(dl, w, out=gx[r0:r1])
+            if wk is not None:
+                # weight and bias gradient of the chunk from one transpose-read pass over g_row (pre-scaled by its exact maximum)
+                gwi, gbi = ops.wgrad_x3(dl, x[r0:r1], want_bias=True, amax=ops.absmax(dl))
+                gw += gwi
+                gb += gbi
+                continue
             # summed in f32 (one rounding of each chunk's partial to the GEMM dtype: 3 chunks at configs[2], below the bf16
             # GEMM's own rounding)
             gw += torch.mm(dl.t(), x[r0:r1], out=gwc)
