@@ -994,6 +994,15 @@ class Mask2FormerHeadOpen(nn.Module):
             else:
                 pred_pts = torch.stack([all_mask_preds[li].sample_points(pts[li]) if isinstance(all_mask_preds[li], LazyMasks)
                                         else point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)
+            # the prediction-only halves of the mask / dice costs ONCE for all layers and images (mmdet CrossEntropyLossCost forms
+            # pos . t + neg . (1 - t) with pos = softplus(-x), neg = softplus(x); pos - neg = -x, so the pair of contractions is
+            # sum_p softplus(x) - x . t: per image one contraction with the targets instead of ~12 passes over its (n, Q, P) logits)
+            x_all = pred_pts.float()                                                          # (n, B, Q, P)
+            sp_sum = F.softplus(x_all).sum(-1) if a.mask_cost.weight != 0 else None           # (n, B, Q)
+            xx_all = xx_sum = None
+            if a.dice_cost.weight != 0:
+                xx_all = x_all.sigmoid() if a.dice_cost.pred_act else x_all
+                xx_sum = xx_all.sum(-1) if a.dice_cost.naive_dice else xx_all.pow(2).sum(-1)
             costs, shapes = [], []
             for b in range(B):
                 G = int(gt_labels_list[b].shape[0])
@@ -1003,7 +1012,8 @@ class Mask2FormerHeadOpen(nn.Module):
                 gl = gt_labels_list[b]
                 t = point_sample(gt_f[b][None], pts[:, b].reshape(1, n * P, 2))[0]          # (G, n*P)
                 t = t.view(G, n, P).permute(1, 0, 2).contiguous()                             # (n, G, P)
-                x = pred_pts[:, b].float()                                                    # (n, Q, P)
+                x = x_all[:, b]                                                               # (n, Q, P)
+                tt = t.transpose(1, 2)
                 cost = 0
                 if a.cls_cost.weight != 0:
                     cs = torch.stack([c[b] for c in all_cls_scores], 0)
@@ -1012,19 +1022,12 @@ class Mask2FormerHeadOpen(nn.Module):
                     es = torch.stack([e[b] for e in emb_logits], 0)
                     cost = cost + (-es.detach().softmax(-1)[..., gl] * a.cls_emb_cost.weight)
                 if a.mask_cost.weight != 0:
-                    pos = F.binary_cross_entropy_with_logits(x, torch.ones_like(x), reduction='none')
-                    neg = F.binary_cross_entropy_with_logits(x, torch.zeros_like(x), reduction='none')
-                    tt = t.transpose(1, 2)
-                    c = torch.bmm(pos, tt) + torch.bmm(neg, 1 - tt)
+                    c = sp_sum[:, b][:, :, None] - torch.bmm(x, tt)
                     cost = cost + c / P * a.mask_cost.weight
                 if a.dice_cost.weight != 0:
                     dc = a.dice_cost
-                    xx = x.sigmoid() if dc.pred_act else x
-                    num = 2 * torch.bmm(xx, t.transpose(1, 2))
-                    if dc.naive_dice:
-                        den = xx.sum(-1)[:, :, None] + t.sum(-1)[:, None, :]
-                    else:
-                        den = xx.pow(2).sum(-1)[:, :, None] + t.pow(2).sum(-1)[:, None, :]
+                    num = 2 * torch.bmm(xx_all[:, b], tt)
+                    den = xx_sum[:, b][:, :, None] + (t.sum(-1) if dc.naive_dice else t.pow(2).sum(-1))[:, None, :]
                     cost = cost + (1 - (num + dc.eps) / (den + dc.eps)) * dc.weight
                 if getattr(self, 'cost_trace', None) is not None:      # test hook: the (n, Q, G) cost matrices of image b
                     self.cost_trace.append((b, cost.detach().float().clone()))
