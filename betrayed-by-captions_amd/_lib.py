@@ -50,6 +50,7 @@ PROTOTYPES = {
     'cgg_grounding_pair_costs_backward': (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_f, _c_vp]),
     'cgg_ce_rows_forward': (_c_int, [_c_vp] * 4 + [_c_int, _c_int, _c_i64, _c_i64, _c_int, _c_vp]),
     'cgg_ce_rows_backward': (_c_int, [_c_vp] * 4 + [_c_int, _c_int, _c_i64, _c_i64, _c_int, _c_vp]),
+    'cgg_match_cost_rows': (_c_int, [_c_vp] * 4 + [_c_int, _c_int, _c_int, _c_vp]),
     'cgg_rle_encode_bitmasks': (_c_i64, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_i64, _c_vp]),
     'cgg_masked_xattn_forward_bf16': (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_f, _c_int, _c_i64, _c_int, _c_vp]),
     'cgg_linear_rows': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp] + [_c_int] * 6 + [_c_vp]),

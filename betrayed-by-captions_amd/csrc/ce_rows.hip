@@ -147,3 +147,61 @@ extern "C" int cgg_ce_rows_backward(void* logits, const int64_t* target, const f
   CGG_CHECK_LAUNCH("cgg_ce_rows_backward");
   return CGG_OK;
 }
+
+
+// ----------------------------------------------------------------------------------------------
+// Prediction-only halves of the Hungarian matching costs (open_set/models/mask2former_head.py:320-390 -> mmdet
+// CrossEntropyLossCost(use_sigmoid) / DiceCost(pred_act) on the point-sampled mask logits), one pass over the (rows, P) logits:
+//   sp_sum[row]  = sum_p softplus(x)                (pos . t + neg . (1 - t) = sp_sum - x . t, since softplus(-x) - softplus(x) = -x)
+//   sig[row][p]  = sigmoid(x)                       (the dice numerator's operand: the caller contracts it with the targets)
+//   sig_sum[row] = sum_p sigmoid(x)  (square = 0)   |  sum_p sigmoid(x)^2  (square = 1, DiceCost(naive_dice = False))
+// One workgroup per row, float4 loads / stores, sums in a fixed order (lane-serial, then the butterfly, then the four waves).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cgg_match_cost_rows_kernel(const float* __restrict__ x, float* __restrict__ sig,
+                                                                  float* __restrict__ sp_sum, float* __restrict__ sig_sum, int P,
+                                                                  int square) {
+  const size_t row = blockIdx.x;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * (size_t)P);
+  float4* sr = reinterpret_cast<float4*>(sig + row * (size_t)P);
+  float a_sp = 0.f, a_sg = 0.f;
+  auto one = [&](float v, float& s) {
+    const float e = expf(-fabsf(v));                     // in (0, 1]
+    a_sp += fmaxf(v, 0.f) + log1pf(e);
+    s = (v >= 0.f ? 1.f : e) / (1.f + e);                // sigmoid without overflow on either side
+    a_sg += square ? s * s : s;
+  };
+  for (int i = threadIdx.x; i < P / 4; i += 256) {
+    const float4 v = xr[i];
+    float4 s;
+    one(v.x, s.x);
+    one(v.y, s.y);
+    one(v.z, s.z);
+    one(v.w, s.w);
+    sr[i] = s;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a_sp += __shfl_xor(a_sp, o);
+    a_sg += __shfl_xor(a_sg, o);
+  }
+  __shared__ float red[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a_sp;
+    red[1][threadIdx.x >> 6] = a_sg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sp_sum[row] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sig_sum[row] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+extern "C" int cgg_match_cost_rows(const float* x, float* sig, float* sp_sum, float* sig_sum, int rows, int P, int square,
+                                   cgg_stream_t stream) {
+  CGG_REQUIRE(x && sig && sp_sum && sig_sum, CGG_EINVAL, "cgg_match_cost_rows: null pointer");
+  CGG_REQUIRE(rows > 0 && P > 0, CGG_EINVAL, "cgg_match_cost_rows: bad sizes");
+  CGG_REQUIRE(P % 4 == 0, CGG_EUNSUPPORTED, "cgg_match_cost_rows: P=%d must be a multiple of 4", P);
+  CGG_REQUIRE(cgg_aligned16(x) && cgg_aligned16(sig), CGG_EALIGN, "cgg_match_cost_rows: x / sig must be 16-B aligned");
+  hipLaunchKernelGGL(cgg_match_cost_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, sig, sp_sum, sig_sum, P, square);
+  CGG_CHECK_LAUNCH("cgg_match_cost_rows");
+  return CGG_OK;
+}

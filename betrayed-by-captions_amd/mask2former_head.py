@@ -989,8 +989,10 @@ class Mask2FormerHeadOpen(nn.Module):
                 nhwc = getattr(mf0, '_cgg_nhwc', None)     # (the channel-last FPN path hands its own channel-last copy along)
                 fs = ops.point_sample_nhwc(nhwc if nhwc is not None else mf0.detach().permute(0, 2, 3, 1).contiguous(),
                                            pts.permute(1, 0, 2, 3).reshape(B, n * P, 2))           # (B, n*P, C)
-                pred_pts = torch.stack([torch.bmm(all_mask_preds[li].mask_embed.detach().float(),
-                                                  fs[:, li * P:(li + 1) * P].transpose(1, 2)) for li in range(n)], 0)
+                pred_pts = torch.empty((n, B, Q, P), dtype=torch.float32, device=dev)     # (no stack: each product lands in its slab)
+                for li in range(n):
+                    torch.bmm(all_mask_preds[li].mask_embed.detach().float(), fs[:, li * P:(li + 1) * P].transpose(1, 2),
+                              out=pred_pts[li])
             else:
                 pred_pts = torch.stack([all_mask_preds[li].sample_points(pts[li]) if isinstance(all_mask_preds[li], LazyMasks)
                                         else point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)
@@ -998,11 +1000,15 @@ class Mask2FormerHeadOpen(nn.Module):
             # pos . t + neg . (1 - t) with pos = softplus(-x), neg = softplus(x); pos - neg = -x, so the pair of contractions is
             # sum_p softplus(x) - x . t: per image one contraction with the targets instead of ~12 passes over its (n, Q, P) logits)
             x_all = pred_pts.float()                                                          # (n, B, Q, P)
-            sp_sum = F.softplus(x_all).sum(-1) if a.mask_cost.weight != 0 else None           # (n, B, Q)
-            xx_all = xx_sum = None
-            if a.dice_cost.weight != 0:
-                xx_all = x_all.sigmoid() if a.dice_cost.pred_act else x_all
-                xx_sum = xx_all.sum(-1) if a.dice_cost.naive_dice else xx_all.pow(2).sum(-1)
+            xx_all = xx_sum = sp_sum = None
+            if x_all.is_cuda and x_all.is_contiguous() and P % 4 == 0 and a.dice_cost.weight != 0 and a.dice_cost.pred_act:
+                # one pass (cgg_match_cost_rows): sigmoid(x), sum softplus(x), sum sigmoid(x) [^2]
+                xx_all, sp_sum, xx_sum = ops.match_cost_rows(x_all, square=not a.dice_cost.naive_dice)
+            else:
+                sp_sum = F.softplus(x_all).sum(-1) if a.mask_cost.weight != 0 else None       # (n, B, Q)
+                if a.dice_cost.weight != 0:
+                    xx_all = x_all.sigmoid() if a.dice_cost.pred_act else x_all
+                    xx_sum = xx_all.sum(-1) if a.dice_cost.naive_dice else xx_all.pow(2).sum(-1)
             costs, shapes = [], []
             for b in range(B):
                 G = int(gt_labels_list[b].shape[0])

@@ -579,6 +579,23 @@ def ce_rows_forward(logits, target, ignore_index):
     return loss, lse
 
 
+def match_cost_rows(x, square=False):
+    """x (..., P) f32 point-sampled mask logits (contiguous, P % 4 == 0) -> (sigmoid(x) (..., P), sum_p softplus(x) (...),
+    sum_p sigmoid(x) [or sigmoid(x)^2 with square] (...)) in one pass (csrc/ce_rows.hip `cgg_match_cost_rows`): the prediction-only
+    halves of the Hungarian mask / dice costs."""
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[-1] % 4:
+        raise CggError('match_cost_rows: x must be a contiguous float32 ROCm tensor with a last dim that is a multiple of 4')
+    P = x.shape[-1]
+    rows = x.numel() // P
+    sig = torch.empty_like(x)
+    sp = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    ss = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    rc = _lib_().cgg_match_cost_rows(dev_ptr(x, 'x', torch.float32), dev_ptr(sig), dev_ptr(sp), dev_ptr(ss), rows, P, int(bool(square)),
+                                     stream_ptr(x.device))
+    check(rc, 'cgg_match_cost_rows')
+    return sig, sp, ss
+
+
 def ce_rows_backward_(logits, target, lse, grad_rows, ignore_index):
     """logits (M, N) -> d loss / d logits IN PLACE: grad_rows[row] * (softmax - onehot); returns `logits`."""
     M, N = logits.shape

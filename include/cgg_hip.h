@@ -303,6 +303,21 @@ int cgg_ce_rows_backward(void* logits, const int64_t* target, const float* lse, 
                          int64_t ld, int64_t ignore_index, int dtype, cgg_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Prediction-only halves of the Hungarian matching costs on point-sampled mask logits, one pass.
+ *
+ * Replaces, per training step, the per-(layer, image) elementwise chain of open_set/models/mask2former_head.py:320-390
+ * (`_get_target_single` -> mmdet CrossEntropyLossCost(use_sigmoid=True): pos = softplus(-x), neg = softplus(x),
+ * einsum(pos, t) + einsum(neg, 1 - t); DiceCost(pred_act=True): sigmoid(x)). With softplus(-x) - softplus(x) = -x the pair of
+ * contractions is sp_sum - x . t, so only row sums and sigmoid(x) are needed from the predictions:
+ *   x        (rows, P) f32 logits, contiguous, 16-B aligned, P % 4 == 0
+ *   sig      (rows, P) f32 out: sigmoid(x)
+ *   sp_sum   (rows)    f32 out: sum_p softplus(x)
+ *   sig_sum  (rows)    f32 out: sum_p sigmoid(x)   (square = 0)  |  sum_p sigmoid(x)^2   (square = 1: naive_dice = False)
+ * ---------------------------------------------------------------------------------------------- */
+int cgg_match_cost_rows(const float* x, float* sig, float* sp_sum, float* sig_sum, int rows, int P, int square,
+                        cgg_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * HOST function (no device work, no stream): COCO run-length encoding of bit-packed instance masks.
  *
  * Replaces, for the serving / evaluation path, the per-mask `.cpu().numpy()` of open_set/models/maskformer.py:205-208

@@ -26,17 +26,27 @@ def patched(args, cfg, model, img, metas, dev, rank, world, steps=None, warmup=N
     for _ in range(3):
         train_step(model, optimizer, reducer, data, clip)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
         train_step(model, optimizer, reducer, data, clip)
         torch.cuda.synchronize()
     rows = []
     for e in prof.key_averages(group_by_input_shape=True):
         t = getattr(e, 'self_device_time_total', 0) or getattr(e, 'self_cuda_time_total', 0)
-        if t > 150:
+        if t > 100:
             rows.append((t, e.count, e.key, str(e.input_shapes)[:150]))
     rows.sort(reverse=True)
-    for t, c, k, sh in rows[:70]:
+    for t, c, k, sh in rows[:130]:
         print(f'{t:9.0f} us {c:4d}  {k:45s} {sh}', flush=True)
+    print('---- elementwise / copy ops by call site ----', flush=True)
+    rows = []
+    for e in prof.key_averages(group_by_stack_n=12):
+        t = getattr(e, 'self_device_time_total', 0) or getattr(e, 'self_cuda_time_total', 0)
+        if t > 150 and e.key.startswith('aten::') and not any(k in e.key for k in ('mm', 'conv', 'linear')):
+            st = [f for f in (e.stack or []) if 'captions_amd' in f or 'cgg_amd' in f]
+            rows.append((t, e.count, e.key, ' <- '.join(x.split('/')[-1] for x in st[:3])))
+    rows.sort(reverse=True)
+    for t, c, k, sh in rows[:80]:
+        print(f'{t:9.0f} us {c:4d}  {k:28s} {sh}', flush=True)
     return dict(value=0.0, ms_per_step=0.0, loss=0.0)
 
 

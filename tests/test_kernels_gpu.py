@@ -1113,6 +1113,30 @@ def test_subsample_nhwc(dev):
         assert torch.equal(ops.subsample_nhwc(x, st), x[:, ::st, ::st, :].contiguous())
 
 
+@pytest.mark.parametrize('shape,square', [((3, 2, 7, 12544), False), ((5, 8), True), ((1, 100, 1000), False)])
+def test_match_cost_rows_vs_float64(dev, shape, square):
+    """`cgg_match_cost_rows`: sigmoid(x), sum_p softplus(x) and sum_p sigmoid(x) [^2] of point-sampled mask logits in one pass
+    (the prediction-only halves of mmdet's CrossEntropyLossCost / DiceCost, mask2former_head.py:320-390) against float64, with
+    saturating logits on both sides; and the identity the caller relies on: pos . t + neg . (1 - t) = sum softplus(x) - x . t."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 6
+    x.view(-1)[:6] = torch.tensor([120.0, -120.0, 20.0, -20.0, 0.0, 88.0])
+    sig, sp, ss = ops.match_cost_rows(x.to(dev), square=square)
+    xd = x.double()
+    wsig = xd.sigmoid()
+    assert (sig.cpu().double() - wsig).abs().max().item() <= 2e-7
+    wsp = torch.nn.functional.softplus(xd).sum(-1)
+    assert (sp.cpu().double() - wsp).abs().max().item() <= 2e-6 * wsp.abs().max().item()
+    wss = (wsig ** 2 if square else wsig).sum(-1)
+    assert (ss.cpu().double() - wss).abs().max().item() <= 2e-6 * wss.abs().max().item()
+    t = (torch.rand(shape, generator=g) < 0.3).double()
+    F = torch.nn.functional
+    ref = (F.binary_cross_entropy_with_logits(xd, torch.ones_like(xd), reduction='none') * t
+           + F.binary_cross_entropy_with_logits(xd, torch.zeros_like(xd), reduction='none') * (1 - t)).sum(-1)
+    got = sp.cpu().double() - (xd * t).sum(-1)
+    assert (got - ref).abs().max().item() <= 2e-6 * (1 + ref.abs().max().item())
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_generator_ce_rows_vs_materialised_logits(dev, precision):
     """`CaptionTransformer.generator_ce_rows` (cgg_ce_rows_forward / _backward over GEMM row chunks; the logits are never
