@@ -417,6 +417,7 @@ class ResNet(nn.Module):
                 return self._forward_x3(x)
             runtime.note_fallback('ResNet', 'a convolution outside the implicit-GEMM rules (groups, dilation, C % 32, N % 8): MIOpen f32')
         outs = []
+        frozen_nhwc = []
         first = 0
         if (FROZEN_FOLDED and runtime.x3_enabled() and torch.is_grad_enabled() and frozen_bn and x.is_cuda and self.frozen_stages >= 1
                 and not x.requires_grad and self._x3_ok() and x.dtype == torch.float32
@@ -427,6 +428,7 @@ class ResNet(nn.Module):
             with torch.no_grad():
                 fouts, xf = self._forward_x3(x, upto=self.frozen_stages)
             outs = [o.permute(0, 3, 1, 2) for o in fouts]
+            frozen_nhwc = list(fouts)
             x = xf.permute(0, 3, 1, 2)
             first = self.frozen_stages
         if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1 and not x.requires_grad
@@ -456,4 +458,16 @@ class ResNet(nn.Module):
                 x = getattr(self, name)(x)
                 if i in self.out_indices:
                     outs.append(x)
-        return tuple(o.float().contiguous() for o in outs)
+        res = []
+        for k, o in enumerate(outs):
+            src = frozen_nhwc[k] if k < len(frozen_nhwc) else None
+            if src is not None and src.dtype == torch.float32 and src.is_cuda and src.is_contiguous() and not src.requires_grad:
+                # a frozen stage's channel-last f32 map: NCHW by the tiled transpose kernel (ATen's strided clone of the 1-GB stride-4
+                # map took 1.1 ms, this 0.35), and the channel-last original rides along for consumers that read rows
+                # (`runtime.fpn_level_x3_train`)
+                t = ops.nhwc_to_nchw(src)
+                t._cgg_nhwc = src
+                res.append(t)
+            else:
+                res.append(o.float().contiguous())
+        return tuple(res)

@@ -606,7 +606,11 @@ def fpn_level_x3_train(pd, x, lo_rows, lo_hw):
     lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
     gn1, gn2 = getattr(lat, lat.norm_name), getattr(outc, outc.norm_name)
     B, Cin, H, W = x.shape
-    xr = _NchwToRowsFn.apply(x.float())
+    nh = getattr(x, '_cgg_nhwc', None)            # a frozen backbone stage hands its channel-last original along (backbones.ResNet)
+    if nh is not None and not x.requires_grad and nh.dtype == torch.float32 and tuple(nh.shape) == (B, H, W, Cin) and nh.is_contiguous():
+        xr = nh.view(B, H * W, Cin)
+    else:
+        xr = _NchwToRowsFn.apply(x.float())
     cur = _X3LinearFn.apply(xr, lat.conv.weight.flatten(1), None)
     y = _X3FpnLevelFn.apply(cur, lo_rows.float(), gn1.weight, gn1.bias, outc.conv.weight, gn2.weight, gn2.bias, gn1.num_groups, gn1.eps, gn2.eps,
                             (H, W), tuple(lo_hw))
