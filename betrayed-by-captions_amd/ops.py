@@ -1510,6 +1510,27 @@ def gemm_x3_split(a, packed, N, col2, bias=None, res_table=None):
     return y1, y2
 
 
+def gemm_x3_table(a, packed, N, res_table, bias=None, out=None):
+    """a (M, K) f32 rows x x3 image of an (N, K) weight -> a W^T + bias + res_table[row % len(res_table)] (M, N) f32, one launch
+    (`cgg_gemm_x3_ex` with a row-periodic residual): a linear layer whose bias is a per-token table shared by the images of a batch."""
+    if a.dim() != 2 or a.stride(1) != 1 or a.dtype != torch.float32 or not a.is_cuda or not is_x3(packed):
+        raise CggError('gemm_x3_table: a must be a 2-D float32 ROCm tensor with a contiguous last dim, packed an x3 image')
+    M, K = a.shape
+    _x3_check(packed, N, K, 'gemm_x3_table')
+    if res_table.dim() != 2 or res_table.shape[1] != N or not res_table.is_contiguous() or res_table.dtype != torch.float32 \
+            or M % res_table.shape[0]:
+        raise CggError('gemm_x3_table: res_table must be a contiguous (R, N) float32 tensor with R dividing the row count')
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if y.shape != (M, N) or not y.is_contiguous() or y.dtype != torch.float32:
+        raise CggError('gemm_x3_table: bad `out`')
+    with _timed('gemm_x3', flops=2.0 * M * N * K, bytes=4.0 * (M * K + M * N + N * K), shape=(M, N, K)):
+        rc = _lib_().cgg_gemm_x3_ex(ctypes.c_void_p(a.data_ptr()), a.stride(0), dev_ptr(packed), dev_ptr(bias, 'bias', torch.float32),
+                                    dev_ptr(res_table), N, res_table.shape[0], dev_ptr(y), N, None, 0, 0, M, N, K, 0,
+                                    stream_ptr(a.device))
+    check(rc, 'cgg_gemm_x3_ex')
+    return y
+
+
 def conv_x3_nhwc(x, packed, N, kernel, stride=1, pad=0, bias=None, res=None, relu=False, amax=None):
     """x (B, H, W, C) f32 channel-last (contiguous) -> act(conv + bias (+ res)) (B, OH, OW, N) f32 as an implicit GEMM on the
     x3 image made by `pack_conv_weight_x3` (C % 32 == 0). amax: device scalar max |x| -> per-tensor pre-scale (gradient maps)."""

@@ -108,6 +108,10 @@ class MultiheadAttention(nn.Module):
             for b in range(mem.shape[0]):
                 runtime.linear_x3(mem[b], w_kv, None, res=bias, out=kv[b])
             return kv
+        if (bias.dim() == 2 and mem.dim() == 3 and runtime.x3_train_linear_ok(mem, w_kv) and not runtime.is_bf16()
+                and bias.shape == (mem.shape[1], w_kv.shape[0])):
+            # parity-mode training: the same table in the x3 node's residual input (no broadcast add over the (B, S, 2C) result)
+            return runtime._X3LinearTableFn.apply(mem, w_kv, bias)
         kv = runtime.linear(mem, w_kv)
         return (kv + bias).contiguous()
 

@@ -230,6 +230,46 @@ class _X3LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _X3LinearTableFn(torch.autograd.Function):
+    """y[b] = x[b] W^T + table for x (B, S, K), table (S, N) -- a linear layer whose bias differs per ROW but not per image (the
+    query decoder's [K | V] projection of a memory level: `(mem + pos) Wk^T + b_k | mem Wv^T + b_v` with the position part folded into
+    the table, query_decoder.project_kv) as one x3 node in PARITY-mode training: the table rides in the GEMM's row-periodic residual
+    input instead of a broadcast add over the (B, S, N) result (1 GB per stride-8 level at configs[2]); backward as `_X3LinearFn`
+    plus table.grad = sum over the images of grad_output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, table):
+        from . import ops
+        B, S, K = x.shape
+        N = weight.shape[0]
+        x2 = _rows(x, K)
+        wk = derived_cached('x3_image', (weight,), lambda: ops.pack_linear_weight_x3(weight))
+        tb = table.detach().contiguous()
+        y = torch.empty((B, S, N), dtype=torch.float32, device=x.device)
+        ops.gemm_x3_table(x2, wk, N, tb, out=y.view(B * S, N))        # row m adds table[m % S]: one launch for all images
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        g2 = _rows(gy, N)
+        gx = gw = gt = None
+        amax = ops.absmax(g2) if _X3_GSCALE else None
+        if ctx.needs_input_grad[0]:
+            wtk = derived_cached('x3_image_t', (weight,), lambda: ops.pack_linear_weight_x3(weight.detach().t().contiguous()))
+            gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g2.device)
+            ops.gemm_x3(g2, wtk, K, out=gx.view(-1, K), amax=amax)
+        if ctx.needs_input_grad[1]:
+            gw = ops.wgrad_x3(g2, x2, amax=amax)
+        if ctx.needs_input_grad[2]:
+            gt = g2.view(ctx.x_shape[0], -1, N).sum(0)
+        return gx, gw, gt
+
+
 class _X3FfnFn(torch.autograd.Function):
     """Training-time FFN branch y = W2 relu(W1 x + b1) + b2 of an encoder layer ([3P] FFN behind mask2former_head.py:787) in PARITY
     mode as ONE autograd node on the x3 kernels. Compared with two `_X3LinearFn`s around `torch.relu_`: the ReLU is the first GEMM's

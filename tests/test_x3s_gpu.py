@@ -176,6 +176,30 @@ def test_x3_training_linear_forward_and_gradients_vs_float64(dev):
         assert err <= 2e-5 * scale, (name, err, scale)
 
 
+@pytest.mark.parametrize('B,S,K,N', [(2, 4096, 256, 512), (3, 1000, 256, 512), (2, 5000, 256, 96)])
+def test_x3_training_linear_with_a_per_token_table_vs_float64(dev, B, S, K, N):
+    """runtime._X3LinearTableFn (the query decoder's [K | V] projection in parity-mode training, query_decoder.project_kv): y[b] =
+    x[b] W^T + table with the (S, N) table in the GEMM's row-periodic residual input (`cgg_gemm_x3_ex`, res_mod = S; S not a
+    multiple of the tile height: a tile then spans two images) vs float64 autograd -- y, dx, dW and d table = sum over images."""
+    from cgg_amd import runtime
+    g = torch.Generator().manual_seed(B * S + N)
+    x = torch.randn(B, S, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    t = torch.randn(S, N, generator=g)
+    gy = torch.randn(B, S, N, generator=g) * 1e-3
+    xd, wd, td = (v.double().requires_grad_(True) for v in (x, w, t))
+    yd = F.linear(xd, wd) + td[None]
+    yd.backward(gy.double())
+    xg, wg, tg = (v.to(dev).requires_grad_(True) for v in (x, w, t))
+    with runtime.precision_scope('fp32'):
+        y = runtime._X3LinearTableFn.apply(xg, wg, tg)
+        y.backward(gy.to(dev))
+    for got, want, name in ((y, yd, 'y'), (xg.grad, xd.grad, 'dx'), (wg.grad, wd.grad, 'dW'), (tg.grad, td.grad, 'dtable')):
+        scale = want.abs().max().item()
+        err = (got.detach().cpu().double() - want.detach()).abs().max().item()
+        assert err <= 2e-5 * scale, (name, err, scale)
+
+
 def test_overflow_in_the_stream_is_reported_not_silent(dev):
     """A stored activation beyond the f16 x 3 range (|a| >= 4094) must not pass silently as inf / NaN masks: the
     ResNet's x3a producers raise the device flag, `ops.x3_overflow_check` reports it (tools/test.py turns it into an error)."""
