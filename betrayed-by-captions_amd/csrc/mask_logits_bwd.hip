@@ -37,7 +37,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(512) void cgg_mask_logits_grad_feat_kernel(const float* __restrict__ embed,
                                                                         const float* __restrict__ gout,
                                                                         float* __restrict__ gfeat, int Q, int npix, int T,
-                                                                        int KS) {
+                                                                        int KS, int q0, int Qtot, int accumulate) {
   constexpr int C = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   mlb_u32x4* a_hi = reinterpret_cast<mlb_u32x4*>(smem_raw);            // [8 ct][KS][64]
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(512) void cgg_mask_logits_grad_feat_kernel(const fl
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
   // ---- prologue: embed^T[b] -> A fragments: slot (ct, ks, lane) = E[q = 16 ks + 8 hi + e][c = 32 ct + j], e = 0..7 ----
-  const float* eb = embed + (size_t)b * Q * C;
+  // rows [q0, q0 + Q) of the (B, Qtot, .) operands; accumulate: a later row group adds into the first group's result
+  const float* eb = embed + ((size_t)b * Qtot + q0) * C;
   for (int s = tid; s < 8 * KS * 64; s += 512) {
     const int sl = s & 63, ks = (s >> 6) % KS, ct = (s >> 6) / KS;
     const int c = 32 * ct + (sl & 31), q0 = 16 * ks + 8 * (sl >> 5);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(512) void cgg_mask_logits_grad_feat_kernel(const fl
     if (SPLIT) a_lo[s] = l;
   }
   __syncthreads();
-  const float* gb = gout + (size_t)b * Q * npix;
+  const float* gb = gout + ((size_t)b * Qtot + q0) * npix;
   float* ob = gfeat + (size_t)b * C * npix;
   for (int t = blockIdx.x * 8 + wave; t < T; t += gridDim.x * 8) {
     const int p = 32 * t + j;
@@ -117,8 +118,10 @@ __global__ __launch_bounds__(512) void cgg_mask_logits_grad_feat_kernel(const fl
         float* crow = ob + (size_t)(32 * ct) * npix;                           // uniform
         const unsigned soff = (unsigned)(4 * hi) * (unsigned)npix + (unsigned)p;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          __builtin_nontemporal_store(acc[r], crow + (size_t)((r & 3) + 8 * (r >> 2)) * npix + soff);
+        for (int r = 0; r < 16; ++r) {
+          float* dst = crow + (size_t)((r & 3) + 8 * (r >> 2)) * npix + soff;
+          __builtin_nontemporal_store(accumulate ? *dst + acc[r] : acc[r], dst);
+        }
       }
     }
   }
@@ -263,24 +266,30 @@ extern "C" int cgg_mask_logits_backward(const float* embed, const float* feat, c
   CGG_REQUIRE(embed && feat && grad_out && ws && (grad_embed || grad_feat), CGG_EINVAL, "cgg_mask_logits_backward: null pointer");
   CGG_REQUIRE(B > 0 && Q > 0 && npix > 0, CGG_EINVAL, "cgg_mask_logits_backward: bad sizes");
   CGG_REQUIRE(C == 256, CGG_EUNSUPPORTED, "cgg_mask_logits_backward: C=%d (only 256 is built)", C);
-  CGG_REQUIRE(Q <= (split ? 128 : 256), CGG_EUNSUPPORTED, "cgg_mask_logits_backward: Q=%d > %d", Q, split ? 128 : 256);
   CGG_REQUIRE(npix % 8 == 0, CGG_EUNSUPPORTED, "cgg_mask_logits_backward: npix=%d must be a multiple of 8", npix);
   CGG_REQUIRE(cgg_aligned16(embed) && cgg_aligned16(feat) && cgg_aligned16(grad_out) && cgg_aligned16(ws) &&
                   (!grad_embed || cgg_aligned16(grad_embed)) && (!grad_feat || cgg_aligned16(grad_feat)),
               CGG_EALIGN, "cgg_mask_logits_backward: buffers must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
   if (grad_feat) {
-    const int T = (npix + 31) / 32, KS = (Q + 15) / 16;
-    const size_t lds = (size_t)8 * KS * 64 * 16 * (split ? 2 : 1);
+    // query rows in groups of <= 128 (split: the lo fragments of 8 k-steps live in registers) / 256; a group after the first adds
+    // into the result of the ones before it (same lane, same element: no atomics, fixed order)
+    const int lim = split ? 128 : 256;
+    const int T = (npix + 31) / 32;
     int gx = (T + 7) / 8, cap = (512 + B - 1) / B;
     if (gx > cap) gx = cap;
     auto kern = split ? cgg_mask_logits_grad_feat_kernel<true> : cgg_mask_logits_grad_feat_kernel<false>;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_mask_logits_backward: cannot raise dynamic LDS to %zu", lds);
+    for (int q0 = 0; q0 < Q; q0 += lim) {
+      const int qc = Q - q0 < lim ? Q - q0 : lim;
+      const int KS = (qc + 15) / 16;
+      const size_t lds = (size_t)8 * KS * 64 * 16 * (split ? 2 : 1);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_mask_logits_backward: cannot raise dynamic LDS to %zu", lds);
+      }
+      hipLaunchKernelGGL(kern, dim3(gx, B), dim3(512), lds, s, embed, grad_out, grad_feat, qc, npix, T, KS, q0, Q, q0 > 0 ? 1 : 0);
+      CGG_CHECK_LAUNCH("cgg_mask_logits_backward(grad_feat)");
     }
-    hipLaunchKernelGGL(kern, dim3(gx, B), dim3(512), lds, s, embed, grad_out, grad_feat, Q, npix, T, KS);
-    CGG_CHECK_LAUNCH("cgg_mask_logits_backward(grad_feat)");
   }
   if (grad_embed) {
     int spc, nch;

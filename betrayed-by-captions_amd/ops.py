@@ -340,33 +340,23 @@ def mask_logits_backward_ok(embed, feat):
 
 def mask_logits_backward(embed, feat, grad_out, split, need_embed=True, need_feat=True):
     """Gradients of einsum('bqc,bchw->bqhw', embed, feat): embed (B,Q,C) f32, feat (B,C,h,w) f32, grad_out (B,Q,h,w) f32
-    -> (grad_embed (B,Q,C) | None, grad_feat (B,C,h,w) | None) on cgg_mask_logits_backward. Row groups beyond the
-    kernel's limit (128 in split mode, 256 otherwise) are separate launches; their grad_feat parts are summed."""
+    -> (grad_embed (B,Q,C) | None, grad_feat (B,C,h,w) | None) on cgg_mask_logits_backward (any Q: the library walks the row
+    groups of its kernels -- 128 rows in split mode, 256 otherwise -- on the operands in place and sums their grad_feat parts
+    in the kernel's store; round 5: no row-group copies of grad_out, no partial grad_feat maps)."""
     B, Q, C = embed.shape
     h, w = feat.shape[-2:]
     npix = h * w
-    lim = 128 if split else 256
     feat = feat.contiguous()
     go = grad_out.contiguous()
+    embed = embed.contiguous()
     lib = _lib_()
     ge = torch.empty((B, Q, C), dtype=torch.float32, device=embed.device) if need_embed else None
-    gf = None
-    for s0 in range(0, Q, lim):
-        s1 = min(Q, s0 + lim)
-        e_part = embed[:, s0:s1].contiguous()
-        g_part = go[:, s0:s1].contiguous() if (s0 > 0 or s1 < Q) else go
-        n = s1 - s0
-        ws = _workspace(lib.cgg_mask_logits_backward_workspace_bytes(B, n, C, npix), embed.device)
-        ge_part = torch.empty((B, n, C), dtype=torch.float32, device=embed.device) if need_embed else None
-        gf_part = torch.empty((B, C, h, w), dtype=torch.float32, device=embed.device) if need_feat else None
-        rc = lib.cgg_mask_logits_backward(dev_ptr(e_part, 'embed', torch.float32), dev_ptr(feat, 'feat', torch.float32),
-                                          dev_ptr(g_part, 'grad_out', torch.float32), dev_ptr(ge_part), dev_ptr(gf_part),
-                                          dev_ptr(ws), B, n, C, npix, int(bool(split)), stream_ptr(embed.device))
-        check(rc, 'cgg_mask_logits_backward')
-        if need_embed:
-            ge[:, s0:s1] = ge_part
-        if need_feat:
-            gf = gf_part if gf is None else gf.add_(gf_part)
+    gf = torch.empty((B, C, h, w), dtype=torch.float32, device=embed.device) if need_feat else None
+    ws = _workspace(lib.cgg_mask_logits_backward_workspace_bytes(B, min(Q, 128), C, npix), embed.device)
+    rc = lib.cgg_mask_logits_backward(dev_ptr(embed, 'embed', torch.float32), dev_ptr(feat, 'feat', torch.float32),
+                                      dev_ptr(go, 'grad_out', torch.float32), dev_ptr(ge), dev_ptr(gf), dev_ptr(ws), B, Q, C, npix,
+                                      int(bool(split)), stream_ptr(embed.device))
+    check(rc, 'cgg_mask_logits_backward')
     return ge, gf
 
 

@@ -177,9 +177,10 @@ int cgg_mask_logits_f32(const float* embed, const float* feat, float* out, uint3
  *   grad_feat [B, C, npix] f32 = sum_q embed[b][q][c] * grad_out[b][q][p]     (nullable: skipped)
  *   grad_embed[B, Q, C]   f32 = sum_p grad_out[b][q][p] * feat[b][c][p]       (nullable: skipped)
  * embed [B, Q, C] f32, feat [B, C, npix] f32 (the un-packed mask feature), grad_out [B, Q, npix] f32; outputs are written,
- * not accumulated. bf16 MFMA with f32 accumulation; split != 0 = 3 MFMAs on (hi, lo) bf16 pairs (f32-class accuracy,
- * Q <= 128), else Q <= 256. ws: cgg_mask_logits_backward_workspace_bytes(...) bytes (grad_embed partial planes, summed
- * in a fixed order: no atomics). Requires C == 256, npix % 8 == 0.                                                  */
+ * not accumulated. bf16 MFMA with f32 accumulation; split != 0 = 3 MFMAs on (hi, lo) bf16 pairs (f32-class accuracy).
+ * Any Q: query rows are processed in groups of 128 (split) / 256 launches, a later group adding into grad_feat in place
+ * (same lane, same element, fixed order). ws: cgg_mask_logits_backward_workspace_bytes(...) bytes (grad_embed partial
+ * planes, summed in a fixed order: no atomics). Requires C == 256, npix % 8 == 0.                                     */
 int64_t cgg_mask_logits_backward_workspace_bytes(int B, int Q, int C, int npix);
 int cgg_mask_logits_backward(const float* embed, const float* feat, const float* grad_out, float* grad_embed,
                              float* grad_feat, void* ws, int B, int Q, int C, int npix, int split, cgg_stream_t stream);
