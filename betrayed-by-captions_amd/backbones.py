@@ -17,6 +17,7 @@ from .registry import BACKBONES
 FUSED_BOTTLENECK = os.environ.get('CGG_FUSED_BOTTLENECK', '1') != '0'
 # training: frozen stem + stages on the BN-folded inference path under no_grad (CGG_FROZEN_FOLDED=0 = autograd-recorded torch path)
 FROZEN_FOLDED = os.environ.get('CGG_FROZEN_FOLDED', '1') != '0'
+FROZEN_NHWC_BF16 = os.environ.get('CGG_FROZEN_NHWC_BF16', '1') != '0'   # throughput mode: frozen stages' maps through the transpose kernel
 # parity mode: the 7x7 stem on the x3 MFMA kernel (CGG_X3_STEM=0 = MIOpen f32 convolution, A/B)
 X3_STEM = os.environ.get('CGG_X3_STEM', '1') != '0'
 
@@ -440,6 +441,7 @@ class ResNet(nn.Module):
             with torch.no_grad():
                 fouts, xf = self._forward_folded(x, upto=self.frozen_stages)
             outs = [o.permute(0, 3, 1, 2) for o in fouts]
+            frozen_nhwc = list(fouts)
             x = xf.permute(0, 3, 1, 2)                       # channels-last strided (B, C, H, W) bf16 view
             first = self.frozen_stages
         with runtime.autocast():
@@ -461,12 +463,14 @@ class ResNet(nn.Module):
         res = []
         for k, o in enumerate(outs):
             src = frozen_nhwc[k] if k < len(frozen_nhwc) else None
-            if src is not None and src.dtype == torch.float32 and src.is_cuda and src.is_contiguous() and not src.requires_grad:
-                # a frozen stage's channel-last f32 map: NCHW by the tiled transpose kernel (ATen's strided clone of the 1-GB stride-4
-                # map took 1.1 ms, this 0.35), and the channel-last original rides along for consumers that read rows
-                # (`runtime.fpn_level_x3_train`)
-                t = ops.nhwc_to_nchw(src)
-                t._cgg_nhwc = src
+            if (src is not None and (src.dtype == torch.float32 or (src.dtype == torch.bfloat16 and FROZEN_NHWC_BF16))
+                    and src.is_cuda and src.is_contiguous() and not src.requires_grad):
+                # a frozen stage's channel-last map (f32 in parity mode, bf16 in throughput mode: one contiguous cast pass first): NCHW
+                # by the tiled transpose kernel (ATen's strided clone of the 1-GB stride-4 map took 1.1 ms, this 0.35), and the
+                # channel-last f32 original rides along for consumers that read rows (`runtime.fpn_level_x3_train`)
+                f = src if src.dtype == torch.float32 else src.float()
+                t = ops.nhwc_to_nchw(f)
+                t._cgg_nhwc = f
                 res.append(t)
             else:
                 res.append(o.float().contiguous())
