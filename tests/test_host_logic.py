@@ -490,3 +490,56 @@ def test_splitk_linear_function_matches_autograd_on_cpu():
     assert (got[2].double() - gw64).abs().max().item() <= 2 ** -8 * gw64.abs().max().item() + 1e-3
     assert (got[3].double() - gy.double().sum(0)).abs().max().item() <= 1e-2
     assert got[2].dtype == torch.float32 and got[3].dtype == torch.float32
+
+
+def test_batched_targets_cost_formulation_equals_oracle_on_cpu():
+    """Host logic of `Mask2FormerHeadOpen._targets_batched` on CPU tensors (no kernel involved): the cost matrices built from the
+    prediction-only halves -- sum_p softplus(x) - x . t for mmdet's pos . t + neg . (1 - t), one sigmoid for the dice numerator --
+    against the oracle's per-(layer, image) `get_target_single` (reference: open_set/models/mask2former_head.py:320-390,
+    assigners/mask_hungarian_assigner.py:100-143) with the same pinned random points: costs within 1e-5, labels equal; one image
+    without ground truth."""
+    import warnings
+    from cgg_amd import synthetic
+    from util import build_heads, small_cfg
+
+    class Bank:
+        def __init__(self, seed):
+            self.seed, self.count = seed, {}
+
+        def __call__(self, kind, shape, device):
+            i = self.count.get(kind, 0)
+            self.count[kind] = i + 1
+            g = torch.Generator().manual_seed(self.seed + 1000 * i + {'target': 1, 'oversample': 2, 'random': 3}[kind])
+            return torch.rand(*shape, generator=g).to(device)
+
+    cfg = small_cfg(num_queries=12, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prod, orc = build_heads(cfg)
+    prod.train()
+    B, n, Q, h, H = 3, len(prod.transformer_decoder.layers) + 1, 12, 32, 128
+    K1 = prod.class_embs.shape[0]
+    g = torch.Generator().manual_seed(5)
+    batch = synthetic.train_batch(B, H, H, num_classes=cfg['panoptic_head']['num_things_classes'], max_inst=4, vocab=500, seed=3)
+    gt_labels, gt_masks = batch['gt_labels'], [m.long() for m in batch['gt_masks']]
+    gt_labels[1], gt_masks[1] = gt_labels[1][:0], gt_masks[1][:0]
+    cls = [torch.randn(B, Q, K1, generator=g) for _ in range(n)]
+    emb = [torch.randn(B, Q, K1, generator=g) * 2 for _ in range(n)]
+    masks = [torch.randn(B, Q, h, h, generator=g) * 2 for _ in range(n)]
+    orc.point_hook = Bank(11)
+    ref = [[orc.get_target_single(cls[li][b], emb[li][b], masks[li][b], gt_labels[b], gt_masks[b]) for b in range(B)]
+           for li in range(n)]
+    prod.point_hook = Bank(11)
+    prod.cost_trace = []
+    out = prod._targets_batched(cls, emb, masks, gt_labels, [m.float() for m in gt_masks])
+    costs = dict(prod.cost_trace)
+    prod.cost_trace = None
+    for li in range(n):
+        labels = out[li][0]
+        for b in range(B):
+            r_labels, r_cost = ref[li][b][0], ref[li][b][6]
+            if gt_labels[b].numel() == 0:
+                assert (labels[b] == prod.num_classes).all()
+                continue
+            assert torch.allclose(costs[b][li], r_cost, atol=1e-5, rtol=1e-5), (li, b)
+            assert torch.equal(labels[b], r_labels), (li, b)
