@@ -469,9 +469,7 @@ class ResNet(nn.Module):
                 # by the tiled transpose kernel (ATen's strided clone of the 1-GB stride-4 map took 1.1 ms, this 0.35), and the
                 # channel-last f32 original rides along for consumers that read rows (`runtime.fpn_level_x3_train`)
                 f = src if src.dtype == torch.float32 else src.float()
-                t = ops.nhwc_to_nchw(f)
-                t._cgg_nhwc = f
-                res.append(t)
+                res.append(runtime.hand_nhwc(ops.nhwc_to_nchw(f), f))
             else:
                 res.append(o.float().contiguous())
         return tuple(res)

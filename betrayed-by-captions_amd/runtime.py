@@ -640,14 +640,34 @@ def x3_fpn_level_ok(pd, x, lo_hw):
     return bool(ok)
 
 
+def hand_nhwc(nchw, nhwc):
+    """Attach the contiguous channel-last f32 tensor `nchw` (B, C, H, W) was transposed from, for consumers that read rows; valid only
+    while neither tensor is written in place (`handed_nhwc` checks both version counters)."""
+    nchw._cgg_nhwc = nhwc
+    nchw._cgg_nhwc_versions = (nchw._version, nhwc._version)
+    return nchw
+
+
+def handed_nhwc(x):
+    """The channel-last f32 original of the NCHW map x (`hand_nhwc`), or None: absent, x under autograd, shapes / dtype that do not
+    match, or either tensor modified in place since the hand-over."""
+    nh = getattr(x, '_cgg_nhwc', None)
+    if nh is None or x.requires_grad or x.dim() != 4 or nh.dtype != torch.float32 or not nh.is_contiguous():
+        return None
+    B, C, H, W = x.shape
+    if tuple(nh.shape) != (B, H, W, C) or getattr(x, '_cgg_nhwc_versions', None) != (x._version, nh._version):
+        return None
+    return nh
+
+
 def fpn_level_x3_train(pd, x, lo_rows, lo_hw):
     """mask_feature (B, C_out, H, W) of the pixel decoder from the stride-4 backbone map x (B, Cin, H, W) and the finest encoder memory
     level lo_rows (B, h w, C) -- see `x3_fpn_level_ok`."""
     lat, outc, mf = pd.lateral_convs[0], pd.output_convs[0], pd.mask_feature
     gn1, gn2 = getattr(lat, lat.norm_name), getattr(outc, outc.norm_name)
     B, Cin, H, W = x.shape
-    nh = getattr(x, '_cgg_nhwc', None)            # a frozen backbone stage hands its channel-last original along (backbones.ResNet)
-    if nh is not None and not x.requires_grad and nh.dtype == torch.float32 and tuple(nh.shape) == (B, H, W, Cin) and nh.is_contiguous():
+    nh = handed_nhwc(x)                           # a frozen backbone stage hands its channel-last original along (backbones.ResNet)
+    if nh is not None:
         xr = nh.view(B, H * W, Cin)
     else:
         xr = _NchwToRowsFn.apply(x.float())

@@ -543,3 +543,20 @@ def test_batched_targets_cost_formulation_equals_oracle_on_cpu():
                 continue
             assert torch.allclose(costs[b][li], r_cost, atol=1e-5, rtol=1e-5), (li, b)
             assert torch.equal(labels[b], r_labels), (li, b)
+
+
+def test_channel_last_hand_over_is_dropped_after_in_place_writes():
+    """`runtime.hand_nhwc` / `handed_nhwc` (frozen ResNet stages hand their channel-last f32 maps to the FPN rows path): the original
+    is returned only for the very tensor it was attached to, and not after either tensor was written in place."""
+    from cgg_amd import runtime
+    f = torch.randn(2, 4, 5, 8)
+    t = runtime.hand_nhwc(f.permute(0, 3, 1, 2).contiguous(), f)
+    assert runtime.handed_nhwc(t) is f
+    assert runtime.handed_nhwc(t.clone()) is None and runtime.handed_nhwc(torch.randn(2, 8, 4, 5)) is None
+    t.add_(1)
+    assert runtime.handed_nhwc(t) is None
+    t = runtime.hand_nhwc(f.permute(0, 3, 1, 2).contiguous(), f)
+    f.mul_(2)
+    assert runtime.handed_nhwc(t) is None
+    t = runtime.hand_nhwc(f.permute(0, 3, 1, 2).contiguous(), f)
+    assert runtime.handed_nhwc(t.requires_grad_(True)) is None
