@@ -34,6 +34,7 @@ f32-class arithmetic on the f16 matrix cores (csrc/x3.h), the mode the 1e-3 / bi
 import argparse
 import json
 import os
+import re
 import sys
 import time
 import warnings
@@ -66,6 +67,197 @@ WORKLOADS = {
     'cfg4': dict(mode='infer', backbone='r50', queries=100, hw=(800, 1344), batch=2, panoptic=True,
                  name='configs[4]: COCO-panoptic (80 things + 53 stuff), 1333x800 padded to 800x1344, batch 2/GPU, forward-only'),
 }
+
+
+LINE_LIMIT = 4096       # bytes of the final stdout line (the driver keeps an 8 KB tail; round 5's 36 KB line came back `parsed: null`)
+
+
+def _r(x, n=4):
+    """float -> n significant digits (the compact line carries numbers, not prose; the full record keeps full precision)"""
+    if isinstance(x, float):
+        if x != x or x in (float('inf'), float('-inf')):
+            return None
+        return float(f'{x:.{n}g}')
+    return x
+
+
+def _finite(o):
+    """strict-JSON form of a record: non-finite floats -> None (json.dumps would print NaN / Infinity, which is not JSON)"""
+    if isinstance(o, float):
+        return o if (o == o and abs(o) != float('inf')) else None
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def _pick(d, *keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def _roof_short(r):
+    """name-only kernel + the roofline numbers of one kernel / family object of the full record"""
+    if not isinstance(r, dict):
+        return None
+    o = {}
+    if r.get('kernel'):
+        o['kernel'] = re.split(r'[ <(]', r['kernel'], 1)[0]
+    o['bound'] = r.get('bound')
+    ach = r.get('achieved', r.get('achieved_GBs') if r.get('bound') == 'hbm' else None)
+    peak = r.get('peak', HBM_PEAK_GBS if r.get('bound') == 'hbm' else None)
+    frac = r.get('frac', r.get('frac_hbm_peak'))
+    o.update(achieved=_r(ach), peak=_r(peak), unit=r.get('unit', 'GB/s' if r.get('bound') == 'hbm' else 'TFLOP/s'), frac=_r(frac),
+             traffic=_r(r.get('traffic', r.get('traffic_bytes_per_step'))))
+    for src, dst in (('algorithmic_bytes_per_step', 'algorithmic_bytes_per_step'), ('algorithmic_bytes', 'algorithmic_bytes'),
+                     ('flops_per_step', 'flops_per_step'), ('flops', 'flops'), ('ms_per_step', 'ms_per_step'), ('launch_ms', 'launch_ms'),
+                     ('launches_per_step', 'launches_per_step'), ('share_of_step', 'share_of_step')):
+        if r.get(src) is not None:
+            o[dst] = _r(r[src])
+    return o
+
+
+def _train_short(t):
+    if not isinstance(t, dict):
+        return None
+    if 'error' in t:
+        return dict(error=str(t['error'])[:120])
+    o = _pick(t, 'value', 'ms_per_step', 'n_gpus', 'loss', 'launches_per_step', 'hand_written_share_of_kernel_time')
+    o['dtype'] = str(t.get('dtype', '')).split(' ')[0]
+    if isinstance(t.get('roofline'), dict):
+        rr = _roof_short(t['roofline'])
+        o['roofline'] = {k: rr[k] for k in ('kernel', 'bound', 'frac', 'ms_per_step', 'share_of_step') if rr.get(k) is not None}
+    if isinstance(t.get('bf16_mode'), dict):
+        o['bf16'] = _pick(t['bf16_mode'], 'value', 'ms_per_step', 'error')
+    return o
+
+
+def compact_record(res):
+    """The driver-readable form of a full bench record: the contract keys + `roofline` + `cpu_baseline` + one short object per
+    secondary measurement, numbers only (4 significant digits), every string short. `emit` asserts it stays under LINE_LIMIT."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data')
+    out = {k: res.get(k) for k in keep}
+    out['dtype'] = str(out['dtype']).split(' ')[0] if out.get('dtype') else out.get('dtype')
+    cfg = res.get('config') or {}
+    wl = str(cfg.get('workload', ''))
+    c = dict(workload=wl.split(' (')[0][:120], global_batch=cfg.get('global_batch'), parallelism=cfg.get('parallelism'))
+    if cfg.get('precision'):
+        c['precision'] = str(cfg['precision']).split(' ')[0] + (' (parity mode, f16x3 MFMA)' if str(cfg['precision']).startswith('fp32') else '')
+    for k in ('hip_graph', 'x3_overflow', 'ranks_share_devices', 'trainable_params', 'grad_buckets'):
+        if cfg.get(k) is not None:
+            c[k] = cfg[k]
+    if isinstance(cfg.get('library_fallbacks'), dict):
+        c['library_fallbacks'] = cfg['library_fallbacks'].get('count')
+    ag = cfg.get('parity_mode_agreement_without_injection')
+    if isinstance(ag, dict) and isinstance(ag.get('record'), dict):
+        c['no_injection'] = _pick(ag['record'], 'final_mask_logit_err', 'attn_mask_bit_agreement_min', 'topk_pairs_swapped_max',
+                                  'det_score_abs_err_max')
+    out['config'] = c
+    if res.get('latency_ms_per_batch') is not None:
+        out['latency_ms_per_batch'] = _r(res['latency_ms_per_batch'])
+    for k in ('value', 'ms_per_step'):
+        out[k] = _r(out[k], 6) if out.get(k) is not None else None
+    out['roofline'] = _roof_short(res.get('roofline'))
+    ks = {}
+    for name, r in (res.get('kernels') or {}).items():
+        rr = _roof_short(r)
+        if rr:
+            ks[name] = {k: rr[k] for k in ('bound', 'frac', 'traffic', 'launch_ms', 'ms_per_step', 'algorithmic_bytes', 'flops')
+                        if rr.get(k) is not None}
+    if ks:
+        out['kernels'] = ks
+    sw = res.get('einsum_mfma_target')
+    if sw:
+        rows = [r for r in sw if 'queries' in r]
+        if rows:
+            best = max(rows, key=lambda r: r['frac_mfma_peak'] * (r['mfma_peak_tf'] / MFMA_BF16_PEAK_TF))
+            out['einsum'] = dict(
+                target='>=0.40 of 2500 TF bf16 MFMA', kernel='bqc,bchw->bqhw',
+                best=dict(B=best.get('batch'), Q=best['queries'], form=best.get('form', best['mode'][:24]),
+                          frac_bf16_mfma_peak=_r(best['tflops'] / MFMA_BF16_PEAK_TF), tflops=_r(best['tflops']), launch_ms=_r(best['launch_ms'])),
+                rows=[[r.get('batch'), r['queries'], r.get('form', r['mode'][:24]), _r(r['tflops'] / MFMA_BF16_PEAK_TF, 3),
+                       _r(r['frac_hbm_peak'], 3)] for r in rows],
+                row_keys=['B', 'Q', 'form', 'frac_bf16_mfma_peak', 'frac_hbm_peak'])
+            cp = [r for r in sw if 'reference' in r]
+            if cp:
+                out['einsum']['copy_frac_hbm_peak'] = _r(cp[0]['frac_hbm_peak'], 3)
+    b = res.get('bf16_mode')
+    if isinstance(b, dict):
+        o = _pick(b, 'value', 'ms_per_step')
+        rec = (b.get('agreement_with_f32_oracle') or {}).get('record')
+        if isinstance(rec, dict):
+            if rec.get('attn_mask_bit_agreement_per_layer'):
+                o['attn_bit_agreement_min'] = min(rec['attn_mask_bit_agreement_per_layer'])
+            o.update(_pick(rec, 'mask_iou_mean', 'topk_pair_jaccard_mean', 'panoptic_pixel_agreement'))
+        out['bf16_mode'] = o
+    h = res.get('host_results')
+    if isinstance(h, dict):
+        out['host_results'] = dict(_pick(h, 'value', 'rle_bytes_per_mask'),
+                                   trained_like_masks=_r((h.get('trained_like_masks') or {}).get('value')))
+    cb = res.get('cpu_baseline')
+    if isinstance(cb, dict):
+        o = _pick(cb, 'value', 'unit', 'cores', 'threads', 'kind', 'host_logical_cpus')
+        o['sample'] = str(cb.get('sample', '')).split(' (')[0][:100]
+        if isinstance(cb.get('cfg1_512'), dict):
+            o['configs0_512x512'] = _r(cb['cfg1_512'].get('value'))
+        out['cpu_baseline'] = o
+    if res.get('train_step') is not None:
+        out['train_step'] = _train_short(res['train_step'])
+    ex = res.get('extra')
+    if isinstance(ex, dict):
+        e = {}
+        c3, c4 = ex.get('configs[3]'), ex.get('configs[4]')
+        if c3 is not None:
+            e['cfg3'] = _train_short(c3)
+        if isinstance(c4, dict):
+            if 'error' in c4:
+                e['cfg4'] = dict(error=str(c4['error'])[:120])
+            else:
+                o = _pick(c4, 'value', 'ms_per_step')
+                if isinstance(c4.get('roofline'), dict):
+                    o['roofline_frac'] = _r(c4['roofline'].get('frac'))
+                if isinstance(c4.get('bf16_mode'), dict):
+                    o['bf16'] = _r(c4['bf16_mode'].get('value'))
+                e['cfg4'] = o
+        out['extra'] = e
+    for k in ('loss', 'peak_mem_gb'):
+        if res.get(k) is not None:
+            out[k] = _r(res[k])
+    return out
+
+
+def emit(res, full_path=None, stream=None):
+    """Write the full record to `full_path` (default gpurun_out/bench_full.json; also echoed on stderr) and print the compact line --
+    ONE line of strict JSON under LINE_LIMIT bytes -- as the last line of stdout. If the compact record ever outgrows the
+    limit, the optional objects are dropped largest first (never `roofline` / `cpu_baseline`) and the line says which."""
+    stream = stream or sys.stdout
+    full_path = full_path or os.path.join(ROOT, 'gpurun_out', 'bench_full.json')
+    try:
+        os.makedirs(os.path.dirname(full_path), exist_ok=True)
+        with open(full_path, 'w') as f:
+            json.dump(_finite(res), f, indent=1, allow_nan=False)
+    except OSError as e:
+        print(f'bench.py: could not write {full_path}: {e}', file=sys.stderr)
+        full_path = None
+    rec = _finite(compact_record(res))
+    if full_path:
+        rec['full_record'] = os.path.relpath(full_path, ROOT)
+    dropped = []
+    line = json.dumps(rec, allow_nan=False, separators=(',', ':'))
+    optional = ['einsum', 'kernels', 'extra', 'host_results', 'bf16_mode', 'train_step']
+    while len(line) >= LINE_LIMIT and optional:
+        k = max(optional, key=lambda k: len(json.dumps(rec.get(k))) if k in rec else -1)
+        optional.remove(k)
+        if k in rec:
+            del rec[k]
+            dropped.append(k)
+            rec['dropped_for_length'] = dropped
+        line = json.dumps(rec, allow_nan=False, separators=(',', ':'))
+    assert len(line) < LINE_LIMIT, f'bench line is {len(line)} bytes'
+    assert '\n' not in line
+    print(line, file=stream, flush=True)
+    return line
 
 
 def workload_config(args):
@@ -185,6 +377,19 @@ def committed_profile(name):
         return json.load(open(path))
     except Exception:
         return None
+
+
+AGREEMENT_KEYS = ('configs1_fp32_no_injection', 'configs1_bf16', 'configs3_bf16', 'configs4_bf16', 'configs2_train_slice',
+                  'configs3_train_slice')
+
+
+def agreement_records():
+    """(records, path) of the newest committed agreement profile (tools/collect_agreement.sh publish)."""
+    for name in ('r6_agreement.json', 'r5_agreement.json'):
+        d = committed_profile(name)
+        if d:
+            return d, 'profiles/' + name
+    return {}, 'profiles/r6_agreement.json'
 
 
 def host_results_rate(args, model, img, metas, dev):
@@ -389,10 +594,20 @@ def time_mode(args, model, img, metas, dev, precision, barrier, collect_events):
     return out
 
 
+def emit_result(args, res):
+    """rank 0's output: a child of another bench.py run (`--full-line`) hands its parent the full record as one stdout line; every
+    other run prints the compact line (and leaves the full record in gpurun_out/)."""
+    if args.full_line:
+        print(json.dumps(_finite(res), allow_nan=False), flush=True)
+        return
+    name = 'bench_full.json' if args.workload == 'cfg1' else f'bench_full_{args.workload}.json'
+    emit(res, full_path=os.path.join(ROOT, 'gpurun_out', name))
+
+
 def train_main(args, cfg, model, img, metas, dev, rank, world):
     res = train_run(args, cfg, model, img, metas, dev, rank, world)
     if rank == 0:
-        print(json.dumps(res))
+        emit_result(args, res)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -629,24 +844,29 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
 
 
 def einsum_q_sweep(dev, B, H, W):
-    """BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200 (1024 x 1024 -> 256 x 256 mask feature), both
-    arithmetic modes, launches timed back to back with HIP events (cache-warm: the 10-call sequence of a forward is)."""
+    """BASELINE.json's kernel target: the mask-logit einsum bqc,bchw->bqhw (1024 x 1024 -> 256 x 256 mask feature) at the benched
+    shape (B, Q = 100), at Q = 200, and at the shapes where the fixed cost amortises -- configs[3]'s per-GPU B = 4 x Q = 200 and
+    configs[2]'s B = 16 x Q = 100 -- both arithmetic modes, 20 launches back to back in one hipGraph (cache-warm:
+    the 10-call sequence of a forward is)."""
     from cgg_amd import ops, runtime
     HW4 = (H // 4) * (W // 4)
     g = torch.Generator().manual_seed(7)
-    feat = torch.randn(B, 256, H // 4, W // 4, generator=g).to(dev)
     res = []
-    for Q in (100, 200):
-        emb = torch.randn(B, Q, 256, generator=g).to(dev)
+    forms = (('bf16 stored', 'bf16 MFMA, f32 logits out', False, False),
+             ('x3 stored', 'f32-class f16 x 3 MFMA, f32 logits out', True, False),
+             ('bf16 fused', 'bf16 MFMA, consumer fused: threshold bits out, logits never stored', False, True),
+             ('x3 fused', 'f32-class f16 x 3 MFMA, consumer fused: threshold bits out, logits never stored', True, True),
+             ('bf16 fused astat', 'bf16 MFMA, consumer fused + query tiles stationary in registers (cgg_mask_logits_bits_astat): '
+                                  'threshold bits out, logits never stored', False, 'astat'))
+    for Bs, Q in ((B, 100), (B, 200), (4, 200), (16, 100)):
+        feat = torch.randn(Bs, 256, H // 4, W // 4, generator=g).to(dev)
+        emb = torch.randn(Bs, Q, 256, generator=g).to(dev)
         # `fused` = the consumer in the epilogue, logits NEVER stored: the full-resolution contraction with the attention-mask rule
         # (mask2former_head.py:749-759: threshold) applied to the accumulators, one bit per (query, pixel) out -- the form SURVEY 7
         # names as the only one that can approach the MFMA roofline (the stored-f32-logits form is HBM-bound at AI = 56-100 FLOP/B).
-        # 10 back-to-back calls per sample = the 10 forward_head calls of a forward (the 67-MB bf16 feature stays cache-resident)
-        for mode, split, fused in (('bf16 MFMA, f32 logits out', False, False), ('f32-class f16 x 3 MFMA, f32 logits out', True, False),
-                                   ('bf16 MFMA, consumer fused: threshold bits out, logits never stored', False, True),
-                                   ('f32-class f16 x 3 MFMA, consumer fused: threshold bits out, logits never stored', True, True),
-                                   ('bf16 MFMA, consumer fused + query tiles stationary in registers (cgg_mask_logits_bits_astat): '
-                                    'threshold bits out, logits never stored', False, 'astat')):
+        for form, mode, split, fused in forms:
+            if Bs != B and not fused and split:
+                continue                                   # the big shapes: fused forms + the bf16 stored form
             with runtime.precision_scope('fp32' if split else 'bf16'):
                 packed = ops.pack_mask_feature(feat, 1, split)
                 if split:
@@ -685,18 +905,23 @@ def einsum_q_sweep(dev, B, H, W):
                     e.record()
                     torch.cuda.synchronize()
                     ms = s.elapsed_time(e) / 100
+                    del gr
                 except Exception as ex:          # loud: the line says which figure it carries
                     print(f'bench.py: einsum sweep graph capture failed ({type(ex).__name__}: {ex}); eager timing', file=sys.stderr)
-            fl = 2.0 * B * Q * 256 * HW4
-            by = B * (256 * HW4 * (4 if split else 2) + Q * 256 * 4 + (Q * HW4 // 8 if fused else Q * HW4 * 4))
+                del packed
+            fl = 2.0 * Bs * Q * 256 * HW4
+            by = Bs * (256 * HW4 * (4 if split else 2) + Q * 256 * 4 + (Q * HW4 // 8 if fused else Q * HW4 * 4))
             peak = X3_PEAK_TF if split else MFMA_BF16_PEAK_TF
             tf = fl / (ms * 1e-3) / 1e12
             ai = fl / by
-            res.append(dict(queries=Q, mode=mode, launch_ms=ms, launch_ms_eager_loop=ms_eager,
+            res.append(dict(batch=Bs, queries=Q, form=form, mode=mode, launch_ms=ms, launch_ms_eager_loop=ms_eager,
                             timed='20 launches back to back in one hipGraph, 5 replays' if ms != ms_eager else 'eager launches', tflops=tf, frac_mfma_peak=tf / peak, mfma_peak_tf=peak,
+                            frac_bf16_mfma_peak=tf / MFMA_BF16_PEAK_TF,
                             frac_hbm_roofline_attainable=tf / min(peak, ai * HBM_PEAK_GBS / 1e3), GBs=by / (ms * 1e-3) / 1e9,
                             frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=by, flops=fl,
-                            arithmetic_intensity=ai, launches_q_split=2 if (split and Q > 128) else 1))
+                            arithmetic_intensity=ai, launches_q_split=ops.mask_logits_launches(Q, split)))
+        del feat, emb
+        torch.cuda.empty_cache()
     # what this device's memory system delivers to a pure read + write stream of the same size class (torch device copy, 128 MiB
     # in + 128 MiB out): the practical ceiling the `GBs` figures above sit under (the 8 TB/s of `frac_hbm_peak` is the pin rate)
     src = torch.empty(32 << 20, dtype=torch.float32, device=dev).normal_()
@@ -720,7 +945,7 @@ def workload_child(workload, extra_args, timeout=900):
     """Another BASELINE config measured by THIS script in a child process (started after the parent has finished its GPU work,
     never an exec from a GPU-initialised process) -> its parsed JSON line or an error record."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload] + list(extra_args)
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--full-line'] + list(extra_args)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -739,7 +964,7 @@ def train_step_child(args, precision='fp32', workload='cfg2'):
     training arithmetic, open_set/apis/train.py:182-189) / `train_step.bf16_mode` (bf16 autocast: narrower, secondary)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', str(args.train_steps), '--warmup', '3',
-           '--precision', precision]
+           '--precision', precision, '--full-line']
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -818,6 +1043,9 @@ def main():
     ap.add_argument('--no-einsum-sweep', action='store_true', help='skip the Q = 100 / 200 mask-logit einsum launches (profile runs)')
     ap.add_argument('--extra-workloads', type=int, default=1,
                     help='1 (default, rank 0 of a 1-GPU cfg1 run): also measure configs[3] and configs[4] in child processes -> `extra`')
+    ap.add_argument('--full-line', action='store_true',
+                    help='print the FULL record as the stdout line (what a parent bench.py run parses from its children); default: '
+                         'the compact line, full record in gpurun_out/bench_full*.json')
     args = ap.parse_args()
     if args.workload is None:
         args.workload = 'cfg2' if args.mode == 'train' else 'cfg1'
@@ -888,12 +1116,17 @@ def main():
         kernels = kernel_summaries(args, main_mode.get('events', {}), main_mode.get('meta', {}), B, H, W, Q)
     roofline = kernels.pop('gemm_x3', None)
 
-    # agreement with the f32 CPU oracle at this config's real shapes, measured by tests/test_fullsize_gpu.py on an MI355X and
-    # committed by scratch/collect_agreement_r5.sh (`profiles/r5_agreement.json` = the tests' gpurun_out/fullsize_agreement.json):
-    # the bf16 record of THIS config under `bf16_mode`, parity mode's own no-injection record under `config` (VERDICT r4 weak 4:
-    # the r3 file published fp32 numbers under the bf16 heading)
-    agree_all = committed_profile('r5_agreement.json') or {}
+    # agreement with the f32 CPU oracle at this config's real shapes, measured by tests/test_fullsize_gpu.py on an MI355X and committed
+    # by tools/collect_agreement.sh (run on the GPU box, then `publish`): the bf16 record of THIS config under `bf16_mode`, parity
+    # mode's own no-injection record under `config`. A key this line is meant to publish must be there: no `record: null`.
+    agree_all, agree_src = agreement_records()
     agree_key = {'cfg1': 'configs1_bf16', 'cfg4': 'configs4_bf16'}.get(args.workload)
+    need = ([agree_key] if (agree_key and not args.no_bf16_mode and args.precision == 'fp32') else []) + \
+        (['configs1_fp32_no_injection'] if primary else [])
+    missing = [k for k in need if not isinstance(agree_all.get(k), dict)]
+    if missing:
+        raise SystemExit(f'bench.py: {agree_src} lacks the agreement record(s) {missing} this line publishes -- regenerate it with '
+                         'tools/collect_agreement.sh (run on the GPU box, then publish)')
     other = None
     if not args.no_bf16_mode and args.precision == 'fp32':
         o = time_mode(args, model, img, metas, dev, 'bf16', barrier, collect_events=False)
@@ -904,8 +1137,7 @@ def main():
                           ('; NOT a usable panoptic path: one flipped segment-level threshold decision moves up to a third of an '
                            'image\'s pixels (panoptic_pixel_agreement below)' if args.panoptic else ''),
                      agreement_with_f32_oracle=dict(record=agree_all.get(agree_key), key=agree_key,
-                                                    source='committed profile: profiles/r5_agreement.json (tests/test_fullsize_gpu.py, '
-                                                           'bf16 mode, no mask injection)'))
+                                                    source=f'committed profile: {agree_src} (tests/test_fullsize_gpu.py, bf16 mode, no mask injection)'))
     host = None
     if args.host_results and rank == 0 and primary:
         with runtime.precision_scope(args.precision):
@@ -945,7 +1177,7 @@ def main():
                                                   if (f32 and runtime.x3a_enabled()) else 'f32'),
                                parity_mode_agreement_without_injection=dict(
                                    record=agree_all.get('configs1_fp32_no_injection'),
-                                   source='committed profile: profiles/r5_agreement.json (tests/test_fullsize_gpu.py::'
+                                   source=f'committed profile: {agree_src} (tests/test_fullsize_gpu.py::'
                                           'test_configs1_fp32_mode_end_to_end_without_injection, fp32 = parity mode)') if primary else None,
                                x3_overflow=overflow, library_fallbacks=dict(count=runtime.library_fallbacks(), sites=dict(runtime.FALLBACKS)),
                                hip_graph=main_mode['hip_graph'], ranks_share_devices=bool(args.shared_devices),
@@ -993,7 +1225,7 @@ def main():
             ts['how'] = f'the {world} ranks of this run, in-process after the inference region (RCCL gradient all-reduce)'
             res['train_step'] = ts
     if rank == 0:
-        print(json.dumps(res))
+        emit_result(args, res)
     if world > 1:
         dist.destroy_process_group()
 

@@ -23,6 +23,8 @@ _c_i64 = ctypes.c_int64
 # name -> (restype, argtypes); must list every symbol of include/cgg_hip.h
 PROTOTYPES = {
     'cgg_version': (_c_int, []),
+    'cgg_init': (_c_int, [_c_int]),
+    'cgg_msda_read_levels': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
     'cgg_last_error_string': (ctypes.c_char_p, []),
     'cgg_msda_forward': (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     'cgg_msda_forward_fused': (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 2 + [_c_int] * 8 + [_c_vp]),

@@ -191,14 +191,22 @@ __global__ __launch_bounds__(256) void cgg_pack_nhwc_f32_x3_kernel(const float* 
 template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
     const float* __restrict__ embed, const u32x4* __restrict__ fhi, const u32x4* __restrict__ flo,
-    float* __restrict__ out, uint32_t* __restrict__ bits, int Q, int npix, int T, int MT, int q_total, int q0) {
-  // Q rows q0 .. q0 + Q - 1 of tensors with q_total rows per image (a row group of a larger query set: split mode keeps <= 4
-  // query tiles in LDS, the C entry walks the groups -- the outputs land in place, nothing is concatenated afterwards)
+    float* __restrict__ out, uint32_t* __restrict__ bits, int Q, int npix, int T, int MT, int q_total, int G) {
+  // G row groups of <= 128 queries in ONE launch (split mode keeps <= 4 query tiles = 128 KiB of hi + lo fragments in LDS): workgroup
+  // x = tile_slot * G + group, so the G workgroups that stream the same feature tiles are dispatched together and the second read of a
+  // tile is an Infinity-Cache hit; every group writes its rows q0 .. q0 + Q - 1 of the q_total-row outputs in place.
+  const int grp = G > 1 ? (int)(blockIdx.x % (unsigned)G) : 0;
+  const int bx = G > 1 ? (int)(blockIdx.x / (unsigned)G) : (int)blockIdx.x;
+  const int q0 = grp * 128;
+  if (G > 1) {
+    Q = q_total - q0 < 128 ? q_total - q0 : 128;
+    MT = (Q + 31) / 32;
+  }
   constexpr int KS = 16;  // C = 256
   constexpr int C = KS * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* a_hi = reinterpret_cast<u32x4*>(smem_raw);
-  u32x4* a_lo = a_hi + MT * KS * 64;
+  u32x4* a_lo = a_hi + MT * KS * 64;      // this group's own MT (the launch sized the LDS for the largest group)
 
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
@@ -207,12 +215,12 @@ __global__ __launch_bounds__(512, 2) void cgg_mask_logits_kernel(
 
   const int hi5 = lane >> 5;
   const int col = lane & 31;
-  const int tstride = gridDim.x * 8;
+  const int tstride = (int)(gridDim.x / (unsigned)G) * 8;
   float* __restrict__ ob = out ? out + ((size_t)b * q_total + q0) * npix : nullptr;       // uniform
   uint32_t* __restrict__ bb = bits ? bits + ((size_t)b * q_total + q0) * T : nullptr;     // uniform
   const u32x4* __restrict__ fhb = fhi + (size_t)b * T * (KS * 64) + lane;
   const u32x4* __restrict__ flb = SPLIT ? flo + (size_t)b * T * (KS * 64) + lane : nullptr;
-  int t = blockIdx.x * 8 + wave;
+  int t = bx * 8 + wave;
 
   // ---- (0) request the first tile's B fragments BEFORE the prologue: their HBM latency hides under it ----
   u32x4 bh[KS];
@@ -499,16 +507,14 @@ extern "C" int cgg_pack_mask_feature_nhwc(const void* feat, void* hi, int B, int
 
 template <bool SPLIT>
 static int launch_mask_logits(const float* embed, const void* hi, const void* lo, float* out,
-                              uint32_t* bits, int B, int Q, int npix, hipStream_t s, int q_total, int q0) {
+                              uint32_t* bits, int B, int Q, int npix, hipStream_t s, int q_total, int G) {
+  // G > 1: Q is the largest group's row count (128)
   const int MT = (Q + 31) / 32;
   const int T = (npix + 31) / 32;
   const size_t lds = (size_t)MT * 16 * 64 * 16 * (SPLIT ? 2 : 1);
   // ~one 8-wave workgroup per CU (two tiles per wave at 1024x1024); every wave gets >= 1 tile where possible
   int gx = (T + 7) / 8;
   int cap = (256 + B - 1) / B;
-#ifdef CGG_ML_HARNESS
-  if (getenv("CGG_ML_CAP")) cap = atoi(getenv("CGG_ML_CAP"));
-#endif
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   auto kern = cgg_mask_logits_kernel<SPLIT>;
@@ -521,8 +527,8 @@ static int launch_mask_logits(const float* embed, const void* hi, const void* lo
       return (int)e;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(gx, B), dim3(512), lds, s, embed, (const u32x4*)hi,
-                     (const u32x4*)lo, out, bits, Q, npix, T, MT, q_total, q0);
+  hipLaunchKernelGGL(kern, dim3(gx * G, B), dim3(512), lds, s, embed, (const u32x4*)hi,
+                     (const u32x4*)lo, out, bits, Q, npix, T, MT, q_total, G);
   CGG_CHECK_LAUNCH("cgg_mask_logits");
   return CGG_OK;
 }
@@ -538,16 +544,13 @@ extern "C" int cgg_mask_logits(const float* embed, const void* hi, const void* l
   hipStream_t s = (hipStream_t)stream;
   const int mt = (Q + 31) / 32;
   if (lo) {
-    // split mode keeps <= 4 query tiles (hi + lo fragment images, 128 KiB) in LDS: larger query sets run as row groups of 128,
-    // every group writing its rows of the outputs in place
-    for (int q0 = 0; q0 < Q; q0 += 128) {
-      const int rc = launch_mask_logits<true>(embed, hi, lo, out, bits, B, Q - q0 < 128 ? Q - q0 : 128, npix, s, Q, q0);
-      if (rc != CGG_OK) return rc;
-    }
-    return CGG_OK;
+    // split mode keeps <= 4 query tiles (hi + lo fragment images, 128 KiB) in LDS: larger query sets run as row groups of 128
+    // inside ONE launch (workgroup x = tile slot * G + group), every group writing its rows of the outputs in place
+    const int G = (Q + 127) / 128;
+    return launch_mask_logits<true>(embed, hi, lo, out, bits, B, G > 1 ? 128 : Q, npix, s, Q, G);
   }
   CGG_REQUIRE(mt <= 8, CGG_EUNSUPPORTED, "cgg_mask_logits: Q <= 256 (Q=%d)", Q);
-  return launch_mask_logits<false>(embed, hi, lo, out, bits, B, Q, npix, s, Q, 0);
+  return launch_mask_logits<false>(embed, hi, lo, out, bits, B, Q, npix, s, Q, 1);
 }
 
 extern "C" int cgg_attn_mask_fix_full_rows(uint32_t* bits, int rows, int npix, cgg_stream_t stream) {

@@ -699,6 +699,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_GATHER
   }
 }
 
+// CGG_MSDA_GENERIC=1 forces the generic kernels (the fallback of every other shape; tests run them on the stream's shapes too).
+// Read ONCE, when the library is loaded -- no getenv in a launch path.
+static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
+
 // -------------------------------------------------------------------------------------------------
 static int msda_read_levels(const int64_t* spatial_shapes, const int64_t* level_start, int L,
                             int Nv, hipStream_t s, MsdaLevels* lv, const char* who) {
@@ -728,6 +732,23 @@ static int msda_read_levels(const int64_t* spatial_shapes, const int64_t* level_
   return CGG_OK;
 }
 
+// The ONE synchronising helper of the MSDeformAttn family: the mmcv-style device level table -> host int32 arrays for the
+// *_hostlevels entry points. A binding calls it once per `spatial_shapes` tensor (once per forward), not once per op call.
+extern "C" int cgg_msda_read_levels(const int64_t* spatial_shapes, const int64_t* level_start, int L, int Nv,
+                                    int32_t* level_hw_host, int32_t* level_start_host, cgg_stream_t stream) {
+  CGG_REQUIRE(spatial_shapes && level_start && level_hw_host && level_start_host, CGG_EINVAL, "cgg_msda_read_levels: null pointer");
+  CGG_REQUIRE(L >= 1 && L <= 8 && Nv > 0, CGG_EINVAL, "cgg_msda_read_levels: bad sizes (L=%d, Nv=%d)", L, Nv);
+  MsdaLevels lv;
+  const int rc = msda_read_levels(spatial_shapes, level_start, L, Nv, (hipStream_t)stream, &lv, "cgg_msda_read_levels");
+  if (rc) return rc;
+  for (int l = 0; l < L; ++l) {
+    level_hw_host[2 * l] = lv.h[l];
+    level_hw_host[2 * l + 1] = lv.w[l];
+    level_start_host[l] = lv.start[l];
+  }
+  return CGG_OK;
+}
+
 // Host-side level table variant: identical kernels, no D2H (used by the graph-captured forward).
 extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
                                            const int32_t* level_start, const float* sampling_loc,
@@ -746,7 +767,6 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
                      (const VT*)value, lv, loc, attw, ref, ld, out, Nv, H, D, L, Nq, P, total)
   const bool st = (L == 3 && P == 4);  // the shipped configs: num_levels=3, num_points=4
   // the encoder stream's shape (8 heads x 32 channels, 3 levels x 4 points, rows = [offsets | logits]): quad-shared taps
-  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
   const long long total8 = (long long)B * Nq * H * (D / 8);
   if (dtype == CGG_F32 && fused && st && H == 8 && D == 32 && ld % 4 == 0 && cgg_aligned16(loc) && !generic_only &&
       (long long)Nv * H * D < (1ll << 31) && total8 < (1ll << 31)) {
@@ -898,7 +918,6 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
                            int L, int Nq, int P, hipStream_t s, bool overwrite, hipStream_t side) {
   const int DQ = D / 4;
-  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
   // side != null: the gather kernel (grad_loc / grad_attn) runs on `side` next to the sorted-scatter kernel (grad_value) on `s` --
   // they share inputs only; one is bound by the LDS pipe, the other by VALU issue and L1 gathers. Fork / join by events: `side`
   // starts after everything enqueued on `s` so far, `s` continues after the gather.
@@ -993,7 +1012,7 @@ static int msda_bwd_hostlevels(const float* value, const int32_t* level_hw, cons
   // on accumulation and must still zero the two tensors unless cgg_msda_backward_overwrites(...) says the fast path applies
   const bool tileable = msda_bwd_sorted_ok(lv, B, Nv, H, D, L, Nq, P);
   const bool ow = overwrite_loc_attn && tileable && P == 4 && cgg_aligned16(sampling_loc) && cgg_aligned16(attn_weight) &&
-                  cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn) && getenv("CGG_MSDA_GENERIC") == nullptr;
+                  cgg_aligned16(grad_loc) && cgg_aligned16(grad_attn) && !generic_only;
   CGG_REQUIRE(!overwrite_loc_attn || ow, CGG_EUNSUPPORTED,
               "cgg_msda_backward_hostlevels: overwrite_loc_attn needs the split backward (tileable pyramid, D == 32, P == 4, aligned)");
   return msda_bwd_launch(value, lv, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv, H, D, L, Nq, P,
@@ -1029,7 +1048,7 @@ extern "C" int cgg_msda_backward_overwrites(const int32_t* level_hw, const int32
     lv.w[l] = level_hw[2 * l + 1];
     lv.start[l] = level_start[l];
   }
-  return (P == 4 && getenv("CGG_MSDA_GENERIC") == nullptr && msda_bwd_sorted_ok(lv, B, Nv, H, D, L, Nq, P)) ? 1 : 0;
+  return (P == 4 && !generic_only && msda_bwd_sorted_ok(lv, B, Nv, H, D, L, Nq, P)) ? 1 : 0;
 }
 
 // Throughput-mode encoder stream: bf16 value, bf16 raw [offsets | logits] rows (a bf16 GEMM's output), bf16 output
@@ -1055,7 +1074,6 @@ static int msda_fused_bf16_impl(bool head_major, const void* value, const int32_
   const int nblk = (int)((total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   // CGG_MSDA_GENERIC=1 forces the generic kernel (the fallback of every other shape; tests run it on the stream's shapes too)
-  static const bool generic_only = getenv("CGG_MSDA_GENERIC") != nullptr;
   const bool fast_ok = L == 3 && P == 4 && D == 32 && ld % 8 == 0 && cgg_aligned16(offs_logits) && !generic_only;
   const bool quad_ok = fast_ok && H == 8 && (long long)Nv * H * D < (1ll << 31) && total < (1ll << 31);
   CGG_REQUIRE(!head_major || quad_ok, CGG_EUNSUPPORTED,

@@ -24,6 +24,7 @@
 //     row: residual read (f32 or x3a), ReLU, then 32 contiguous bytes out -- 8 floats or the x3a group [8 hi | 8 lo] -- so the
 //     next GEMM's A operand is produced in the form it is consumed. |16 v| > 65504 (f16 overflow of a stored value) raises
 //     the device-side overflow flag instead of silently storing inf.
+#include <mutex>
 #include "x3.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -513,16 +514,32 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void cgg_gemm_x3s_kernel(const X
 // the device-side overflow flag of the x3a producers (one word per process and device, zeroed at creation; read by
 // cgg_x3_overflow_check)
 static int* g_xs_flag[16] = {nullptr};
+static std::once_flag g_xs_once[16];
 int* cgg_x3_overflow_flag_ptr() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!g_xs_flag[dev]) {
+  // created once per device, race-free (two autograd / DDP threads may make the first call together); cgg_init(device) makes the
+  // creation explicit -- it must have happened before a graph capture, hipMalloc is not capturable
+  std::call_once(g_xs_once[dev], [dev] {
     int* q = nullptr;
-    if (hipMalloc(&q, 64) != hipSuccess) return nullptr;
-    if (hipMemset(q, 0, 64) != hipSuccess) return nullptr;
+    if (hipMalloc(&q, 64) != hipSuccess) return;
+    if (hipMemset(q, 0, 64) != hipSuccess) { (void)hipFree(q); return; }
     g_xs_flag[dev] = q;
-  }
+  });
   return g_xs_flag[dev];
+}
+
+extern "C" int cgg_init(int device) {
+  int prev = 0;
+  hipError_t e = hipGetDevice(&prev);
+  CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_init: %s", hipGetErrorString(e));
+  CGG_REQUIRE(device >= 0 && device < 16, CGG_EINVAL, "cgg_init: device %d (0..15)", device);
+  e = hipSetDevice(device);
+  CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_init: hipSetDevice(%d): %s", device, hipGetErrorString(e));
+  int* f = cgg_x3_overflow_flag_ptr();
+  (void)hipSetDevice(prev);
+  CGG_REQUIRE(f, CGG_EINVAL, "cgg_init: could not create the overflow flag word on device %d", device);
+  return CGG_OK;
 }
 
 extern "C" int cgg_x3_overflow_check(int reset, int* value_host, cgg_stream_t stream) {

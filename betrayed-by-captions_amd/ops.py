@@ -174,23 +174,49 @@ def _msda_side_stream(dev):
     return s
 
 
+def msda_read_levels(spatial_shapes, level_start_index, Nv):
+    """mmcv's DEVICE level table -> host ((H_l, W_l), ...), (start_l, ...): `cgg_msda_read_levels`, the one synchronising call of
+    the MSDeformAttn family. The result is remembered ON the `spatial_shapes` tensor object (with both tensors' version counters),
+    so the six encoder layers of a forward pass and their backwards -- which share one tensor -- pay ONE device->host read, and
+    every op call goes through the non-synchronising *_hostlevels entries."""
+    key = (spatial_shapes._version, level_start_index.data_ptr(), level_start_index._version, int(Nv))
+    hit = getattr(spatial_shapes, '_cgg_levels', None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    L = int(spatial_shapes.shape[0])
+    hw, st = (ctypes.c_int32 * (2 * L))(), (ctypes.c_int32 * L)()
+    rc = _lib_().cgg_msda_read_levels(dev_ptr(spatial_shapes, 'spatial_shapes', torch.int64),
+                                      dev_ptr(level_start_index, 'level_start_index', torch.int64), L, int(Nv), hw, st,
+                                      stream_ptr(spatial_shapes.device))
+    check(rc, 'cgg_msda_read_levels')
+    level_hw = tuple((int(hw[2 * l]), int(hw[2 * l + 1])) for l in range(L))
+    level_start = tuple(int(st[l]) for l in range(L))
+    try:
+        spatial_shapes._cgg_levels = (key, level_hw, level_start)
+    except Exception:
+        pass
+    return level_hw, level_start
+
+
 class MultiScaleDeformableAttnFunction(torch.autograd.Function):
-    """Drop-in for [3P] mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction
-    (same positional signature incl. the unused im2col_step)."""
+    """Drop-in for [3P] mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction (same positional signature incl. the
+    unused im2col_step). The device level table is read once per `value_spatial_shapes` tensor (`msda_read_levels`); forward and
+    backward then run the *_hostlevels entries: no per-call synchronisation, the split (sorted-scatter) backward where the pyramid
+    allows it."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step=64):
-        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
-                              sampling_locations, attention_weights)
-        return msda_forward(value.contiguous(), value_spatial_shapes, value_level_start_index,
-                            sampling_locations.contiguous(), attention_weights.contiguous())
+        ctx.save_for_backward(value, sampling_locations, attention_weights)
+        ctx.levels = msda_read_levels(value_spatial_shapes, value_level_start_index, value.shape[1])
+        return msda_forward_hostlevels(value.contiguous(), ctx.levels[0], ctx.levels[1], sampling_locations.contiguous(),
+                                       attention_weights.contiguous())
 
     @staticmethod
     def backward(ctx, grad_output):
-        value, shapes, starts, loc, attw = ctx.saved_tensors
-        gv, gl, gw = msda_backward(value.contiguous().float(), shapes, starts, loc.contiguous(),
-                                   attw.contiguous(), grad_output.contiguous())
+        value, loc, attw = ctx.saved_tensors
+        gv, gl, gw = msda_backward_hostlevels(value.contiguous().float(), ctx.levels[0], ctx.levels[1], loc.contiguous(),
+                                              attw.contiguous(), grad_output.contiguous())
         return gv.to(value.dtype), None, None, gl, gw, None
 
 
@@ -316,6 +342,12 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
                                      stream_ptr(embed.device))
     check(rc, 'cgg_mask_logits')
     return out, bits
+
+
+def mask_logits_launches(Q, split):
+    """kernel launches of one `mask_logits` call on the packed (f16 x 3 / bf16) kernels: 1 -- split mode's row groups of 128 queries
+    (LDS holds 4 query tiles of hi + lo fragments) are workgroups of ONE launch since round 6 (it was ceil(Q / 128) launches)."""
+    return 1
 
 
 def mask_logits_bits_astat(embed, packed):

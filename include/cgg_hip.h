@@ -6,8 +6,14 @@
  * Conventions (every entry point):
  *   - extern "C", plain pointers and sizes; NO torch / C++ types cross this boundary.
  *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in
- *     this repo); the library never allocates, frees or keeps global state between calls.
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
+ *     this repo); the library never allocates or frees caller-visible memory. Its only state: one 64-byte
+ *     overflow flag word per device (created by cgg_init(device), or thread-safely on first use -- call
+ *     cgg_init before a hipGraph capture) and the read-only switches it took from the environment at load.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and NOTHING SYNCHRONISES, with
+ *     exactly these exceptions, each of which copies a few bytes device->host and waits for them (not legal
+ *     inside a graph capture): cgg_msda_read_levels, the mmcv-contract entries that take the DEVICE level
+ *     table (cgg_msda_forward, cgg_msda_forward_fused, cgg_msda_backward -- each = cgg_msda_read_levels +
+ *     the *_hostlevels entry), and cgg_x3_overflow_check.
  *   - return value: 0 (CGG_OK) on success, a negative CGG_E* for argument errors, or a positive
  *     hipError_t if the launch failed. No C++ exception crosses the ABI.
  *     cgg_last_error_string() gives a thread-local description of the last failure.
@@ -46,6 +52,11 @@ extern "C" {
 typedef void* cgg_stream_t; /* hipStream_t */
 
 int cgg_version(void);
+
+/* Creates the library's per-device state (the 64-byte x3a overflow flag word) on `device`. Optional -- the first x3a producer on a
+ * device creates it thread-safely -- but REQUIRED before capturing x3a kernels into a hipGraph on a device that has not run one yet
+ * (the creation is a hipMalloc). Idempotent; restores the caller's current device. */
+int cgg_init(int device);
 const char* cgg_last_error_string(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -80,6 +91,13 @@ int cgg_msda_forward_fused(const void* value, const int64_t* spatial_shapes,
                            const int64_t* level_start, const float* offs_logits, int ld,
                            const float* ref_points, float* out, int B, int Nv, int H, int D, int L,
                            int Nq, int P, int value_dtype, cgg_stream_t stream);
+
+/* The one synchronising step of the mmcv contract, factored out: spatial_shapes [L,2] / level_start [L] (int64, DEVICE, as mmcv's
+ * MultiScaleDeformableAttnFunction receives them) -> HOST int32 level_hw [2L] = (H_l, W_l) and level_start [L], validated against
+ * Nv. A binding calls it ONCE per spatial_shapes tensor (once per forward pass: the 6 encoder layers and their backwards share the
+ * tensor) and then uses the non-synchronising, graph-capturable *_hostlevels entries (INTEGRATION.md shows the stub). */
+int cgg_msda_read_levels(const int64_t* spatial_shapes, const int64_t* level_start, int L, int Nv,
+                         int32_t* level_hw_host, int32_t* level_start_host, cgg_stream_t stream);
 
 /* Same kernels with the level table given as HOST int32 arrays (level_hw [L,2] = (H_l, W_l),
  * level_start [L]): no device->host read of the table, so the call is legal inside a hipGraph
