@@ -29,6 +29,9 @@ __device__ __forceinline__ void mla_load_tile(u32x4 (&dst)[MLA_KS], const u32x4*
   for (int ks = 0; ks < MLA_KS; ++ks) dst[ks] = stream ? __builtin_nontemporal_load(p + ks * 64) : p[ks * 64];
 }
 
+// (by value: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0 whatever the index -- hipcc 7.2)
+__device__ __forceinline__ uint32_t mla_f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+
 #define MLA_RUN 16       // tiles whose mask words a wave stages in LDS before it writes them out as rows
 
 template <int MTW>
@@ -55,8 +58,9 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
 
   // ---- (0) the first two tiles are requested before the prologue: their HBM latency hides under it ----
   u32x4 b0[MLA_KS], b1[MLA_KS];
-  if (tbeg < tend) mla_load_tile(b0, fb, tbeg, nt);
-  if (tbeg + 1 < tend) mla_load_tile(b1, fb, tbeg + 1, nt);      // (MLA_RUN >= 2: inside the first run)
+  // (unconditional, clamped into the image: a stream without tiles requests tile T - 1 and never uses it)
+  mla_load_tile(b0, fb, min(tbeg, T - 1), nt);
+  mla_load_tile(b1, fb, min(tbeg + 1, min(tbeg + MLA_RUN, tend) - 1 < tbeg ? T - 1 : min(tbeg + MLA_RUN, tend) - 1), nt);
 
   // ---- (1) prologue: mask_embed[b] -> bf16 A fragments in LDS (float4 (q, c4) -> slot (q / 32, c4 / 4, q % 32 + 32 ((c4 / 2) & 1)),
   //      half c4 & 1), rows >= Q are zero; then this wave's MTW x 16 fragments into registers ----
@@ -100,55 +104,49 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
   uint32_t* __restrict__ bb = bits + ((size_t)b * Q + mt0 * 32) * T;
   const int nrows = min(MTW * 32, Q - mt0 * 32);               // uniform
 
-  // one pixel tile: MTW x 16 MFMAs against the register-resident query tiles. The threshold consumer of query tile i is interleaved,
-  // step by step, with the MFMAs of query tile i + 1 (two accumulators): a wave issues in order, and with one wave per SIMD the
-  // 16 ballots + 32 v_writelane of a tile's epilogue would otherwise run while the matrix pipe idles (measured before the
-  // interleave: 0.5 us per (tile, query tile) unit against 0.21 us of MFMA time).
-  // Threshold consumer: 16 ballots -> the 32 rows' words gathered into ONE register (lane = row) by v_writelane, one LDS store per
-  // query tile (a predicated store per ballot = 16 exec-mask branches per query tile cost 0.9 us per unit).
-  auto epi_step = [&](const f32x16& acc, int r, bool pin, uint32_t& wv) {
-    const unsigned long long m = __ballot(pin && acc[r] < 0.f);
-    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);     // lanes 0-31 voted for row ql, lanes 32-63 for row ql + 4
-    // (inline asm is opaque to the hazard recognizer: the s_nop covers "VALU writes an SGPR -> v_writelane reads it" -- without it
-    // ONE of the 32 words of a query tile came out as all-ones, the one whose compare the scheduler had put right in front)
-    switch (r) {
-#define MLA_WL(R)                                                                                         \
-  case R:                                                                                                 \
-    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"                 \
-                 : "+v"(wv)                                                                               \
-                 : "s"(mlo), "s"(mhi), "n"(((R) & 3) + 8 * ((R) >> 2)), "n"(((R) & 3) + 8 * ((R) >> 2) + 4)); \
-    break;
-      MLA_WL(0) MLA_WL(1) MLA_WL(2) MLA_WL(3) MLA_WL(4) MLA_WL(5) MLA_WL(6) MLA_WL(7)
-      MLA_WL(8) MLA_WL(9) MLA_WL(10) MLA_WL(11) MLA_WL(12) MLA_WL(13) MLA_WL(14) MLA_WL(15)
-#undef MLA_WL
-    }
+  // one pixel tile: MTW x 16 MFMAs against the register-resident query tiles, TRANSPOSED (round 6): the pixel fragments are the
+  // MFMA's A operand and the query fragments its B operand (the two share one register format), so the accumulator of lane l holds,
+  // for query column l & 31, the 16 pixels (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile. The threshold consumer is then lane-local:
+  // logit < 0 <=> sign bit (the accumulators start at +0 and the operands are finite: no -0, no NaN), shifted into a 16-bit pattern
+  // by ONE v_alignbit_b32 per accumulator register, spread to the lane's pixel positions with two shift-or-and steps, and joined with
+  // the other half-wave's 16 pixels by one v_permlane32_swap: ~24 VALU operations per (tile, query tile) unit instead of the round-5
+  // form's 16 ballots + 32 v_writelane + 16 s_nop (~110 operations, as long as the unit's 16 MFMAs themselves).
+  // The consumer of query tile i is interleaved, step by step, with the MFMAs of query tile i + 1 (two accumulators).
+  const uint32_t sh = 4u * (uint32_t)hi5;
+  auto finish = [&](uint32_t w16, uint32_t tmask) -> uint32_t {
+    uint32_t x = (w16 | (w16 << 8)) & 0x00FF00FFu;             // nibbles g of the 16-bit pattern -> bits 8 g .. 8 g + 3
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x <<= sh;                                                  // the upper half-wave owns pixels 8 g + 4 .. 8 g + 7
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (r[0] | r[1]) & tmask;                              // both half-waves now hold query l & 31's 32-pixel word
   };
   auto do_tile = [&](auto nmt_c, const u32x4 (&cur)[MLA_KS], int tt, int slot) {
     constexpr int NMT = decltype(nmt_c)::value;                // query tiles of this wave's group (compile time: straight-line code)
-    const bool pin = tt * 32 + col < npix;
+    const int valid = npix - tt * 32;                          // (uniform) < 32 only in the image's last tile
+    const uint32_t tmask = valid >= 32 ? 0xffffffffu : ((1u << valid) - 1u);
     f32x16 accC, accN;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accC[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < MLA_KS; ++ks)
-      accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0][ks]), __builtin_bit_cast(bf16x8, cur[ks]), accC, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[ks]), __builtin_bit_cast(bf16x8, A[0][ks]), accC, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < NMT; ++i) {
-      uint32_t wv = 0u;
+      uint32_t w = 0u;
       if (i + 1 < NMT) {                                     // (compile time after unrolling)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accN[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < MLA_KS; ++ks) {
-          accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[i + 1 < MTW ? i + 1 : i][ks]),
-                                                         __builtin_bit_cast(bf16x8, cur[ks]), accN, 0, 0, 0);
-          epi_step(accC, ks, pin, wv);
+          accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[ks]),
+                                                         __builtin_bit_cast(bf16x8, A[i + 1 < MTW ? i + 1 : i][ks]), accN, 0, 0, 0);
+          w = __builtin_amdgcn_alignbit(w, mla_f2u(accC[15 - ks]), 31);     // w = (w << 1) | sign
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) epi_step(accC, r, pin, wv);
+        for (int r = 15; r >= 0; --r) w = __builtin_amdgcn_alignbit(w, mla_f2u(accC[r]), 31);
       }
-      if (lane < 32) stage[(i * 32 + lane) * MLA_RUN + slot] = wv;
+      stage[(i * 32 + col) * MLA_RUN + slot] = finish(w, tmask);   // (lanes l and l + 32 store the same word to the same slot)
       accC = accN;
     }
   };
@@ -159,26 +157,29 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
     }
   };
 
-  // ---- (2) stream: two register sets (the next tile in flight behind the one being multiplied; a third set measured the same:
-  //      35.8 vs 36.0 us -- the stream was never the bound) + two accumulators: 256 A + 2 x 64 B + 32 accumulator registers ----
-  // Runs of <= MLA_RUN tiles: the tile loop of a run contains NO stores (the words wait in LDS), the run's flush follows it. With the
-  // flush inside the tile loop the compiler's s_waitcnt pass saw stores of unknown count outstanding at the loop header and fell
-  // back to vmcnt(0) in front of the first MFMA of every pair: the prefetched tile was waited for as well, i.e. half of the loads
-  // had no compute to hide behind (stream and MFMA time added up: 35 us at Q = 200 instead of max(stream, compute) + prologue).
+  // ---- (2) stream: two register sets (the next tile in flight behind the one being multiplied) + two accumulators: 256 A +
+  //      2 x 64 B + 32 accumulator registers. Runs of <= MLA_RUN tiles: the tile loop of a run contains NO stores (the words wait in
+  //      LDS), the run's flush follows it.
+  // Round 6: the tile loop is BRANCH-FREE -- every prefetch is issued unconditionally (the tile index is clamped to the run's last
+  // tile: a redundant L2-hit load at the end of a run; an odd run repeats its last tile, writing the same words again). With the
+  // round-5 form's `if (t + 2 < rend)` around the prefetches the compiler's s_waitcnt pass merged "16 loads pending" with "none" at
+  // the loop header and waited with vmcnt(15 .. 0) in front of the first query tile's MFMAs -- i.e. for the NEXT tile's loads too, so
+  // that no load ever had a tile's worth of MFMAs to hide behind (profiles/r6_einsum_astat.txt: 2.9 us per tile and stream against
+  // 0.85 us of MFMA time). Now the loop header waits with vmcnt(31 .. 16): only for the tile it multiplies. ----
   auto stream_tiles = [&](auto nmt_c) {
     for (int run0 = tbeg; run0 < tend; run0 += MLA_RUN) {
       const int rend = min(tend, run0 + MLA_RUN);
+      const int last = rend - 1;
       if (run0 != tbeg) {                                      // (the first run's tiles were requested before the prologue)
         mla_load_tile(b0, fb, run0, nt);
-        if (run0 + 1 < rend) mla_load_tile(b1, fb, run0 + 1, nt);
+        mla_load_tile(b1, fb, min(run0 + 1, last), nt);
       }
       for (int t = run0; t < rend; t += 2) {
         do_tile(nmt_c, b0, t, t - run0);
-        if (t + 2 < rend) mla_load_tile(b0, fb, t + 2, nt);
-        if (t + 1 < rend) {
-          do_tile(nmt_c, b1, t + 1, t + 1 - run0);
-          if (t + 3 < rend) mla_load_tile(b1, fb, t + 3, nt);
-        }
+        mla_load_tile(b0, fb, min(t + 2, last), nt);
+        const int t1 = min(t + 1, last);
+        do_tile(nmt_c, b1, t1, t1 - run0);
+        mla_load_tile(b1, fb, min(t + 3, last), nt);
       }
       flush(run0, rend - run0);
     }

@@ -268,6 +268,9 @@ class Mask2FormerHeadOpen(nn.Module):
         self.loss_dice = build_loss(loss_dice)
         self.point_hook = None  # callable(kind, shape, device) -> coords; pins the random draws in tests
         self.attn_mask_hook = None  # callable(layer_idx, bits) -> bits; tests inject the oracle's masks
+        # callable(layer_idx, image_idx, rows, cols, cost) -> (rows, cols); tests check the Hungarian solution against the oracle's
+        # cost matrix and inject the oracle's own (a near-tie may legitimately resolve either way in float32)
+        self.assign_hook = None
         self.init_kwargs(**kwargs)
 
     # ------------------------------------------------------------------------------------------
@@ -1083,12 +1086,16 @@ class Mask2FormerHeadOpen(nn.Module):
                 off += n * Q * G
                 mats.extend(cm[li] for li in range(n))
         solved = iter(ops.linear_sum_assignment_batch(mats))
+        mi = 0
         for b in range(B):
             G = shapes[b]
             if G == 0:
                 continue
             for li in range(n):
                 rows, cols = (t.numpy() for t in next(solved))
+                if self.assign_hook is not None:
+                    rows, cols = self.assign_hook(li, b, rows, cols, mats[mi])
+                mi += 1
                 order = np.argsort(rows)                     # positives in ascending query order (sampler: unique())
                 rows, cols = rows[order], cols[order]
                 labels_np[li, b, rows] = gl_host[b][cols]

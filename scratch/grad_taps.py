@@ -87,6 +87,33 @@ def build_heads(cfg, seed=0):
 
 util.build_heads = build_heads
 
+# ---- assignment log: (who, layer, image) -> (rows, cols) ----
+import numpy as np
+from oracle import head as OHm
+from cgg_amd import ops as OPS
+ASSIGN = {'o32': [], 'o64': [], 'prod': []}
+_lsa = OHm.linear_sum_assignment
+
+
+def lsa(cost):
+    r, c = _lsa(cost)
+    ASSIGN['o64' if cost.dtype == torch.float64 else 'o32'].append((np.asarray(r), np.asarray(c), cost.clone()))
+    return r, c
+
+
+OHm.linear_sum_assignment = lsa
+_lsab = OPS.linear_sum_assignment_batch
+
+
+def lsab(mats):
+    out = _lsab(mats)
+    for m, (r, c) in zip(mats, out):
+        ASSIGN['prod'].append((r.numpy(), c.numpy(), m.clone()))
+    return out
+
+
+OPS.linear_sum_assignment_batch = lsab
+
 Q, B, tag = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]) if len(sys.argv) > 3 else (200, 4, 'swin')
 ch = (128, 256, 512, 1024) if tag == 'swin' else (256, 512, 1024, 2048)
 cfg = T.swin_b_config(Q) if tag == 'swin' else synthetic.model_config(num_things=65, num_stuff=0, num_unknown=17, num_queries=Q, depth=50)
@@ -121,3 +148,22 @@ pf = sum(TAPS['prod'][n].sum(0) for n in names if n.endswith('.pos'))
 of = sum(TAPS['o32'][n].sum(0) for n in names if n.endswith('.pos'))
 print('query_embed total: scale %.3g  prod err %.3g  o32 err %.3g' % (fs, (pf - final).abs().max().item() / fs, (of - final).abs().max().item() / fs))
 json.dump({k: list(v) for k, v in rows.items()}, open(os.path.join(R, 'gpurun_out', 'grad_taps.json'), 'w'), indent=1)
+
+# ---- assignments: oracle order = layer-major (layer, image); product = image-major (image, layer) ----
+nl = 10
+Bn = len(ASSIGN['o32']) // nl
+print('assignment problems: o32 %d o64 %d prod %d (B=%d)' % (len(ASSIGN['o32']), len(ASSIGN['o64']), len(ASSIGN['prod']), Bn))
+for li in range(nl):
+    for b in range(Bn):
+        r32, c32, m32 = ASSIGN['o32'][li * Bn + b]
+        r64, c64, m64 = ASSIGN['o64'][li * Bn + b]
+        rp, cp, mp = ASSIGN['prod'][b * nl + li]
+        def key(r, c):
+            o = np.argsort(c)
+            return tuple(r[o].tolist())
+        k32, k64, kp = key(r32, c32), key(r64, c64), key(rp, cp)
+        if not (k32 == k64 == kp):
+            c_opt = float(m64[r64, c64].sum())
+            print('layer %d image %d: o32==o64 %s  prod==o32 %s  prod==o64 %s | f64 cost of: o64 %.9g  o32 %.9g  prod %.9g | max |prod cost - o32 cost| %.3g'
+                  % (li, b, k32 == k64, kp == k32, kp == k64, c_opt, float(m64[r32, c32].sum()), float(m64[rp, cp].sum()),
+                     float((mp.double() - m32.double()).abs().max())))

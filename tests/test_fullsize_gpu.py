@@ -26,7 +26,7 @@ import cgg_amd  # noqa: F401
 from cgg_amd import ops, registry, runtime, synthetic
 from oracle import head as OH
 
-from util import MaskTeacher, head_cfg, plain, randomize
+from util import AssignTeacher, MaskTeacher, head_cfg, plain, randomize
 
 pytestmark = pytest.mark.gpu
 
@@ -593,8 +593,12 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
     t0 = time.perf_counter()
     ofeats = [f.clone().requires_grad_(True) for f in feats]
     oc, oe, om = teacher.run_oracle(lambda: orc.forward(ofeats, metas))
-    olosses = orc.loss(oc, oe, om, batch['gt_labels'], [m.long() for m in batch['gt_masks']], batch['gt_caption_ids'],
-                       batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
+    # the Hungarian matching is the step's other discrete decision: the float32 oracle's solutions are recorded, replayed in the
+    # float64 run and -- after the product's own solutions were checked against the oracle's cost matrices -- injected into the product
+    matcher = AssignTeacher([b for b in range(B) if len(batch['gt_labels'][b])])
+    with matcher.record():
+        olosses = orc.loss(oc, oe, om, batch['gt_labels'], [m.long() for m in batch['gt_masks']], batch['gt_caption_ids'],
+                           batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
     sum(olosses.values()).backward()
     ograds = {k: (None if p.grad is None else p.grad.clone()) for k, p in orc.named_parameters()}
     # float64 run of the same oracle with the float32 run's attention-mask decisions injected: the TRUTH both float32 implementations are
@@ -608,8 +612,9 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
     orc64.point_hook = lambda kind, shape, device: bank64(kind, shape, device).double()      # the same draws
     feats64 = [f.double().requires_grad_(True) for f in feats]
     c64, e64, m64 = orc64.forward(feats64, metas)
-    l64 = orc64.loss(c64, e64, m64, batch['gt_labels'], [m.long() for m in batch['gt_masks']], batch['gt_caption_ids'],
-                     batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
+    with matcher.replay():
+        l64 = orc64.loss(c64, e64, m64, batch['gt_labels'], [m.long() for m in batch['gt_masks']], batch['gt_caption_ids'],
+                         batch['gt_caption_mask'], batch['gt_caption_nouns_ids'], batch['gt_caption_nouns_mask'])
     sum(l64.values()).backward()
     g64 = {k: (None if p.grad is None else p.grad.float()) for k, p in orc64.named_parameters()}
     f64 = [f.grad.float() for f in feats64]
@@ -617,6 +622,7 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
     t_oracle = time.perf_counter() - t0
     prod.point_hook = Bank(9)
     prod.attn_mask_hook = teacher.hook
+    prod.assign_hook = matcher.hook
     to = lambda lst: [t.to(dev) for t in lst]   # noqa: E731
     pfeats = [f.to(dev).requires_grad_(True) for f in feats]
     with runtime.precision_scope('fp32'):
@@ -625,8 +631,13 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
                                     to(batch['gt_caption_mask']), to(batch['gt_caption_nouns_ids']),
                                     to(batch['gt_caption_nouns_mask']))
         sum(losses.values()).backward()
-    prod.attn_mask_hook = None
+    prod.attn_mask_hook = prod.assign_hook = None
     teacher.check()
+    matcher.check(10)
+    if matcher.flips:
+        print(f'{name}: {len(matcher.flips)} of {matcher.calls} Hungarian problems are near-ties the product resolved differently from '
+              f'the float32 oracle (layer, image, cost excess under the oracle\'s matrix): {matcher.flips}; worst relative excess '
+              f'{matcher.worst_tie:.1e}, cost matrices within {matcher.worst_cost:.1e}')
     assert set(losses) == set(olosses) and len(losses) == 70      # 7 losses x 10 decoder outputs
     worst = 0.0
     for k in sorted(losses):
@@ -647,17 +658,21 @@ def _forward_train_slice(dev, cfg, B, channels, seed, name):
         gworst[k] = (pf.grad.cpu() - tf).abs().max().item() / scale
         oworst[k] = (of.grad - tf).abs().max().item() / scale
     # bound per gradient, against the FLOAT64 oracle: 1e-3 of the gradient's scale, or 4 x the float32 oracle's own distance from
-    # float64 where that is larger. CONDITIONING-LIMITED gradients get 64 x: the feature-map gradients and the lateral convolution
-    # (the end of the longest chain, behind two GroupNorm backwards = differences of large sums), query_embed (a sum over batch x 27
-    # attention inputs that nearly cancels: the float32 ORACLE itself is off by 0.3 % .. 23 % there from run to run) and the
-    # sampling-offset / level-encoding parameters (differences of neighbouring bilinear taps over 43 008+ rows). Measured with
-    # scratch/slice_dbg.py: the excess over the oracle's own error on these keys is the same with CGG_X3_TRAIN=0 (f32 library GEMMs
-    # instead of the f16 x 3 kernels) and with torch.einsum in place of cgg_mask_logits_backward -- it is float32 summation order in
-    # the library kernels under autograd (MIOpen wrw / bwd, ATen GroupNorm backward), not the hand-written arithmetic.
+    # float64 where that is larger; 8 x for the CONDITIONING-LIMITED gradients (the feature-map gradients and the lateral convolution:
+    # the end of the longest chain, behind two GroupNorm backwards = differences of large sums; query_embed: a sum over batch x 27
+    # attention inputs that nearly cancels; the sampling-offset / level-encoding parameters: differences of neighbouring bilinear taps
+    # over 43 008+ rows), and never more than 5e-2 of the gradient's scale whatever the oracle's own error is.
+    # Round 5 needed 64 x here: scratch/grad_taps.py (round 6) traced that to ONE Hungarian near-tie at configs[3] (total costs
+    # 205.352778 vs 205.352773) that the product resolved the other way -- a different loss graph for one (layer, image), not
+    # arithmetic; with the matching pinned (AssignTeacher) the product sits within a few x of the float32 oracle on every key.
     print(f'{name} gradient errors vs the float64 oracle, relative to each gradient\'s scale (product | float32 oracle):',
           json.dumps({k: [float('%.3g' % gworst[k]), float('%.3g' % oworst[k])] for k in sorted(gworst)}))
     loose = ('feat(', 'lateral_convs', 'query_embed', 'sampling_offsets', 'level_encoding', 'level_embed')
-    bad = {k: (v, oworst[k]) for k, v in gworst.items() if v > max(1e-3, (64 if any(t in k for t in loose) else 4) * oworst[k])}
+    for k, v in oworst.items():
+        if v > 1e-2:
+            warnings.warn(f'{name}: the float32 oracle itself is {v:.1e} off the float64 gradient of {k}')
+    bad = {k: (v, oworst[k]) for k, v in gworst.items()
+           if v > min(5e-2, max(1e-3, (8 if any(t in k for t in loose) else 4) * oworst[k]))}
     assert not bad, bad
     for n, p in prod.named_parameters():
         if p.grad is not None:

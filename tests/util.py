@@ -131,6 +131,77 @@ class MaskTeacher:
         assert min(frac for _, frac in self.seen) > 0.98, self.seen
 
 
+class AssignTeacher:
+    """Tie-aware parity harness for the Hungarian matching (mask_hungarian_assigner.py:126-131), the second DISCRETE decision of a
+    training step besides the attention-mask threshold.
+
+    Two assignments whose total costs differ by less than the float32 noise of the cost matrix are equally "optimal"; which one a
+    solver returns depends on the last bits of the costs, and the two choices give different loss graphs for that (layer, image) --
+    i.e. gradients that differ by O(1) downstream (round 6, scratch/grad_taps.py: ONE such near-tie at configs[3], total costs
+    205.352778 vs 205.352773, was the whole of query_embed's "15 % gradient error"). So, as for the masks: (1) the product's cost
+    matrix must equal the float32 oracle's entry-wise within `cost_tol`, and its assignment must be optimal under the ORACLE's matrix
+    within `tie_tol` (relative to the optimum); (2) the oracle's assignment is then injected into the product (and replayed in the
+    float64 oracle run), so that all three runs differentiate the same graph."""
+
+    def __init__(self, nonempty_images, cost_tol=1e-3, tie_tol=2e-5):
+        self.images = list(nonempty_images)                    # image indices with >= 1 ground-truth instance, ascending
+        self.cost_tol, self.tie_tol = cost_tol, tie_tol
+        self.recorded, self.flips, self.calls, self.worst_cost, self.worst_tie = [], [], 0, 0.0, 0.0
+
+    def _patch(self, fn):
+        import contextlib
+        from oracle import head as OH
+
+        @contextlib.contextmanager
+        def cm():
+            old = OH.linear_sum_assignment
+            OH.linear_sum_assignment = fn
+            try:
+                yield self
+            finally:
+                OH.linear_sum_assignment = old
+        return cm()
+
+    def record(self):
+        """context: the float32 oracle run -- its solutions, in call order (layer-major over the non-empty images)"""
+        from scipy.optimize import linear_sum_assignment as lsa
+
+        def fn(cost):
+            r, c = lsa(cost)
+            self.recorded.append((r.copy(), c.copy(), cost.detach().clone().float()))
+            return r, c
+        return self._patch(fn)
+
+    def replay(self):
+        """context: another oracle run (float64) that must take the SAME assignments"""
+        it = iter(self.recorded)
+
+        def fn(cost):
+            r, c, _ = next(it)
+            return r, c
+        return self._patch(fn)
+
+    def hook(self, layer_idx, image_idx, rows, cols, cost):
+        import numpy as np
+        r, c, oc = self.recorded[layer_idx * len(self.images) + self.images.index(image_idx)]
+        oc = oc.double()
+        if cost is not None:
+            self.worst_cost = max(self.worst_cost, float(((cost.double().cpu() - oc).abs() / (1 + oc.abs())).max()))
+        opt, mine = float(oc[r, c].sum()), float(oc[rows, cols].sum())
+        self.worst_tie = max(self.worst_tie, abs(mine - opt) / (1 + abs(opt)))
+        o1, o2 = np.argsort(c), np.argsort(cols)
+        if not (len(c) == len(cols) and np.array_equal(r[o1], rows[o2])):
+            self.flips.append((layer_idx, image_idx, mine - opt))
+        self.calls += 1
+        return r, c
+
+    def check(self, n_layers):
+        assert self.calls == n_layers * len(self.images) == len(self.recorded), (self.calls, len(self.recorded))
+        assert self.worst_cost <= self.cost_tol, f'cost matrix differs from the oracle by {self.worst_cost:.2e} (relative)'
+        assert self.worst_tie <= self.tie_tol, (f'an assignment of the product is not optimal under the oracle\'s costs '
+                                                f'(relative excess {self.worst_tie:.2e}; flips {self.flips})')
+
+
 # ---- deterministic inputs shared by tests/golden/make_golden.py and the golden tests -----------------
 def g4_inputs():
     """(cfg, B, H, W, feats, metas, fh_query, fh_feat) of the G3/G4 head fixtures."""
