@@ -989,7 +989,9 @@ class Mask2FormerHeadOpen(nn.Module):
                     and all(isinstance(m, LazyMasks) and m.mask_feature is mf0 for m in all_mask_preds)):
                 # all layers share the mask feature: ONE channel-last sampling pass at the n * P points of every image,
                 # then a (Q x C) x (C x P) product per layer (sample(E F) = E sample(F))
-                nhwc = getattr(mf0, '_cgg_nhwc', None)     # (the channel-last FPN path hands its own channel-last copy along)
+                # (the channel-last FPN path hands its own channel-last copy along: taken only if shape / dtype match and neither
+                # tensor was written in place since -- runtime.handed_nhwc; the permute copy otherwise)
+                nhwc = runtime.handed_nhwc(mf0, allow_grad=True)
                 fs = ops.point_sample_nhwc(nhwc if nhwc is not None else mf0.detach().permute(0, 2, 3, 1).contiguous(),
                                            pts.permute(1, 0, 2, 3).reshape(B, n * P, 2))           # (B, n*P, C)
                 pred_pts = torch.empty((n, B, Q, P), dtype=torch.float32, device=dev)     # (no stack: each product lands in its slab)

@@ -20,6 +20,18 @@ Correctness: the pipelined results are the sequential results (tests/test_head_g
 import torch
 
 
+def _record_stream(obj, stream):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
 class StagePipeline:
     """`submit(x)` enqueues one batch and returns its slot; `wait(slot)` makes the caller's stream wait for that
     batch's results (`results[slot]`); `flush()` waits for everything.
@@ -38,6 +50,10 @@ class StagePipeline:
         n = len(self.stages)
         self.tail = tail
         self.slots = slots if slots is not None else max(2, n)
+        if tail is not None and self.slots < 2:
+            # the eager tail runs ONE batch behind the graphs: with a single slot batch k + 1's graphs would overwrite the stage
+            # outputs batch k's tail has not read yet
+            raise ValueError('StagePipeline: a tail needs slots >= 2')
         dev = example.device
         self.dev = dev
         import os
@@ -128,7 +144,12 @@ class StagePipeline:
             if self._tail_pending == slot:
                 self._run_tail(slot)
                 self._tail_pending = None
-            torch.cuda.current_stream(self.dev).wait_event(self.tail_done[slot])
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(self.tail_done[slot])
+            # the tail's results were allocated from the TAIL stream's pool: tell the allocator the caller's stream reads them too,
+            # or their blocks could be handed to later tail-stream work while e.g. an asynchronous D2H copy on the caller's stream
+            # is still reading them
+            _record_stream(self.results[slot], cur)
             return self.results[slot]
         torch.cuda.current_stream(self.dev).wait_event(self.done[-1][slot])
         return self.results[slot]

@@ -634,6 +634,11 @@ def x3_fpn_level_ok(pd, x, lo_hw):
           and gn1.num_groups == gn2.num_groups and 256 % gn1.num_groups == 0 and lat.activate is None and isinstance(outc.activate, nn.ReLU)
           and lat.conv.bias is None and outc.conv.bias is None and tuple(lat.conv.kernel_size) == (1, 1) and tuple(mf.kernel_size) == (1, 1)
           and lat.conv.groups == 1 and mf.groups == 1 and tuple(lat.conv.stride) == (1, 1) and tuple(mf.stride) == (1, 1)
+          and tuple(lat.conv.padding) == (0, 0) and tuple(mf.padding) == (0, 0)
+          and tuple(lat.conv.dilation) == (1, 1) and tuple(mf.dilation) == (1, 1)
+          # the GEOMETRY of the output convolution is checked in both precisions (throughput mode skipped it, so a
+          # non-standard output conv would have been computed silently as 3x3 / pad 1 / no bias); only the precision test is `bf`'s
+          and _conv3x3_geometry_ok(outc.conv)
           and (bf or x3_train_conv3x3_ok(outc.conv, x.new_empty((B, C, H, W))))
           and Cin % 32 == 0 and C % 32 == 0 and mf.out_channels % 32 == 0 and B * H * W >= X3_TRAIN_ROWS
           and B * H * W * max(Cin, C, mf.out_channels) * 4 < _X3_MAX_BYTES and lo_hw[0] > 0 and lo_hw[1] > 0)
@@ -648,11 +653,12 @@ def hand_nhwc(nchw, nhwc):
     return nchw
 
 
-def handed_nhwc(x):
-    """The channel-last f32 original of the NCHW map x (`hand_nhwc`), or None: absent, x under autograd, shapes / dtype that do not
-    match, or either tensor modified in place since the hand-over."""
+def handed_nhwc(x, allow_grad=False):
+    """The channel-last f32 original of the NCHW map x (`hand_nhwc`), or None: absent, x under autograd (unless `allow_grad`: a
+    consumer that only READS the values, under no_grad), shapes / dtype that do not match, or either tensor modified in place since
+    the hand-over."""
     nh = getattr(x, '_cgg_nhwc', None)
-    if nh is None or x.requires_grad or x.dim() != 4 or nh.dtype != torch.float32 or not nh.is_contiguous():
+    if nh is None or (x.requires_grad and not allow_grad) or x.dim() != 4 or nh.dtype != torch.float32 or not nh.is_contiguous():
         return None
     B, C, H, W = x.shape
     if tuple(nh.shape) != (B, H, W, C) or getattr(x, '_cgg_nhwc_versions', None) != (x._version, nh._version):
@@ -678,21 +684,26 @@ def fpn_level_x3_train(pd, x, lo_rows, lo_hw):
     out = _RowsToNchwFn.apply(m, (H, W))
     # the channel-last form the map was computed in, for consumers that sample it channel-last (the head's loss points): saves them a
     # 1-GB strided copy back
-    out._cgg_nhwc = m.detach().view(B, H, W, m.shape[-1])
-    return out
+    return hand_nhwc(out, m.detach().view(B, H, W, m.shape[-1]))
 
 
 X3_CONV_ROWS = 65536      # output pixels from which a 3 x 3 training convolution takes the x3 node (16 384 -- the trainable ResNet stage's
                           # 512-channel convolutions at 32^2 -- measured the same as MIOpen: 212.4 vs 212.1 ms per configs[2] step)
 
 
+def _conv3x3_geometry_ok(conv):
+    """3x3 / stride 1 / pad 1 / dilation 1 / ungrouped / bias-free with channel counts the x3 kernels tile"""
+    return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 32 == 0
+            and conv.out_channels % 32 == 0 and getattr(conv, 'padding_mode', 'zeros') == 'zeros')
+
+
 def x3_train_conv3x3_ok(conv, x):
     """parity mode under autograd, a 3x3 / s1 / p1 / ungrouped / bias-free convolution whose channel counts the x3 kernels tile,
     large enough to be worth the layout changes."""
     return (_X3_TRAIN and _X3A and x3_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
-            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 32 == 0
-            and conv.out_channels % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= X3_CONV_ROWS and x.shape[2] >= 4 and x.shape[3] >= 4
+            and _conv3x3_geometry_ok(conv)
+            and x.shape[0] * x.shape[2] * x.shape[3] >= X3_CONV_ROWS and x.shape[2] >= 4 and x.shape[3] >= 4
             # the kernels address their operands through 32-bit buffer descriptors: the zero-padded maps of the weight-gradient
             # contraction are the largest operand (ADVICE r4: from B = 64 at 256^2 x 256 the call raised instead of running on MIOpen)
             and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * max(conv.in_channels, conv.out_channels) * 4 < _X3_MAX_BYTES)

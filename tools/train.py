@@ -172,10 +172,20 @@ def main(argv=None):
                 # parity mode's f16 x 3 kernels hold activations up to |a| < 4094 (csrc/x3.h): beyond it the forward turns into
                 # inf / NaN; name the cause once per logging interval instead of letting a NaN loss speak for itself
                 from cgg_amd import ops
-                if ops.x3_overflow_check(device, reset=True):
-                    raise RuntimeError(f'iteration {it}: an activation left the range of the f32-class f16 x 3 kernels '
-                                       '(|a| >= 4094, csrc/x3.h) -- the losses since the last check are invalid; re-run with '
-                                       'CGG_X3_TRAIN=0 (f32 library GEMMs) or --precision bf16')
+                over = torch.tensor([int(bool(ops.x3_overflow_check(device, reset=True)))], device=device)
+                if distributed:
+                    # every rank must take the same branch: a rank that raised alone would leave the others waiting in the next
+                    # gradient all-reduce
+                    torch.distributed.all_reduce(over, op=torch.distributed.ReduceOp.MAX)
+                if int(over.item()):
+                    # (what the flag covers: the producers of STORED x3a rows -- cgg_gemm_x3s / cgg_conv_x3s epilogues, the x3a
+                    # norm / epilogue kernels. The training GEMMs that split f32 operands in-kernel, cgg_gemm_x3* / cgg_wgrad_x3,
+                    # do NOT raise it: gradients carry a per-tensor scale from cgg_absmax_f32, but activations take the fixed 2^4
+                    # pre-scale there too -- an |a| >= 4094 in those shows up as inf / NaN losses, not as this message.)
+                    raise RuntimeError(f'iteration {it}: a stored x3a activation left the range of the f32-class f16 x 3 format '
+                                       '(|a| >= 4094, csrc/x3.h: the x3s GEMM / convolution / norm epilogues raise the flag) on at '
+                                       'least one rank -- the losses since the last check are invalid; re-run with CGG_X3A=0 '
+                                       '(f32 rows, in-kernel split) or --precision bf16')
             if rank == 0 and (it % args.log_interval == 0 or it == max_iters):
                 dt = (time.perf_counter() - t0) / max(it - start_iter, 1)
                 rec = dict(iter=it, time=round(dt, 4), lr=optimizer.param_groups[0]['lr'],
