@@ -191,6 +191,177 @@ __global__ __launch_bounds__(256, 1) void cgg_mask_logits_astat_kernel(const flo
   else if (nmt == 1) stream_tiles(std::integral_constant<int, 1>{});
 }
 
+// -------------------------------------------------------------------------------------------------------------------------------
+// Round 6, Q > 128: the same contraction with the pixel tiles streamed through an LDS RING by LDS-DMA and TWO wavefronts per SIMD.
+// What the register-stream kernel above runs into at Q = 200 (profiles/r6_einsum_astat.txt): (a) one 16-KB tile in flight per
+// wavefront, both waves of a group pair fetching the same tile -- after the vmcnt fix 1.98 us per tile against 0.85 us of MFMA time,
+// the memory system's loaded latency; (b) with the 256 query-fragment registers of 4 query tiles a wave needs 464 VGPRs = ONE wave
+// per SIMD, and a wave issues in order: its consumer VALU work, LDS reads and DMA issue all run with the matrix pipe idle (a first
+// ring version with 4 such waves: 1.64 us per tile). Here:
+//   * 8 waves per workgroup = 2 per SIMD, each holding TWO query tiles (128 fragment registers; <= 256 VGPRs): while one wave of a
+//     SIMD is in its consumer / LDS / DMA code the other one's MFMAs keep the matrix pipe busy;
+//   * a stream QUAD (the four waves that multiply the same pixel tiles against query tiles [0,2) [2,4) [4,6) [6,8)) shares a 4-slot
+//     ring of 16-KB tiles in LDS, two quads per workgroup; `global_load_lds_dwordx4` moves a tile HBM -> LDS in 16 wave-instructions
+//     (4 per wave of the quad), no registers involved; up to 3 tiles (48 KB) per quad = 96 KB per CU in flight, each fetched ONCE;
+//   * a wave copies a tile's 16 B fragments LDS -> registers (ds_read_b128, conflict-free: the packed image is in fragment order)
+//     INSIDE the previous tile's last MFMA chain -- fragment ks is overwritten right after the last MFMA that reads it -- so one
+//     64-register set suffices and the LDS latency hides under MFMAs;
+//   * per tile step: [s_waitcnt vmcnt(8): my 4 pieces of tile t + 1 have landed, counted by hand -- the DMAs are inline asm, so the
+//     compiler neither waits for them nor drains them at the barrier] -> s_barrier (everybody's pieces have; everybody has copied
+//     tile t out of its slot) -> issue my 4 pieces of tile t + 4 into tile t's slot -> MFMAs of tile t (+ the copy of tile t + 1).
+// LDS: 2 quads x 4 slots x 16 KB = 128 KB ring + 32 KB word staging = the CU's 160 KB, one workgroup per CU.
+// The prologue's A-fragment image (MT x 16 KB <= 128 KB from byte 0, dead after the prologue) overlays staging + the low slots; ring
+// slots 3 of both quads ([128 KB, 160 KB)) are outside it, and tile 0 of each quad is requested into them BEFORE the prologue.
+#define MLR_D 4                                                // ring depth (tiles per stream quad)
+#define MLR_STAGE (8 * 2 * 32 * MLA_RUN * 4)                   // 32 KB: 8 waves x 64 query rows x MLA_RUN words
+#define MLR_RING(quad, j) (MLR_STAGE + (((j) * 2 + (quad)) * (MLA_KS * 1024)))   // byte offset of slot j of a quad (interleaved)
+
+// one 1-KB piece (a wave-instruction): lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l. M0 is written in the same
+// statement that reads it and restored (it is compiler-reserved).
+__device__ __forceinline__ void mlr_dma16(const u32x4* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+__global__ __launch_bounds__(512) void cgg_mask_logits_astat_ring_kernel(const float* __restrict__ embed, const u32x4* __restrict__ fhi,
+                                                                         uint32_t* __restrict__ bits, int Q, int npix, int T, int MT,
+                                                                         int per) {
+  constexpr int MTW = 2;
+  constexpr int C = MLA_KS * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* a_lds = reinterpret_cast<u32x4*>(smem_raw);          // prologue: [MT][KS][64] bf16 A fragments from byte 0
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi5 = lane >> 5, col = lane & 31;
+  const int grp = wave >> 1, quad = wave & 1;                  // waves {0, 2, 4, 6} = quad 0 (query-tile groups 0..3), odd waves = quad 1
+  const int mt0 = grp * MTW;
+  const int sid = blockIdx.x * 2 + quad;                       // stream quad -> contiguous run of `per` pixel tiles
+  const int tbeg = sid * per;
+  const int nvalid = max(0, min(T, tbeg + per) - tbeg);        // tiles of this quad that exist (the image's last quads may run short)
+  const u32x4* __restrict__ fb = fhi + (size_t)b * T * (MLA_KS * 64) + lane;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;         // LDS byte address of the dynamic segment (no static LDS in this kernel)
+  auto tile_of = [&](int i) { return min(tbeg + i, T - 1); };  // (clamped: a short quad re-reads the image's last tile, never stores it)
+  // this wave's 4 pieces of step i's tile -> ring slot (i + 3) % 4 of its quad
+  auto dma_tile = [&](int i) {
+    const u32x4* src = fb + (size_t)tile_of(i) * (MLA_KS * 64) + grp * (4 * 64);
+    const uint32_t dst = lds0 + MLR_RING(quad, (i + 3) & 3) + grp * (4 * 1024);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mlr_dma16(src + k * 64, dst + k * 1024);
+  };
+  dma_tile(0);                                                 // (slot 3: outside the A image)
+
+  // ---- (1) prologue: mask_embed[b] -> bf16 A fragments in LDS -> this wave's 2 x 16 fragments in registers ----
+  {
+    const f32x4* __restrict__ eb4 = reinterpret_cast<const f32x4*>(embed + (size_t)b * Q * C);
+    uint2* a2 = reinterpret_cast<uint2*>(a_lds);
+    const int nf = MT * 32 * (C / 4), nvalidf = Q * (C / 4);
+    constexpr int NF = 32;                                     // float4 per thread for MT = 8 query tiles (512 threads)
+    f32x4 ev[NF];
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + 512 * u;
+      ev[u] = (f < nvalidf) ? eb4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + 512 * u;
+      if (f < nf) {
+        const int q = f >> 6, c4 = f & 63;
+        const int slot = ((q >> 5) * MLA_KS + (c4 >> 2)) * 64 + (q & 31) + 32 * ((c4 >> 1) & 1);
+        a2[slot * 2 + (c4 & 1)] = make_uint2(cgg_pack2(cgg_f2bf(ev[u][0]), cgg_f2bf(ev[u][1])),
+                                             cgg_pack2(cgg_f2bf(ev[u][2]), cgg_f2bf(ev[u][3])));
+      }
+    }
+  }
+  __syncthreads();
+  u32x4 A[MTW][MLA_KS];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int ks = 0; ks < MLA_KS; ++ks)
+      A[i][ks] = a_lds[(min(mt0 + i, MT - 1) * MLA_KS + ks) * 64 + lane];    // (a tile >= MT is never multiplied: `nmt` below)
+  __syncthreads();                                             // the A image is dead: its LDS is staging + ring from here on
+  dma_tile(1);
+  dma_tile(2);
+
+  uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw) + wave * (MTW * 32 * MLA_RUN);
+  uint32_t* __restrict__ bb = bits + ((size_t)b * Q + mt0 * 32) * T;
+  const int nrows = max(0, min(MTW * 32, Q - mt0 * 32));
+  const int nmt = max(0, min(MTW, MT - mt0));                  // (wave-uniform) 2, 1, or 0 query tiles: a wave without any still
+                                                               // carries its DMA share and the barriers
+  const uint32_t sh = 4u * (uint32_t)hi5;
+  auto finish = [&](uint32_t w16, uint32_t tmask) -> uint32_t {
+    uint32_t x = (w16 | (w16 << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x <<= sh;
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (r[0] | r[1]) & tmask;
+  };
+  // all of this wave's DMA pieces except the newest `n` have landed; its own LDS accesses are complete
+#define MLR_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory")
+
+  // step i multiplies tile i straight out of its ring slot: fragment ks feeds the two query tiles' MFMAs (two independent
+  // accumulator chains), a few fragments ahead in registers. When step i starts this wave's outstanding DMA groups are tiles
+  // i, i + 1, i + 2 (4 pieces each, in that order).
+  auto step = [&](auto nmt_c, int i) {
+    constexpr int NMT = decltype(nmt_c)::value;
+    __builtin_amdgcn_sched_barrier(0);                         // (nothing of the previous step may sink below the wait / barrier)
+    MLR_WAIT(8);                                               // my pieces of tile i have landed
+    __builtin_amdgcn_s_barrier();                              // ... everybody's have; everybody is done with tile i - 1's slot
+    dma_tile(i + 3);                                           // -> slot (i + 6) % 4 = tile i - 1's
+    if constexpr (NMT > 0) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(smem_raw + MLR_RING(quad, (i + 3) & 3)) + lane;
+      const int tt = tile_of(i), slot = i & (MLA_RUN - 1);
+      const int valid = npix - tt * 32;
+      const uint32_t tmask = valid >= 32 ? 0xffffffffu : ((1u << valid) - 1u);
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < MLA_KS; ++ks) {
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, p[ks * 64]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8, A[0][ks]), acc0, 0, 0, 0);
+        if constexpr (NMT == 2)
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8, A[1][ks]), acc1, 0, 0, 0);
+      }
+      uint32_t w = 0u;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) w = __builtin_amdgcn_alignbit(w, mla_f2u(acc0[r]), 31);
+      stage[(0 * 32 + col) * MLA_RUN + slot] = finish(w, tmask);
+      if constexpr (NMT == 2) {
+        w = 0u;
+#pragma unroll
+        for (int r = 15; r >= 0; --r) w = __builtin_amdgcn_alignbit(w, mla_f2u(acc1[r]), 31);
+        stage[(1 * 32 + col) * MLA_RUN + slot] = finish(w, tmask);
+      }
+    }
+  };
+  auto flush = [&](int t0, int n) {
+    for (int idx = lane; idx < nrows * MLA_RUN; idx += 64) {
+      const int row = idx / MLA_RUN, k = idx - row * MLA_RUN;
+      if (k < n) bb[(size_t)row * T + t0 + k] = stage[idx];
+    }
+  };
+  auto stream_tiles = [&](auto nmt_c) {
+    for (int i = 0; i < per; ++i) {
+      step(nmt_c, i);
+      if (((i + 1) & (MLA_RUN - 1)) == 0 || i + 1 >= per) {    // (uniform) a run of MLA_RUN tiles is staged: write its rows
+        const int t0 = tbeg + (i & ~(MLA_RUN - 1));
+        flush(t0, min(MLA_RUN, tbeg + nvalid - t0));
+      }
+    }
+  };
+  if (nmt == 2) stream_tiles(std::integral_constant<int, 2>{});
+  else if (nmt == 1) stream_tiles(std::integral_constant<int, 1>{});
+  else stream_tiles(std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the tail's redundant prefetches must not outlive the workgroup's LDS
+#undef MLR_WAIT
+}
+
 // Consumer-fused bf16 form of cgg_mask_logits with the query operand stationary: embed (B, Q, 256) f32, hi = packed bf16 feature
 // (cgg_pack_mask_feature*), bits (B, Q, ceil(npix / 32)) u32 = (logit < 0); the logits themselves are never stored. Q <= 256.
 extern "C" int cgg_mask_logits_bits_astat(const float* embed, const void* hi, uint32_t* bits, int B, int Q, int C, int npix,
@@ -210,6 +381,22 @@ extern "C" int cgg_mask_logits_bits_astat(const float* embed, const void* hi, ui
   const int want = (T + 2 * streams - 1) / (2 * streams);
   if (gx > want) gx = want;
   if (gx < 1) gx = 1;
+  if (MT > 4) {
+    // more than four query tiles: the LDS-ring kernel (8 waves, two stream quads per workgroup, `per` tiles per quad)
+    int gr = (256 + B - 1) / B;
+    const int wantr = (T + 3) / 4;                             // >= 2 tiles per quad where possible
+    if (gr > wantr) gr = wantr;
+    if (gr < 1) gr = 1;
+    int per = (T + 2 * gr - 1) / (2 * gr);
+    gr = (T + 2 * per - 1) / (2 * per);
+    const size_t ldsr = (size_t)MLR_STAGE + 2 * MLR_D * (MLA_KS * 1024);
+    auto kr = cgg_mask_logits_astat_ring_kernel;
+    hipError_t er = hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+    CGG_REQUIRE(er == hipSuccess, (int)er, "cgg_mask_logits_bits_astat: cannot raise dynamic LDS to %zu", ldsr);
+    hipLaunchKernelGGL(kr, dim3(gr, B), dim3(512), ldsr, (hipStream_t)stream, embed, (const u32x4*)hi, bits, Q, npix, T, MT, per);
+    CGG_CHECK_LAUNCH("cgg_mask_logits_bits_astat(ring)");
+    return CGG_OK;
+  }
   auto kern = cgg_mask_logits_astat_kernel<4>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_mask_logits_bits_astat: cannot raise dynamic LDS to %zu", lds);

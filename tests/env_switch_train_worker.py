@@ -42,7 +42,7 @@ def main():
     teacher = MaskTeacher(orc)
     matcher = AssignTeacher([b for b in range(B) if len(batch['gt_labels'][b])])
     if os.path.exists(cache):
-        c = torch.load(cache)
+        c = torch.load(cache, weights_only=False)
         olosses, ograds, ofg, teacher.logits, matcher.recorded = c['losses'], c['grads'], c['fgrads'], c['logits'], c['assign']
     else:
         orc.point_hook = Bank(9)
