@@ -889,7 +889,8 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
 
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
-                           int L, int Nq, int P, hipStream_t s, bool overwrite = false, hipStream_t side = nullptr);
+                           int L, int Nq, int P, hipStream_t s, bool overwrite = false, hipStream_t side = nullptr, void* ws = nullptr,
+                           long long ws_bytes = 0);
 
 extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shapes,
                                  const int64_t* level_start, const float* sampling_loc,
@@ -916,7 +917,7 @@ extern "C" int cgg_msda_backward(const float* value, const int64_t* spatial_shap
 // geometry: the generic one-kernel form with global f32 atomics for grad_value.
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,
                            const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D,
-                           int L, int Nq, int P, hipStream_t s, bool overwrite, hipStream_t side) {
+                           int L, int Nq, int P, hipStream_t s, bool overwrite, hipStream_t side, void* ws, long long ws_bytes) {
   const int DQ = D / 4;
   // side != null: the gather kernel (grad_loc / grad_attn) runs on `side` next to the sorted-scatter kernel (grad_value) on `s` --
   // they share inputs only; one is bound by the LDS pipe, the other by VALU issue and L1 gathers. Fork / join by events: `side`
@@ -933,8 +934,10 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
   } else {
     side = nullptr;
   }
+  // (a workspace selects the two-pass sorted scatter -- robust to offsets of several pixels; without one: the single pass)
   int rc = generic_only ? CGG_EUNSUPPORTED
-                        : msda_bwd_sorted_launch(lv, sampling_loc, attn_weight, grad_out, grad_value, B, Nv, H, D, L, Nq, P, s);
+           : ws ? msda_bwd_sorted_launch_two_pass(lv, sampling_loc, attn_weight, grad_out, grad_value, B, Nv, H, D, L, Nq, P, ws, ws_bytes, s)
+                : msda_bwd_sorted_launch(lv, sampling_loc, attn_weight, grad_out, grad_value, B, Nv, H, D, L, Nq, P, s);
   if (rc == CGG_OK) {
     hipStream_t s_main = s;
     if (side) s = side;
@@ -993,7 +996,7 @@ static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float
 static int msda_bwd_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start, const float* sampling_loc,
                                const float* attn_weight, const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
                                int B, int Nv, int H, int D, int L, int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream,
-                               cgg_stream_t side_stream) {
+                               cgg_stream_t side_stream, void* ws = nullptr, long long ws_bytes = 0) {
   int rc = msda_check("cgg_msda_backward_hostlevels", value, sampling_loc, attn_weight, grad_out, B, Nv, H, D, L, Nq, P, CGG_F32);
   if (rc) return rc;
   CGG_REQUIRE(level_hw && level_start && grad_value && grad_loc && grad_attn, CGG_EINVAL, "cgg_msda_backward_hostlevels: null pointer");
@@ -1016,7 +1019,7 @@ static int msda_bwd_hostlevels(const float* value, const int32_t* level_hw, cons
   CGG_REQUIRE(!overwrite_loc_attn || ow, CGG_EUNSUPPORTED,
               "cgg_msda_backward_hostlevels: overwrite_loc_attn needs the split backward (tileable pyramid, D == 32, P == 4, aligned)");
   return msda_bwd_launch(value, lv, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv, H, D, L, Nq, P,
-                         (hipStream_t)stream, ow, (hipStream_t)side_stream);
+                         (hipStream_t)stream, ow, (hipStream_t)side_stream, ws, ws_bytes);
 }
 
 extern "C" int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, const int32_t* level_start,
@@ -1036,6 +1039,31 @@ extern "C" int cgg_msda_backward_hostlevels_2s(const float* value, const int32_t
                                                int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream, cgg_stream_t side_stream) {
   return msda_bwd_hostlevels(value, level_hw, level_start, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv,
                              H, D, L, Nq, P, overwrite_loc_attn, stream, side_stream == stream ? nullptr : side_stream);
+}
+
+// ... with a workspace for the TWO-PASS sorted scatter of grad_value (csrc/msda_bwd.hip): corners that leave the 4-pixel halo of
+// the first pass are re-sorted on larger tiles with a 12-pixel halo instead of costing one 128-byte atomic each. ws_bytes >=
+// cgg_msda_backward_workspace_bytes(...) (0 there = the geometry has no two-pass form; ws may then be null = the _2s entry).
+extern "C" int cgg_msda_backward_hostlevels_ws(const float* value, const int32_t* level_hw, const int32_t* level_start,
+                                               const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                               float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
+                                               int Nq, int P, int overwrite_loc_attn, void* ws, long long ws_bytes, cgg_stream_t stream,
+                                               cgg_stream_t side_stream) {
+  CGG_REQUIRE(!ws || cgg_aligned16(ws), CGG_EALIGN, "cgg_msda_backward_hostlevels_ws: workspace must be 16-B aligned");
+  return msda_bwd_hostlevels(value, level_hw, level_start, sampling_loc, attn_weight, grad_out, grad_value, grad_loc, grad_attn, B, Nv,
+                             H, D, L, Nq, P, overwrite_loc_attn, stream, side_stream == stream ? nullptr : side_stream, ws, ws_bytes);
+}
+
+extern "C" long long cgg_msda_backward_workspace_bytes(const int32_t* level_hw, const int32_t* level_start, int B, int Nv, int H, int D,
+                                                       int L, int Nq, int P) {
+  if (!level_hw || !level_start || L < 1 || L > 8 || generic_only) return 0;
+  MsdaLevels lv;
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = level_start[l];
+  }
+  return msda_bwd_two_pass_workspace_bytes(lv, B, Nv, H, D, L, Nq, P);
 }
 
 // 1 when cgg_msda_backward_hostlevels(..., overwrite_loc_attn = 1) is valid for this geometry (pointer alignment aside)

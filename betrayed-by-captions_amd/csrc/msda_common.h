@@ -54,5 +54,8 @@ __device__ __forceinline__ MsdaTap cgg_msda_tap(float x, float y, int Hl, int Wl
 // grad_value of the encoder's self-attention case by the sorted-scatter kernel (msda_bwd.hip); returns CGG_EUNSUPPORTED (without
 // setting the error string) when the pyramid is not tileable -- the caller then takes the generic global-atomic kernel
 bool msda_bwd_sorted_ok(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P);
+long long msda_bwd_two_pass_workspace_bytes(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P);
+int msda_bwd_sorted_launch_two_pass(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B,
+                                    int Nv, int H, int D, int L, int Nq, int P, void* ws, long long ws_bytes, hipStream_t s);
 int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B, int Nv,
                            int H, int D, int L, int Nq, int P, hipStream_t s);

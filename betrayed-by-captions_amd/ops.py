@@ -153,17 +153,22 @@ def msda_backward_hostlevels(value, level_hw, level_start, sampling_locations, a
     # split backward: the gather kernel (grad_loc / grad_attn) on a second stream next to the sorted-scatter kernel (grad_value); the
     # C call forks / joins by events, every result is ordered on the caller's stream (CGG_MSDA_BWD_2S=0: one stream)
     side = _msda_side_stream(value.device) if (ow and MSDA_BWD_2S) else None
+    # two-pass sorted scatter (corners beyond the first pass' 4-pixel halo are re-sorted on larger tiles instead of costing one
+    # 128-byte atomic each): a per-region counter workspace, 0 bytes where the geometry has no such form (CGG_MSDA_BWD_2P=0: A/B)
+    wsb = int(_lib_().cgg_msda_backward_workspace_bytes(hw, st, B, Nv, H, D, L, Nq, P)) if MSDA_BWD_2P else 0
+    ws = _workspace(wsb, value.device) if wsb > 0 else None
     with _timed('msda_backward', bytes=nbytes, flops=0.0, shape=(B, Nq, H, D, L, P)):
-        rc = _lib_().cgg_msda_backward_hostlevels_2s(
+        rc = _lib_().cgg_msda_backward_hostlevels_ws(
             dev_ptr(value, 'value', torch.float32), hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
             dev_ptr(attention_weights, 'attention_weights', torch.float32), dev_ptr(grad_output, 'grad_output', torch.float32),
-            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow), stream_ptr(value.device),
-            ctypes.c_void_p(side.cuda_stream) if side is not None else None)
-    check(rc, 'cgg_msda_backward_hostlevels_2s')
+            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow), dev_ptr(ws) if ws is not None else None, wsb,
+            stream_ptr(value.device), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
+    check(rc, 'cgg_msda_backward_hostlevels_ws')
     return gv, gl, gw
 
 
 MSDA_BWD_2S = os.environ.get('CGG_MSDA_BWD_2S', '1') != '0'
+MSDA_BWD_2P = os.environ.get('CGG_MSDA_BWD_2P', '1') != '0'
 _MSDA_SIDE = {}
 
 

@@ -145,6 +145,20 @@ int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, co
                                  const float* sampling_loc, const float* attn_weight, const float* grad_out,
                                  float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
                                  int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream);
+/* ... with a workspace (device, 16-B aligned, >= cgg_msda_backward_workspace_bytes(...) bytes; its contents need not be initialised)
+ * for the TWO-PASS sorted scatter of grad_value: the first pass sums the corners inside a 4-pixel halo of 2 x 2-coarse-pixel tiles and
+ * counts the others per region; the second pass re-sorts exactly those on 4 x 4-coarse-pixel tiles with a 12-pixel halo (a region
+ * without any returns at once). Offsets of several pixels (trained models) then cost a second sort instead of one 128-byte atomic
+ * per corner (round 5: 8.5 ms per call at +-8 px against 2.0 ms at the initialisation's +-0.5 px). ws null or workspace_bytes == 0:
+ * identical to cgg_msda_backward_hostlevels_2s. Same results as the single pass up to float summation order. */
+int cgg_msda_backward_hostlevels_ws(const float* value, const int32_t* level_hw, const int32_t* level_start,
+                                    const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                    float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
+                                    int Nq, int P, int overwrite_loc_attn, void* ws, long long ws_bytes, cgg_stream_t stream,
+                                    cgg_stream_t side_stream);
+long long cgg_msda_backward_workspace_bytes(const int32_t* level_hw, const int32_t* level_start, int B, int Nv, int H, int D, int L,
+                                            int Nq, int P);
+
 /* ... with the split backward's two kernels on two streams (grad_value on `stream`, grad_loc / grad_attn on `side_stream`, forked
  * from and joined back into `stream` by events inside the call; side_stream null or == stream: the one-stream form). */
 int cgg_msda_backward_hostlevels_2s(const float* value, const int32_t* level_hw, const int32_t* level_start,

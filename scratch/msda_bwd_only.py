@@ -23,8 +23,17 @@ loc = (ref.view(1, N, 1, 1, 1, 2) + off / norm).contiguous().to(dev)
 attw = torch.softmax(torch.randn(B, N, H, L * P, generator=g), -1).view(B, N, H, L, P).contiguous().to(dev)
 gout = torch.randn(B, N, H * D, generator=g).to(dev)
 starts = [0, 1024, 1024 + 4096]
+def single_pass():
+    ops.MSDA_BWD_2P = False
+    try:
+        return ops.msda_backward_hostlevels(value, hw, starts, loc, attw, gout)
+    finally:
+        ops.MSDA_BWD_2P = True
+
+
 for name, fn in (('mmcv-contract entry (device level table, accumulate)', lambda: ops.msda_backward(value, shapes, start, loc, attw, gout)),
-                 ('host-level entry (autograd path: grad_loc / grad_attn written)', lambda: ops.msda_backward_hostlevels(value, hw, starts, loc, attw, gout))):
+                 ('host-level entry, single-pass sorted scatter (round 5)', single_pass),
+                 ('host-level entry (autograd path: two-pass sorted scatter, grad_loc / grad_attn written)', lambda: ops.msda_backward_hostlevels(value, hw, starts, loc, attw, gout))):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()

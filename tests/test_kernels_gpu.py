@@ -202,13 +202,17 @@ def test_msda_backward_self_attention_tiled(dev, shapes, H, D, P, spread):
     assert (ga2 - ga).abs().max().item() <= 1e-5 * ga.abs().max().item() and (gl2 - gl).abs().max().item() <= 1e-5 * gl.abs().max().item()
 
 
-@pytest.mark.parametrize('B,shapes,spread', [(2, [(16, 16), (32, 32), (64, 64)], 0.0),     # full 4 x 4 tiles (c = 4), patch-mapped gather
-                                             (1, [(12, 20), (24, 40), (48, 80)], 0.6),     # ragged tile grid, most taps outside the windows
-                                             (3, [(8, 8), (16, 16), (32, 32)], 0.2)])
-def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread):
+@pytest.mark.parametrize('B,shapes,spread,amp', [(2, [(16, 16), (32, 32), (64, 64)], 0.0, 8.0),     # full tiles, patch-mapped gather
+                                                 (1, [(12, 20), (24, 40), (48, 80)], 0.6, 8.0),     # ragged tile grid, most taps outside the windows
+                                                 (3, [(8, 8), (16, 16), (32, 32)], 0.2, 8.0),
+                                                 (2, [(16, 16), (32, 32), (64, 64)], 0.0, 16.0),    # +-8 px: most corners in the SECOND pass' window
+                                                 (1, [(12, 20), (24, 40), (48, 80)], 0.1, 40.0),    # +-20 px: all three destinations of a corner
+                                                 (2, [(9, 7), (18, 14), (36, 28)], 0.05, 20.0)])    # odd coarse grid (ragged second-pass regions)
+def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread, amp):
     """csrc/msda_bwd.hip at encoder-like sizes: the corner records of a tile sorted by destination pixel, destination-stationary
-    sums, out-of-window corners through the record list's tail -- against float64 autograd of the op's definition, local offsets
-    and far-away samples mixed; two runs differ only by f32 summation order."""
+    sums, out-of-window corners through the second pass (re-sorted on larger tiles, round 6) and the record list's tail -- against
+    float64 autograd of the op's definition, local offsets (uniform +- amp / 2 pixels) and far-away samples mixed; two runs differ only
+    by f32 summation order; the single-pass form (CGG_MSDA_BWD_2P=0) gives the same gradient."""
     g = torch.Generator().manual_seed(61 + B)
     starts, Nv = _levels(shapes)
     L, H, D, P = len(shapes), 8, 32, 4
@@ -219,7 +223,7 @@ def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread):
         refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
     refp = torch.cat(refs, 0)
     wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
-    off = (torch.rand(B, Nv, H, L, P, 2, generator=g) - 0.5) * 8.0
+    off = (torch.rand(B, Nv, H, L, P, 2, generator=g) - 0.5) * amp
     loc = refp[None, :, None, None, None, :] + off / wh[None, None, None, :, None, :]
     far = torch.rand(B, Nv, H, L, P, 1, generator=g) < spread
     loc = torch.where(far, torch.rand(B, Nv, H, L, P, 2, generator=g) * 1.4 - 0.2, loc)
@@ -234,6 +238,13 @@ def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread):
     assert (gl.cpu().double() - l64.grad).abs().max().item() <= 5e-3 * l64.grad.abs().max().item()
     gv2, _, _ = ops.msda_backward_hostlevels(value.to(dev), shapes, starts, loc.to(dev), aw.to(dev), go.to(dev))
     assert (gv2 - gv).abs().max().item() <= 1e-5 * sc
+    old = ops.MSDA_BWD_2P
+    try:
+        ops.MSDA_BWD_2P = not old                     # the other form (single pass <-> two passes)
+        gv3, _, _ = ops.msda_backward_hostlevels(value.to(dev), shapes, starts, loc.to(dev), aw.to(dev), go.to(dev))
+    finally:
+        ops.MSDA_BWD_2P = old
+    assert (gv3 - gv).abs().max().item() <= 1e-5 * sc
 
 
 # ------------------------------------------------------------------------------------------------
@@ -249,7 +260,8 @@ def test_mask_logits_split_within_1e3(dev, B, Q, H, W):
     assert err <= 1e-3, err  # north_star: mask logits within 1e-3 (values are O(16) here)
 
 
-@pytest.mark.parametrize('B,Q,H,W', [(2, 100, 64, 64), (1, 200, 64, 96), (2, 37, 20, 28), (1, 128, 16, 24), (1, 256, 40, 33)])
+@pytest.mark.parametrize('B,Q,H,W', [(2, 100, 64, 64), (1, 200, 64, 96), (2, 37, 20, 28), (1, 128, 16, 24), (1, 256, 40, 33), (3, 160, 100, 97),
+                                     (2, 200, 256, 256), (1, 129, 8, 8)])
 def test_mask_logits_bits_astat_equals_streamed_kernel(dev, B, Q, H, W):
     """cgg_mask_logits_bits_astat (query tiles stationary in registers, threshold consumer in the epilogue, logits never stored)
     gives exactly the bits of cgg_mask_logits' bf16 mode (same bf16 operands, same MFMA order) -- one / two query-tile groups,
