@@ -766,8 +766,8 @@ def kernel_summaries(args, events, meta, B, H, W, Q):
     timed = ('HIP events around the launches in the same %d steps re-run eagerly right after the timed region (events cannot be '
              'recorded inside a hipGraph replay); raw means' % args.steps)
     out = {}
-    prof = committed_profile('r5_cfg4_kernels.json' if getattr(args, 'workload', 'cfg1') == 'cfg4' else 'r5_fp32_kernels.json') or \
-        (committed_profile('r4_fp32_kernels.json') if getattr(args, 'workload', 'cfg1') == 'cfg1' else None) or {}
+    pname = 'cfg4_kernels.json' if getattr(args, 'workload', 'cfg1') == 'cfg4' else 'fp32_kernels.json'
+    prof = committed_profile('r6_' + pname) or committed_profile('r5_' + pname) or {}
 
     def ms_list(name):
         return [s.elapsed_time(e) for s, e in events.get(name, [])]
@@ -976,9 +976,9 @@ def train_step_child(args, precision='fp32', workload='cfg2'):
         # last 3 steps) -- labelled as such
         prof = {}
         try:
-            table = ('r5_train_step_kernels_%s.txt' if workload == 'cfg2' else 'r5_cfg3_train_step_kernels_%s.txt') % precision
-            if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', table)) and workload == 'cfg2':
-                table = 'r4_train_step_kernels_%s.txt' % precision
+            table = ('r6_train_step_kernels_%s.txt' if workload == 'cfg2' else 'r6_cfg3_train_step_kernels_%s.txt') % precision
+            if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', table)):
+                table = table.replace('r6_', 'r5_')
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', table)) as f:
                 rows = f.read().splitlines()
             head = [r for r in rows if r.startswith('step (eager')][0]
