@@ -247,6 +247,58 @@ def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread, amp):
     assert (gv3 - gv).abs().max().item() <= 1e-5 * sc
 
 
+def test_msda_mmcv_function_reads_the_level_table_once_per_tensor(dev):
+    """`ops.MultiScaleDeformableAttnFunction` (mmcv's positional signature): the DEVICE level table is read by
+    `cgg_msda_read_levels` once per `spatial_shapes` tensor -- the result rides on the tensor with both version counters -- and the
+    op itself runs the non-synchronising *_hostlevels entries, forward and backward (== the mmcv-contract entries' results); an
+    in-place change of the table invalidates the cached copy; `cgg_init` is idempotent; the two-pass backward reports a workspace
+    size only for a tileable pyramid."""
+    from cgg_amd import _lib
+    lib = _lib.load()
+    assert lib.cgg_init(0) == 0 and lib.cgg_init(0) == 0 and lib.cgg_init(99) < 0
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    value, ss, st, loc, aw = _msda_inputs(2, shapes, 8, 32, 4, 1344, seed=7)
+    ssd, std_ = ss.to(dev), st.to(dev)
+    calls = []
+
+    class Spy:
+        def __getattr__(self, name):
+            f = getattr(_lib.load(), name)
+            if name == 'cgg_msda_read_levels':
+                def g(*a):
+                    calls.append(1)
+                    return f(*a)
+                return g
+            return f
+    old = ops._lib_
+    ops._lib_ = lambda: Spy()
+    try:
+        v = value.to(dev).requires_grad_(True)
+        l, a = loc.to(dev).requires_grad_(True), aw.to(dev).requires_grad_(True)
+        out = ops.MultiScaleDeformableAttnFunction.apply(v, ssd, std_, l, a, 64)
+        out2 = ops.MultiScaleDeformableAttnFunction.apply(v, ssd, std_, l, a, 64)            # the same tensor: no second read
+        assert len(calls) == 1 and torch.equal(out, out2)
+        go = torch.randn_like(out)
+        out.backward(go)
+        assert len(calls) == 1
+        ssd.add_(0)                                                                            # in-place write: version bump
+        ops.MultiScaleDeformableAttnFunction.apply(v, ssd, std_, l, a, 64)
+        assert len(calls) == 2
+    finally:
+        ops._lib_ = old
+    want = ops.msda_forward(value.to(dev), ssd, std_, loc.to(dev), aw.to(dev))
+    assert torch.equal(out.detach(), want)
+    gv, gl, ga = ops.msda_backward(value.to(dev), ssd, std_, loc.to(dev), aw.to(dev), go)
+    sc = gv.abs().max().item()
+    assert (v.grad - gv).abs().max().item() <= 1e-5 * sc                                       # (atomics: summation order only)
+    assert (l.grad - gl).abs().max().item() <= 1e-5 * gl.abs().max().item() and (a.grad - ga).abs().max().item() <= 1e-5 * ga.abs().max().item()
+    hw = ops._int_array([x for pair in shapes for x in pair])
+    stt = ops._int_array(_levels(shapes)[0])
+    assert lib.cgg_msda_backward_workspace_bytes(hw, stt, 2, 1344, 8, 32, 3, 1344, 4) > 0
+    assert lib.cgg_msda_backward_workspace_bytes(hw, stt, 2, 1344, 8, 32, 3, 700, 4) == 0       # queries != pixels: no sorted scatter
+    assert lib.cgg_msda_backward_workspace_bytes(hw, stt, 2, 1344, 8, 16, 3, 1344, 4) == 0      # D != 32
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B,Q,H,W', [(2, 100, 32, 32), (1, 100, 20, 28), (2, 37, 16, 24), (1, 128, 64, 64)])
 def test_mask_logits_split_within_1e3(dev, B, Q, H, W):
