@@ -329,10 +329,12 @@ __device__ __forceinline__ void msda_point_gather_f32_b(msda_v2f (&acc)[4], cons
 // T2D: 0 = a wave is 16 consecutive queries, the block's 4 waves are 4 heads; 1 = a wave is a 4 x 4 pixel tile of its level, the
 // block's 4 waves are 4 heads of it; 2 = a wave is a 4 x 4 tile, the block's 4 waves are the four tiles of an 8 x 8 pixel block
 // of ONE head (their taps share a (8 + 2 r)^2 window of lines), blockIdx enumerates (8 x 8 block, head)
-template <int T2D>
+// VS: `value` rows have a run-time stride of vld floats (the value columns of a wider row: round 6's merged projection GEMM writes
+// [value | offsets | logits] rows of 544 floats; a head's 32 channels stay one aligned 128-byte line as long as vld % 32 == 0)
+template <int T2D, bool VS = false>
 __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ rows, const float* __restrict__ ref,
-    int ld, float* __restrict__ out, int Nv, int Nq, unsigned total) {
+    int ld, float* __restrict__ out, int Nv, int Nq, unsigned total, int vld) {
   constexpr int D = 32, CPL = 8, H = 8, L = 3, LP = 12;
   // a wavefront = 16 consecutive queries of ONE head: in f32 a head's slice of a pixel is one 128-byte line, so the x-neighbour
   // taps of neighbouring queries are the SAME lines (the (x + 1) corner of query i is the x corner of query i + 1) and meet in
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     q = lv.start[l] + (4 * ty + (i >> 2)) * lv.w[l] + 4 * tx + (i & 3);
     bq = b * (unsigned)Nq + (unsigned)q;
   }
-  constexpr int rowstride = H * D;
+  const int rowstride = VS ? vld : H * D;                    // (a compile-time constant unless VS)
   // lane cq owns channels 4 cq .. + 3 and 16 + 4 cq .. + 3: each of a tap's two loads covers a CONTIGUOUS 64-byte half line per quad
   const float* vb = value + (size_t)b * Nv * rowstride + (size_t)h * D + cq * 4;
   // T2D == 2: image and head are block-uniform -> the level base lives in scalar registers, the lane's channel offset in the taps
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(256) void cgg_msda_fwd_stream2_f32_kernel(
     const float my_w[4] = {t.w00 * wl, t.w01 * wl, t.w10 * wl, t.w11 * wl};
     if constexpr (T2D == 2) {
       const char* vlb = reinterpret_cast<const char*>(vbu + (size_t)lv.start[l] * rowstride);
-      const uint32_t my_ob[4] = {(uint32_t)t.o00 * (rowstride * 4u), (uint32_t)t.o01 * (rowstride * 4u),
-                                 (uint32_t)t.o10 * (rowstride * 4u), (uint32_t)t.o11 * (rowstride * 4u)};
+      const uint32_t rs4 = (uint32_t)rowstride * 4u;
+      const uint32_t my_ob[4] = {(uint32_t)t.o00 * rs4, (uint32_t)t.o01 * rs4, (uint32_t)t.o10 * rs4, (uint32_t)t.o11 * rs4};
       msda_point_gather_f32_b<0>(acc, vlb, my_ob, my_w, lane_b);
       msda_point_gather_f32_b<1>(acc, vlb, my_ob, my_w, lane_b);
       msda_point_gather_f32_b<2>(acc, vlb, my_ob, my_w, lane_b);
@@ -758,7 +760,8 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
 
 static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float* loc,
                            const float* attw, const float* ref, int ld, float* out, int B, int Nv,
-                           int H, int D, int L, int Nq, int P, int dtype, bool fused, hipStream_t s) {
+                           int H, int D, int L, int Nq, int P, int dtype, bool fused, hipStream_t s, int vld = 0) {
+  if (vld == H * D) vld = 0;                                // 0 = the packed (B, Nv, H, D) layout
   const int cpl = dtype == CGG_F32 ? 4 : 8;
   const long long total = (long long)B * Nq * H * (D / cpl);
   const int nblk = (int)((total + 255) / 256);
@@ -769,7 +772,7 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
   // the encoder stream's shape (8 heads x 32 channels, 3 levels x 4 points, rows = [offsets | logits]): quad-shared taps
   const long long total8 = (long long)B * Nq * H * (D / 8);
   if (dtype == CGG_F32 && fused && st && H == 8 && D == 32 && ld % 4 == 0 && cgg_aligned16(loc) && !generic_only &&
-      (long long)Nv * H * D < (1ll << 31) && total8 < (1ll << 31)) {
+      (long long)Nv * (vld ? vld : H * D) < (1ll << 31) && total8 < (1ll << 31) && vld % 32 == 0) {
     // Query -> lane mapping when the queries are the pixels of a pyramid whose levels allow it (the encoder), all bit-identical
     // (round 4; scratch/msda_f32_bench.py, init offsets / +-1 px of noise on them):
     //   16 x 1 strips, a block = 4 heads of a strip (round 3)                                   118-119 us / 132 us
@@ -792,18 +795,23 @@ static int msda_fwd_launch(const void* value, const MsdaLevels& lv, const float*
     bool t8 = t2d && Nq % 64 == 0;
     for (int l = 0; l < L && t8; ++l) t8 = lv.w[l] % 8 == 0 && lv.h[l] % 8 == 0 && lv.start[l] % 64 == 0;
     const unsigned nb = 2 * (unsigned)(((long long)B * Nq + 15) / 16);
-    if (t8)
-      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<2>, dim3(nb), dim3(256), 36000, s, (const float*)value, lv, loc, ref, ld, out,
-                         Nv, Nq, (unsigned)total8);
-    else if (t2d)
-      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<1>, dim3(nb), dim3(256), 0, s, (const float*)value, lv, loc, ref, ld, out,
-                         Nv, Nq, (unsigned)total8);
-    else
-      hipLaunchKernelGGL(cgg_msda_fwd_stream2_f32_kernel<0>, dim3(nb), dim3(256), 0, s, (const float*)value, lv, loc, ref, ld, out,
-                         Nv, Nq, (unsigned)total8);
+#define CGG_S2(T, LDS)                                                                                                          \
+  do {                                                                                                                          \
+    if (vld)                                                                                                                    \
+      hipLaunchKernelGGL((cgg_msda_fwd_stream2_f32_kernel<T, true>), dim3(nb), dim3(256), LDS, s, (const float*)value, lv, loc, ref, ld, \
+                         out, Nv, Nq, (unsigned)total8, vld);                                                                  \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((cgg_msda_fwd_stream2_f32_kernel<T, false>), dim3(nb), dim3(256), LDS, s, (const float*)value, lv, loc, ref, ld, \
+                         out, Nv, Nq, (unsigned)total8, 0);                                                                    \
+  } while (0)
+    if (t8) CGG_S2(2, 36000);
+    else if (t2d) CGG_S2(1, 0);
+    else CGG_S2(0, 0);
+#undef CGG_S2
     CGG_CHECK_LAUNCH("cgg_msda_forward");
     return CGG_OK;
   }
+  CGG_REQUIRE(vld == 0, CGG_EUNSUPPORTED, "cgg_msda_forward: strided value rows (vld=%d) need the f32 fused stream kernel (H=8, D=32, L=3, P=4)", vld);
   if (dtype == CGG_F32) {
     if (fused) { if (st) CGG_MSDA_LAUNCH(float, 3, 4, true); else CGG_MSDA_LAUNCH(float, 0, 0, true); }
     else       { if (st) CGG_MSDA_LAUNCH(float, 3, 4, false); else CGG_MSDA_LAUNCH(float, 0, 0, false); }
@@ -885,6 +893,27 @@ extern "C" int cgg_msda_forward_hostlevels(const void* value, const int32_t* lev
   }
   return msda_fwd_launch(value, lv, sampling_loc, attn_weight, ref_points, ld, out, B, Nv, H, D, L, Nq,
                          P, value_dtype, fused != 0, (hipStream_t)stream);
+}
+
+// Fused f32 form with the value operand as COLUMNS of wider rows: value[b, n, h, :] = value_rows[(b Nv + n) vld + h D ...] (vld % 32
+// == 0, 16-byte aligned base). For the merged projection GEMM of the x3a encoder stream, whose rows are [value | offsets | logits].
+extern "C" int cgg_msda_forward_fused_vld(const float* value_rows, int vld, const int32_t* level_hw, const int32_t* level_start,
+                                          const float* offs_logits, int ld, const float* ref_points, float* out, int B, int Nv, int H,
+                                          int D, int L, int Nq, int P, cgg_stream_t stream) {
+  int rc = msda_check("cgg_msda_forward_fused_vld", value_rows, offs_logits, ref_points, out, B, Nv, H, D, L, Nq, P, CGG_F32);
+  if (rc) return rc;
+  CGG_REQUIRE(level_hw && level_start, CGG_EINVAL, "cgg_msda_forward_fused_vld: null level table");
+  CGG_REQUIRE(vld >= H * D && vld % 32 == 0 && ld >= H * L * P * 3, CGG_EINVAL, "cgg_msda_forward_fused_vld: vld=%d ld=%d", vld, ld);
+  MsdaLevels lv;
+  for (int l = 0; l < L; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    lv.start[l] = level_start[l];
+    CGG_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0 && lv.start[l] >= 0 && (long long)lv.start[l] + (long long)lv.h[l] * lv.w[l] <= Nv,
+                CGG_EINVAL, "cgg_msda_forward_fused_vld: level %d does not fit Nv=%d", l, Nv);
+  }
+  return msda_fwd_launch(value_rows, lv, offs_logits, nullptr, ref_points, ld, out, B, Nv, H, D, L, Nq, P, CGG_F32, true,
+                         (hipStream_t)stream, vld);
 }
 
 static int msda_bwd_launch(const float* value, const MsdaLevels& lv, const float* sampling_loc, const float* attn_weight,

@@ -117,6 +117,27 @@ def msda_forward_fused(value, level_hw, level_start, offs_logits, ref_points, nu
     return out
 
 
+def msda_forward_fused_rows(rows_all, level_hw, level_start, ref_points, num_points, num_heads, head_dim):
+    """`msda_forward_fused` on the rows of the MERGED projection GEMM: rows_all (B, Nq, H D + 3 H L P) f32 = [value | offsets |
+    logits] per token (queries == value pixels) -> (B, Nq, H D). The value operand is read as the first H D columns of the rows
+    (`cgg_msda_forward_fused_vld`), the raw offsets / logits as the rest -- nothing is copied apart."""
+    B, Nq, ldr = rows_all.shape
+    H, D = int(num_heads), int(head_dim)
+    L, P = len(level_start), int(num_points)
+    if rows_all.dtype != torch.float32 or not rows_all.is_contiguous() or ldr != H * D + 3 * H * L * P or ldr % 32:
+        raise CggError(f'msda_forward_fused_rows: rows {tuple(rows_all.shape)} for H={H} D={D} L={L} P={P}')
+    out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=rows_all.device)
+    hw = _int_array([v for pair in level_hw for v in pair])
+    st = _int_array(level_start)
+    base = dev_ptr(rows_all, 'rows_all', torch.float32)
+    offs = ctypes.c_void_p(rows_all.data_ptr() + H * D * 4)
+    with _timed('msda_fused'):
+        rc = _lib_().cgg_msda_forward_fused_vld(base, ldr, hw, st, offs, ldr, dev_ptr(ref_points, 'ref_points', torch.float32),
+                                                dev_ptr(out), B, Nq, H, D, L, Nq, P, stream_ptr(rows_all.device))
+    check(rc, 'cgg_msda_forward_fused_vld')
+    return out
+
+
 def msda_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
                   grad_output):
     B, Nv, H, D, L, Nq, P = _msda_dims(value, sampling_locations)

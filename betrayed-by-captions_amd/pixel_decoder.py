@@ -33,6 +33,7 @@ FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
 FUSED_TRAIN_MSDA = os.environ.get('CGG_FUSED_TRAIN_MSDA', '1') != '0'   # training: MSDeformAttn prologue inside the kernels (fwd + bwd)
 FUSED_TRAIN_LN = os.environ.get('CGG_FUSED_TRAIN_LN', '1') != '0'   # training: residual + LayerNorm as one-pass HIP fwd / bwd
 VALUE_HEAD_MAJOR = os.environ.get('CGG_VALUE_HEAD_MAJOR', '1') != '0'   # value written (B, 8, N, 32) for the MSDeformAttn gather
+MERGED_PROJ = os.environ.get('CGG_MERGED_PROJ', '1') != '0'   # x3a encoder stream: value / offsets / logits of a layer from ONE GEMM
 POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
 
 
@@ -889,21 +890,57 @@ class MSDeformAttnPixelDecoder(nn.Module):
         for layer in self.encoder.layers:
             attn = layer.attentions[0]
             H = attn.num_heads
-            so, aw = attn.sampling_offsets, attn.attention_weights
+            so, aw, vp = attn.sampling_offsets, attn.attention_weights, attn.value_proj
+            n0, n1 = layer.norms
+            fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
+            last = layer is self.encoder.layers[-1]
+            n_cat = so.weight.shape[0] + aw.weight.shape[0]
+            if self._merged_proj_ok(layer):
+                # ONE projection GEMM per layer (round 6): rows [value | offsets | logits] = src [Wv; Woff; Watt]^T + [bv; boff; batt]
+                # + T with the batch-independent table T = [0 | pos [Woff; Watt]^T] in the GEMM's residual input ((src + pos) W =
+                # src W + pos W: `srcp` rows are neither written by the layer tail nor read here); the sampling kernel takes its
+                # value operand as the first 256 columns of those rows.
+                w_all = runtime.derived_cached('msda_wall32', (vp.weight, so.weight, aw.weight),
+                                               lambda: torch.cat([vp.weight, so.weight, aw.weight], 0).float().contiguous())
+                b_all = runtime.derived_cached('msda_ball32', (vp.bias, so.bias, aw.bias),
+                                               lambda: torch.cat([vp.bias, so.bias, aw.bias], 0).float().contiguous())
+
+                def table():
+                    w_cat = torch.cat([so.weight, aw.weight], 0).float().contiguous()
+                    t = torch.zeros((N, C + n_cat), dtype=torch.float32, device=pos.device)
+                    t[:, C:] = runtime.linear_x3(pos.float().contiguous(), w_cat)
+                    return t
+                tab = runtime.derived_cached('msda_pos_table', (pos, so.weight, aw.weight), table)
+                rows_all = runtime.linear_x3s(src.view(B * N, C), w_all, b_all, res=tab, res_mod=N).view(B, N, C + n_cat)
+                a = ops.msda_forward_fused_rows(rows_all, level_hw, level_start, ref, attn.num_points, H, C // H)
+                src, srcp = ops.encoder_layer_tail_x3(a, src, x3w(attn.output_proj), attn.output_proj.bias,
+                                                      (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
+                                                      (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=False, x3a=True)
+                continue
             w_cat = runtime.derived_cached('msda_wcat32', (so.weight, aw.weight),
                                            lambda: torch.cat([so.weight, aw.weight], 0).float().contiguous())
             b_cat = runtime.derived_cached('msda_bcat32', (so.bias, aw.bias),
                                            lambda: torch.cat([so.bias, aw.bias], 0).float().contiguous())
+            if srcp is None:             # (a merged layer in front of this one did not produce src + pos)
+                raise ops.CggError('encoder stream: mixed merged / split projection layers are not supported')
             value = runtime.linear_x3s(src.view(B * N, C), attn.value_proj.weight, attn.value_proj.bias).view(B, N, H, C // H)
             offs = runtime.linear_x3s(srcp.view(B * N, C), w_cat, b_cat).view(B, N, -1)
             a = ops.msda_forward_fused(value, level_hw, level_start, offs, ref, attn.num_points)
-            n0, n1 = layer.norms
-            fc1, fc2 = layer.ffns[0].layers[0][0], layer.ffns[0].layers[1]
-            last = layer is self.encoder.layers[-1]
             src, srcp = ops.encoder_layer_tail_x3(a, src, x3w(attn.output_proj), attn.output_proj.bias,
                                                   (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
                                                   (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True)
         return src
+
+    @staticmethod
+    def _merged_proj_ok(layer):
+        """the layer's value / offsets / logits projections as one GEMM + `cgg_msda_forward_fused_vld` (H = 8, D = 32, L = 3, P = 4)"""
+        attn = layer.attentions[0]
+        so, aw, vp = attn.sampling_offsets, attn.attention_weights, attn.value_proj
+        C, H = vp.weight.shape[1], attn.num_heads
+        n_cat = so.weight.shape[0] + aw.weight.shape[0]
+        return (MERGED_PROJ and H == 8 and C == 256 and vp.weight.shape[0] == 256 and attn.num_levels == 3 and attn.num_points == 4
+                and n_cat == 3 * H * attn.num_levels * attn.num_points and (C + n_cat) % 32 == 0
+                and all(m.bias is not None for m in (vp, so, aw)))
 
     def _forward_stream_x3a(self, feats, defer_fpn=False):
         """`forward_stream_x3` on x3a rows: the backbone maps arrive as x3a (`ops.X3ATensor`; plain f32 maps are encoded), every
@@ -926,7 +963,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
         pos = self._pos_cached(level_hw, dev)
         ref = self._reference_points(level_hw, dev)
         src = torch.empty((B, N, C), dtype=torch.float32, device=dev)      # x3a rows
-        srcp = torch.empty((B, N, C), dtype=torch.float32, device=dev)     # src + pos, x3a rows (the first layer's offsets input)
+        # src + pos, x3a rows (the first layer's offsets input) -- not needed when every layer takes the merged projection
+        need_srcp = not all(self._merged_proj_ok(l) for l in self.encoder.layers)
+        srcp = torch.empty((B, N, C), dtype=torch.float32, device=dev) if need_srcp else None
         ws = ops.group_norm_nhwc_workspace(B, int(feats[0].shape[2]) * int(feats[0].shape[3]), 32, dev)   # largest map
         for i in range(self.num_encoder_levels):
             f = feats[self.num_input_levels - i - 1]
@@ -935,7 +974,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
             y = runtime.linear_x3s(rows(f), cm.conv.weight.flatten(1), cm.conv.bias)
             gn = getattr(cm, cm.norm_name)
             ops.group_norm_nhwc_x3a(y.view(B, h * w, C), gn.weight, gn.bias, 32, gn.eps, ws, out=(src, level_start[i] * C, N * C),
-                                    pos=(pos, level_start[i] * C), outp=(srcp, level_start[i] * C))
+                                    pos=(pos, level_start[i] * C) if need_srcp else None,
+                                    outp=(srcp, level_start[i] * C) if need_srcp else None)
         src = self._encoder_stream_x3a(src, srcp, pos, ref, level_hw, level_start)
         mems = [ops.as_x3a(src[:, s0:s0 + h * w, :]) for s0, (h, w) in zip(level_start, level_hw)]
         fpn = (rows(feats[0]), int(feats[0].shape[2]), int(feats[0].shape[3]), src, level_start[-1], N, level_hw[-1], ws)

@@ -109,6 +109,14 @@ int cgg_msda_forward_hostlevels(const void* value, const int32_t* level_hw,
                                 float* out, int B, int Nv, int H, int D, int L, int Nq, int P,
                                 int value_dtype, int fused, cgg_stream_t stream);
 
+/* cgg_msda_forward_fused (host level table, f32) with `value` as the first H*D COLUMNS of wider rows (row stride vld floats, vld % 32
+ * == 0): the x3a encoder stream (round 6) projects value, sampling offsets and attention logits of a layer with ONE GEMM whose rows
+ * are [value 256 | offsets 192 | logits 96]; value_rows and offs_logits then point into the same (B, Nq, 544) buffer. H = 8, D = 32,
+ * L = 3, P = 4 only (CGG_EUNSUPPORTED otherwise). */
+int cgg_msda_forward_fused_vld(const float* value_rows, int vld, const int32_t* level_hw, const int32_t* level_start,
+                               const float* offs_logits, int ld, const float* ref_points, float* out, int B, int Nv, int H, int D,
+                               int L, int Nq, int P, cgg_stream_t stream);
+
 /* Training: the MSDeformAttn prologue ([3P] MultiScaleDeformableAttention.forward: reference_points + offsets / (W_l, H_l),
  * softmax of the attention logits) and its backward as elementwise kernels on the raw rows [offsets H*L*P*2 | logits H*L*P]
  * (f32, row stride ld): loc (B, Nq, H, L, P, 2) / attn (B, Nq, H, L, P) out; backward: grad_rows (ld == 3 H L P) from the
