@@ -45,18 +45,19 @@ struct E3Q {                   // rotating B-fragment queue of one n-tile: hi an
   e3_u32x4 h[E3_PF], l[E3_PF];
 };
 
-// One 64 x 64 block of C += A B^T over 16 k-steps, x3 arithmetic. A-fragment images (hi at a, lo at a + lo_off) of the two
-// 32-row m-tiles in LDS; B fragments of the two 32-column n-tiles come through the rotating queues q0 / q1, which on entry hold
-// this block's first E3_PF k-steps and on exit the NEXT block's (nb*), so the weight stream never drains at a block boundary.
+// One 64 x (32 TN) block of C += A B^T over 16 k-steps, x3 arithmetic. A-fragment images (hi at a, lo at a + lo_off) of the two
+// 32-row m-tiles in LDS; B fragments of the TN 32-column n-tiles come through the rotating queues q[], which on entry hold this
+// block's first E3_PF k-steps and on exit the NEXT block's (nh / nl), so the weight stream never drains at a block boundary.
 // XS = true: row image, swizzled by the whole k-step (slot ^ s); XS = false: hidden image, swizzled by k-step parity (see
 // the store below): a0 / a1 = even k-step lane pointers, a0o / a1o odd ones.
-template <bool XS>
-__device__ __forceinline__ void e3_block(f32x16 (&acc)[2][2], const e3_u32x4* __restrict__ a0, const e3_u32x4* __restrict__ a1,
+// TN = 2: four wavefronts per workgroup (one per SIMD), 64 columns each; TN = 1 (round 6): EIGHT wavefronts = two per SIMD, 32
+// columns each -- a wave issues in order, so with one wave per SIMD its LDS reads, weight loads and epilogue VALU work all ran with
+// the matrix pipe idle; with two, one wave's MFMAs cover the other's non-MFMA code (the lesson of this round's einsum kernel).
+template <bool XS, int TN>
+__device__ __forceinline__ void e3_block(f32x16 (&acc)[2][TN], const e3_u32x4* __restrict__ a0, const e3_u32x4* __restrict__ a1,
                                          const e3_u32x4* __restrict__ a0o, const e3_u32x4* __restrict__ a1o, int lo_off, int xl,
-                                         E3Q& q0, E3Q& q1, const e3_u32x4* __restrict__ b0h, const e3_u32x4* __restrict__ b0l,
-                                         const e3_u32x4* __restrict__ b1h, const e3_u32x4* __restrict__ b1l,
-                                         const e3_u32x4* __restrict__ n0h, const e3_u32x4* __restrict__ n0l,
-                                         const e3_u32x4* __restrict__ n1h, const e3_u32x4* __restrict__ n1l) {
+                                         E3Q (&q)[TN], const e3_u32x4* const (&bh)[TN], const e3_u32x4* const (&bl)[TN],
+                                         const e3_u32x4* const (&nh)[TN], const e3_u32x4* const (&nl)[TN]) {
   if constexpr (XS) asm volatile("" : "+v"(xl));
   auto load_a = [&](int s, e3_u32x4& h0, e3_u32x4& l0, e3_u32x4& h1, e3_u32x4& l1) {
     if constexpr (XS) {
@@ -78,40 +79,48 @@ __device__ __forceinline__ void e3_block(f32x16 (&acc)[2][2], const e3_u32x4* __
   load_a(0, ah0, al0, ah1, al1);
 #pragma unroll
   for (int s = 0; s < E3_STEPS; ++s) {
-    const e3_u32x4 b0hv = q0.h[s % E3_PF], b0lv = q0.l[s % E3_PF], b1hv = q1.h[s % E3_PF], b1lv = q1.l[s % E3_PF];
+    e3_u32x4 bhv[TN], blv[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      bhv[t] = q[t].h[s % E3_PF];
+      blv[t] = q[t].l[s % E3_PF];
+    }
     const e3_u32x4 vah0 = ah0, val0 = al0, vah1 = ah1, val1 = al1;
     if (s + 1 < E3_STEPS) load_a(s + 1, ah0, al0, ah1, al1);
-    if (s + E3_PF < E3_STEPS) {
-      q0.h[s % E3_PF] = b0h[(s + E3_PF) * 64];
-      q0.l[s % E3_PF] = b0l[(s + E3_PF) * 64];
-      q1.h[s % E3_PF] = b1h[(s + E3_PF) * 64];
-      q1.l[s % E3_PF] = b1l[(s + E3_PF) * 64];
-    } else {
-      q0.h[s % E3_PF] = n0h[(s + E3_PF - E3_STEPS) * 64];
-      q0.l[s % E3_PF] = n0l[(s + E3_PF - E3_STEPS) * 64];
-      q1.h[s % E3_PF] = n1h[(s + E3_PF - E3_STEPS) * 64];
-      q1.l[s % E3_PF] = n1l[(s + E3_PF - E3_STEPS) * 64];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      if (s + E3_PF < E3_STEPS) {
+        q[t].h[s % E3_PF] = bh[t][(s + E3_PF) * 64];
+        q[t].l[s % E3_PF] = bl[t][(s + E3_PF) * 64];
+      } else {
+        q[t].h[s % E3_PF] = nh[t][(s + E3_PF - E3_STEPS) * 64];
+        q[t].l[s % E3_PF] = nl[t][(s + E3_PF - E3_STEPS) * 64];
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);                 // loads of the later steps issue BEFORE this step's twelve MFMAs
+    __builtin_amdgcn_sched_barrier(0);                 // loads of the later steps issue BEFORE this step's MFMAs
 #define E3_MF(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
-    E3_MF(val0, b0hv, acc[0][0]);
-    E3_MF(val0, b1hv, acc[0][1]);
-    E3_MF(val1, b0hv, acc[1][0]);
-    E3_MF(val1, b1hv, acc[1][1]);
-    E3_MF(vah0, b0lv, acc[0][0]);
-    E3_MF(vah0, b1lv, acc[0][1]);
-    E3_MF(vah1, b0lv, acc[1][0]);
-    E3_MF(vah1, b1lv, acc[1][1]);
-    E3_MF(vah0, b0hv, acc[0][0]);
-    E3_MF(vah0, b1hv, acc[0][1]);
-    E3_MF(vah1, b0hv, acc[1][0]);
-    E3_MF(vah1, b1hv, acc[1][1]);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      E3_MF(val0, bhv[t], acc[0][t]);
+      E3_MF(val1, bhv[t], acc[1][t]);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      E3_MF(vah0, blv[t], acc[0][t]);
+      E3_MF(vah1, blv[t], acc[1][t]);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      E3_MF(vah0, bhv[t], acc[0][t]);
+      E3_MF(vah1, bhv[t], acc[1][t]);
+    }
 #undef E3_MF
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-__global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void cgg_encoder_tail_x3_kernel(
     const float* __restrict__ a32, const float* __restrict__ x32, const CggX3W wo, const float* __restrict__ bo,
     const float* __restrict__ gamma0, const float* __restrict__ beta0, float eps0, const CggX3W w1, const float* __restrict__ b1,
     const CggX3W w2, const float* __restrict__ b2, const float* __restrict__ gamma1, const float* __restrict__ beta1, float eps1,
@@ -121,6 +130,10 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   e3_u32x4* xfrag = reinterpret_cast<e3_u32x4*>(e3_smem);                   // row image: hi [2 m-tiles][16][64] | lo    64 KiB
   e3_u32x4* hfrag = xfrag + 2 * E3_IMG;                                      // hidden chunk: hi | lo                     64 KiB
   float* tile = reinterpret_cast<float*>(hfrag);                             // [64][E3_TS] f32 LayerNorm tile, overlays the hidden images (65 KiB)
+  constexpr int NT = 64 * NWV;                                               // threads per workgroup
+  constexpr int TN = 8 / NWV;                                                // 32-column n-tiles per wave (2: four waves, 1: eight)
+  constexpr int RW = E3_RB / NWV;                                            // rows per wave in the row-major (LayerNorm) phases
+  constexpr int NIT = RW / 4;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int j = lane & 31, hi5 = lane >> 5;
   const int m0 = blockIdx.x * E3_RB;
@@ -128,24 +141,24 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   const int KS2 = F >> 4;                                                    // k-steps of W2
 
   // weight stream: the first E3_PF k-steps of the output projection are in flight while the rows are staged
-  E3Q q0, q1;
+  E3Q q[TN];
 #pragma unroll
-  for (int s = 0; s < E3_PF; ++s) {
-    q0.h[s] = wo.hi[((size_t)(2 * wn) * E3_STEPS + s) * 64 + lane];
-    q0.l[s] = wo.lo[((size_t)(2 * wn) * E3_STEPS + s) * 64 + lane];
-    q1.h[s] = wo.hi[((size_t)(2 * wn + 1) * E3_STEPS + s) * 64 + lane];
-    q1.l[s] = wo.lo[((size_t)(2 * wn + 1) * E3_STEPS + s) * 64 + lane];
-  }
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int s = 0; s < E3_PF; ++s) {
+      q[t].h[s] = wo.hi[((size_t)(TN * wn + t) * E3_STEPS + s) * 64 + lane];
+      q[t].l[s] = wo.lo[((size_t)(TN * wn + t) * E3_STEPS + s) * 64 + lane];
+    }
   // ---- attention rows -> split A-fragment images: 32-byte piece (row, k8) = 8 consecutive channels -> slot (mt, k-step = k8 / 2,
   //      (row % 32 + 32 (k8 & 1)) ^ k-step): the XOR spreads a row's pieces over all bank groups ----
   //      All 16 loads of a thread are issued before the first split: the rolled loop the compiler made of the one-piece-at-a-time
   //      form waited for every pair of loads (8 serial memory latencies at the head of every workgroup).
   {
-    constexpr int NP = E3_RB * 32 / E3_NT;
+    constexpr int NP = E3_RB * 32 / NT;
     f32x4 v0[NP], v1[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int p = tid + i * E3_NT, row = p >> 5, k8 = p & 31;
+      const int p = tid + i * NT, row = p >> 5, k8 = p & 31;
       const int mc = m0 + row < M ? m0 + row : M - 1;
       const float* src = a32 + (size_t)mc * E3_C + 8 * k8;
       v0[i] = *reinterpret_cast<const f32x4*>(src);
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int p = tid + i * E3_NT, row = p >> 5, k8 = p & 31;
+      const int p = tid + i * NT, row = p >> 5, k8 = p & 31;
       e3_u32x4 h, l;
       cgg_x3_split8(v0[i], v1[i], h, l);
       const int slot = ((row >> 5) * E3_STEPS + (k8 >> 1)) * 64 + (((row & 31) + 32 * (k8 & 1)) ^ (k8 >> 1));
@@ -164,10 +177,10 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   }
   // the layer-input rows LayerNorm 0 adds (its residual) are requested now: they arrive behind the output projection's MFMAs
   const int sub = lane & 15, rsub = lane >> 4;
-  f32x4 xr[4][4];                                       // residual rows (later: x1, LayerNorm 1's residual), f32
+  f32x4 xr[NIT][4];                                     // residual rows (later: x1, LayerNorm 1's residual), f32
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = 16 * wn + 4 * it + rsub;
+  for (int it = 0; it < NIT; ++it) {
+    const int row = RW * wn + 4 * it + rsub;
     const int mc = m0 + row < M ? m0 + row : M - 1;
     if (x3a) {
       // x3a rows (csrc/x3.h): channels c0 = 4 sub + 64 k .. + 3 are half (sub & 1) of the group c0 / 8 = [8 hi | 8 lo]
@@ -181,23 +194,30 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
       for (int k = 0; k < 4; ++k) xr[it][k] = *reinterpret_cast<const f32x4*>(x32 + (size_t)mc * E3_C + 4 * sub + 64 * k);
     }
   }
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   __syncthreads();
   // ---- output projection: a Wo^T (next block in the weight stream: W1's first chunk) ----
   {
-    const size_t o0 = ((size_t)(2 * wn) * E3_STEPS) * 64 + lane, o1 = ((size_t)(2 * wn + 1) * E3_STEPS) * 64 + lane;
-    e3_block<true>(acc, xfrag, xfrag, xfrag, xfrag, E3_IMG, lane, q0, q1, wo.hi + o0, wo.lo + o0, wo.hi + o1, wo.lo + o1,
-                   w1.hi + o0, w1.lo + o0, w1.hi + o1, w1.lo + o1);
+    const e3_u32x4 *bh[TN], *bl[TN], *nh[TN], *nl[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const size_t o = ((size_t)(TN * wn + t) * E3_STEPS) * 64 + lane;
+      bh[t] = wo.hi + o;
+      bl[t] = wo.lo + o;
+      nh[t] = w1.hi + o;
+      nl[t] = w1.lo + o;
+    }
+    e3_block<true, TN>(acc, xfrag, xfrag, xfrag, xfrag, E3_IMG, lane, q, bh, bl, nh, nl);
   }
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = 64 * wn + 32 * nt + j;
+  for (int nt = 0; nt < TN; ++nt) {
+    const int col = 32 * TN * wn + 32 * nt + j;
     const float cs = wo.scale[col], bias = bo[col];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -211,8 +231,8 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
     uint2* xl2 = reinterpret_cast<uint2*>(xfrag + E3_IMG);
     constexpr float inv_n = 1.f / (float)E3_C;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = 16 * wn + 4 * it + rsub;
+    for (int it = 0; it < NIT; ++it) {
+      const int row = RW * wn + 4 * it + rsub;
       f32x4 v[4];
       float sm = 0.f;
 #pragma unroll
@@ -246,11 +266,11 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
       }
     }
   }
-  f32x16 acc2[2][2];
+  f32x16 acc2[2][TN];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
   __syncthreads();                                     // x1 image complete; the tile (hidden region) is free again
@@ -269,27 +289,38 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   for (int X = 0; X < 2; ++X)
 #pragma unroll
     for (int Y = 0; Y < 2; ++Y)
-      hb[X][Y] = (((4 * wn + k1) * 64 + half * 32 + 2 * (X ^ k1) + 8 * (Y ^ half) + 4 * hi5 + odd) << 2) + ((j & 7) >> 1);
+      hb[X][Y] = (((2 * TN * wn + k1) * 64 + half * 32 + 2 * (X ^ k1) + 8 * (Y ^ half) + 4 * hi5 + odd) << 2) + ((j & 7) >> 1);
   const uint32_t rot = 16u * (uint32_t)odd;
   float hmax = 0.f;                                    // largest hidden activation: beyond the f16 x 3 range it raises the overflow flag
   for (int c = 0; c < nchunk; ++c) {
-    // ---- GEMM 1: hidden columns 256 c + 64 wn .. (n-tiles 8 c + 2 wn, + 1 of W1); next in the stream: this chunk's W2 slice ----
+    // ---- GEMM 1: hidden columns 256 c + 32 TN wn .. (n-tiles 8 c + TN wn .. of W1); next in the stream: this chunk's W2 slice ----
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const size_t g20 = ((size_t)(2 * wn) * KS2 + 16 * c) * 64 + lane, g21 = ((size_t)(2 * wn + 1) * KS2 + 16 * c) * 64 + lane;
-    const size_t g10 = ((size_t)(8 * c + 2 * wn) * E3_STEPS) * 64 + lane, g11 = ((size_t)(8 * c + 2 * wn + 1) * E3_STEPS) * 64 + lane;
-    e3_block<true>(acc, xfrag, xfrag, xfrag, xfrag, E3_IMG, lane, q0, q1, w1.hi + g10, w1.lo + g10, w1.hi + g11, w1.lo + g11,
-                   w2.hi + g20, w2.lo + g20, w2.hi + g21, w2.lo + g21);
+    const e3_u32x4 *w1h[TN], *w1l[TN], *w2h[TN], *w2l[TN], *n1h[TN], *n1l[TN];
+    const int cn = c + 1 < nchunk ? c + 1 : 0;         // last chunk: the queue refills with chunk 0 again (unused)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const size_t g2 = ((size_t)(TN * wn + t) * KS2 + 16 * c) * 64 + lane;
+      const size_t g1 = ((size_t)(8 * c + TN * wn + t) * E3_STEPS) * 64 + lane;
+      const size_t gn = ((size_t)(8 * cn + TN * wn + t) * E3_STEPS) * 64 + lane;
+      w1h[t] = w1.hi + g1;
+      w1l[t] = w1.lo + g1;
+      w2h[t] = w2.hi + g2;
+      w2l[t] = w2.lo + g2;
+      n1h[t] = w1.hi + gn;
+      n1l[t] = w1.lo + gn;
+    }
+    e3_block<true, TN>(acc, xfrag, xfrag, xfrag, xfrag, E3_IMG, lane, q, w1h, w1l, w2h, w2l);
     // relu(. + b1) -> split A-fragment images of the chunk; column (64 wn + 32 nt + j) of the chunk = k index of GEMM 2. Lanes j,
     // j ^ 1 hold neighbouring columns: per register pair they swap one value, the even lane then owns row(2 rp), the odd lane
     // row(2 rp + 1), and each stores one 32-bit word per image
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int hc = 256 * c + 64 * wn + 32 * nt + j;
+    for (int nt = 0; nt < TN; ++nt) {
+      const int hc = 256 * c + 32 * TN * wn + 32 * nt + j;
       const float cs1 = w1.scale[hc], bias1 = b1[hc];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -308,19 +339,16 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
       }
     }
     __syncthreads();                                   // the chunk's hidden block is complete
-    // ---- GEMM 2: output columns 64 wn .. over the chunk's 256 hidden units (k-steps 16 c .. of W2); next: W1's next chunk ----
-    const int cn = c + 1 < nchunk ? c + 1 : 0;         // last chunk: the queue refills with chunk 0 again (unused)
-    const size_t n10 = ((size_t)(8 * cn + 2 * wn) * E3_STEPS) * 64 + lane, n11 = ((size_t)(8 * cn + 2 * wn + 1) * E3_STEPS) * 64 + lane;
-    e3_block<false>(acc2, ha0, ha1, ha0o, ha1o, E3_IMG, 0, q0, q1, w2.hi + g20, w2.lo + g20, w2.hi + g21, w2.lo + g21,
-                    w1.hi + n10, w1.lo + n10, w1.hi + n11, w1.lo + n11);
+    // ---- GEMM 2: output columns 32 TN wn .. over the chunk's 256 hidden units (k-steps 16 c .. of W2); next: W1's next chunk ----
+    e3_block<false, TN>(acc2, ha0, ha1, ha0o, ha1o, E3_IMG, 0, q, w2h, w2l, n1h, n1l);
     __syncthreads();                                   // hfrag is rewritten by the next chunk (and by the tile below)
   }
 
   if (flag && !(hmax * CGG_X3_ASCALE <= CGG_X3A_MAX)) atomicOr(flag, 1);
   // ---- f32 block (* colscale + b2) -> LDS tile; the hidden images are dead ----
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = 64 * wn + 32 * nt + j;
+  for (int nt = 0; nt < TN; ++nt) {
+    const int col = 32 * TN * wn + 32 * nt + j;
     const float cs2 = w2.scale[col], bias2 = b2[col];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -329,11 +357,11 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   }
   // the pos rows of this wave's 16 output rows are requested before the barrier (unpredicated: rows past M use row M - 1) and arrive
   // under the LayerNorm reductions; loaded inside the store loop they were two loads + s_waitcnt vmcnt(0) per 4 stores
-  f32x4 pp[4][4];
+  f32x4 pp[NIT][4];
   if (yp32) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int m = m0 + 16 * wn + 4 * it + rsub;
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + RW * wn + 4 * it + rsub;
       const float* prow = pos + (size_t)((m < M ? m : M - 1) % pos_rows) * E3_C;
 #pragma unroll
       for (int k = 0; k < 4; ++k) pp[it][k] = *reinterpret_cast<const f32x4*>(prow + 4 * sub + 64 * k);
@@ -349,8 +377,8 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
   }
   constexpr float inv_n = 1.f / (float)E3_C;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = 16 * wn + 4 * it + rsub, m = m0 + row;
+  for (int it = 0; it < NIT; ++it) {
+    const int row = RW * wn + 4 * it + rsub, m = m0 + row;
     f32x4 v[4];
     float sm = 0.f;
 #pragma unroll
@@ -405,6 +433,9 @@ __global__ __launch_bounds__(E3_NT) void cgg_encoder_tail_x3_kernel(
 
 int* cgg_x3_overflow_flag_ptr();       // x3s_gemm.hip
 
+// CGG_TAIL_WAVES=4: round 3-5's four-wavefront form (A/B); read once, when the library is loaded
+static const bool e3_waves8 = !(getenv("CGG_TAIL_WAVES") && atoi(getenv("CGG_TAIL_WAVES")) == 4);
+
 static int e3_launch(const float* a32, const float* x32, const void* wo_x3, const float* bo, const float* gamma0,
                      const float* beta0, float eps0, const void* w1_x3, const float* b1, const void* w2_x3,
                      const float* b2, const float* gamma1, const float* beta1, float eps1, const float* pos,
@@ -424,14 +455,20 @@ static int e3_launch(const float* a32, const float* x32, const void* wo_x3, cons
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_tail_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)cgg_encoder_tail_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)cgg_encoder_tail_x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     CGG_REQUIRE(e == hipSuccess, (int)e, "%s: cannot raise dynamic LDS to %zu", who, lds);
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(cgg_encoder_tail_x3_kernel, dim3((M + E3_RB - 1) / E3_RB), dim3(E3_NT), lds, (hipStream_t)stream, a32, x32,
-                     cgg_x3_view(wo_x3, E3_C, E3_C), bo, gamma0, beta0, eps0, cgg_x3_view(w1_x3, F, E3_C), b1,
-                     cgg_x3_view(w2_x3, E3_C, F), b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M, F, x3a,
-                     cgg_x3_overflow_flag_ptr());
+#define E3_GO(NWV)                                                                                                               \
+  hipLaunchKernelGGL(cgg_encoder_tail_x3_kernel<NWV>, dim3((M + E3_RB - 1) / E3_RB), dim3(64 * NWV), lds, (hipStream_t)stream, a32, x32, \
+                     cgg_x3_view(wo_x3, E3_C, E3_C), bo, gamma0, beta0, eps0, cgg_x3_view(w1_x3, F, E3_C), b1,                  \
+                     cgg_x3_view(w2_x3, E3_C, F), b2, gamma1, beta1, eps1, pos, pos_rows, y32, yp32, M, F, x3a,                 \
+                     cgg_x3_overflow_flag_ptr())
+  if (e3_waves8) E3_GO(8);
+  else E3_GO(4);
+#undef E3_GO
   CGG_CHECK_LAUNCH(who);
   return CGG_OK;
 }

@@ -33,7 +33,9 @@ FUSED_PROJ = os.environ.get('CGG_FUSED_PROJ', '1') != '0'
 FUSED_TRAIN_MSDA = os.environ.get('CGG_FUSED_TRAIN_MSDA', '1') != '0'   # training: MSDeformAttn prologue inside the kernels (fwd + bwd)
 FUSED_TRAIN_LN = os.environ.get('CGG_FUSED_TRAIN_LN', '1') != '0'   # training: residual + LayerNorm as one-pass HIP fwd / bwd
 VALUE_HEAD_MAJOR = os.environ.get('CGG_VALUE_HEAD_MAJOR', '1') != '0'   # value written (B, 8, N, 32) for the MSDeformAttn gather
-MERGED_PROJ = os.environ.get('CGG_MERGED_PROJ', '1') != '0'   # x3a encoder stream: value / offsets / logits of a layer from ONE GEMM
+# x3a encoder stream: value / offsets / logits of a layer from ONE GEMM (needs the strided-value sampling kernel: not with the
+# generic MSDeformAttn kernels forced)
+MERGED_PROJ = os.environ.get('CGG_MERGED_PROJ', '1') != '0' and not os.environ.get('CGG_MSDA_GENERIC')
 POS_IN_PROJ = os.environ.get('CGG_POS_IN_PROJ', '1') != '0'   # the projection kernel forms x + pos from a bf16 pos table   # value_proj + offsets/weights GEMMs as one HIP launch
 
 

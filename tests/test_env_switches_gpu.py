@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SWITCHES = ['', 'CGG_X3=0', 'CGG_X3A=0', 'CGG_X3_STEM=0', 'CGG_FUSED_TAIL=0', 'CGG_MSDA_GENERIC=1', 'CGG_MERGED_PROJ=0',
+SWITCHES = ['', 'CGG_X3=0', 'CGG_X3A=0', 'CGG_X3_STEM=0', 'CGG_FUSED_TAIL=0', 'CGG_MSDA_GENERIC=1', 'CGG_MERGED_PROJ=0', 'CGG_TAIL_WAVES=4',
             'CGG_EXACT_F32_LOGITS=0', 'CGG_XATTN_X3=0', 'CGG_X3_GSCALE=0']
 
 
