@@ -366,7 +366,7 @@ static int xg_launch(bool conv, const char* who, const float* a, int lda, const 
               "%s: second output needs 0 < col2 < N, col2 %% 32 == 0, ldc2 >= N - col2 (col2=%d ldc2=%d)", who, col2, ldc2);
   CGG_REQUIRE(res_mod >= 0 && (!res_mod || res), CGG_EINVAL, "%s: res_mod without res", who);
   // tile shape: the largest whose grid still has >= 192 workgroups. Measured in the 3-stage pipelined step (A/B pairs on one box,
-  // scratch/ab_tiles.sh): the larger tiles are the more efficient ones per FLOP, and the CUs a small grid leaves idle are taken by
+  // round-4 A/B script, `git log -- scratch/`): the larger tiles are the more efficient ones per FLOP, and the CUs a small grid leaves idle are taken by
   // the other streams' kernels, so the step prefers FEWER, BIGGER tiles than a stand-alone launch does -- threshold 384 + smaller
   // tiles for K <= 512 (the stand-alone optimum of the first version): 349 images/s; 192, no K rule: 358 (eager GEMM time equal);
   // 128: 363 with +7 % eager GEMM time and +3 % latency (not taken).

@@ -694,7 +694,7 @@ def test_add_layernorm_stream_and_bf16_msda(dev):
     got = ops.msda_forward_fused_bf16(value.to(dev), shapes, starts, raw.to(dev), refp.to(dev), P)
     assert got.dtype == torch.bfloat16
     # the quad-shared-tap kernel folds w_point * w_corner before the channel loop: the f32 sums agree to rounding, the
-    # bf16 outputs to one ulp (scratch/msda_ab.py: 0.01 % of the elements differ, never by more than one ulp)
+    # bf16 outputs to one ulp (round-2 A/B measurement: 0.01 % of the elements differ, never by more than one ulp)
     want = ref32.cpu().bfloat16().float()
     d = (got.cpu().float() - want).abs()
     assert bool((d <= want.abs().clamp(min=1e-3) * 2.0 ** -7).all()), float(d.max())
