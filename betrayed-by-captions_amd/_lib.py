@@ -25,7 +25,7 @@ PROTOTYPES = {
     'cgg_version': (_c_int, []),
     'cgg_init': (_c_int, [_c_int]),
     'cgg_msda_forward_fused_vld': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp]),
-    'cgg_msda_backward_hostlevels_ws': (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp, _c_i64, _c_vp, _c_vp]),
+    'cgg_msda_backward_hostlevels_ws': (_c_int, [_c_vp, _c_int] + [_c_vp] * 8 + [_c_int] * 8 + [_c_vp, _c_i64, _c_vp, _c_vp]),
     'cgg_msda_backward_workspace_bytes': (_c_i64, [_c_vp, _c_vp] + [_c_int] * 7),
     'cgg_msda_read_levels': (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
     'cgg_last_error_string': (ctypes.c_char_p, []),

@@ -48,7 +48,8 @@ template <int NT, int MAXIT, int PT, int MODE>
 __device__ __forceinline__ void msda_sorted_region(const MsdaLevels& lv, const MsdaSortPlan& pl, const float* __restrict__ loc,
                                                    const float* __restrict__ attw, const float* __restrict__ gout,
                                                    float* __restrict__ gvalue, int Nv, int H, int L, int Nq, int P_rt,
-                                                   uint32_t* __restrict__ ovf, uint32_t* __restrict__ aflags, const int bid, float* smem) {
+                                                   uint32_t* __restrict__ ovf, uint32_t* __restrict__ aflags, const int bid, float* smem,
+                                                   const int gvld) {
   constexpr int D = 32;
   constexpr bool light = MODE == 3;
   const int P = PT ? PT : P_rt;
@@ -108,7 +109,10 @@ __device__ __forceinline__ void msda_sorted_region(const MsdaLevels& lv, const M
   if (tid == 0) nfb = 0u;
   __syncthreads();
 
-  float* gvl = gvalue + ((size_t)b * Nv + lv.start[ld]) * rowstride + (size_t)h * D;
+  // grad_value rows may be padded like the value rows (gvld floats per pixel, 0 = H D): consecutive pixels' 128-byte atomics then
+  // rotate over the L2 channels instead of hitting one 512-byte-aligned set
+  const size_t gvrow = gvld ? (size_t)gvld : rowstride;
+  float* gvl = gvalue + ((size_t)b * Nv + lv.start[ld]) * gvrow + (size_t)h * D;
   const int nitems = nslots * P;
   // ---- this thread's taps: locations / weights requested first (the longest latency), then the grad_out rows are staged ----
   float tx_[MAXIT], ty_[MAXIT], tw_[MAXIT];
@@ -260,7 +264,7 @@ __device__ __forceinline__ void msda_sorted_region(const MsdaLevels& lv, const M
           a3 = fmaf(__uint_as_float(rb.w), g3, a3);
         }
         // inside the image: only valid corners were counted
-        atomicAdd(gvl + (size_t)((oy + wy) * Wd + ox + wx) * rowstride + lane, (a0 + a1) + (a2 + a3));
+        atomicAdd(gvl + (size_t)((oy + wy) * Wd + ox + wx) * gvrow + lane, (a0 + a1) + (a2 + a3));
       }
       wy += dy;
       wx += dx;
@@ -287,7 +291,7 @@ __device__ __forceinline__ void msda_sorted_region(const MsdaLevels& lv, const M
     const uint2 r0 = rec[cap - 1 - i];
     const uint32_t slot = r0.x & 0xfffu;
     const float g = light ? gout[((size_t)b * Nq + qn[slot]) * rowstride + (size_t)h * D + lane] : gs[slot * D + lane];
-    atomicAdd(gvl + (size_t)(r0.x >> 12) * rowstride + lane, __uint_as_float(r0.y) * g);
+    atomicAdd(gvl + (size_t)(r0.x >> 12) * gvrow + lane, __uint_as_float(r0.y) * g);
   }
 }
 
@@ -298,10 +302,10 @@ template <int NT, int MAXIT, int PT, int MODE>
 __global__ __launch_bounds__(NT) void cgg_msda_bwd_sorted_kernel(MsdaLevels lv, MsdaSortPlan pl, const float* __restrict__ loc,
                                                                 const float* __restrict__ attw, const float* __restrict__ gout,
                                                                 float* __restrict__ gvalue, int Nv, int H, int L, int Nq, int P_rt,
-                                                                uint32_t* __restrict__ ovf, uint32_t* __restrict__ aflags) {
+                                                                uint32_t* __restrict__ ovf, uint32_t* __restrict__ aflags, int gvld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   msda_sorted_region<NT, MAXIT, PT, MODE>(lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P_rt, ovf, aflags,
-                                          cgg_xcd_remap(blockIdx.x, gridDim.x), smem);
+                                          cgg_xcd_remap(blockIdx.x, gridDim.x), smem, gvld);
 }
 
 // pass B: PERSISTENT workgroups walk a list of units (built on the device by cgg_msda_bwd_classify_kernel from pass A's counters)
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_list_kernel(MsdaLevels lv, Ms
                                                               float* __restrict__ gvalue, int Nv, int H, int L, int Nq, int P_rt,
                                                               uint32_t* __restrict__ ovf, uint32_t* __restrict__ aflags,
                                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                              uint32_t* __restrict__ cursor) {
+                                                              uint32_t* __restrict__ cursor, int gvld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ uint32_t cur;
   const uint32_t n = *count;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(NT) void cgg_msda_bwd_list_kernel(MsdaLevels lv, Ms
     __syncthreads();
     const uint32_t idx = cur;
     if (idx >= n) break;                                                  // (workgroup-uniform)
-    msda_sorted_region<NT, MAXIT, PT, MODE>(lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P_rt, ovf, aflags, (int)list[idx], smem);
+    msda_sorted_region<NT, MAXIT, PT, MODE>(lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P_rt, ovf, aflags, (int)list[idx], smem, gvld);
     __syncthreads();                                                      // the unit's LDS (and `cur`) are reused by the next one
   }
 }
@@ -408,7 +412,8 @@ static int msda_sort_plan(const MsdaLevels& lv, int B, int Nv, int H, int D, int
 
 template <int MODE>
 static int msda_sorted_go(const MsdaLevels& lv, const MsdaSortPlan& pl, size_t lds, const float* loc, const float* attw, const float* gout,
-                          float* gvalue, int B, int Nv, int H, int L, int Nq, int P, uint32_t* ovf, uint32_t* aflags, hipStream_t s) {
+                          float* gvalue, int B, int Nv, int H, int L, int Nq, int P, uint32_t* ovf, uint32_t* aflags, hipStream_t s,
+                          int gvld) {
   const long long nblk = (long long)B * H * pl.ntile * L;
   const int items = pl.maxslots * P;
   // 256 threads where two taps per thread cover the tile (c = 2: 336 taps), 512 for the c = 4 tile; 384-thread workgroups with one
@@ -422,18 +427,18 @@ static int msda_sorted_go(const MsdaLevels& lv, const MsdaSortPlan& pl, size_t l
     cgg_set_error("cgg_msda_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
     return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(nt), lds, s, lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(nt), lds, s, lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags, gvld);
   CGG_CHECK_LAUNCH("cgg_msda_backward(sorted scatter)");
   return CGG_OK;
 }
 
 int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B, int Nv,
-                           int H, int D, int L, int Nq, int P, hipStream_t s) {
+                           int H, int D, int L, int Nq, int P, hipStream_t s, int gvld) {
   MsdaSortPlan pl;
   size_t lds;
   const int rc = msda_sort_plan(lv, B, Nv, H, D, L, Nq, P, pl, lds);
   if (rc != CGG_OK) return rc;
-  return msda_sorted_go<0>(lv, pl, lds, loc, attw, gout, gvalue, B, Nv, H, L, Nq, P, nullptr, nullptr, s);
+  return msda_sorted_go<0>(lv, pl, lds, loc, attw, gout, gvalue, B, Nv, H, L, Nq, P, nullptr, nullptr, s, gvld);
 }
 
 // ---- two passes (see the header of this file): workspace = one counter per (image, pass-B tile, head, level) ----
@@ -469,7 +474,7 @@ long long msda_bwd_two_pass_workspace_bytes(const MsdaLevels& lv, int B, int Nv,
 template <int MODE>
 static int msda_list_go(const MsdaLevels& lv, const MsdaSortPlan& pl, size_t lds, int nwg, const float* loc, const float* attw,
                         const float* gout, float* gvalue, int Nv, int H, int L, int Nq, int P, uint32_t* ovf, uint32_t* aflags,
-                        const uint32_t* list, const uint32_t* count, uint32_t* cursor, hipStream_t s) {
+                        const uint32_t* list, const uint32_t* count, uint32_t* cursor, hipStream_t s, int gvld) {
   auto kern = cgg_msda_bwd_list_kernel<512, 3, 0, MODE>;                     // (pass-B tiles: c = 4, 1 344 taps at P = 4)
   if (pl.maxslots * P > 3 * 512) return CGG_EUNSUPPORTED;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -478,20 +483,20 @@ static int msda_list_go(const MsdaLevels& lv, const MsdaSortPlan& pl, size_t lds
     return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, s, lv, pl, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags, list, count,
-                     cursor);
+                     cursor, gvld);
   CGG_CHECK_LAUNCH("cgg_msda_backward(sorted scatter, second pass)");
   return CGG_OK;
 }
 
 int msda_bwd_sorted_launch_two_pass(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B,
-                                    int Nv, int H, int D, int L, int Nq, int P, void* ws, long long ws_bytes, hipStream_t s) {
+                                    int Nv, int H, int D, int L, int Nq, int P, void* ws, long long ws_bytes, hipStream_t s, int gvld) {
   MsdaSortPlan pa, pb;
   size_t la, lb;
   int rc = msda_two_pass_plans(lv, B, Nv, H, D, L, Nq, P, pa, la, pb, lb);
   const long long nr = rc == CGG_OK ? (long long)B * pb.ntile * H * L : 0;
   const long long na = rc == CGG_OK ? (long long)B * pa.ntile * H * L : 0;
   if (rc != CGG_OK || !ws || ws_bytes < msda_two_pass_ws_bytes(nr, na) || na >= (1ll << 31))
-    return msda_bwd_sorted_launch(lv, loc, attw, gout, gvalue, B, Nv, H, D, L, Nq, P, s);
+    return msda_bwd_sorted_launch(lv, loc, attw, gout, gvalue, B, Nv, H, D, L, Nq, P, s, gvld);
   uint32_t* ovf = (uint32_t*)ws;
   uint32_t* hdr = ovf + nr;
   uint32_t* aflags = hdr + 16;
@@ -502,15 +507,15 @@ int msda_bwd_sorted_launch_two_pass(const MsdaLevels& lv, const float* loc, cons
     cgg_set_error("cgg_msda_backward: zeroing the overflow counters failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  rc = msda_sorted_go<1>(lv, pa, la, loc, attw, gout, gvalue, B, Nv, H, L, Nq, P, ovf, aflags, s);
+  rc = msda_sorted_go<1>(lv, pa, la, loc, attw, gout, gvalue, B, Nv, H, L, Nq, P, ovf, aflags, s, gvld);
   if (rc != CGG_OK) return rc;
   hipLaunchKernelGGL(cgg_msda_bwd_classify_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, ovf, hdr, light_list, sort_list,
                      (int)nr);
   CGG_CHECK_LAUNCH("cgg_msda_backward(classify)");
   // light form: records of < MSDA_LIGHT_MAX corners + the slot tables = ~9 KB of LDS, 4 workgroups of 512 threads per CU
   const size_t ll = (size_t)MSDA_LIGHT_MAX * 8 + (size_t)pb.maxslots * 4 * 2;
-  rc = msda_list_go<3>(lv, pb, ll, 256 * 4, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags, light_list, hdr + 0, hdr + 2, s);
+  rc = msda_list_go<3>(lv, pb, ll, 256 * 4, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags, light_list, hdr + 0, hdr + 2, s, gvld);
   if (rc != CGG_OK) return rc;
   // sort form: ~137 KB of LDS, one workgroup per CU
-  return msda_list_go<2>(lv, pb, lb, 256, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags, sort_list, hdr + 1, hdr + 3, s);
+  return msda_list_go<2>(lv, pb, lb, 256, loc, attw, gout, gvalue, Nv, H, L, Nq, P, ovf, aflags, sort_list, hdr + 1, hdr + 3, s, gvld);
 }

@@ -56,6 +56,6 @@ __device__ __forceinline__ MsdaTap cgg_msda_tap(float x, float y, int Hl, int Wl
 bool msda_bwd_sorted_ok(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P);
 long long msda_bwd_two_pass_workspace_bytes(const MsdaLevels& lv, int B, int Nv, int H, int D, int L, int Nq, int P);
 int msda_bwd_sorted_launch_two_pass(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B,
-                                    int Nv, int H, int D, int L, int Nq, int P, void* ws, long long ws_bytes, hipStream_t s);
+                                    int Nv, int H, int D, int L, int Nq, int P, void* ws, long long ws_bytes, hipStream_t s, int gvld = 0);
 int msda_bwd_sorted_launch(const MsdaLevels& lv, const float* loc, const float* attw, const float* gout, float* gvalue, int B, int Nv,
-                           int H, int D, int L, int Nq, int P, hipStream_t s);
+                           int H, int D, int L, int Nq, int P, hipStream_t s, int gvld = 0);

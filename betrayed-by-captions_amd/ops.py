@@ -108,6 +108,15 @@ def msda_forward_fused(value, level_hw, level_start, offs_logits, ref_points, nu
     out = torch.empty((B, Nq, H * D), dtype=torch.float32, device=value.device)
     hw = _int_array([v for pair in level_hw for v in pair])
     st = _int_array(level_start)
+    vld = _value_row_stride(value)
+    if vld != H * D:                        # padded value rows (`padded_value_rows`): the strided-value form of the f32 kernel
+        with _timed('msda_fused'):
+            rc = _lib_().cgg_msda_forward_fused_vld(ctypes.c_void_p(value.data_ptr()), vld, hw, st,
+                                                    dev_ptr(offs_logits, 'offs_logits', torch.float32), ld,
+                                                    dev_ptr(ref_points, 'ref_points', torch.float32), dev_ptr(out), B, Nv, H, D, L, Nq, P,
+                                                    stream_ptr(value.device))
+        check(rc, 'cgg_msda_forward_fused_vld')
+        return out
     with _timed('msda_fused'):
         rc = _lib_().cgg_msda_forward_hostlevels(
             dev_ptr(value, 'value'), hw, st, dev_ptr(offs_logits, 'offs_logits', torch.float32), None,
@@ -115,6 +124,31 @@ def msda_forward_fused(value, level_hw, level_start, offs_logits, ref_points, nu
             1, stream_ptr(value.device))
     check(rc, 'cgg_msda_forward_hostlevels(fused)')
     return out
+
+
+MSDA_VALUE_PAD = 0 if os.environ.get('CGG_MSDA_VALUE_PAD', '1') == '0' else 32
+
+
+def padded_value_rows(B, Nv, H, D, device):
+    """(buffer (B, Nv, H D + pad) f32, value view (B, Nv, H, D) into it): MSDeformAttn value rows with a padded row stride. A stride
+    that is a multiple of 512 bytes (H D = 256 floats = 1 KiB) sends the four corner lines of a tap, and neighbouring pixels' lines,
+    to the same L2 channels; 288 floats per row instead of 256 made the forward gather 20 % faster at configs[1] / [2] shapes
+    (scratch/msda_vld_probe.py: 256 -> 115 us, 288 -> 92, 320 -> 98, 384 -> 110, 512 -> 112, 544 -> 93). CGG_MSDA_VALUE_PAD=0: packed."""
+    C = H * D
+    buf = torch.empty((B, Nv, C + MSDA_VALUE_PAD), dtype=torch.float32, device=device)
+    return buf, buf[..., :C].unflatten(-1, (H, D))
+
+
+def _value_row_stride(value):
+    """floats per pixel of a (B, Nv, H, D) value operand: H D when packed, more for a `padded_value_rows` view"""
+    B, Nv, H, D = value.shape
+    if value.is_contiguous():
+        return H * D
+    vld = value.stride(1)
+    if value.dtype != torch.float32 or value.stride(3) != 1 or value.stride(2) != D or value.stride(0) != Nv * vld or vld < H * D \
+            or vld % 4 or value.data_ptr() % 16:
+        raise CggError(f'value: (B, Nv, H, D) f32 rows, packed or with a padded row stride, expected (strides {value.stride()})')
+    return vld
 
 
 def msda_forward_fused_rows(rows_all, level_hw, level_start, ref_points, num_points, num_heads, head_dim):
@@ -167,7 +201,14 @@ def msda_backward_hostlevels(value, level_hw, level_start, sampling_locations, a
     # split backward on a tileable pyramid: grad_loc / grad_attn are written by the gather kernel (no zero-fill, no read of old values)
     ow = bool(_lib_().cgg_msda_backward_overwrites(hw, st, B, Nv, H, D, L, Nq, P)) and \
         sampling_locations.data_ptr() % 16 == 0 and attention_weights.data_ptr() % 16 == 0
-    gv = torch.zeros_like(value)
+    vld = _value_row_stride(value)
+    if vld != H * D:                        # padded value rows: grad_value comes back in the same padded layout
+        if not ow:
+            raise CggError('msda_backward_hostlevels: padded value rows need the split backward (tileable pyramid, D = 32, P = 4)')
+        gbuf = torch.zeros((B, Nv, vld), dtype=torch.float32, device=value.device)
+        gv = gbuf[..., :H * D].unflatten(-1, (H, D))
+    else:
+        gv = torch.zeros_like(value)
     gl = torch.empty_like(sampling_locations) if ow else torch.zeros_like(sampling_locations)
     gw = torch.empty_like(attention_weights) if ow else torch.zeros_like(attention_weights)
     nbytes = 4.0 * (2 * value.numel() + 2 * sampling_locations.numel() + 2 * attention_weights.numel() + grad_output.numel())
@@ -180,9 +221,10 @@ def msda_backward_hostlevels(value, level_hw, level_start, sampling_locations, a
     ws = _workspace(wsb, value.device) if wsb > 0 else None
     with _timed('msda_backward', bytes=nbytes, flops=0.0, shape=(B, Nq, H, D, L, P)):
         rc = _lib_().cgg_msda_backward_hostlevels_ws(
-            dev_ptr(value, 'value', torch.float32), hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
+            ctypes.c_void_p(value.data_ptr()), vld, hw, st, dev_ptr(sampling_locations, 'sampling_locations', torch.float32),
             dev_ptr(attention_weights, 'attention_weights', torch.float32), dev_ptr(grad_output, 'grad_output', torch.float32),
-            dev_ptr(gv), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow), dev_ptr(ws) if ws is not None else None, wsb,
+            ctypes.c_void_p(gv.data_ptr()), dev_ptr(gl), dev_ptr(gw), B, Nv, H, D, L, Nq, P, int(ow),
+            dev_ptr(ws) if ws is not None else None, wsb,
             stream_ptr(value.device), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
     check(rc, 'cgg_msda_backward_hostlevels_ws')
     return gv, gl, gw

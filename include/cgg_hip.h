@@ -159,7 +159,9 @@ int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, co
  * without any returns at once). Offsets of several pixels (trained models) then cost a second sort instead of one 128-byte atomic
  * per corner (round 5: 8.5 ms per call at +-8 px against 2.0 ms at the initialisation's +-0.5 px). ws null or workspace_bytes == 0:
  * identical to cgg_msda_backward_hostlevels_2s. Same results as the single pass up to float summation order. */
-int cgg_msda_backward_hostlevels_ws(const float* value, const int32_t* level_hw, const int32_t* level_start,
+/* vld: floats per pixel of the `value` AND `grad_value` rows (0 or H*D = packed (B, Nv, H, D)); a padded stride (e.g. 288 for H*D = 256)
+ * keeps neighbouring pixels' lines / atomics off the same L2 channels. */
+int cgg_msda_backward_hostlevels_ws(const float* value, int vld, const int32_t* level_hw, const int32_t* level_start,
                                     const float* sampling_loc, const float* attn_weight, const float* grad_out,
                                     float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
                                     int Nq, int P, int overwrite_loc_attn, void* ws, long long ws_bytes, cgg_stream_t stream,

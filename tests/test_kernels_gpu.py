@@ -247,6 +247,36 @@ def test_msda_backward_sorted_scatter_vs_float64(dev, B, shapes, spread, amp):
     assert (gv3 - gv).abs().max().item() <= 1e-5 * sc
 
 
+def test_msda_padded_value_rows_equal_packed_rows(dev):
+    """`ops.padded_value_rows`: value (and grad_value) rows with a 288-float stride instead of 256 -- the strided-value forms of the
+    fused forward (`cgg_msda_forward_fused_vld`) and of the split backward (`cgg_msda_backward_hostlevels_ws`, vld) give the packed
+    layout's results (forward bit-identical, grad_value up to the atomics' summation order); the pad columns stay untouched."""
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    starts, Nv = _levels(shapes)
+    B, H, D, L, P = 2, 8, 32, 3, 4
+    g = torch.Generator().manual_seed(91)
+    value = torch.randn(B, Nv, H, D, generator=g).to(dev)
+    rows = torch.randn(B, Nv, 3 * H * L * P, generator=g).to(dev)
+    refs = []
+    for (h, w) in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref_pts = torch.cat(refs, 0).to(dev)
+    buf, v4 = ops.padded_value_rows(B, Nv, H, D, dev)
+    assert ops.MSDA_VALUE_PAD == 32 and v4.stride(1) == 288
+    buf.fill_(7.0)
+    v4.copy_(value)
+    want = ops.msda_forward_fused(value, shapes, starts, rows, ref_pts, P)
+    got = ops.msda_forward_fused(v4, shapes, starts, rows, ref_pts, P)
+    assert torch.equal(got, want)
+    go = torch.randn(B, Nv, H * D, generator=g).to(dev) * 1e-3
+    gv0, gr0 = ops.msda_rows_backward(value, rows, ref_pts, shapes, starts, P, go)
+    gv1, gr1 = ops.msda_rows_backward(v4, rows, ref_pts, shapes, starts, P, go)
+    assert gv1.stride(1) == 288 and torch.equal(gr0, gr1)
+    assert (gv1 - gv0).abs().max().item() <= 1e-5 * gv0.abs().max().item()
+    assert bool((buf[..., 256:] == 7.0).all())                                # the pad columns of the value rows were only ever read past
+
+
 def test_msda_mmcv_function_reads_the_level_table_once_per_tensor(dev):
     """`ops.MultiScaleDeformableAttnFunction` (mmcv's positional signature): the DEVICE level table is read by
     `cgg_msda_read_levels` once per `spatial_shapes` tensor -- the result rides on the tensor with both version counters -- and the
