@@ -154,9 +154,10 @@ int cgg_msda_backward_hostlevels(const float* value, const int32_t* level_hw, co
                                  float* grad_value, float* grad_loc, float* grad_attn, int B, int Nv, int H, int D, int L,
                                  int Nq, int P, int overwrite_loc_attn, cgg_stream_t stream);
 /* ... with a workspace (device, 16-B aligned, >= cgg_msda_backward_workspace_bytes(...) bytes; its contents need not be initialised)
- * for the TWO-PASS sorted scatter of grad_value: the first pass sums the corners inside a 4-pixel halo of 2 x 2-coarse-pixel tiles and
- * counts the others per region; the second pass re-sorts exactly those on 4 x 4-coarse-pixel tiles with a 12-pixel halo (a region
- * without any returns at once). Offsets of several pixels (trained models) then cost a second sort instead of one 128-byte atomic
+ * for the TWO-PASS sorted scatter of grad_value: the first pass sums the corners inside a 4-pixel halo of 2 x 2-coarse-pixel tiles; a
+ * tile with FEW corners outside it scatters them itself, a tile with many (>= 256 of its 1 344) flags itself and counts them per
+ * region; a device-side classify step lists the regions that have something left, and persistent second-pass workgroups re-sort
+ * exactly those corners on 4 x 4-coarse-pixel tiles with a 12-pixel halo (regions with < 768 corners left: straight to atomics). Offsets of several pixels (trained models) then cost a second sort instead of one 128-byte atomic
  * per corner (round 5: 8.5 ms per call at +-8 px against 2.0 ms at the initialisation's +-0.5 px). ws null or workspace_bytes == 0:
  * identical to cgg_msda_backward_hostlevels_2s. Same results as the single pass up to float summation order. */
 /* vld: floats per pixel of the `value` AND `grad_value` rows (0 or H*D = packed (B, Nv, H, D)); a padded stride (e.g. 288 for H*D = 256)
