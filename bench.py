@@ -15,14 +15,17 @@ GPU; rank r binds device r, RCCL for the barrier / max-over-ranks); under an ext
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) RANK / LOCAL_RANK / WORLD_SIZE come from
 the environment and `--gpus` must agree with WORLD_SIZE (it fails loudly otherwise).
 
-Prints ONE JSON line (rank 0). `value` is PARITY mode (`--precision fp32`, the default): every contraction of the path in
-f32-class arithmetic on the f16 matrix cores (csrc/x3.h), the mode the 1e-3 / bit-exact parity tests run in. Extra objects:
+Prints ONE JSON line (rank 0) as the LAST line of stdout: the compact record (`compact_record` / `emit`: < 4 KB of strict JSON -- the
+contract keys, `roofline`, `cpu_baseline` and one short object per secondary measurement); the full record with every note goes to
+gpurun_out/bench_full.json (`--full-line` prints it instead: what a parent bench.py run parses from its children). `value` is PARITY
+mode (`--precision fp32`, the default): every contraction of the path in f32-class arithmetic on the f16 matrix cores (csrc/x3.h), the
+mode the 1e-3 / bit-exact parity tests run in. Objects of the full record:
   roofline      -- the dominant kernel family of that step, the x3 GEMM / implicit-GEMM convolution family (cgg_gemm_x3s_kernel: LDS-DMA
                    GEMM over pre-split x3a rows), from HIP events on the launch stream around every launch of the K steps re-run eagerly
                    after the timed region; kernels.* hold the encoder layer tail, the mask-logit einsum and MSDeformAttn the same way;
                    `traffic` / `rocprof` fields come from the committed rocprofv3 runs of this command (labelled as such).
-  einsum_mfma_target -- BASELINE.json's kernel target: the mask-logit einsum at Q = 100 and Q = 200 (stored-logits and consumer-fused
-                   forms, incl. the query-stationary kernel), 20 launches in one hipGraph, % of MFMA peak.
+  einsum_mfma_target -- BASELINE.json's kernel target: the mask-logit einsum at (B, Q) = (2, 100), (2, 200), (4, 200), (16, 100) (stored-
+                   logits and consumer-fused forms, incl. the query-stationary / LDS-ring kernel), 20 launches in one hipGraph, % of MFMA peak.
   bf16_mode     -- the same step in throughput mode (bf16 MFMA): secondary, never `value`; with the bf16 agreement record of this config.
   train_step    -- configs[2]'s training step, run in child processes: the parity-mode (f32-class) step is the object itself, the
                    bf16 autocast step its `bf16_mode` member; each with `roofline` / `kernels` from live events.
