@@ -69,6 +69,22 @@ class StagePipeline:
         cur = torch.cuda.current_stream(dev)
         for s in range(self.slots):
             self.inputs[s].copy_(example)
+        # every tensor the model's caches hand out while the stages warm up and are captured (positional encodings, projection
+        # tables, folded biases of THIS image shape) is kept for the pipeline's lifetime: the graphs replay raw addresses, and the
+        # caches are bounded / replace their entry when another shape arrives
+        from . import runtime as _rt
+        self._scope = _rt.keepalive_scope()
+        self._keepalive = self._scope.__enter__()
+        try:
+            self._capture(cur, dev, warmup)
+        finally:
+            self._scope.__exit__(None, None, None)
+        self.results = self.outs[-1]
+        self._tail_pending = None
+        if tail is not None:
+            self._init_tail(tail, dev)
+
+    def _capture(self, cur, dev, warmup):
         with torch.no_grad():
             # eager warm-up on the stage streams: solver searches, weight packing, allocator pools settle before capture
             for _ in range(max(warmup, 1)):
@@ -90,18 +106,17 @@ class StagePipeline:
                     self.graphs[i][s] = g
                     self.outs[i][s] = x
                     torch.cuda.synchronize(dev)
-        self.results = self.outs[-1]
-        self._tail_pending = None
-        if tail is not None:
-            self.tail_stream = torch.cuda.Stream(dev)
-            self.tail_done = [torch.cuda.Event() for _ in range(self.slots)]
-            self.results = [None] * self.slots
-            self._tail_ran = [False] * self.slots
-            with torch.no_grad():                                 # warm-up (allocator, first-call setup) on the tail stream
-                self.tail_stream.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(self.tail_stream):
-                    tail(self.outs[-1][0])
-                torch.cuda.synchronize(dev)
+
+    def _init_tail(self, tail, dev):
+        self.tail_stream = torch.cuda.Stream(dev)
+        self.tail_done = [torch.cuda.Event() for _ in range(self.slots)]
+        self.results = [None] * self.slots
+        self._tail_ran = [False] * self.slots
+        with torch.no_grad():                                 # warm-up (allocator, first-call setup) on the tail stream
+            self.tail_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.tail_stream):
+                tail(self.outs[-1][0])
+            torch.cuda.synchronize(dev)
 
     def _run_tail(self, slot):
         st = self.tail_stream

@@ -572,7 +572,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 pts.append(torch.stack([(xs.flatten() + 0.5) / w, (ys.flatten() + 0.5) / h], -1))
             ref = torch.cat(pts, 0).contiguous()
             self._ref_cache[key] = ref
-        return ref
+        return runtime.keepalive(ref)
 
     @staticmethod
     def _stream_ok(layer):
@@ -698,7 +698,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                              for i, (h, w) in enumerate(level_hw)], 0).detach().contiguous()
             hit = (key, pos)
             self.__dict__['_pos_cache'] = hit
-        return hit[1]
+        return runtime.keepalive(hit[1])
 
     def stream_ready(self, feats):
         """True when `forward_stream` applies: throughput mode, no autograd, channel-last bf16 features (what the
@@ -907,12 +907,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 b_all = runtime.derived_cached('msda_ball32', (vp.bias, so.bias, aw.bias),
                                                lambda: torch.cat([vp.bias, so.bias, aw.bias], 0).float().contiguous())
 
-                def table():
-                    w_cat = torch.cat([so.weight, aw.weight], 0).float().contiguous()
-                    t = torch.zeros((N, C + n_cat), dtype=torch.float32, device=pos.device)
-                    t[:, C:] = runtime.linear_x3(pos.float().contiguous(), w_cat)
-                    return t
-                tab = runtime.derived_cached('msda_pos_table', (pos, so.weight, aw.weight), table)
+                tab = self._proj_pos_table(layer, pos, so, aw, tuple(level_hw), N, C, n_cat)
                 rows_all = runtime.linear_x3s(src.view(B * N, C), w_all, b_all, res=tab, res_mod=N).view(B, N, C + n_cat)
                 a = ops.msda_forward_fused_rows(rows_all, level_hw, level_start, ref, attn.num_points, H, C // H)
                 src, srcp = ops.encoder_layer_tail_x3(a, src, x3w(attn.output_proj), attn.output_proj.bias,
@@ -932,6 +927,28 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                                   (n0.weight, n0.bias, n0.eps), x3w(fc1), fc1.bias, x3w(fc2), fc2.bias,
                                                   (n1.weight, n1.bias, n1.eps), pos=pos, want_pos=not last, x3a=True)
         return src
+
+    def _proj_pos_table(self, layer, pos, so, aw, level_hw, N, C, n_cat):
+        """T = [0 | pos [Woff; Watt]^T] (N, C + n_cat) f32 of a layer's merged projection, cached per (layer, pyramid) in a SMALL
+        LRU on this module (46.8 MB per layer at 1024^2: a cache keyed on the `pos` tensor object would keep one table per image
+        shape ever seen -- `_pos_cached` rebuilds `pos` whenever the shape changes) and rebuilt when the weights or the level
+        encoding change."""
+        import collections
+        cache = self.__dict__.setdefault('_proj_tables', collections.OrderedDict())
+        key = (id(layer), level_hw, str(pos.device))
+        ver = (so.weight._version, aw.weight._version, so.weight.data_ptr(), aw.weight.data_ptr(), self.level_encoding.weight._version)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            cache.move_to_end(key)
+            return runtime.keepalive(hit[1])
+        with torch.no_grad():
+            w_cat = torch.cat([so.weight, aw.weight], 0).float().contiguous()
+            t = torch.zeros((N, C + n_cat), dtype=torch.float32, device=pos.device)
+            t[:, C:] = runtime.linear_x3(pos.float().contiguous(), w_cat)
+        cache[key] = (ver, t)
+        while len(cache) > 2 * len(self.encoder.layers):        # two pyramids' worth of tables (a captured pipeline of an older
+            cache.popitem(last=False)                           # pyramid keeps ITS tables alive itself: runtime.keepalive_scope)
+        return runtime.keepalive(t)
 
     @staticmethod
     def _merged_proj_ok(layer):

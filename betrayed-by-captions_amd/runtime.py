@@ -877,17 +877,44 @@ def packed_cached(weights, biases=None):
 _DCACHE = {}
 
 
+_KEEPALIVE = []        # stack of lists: the tensors the caches hand out while a graph pipeline warms up / is captured
+
+
+class keepalive_scope:
+    """`with keepalive_scope() as refs:` -- every tensor that `derived_cached`, the positional-encoding / reference-point / projection-
+    table caches return inside the scope is appended to `refs`. A hipGraph replays raw device addresses: whoever captures graphs
+    (pipeline.StagePipeline) keeps `refs` for its lifetime, so that a bounded cache may drop an entry (another image shape arrives)
+    without freeing memory a captured graph of an earlier shape still reads."""
+
+    def __enter__(self):
+        self.refs = {}                      # id -> object (a cache hit is registered once, however often it is returned)
+        _KEEPALIVE.append(self.refs)
+        return self.refs
+
+    def __exit__(self, *exc):
+        _KEEPALIVE[:] = [r for r in _KEEPALIVE if r is not self.refs]
+        return False
+
+
+def keepalive(val):
+    """register a cache's return value with every active `keepalive_scope` (cheap no-op outside one); returns val"""
+    if _KEEPALIVE:
+        for refs in _KEEPALIVE:
+            refs[id(val)] = val
+    return val
+
+
 def derived_cached(tag, tensors, fn):
     """Cache `fn()` (any tensor derived from parameters, e.g. a folded bias) until one of `tensors` changes."""
     bases = [t._base if t._base is not None else t for t in tensors]
     key = (tag,) + tuple(_wkey(t, None) for t in tensors)
     hit = _DCACHE.get(key)
     if hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and hit[1] == tuple(b._version for b in bases):
-        return hit[2]
+        return keepalive(hit[2])
     if len(_DCACHE) > 4096:
         for k in [k for k, v in _DCACHE.items() if any(r() is None for r in v[0])]:
             del _DCACHE[k]
     with torch.no_grad():
         val = fn()
     _DCACHE[key] = ([weakref.ref(b) for b in bases], tuple(b._version for b in bases), val)
-    return val
+    return keepalive(val)

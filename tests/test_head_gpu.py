@@ -453,6 +453,69 @@ def test_test_driver_mixed_shapes_keep_order(dev, tmp_path):
             assert int(ra[k][2].sum()) == int(rb[k][2].sum()), (i, k)
 
 
+def four_shape_stream(cfg, rank, world):
+    """`--data` hook: batches of four different pyramids, then every one of them AGAIN -- the captured pipelines of the first visits are
+    replayed after the model's shape-keyed caches (one positional encoding, two pyramids of projection tables) have long moved on."""
+    g = torch.Generator().manual_seed(6)
+    shapes = [(128, 128)] * 2 + [(128, 160)] * 2 + [(160, 128)] * 2 + [(160, 160)] * 2
+    shapes = shapes + shapes
+    for i, (h, w) in enumerate(shapes):
+        if i % world != rank:
+            continue
+        if i == len(shapes) // 2 and torch.cuda.is_available():
+            # before the second visits: every block the caches have dropped since is overwritten with NaN (allocator churn over the
+            # size classes of the encodings / tables / biases) -- a graph that still read such a block would poison its results
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            ns = sorted({sum((h2 // s_) * (w2 // s_) for s_ in (8, 16, 32)) for h2, w2 in shapes})
+            sizes = [n * c for n in ns for c in (544, 512, 288, 256, 2)] + [3 << 10, 24 << 10, 400 << 10]
+            junk = [torch.full((n,), float('nan'), device='cuda') for _ in range(24) for n in sizes]
+            torch.cuda.synchronize()
+            del junk
+        meta = synthetic.img_metas(1, h, w)[0]
+        yield torch.randn(3, h, w, generator=g), dict(meta, filename=f'four_{i}.jpg')
+
+
+def test_test_driver_replays_old_pipelines_after_the_caches_moved_on(dev, tmp_path):
+    """A hipGraph replays raw device addresses. The model's shape-keyed caches are bounded (`_pos_cached` holds ONE pyramid's
+    encoding, `_proj_pos_table` two pyramids' tables), so a pipeline captured for an earlier shape must keep the tensors its graphs
+    read alive itself (`runtime.keepalive_scope` around StagePipeline's warm-up + capture; round 6 -- before, a revisited shape
+    replayed freed memory and was only right while the allocator had not reused the blocks). Four pyramids, each visited twice, with
+    allocator churn in between: pipelined results == the sequential loop's."""
+    import importlib.util
+    import sys
+    from util import randomize
+    from cgg_amd.checkpoint import save_checkpoint
+    cfg = synthetic.model_config(num_things=10, num_stuff=0, num_unknown=3, num_queries=20, depth=50, enc_layers=2,
+                                 dec_layers=3, vocab=500, num_points=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = registry.build_detector(cfg)
+    randomize(model, seed=23)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.fill_(1.0)
+            m.running_mean.zero_()
+    ck = save_checkpoint(model, str(tmp_path / 'w.pth'))
+    cfg_file = tmp_path / 'tiny.py'
+    cfg_file.write_text('model = ' + repr(cfg) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    spec = importlib.util.spec_from_file_location('cgg_tools_test3', os.path.join(root, 'tools', 'test.py'))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    b = drv.main([str(cfg_file), ck, '--data', 'test_head_gpu:four_shape_stream', '--no-pipeline'])
+    torch.cuda.empty_cache()                                   # freed blocks really go back: stale addresses would not survive
+    a = drv.main([str(cfg_file), ck, '--data', 'test_head_gpu:four_shape_stream'])
+    assert len(a) == 16 and len(b) == 16
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        for k in ra:
+            assert ra[k][2].shape == rb[k][2].shape, (i, k)
+            assert sorted(ra[k][0].tolist()) == sorted(rb[k][0].tolist()), (i, k)
+            assert int(ra[k][2].sum()) == int(rb[k][2].sum()), (i, k)
+
+
 def test_test_driver_rle_results_equal_bool_masks(dev, tmp_path):
     """tools/test.py --rle (pinned staging + asynchronous copies + C++ COCO-RLE encoder, overlapped with the pipeline):
     every detection's decoded RLE equals the bool mask the plain driver returns, per class, in dataset order."""

@@ -560,3 +560,30 @@ def test_channel_last_hand_over_is_dropped_after_in_place_writes():
     assert runtime.handed_nhwc(t) is None
     t = runtime.hand_nhwc(f.permute(0, 3, 1, 2).contiguous(), f)
     assert runtime.handed_nhwc(t.requires_grad_(True)) is None
+
+
+def test_keepalive_scope_holds_what_the_caches_hand_out():
+    """runtime.keepalive_scope (what pipeline.StagePipeline wraps its warm-up + capture in): every value `derived_cached` returns
+    inside the scope -- a fresh entry or a hit -- is referenced by the scope's dict, once; outside a scope nothing is recorded; the
+    value stays alive through the scope's references after its cache entry is gone."""
+    import gc
+    import weakref
+    from cgg_amd import runtime
+    w = torch.nn.Parameter(torch.randn(4, 4))
+    outside = runtime.derived_cached('t_keepalive', (w,), lambda: w.detach() * 2)
+    with runtime.keepalive_scope() as refs:
+        a = runtime.derived_cached('t_keepalive', (w,), lambda: w.detach() * 2)       # a hit
+        b = runtime.derived_cached('t_keepalive2', (w,), lambda: w.detach() * 3)      # a new entry
+        a2 = runtime.derived_cached('t_keepalive', (w,), lambda: w.detach() * 2)
+        assert a is outside and a2 is a and len(refs) == 2 and set(map(id, refs.values())) == {id(a), id(b)}
+    c = runtime.derived_cached('t_keepalive3', (w,), lambda: w.detach() * 4)          # after the scope: not recorded
+    assert len(refs) == 2 and not runtime._KEEPALIVE
+    wr = weakref.ref(b)
+    for k in [k for k in runtime._DCACHE if k[0] == 't_keepalive2']:
+        del runtime._DCACHE[k]
+    del b
+    gc.collect()
+    assert wr() is not None                                                           # the scope's dict still holds it
+    refs.clear()
+    gc.collect()
+    assert wr() is None and c is not None
