@@ -911,7 +911,11 @@ def derived_cached(tag, tensors, fn):
     hit = _DCACHE.get(key)
     if hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and hit[1] == tuple(b._version for b in bases):
         return keepalive(hit[2])
-    if len(_DCACHE) > 4096:
+    if len(_DCACHE) > 256:
+        # entries whose source tensors are gone (e.g. the positional encoding of an image shape that is no longer the current one:
+        # a (S, 512) bias table per decoder level = ~100 MB per shape at 1024^2) are dropped as soon as the cache has some size --
+        # an evaluation set has hundreds of distinct padded shapes. A captured pipeline of such a shape holds what its graphs read
+        # through `keepalive_scope`.
         for k in [k for k, v in _DCACHE.items() if any(r() is None for r in v[0])]:
             del _DCACHE[k]
     with torch.no_grad():
