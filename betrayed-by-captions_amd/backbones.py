@@ -420,6 +420,7 @@ class ResNet(nn.Module):
         outs = []
         frozen_nhwc = []
         first = 0
+        xn = None
         if (FROZEN_FOLDED and runtime.x3_enabled() and torch.is_grad_enabled() and frozen_bn and x.is_cuda and self.frozen_stages >= 1
                 and not x.requires_grad and self._x3_ok() and x.dtype == torch.float32
                 and not any(p.requires_grad for n in self.res_layers[:self.frozen_stages] for p in getattr(self, n).parameters())
@@ -431,6 +432,7 @@ class ResNet(nn.Module):
             outs = [o.permute(0, 3, 1, 2) for o in fouts]
             frozen_nhwc = list(fouts)
             x = xf.permute(0, 3, 1, 2)
+            xn = xf                                          # the same map channel-last: what the x3 training stages read
             first = self.frozen_stages
         if (FROZEN_FOLDED and runtime.is_bf16() and frozen_bn and x.is_cuda and self.frozen_stages >= 1 and not x.requires_grad
                 and not any(p.requires_grad for n in self.res_layers[:self.frozen_stages] for p in getattr(self, n).parameters())
@@ -457,8 +459,20 @@ class ResNet(nn.Module):
             for i, name in enumerate(self.res_layers):
                 if i < first:
                     continue
-                x = getattr(self, name)(x)
+                stage = getattr(self, name)
+                if xn is not None and runtime.x3_resnet_stage_ok(stage, xn):
+                    # parity-mode training: the trainable stage stays channel-last on the x3 kernels (one autograd node per
+                    # convolution + frozen BatchNorm + ReLU / residual: `runtime._X3ConvBnFn`); x = None until somebody needs NCHW
+                    xn = runtime.resnet_stage_x3_train(stage, xn)
+                    x = None
+                else:
+                    if x is None:
+                        x = runtime.nhwc_to_nchw_train(xn)
+                    x = stage(x)
+                    xn = None
                 if i in self.out_indices:
+                    if x is None:
+                        x = runtime.nhwc_to_nchw_train(xn)
                     outs.append(x)
         res = []
         for k, o in enumerate(outs):

@@ -520,6 +520,164 @@ class _X3Conv3x3Fn(torch.autograd.Function):
         return gx, gw
 
 
+_X3_RESNET_TRAIN = _os.environ.get('CGG_X3_RESNET_TRAIN', '1') != '0'      # parity-mode training: trainable ResNet stages channel-last on own kernels (A/B)
+
+
+class _X3ConvBnFn(torch.autograd.Function):
+    """y = act(conv(x, W) * s + t (+ res)) on CHANNEL-LAST f32 maps: one convolution of a trainable ResNet stage with its FROZEN
+    BatchNorm (norm_eval=True, requires_grad=False: a per-channel affine s = gamma / sqrt(var + eps), t = beta - mean s), the
+    Bottleneck's ReLU and its residual add as ONE autograd node in PARITY-mode training ([3P] mmdet ResNet layer4 under
+    frozen_stages=3, configs/_base_ backbones; reference call site open_set/models/mask2former_head.py:787's inputs). 1 x 1 (stride 1 / 2)
+    and 3 x 3 / stride 1 / pad 1 filters. Replaces MIOpen's f32 implicit GEMMs (~120 TF/s at these shapes) + batch_norm + relu +
+    add launches and their backward kernels: forward = the x3 implicit GEMM with s folded into the packed filter and (t, res, ReLU) in
+    its epilogue; backward = one ReLU-mask pass, one max |g| pass (per-tensor pre-scale, see `_X3LinearFn`), grad-input as the x3
+    GEMM / convolution with the transposed (flipped) filter, grad-weight as `ops.wgrad_x3` (nine taps over zero-padded maps for
+    3 x 3, see `_X3Conv3x3Fn`), scaled by s."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, res, stride, relu):
+        from . import ops
+        N, C, k, _ = weight.shape
+        B, H, W, _ = x.shape
+        x = x.detach()
+        wk = derived_cached('x3_convbn_image', (weight, scale),
+                            lambda: ops.pack_conv_weight_x3(weight.detach() * scale.view(-1, 1, 1, 1)))
+        r = res.detach().contiguous() if res is not None else None
+        if k == 1 and stride == 1:
+            y = ops.gemm_x3(x.view(-1, C), wk, N, shift, res=r.view(-1, N) if r is not None else None, relu=relu).view(B, H, W, N)
+        else:
+            y = ops.conv_x3_nhwc(x, wk, N, k, stride, k // 2, bias=shift, res=r, relu=relu)
+        ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.cfg = (int(stride), bool(relu), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        import torch.nn.functional as F
+        x, weight, scale, y = ctx.saved_tensors
+        stride, relu, has_res = ctx.cfg
+        N, C, k, _ = weight.shape
+        B, H, W, _ = x.shape
+        g = gy.contiguous()
+        if relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0.0)
+        OH, OW = g.shape[1], g.shape[2]
+        g2 = g.view(-1, N)
+        amax = ops.absmax(g2) if _X3_GSCALE else None
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if k == 1:
+                wt = derived_cached('x3_convbn_image_t', (weight, scale), lambda: ops.pack_linear_weight_x3(
+                    (weight.detach().flatten(1) * scale.view(-1, 1)).t().contiguous()))
+                gs = ops.gemm_x3(g2, wt, C, amax=amax).view(B, OH, OW, C)
+                if stride == 1:
+                    gx = gs
+                else:       # the pixels a stride-s 1 x 1 filter never read get no gradient
+                    gx = torch.zeros_like(x)
+                    gx[:, ::stride, ::stride] = gs
+            else:
+                wt = derived_cached('x3_convbn_image_t', (weight, scale), lambda: ops.pack_conv_weight_x3(
+                    (weight.detach() * scale.view(-1, 1, 1, 1)).flip(2, 3).transpose(0, 1).contiguous()))
+                gx = ops.conv_x3_nhwc(g, wt, C, k, 1, k // 2, amax=amax)
+        if ctx.needs_input_grad[1]:
+            if k == 1:
+                xs = x if stride == 1 else x[:, ::stride, ::stride].contiguous()
+                gw = ops.wgrad_x3(g2, xs.view(-1, C), amax=amax).view(N, C, 1, 1)
+            else:
+                # both maps zero-padded by one pixel: a filter tap is a constant row offset between two row-major matrices
+                xr = F.pad(x, (0, 0, 1, 1, 1, 1)).view(-1, C)
+                gr = F.pad(g, (0, 0, 1, 1, 1, 1)).view(-1, N)
+                Mp = xr.shape[0]
+                lo, hi = W + 3, Mp - (W + 3)
+                gw = torch.empty((N, k, k, C), dtype=torch.float32, device=x.device)
+                for ky in range(3):
+                    for kx in range(3):
+                        off = (ky - 1) * (W + 2) + (kx - 1)
+                        gw[:, ky, kx, :] = ops.wgrad_x3(gr[lo:hi], xr[lo + off:hi + off], amax=amax)
+                gw = gw.permute(0, 3, 1, 2)
+            gw = gw * scale.view(-1, 1, 1, 1)
+        return gx, gw, None, None, (g if has_res else None), None, None
+
+
+def _bn_affine(bn):
+    """(s, t) of a frozen BatchNorm2d: y = x s + t"""
+    def make():
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        return s.contiguous(), (bn.bias.detach().float() - bn.running_mean.detach().float() * s).contiguous()
+    return derived_cached('bn_affine', (bn.weight, bn.bias, bn.running_mean, bn.running_var), make)
+
+
+def _x3_convbn_ok(conv, bn):
+    k, s = tuple(conv.kernel_size), tuple(conv.stride)
+    return (isinstance(conv, torch.nn.Conv2d) and isinstance(bn, torch.nn.BatchNorm2d) and not bn.training and bn.affine
+            and bn.track_running_stats and not bn.weight.requires_grad and not bn.bias.requires_grad and conv.bias is None
+            and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and getattr(conv, 'padding_mode', 'zeros') == 'zeros'
+            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.weight.requires_grad
+            and ((k == (1, 1) and s in ((1, 1), (2, 2)) and tuple(conv.padding) == (0, 0))
+                 or (k == (3, 3) and s == (1, 1) and tuple(conv.padding) == (1, 1))))
+
+
+def x3_resnet_stage_ok(stage, x):
+    """PARITY-mode training of a ResNet stage of Bottlenecks with frozen BatchNorm on channel-last maps and own kernels
+    (`_X3ConvBnFn`; a 3 x 3 / stride-2 convolution -- the first block's -- stays a library call on the channel-last view). x: the
+    stage's channel-last f32 input (B, H, W, C)."""
+    from .backbones import Bottleneck
+    if not (_X3_RESNET_TRAIN and _X3_TRAIN and _X3_WGRAD and x3_enabled() and torch.is_grad_enabled() and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    B, H, W, C = x.shape
+    for j, blk in enumerate(stage):
+        if not isinstance(blk, Bottleneck) or not isinstance(blk.relu, torch.nn.ReLU):
+            return False
+        pairs = [(blk.conv1, blk.bn1), (blk.conv3, blk.bn3)]
+        if blk.downsample is not None:
+            if len(blk.downsample) != 2:
+                return False
+            pairs.append((blk.downsample[0], blk.downsample[1]))
+        s2 = tuple(blk.conv2.stride)
+        if s2 == (1, 1):
+            pairs.append((blk.conv2, blk.bn2))
+        elif not (isinstance(blk.bn2, torch.nn.BatchNorm2d) and not blk.bn2.training):
+            return False
+        if not all(_x3_convbn_ok(c, b) for c, b in pairs) or tuple(blk.conv1.stride) != (1, 1) or tuple(blk.conv3.stride) != (1, 1):
+            return False
+        if blk.downsample is not None and tuple(blk.downsample[0].stride) != s2:
+            return False
+        if blk.downsample is None and (s2 != (1, 1) or blk.conv1.in_channels != blk.conv3.out_channels):
+            return False
+        H, W = (H - 1) // s2[0] + 1, (W - 1) // s2[1] + 1
+    # the smallest map of the stage still has to fill the GEMM grid, the largest operand has to fit a 32-bit buffer descriptor
+    return (B * H * W >= X3_TRAIN_ROWS
+            and x.numel() * 4 < _X3_MAX_BYTES and B * (H + 2) * (W + 2) * stage[-1].conv3.out_channels * 4 < _X3_MAX_BYTES)
+
+
+def resnet_stage_x3_train(stage, x, tap=None):
+    """channel-last (B, H, W, C) f32 -> the stage's channel-last output, under autograd (see `x3_resnet_stage_ok`). tap: called with
+    every post-ReLU map in execution order (tests pin the ReLU decisions of a float64 reference to them: an activation that is zero
+    to rounding is a tie, and a flipped tie moves a gradient by one row's contribution -- ~1e-3 of a weight gradient)."""
+    tap = tap or (lambda y: None)
+
+    def cb(x, conv, bn, relu, res=None):
+        s, t = _bn_affine(bn)
+        y = _X3ConvBnFn.apply(x, conv.weight, s, t, res, int(conv.stride[0]), relu)
+        if relu:
+            tap(y)
+        return y
+
+    for blk in stage:
+        identity = x if blk.downsample is None else cb(x, blk.downsample[0], blk.downsample[1], False)
+        y = cb(x, blk.conv1, blk.bn1, True)
+        if tuple(blk.conv2.stride) == (1, 1):
+            y = cb(y, blk.conv2, blk.bn2, True)
+        else:
+            # (3 x 3 / stride 2: grad-input would be four sub-filter convolutions; the library's channel-last kernels on the views)
+            y = torch.relu(blk.bn2(blk.conv2(y.permute(0, 3, 1, 2)))).permute(0, 2, 3, 1).contiguous()
+            tap(y)
+        x = cb(y, blk.conv3, blk.bn3, True, identity)
+    return x
+
+
 _X3_FPN_ROWS_BF16 = _os.environ.get('CGG_X3_FPN_ROWS_BF16', '1') != '0'      # ... also in throughput (bf16) mode: 170.4 -> 166.0 ms per configs[2] step
 _X3_FPN_ROWS = _os.environ.get('CGG_X3_FPN_ROWS', '1') != '0'      # parity-mode training: the finest FPN level channel-last on own kernels (A/B)
 
@@ -615,6 +773,16 @@ class _X3FpnLevelFn(torch.autograd.Function):
         dcur, dg1, db1, dlo = ops.group_norm_nhwc_backward(cur, None, gy1.view(B, HW, C), stats1, g1, groups, eps1, False, (H, W),
                                                            lo_hw=lo_hw)
         return dcur, dlo, dg1, db1, gw.permute(0, 3, 1, 2), dg2, db2, None, None, None, None, None
+
+
+def nhwc_to_nchw_train(xn):
+    """channel-last (B, H, W, C) f32 under autograd -> contiguous (B, C, H, W) (tiled transpose kernel both ways); the channel-last
+    original rides along as `_cgg_rows` (B, H W, C) for consumers that read rows under autograd."""
+    B, H, W, C = xn.shape
+    rows = xn.reshape(B, H * W, C)
+    out = _RowsToNchwFn.apply(rows, (H, W))
+    out._cgg_rows = rows
+    return out
 
 
 def x3_fpn_level_ok(pd, x, lo_hw):

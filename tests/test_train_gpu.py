@@ -407,3 +407,46 @@ def test_frozen_folded_backbone_matches_the_autograd_recorded_path(dev, monkeypa
         xg = x.clone().requires_grad_(True)
         sum((o.float() ** 2).mean() for o in net(xg)).backward()
         assert xg.grad is not None and float(xg.grad.abs().max()) > 0
+
+
+def test_trainable_resnet_stage_on_x3_nodes_matches_the_library_path(dev, monkeypatch):
+    """Parity-mode training with frozen stages: layer4 channel-last on the x3 nodes (`runtime.resnet_stage_x3_train`, default on,
+    CGG_X3_RESNET_TRAIN=0 = the torch modules on MIOpen f32) through `ResNet.forward` -- the four maps and every layer4 gradient of
+    the two paths agree to f32-class accuracy, only layer4 receives gradients, and the C5 map hands its channel-last rows along."""
+    from cgg_amd import registry, runtime
+    torch.manual_seed(4)
+    net = registry.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=3,
+                                       norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch')).to(dev)
+    net.init_weights()
+    x = torch.randn(2, 3, 512, 640, device=dev)
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    with torch.no_grad(), runtime.precision_scope('fp32'):
+        for m in bns:                                          # a "trained" frozen BatchNorm: non-trivial affine, and statistics that
+            m.weight.uniform_(0.5, 1.5)                        # keep the activations at unit scale (one calibration pass:
+            m.bias.normal_(0, 0.1)                             # running stats := batch stats) -- the x3 kernels' operand range
+            m.training, m.momentum = True, 1.0
+        net(x)
+    net.train()
+    assert not any(m.training for m in bns)
+    monkeypatch.setattr(runtime, 'X3_TRAIN_ROWS', 256)       # (the size rule is about filling the grid, not about correctness)
+    res = {}
+    with runtime.precision_scope('fp32'):
+        for flag in (True, False):
+            monkeypatch.setattr(runtime, '_X3_RESNET_TRAIN', flag)
+            for p in net.parameters():
+                p.grad = None
+            outs = net(x)
+            assert (getattr(outs[3], '_cgg_rows', None) is not None) == flag
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            res[flag] = ([o.detach().float() for o in outs],
+                         {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert set(res[True][1]) == set(res[False][1]) and all(n.startswith('layer4') for n in res[True][1]) and len(res[True][1]) == 10
+    for a, b in zip(*[res[f][0] for f in (True, False)]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    for n, ga in res[True][1].items():
+        gb = res[False][1][n]
+        # (two f32-class arithmetics: an activation that is zero to rounding may take the other side of its ReLU in one of them, and
+        # one such flip moves a filter gradient by a row's contribution, 3e-3 of its scale with the 640 rows of this test -- the
+        # tie-aware comparison is test_resnet_stage_rows_path_vs_float64)
+        assert (ga - gb).abs().max().item() <= 1e-2 * gb.abs().max().item(), n
+        assert torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item() >= 0.9999, n

@@ -586,3 +586,79 @@ def test_fpn_level_rows_path_vs_float64(dev):
         # gradients through two GroupNorms are cancelling sums over 73 728 pixels: f32 library kernels are 1e-4 .. 1e-3 of scale from
         # float64 on the weights; the channel-last path must be no worse than twice that (or 3e-5)
         assert scale > 0 and err <= max(3e-5 * scale, 2.0 * err32), (k, err, err32, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('first_stride', [2, 1])
+def test_resnet_stage_rows_path_vs_float64(dev, first_stride):
+    """PARITY-mode training of a trainable ResNet stage with frozen BatchNorm on channel-last maps (`runtime.resnet_stage_x3_train`:
+    one `_X3ConvBnFn` node per convolution + BN affine + ReLU / residual, the 3 x 3 / stride-2 convolution on the library) against the
+    same Bottlenecks in float64 torch modules: the stage output and every gradient (all filters incl. the down-sample path, the
+    input map) at a 1e-5-scale upstream gradient, with the f32 library modules as the yardstick."""
+    import copy
+    from cgg_amd import runtime
+    from cgg_amd.backbones import Bottleneck
+    torch.manual_seed(11)
+    cin, planes = 64, 32
+    down = torch.nn.Sequential(torch.nn.Conv2d(cin, planes * 4, 1, stride=first_stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+    stage = torch.nn.Sequential(Bottleneck(cin, planes, first_stride, down), Bottleneck(planes * 4, planes), Bottleneck(planes * 4, planes))
+    g = torch.Generator().manual_seed(12)
+    for m in stage.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):      # a "trained" frozen BatchNorm: non-trivial statistics and affine
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.weight.requires_grad = m.bias.requires_grad = False
+    stage = stage.to(dev).eval()                     # norm_eval=True: BatchNorm in eval mode while the filters train
+    B, H, W = 8, 64, 64                              # (8 192 rows behind the stride-2 block: the x3 nodes' size rule)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev).requires_grad_()
+    OH, OW = (H - 1) // first_stride + 1, (W - 1) // first_stride + 1
+    gm = (torch.randn(B, OH, OW, planes * 4, generator=g) * 1e-5).to(dev)
+    masks = []                                        # the ReLU decisions of the x3 run, NCHW like the modules' maps
+    with runtime.precision_scope('fp32'):
+        assert runtime.x3_resnet_stage_ok(stage, x.detach())
+        got = runtime.resnet_stage_x3_train(stage, x, tap=lambda y: masks.append((y.detach() > 0).permute(0, 3, 1, 2)))
+    assert len(masks) == 9
+    (got * gm).sum().backward()
+    names = [n for n, p in stage.named_parameters() if p.requires_grad]
+    grads = {n: p.grad.detach().double() for n, p in stage.named_parameters() if p.requires_grad}
+    assert all(n.endswith('weight') and ('conv' in n or 'downsample.0' in n) for n in names) and len(names) == 10
+    grads['x'] = x.grad.double()
+
+    class PinnedReLU(torch.nn.Module):
+        # an activation that is zero to rounding is a tie between the two arithmetics, and ONE flipped tie moves a weight gradient by
+        # a whole row's contribution (~5e-4 of its scale here): the references take the x3 run's decisions
+        def __init__(self):
+            super().__init__()
+            self.it = iter(masks)
+
+        def forward(self, z):
+            return z * next(self.it).to(z.dtype)
+
+    def composite(dt):
+        st = copy.deepcopy(stage).to(dt)
+        relu = PinnedReLU()
+        for blk in st:
+            blk.relu = relu
+        for p in st.parameters():
+            p.grad = None
+        xd = x.detach().to(dt).requires_grad_()
+        out = st(xd.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        (out * gm.to(dt)).sum().backward()
+        gr = {n: p.grad.double() for n, p in st.named_parameters() if p.requires_grad}
+        gr['x'] = xd.grad.double()
+        return out.detach().double(), gr
+
+    ref, want = composite(torch.float64)
+    _, lib32 = composite(torch.float32)
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    bad = []
+    for k in want:
+        scale = want[k].abs().max().item()
+        err = (grads[k] - want[k]).abs().max().item()
+        err32 = (lib32[k] - want[k]).abs().max().item()
+        print(f'{k}: err {err / scale:.2e} of scale, f32 library {err32 / scale:.2e}')
+        if not (scale > 0 and err <= max(3e-5 * scale, 2.0 * err32)):
+            bad.append((k, err, err32, scale))
+    assert not bad, bad
