@@ -1078,11 +1078,15 @@ class MSDeformAttnPixelDecoder(nn.Module):
         srcs, poss, level_hw = [], [], []
         for i in range(self.num_encoder_levels):
             feat = feats[self.num_input_levels - i - 1]
-            with runtime.autocast():
-                proj = self.input_convs[i](feat)
             h, w = feat.shape[-2:]
             level_hw.append((int(h), int(w)))
-            srcs.append(proj.float().flatten(2).transpose(1, 2))                     # (B, hw, C)
+            rows = runtime.input_level_x3_train(self.input_convs[i], feat)      # parity-mode training: channel-last rows end to end
+            if rows is not None:
+                srcs.append(rows)
+            else:
+                with runtime.autocast():
+                    proj = self.input_convs[i](feat)
+                srcs.append(proj.float().flatten(2).transpose(1, 2))                 # (B, hw, C)
             poss.append(self.postional_encoding.flat_unpadded(int(h), int(w), dev)
                         + self.level_encoding.weight[i][None])                      # (hw, C)
         level_start, s = [], 0

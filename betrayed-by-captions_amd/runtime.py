@@ -785,6 +785,39 @@ def nhwc_to_nchw_train(xn):
     return out
 
 
+_X3_INPUT_ROWS = _os.environ.get('CGG_X3_INPUT_ROWS', '1') != '0'      # parity-mode training: the encoder's input levels on channel-last rows (A/B)
+
+
+def input_level_x3_train(cm, feat):
+    """One encoder input level of the pixel decoder ([3P] MSDeformAttnPixelDecoder.input_convs: 1 x 1 convolution with bias +
+    GroupNorm, no activation; open_set/models/mask2former_head.py:787's inputs) in PARITY-mode training on channel-last rows: the
+    backbone map's channel-last original (`hand_nhwc` of a frozen stage / `_cgg_rows` of a trainable x3 stage) x the filter as an x3
+    row GEMM (`_X3LinearFn`: forward, grad-input, grad-weight + bias), GroupNorm by the channel-last kernels (`ops.GroupNormRowsFn`).
+    Returns (B, H W, C) rows -- what the encoder concatenates -- or None when the level has to take the module path (NCHW library
+    convolution + GroupNorm, then flatten + transpose)."""
+    import torch.nn as nn
+    from . import ops
+    conv = cm.conv
+    gn = getattr(cm, cm.norm_name, None) if cm.norm_name else None
+    if not (_X3_INPUT_ROWS and _X3_TRAIN and _X3_WGRAD and x3_enabled() and torch.is_grad_enabled() and feat.is_cuda
+            and feat.dim() == 4 and feat.dtype == torch.float32 and cm.activate is None and isinstance(gn, nn.GroupNorm)
+            and gn.num_groups * 8 == conv.out_channels == gn.num_channels and gn.affine
+            and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1):
+        return None
+    B, Cin, H, W = feat.shape
+    rows = getattr(feat, '_cgg_rows', None)
+    if rows is not None and (tuple(rows.shape) != (B, H * W, Cin) or rows.dtype != torch.float32):
+        rows = None
+    if rows is None:
+        nh = handed_nhwc(feat)
+        rows = nh.view(B, H * W, Cin) if nh is not None else None
+    if rows is None or not x3_train_linear_ok(rows, conv.weight.flatten(1)):
+        return None
+    y = _X3LinearFn.apply(rows, conv.weight.flatten(1), conv.bias)
+    return ops.GroupNormRowsFn.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, False, None, (H, W), None)
+
+
 def x3_fpn_level_ok(pd, x, lo_hw):
     """PARITY-mode training of the pixel decoder's single FPN level (lateral 1 x 1 + GN, + up-sample, 3 x 3 + GN + ReLU, mask-feature
     1 x 1) on channel-last rows and own kernels: `_X3FpnLevelFn` + `_X3LinearFn`s."""

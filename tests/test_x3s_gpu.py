@@ -662,3 +662,58 @@ def test_resnet_stage_rows_path_vs_float64(dev, first_stride):
         if not (scale > 0 and err <= max(3e-5 * scale, 2.0 * err32)):
             bad.append((k, err, err32, scale))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('handed', ['frozen_nhwc', 'trainable_rows'])
+def test_encoder_input_level_rows_path_vs_float64(dev, handed):
+    """PARITY-mode training of an encoder input level of the pixel decoder (`runtime.input_level_x3_train`: 1 x 1 convolution + bias
+    as an x3 row GEMM on the backbone map's channel-last original, GroupNorm by the channel-last kernels) against the same ConvModule
+    in float64 (F.conv2d + F.group_norm on NCHW): rows, filter / bias / GroupNorm gradients and -- for a trainable backbone stage's
+    map -- the gradient into the map; a map without a channel-last original takes the module path (None)."""
+    from cgg_amd import runtime
+    from cgg_amd.pixel_decoder import ConvModule
+    torch.manual_seed(21)
+    Cin, C, B, H, W = 512, 256, 4, 48, 64
+    cm = ConvModule(Cin, C, kernel_size=1, norm_cfg=dict(type="GN", num_groups=32), act_cfg=None, bias=True).to(dev).train()
+    with torch.no_grad():
+        cm.conv.bias.normal_(0, 0.1)
+        cm.gn.weight.uniform_(0.5, 1.5)
+        cm.gn.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(22)
+    nhwc = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    gm = (torch.randn(B, H * W, C, generator=g) * 1e-5).to(dev)
+    with runtime.precision_scope('fp32'):
+        assert runtime.input_level_x3_train(cm, nhwc.permute(0, 3, 1, 2).contiguous()) is None      # nothing handed over
+        if handed == 'frozen_nhwc':
+            feat = runtime.hand_nhwc(nhwc.permute(0, 3, 1, 2).contiguous(), nhwc)
+            leaf = None
+        else:
+            leaf = nhwc.clone().requires_grad_()
+            feat = runtime.nhwc_to_nchw_train(leaf)
+        got = runtime.input_level_x3_train(cm, feat)
+    assert got is not None and tuple(got.shape) == (B, H * W, C)
+    (got * gm).sum().backward()
+    params = dict(w=cm.conv.weight, b=cm.conv.bias, gamma=cm.gn.weight, beta=cm.gn.bias)
+    grads = {k: v.grad.detach().double() for k, v in params.items()}
+    if leaf is not None:
+        grads['x'] = leaf.grad.double()
+
+    def composite(dt):
+        d = {k: v.detach().to(dt).requires_grad_() for k, v in params.items()}
+        xd = nhwc.detach().to(dt).requires_grad_()
+        y = F.group_norm(F.conv2d(xd.permute(0, 3, 1, 2), d['w'], d['b']), 32, d['gamma'], d['beta'], cm.gn.eps)
+        y = y.flatten(2).transpose(1, 2)
+        (y * gm.to(dt)).sum().backward()
+        gr = {k: v.grad.double() for k, v in d.items()}
+        gr['x'] = xd.grad.double()
+        return y.detach().double(), gr
+
+    ref, want = composite(torch.float64)
+    _, lib32 = composite(torch.float32)
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    for k in grads:
+        scale = want[k].abs().max().item()
+        err = (grads[k] - want[k]).abs().max().item()
+        err32 = (lib32[k] - want[k]).abs().max().item()
+        assert scale > 0 and err <= max(3e-5 * scale, 2.0 * err32), (k, err, err32, scale)
