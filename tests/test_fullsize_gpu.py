@@ -755,3 +755,60 @@ def test_configs3_detector_train_step_runs(dev):
             if n.startswith(k) and float(p.grad.abs().max()) > 0:
                 seen[k] = True
     assert all(seen.values()), seen
+
+
+def test_configs2_detector_train_step_rows_paths_match_module_paths(dev, monkeypatch):
+    """The whole configs[2] detector (ResNet-50, frozen_stages=3, under autograd + head) at batch 8 x 1024^2 in parity mode: the
+    channel-last x3 paths of the trainable backbone stage and of the encoder's input levels (`runtime.resnet_stage_x3_train`,
+    `runtime.input_level_x3_train`, default on) against the module paths (MIOpen f32 convolutions + torch BatchNorm / GroupNorm,
+    CGG_X3_RESNET_TRAIN=0 CGG_X3_INPUT_ROWS=0): the 70 losses and the gradients of layer4 / the input convolutions / a decoder weight.
+    Both are f32-class arithmetics on the same graph, so the comparison is loose where a ReLU / matching tie may fall the other way
+    (cosine) and tight on the losses; the tie-aware float64 comparisons are tests/test_x3s_gpu.py::test_resnet_stage_rows_path_vs_float64
+    and ::test_encoder_input_level_rows_path_vs_float64."""
+    cfg = synthetic.model_config(num_things=65, num_stuff=0, num_unknown=17, num_queries=100, depth=50)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.manual_seed(0)
+        model = registry.build_detector(cfg)
+        model.init_weights()
+    model = model.to(dev).train()
+    B, H, W = 8, 1024, 1024
+    img = synthetic.structured_images(B, H, W, seed=15).to(dev)
+    # a "trained" frozen BatchNorm: non-trivial affine (the zero-initialised last gamma of a Bottleneck would silence the whole residual
+    # branch and its gradients), statistics from one calibration pass (activations at unit scale, as with trained weights)
+    bns = [m for m in model.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    with torch.no_grad(), runtime.precision_scope('fp32'):
+        for m in bns:
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+            m.training, m.momentum = True, 1.0
+        model.backbone(img)
+        for m in bns:
+            m.training = False
+    metas = synthetic.img_metas(B, H, W)
+    batch = synthetic.train_batch(B, H, W, num_classes=cfg['panoptic_head']['num_things_classes'], seed=16, device=dev)
+    keys = [n for n, p in model.named_parameters() if p.requires_grad and (n.startswith('backbone.layer4') or 'input_convs' in n)]
+    keys += ['panoptic_head.transformer_decoder.layers.8.ffns.0.layers.1.weight', 'panoptic_head.pixel_decoder.encoder.layers.0.ffns.0.layers.1.weight']
+    named = dict(model.named_parameters())
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(runtime, '_X3_RESNET_TRAIN', flag)
+        monkeypatch.setattr(runtime, '_X3_INPUT_ROWS', flag)
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(1)                                    # the loss's random points
+        with runtime.precision_scope('fp32'):
+            out = model.train_step(dict(img=img, img_metas=metas, **batch))
+            out['loss'].backward()
+        res[flag] = ({k: float(v) for k, v in out['log_vars'].items()}, {k: named[k].grad.detach().clone() for k in keys})
+    assert len(keys) >= 10 + 12 + 2
+    la, lb = res[True][0], res[False][0]
+    assert set(la) == set(lb) and len(la) >= 70
+    worst = max(abs(la[k] - lb[k]) / max(abs(lb[k]), 1.0) for k in la)
+    assert worst <= 2e-3, worst
+    for k in keys:
+        ga, gb = res[True][1][k], res[False][1][k]
+        assert torch.isfinite(ga).all() and float(gb.abs().max()) > 0, k
+        cos = torch.nn.functional.cosine_similarity(ga.flatten().double(), gb.flatten().double(), dim=0).item()
+        assert cos >= 0.995, (k, cos)
+    print(f'configs[2] detector step, rows paths vs module paths: worst loss difference {worst:.1e}')
