@@ -48,16 +48,27 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
   constexpr int WG_PLANE = 32 * RS;
   constexpr int CG = BT / 4;                          // 16-byte column groups per row
   constexpr int RPI = NT / CG;                        // rows staged per pass (8)
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];            // Yh | Yl | Xh | Xl
+  // LDS stages of Yh | Yl | Xh | Xl. The 256-wide tile is ONE 8-wave workgroup per CU: with a single stage its waves alternate in lock
+  // step between the split / LDS-write phase and the transpose-read / MFMA phase (two barriers per chunk, the matrix pipe idle in
+  // between); with two stages (144 of 160 KiB) chunk c + 1 is staged while chunk c is multiplied, one barrier per chunk. The 128-wide
+  // tile keeps one stage: four workgroups share a CU and fill each other's phases.
+  constexpr int NBUF = BT == 256 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Yh = lds;
   unsigned char* Yl = lds + WG_PLANE;
   unsigned char* Xh = lds + 2 * WG_PLANE;
   unsigned char* Xl = lds + 3 * WG_PLANE;
+  constexpr int STAGE_B = 4 * WG_PLANE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WK, wk = wave - wn * WK;
-  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  // the tiles of one row range run on ONE XCD (they re-read the range's dy / x columns: 4 x for a 1024 x 256 weight -- from that XCD's
+  // L2 instead of HBM): the hardware deals workgroups x-fastest round-robin over the 8 XCDs, the remap hands every XCD a contiguous
+  // run of (split, tile) pairs, all of them resident at once (one grid round)
+  const int lin = cgg_xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+  const int bx = lin % (int)gridDim.x, by = lin / (int)gridDim.x;
+  const int tile_n = bx / tiles_k, tile_k = bx - tile_n * tiles_k;
   const int n0 = tile_n * BT, k0 = tile_k * BT;
-  const int m_begin = blockIdx.y * rows_per_split;
+  const int m_begin = by * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
 
   // staging: thread = (row r8 + 8 i, 16-byte column group c4) of both tiles
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
   // interior tiles (every column group inside N and K) and chunks with all 32 rows live skip the zero-fill selects: 48 of the
   // ~200 VALU instructions a chunk cost next to its 48 MFMAs (workgroup-uniform conditions)
   const bool colfull = n0 + BT <= N && k0 + BT <= K;
-  auto stage_t = [&](int m0, auto fullc_t) {
+  auto stage_t = [&](int m0, int sb, auto fullc_t) {
     constexpr bool FULLC = decltype(fullc_t)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
       uint2 h, l;
       if (want_bias) bsum += y;
       cgg_x3_split4_s(y, sy, h, l);
-      const int o = (r8 + 8 * i) * RS + 8 * c4;
+      const int o = sb + (r8 + 8 * i) * RS + 8 * c4;
       *reinterpret_cast<uint2*>(Yh + o) = h;
       *reinterpret_cast<uint2*>(Yl + o) = l;
       cgg_x3_split4(xx, h, l);
@@ -105,9 +116,9 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
       *reinterpret_cast<uint2*>(Xl + o) = l;
     }
   };
-  auto stage = [&](int m0) {
-    if (colfull && m0 + 32 <= m_end) stage_t(m0, std::true_type{});
-    else stage_t(m0, std::false_type{});
+  auto stage = [&](int m0, int sb) {
+    if (colfull && m0 + 32 <= m_end) stage_t(m0, sb, std::true_type{});
+    else stage_t(m0, sb, std::false_type{});
   };
 
   f32x16 acc[TA][TB];
@@ -124,31 +135,63 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
   const int colb = 2 * (16 * (g & 1) + 4 * (i16 & 3));      // byte offset inside a 32-column MFMA tile
   const int rowl = 8 * u + (i16 >> 2);
 
-  if (m_begin < m_end) load(m_begin);
-  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
-    __syncthreads();                       // the previous chunk's fragments are read
-    stage(m0);
-    __syncthreads();
-    if (m0 + 32 < m_end) load(m0 + 32);    // workgroup-uniform
+  auto compute = [&](int sb) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       wg_u32x4 ah[TA], al[TA], bh[TB], bl[TB];
 #pragma unroll
       for (int t = 0; t < TA; ++t) {
         const int cy = 2 * (wn * 32 * TA + t * 32) + colb;
-        ah[t] = wg_tr_frag<RS>(Yh, 16 * s + rowl, cy);
-        al[t] = wg_tr_frag<RS>(Yl, 16 * s + rowl, cy);
+        ah[t] = wg_tr_frag<RS>(Yh + sb, 16 * s + rowl, cy);
+        al[t] = wg_tr_frag<RS>(Yl + sb, 16 * s + rowl, cy);
       }
 #pragma unroll
       for (int t = 0; t < TB; ++t) {
         const int cx = 2 * (wk * 32 * TB + t * 32) + colb;
-        bh[t] = wg_tr_frag<RS>(Xh, 16 * s + rowl, cx);
-        bl[t] = wg_tr_frag<RS>(Xl, 16 * s + rowl, cx);
+        bh[t] = wg_tr_frag<RS>(Xh + sb, 16 * s + rowl, cx);
+        bl[t] = wg_tr_frag<RS>(Xl + sb, 16 * s + rowl, cx);
       }
+      // the three products of a tile in three rounds over the tiles (small terms first): neighbouring MFMAs are independent
 #pragma unroll
       for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < TB; ++b) cgg_x3_mfma(acc[a][b], ah[a], al[a], bh[b], bl[b]);
+        for (int b = 0; b < TB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[a]), __builtin_bit_cast(f16x8, bh[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[a]), __builtin_bit_cast(f16x8, bl[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[a]), __builtin_bit_cast(f16x8, bh[b]), acc[a][b], 0, 0, 0);
+    }
+  };
+  if (m_begin < m_end) load(m_begin);
+  if constexpr (NBUF == 2) {
+    if (m_begin < m_end) {
+      stage(m_begin, 0);
+      if (m_begin + 32 < m_end) load(m_begin + 32);
+    }
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += 32, cur ^= STAGE_B) {
+      // chunk m0 is staged by every wave, and every wave is done with the other stage (its MFMAs of the previous iteration)
+      __syncthreads();
+      if (m0 + 32 < m_end) {               // workgroup-uniform
+        stage(m0 + 32, cur ^ STAGE_B);
+        if (m0 + 64 < m_end) load(m0 + 64);
+      }
+      compute(cur);
+    }
+  } else {
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+      __syncthreads();                       // the previous chunk's fragments are read
+      stage(m0, 0);
+      __syncthreads();
+      if (m0 + 32 < m_end) load(m0 + 32);    // workgroup-uniform
+      compute(0);
     }
   }
 
@@ -163,12 +206,12 @@ __global__ __launch_bounds__(BT == 128 ? 256 : 512) void cgg_wgrad_x3_kernel(con
 #pragma unroll
       for (int r = 1; r < 8; ++r) t += red[tid + CG * r];
       const int n = n0 + 4 * tid;
-      if (n < N) *reinterpret_cast<f32x4*>(ws_bias + (size_t)blockIdx.y * N + n) = t;
+      if (n < N) *reinterpret_cast<f32x4*>(ws_bias + (size_t)by * N + n) = t;
     }
   }
   // partial tile -> ws[split][n][k]; lane (k column j, half hi5), register r <-> n row 8 (r >> 2) + 4 hi5 + (r & 3)
   const int j = lane & 31, hi5 = lane >> 5;
-  float* wsp = ws + (size_t)blockIdx.y * N * K;
+  float* wsp = ws + (size_t)by * N * K;
   if (colfull && (size_t)N * K * 4u < 0xFFFFFF00ull) {
     // interior tile: buffer stores, the row term of the address in a scalar register (one multiply + one store per element; the
     // generic form below computes a 64-bit address and two bounds tests per element)
@@ -243,7 +286,7 @@ static int wgrad_launch(const float* dy, int ldy, const float* x, int ldx, float
     hipLaunchKernelGGL(cgg_wgrad_x3_kernel<128>, dim3(tiles_n * tiles_k, sp), dim3(256), 4 * 32 * (2 * 128 + 64), (hipStream_t)stream, dy,
                        ldy, x, ldx, ws, ws_bias, M, N, K, tiles_k, rps, dy_amax);
   } else {
-    const int lds = 4 * 32 * (2 * 256 + 64);           // 72 KiB: above the default dynamic-LDS limit
+    const int lds = 2 * 4 * 32 * (2 * 256 + 64);       // two stages of 72 KiB: above the default dynamic-LDS limit
     static bool attr_set[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
