@@ -539,7 +539,7 @@ class _X3ConvBnFn(torch.autograd.Function):
         from . import ops
         N, C, k, _ = weight.shape
         B, H, W, _ = x.shape
-        x = x.detach()
+        x = x.detach().contiguous()
         wk = derived_cached('x3_convbn_image', (weight, scale),
                             lambda: ops.pack_conv_weight_x3(weight.detach() * scale.view(-1, 1, 1, 1)))
         r = res.detach().contiguous() if res is not None else None
