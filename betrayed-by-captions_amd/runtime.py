@@ -532,7 +532,12 @@ class _X3ConvBnFn(torch.autograd.Function):
     add launches and their backward kernels: forward = the x3 implicit GEMM with s folded into the packed filter and (t, res, ReLU) in
     its epilogue; backward = one ReLU-mask pass, one max |g| pass (per-tensor pre-scale, see `_X3LinearFn`), grad-input as the x3
     GEMM / convolution with the transposed (flipped) filter, grad-weight as `ops.wgrad_x3` (nine taps over zero-padded maps for
-    3 x 3, see `_X3Conv3x3Fn`), scaled by s."""
+    3 x 3, see `_X3Conv3x3Fn`), scaled by s.
+    3 x 3 / STRIDE 2 / pad 1 (even H, W; the first block's convolution): x[iy] reaches out[oy] through tap ky = iy + 1 - 2 oy, so the
+    input pixels of one parity class (iy & 1, ix & 1) see a fixed 1 x 1, 1 x 2, 2 x 1 or 2 x 2 sub-filter of grad_output -- grad-input is
+    FOUR small stride-1 convolutions over grad_output (zero row / column appended: the 2-tap reach to oy + 1) whose results interleave,
+    nine taps' worth of MFMA work like the forward (a zero-dilated grad_output would cost four times that); grad-weight pairs
+    grad_output with the four parity-class sub-maps of the zero-padded input, in which a tap is again a constant row offset."""
 
     @staticmethod
     def forward(ctx, x, weight, scale, shift, res, stride, relu):
@@ -576,14 +581,39 @@ class _X3ConvBnFn(torch.autograd.Function):
                 else:       # the pixels a stride-s 1 x 1 filter never read get no gradient
                     gx = torch.zeros_like(x)
                     gx[:, ::stride, ::stride] = gs
-            else:
+            elif stride == 1:
                 wt = derived_cached('x3_convbn_image_t', (weight, scale), lambda: ops.pack_conv_weight_x3(
                     (weight.detach() * scale.view(-1, 1, 1, 1)).flip(2, 3).transpose(0, 1).contiguous()))
                 gx = ops.conv_x3_nhwc(g, wt, C, k, 1, k // 2, amax=amax)
+            else:
+                taps = ([1], [2, 0])                      # filter taps seen by even / odd input coordinates, at offsets 0 (, + 1)
+
+                def sub_images():
+                    ws = weight.detach() * scale.view(-1, 1, 1, 1)
+                    return [ops.pack_conv_weight_x3(ws[:, :, taps[py]][:, :, :, taps[px]].transpose(0, 1).contiguous())
+                            for py in (0, 1) for px in (0, 1)]
+                imgs = derived_cached('x3_convbn_image_t_s2', (weight, scale), sub_images)
+                gp = F.pad(g, (0, 0, 0, 1, 0, 1))          # (B, OH + 1, OW + 1, N): zero last row / column
+                gx = torch.empty_like(x)
+                for py in (0, 1):
+                    for px in (0, 1):
+                        o = ops.conv_x3_nhwc(gp, imgs[2 * py + px], C, (len(taps[py]), len(taps[px])), 1, 0, amax=amax)
+                        gx[:, py::2, px::2] = o[:, :OH, :OW]
         if ctx.needs_input_grad[1]:
             if k == 1:
                 xs = x if stride == 1 else x[:, ::stride, ::stride].contiguous()
                 gw = ops.wgrad_x3(g2, xs.view(-1, C), amax=amax).view(N, C, 1, 1)
+            elif stride == 2:
+                xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+                gr = F.pad(g, (0, 0, 0, 1, 0, 1)).view(-1, N)      # rows of the (B, OH + 1, OW + 1) grid the sub-maps share
+                Mp = gr.shape[0]
+                ph = [[xp[:, py::2, px::2].contiguous().view(-1, C) for px in (0, 1)] for py in (0, 1)]
+                gw = torch.empty((N, k, k, C), dtype=torch.float32, device=x.device)
+                for ky in range(3):
+                    for kx in range(3):
+                        off = (ky >> 1) * (OW + 1) + (kx >> 1)
+                        gw[:, ky, kx, :] = ops.wgrad_x3(gr[:Mp - off], ph[ky & 1][kx & 1][off:], amax=amax)
+                gw = gw.permute(0, 3, 1, 2)
             else:
                 # both maps zero-padded by one pixel: a filter tap is a constant row offset between two row-major matrices
                 xr = F.pad(x, (0, 0, 1, 1, 1, 1)).view(-1, C)
@@ -615,13 +645,24 @@ def _x3_convbn_ok(conv, bn):
             and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and getattr(conv, 'padding_mode', 'zeros') == 'zeros'
             and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.weight.requires_grad
             and ((k == (1, 1) and s in ((1, 1), (2, 2)) and tuple(conv.padding) == (0, 0))
-                 or (k == (3, 3) and s == (1, 1) and tuple(conv.padding) == (1, 1))))
+                 or (k == (3, 3) and s in ((1, 1), (2, 2)) and tuple(conv.padding) == (1, 1))))
+
+
+# the first block's 3 x 3 / stride-2 convolution on `_X3ConvBnFn` too (four sub-filter convolutions for grad-input, parity-class
+# sub-maps for grad-weight). OFF by default: correct (tests/test_x3s_gpu.py) but 2 % SLOWER per configs[2] step than MIOpen's kernels
+# on the channel-last views (85.0 vs 86.8 images/s) -- the padding / parity-class copies and 13 small launches cost more than the one
+# convolution saves (profiles/r6_resnet_stage_train_ab.txt)
+_X3_RESNET_S2 = _os.environ.get('CGG_X3_RESNET_S2', '0') == '1'
+
+
+def _conv2_s2_on_x3(blk, H, W):
+    return _X3_RESNET_S2 and tuple(blk.conv2.stride) == (2, 2) and H % 2 == 0 and W % 2 == 0
 
 
 def x3_resnet_stage_ok(stage, x):
     """PARITY-mode training of a ResNet stage of Bottlenecks with frozen BatchNorm on channel-last maps and own kernels
-    (`_X3ConvBnFn`; a 3 x 3 / stride-2 convolution -- the first block's -- stays a library call on the channel-last view). x: the
-    stage's channel-last f32 input (B, H, W, C)."""
+    (`_X3ConvBnFn`; a 3 x 3 / stride-2 convolution -- the first block's -- needs even H, W, else it stays a library call on the
+    channel-last view -- which is also the default, CGG_X3_RESNET_S2=1 moves it). x: the stage's channel-last f32 input (B, H, W, C)."""
     from .backbones import Bottleneck
     if not (_X3_RESNET_TRAIN and _X3_TRAIN and _X3_WGRAD and x3_enabled() and torch.is_grad_enabled() and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
@@ -636,7 +677,7 @@ def x3_resnet_stage_ok(stage, x):
                 return False
             pairs.append((blk.downsample[0], blk.downsample[1]))
         s2 = tuple(blk.conv2.stride)
-        if s2 == (1, 1):
+        if s2 == (1, 1) or _conv2_s2_on_x3(blk, H, W):
             pairs.append((blk.conv2, blk.bn2))
         elif not (isinstance(blk.bn2, torch.nn.BatchNorm2d) and not blk.bn2.training):
             return False
@@ -668,7 +709,7 @@ def resnet_stage_x3_train(stage, x, tap=None):
     for blk in stage:
         identity = x if blk.downsample is None else cb(x, blk.downsample[0], blk.downsample[1], False)
         y = cb(x, blk.conv1, blk.bn1, True)
-        if tuple(blk.conv2.stride) == (1, 1):
+        if tuple(blk.conv2.stride) == (1, 1) or _conv2_s2_on_x3(blk, y.shape[1], y.shape[2]):
             y = cb(y, blk.conv2, blk.bn2, True)
         else:
             # (3 x 3 / stride 2: grad-input would be four sub-filter convolutions; the library's channel-last kernels on the views)

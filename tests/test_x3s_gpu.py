@@ -589,8 +589,8 @@ def test_fpn_level_rows_path_vs_float64(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('first_stride', [2, 1])
-def test_resnet_stage_rows_path_vs_float64(dev, first_stride):
+@pytest.mark.parametrize('first_stride,s2_x3', [(2, False), (2, True), (1, False)])
+def test_resnet_stage_rows_path_vs_float64(dev, first_stride, s2_x3, monkeypatch):
     """PARITY-mode training of a trainable ResNet stage with frozen BatchNorm on channel-last maps (`runtime.resnet_stage_x3_train`:
     one `_X3ConvBnFn` node per convolution + BN affine + ReLU / residual, the 3 x 3 / stride-2 convolution on the library) against the
     same Bottlenecks in float64 torch modules: the stage output and every gradient (all filters incl. the down-sample path, the
@@ -598,6 +598,8 @@ def test_resnet_stage_rows_path_vs_float64(dev, first_stride):
     import copy
     from cgg_amd import runtime
     from cgg_amd.backbones import Bottleneck
+    # (s2_x3: the 3 x 3 / stride-2 convolution on the x3 node as well -- CGG_X3_RESNET_S2=1, off by default because it is slower)
+    monkeypatch.setattr(runtime, '_X3_RESNET_S2', s2_x3)
     torch.manual_seed(11)
     cin, planes = 64, 32
     down = torch.nn.Sequential(torch.nn.Conv2d(cin, planes * 4, 1, stride=first_stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
