@@ -145,6 +145,7 @@ PROTOTYPES = {
     'cgg_group_norm_nhwc_f32': (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_vp, _c_int, _c_int, _c_i64, _c_int,
                                            _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp]),
     'cgg_pack_mask_feature_nhwc_f32_x3': (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
+    'cgg_point_sample_nhwc_x3': (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     'cgg_pack_mask_feature_nhwc_multi': (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_pack_mask_feature_nhwc': (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     'cgg_blaslt_init': (_c_int, [ctypes.c_char_p]),

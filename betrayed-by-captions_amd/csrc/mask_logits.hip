@@ -176,6 +176,82 @@ __global__ __launch_bounds__(256) void cgg_pack_nhwc_f32_x3_kernel(const float* 
   }
 }
 
+// Point sampling of the channel-last f32 mask feature STRAIGHT into x3 images (training, parity mode: the matching costs need
+// mask_embed . sample(mask_feature) at the P random points of every decoder layer, open_set/models/mask2former_head.py:899-921 with
+// sample(E F) = E sample(F)): round 5 wrote the samples as (B, n P, C) f32 rows (2 GB at configs[2]) and ran one f32 library bmm
+// per layer over them (10 x 234 us at 44 TF/s). Here a workgroup samples one 32-point tile -- the arithmetic of
+// cgg_point_sample_nhwc_kernel (ATen's grid_sampler_2d order), a point's taps read as 1-KiB channel rows by 32 lanes -- splits the
+// values into their f16 pieces and writes the tile octet-major through LDS like the pack kernel above: the result IS the packed B
+// operand of cgg_mask_logits' split mode, one image per (layer, batch image) in layer-major order, so the per-layer einsum runs
+// on the f32-class MFMA kernel with no pack pass and no f32 sample tensor.
+__global__ __launch_bounds__(256) void cgg_point_sample_nhwc_x3_kernel(const float* __restrict__ feat, const float* __restrict__ pts,
+                                                                       u32x4* __restrict__ hi, u32x4* __restrict__ lo, int KC, int H,
+                                                                       int W, int P_total, int P_group, int B) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 tile[];   // hi [KC][32] | lo [KC][32]
+  const int t_all = blockIdx.x, b = blockIdx.y;
+  const int n = KC * 32;
+  const size_t C = (size_t)KC * 8;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    const int pl = idx / KC, kc = idx - pl * KC;
+    const long long bp = (long long)b * P_total + (long long)t_all * 32 + pl;
+    const float px = pts[bp * 2], py = pts[bp * 2 + 1];
+    const float gx = __fsub_rn(__fmul_rn(px, 2.0f), 1.0f), gy = __fsub_rn(__fmul_rn(py, 2.0f), 1.0f);
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 2.f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 2.f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = __fsub_rn(ix, fx), ty = __fsub_rn(iy, fy);
+    const float ux = __fsub_rn(__fadd_rn(fx, 1.f), ix), uy = __fsub_rn(__fadd_rn(fy, 1.f), iy);
+    const float wnw = __fmul_rn(ux, uy), wne = __fmul_rn(tx, uy), wsw = __fmul_rn(ux, ty), wse = __fmul_rn(tx, ty);
+    const float* fb = feat + (size_t)b * H * W * C + kc * 8;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+    auto tap = [&](int yy, int xx, float w) {
+      const float* s0 = fb + ((size_t)yy * W + xx) * C;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(s0), v1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a0[c] = fmaf(v0[c], w, a0[c]);
+        a1[c] = fmaf(v1[c], w, a1[c]);
+      }
+    };
+    if (xin0 && yin0) tap(y0, x0, wnw);
+    if (xin1 && yin0) tap(y0, x0 + 1, wne);
+    if (xin0 && yin1) tap(y0 + 1, x0, wsw);
+    if (xin1 && yin1) tap(y0 + 1, x0 + 1, wse);
+    u32x4 ph, plo;
+    cgg_x3_split8(a0, a1, ph, plo);
+    tile[kc * 32 + pl] = ph;
+    tile[n + kc * 32 + pl] = plo;
+  }
+  __syncthreads();
+  const int Tg = P_group >> 5;                                   // tiles per (layer, image)
+  const int grp = t_all / Tg, t = t_all - grp * Tg;
+  const size_t img = (size_t)grp * B + b;                        // layer-major: the B images of a layer are one PackedFeature
+  u32x4* dh = hi + (img * Tg + t) * n;
+  u32x4* dl = lo + (img * Tg + t) * n;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    dh[idx] = tile[idx];
+    dl[idx] = tile[n + idx];
+  }
+}
+
+extern "C" int cgg_point_sample_nhwc_x3(const float* feat, const float* pts, void* hi, void* lo, int B, int H, int W, int C,
+                                        int P_total, int P_group, cgg_stream_t stream) {
+  CGG_REQUIRE(feat && pts && hi && lo, CGG_EINVAL, "cgg_point_sample_nhwc_x3: null pointer");
+  CGG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && P_total > 0 && P_group > 0, CGG_EINVAL, "cgg_point_sample_nhwc_x3: bad sizes");
+  CGG_REQUIRE(C % 8 == 0 && C <= 1024, CGG_EUNSUPPORTED, "cgg_point_sample_nhwc_x3: C=%d", C);
+  CGG_REQUIRE(P_group % 32 == 0 && P_total % P_group == 0, CGG_EUNSUPPORTED,
+              "cgg_point_sample_nhwc_x3: P_group=%d must be a multiple of 32 dividing P_total=%d", P_group, P_total);
+  CGG_REQUIRE(cgg_aligned16(feat) && cgg_aligned16(hi) && cgg_aligned16(lo), CGG_EALIGN, "cgg_point_sample_nhwc_x3: alignment");
+  const int KC = C / 8;
+  hipLaunchKernelGGL(cgg_point_sample_nhwc_x3_kernel, dim3(P_total / 32, B), dim3(256), (size_t)KC * 32 * 16 * 2, (hipStream_t)stream,
+                     feat, pts, (u32x4*)hi, (u32x4*)lo, KC, H, W, P_total, P_group, B);
+  CGG_CHECK_LAUNCH("cgg_point_sample_nhwc_x3");
+  return CGG_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // mask logits. Workgroup = 8 waves sharing one image's mask_embed in LDS; each wave streams its own
 // 32-pixel tiles: 16 k-steps x ceil(Q/32) m-tiles of v_mfma_f32_32x32x16_bf16 (x3 in SPLIT mode).

@@ -32,6 +32,8 @@ from .registry import (HEADS, build_assigner, build_head, build_loss, build_plug
 
 # throughput mode: the decoder's per-level K / V projections as one HIP launch (ops.decoder_kv_proj); CGG_FUSED_KV=0 = library GEMMs
 FUSED_KV = os.environ.get('CGG_FUSED_KV', '1') != '0'
+# parity-mode training: the matching costs' point logits on the x3 einsum over sampler-written x3 images (CGG_POINT_LOGITS_X3=0: f32 rows + library bmm)
+POINT_LOGITS_X3 = os.environ.get('CGG_POINT_LOGITS_X3', '1') != '0'
 BOS_TOKEN = 101
 EOS_TOKEN = 102
 
@@ -992,12 +994,22 @@ class Mask2FormerHeadOpen(nn.Module):
                 # (the channel-last FPN path hands its own channel-last copy along: taken only if shape / dtype match and neither
                 # tensor was written in place since -- runtime.handed_nhwc; the permute copy otherwise)
                 nhwc = runtime.handed_nhwc(mf0, allow_grad=True)
-                fs = ops.point_sample_nhwc(nhwc if nhwc is not None else mf0.detach().permute(0, 2, 3, 1).contiguous(),
-                                           pts.permute(1, 0, 2, 3).reshape(B, n * P, 2))           # (B, n*P, C)
+                nhwc = nhwc if nhwc is not None else mf0.detach().permute(0, 2, 3, 1).contiguous()
+                all_pts = pts.permute(1, 0, 2, 3).reshape(B, n * P, 2)
                 pred_pts = torch.empty((n, B, Q, P), dtype=torch.float32, device=dev)     # (no stack: each product lands in its slab)
-                for li in range(n):
-                    torch.bmm(all_mask_preds[li].mask_embed.detach().float(), fs[:, li * P:(li + 1) * P].transpose(1, 2),
-                              out=pred_pts[li])
+                if POINT_LOGITS_X3 and runtime.x3_enabled() and ops.point_sample_nhwc_x3_ok(nhwc, all_pts, n) \
+                        and all(m.mask_embed.shape[-1] == nhwc.shape[-1] for m in all_mask_preds):
+                    # parity mode: the sampler writes the samples as x3 images (no (B, n P, C) f32 tensor: 2 GB at configs[2]) and
+                    # each layer's (Q x C) x (C x P) product is the f32-class MFMA einsum kernel on them (the f32 library bmm ran
+                    # these at 44 TF/s: 2.3 ms per step)
+                    packs = ops.point_sample_nhwc_x3(nhwc, all_pts, n)
+                    for li in range(n):
+                        ops.mask_logits(all_mask_preds[li].mask_embed.detach().float().contiguous(), packs[li], out=pred_pts[li])
+                else:
+                    fs = ops.point_sample_nhwc(nhwc, all_pts)                                      # (B, n*P, C)
+                    for li in range(n):
+                        torch.bmm(all_mask_preds[li].mask_embed.detach().float(), fs[:, li * P:(li + 1) * P].transpose(1, 2),
+                                  out=pred_pts[li])
             else:
                 pred_pts = torch.stack([all_mask_preds[li].sample_points(pts[li]) if isinstance(all_mask_preds[li], LazyMasks)
                                         else point_sample(all_mask_preds[li].detach(), pts[li]) for li in range(n)], 0)

@@ -381,9 +381,13 @@ def pack_mask_feature(feat, pool=1, split=True):
     return PackedFeature(hi, lo, B, C, h, w, f32)
 
 
-def mask_logits(embed, packed, want_logits=True, want_bits=False):
-    """embed (B,Q,C) f32 x PackedFeature -> (logits (B,Q,h,w) f32 | None, bits (B,Q,words) int32 | None)."""
+def mask_logits(embed, packed, want_logits=True, want_bits=False, out=None):
+    """embed (B,Q,C) f32 x PackedFeature -> (logits (B,Q,h,w) f32 | None, bits (B,Q,words) int32 | None). out: a contiguous f32
+    tensor of B Q h w elements that receives the logits (packed kernels only)."""
     B, Q, C = embed.shape
+    if out is not None and (packed.f32 is not None or not want_logits or out.dtype != torch.float32 or not out.is_contiguous()
+                            or out.numel() != B * Q * packed.npix):
+        raise CggError('mask_logits: `out` must be a contiguous float32 tensor of B Q h w elements (packed kernels, want_logits)')
     if B != packed.B or C != packed.C:
         raise CggError(f'mask_logits: embed {tuple(embed.shape)} vs packed B={packed.B} C={packed.C}')
     if packed.f32 is not None and Q > 128:
@@ -399,8 +403,10 @@ def mask_logits(embed, packed, want_logits=True, want_bits=False):
                                              dev_ptr(bits), B, Q, C, packed.npix, stream_ptr(embed.device))
         check(rc, 'cgg_mask_logits_f32')
         return out, bits
-    out = torch.empty((B, Q, packed.h, packed.w), dtype=torch.float32, device=embed.device) \
-        if want_logits else None
+    if out is not None:
+        out = out.view(B, Q, packed.h, packed.w)
+    else:
+        out = torch.empty((B, Q, packed.h, packed.w), dtype=torch.float32, device=embed.device) if want_logits else None
     bits = torch.empty((B, Q, packed.words), dtype=torch.int32, device=embed.device) \
         if want_bits else None
     tag = 'mask_logits_full' if want_logits else 'mask_logits_bits'
@@ -2285,6 +2291,32 @@ def point_sample_nhwc(feat, points):
     check(_lib_().cgg_point_sample_nhwc(dev_ptr(feat), dev_ptr(pts), dev_ptr(out), B, H, W, C, P, stream_ptr(feat.device)),
           'cgg_point_sample_nhwc')
     return out
+
+
+def point_sample_nhwc_x3_ok(feat, points, groups):
+    """shapes `point_sample_nhwc_x3` covers"""
+    return (feat.dim() == 4 and feat.dtype == torch.float32 and feat.is_cuda and feat.is_contiguous() and feat.shape[-1] % 8 == 0
+            and feat.shape[-1] <= 1024 and points.dim() == 3 and points.dtype == torch.float32 and groups > 0
+            and points.shape[1] % groups == 0 and (points.shape[1] // groups) % 32 == 0)
+
+
+def point_sample_nhwc_x3(feat, points, groups):
+    """feat (B, H, W, C) f32 channel-last, points (B, groups * P, 2) in [0, 1] (x, y), group g's points at [g P, (g + 1) P) ->
+    [PackedFeature] * groups: the samples of group g as the x3 images of a (B, C, 1, P) "map" (`cgg_point_sample_nhwc_x3`: sampler and
+    pack kernel in one, no f32 sample tensor) -- `mask_logits(embed_g, packed[g])` is then mask_embed_g . sample(feat) at the group's
+    points, the training loss' point logits of one decoder layer, on the f32-class MFMA einsum."""
+    B, H, W, C = feat.shape
+    Pt = points.shape[1]
+    if not point_sample_nhwc_x3_ok(feat, points, groups) or tuple(points.shape) != (B, Pt, 2):
+        raise CggError('point_sample_nhwc_x3: feat (B, H, W, C) contiguous float32 (C % 8 == 0), points (B, groups * P, 2) float32 '
+                       'with P % 32 == 0 expected')
+    P = Pt // groups
+    pts = points.contiguous()
+    hi = torch.empty((groups * B, P // 32, C // 8, 32, 8), dtype=torch.bfloat16, device=feat.device)     # (16-bit pieces: f16 bits)
+    lo = torch.empty_like(hi)
+    check(_lib_().cgg_point_sample_nhwc_x3(dev_ptr(feat), dev_ptr(pts), dev_ptr(hi), dev_ptr(lo), B, H, W, C, Pt, P,
+                                           stream_ptr(feat.device)), 'cgg_point_sample_nhwc_x3')
+    return [PackedFeature(hi[g * B:(g + 1) * B], lo[g * B:(g + 1) * B], B, C, 1, P) for g in range(groups)]
 
 
 def subsample_nhwc(x, stride):

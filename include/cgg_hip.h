@@ -505,6 +505,16 @@ int cgg_group_norm_nhwc_f32(const float* x, const float* gamma, const float* bet
                             cgg_stream_t stream);
 int cgg_pack_mask_feature_nhwc_f32_x3(const float* feat, void* const* hi_host, void* const* lo_host, const int* pools_host,
                                       int n, int B, int C, int H, int W, cgg_stream_t stream);
+/* Training (parity mode), matching costs: mask_embed . sample(mask_feature) at the P_group random points of each of the
+ * P_total / P_group decoder layers (open_set/models/mask2former_head.py:899-921 samples the (B, Q, h, w) mask logits with [3P]
+ * mmcv.ops.point_sample; sample(E F) = E sample(F)). feat [B, H, W, C] channel-last f32, pts [B, P_total, 2] in [0, 1] (x, y), the
+ * points of layer g at [g P_group, (g + 1) P_group). Writes the SAMPLES as x3 images (the packed B operand of cgg_mask_logits'
+ * split mode, as cgg_pack_mask_feature_nhwc_f32_x3 would from an f32 sample tensor that is never materialised): hi / lo
+ * [P_total / P_group][B][P_group / 32][C / 8][32][8] 16-bit pieces -- image (g, b) holds layer g's samples of batch image b, so
+ * cgg_mask_logits(embed_g, hi + g * B * image, lo + ..., npix = P_group) is that layer's (B, Q, P_group) point logits.
+ * grid_sample arithmetic (bilinear, zeros padding, align_corners = False) in ATen's order. P_group % 32 == 0, C % 8 == 0. */
+int cgg_point_sample_nhwc_x3(const float* feat, const float* pts, void* hi, void* lo, int B, int H, int W, int C, int P_total,
+                             int P_group, cgg_stream_t stream);
 /* Parity mode's twin of cgg_encoder_layer_tail_bf16: the whole post-attention half of an encoder layer as ONE launch on the
  * f32-class contraction (csrc/encoder_tail_x3.hip):
  *   x1 = LayerNorm0(x + a Wo^T + bo);   y = LayerNorm1(x1 + W2 relu(W1 x1 + b1) + b2)

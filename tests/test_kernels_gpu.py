@@ -1182,6 +1182,37 @@ def test_point_sample_nhwc_matches_grid_sample(dev):
     assert (got == want.transpose(1, 2)).float().mean() > 0.99          # same arithmetic: bitwise on (nearly) all samples
 
 
+def test_point_sample_nhwc_x3_images_equal_pack_of_samples_and_point_logits_are_f32_class(dev):
+    """`cgg_point_sample_nhwc_x3` (sampler + x3 pack in one launch, layer-major images) against the two-step form it replaces --
+    `point_sample_nhwc` rows packed by `pack_mask_feature_nhwc_x3`: the same 16-bit pieces bit for bit; and the per-layer point logits
+    `mask_logits(embed_g, packed[g])` against float64 mask_embed . grid_sample(feature) within 4 x the f32 bmm's own error."""
+    from cgg_amd import runtime
+    g = torch.Generator().manual_seed(79)
+    B, C, H, W, n, P, Q = 2, 256, 24, 40, 3, 96, 37
+    feat = (torch.randn(B, C, H, W, generator=g) * 2).to(dev)
+    nhwc = feat.permute(0, 2, 3, 1).contiguous()
+    pts = torch.rand(B, n * P, 2, generator=g).to(dev)
+    pts[0, :4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.999, 0.001], [0.5, 0.5]])      # borders: zero padding taps
+    embeds = [(torch.randn(B, Q, C, generator=g) * 2).to(dev) for _ in range(n)]
+    assert ops.point_sample_nhwc_x3_ok(nhwc, pts, n) and not ops.point_sample_nhwc_x3_ok(nhwc, pts[:, :n * P - 8], n)
+    packs = ops.point_sample_nhwc_x3(nhwc, pts, n)
+    rows = ops.point_sample_nhwc(nhwc, pts)                                               # (B, n P, C)
+    want64 = torch.nn.functional.grid_sample(feat.double(), (pts.double() * 2.0 - 1.0).unsqueeze(2), align_corners=False).squeeze(3)
+    with runtime.precision_scope('fp32'):
+        for li in range(n):
+            two = ops.pack_mask_feature_nhwc_x3(rows[:, li * P:(li + 1) * P].contiguous().view(B, 1, P, C), [1])[0]
+            assert torch.equal(packs[li].hi.view(torch.int16), two.hi.view(torch.int16))
+            assert torch.equal(packs[li].lo.view(torch.int16), two.lo.view(torch.int16))
+            out = torch.empty((B, Q, P), dtype=torch.float32, device=dev)
+            got, _ = ops.mask_logits(embeds[li], packs[li], out=out)
+            assert got.data_ptr() == out.data_ptr()
+            fs = want64[:, :, li * P:(li + 1) * P]                                        # (B, C, P)
+            want = torch.bmm(embeds[li].double(), fs)
+            f32_err = (torch.bmm(embeds[li], fs.float()).double() - want).abs().max().item()
+            err = (out.double() - want).abs().max().item()
+            assert err <= 4 * f32_err + 1e-6 * want.abs().max().item(), (li, err, f32_err)
+
+
 def test_instance_masks_picks_bitpacked(dev):
     g = torch.Generator().manual_seed(78)
     Q, H, W = 20, 24, 32
