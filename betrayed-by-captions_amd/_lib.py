@@ -109,6 +109,7 @@ PROTOTYPES = {
     'cgg_nchw_to_nhwc_pad1_f32': (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp]),
     'cgg_topk_select': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     'cgg_absmax_f32': (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    'cgg_relu_bwd_absmax_f32': (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_longlong, _c_vp, _c_vp]),
     'cgg_gemm_x3_bwd': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 3 + [_c_vp]),
     'cgg_gemm_x3_scaled': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 4 + [_c_vp]),
     'cgg_conv_x3_nhwc_scaled': (_c_int, [_c_vp] * 6 + [_c_int] * 10 + [_c_vp]),

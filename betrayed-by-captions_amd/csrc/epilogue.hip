@@ -408,6 +408,67 @@ __global__ __launch_bounds__(256) void cgg_absmax_f32_kernel(const float* __rest
   }
 }
 
+// ReLU backward + max |.| in ONE pass: g = y > 0 ? gy : 0 (autograd's threshold_backward of a ReLU whose OUTPUT is y) and *amax =
+// max |g| -- the two passes in front of the gradient contractions of a conv + frozen-BN + ReLU training node
+// (runtime._X3ConvBnFn.backward, the trainable ResNet stage behind open_set/models/mask2former_head.py:787's inputs): the mask
+// pass wrote g and cgg_absmax_f32 read it again. Dense tensors of n % 4 == 0 elements; g may alias gy.
+__global__ __launch_bounds__(256) void cgg_relu_bwd_absmax_f32_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                      float* __restrict__ g, long long total4,
+                                                                      uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  const f32x4* gv = reinterpret_cast<const f32x4*>(gy);
+  const f32x4* yv = reinterpret_cast<const f32x4*>(y);
+  f32x4* ov = reinterpret_cast<f32x4*>(g);
+  const long long stride = (long long)gridDim.x * 256;
+  auto one = [&](long long u, const f32x4& a, const f32x4& b) {
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float f = b[k] > 0.f ? a[k] : 0.f;
+      r[k] = f;
+      const uint32_t bits = __builtin_bit_cast(uint32_t, f) & 0x7fffffffu;
+      m = bits > m ? bits : m;
+    }
+    ov[u] = r;
+  };
+  long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; u + stride < total4; u += 2 * stride) {              // two independent load pairs in flight per lane
+    const f32x4 a0 = __builtin_nontemporal_load(gv + u), b0 = __builtin_nontemporal_load(yv + u);
+    const f32x4 a1 = __builtin_nontemporal_load(gv + u + stride), b1 = __builtin_nontemporal_load(yv + u + stride);
+    one(u, a0, b0);
+    one(u + stride, a1, b1);
+  }
+  for (; u < total4; u += stride) one(u, __builtin_nontemporal_load(gv + u), __builtin_nontemporal_load(yv + u));
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, s, 64);
+    m = o > m ? o : m;
+  }
+  __shared__ uint32_t wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = wm[0] > wm[1] ? wm[0] : wm[1], b = wm[2] > wm[3] ? wm[2] : wm[3];
+    const uint32_t bm = a > b ? a : b;
+    if (bm > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bm);
+  }
+}
+
+extern "C" int cgg_relu_bwd_absmax_f32(const float* gy, const float* y, float* g, long long n, float* amax, cgg_stream_t stream) {
+  CGG_REQUIRE(gy && y && g && amax, CGG_EINVAL, "cgg_relu_bwd_absmax_f32: null pointer");
+  CGG_REQUIRE(n > 0 && n % 4 == 0, CGG_EUNSUPPORTED, "cgg_relu_bwd_absmax_f32: n=%lld must be a positive multiple of 4", n);
+  CGG_REQUIRE(cgg_aligned16(gy) && cgg_aligned16(y) && cgg_aligned16(g), CGG_EALIGN, "cgg_relu_bwd_absmax_f32: 16-B alignment");
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
+  CGG_REQUIRE(e == hipSuccess, (int)e, "cgg_relu_bwd_absmax_f32: memset failed");
+  const long long total4 = n / 4;
+  long long nb = (total4 + 256 * 4 - 1) / (256 * 4);
+  nb = nb > 1024 ? 1024 : (nb < 1 ? 1 : nb);
+  hipLaunchKernelGGL(cgg_relu_bwd_absmax_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, gy, y, g, total4,
+                     reinterpret_cast<uint32_t*>(amax));
+  CGG_CHECK_LAUNCH("cgg_relu_bwd_absmax_f32");
+  return CGG_OK;
+}
+
 extern "C" int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax, cgg_stream_t stream) {
   CGG_REQUIRE(x && amax, CGG_EINVAL, "cgg_absmax_f32: null pointer");
   CGG_REQUIRE(M > 0 && N > 0 && ld >= N, CGG_EINVAL, "cgg_absmax_f32: bad sizes");

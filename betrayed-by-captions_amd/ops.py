@@ -1434,6 +1434,19 @@ def absmax(x):
     return out
 
 
+def relu_backward_absmax(gy, y):
+    """(g, amax): g = gy where y > 0 else 0 (the ReLU whose output is y), amax = max |g| as a device scalar -- one pass
+    (`cgg_relu_bwd_absmax_f32`) instead of threshold_backward + `absmax`. gy, y contiguous float32 ROCm tensors of one shape, numel % 4 == 0."""
+    if gy.dtype != torch.float32 or y.dtype != torch.float32 or not gy.is_cuda or gy.shape != y.shape or not gy.is_contiguous() \
+            or not y.is_contiguous() or gy.numel() % 4 or gy.numel() == 0:
+        raise CggError('relu_backward_absmax: two contiguous float32 ROCm tensors of one shape with numel % 4 == 0 expected')
+    g = torch.empty_like(gy)
+    amax = torch.empty(1, dtype=torch.float32, device=gy.device)
+    check(_lib_().cgg_relu_bwd_absmax_f32(dev_ptr(gy), dev_ptr(y), dev_ptr(g), gy.numel(), dev_ptr(amax), stream_ptr(gy.device)),
+          'cgg_relu_bwd_absmax_f32')
+    return g, amax
+
+
 def gemm_x3(a, packed, N, bias=None, res=None, relu=False, out=None, amax=None):
     """a (M, K) f32 rows (row stride free, last dim contiguous) x x3 image -> act(a W^T + bias (+ res)) (M, N) f32:
     parity mode's large linear (csrc/x3_gemm.hip). amax: device scalar max |a| (`absmax`) -> a is pre-scaled per tensor instead

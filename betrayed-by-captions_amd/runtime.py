@@ -565,11 +565,15 @@ class _X3ConvBnFn(torch.autograd.Function):
         N, C, k, _ = weight.shape
         B, H, W, _ = x.shape
         g = gy.contiguous()
-        if relu:
+        amax = None
+        if relu and _X3_GSCALE and g.numel() % 4 == 0:
+            g, amax = ops.relu_backward_absmax(g, y)          # ReLU mask and max |g| in one pass
+        elif relu:
             g = torch.ops.aten.threshold_backward(g, y, 0.0)
         OH, OW = g.shape[1], g.shape[2]
         g2 = g.view(-1, N)
-        amax = ops.absmax(g2) if _X3_GSCALE else None
+        if amax is None and _X3_GSCALE:
+            amax = ops.absmax(g2)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if k == 1:

@@ -641,6 +641,10 @@ int cgg_topk_select(const float* x, int ld, int rows, int N, int k, int64_t* idx
  * of 2^4 and fold the inverse into their epilogue (exact). amax pointers are nullable (= the fixed 2^4). Otherwise the
  * contracts of cgg_gemm_x3 / cgg_conv_x3_nhwc / cgg_wgrad_x3 / cgg_wgrad_bias_x3 (ws_bias nullable here). */
 int cgg_absmax_f32(const float* x, int ld, int M, int N, float* amax, cgg_stream_t stream);
+/* ReLU backward + the same maximum in one pass: g[i] = y[i] > 0 ? gy[i] : 0 (autograd's threshold_backward behind a ReLU whose
+ * OUTPUT is y: the Bottleneck ReLUs of the trainable ResNet stage, [3P] mmdet ResNet under mask2former_head.py:787's inputs) and
+ * *amax = max |g|. Dense f32 tensors of n elements, n % 4 == 0; g may alias gy. */
+int cgg_relu_bwd_absmax_f32(const float* gy, const float* y, float* g, long long n, float* amax, cgg_stream_t stream);
 /* cgg_gemm_x3_scaled for the backward of a fused training layer: `mask` (M, N; nullable) zeroes the result where mask <= 0 (the
  * ReLU backward of the layer whose output `mask` is), out_amax (device scalar, nullable) receives max |out| from the epilogue. */
 int cgg_gemm_x3_bwd(const float* a, int lda, const float* a_amax, const void* w_x3, const float* mask, int ldm, float* out, int ldc,

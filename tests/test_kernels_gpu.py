@@ -1213,6 +1213,18 @@ def test_point_sample_nhwc_x3_images_equal_pack_of_samples_and_point_logits_are_
             assert err <= 4 * f32_err + 1e-6 * want.abs().max().item(), (li, err, f32_err)
 
 
+def test_relu_backward_absmax_equals_threshold_backward_and_absmax(dev):
+    g = torch.Generator().manual_seed(80)
+    for shape in ((3, 17, 20, 64), (5, 1000), (4,)):
+        gy = (torch.randn(shape, generator=g) * 1e-5).to(dev)
+        y = torch.relu(torch.randn(shape, generator=g)).to(dev)
+        got, amax = ops.relu_backward_absmax(gy, y)
+        want = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        assert torch.equal(got, want) and float(amax) == float(want.abs().max())
+    with pytest.raises(ops.CggError):
+        ops.relu_backward_absmax(gy[:3], y[:3])                          # numel % 4
+
+
 def test_instance_masks_picks_bitpacked(dev):
     g = torch.Generator().manual_seed(78)
     Q, H, W = 20, 24, 32
