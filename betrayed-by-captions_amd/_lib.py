@@ -51,6 +51,7 @@ PROTOTYPES = {
     'cgg_masked_xattn_forward_lse': (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
     'cgg_masked_xattn_backward_workspace_bytes': (_c_i64, [_c_int] * 5),
     'cgg_masked_xattn_backward': (_c_int, [_c_vp] * 9 + [_c_int] * 5 + [_c_f, _c_int, _c_vp]),
+    'cgg_masked_xattn_backward_x3': (_c_int, [_c_vp] * 10 + [_c_int] * 5 + [_c_f, _c_vp]),
     'cgg_grounding_pair_costs': (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_f, _c_vp]),
     'cgg_grounding_pair_costs_backward': (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_f, _c_vp]),
     'cgg_ce_rows_forward': (_c_int, [_c_vp] * 4 + [_c_int, _c_int, _c_i64, _c_i64, _c_int, _c_vp]),

@@ -68,6 +68,11 @@ __device__ __forceinline__ float cgg_x3_scale_from_amax(float amax) {
 // ONE mixed-precision fma per value (v_fma_mixlo / mixhi_f16: f32 a, f32 sc, f16 hi half -> f16; sc a - hi is exact in f32, so the
 // only rounding is the final one to f16, as before) instead of cvt_f32_f16 + subtract + cvt_pk, and the hi piece from one more (f16(sc a)): 2 VALU per value instead of 3.5 --
 // the split is the main loop's VALU load in the kernels that take f32 operands (training GEMMs: 2.4 VALU per MFMA before).
+// HAZARD (round 6): the pieces must not be consumed by an MFMA straight from these registers. The hazard recogniser does not look
+// inside an asm block, so no wait states are inserted between the VALU writes here and a v_mfma that reads the register a few cycles
+// later -- csrc/xattn_bwd.hip's first x3 form did exactly that and multiplied stale operands in some lanes (gradients off by 20 % ..
+// 100 x). Every user in this library sends the pieces through LDS (or holds them across a barrier) first; a kernel that splits and
+// multiplies in registers takes plain __builtin_convertvector conversions (xattn_bwd.hip `xb_split4`).
 __device__ __forceinline__ void cgg_x3_split2_s(float a, float b, float sc, uint32_t& hi, uint32_t& lo) {
   uint32_t h, l;
   asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a), "v"(sc));      // f16(sc a), RNE

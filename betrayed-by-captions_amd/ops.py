@@ -571,6 +571,7 @@ CGG_F32_BF16MFMA = 2                 # include/cgg_hip.h: f32 rows in memory, bf
 CGG_F32_X3 = 3                       # cgg_masked_xattn_forward_lse only: the forward on the f32-class f16 x 3 contraction
 XATTN_BF16_TRAIN = os.environ.get('CGG_XATTN_BF16_TRAIN', '1') != '0'
 XATTN_X3_TRAIN = os.environ.get('CGG_XATTN_X3_TRAIN', '1') != '0'
+XATTN_X3_BWD = os.environ.get('CGG_XATTN_X3_BWD', '1') != '0'       # parity-mode training: the cross-attention backward on f16 x 3 (0: f32 MFMA)
 
 
 def _xattn_train_dtype(forward=False):
@@ -607,6 +608,18 @@ def masked_xattn_backward(q, kv, bits, out, lse, grad_out, num_heads, scale=None
     ws = _xattn_ws(lib.cgg_masked_xattn_backward_workspace_bytes, q, B, Q, H, D, S)
     gq = torch.empty_like(q)
     gkv = torch.empty_like(kv)
+    from . import runtime
+    if XATTN_X3_BWD and XATTN_X3 and not runtime.is_bf16() and runtime.x3_enabled() and E % 4 == 0:
+        # parity mode: the f16 x 3 form of the kernel (f32-class, 2.7 x less matrix-pipe time than the f32 MFMA); the gradient operands
+        # take their pre-scale from max |grad_out|
+        amax = absmax(grad_out.view(-1, E))
+        rc = lib.cgg_masked_xattn_backward_x3(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
+                                              dev_ptr(bits, 'bits', torch.int32), dev_ptr(out, 'out', torch.float32),
+                                              dev_ptr(lse, 'lse', torch.float32), dev_ptr(grad_out, 'grad_out', torch.float32),
+                                              dev_ptr(amax), dev_ptr(gq), dev_ptr(gkv), dev_ptr(ws), B, Q, H, D, S, float(scale),
+                                              stream_ptr(q.device))
+        check(rc, 'cgg_masked_xattn_backward_x3')
+        return gq, gkv
     rc = lib.cgg_masked_xattn_backward(dev_ptr(q, 'q', torch.float32), dev_ptr(kv, 'kv', torch.float32),
                                        dev_ptr(bits, 'bits', torch.int32), dev_ptr(out, 'out', torch.float32),
                                        dev_ptr(lse, 'lse', torch.float32), dev_ptr(grad_out, 'grad_out', torch.float32),

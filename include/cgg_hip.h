@@ -47,7 +47,7 @@ extern "C" {
 /* kv_dtype of cgg_masked_xattn_forward_lse / cgg_masked_xattn_backward only: f32 rows in memory, products on bf16 MFMA operands
  * (f32 accumulate) -- the throughput-mode training variant of the two kernels */
 #define CGG_F32_BF16MFMA 2
-#define CGG_F32_X3 3 /* cgg_masked_xattn_forward_lse only: f32 rows, products on the f16 x 3 contraction (csrc/x3.h) */
+#define CGG_F32_X3 3 /* cgg_masked_xattn_forward_lse (and cgg_masked_xattn_backward_x3): f32 rows, products on the f16 x 3 contraction (csrc/x3.h) */
 
 typedef void* cgg_stream_t; /* hipStream_t */
 
@@ -303,6 +303,14 @@ int64_t cgg_masked_xattn_backward_workspace_bytes(int B, int Q, int H, int D, in
 int cgg_masked_xattn_backward(const float* q, const void* kv, const uint32_t* bits, const float* out,
                               const float* lse, const float* grad_out, float* grad_q, void* grad_kv, void* ws,
                               int B, int Q, int H, int D, int S, float scale, int kv_dtype, cgg_stream_t stream);
+/* cgg_masked_xattn_backward on the f32-class f16 x 3 contraction of csrc/x3.h (parity-mode training, round 6): the five
+ * contractions of the backward (scores, dP, dV, dK, dQ) as three v_mfma_f32_32x32x8_f16 per four f32 k-steps instead of four
+ * v_mfma_f32_32x32x2_f32 -- as accurate as the f32 MFMA form (tests/test_kernels_gpu.py), 2.7 x less matrix-pipe time.
+ * grad_out_amax = device scalar max |grad_out| (cgg_absmax_f32): the per-tensor pre-scale of the gradient operands; q, K, V
+ * must be unit scale (|value| < 4094) like every x3 activation operand. Same tensors, workspace and limits otherwise. */
+int cgg_masked_xattn_backward_x3(const float* q, const void* kv, const uint32_t* bits, const float* out, const float* lse,
+                                 const float* grad_out, const float* grad_out_amax, float* grad_q, void* grad_kv, void* ws, int B,
+                                 int Q, int H, int D, int S, float scale, cgg_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * K16  Caption-grounding pair costs and their backward.

@@ -28,7 +28,7 @@ def test_parity_mode_switch(dev, switch):
 # the training-side switches (none was ever exercised off-default): each alternative path must give the oracle's
 # losses and gradients too. One parity-mode forward_train + backward at batch 4 x 512^2 per switch (tests/env_switch_train_worker.py).
 TRAIN_SWITCHES = ['', 'CGG_X3_TRAIN=0', 'CGG_X3_WGRAD=0', 'CGG_X3_LAYER_NODES=0', 'CGG_X3_FPN_ROWS=0', 'CGG_MSDA_BWD_2S=0',
-                  'CGG_X3_GENERATOR=0', 'CGG_XATTN_X3_TRAIN=0', 'CGG_FUSED_TRAIN_LN=0', 'CGG_FUSED_TRAIN_MSDA=0', 'CGG_X3A=0', 'CGG_POINT_LOGITS_X3=0']
+                  'CGG_X3_GENERATOR=0', 'CGG_XATTN_X3_TRAIN=0', 'CGG_FUSED_TRAIN_LN=0', 'CGG_FUSED_TRAIN_MSDA=0', 'CGG_X3A=0', 'CGG_POINT_LOGITS_X3=0', 'CGG_XATTN_X3_BWD=0']
 
 
 @pytest.fixture(scope='module')

@@ -501,14 +501,18 @@ def test_masked_xattn_full_row_is_nan_like_reference(dev):
     assert torch.isnan(got[0, 1]).all() and not torch.isnan(got[0, 0]).any()
 
 
+@pytest.mark.parametrize('form', ['x3', 'f32'])
 @pytest.mark.parametrize('B,Q,S,H,masked', [(2, 100, 1050, 8, True), (1, 20, 77, 4, True), (2, 100, 100, 8, False),
                                             (3, 128, 4096, 8, True), (1, 33, 16384, 8, True)])
-def test_masked_xattn_backward_vs_float64_autograd(dev, B, Q, S, H, masked):
+def test_masked_xattn_backward_vs_float64_autograd(dev, B, Q, S, H, masked, form, monkeypatch):
     """cgg_masked_xattn_forward_lse + cgg_masked_xattn_backward against float64 autograd of the reference formulation
     (scores -> masked_fill(-inf) -> softmax -> @ v, the arithmetic of nn.MultiheadAttention at
     mask2former_head.py:829-840): ragged key counts (1050 = the 25 x 42 level of configs[4], 77), fewer queries than one
-    tile, the unmasked self-attention case, several key chunks per head, rows with a single visible key."""
+    tile, the unmasked self-attention case, several key chunks per head, rows with a single visible key. Both forms of the backward:
+    `x3` = the f16 x 3 contraction parity mode takes (cgg_masked_xattn_backward_x3; also with a 1e-6-scale grad_out: its pre-scale comes
+    from max |grad_out|), `f32` = the exact f32 MFMA (CGG_XATTN_X3_BWD=0) -- the same bound for both."""
     from cgg_amd.query_decoder import pack_bool_mask
+    monkeypatch.setattr(ops, 'XATTN_X3_BWD', form == 'x3')
     g = torch.Generator().manual_seed(23 + S)
     D = 32
     E = H * D
@@ -544,6 +548,9 @@ def test_masked_xattn_backward_vs_float64_autograd(dev, B, Q, S, H, masked):
     # run to run bit-identical (no floating-point atomics)
     gq2, gkv2 = ops.masked_xattn_backward(q.to(dev), kv.to(dev), bits, out, lse, go.to(dev), H)
     assert torch.equal(gq, gq2) and torch.equal(gkv, gkv2)
+    # a gradient-scale grad_out (what the training step hands over): the backward is linear in it, to the last bit for a power of two
+    gq3, gkv3 = ops.masked_xattn_backward(q.to(dev), kv.to(dev), bits, out, lse, (go * 2.0**-20).to(dev), H)
+    assert torch.equal(gq3 * 2.0**20, gq) and torch.equal(gkv3 * 2.0**20, gkv)
 
 
 def test_xattn_autograd_function_uses_hip_backward(dev):
