@@ -72,7 +72,9 @@ __device__ __forceinline__ float cgg_x3_scale_from_amax(float amax) {
 // inside an asm block, so no wait states are inserted between the VALU writes here and a v_mfma that reads the register a few cycles
 // later -- csrc/xattn_bwd.hip's first x3 form did exactly that and multiplied stale operands in some lanes (gradients off by 20 % ..
 // 100 x). Every user in this library sends the pieces through LDS (or holds them across a barrier) first; a kernel that splits and
-// multiplies in registers takes plain __builtin_convertvector conversions (xattn_bwd.hip `xb_split4`).
+// multiplies in registers takes plain __builtin_convertvector conversions (xattn_bwd.hip `xb_split4`). (Measured: ONE wait state -- an
+// `s_nop 0` tied to the outputs -- removes the error, but the volatile asm then costs more scheduling freedom than the two VALU
+// instructions per value it saves: 124 vs 118 us at 1 024 keys, profiles/r6_xattn_bwd_x3.txt.)
 __device__ __forceinline__ void cgg_x3_split2_s(float a, float b, float sc, uint32_t& hi, uint32_t& lo) {
   uint32_t h, l;
   asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a), "v"(sc));      // f16(sc a), RNE
