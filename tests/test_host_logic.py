@@ -587,3 +587,31 @@ def test_keepalive_scope_holds_what_the_caches_hand_out():
     refs.clear()
     gc.collect()
     assert wr() is None and c is not None
+
+
+def test_round6_training_paths_are_gated_off_without_a_device():
+    """The channel-last training paths of round 6 (`runtime.x3_resnet_stage_ok` / `input_level_x3_train`, the x3 point-logit sampler)
+    never claim a CPU tensor, a stage that is not frozen-BatchNorm Bottlenecks, or a level without a handed-over channel-last map:
+    the caller keeps the module path (the product has no CPU implementation; these are the host-side gates)."""
+    import torch
+    from cgg_amd import ops, runtime
+    from cgg_amd.backbones import BasicBlock, Bottleneck
+    from cgg_amd.pixel_decoder import ConvModule
+    stage = torch.nn.Sequential(Bottleneck(64, 32, 1, torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, bias=False), torch.nn.BatchNorm2d(128))),
+                                Bottleneck(128, 32)).eval()
+    x = torch.randn(2, 8, 8, 64)
+    with runtime.precision_scope('fp32'):
+        assert not runtime.x3_resnet_stage_ok(stage, x)                                   # CPU tensor
+        assert not runtime.x3_resnet_stage_ok(torch.nn.Sequential(BasicBlock(64, 64)).eval(), x)
+        cm = ConvModule(64, 256, kernel_size=1, norm_cfg=dict(type='GN', num_groups=32), act_cfg=None, bias=True)
+        assert runtime.input_level_x3_train(cm, torch.randn(2, 64, 8, 8)) is None          # CPU map, nothing handed over
+    # the gates of the convolution + frozen-BatchNorm node: trainable filter, frozen affine BatchNorm in eval mode, 1 x 1 or 3 x 3 / pad 1
+    blk = stage[1]
+    assert runtime._x3_convbn_ok(blk.conv1, blk.bn1) is False                             # BatchNorm affine still requires grad
+    for p in blk.bn1.parameters():
+        p.requires_grad = False
+    assert runtime._x3_convbn_ok(blk.conv1, blk.bn1) and not runtime._x3_convbn_ok(blk.conv1, blk.bn1.train())
+    assert not runtime._x3_convbn_ok(torch.nn.Conv2d(64, 64, 3, padding=2, dilation=2, bias=False), blk.bn1.eval())
+    assert not runtime._x3_convbn_ok(torch.nn.Conv2d(48, 64, 1, bias=False), blk.bn1)     # C % 32
+    pts = torch.rand(2, 3 * 64, 2)
+    assert not ops.point_sample_nhwc_x3_ok(torch.randn(2, 8, 8, 64), pts, 3)              # CPU tensor
